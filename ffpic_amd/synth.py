@@ -1,0 +1,97 @@
+"""Synthetic JPEG coefficient grids.
+
+Host-side input generator shared by the tests and bench.py.  It produces what the
+entropy decoder of the reference would hand to the reconstruction stage:
+quantised coefficients, natural (de-zigzagged) order, int16, blocks in MCU order
+per component (index = mcu*(h*v) + vi*h + hi), plus natural-order uint16 quant
+tables (format/jpg.c:78-105 de-zigzags DQT at load).
+
+Distribution: quant tables = JPEG Annex K luma/chroma scaled to quality 85 the
+libjpeg way; DC ~ N(0, 60) quantised units; AC at zig-zag position k ~ Laplace
+with scale 8*exp(-k/6), rounded; everything clipped so |coef * q| <= 2047.
+Roughly 85 % of the coefficients are zero.
+"""
+import numpy as np
+
+SEED_BASE = 0xFF91C
+
+# JPEG Annex K.1 / K.2 example tables, natural (row-major) order.
+ANNEX_K_LUMA = np.array([
+    16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55,
+    14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+    18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
+    49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.int64)
+ANNEX_K_CHROMA = np.array([
+    17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99,
+    24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+    99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+    99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99], dtype=np.int64)
+
+
+def zigzag_rank():
+    """rank[natural_index] = position of that coefficient in zig-zag scan order."""
+    order = sorted(range(64), key=lambda i: (i // 8 + i % 8,
+                                             (i // 8) if (i // 8 + i % 8) % 2 else (i % 8)))
+    rank = np.empty(64, dtype=np.int64)
+    rank[np.array(order)] = np.arange(64)
+    return rank
+
+
+def quant_tables(quality=85):
+    """[4][64] uint16, natural order; tables 0/1 = luma/chroma, 2/3 copies."""
+    scale = 5000 // quality if quality < 50 else 200 - 2 * quality
+    def one(base):
+        return np.clip((base * scale + 50) // 100, 1, 255).astype(np.uint16)
+    l, c = one(ANNEX_K_LUMA), one(ANNEX_K_CHROMA)
+    return np.stack([l, c, l, c])
+
+
+def _blocks(rng, n_blocks, q):
+    rank = zigzag_rank()
+    scale = 8.0 * np.exp(-rank / 6.0)
+    ac = np.rint(rng.laplace(0.0, 1.0, size=(n_blocks, 64)) * scale)
+    dc = np.rint(rng.normal(0.0, 60.0, size=n_blocks))
+    ac[:, 0] = dc
+    lim = 2047 // q.astype(np.int64)
+    return np.clip(ac, -lim, lim).astype(np.int16)
+
+
+def coef_image(index, mcu_cols, mcu_rows, ncomp=3, h=2, v=2, qt_id=(0, 1, 1), quant=None):
+    """One image: (coef_y, coef_u, coef_v) int16 arrays of shape [blocks, 64]."""
+    quant = quant_tables() if quant is None else quant
+    rng = np.random.default_rng(SEED_BASE + index)
+    mcus = mcu_cols * mcu_rows
+    y = _blocks(rng, mcus * h * v, quant[qt_id[0]])
+    if ncomp == 1:
+        return y, None, None
+    u = _blocks(rng, mcus, quant[qt_id[1]])
+    w = _blocks(rng, mcus, quant[qt_id[2]])
+    return y, u, w
+
+
+def coef_batch(n_images, mcu_cols, mcu_rows, ncomp=3, h=2, v=2, qt_id=(0, 1, 1), quant=None, first=0):
+    """Batch planes, image-major: [n*blocks*64] int16 per component."""
+    ys, us, vs = [], [], []
+    for i in range(n_images):
+        y, u, w = coef_image(first + i, mcu_cols, mcu_rows, ncomp, h, v, qt_id, quant)
+        ys.append(y)
+        if ncomp == 3:
+            us.append(u)
+            vs.append(w)
+    cat = lambda l: np.ascontiguousarray(np.concatenate(l).reshape(-1)) if l else None
+    return cat(ys), cat(us), cat(vs)
+
+
+def adversarial_blocks(rng, n_blocks):
+    """Parity-only inputs that drive the int16 truncation points and the
+    mod-2^32 accumulations: full-range int16 levels (use with any quant table)."""
+    b = rng.integers(-32768, 32768, size=(n_blocks, 64), dtype=np.int64).astype(np.int16)
+    k = n_blocks // 8
+    if k:
+        b[:k] = 0                                   # all-zero
+        b[k:2 * k, 1:] = 0                          # DC only
+        b[2 * k:3 * k] = np.where(rng.random((k, 64)) < 0.5, 32767, -32768)   # +-max
+        b[3 * k:4 * k, :56] = 0                     # last row only
+        m = np.zeros(64, bool); m[7::8] = True
+        b[4 * k:5 * k][:, ~m] = 0                   # last column only
+    return b

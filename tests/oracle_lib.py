@@ -1,0 +1,148 @@
+"""ctypes bindings to the CPU checker (oracle/libffo.so) and, where it was built,
+the reference itself (oracle/_ref/libffpic_ref.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product (ffpic_amd) never imports this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+FFO_SO = os.path.join(ORACLE_DIR, "libffo.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libffpic_ref.so")
+
+i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
+u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+
+
+class Geom(C.Structure):
+    """Same layout as ffo_jpeg_geom / ffhip_jpeg_geom."""
+    _fields_ = [("mcu_cols", C.c_int32), ("mcu_rows", C.c_int32), ("ncomp", C.c_int32),
+                ("h", C.c_int32), ("v", C.c_int32), ("qt_id", C.c_int32 * 3)]
+
+    def as_array(self):
+        return np.array([self.mcu_cols, self.mcu_rows, self.ncomp, self.h, self.v,
+                         self.qt_id[0], self.qt_id[1], self.qt_id[2]], dtype=np.int32)
+
+    @property
+    def width(self):
+        return self.mcu_cols * 8 * self.h
+
+    @property
+    def height(self):
+        return self.mcu_rows * 8 * self.v
+
+    @property
+    def mcus(self):
+        return self.mcu_cols * self.mcu_rows
+
+
+def make_geom(mcu_cols, mcu_rows, ncomp=3, h=2, v=2, qt_id=(0, 1, 1)):
+    g = Geom()
+    g.mcu_cols, g.mcu_rows, g.ncomp, g.h, g.v = mcu_cols, mcu_rows, ncomp, h, v
+    for i in range(3):
+        g.qt_id[i] = qt_id[i]
+    return g
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def build_ref():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "ref"])
+
+
+_ffo = None
+_ref = None
+
+
+def ffo():
+    """Load (building on demand) our CPU restatement."""
+    global _ffo
+    if _ffo is None:
+        if not os.path.exists(FFO_SO):
+            build_oracle()
+        L = C.CDLL(FFO_SO)
+        L.ffo_jpeg_dequant.argtypes = [i16p, i16p, u16p, C.c_int]
+        L.ffo_idct_8x8_16.argtypes = [i16p]
+        L.ffo_yuv_to_bgra32_mcu16.argtypes = [u8p, C.c_int, i16p, i16p, i16p, C.c_int, C.c_int]
+        L.ffo_jpeg_recon_image.argtypes = [C.POINTER(Geom), i16p, C.c_void_p, C.c_void_p, u16p, u8p, C.c_int64]
+        L.ffo_jpeg_recon_image.restype = C.c_int
+        L.ffo_jpeg_recon_batch.argtypes = [C.POINTER(Geom), C.c_int, i16p, C.c_void_p, C.c_void_p, u16p,
+                                           C.c_int64, u8p, C.c_int64, C.c_int64, C.c_int]
+        L.ffo_jpeg_recon_batch.restype = C.c_int
+        L.ffo_vp8_idct_4x4.argtypes = [i16p]
+        L.ffo_vp8_iwht_long.argtypes = [i16p, i16p]
+        L.ffo_vp8_iwht_fast.argtypes = [i16p, i16p]
+        L.ffo_hevc_idct_4x4_dst.argtypes = [i16p, i16p, C.c_int, C.c_int]
+        L.ffo_hevc_scale.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.ffo_hevc_transform.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ffo_yuv420_to_bgra32.argtypes = [u8p, C.c_int, u8p, u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ffo_yuv420_to_bgra32_16bit.argtypes = [u8p, C.c_int, i16p, i16p, i16p, C.c_int, C.c_int, C.c_int,
+                                                 C.c_int, C.c_int]
+        L.ffo_yuv400_to_bgra32_16bit.argtypes = [u8p, C.c_int, i16p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _ffo = L
+    return _ffo
+
+
+def have_ref():
+    return os.path.exists(REF_SO) or os.path.isdir("/root/reference")
+
+
+def ref():
+    """Load the compiled reference (only exists if it was built in the build container)."""
+    global _ref
+    if _ref is None:
+        if not os.path.exists(REF_SO):
+            build_ref()
+        L = C.CDLL(REF_SO)
+        L.ref_jpeg_dequant.argtypes = [i16p, i16p, u16p, C.c_int]
+        L.ref_idct_8x8_16.argtypes = [i16p]
+        L.ref_yuv_to_bgra32_mcu16.argtypes = [u8p, C.c_int, i16p, i16p, i16p, C.c_int, C.c_int]
+        L.ref_jpeg_recon_image.argtypes = [i32p, i16p, C.c_void_p, C.c_void_p, u16p, u8p, C.c_int64]
+        L.ref_vp8_idct_4x4.argtypes = [i16p]
+        L.ref_vp8_iwht_long.argtypes = [i16p, i16p]
+        L.ref_vp8_iwht_fast.argtypes = [i16p, i16p]
+        L.idct_4x4_hevc.argtypes = [i16p, i16p, C.c_int, C.c_bool]
+        L.ref_hevc_scale.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.ref_hevc_transform.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.YUV420_to_BGRA32.argtypes = [u8p, C.c_int, u8p, u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.YUV420_to_BGRA32_16bit.argtypes = [u8p, C.c_int, i16p, i16p, i16p, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, C.c_int]
+        L.YUV400_to_BGRA32_16bit.argtypes = [u8p, C.c_int, i16p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _ref = L
+    return _ref
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ---------------------------------------------------------------- JPEG helpers
+
+def oracle_jpeg_recon(g, coef_y, coef_u, coef_v, quant, n_images=1, n_threads=1):
+    """Run the CPU restatement over a batch; returns BGRA [n, H, W, 4]."""
+    H, W = g.height, g.width
+    out = np.zeros((n_images, H, W, 4), dtype=np.uint8)
+    quant = np.ascontiguousarray(quant, dtype=np.uint16)
+    qstride = 0 if quant.ndim == 2 else 4 * 64
+    rc = ffo().ffo_jpeg_recon_batch(C.byref(g), n_images, coef_y, _vp(coef_u), _vp(coef_v), quant,
+                                    qstride, out.reshape(-1), W * 4, H * W * 4, n_threads)
+    assert rc == 0, rc
+    return out
+
+
+def ref_jpeg_recon(g, coef_y, coef_u, coef_v, quant):
+    """Run the compiled reference over ONE image; returns BGRA [H, W, 4]."""
+    H, W = g.height, g.width
+    out = np.zeros((H, W, 4), dtype=np.uint8)
+    quant = np.ascontiguousarray(quant, dtype=np.uint16)
+    ref().ref_jpeg_recon_image(g.as_array(), coef_y, _vp(coef_u), _vp(coef_v), quant, out.reshape(-1), W * 4)
+    return out

@@ -1,0 +1,148 @@
+"""ctypes binding of libffpic_hip.so (include/ffpic_hip.h).  Loading never touches
+the GPU; compute entry points fail loudly (FfhipError) without a gfx950 device."""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libffpic_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+
+# every symbol include/ffpic_hip.h declares (tests check the library exports them all)
+EXPORTS = [
+    "ffhip_device_count", "ffhip_init", "ffhip_shutdown", "ffhip_strerror", "ffhip_arch_name",
+    "ffhip_malloc", "ffhip_free", "ffhip_memcpy_h2d", "ffhip_memcpy_d2h", "ffhip_memset",
+    "ffhip_stream_create", "ffhip_stream_destroy", "ffhip_stream_sync",
+    "ffhip_event_create", "ffhip_event_destroy", "ffhip_event_record", "ffhip_event_elapsed_ms",
+    "hip_accl_init", "hip_accl_uninit", "ffhip_accl_ops_get",
+    "ffhip_get_dct_ops", "ffhip_get_cs_ops", "ffhip_idct_4x4_hevc",
+    "ffhip_jpeg_recon_batch", "ffhip_jpeg_workspace_bytes", "ffhip_jpeg_recon_batch_host",
+    "ffhip_jpeg_kernel_name", "ffhip_copy_calibrate",
+]
+
+
+class FfhipError(RuntimeError):
+    pass
+
+
+class JpegGeom(C.Structure):
+    """ffhip_jpeg_geom"""
+    _fields_ = [("mcu_cols", C.c_int32), ("mcu_rows", C.c_int32), ("ncomp", C.c_int32),
+                ("h", C.c_int32), ("v", C.c_int32), ("qt_id", C.c_int32 * 3)]
+
+    @property
+    def width(self):
+        return self.mcu_cols * 8 * self.h
+
+    @property
+    def height(self):
+        return self.mcu_rows * 8 * self.v
+
+    @property
+    def y_blocks(self):
+        return self.mcu_cols * self.mcu_rows * self.h * self.v
+
+    @property
+    def c_blocks(self):
+        return self.mcu_cols * self.mcu_rows
+
+
+def jpeg_geom(mcu_cols, mcu_rows, ncomp=3, h=2, v=2, qt_id=(0, 1, 1)):
+    g = JpegGeom()
+    g.mcu_cols, g.mcu_rows, g.ncomp, g.h, g.v = mcu_cols, mcu_rows, ncomp, h, v
+    for i in range(3):
+        g.qt_id[i] = qt_id[i]
+    return g
+
+
+class AcclOps(C.Structure):
+    """struct ffhip_accl_ops == struct accl_ops (arch/accl.h:20-25)"""
+    _fields_ = [("idct_4x4", C.CFUNCTYPE(None, C.c_void_p, C.c_int)),
+                ("idct_8x8", C.CFUNCTYPE(None, C.c_void_p, C.c_int)),
+                ("type", C.c_int),
+                ("tqe_next", C.c_void_p), ("tqe_prev", C.c_void_p)]
+
+
+class DctOps(C.Structure):
+    _fields_ = [("bitdepth", C.c_int),
+                ("idct_4x4", C.CFUNCTYPE(None, C.c_void_p, C.c_int)),
+                ("idct_8x8", C.CFUNCTYPE(None, C.c_void_p, C.c_int)),
+                ("fdct_4x4", C.c_void_p), ("fdct_8x8", C.c_void_p)]
+
+
+class CsOps(C.Structure):
+    _fields_ = [("YUV_to_BGRA32", C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_int, C.c_int)),
+                ("YUV420_to_BGRA32", C.c_void_p)]
+
+
+def build(force=False):
+    """Compile libffpic_hip.so in-tree with hipcc for gfx950 (works without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
+    subprocess.check_call(["make", "-s", "-C", CSRC, "-j4"])
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises FfhipError if it has not been built: there is no
+    fallback implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FfhipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(or make -C ffpic_amd/csrc); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, i64, sz = C.c_void_p, C.c_int64, C.c_size_t
+    L.ffhip_device_count.restype = C.c_int
+    L.ffhip_init.argtypes = [C.c_int]
+    L.ffhip_strerror.argtypes = [C.c_int]
+    L.ffhip_strerror.restype = C.c_char_p
+    L.ffhip_arch_name.restype = C.c_char_p
+    L.ffhip_malloc.argtypes = [sz]
+    L.ffhip_malloc.restype = vp
+    L.ffhip_free.argtypes = [vp]
+    L.ffhip_memcpy_h2d.argtypes = [vp, vp, sz, vp]
+    L.ffhip_memcpy_d2h.argtypes = [vp, vp, sz, vp]
+    L.ffhip_memset.argtypes = [vp, C.c_int, sz, vp]
+    L.ffhip_stream_create.restype = vp
+    L.ffhip_stream_destroy.argtypes = [vp]
+    L.ffhip_stream_sync.argtypes = [vp]
+    L.ffhip_event_create.restype = vp
+    L.ffhip_event_destroy.argtypes = [vp]
+    L.ffhip_event_record.argtypes = [vp, vp]
+    L.ffhip_event_elapsed_ms.argtypes = [vp, vp]
+    L.ffhip_event_elapsed_ms.restype = C.c_float
+    L.ffhip_accl_ops_get.restype = C.POINTER(AcclOps)
+    L.ffhip_get_dct_ops.argtypes = [C.c_int]
+    L.ffhip_get_dct_ops.restype = C.POINTER(DctOps)
+    L.ffhip_get_cs_ops.argtypes = [C.c_int]
+    L.ffhip_get_cs_ops.restype = C.POINTER(CsOps)
+    L.ffhip_idct_4x4_hevc.argtypes = [vp, vp, C.c_int, C.c_bool]
+    L.ffhip_idct_4x4_hevc.restype = None
+    L.ffhip_jpeg_recon_batch.argtypes = [C.POINTER(JpegGeom), C.c_int, vp, vp, vp, vp, i64, vp, i64, i64, vp, sz, vp]
+    L.ffhip_jpeg_workspace_bytes.argtypes = [C.POINTER(JpegGeom), C.c_int]
+    L.ffhip_jpeg_workspace_bytes.restype = sz
+    L.ffhip_jpeg_recon_batch_host.argtypes = [C.POINTER(JpegGeom), C.c_int, vp, vp, vp, vp, i64, vp, i64, i64]
+    L.ffhip_jpeg_kernel_name.argtypes = [C.POINTER(JpegGeom)]
+    L.ffhip_jpeg_kernel_name.restype = C.c_char_p
+    L.ffhip_copy_calibrate.argtypes = [vp, vp, sz, vp]
+    _lib = L
+    return L
+
+
+def check(rc, what="ffhip call"):
+    if rc != 0:
+        raise FfhipError(f"{what} failed: {rc} ({lib().ffhip_strerror(rc).decode()})")
+
+
+def require_device(device=0):
+    """Bind to a gfx950 device or raise: the product path never degrades to the CPU."""
+    L = lib()
+    if L.ffhip_device_count() <= device:
+        raise FfhipError("no HIP device visible: ffpic_amd needs an MI355X (gfx950); there is no CPU fallback")
+    check(L.ffhip_init(device), f"ffhip_init({device})")
+    return L

@@ -1,0 +1,549 @@
+/*
+ * ffhip_jpeg.hip -- JPEG post-entropy reconstruction for gfx950 (MI355X).
+ *
+ * Fused dequant + 8x8 IDCT + YCbCr->BGRA for batches of coefficient grids,
+ * bit-exact with the reference's scalar C:
+ *   dequant_data_unit      format/jpg.c:247-253
+ *   idct_8x8_16            utils/idct.c:512-534 (table :358-367)
+ *   YUV_to_BGRA32_16bit    utils/colorspace.c:133-172
+ * driven the way the MCU loop of JPG_decode_scan does (format/jpg.c:512-560).
+ *
+ * Design (see DESIGN.md for the derivations):
+ *  - HBM-bound byte/integer work: 3 B of int16 coefficients in, 4 B of BGRA out
+ *    per pixel at 4:2:0.  No MFMA; the 8-point transforms are packed-int16 dot
+ *    products (v_dot2_i32_i16) on even/odd input pairs, accumulating mod 2^32
+ *    exactly like the reference's int arithmetic.
+ *  - One wave owns a "quad" = 4 horizontally adjacent MCUs (64x16 pixels) and
+ *    works in three rounds of 8 blocks: chroma (4 U + 4 V), luma of MCU 0-1,
+ *    luma of MCU 2-3.  Every global load is one dwordx4 per lane (a block row),
+ *    1 KiB contiguous per wave; every global store is one dwordx4 per lane with
+ *    8 lanes covering one 128-B line of an output row.
+ *  - Per round the 8x8 transposes go through a 1 KiB per-wave LDS tile with
+ *    gfx950's ds_read_b64_tr_b16 (transposing read), whose row order is chosen
+ *    so the lane receives (x0,x4),(x2,x6) / (x1,x3),(x5,x7) pairs ready for the
+ *    even/odd butterflies.  Waves never synchronise with each other.
+ *  - Colour: R and B have exact integer forms on the IDCT's output domain
+ *    [0,8191]; G does too except when 215*uu+381*vv is a non-zero multiple of
+ *    1000, where the reference's double roundings decide -- those pixels are
+ *    re-evaluated in contraction-free fp64 (tests/tools/check_color_int.c
+ *    enumerates the whole domain).  Chroma-only terms are computed once per
+ *    chroma sample and shared by its 4 pixels through LDS.
+ *  - Geometries other than 3-component h=v=2 take a two-kernel path (IDCT to
+ *    int16 sample planes in the workspace, then a per-pixel colour kernel using
+ *    the literal fp64 expressions).
+ *
+ * This file must be compiled with -ffp-contract=off.
+ */
+#include "ffhip_internal.h"
+
+#include <errno.h>
+
+#define WAVES_PER_WG 4
+#define WG_THREADS (64 * WAVES_PER_WG)
+
+/* per-wave LDS layout (bytes) */
+#define LDS_W 0       /* 1 KiB work tile: stage A / B / C and chroma samples */
+#define LDS_TR 1024   /* R terms, 64 entries x 16 B                          */
+#define LDS_TG 2048   /* G terms                                             */
+#define LDS_TB 3072   /* B terms                                             */
+#define LDS_UV 4096   /* raw (uu,vv) pairs for the fp64 fallback             */
+#define LDS_FL 5120   /* sensitivity masks, 64 x 4 B                         */
+#define LDS_WAVE_BYTES 5376
+
+#define PK16(lo, hi) ((u32)(uint16_t)(int16_t)(lo) | ((u32)(uint16_t)(int16_t)(hi) << 16))
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ int dot2(u32 a, u32 b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
+}
+
+/* One 8-point inverse DCT with the 13-bit basis of utils/idct.c:358-367, inputs
+ * as packed int16 pairs e0=(x0,x4) e1=(x2,x6) o0=(x1,x3) o1=(x5,x7); `rnd` is
+ * folded into the even part.  All arithmetic mod 2^32 (== the reference's int). */
+__device__ __forceinline__ void idct8_1d(u32 e0, u32 e1, u32 o0, u32 o1, int rnd, int out[8])
+{
+    const int ap = dot2(e0, PK16(8192, 8192), rnd);
+    const int am = dot2(e0, PK16(8192, -8192), rnd);
+    const int b0 = dot2(e1, PK16(10703, 4433), 0);
+    const int b1 = dot2(e1, PK16(4433, -10704), 0);
+    const int E0 = ap + b0, E3 = ap - b0, E1 = am + b1, E2 = am - b1;
+    const int O0 = dot2(o0, PK16(11363, 9633), dot2(o1, PK16(6437, 2260), 0));
+    const int O1 = dot2(o0, PK16(9633, -2259), dot2(o1, PK16(-11362, -6436), 0));
+    const int O2 = dot2(o0, PK16(6437, -11362), dot2(o1, PK16(2261, 9633), 0));
+    const int O3 = dot2(o0, PK16(2260, -6436), dot2(o1, PK16(9633, -11363), 0));
+    out[0] = E0 + O0; out[7] = E0 - O0;
+    out[1] = E1 + O1; out[6] = E1 - O1;
+    out[2] = E2 + O2; out[5] = E2 - O2;
+    out[3] = E3 + O3; out[4] = E3 - O3;
+}
+
+/* byte offset of row `u` of block `b` in the 8-block work tile; blocks 2,3,6,7
+ * keep their even/odd rows swapped so the transposing reads are conflict-free */
+__device__ __forceinline__ u32 tile_off(u32 b, u32 u) { return b * 128u + ((u ^ ((b >> 1) & 1u)) << 4); }
+
+struct WaveCtx {
+    char *lds;      /* this wave's LDS region (generic pointer)              */
+    u32 lane;
+    u32 wr_off;     /* tile_off(block, row) of the row this lane loads        */
+    u32 tr_even;    /* byte offsets this lane supplies to the transposing     */
+    u32 tr_odd;     /*   reads (even rows 0,4,2,6 / odd rows 1,3,5,7)         */
+    u32 blk, idx;   /* after a transposing read: block and column/row index   */
+};
+
+__device__ __forceinline__ void wave_ctx_init(WaveCtx &c, char *lds, u32 lane)
+{
+    c.lds = lds;
+    c.lane = lane;
+    c.wr_off = tile_off(lane >> 3, lane & 7);
+    const u32 g = lane >> 4, t = lane & 15, q = t >> 2, p = t & 3;
+    const u32 b = 2 * g + (p >> 1);
+    c.tr_even = tile_off(b, ((q & 1) << 2) | (q & 2)) + (p & 1) * 8;
+    c.tr_odd = tile_off(b, 2 * q + 1) + (p & 1) * 8;
+    c.blk = 2 * g + (t >> 3);
+    c.idx = t & 7;
+}
+
+__device__ __forceinline__ u32x2 lds_tr_read(const WaveCtx &c, u32 off)
+{
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(c.lds + LDS_W + off));
+    return __builtin_bit_cast(u32x2, v);
+}
+
+/* Dequantise + 2-D IDCT of 8 blocks held one row per lane (lane = 8*block+row).
+ * raw/quant: the lane's 8 coefficients / quant factors as packed int16 pairs.
+ * Returns in out[0..7] the samples of row c.idx of block c.blk (values 0..8191). */
+__device__ __forceinline__ void idct8x8_round(const WaveCtx &c, u32x4 raw, u32x4 quant, int out[8])
+{
+    /* dequant: low 16 bits of the product = the int16 store of jpg.c:251 */
+    u32x4 dq;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        using u16x2 = unsigned short __attribute__((ext_vector_type(2)));
+        u16x2 a = __builtin_bit_cast(u16x2, raw[i]), b = __builtin_bit_cast(u16x2, quant[i]);
+        dq[i] = __builtin_bit_cast(u32, (u16x2)(a * b));
+    }
+    *(u32x4 *)(c.lds + LDS_W + c.wr_off) = dq;                 /* stage A: [block][row u][x] */
+    u32x2 ev = lds_tr_read(c, c.tr_even), od = lds_tr_read(c, c.tr_odd);
+    int col[8];
+    idct8_1d(ev[0], ev[1], od[0], od[1], 1 << 10, col);       /* column x = c.idx, all y */
+    u32x4 pk;                                                  /* (v >> 11) stored to int16, idct.c:522 */
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        pk[i] = (((u32)col[2 * i] >> 11) & 0xffffu) | (((u32)col[2 * i + 1] >> 11) << 16);
+    *(u32x4 *)(c.lds + LDS_W + tile_off(c.blk, c.idx)) = pk;   /* stage B: [block][col x][y] */
+    ev = lds_tr_read(c, c.tr_even);
+    od = lds_tr_read(c, c.tr_odd);
+    idct8_1d(ev[0], ev[1], od[0], od[1], 257 << 17, out);      /* row y = c.idx, all x */
+    /* clamp((v >> 18), 0, 65535): v >> 18 is in [-8192, 8191] so only the lower
+     * clamp can act and the int16 store never wraps (idct.c:531) */
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        int s = out[i] >> 18;
+        out[i] = s < 0 ? 0 : s;
+    }
+}
+
+__device__ __forceinline__ u32 sat_pk_u8_i16(u32 v)
+{
+    u32 d;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(v));
+    return d;
+}
+
+__device__ __forceinline__ u32 pk_add16(u32 a, u32 b)
+{
+    return __builtin_bit_cast(u32, (s16x2)(__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b)));
+}
+
+/* literal fp64 G of colorspace.c:163 (contraction is off for this file) */
+__device__ __forceinline__ u32 green_fp64(int yy, int uu, int vv)
+{
+    double g = (double)yy - 0.215 * (double)uu;
+    g = g - 0.381 * (double)vv;
+    int gi = (int)g;
+    return (u32)(gi < 0 ? 0 : (gi > 255 ? 255 : gi));
+}
+
+struct JpegBatch {
+    const int16_t *coef_y, *coef_u, *coef_v;
+    const uint16_t *quant;
+    long long quant_stride;
+    uint8_t *bgra;
+    long long pitch, image_stride;
+    int mcu_cols, mcu_rows, quads_per_row, n_images;
+    int qt_y, qt_u, qt_v;
+};
+
+/* ------------------------------------------------------------------------
+ * Fused kernel, 3 components, h = v = 2.
+ * ---------------------------------------------------------------------- */
+__global__ __launch_bounds__(WG_THREADS) void k_jpeg420_fused(JpegBatch p)
+{
+    __shared__ __attribute__((aligned(16))) char lds_all[WAVES_PER_WG * LDS_WAVE_BYTES];
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    WaveCtx c;
+    wave_ctx_init(c, lds_all + wave * LDS_WAVE_BYTES, lane);
+
+    const long long quads_per_image = (long long)p.quads_per_row * p.mcu_rows;
+    const long long total = quads_per_image * p.n_images;
+    const long long n_waves = (long long)gridDim.x * WAVES_PER_WG;
+    const long long mcus_per_image = (long long)p.mcu_cols * p.mcu_rows;
+
+    const u32 row = lane & 7, lblk = lane >> 3; /* load role: block lblk of the round, row `row` */
+    int cur_img = -1;
+    u32x4 q_y, q_c;
+
+    for (long long q = (long long)blockIdx.x * WAVES_PER_WG + wave; q < total; q += n_waves) {
+        const int img = (int)(q / quads_per_image);
+        const int rem = (int)(q - (long long)img * quads_per_image);
+        const int mrow = rem / p.quads_per_row;
+        const int mcu0 = (rem - mrow * p.quads_per_row) * 4;
+
+        if (img != cur_img) { /* wave-uniform */
+            cur_img = img;
+            const uint16_t *qt = p.quant + (long long)img * p.quant_stride;
+            q_y = *(const u32x4 *)(qt + p.qt_y * 64 + row * 8);
+            q_c = *(const u32x4 *)(qt + (lane < 32 ? p.qt_u : p.qt_v) * 64 + row * 8);
+        }
+
+        /* ---- global loads: one block row (16 B) per lane per round ---- */
+        const long long mcu_base = (long long)img * mcus_per_image + (long long)mrow * p.mcu_cols;
+        const int last = p.mcu_cols - 1;
+        int mc = mcu0 + (int)(lblk & 3);
+        mc = mc > last ? last : mc;
+        const int16_t *cplane = lane < 32 ? p.coef_u : p.coef_v;
+        const u32x4 raw_c = *(const u32x4 *)(cplane + (mcu_base + mc) * 64 + row * 8);
+        int my0 = mcu0 + (int)(lblk >> 2), my1 = my0 + 2;
+        my0 = my0 > last ? last : my0;
+        my1 = my1 > last ? last : my1;
+        const u32x4 raw_y0 = *(const u32x4 *)(p.coef_y + ((mcu_base + my0) * 4 + (lblk & 3)) * 64 + row * 8);
+        const u32x4 raw_y1 = *(const u32x4 *)(p.coef_y + ((mcu_base + my1) * 4 + (lblk & 3)) * 64 + row * 8);
+
+        int s[8];
+        /* ---- chroma round: blocks 0-3 = U of MCU 0-3, blocks 4-7 = V ---- */
+        idct8x8_round(c, raw_c, q_c, s);
+        {
+            /* samples -> work tile [block][row][8 x int16]; then each lane picks up
+             * U and V of 4 adjacent chroma columns of one chroma row */
+            u32x4 pk;
+#pragma unroll
+            for (int i = 0; i < 4; i++) pk[i] = (u32)s[2 * i] | ((u32)s[2 * i + 1] << 16);
+            *(u32x4 *)(c.lds + LDS_W + (c.blk * 8 + c.idx) * 16) = pk;
+            /* entry e = j*8 + m*2 + hf  (chroma row j, MCU m, column half hf) */
+            const u32 e = lane, j = e >> 3, m = (e >> 1) & 3, hf = e & 1;
+            const u32x2 us = *(const u32x2 *)(c.lds + LDS_W + (m * 8 + j) * 16 + hf * 8);
+            const u32x2 vs = *(const u32x2 *)(c.lds + LDS_W + 512 + (m * 8 + j) * 16 + hf * 8);
+            u32x4 tr, tg, tb, uv;
+            u32 mask = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int uu = (int)((us[k >> 1] >> ((k & 1) * 16)) & 0xffffu) - 128; /* colorspace.c:149 */
+                const int vv = (int)((vs[k >> 1] >> ((k & 1) * 16)) & 0xffffu) - 128;
+                const u32 fr = (u32)(32 * vv + 25 * 164) / 25u - 164u;       /* floor(32 vv / 25)   */
+                const u32 fb = (u32)(266 * uu + 125 * 273) / 125u - 273u;    /* floor(266 uu / 125) */
+                const int sgm = 215 * uu + 381 * vv;
+                const u32 t = (u32)(4806000 - sgm);
+                const u32 tq = t / 1000u;
+                const u32 fg = tq - 4806u;                                   /* floor(-s / 1000)    */
+                if (t - tq * 1000u == 0 && sgm != 0) mask |= 1u << k;
+                tr[k] = (fr & 0xffffu) * 0x10001u;
+                tg[k] = (fg & 0xffffu) * 0x10001u;
+                tb[k] = (fb & 0xffffu) * 0x10001u;
+                uv[k] = PK16(uu, vv);
+            }
+            *(u32x4 *)(c.lds + LDS_TR + e * 16) = tr;
+            *(u32x4 *)(c.lds + LDS_TG + e * 16) = tg;
+            *(u32x4 *)(c.lds + LDS_TB + e * 16) = tb;
+            *(u32x4 *)(c.lds + LDS_UV + e * 16) = uv;
+            *(u32 *)(c.lds + LDS_FL + e * 4) = mask;
+        }
+
+        /* ---- two luma rounds: MCU 0-1 then MCU 2-3 of the quad ---- */
+#pragma unroll
+        for (int rnd = 0; rnd < 2; rnd++) {
+            idct8x8_round(c, rnd ? raw_y1 : raw_y0, q_y, s);
+            /* stage C: 16 pixel rows x 32 px of int16, 64 B per row, 16-B chunks
+             * XOR-swizzled by (row>>1)&3 so that both the writes here and the
+             * output-order reads below are bank-conflict free */
+            {
+                const u32 mloc = c.blk >> 2, vi = (c.blk >> 1) & 1, hi = c.blk & 1;
+                const u32 prow = vi * 8 + c.idx, chunk = mloc * 2 + hi;
+                u32x4 pk;
+#pragma unroll
+                for (int i = 0; i < 4; i++) pk[i] = (u32)s[2 * i] | ((u32)s[2 * i + 1] << 16);
+                *(u32x4 *)(c.lds + LDS_W + prow * 64 + ((chunk ^ ((prow >> 1) & 3)) << 4)) = pk;
+            }
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                /* output role: 8 lanes cover one 32-px row segment (128 B) */
+                const u32 prow = 8 * k + (lane >> 3), cg = lane & 7;
+                const u32 chunk = cg >> 1;
+                const u32x2 yy = *(const u32x2 *)(c.lds + LDS_W + prow * 64 +
+                                                  ((chunk ^ ((prow >> 1) & 3)) << 4) + (cg & 1) * 8);
+                const u32 m = 2 * rnd + (cg >> 2), hf = (cg >> 1) & 1, pp = cg & 1;
+                const u32 e = (prow >> 1) * 8 + m * 2 + hf;
+                const u32x2 tr = *(const u32x2 *)(c.lds + LDS_TR + e * 16 + pp * 8);
+                const u32x2 tg = *(const u32x2 *)(c.lds + LDS_TG + e * 16 + pp * 8);
+                const u32x2 tb = *(const u32x2 *)(c.lds + LDS_TB + e * 16 + pp * 8);
+                const u32 fl = (*(const u32 *)(c.lds + LDS_FL + e * 4) >> (2 * pp)) & 3u;
+                u32x4 px;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; h2++) {
+                    const u32 r2 = sat_pk_u8_i16(pk_add16(yy[h2], tr[h2]));
+                    const u32 g2 = sat_pk_u8_i16(pk_add16(yy[h2], tg[h2]));
+                    const u32 b2 = sat_pk_u8_i16(pk_add16(yy[h2], tb[h2]));
+                    const u32 bg = __builtin_amdgcn_perm(g2, b2, 0x05010400u); /* b0 g0 b1 g1 */
+                    px[2 * h2] = __builtin_amdgcn_perm(r2, bg, 0x0d040100u);     /* b0 g0 r0 ff */
+                    px[2 * h2 + 1] = __builtin_amdgcn_perm(r2, bg, 0x0d050302u); /* b1 g1 r1 ff */
+                }
+                if (fl) { /* rare: exact-integer G decided by the fp64 roundings */
+                    const u32x2 uvp = *(const u32x2 *)(c.lds + LDS_UV + e * 16 + pp * 8);
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; h2++)
+                        if (fl & (1u << h2)) {
+                            const int uu = (int)(short)(uvp[h2] & 0xffffu), vv = (int)(short)(uvp[h2] >> 16);
+                            const u32 g0 = green_fp64((int)(yy[h2] & 0xffffu), uu, vv);
+                            const u32 g1 = green_fp64((int)(yy[h2] >> 16), uu, vv);
+                            px[2 * h2] = (px[2 * h2] & 0xffff00ffu) | (g0 << 8);
+                            px[2 * h2 + 1] = (px[2 * h2 + 1] & 0xffff00ffu) | (g1 << 8);
+                        }
+                }
+                const int mcol = mcu0 + (int)m;
+                if (mcol <= last) {
+                    uint8_t *dst = p.bgra + (long long)img * p.image_stride +
+                                   ((long long)mrow * 16 + prow) * p.pitch + (long long)mcol * 64 + (cg & 3) * 16;
+                    *(u32x4 *)dst = px;
+                }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------
+ * Generic path, kernel 1: dequant + IDCT of one component plane into int16
+ * sample planes (same block-major layout as the input).
+ * ---------------------------------------------------------------------- */
+struct IdctPlanes {
+    const int16_t *coef;
+    int16_t *samples;
+    const uint16_t *quant;
+    long long quant_stride;
+    long long blocks_per_image, total_blocks;
+    int qt;
+};
+
+__global__ __launch_bounds__(WG_THREADS) void k_jpeg_idct_planes(IdctPlanes p)
+{
+    __shared__ __attribute__((aligned(16))) char lds_all[WAVES_PER_WG * 1024];
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    WaveCtx c;
+    wave_ctx_init(c, lds_all + wave * 1024, lane);
+    const long long n_rounds = (p.total_blocks + 7) / 8;
+    const long long n_waves = (long long)gridDim.x * WAVES_PER_WG;
+    for (long long r = (long long)blockIdx.x * WAVES_PER_WG + wave; r < n_rounds; r += n_waves) {
+        long long b = r * 8 + (lane >> 3);
+        b = b < p.total_blocks ? b : p.total_blocks - 1;
+        const long long img = b / p.blocks_per_image;
+        const u32x4 quant = *(const u32x4 *)(p.quant + img * p.quant_stride + p.qt * 64 + (lane & 7) * 8);
+        const u32x4 raw = *(const u32x4 *)(p.coef + b * 64 + (lane & 7) * 8);
+        int s[8];
+        idct8x8_round(c, raw, quant, s);
+        const long long ob = r * 8 + c.blk;
+        if (ob < p.total_blocks) {
+            u32x4 pk;
+#pragma unroll
+            for (int i = 0; i < 4; i++) pk[i] = (u32)s[2 * i] | ((u32)s[2 * i + 1] << 16);
+            *(u32x4 *)(p.samples + ob * 64 + c.idx * 8) = pk;
+        }
+    }
+}
+
+/* Generic path, kernel 2: per-pixel colour conversion from sample planes with the
+ * literal expressions of colorspace.c:148-164; one lane = 4 horizontal pixels. */
+struct ColorGeneric {
+    const int16_t *sy, *su, *sv; /* su/sv NULL for grey: U = V = 0 (jpg.c:501,552-554) */
+    uint8_t *bgra;
+    long long pitch, image_stride;
+    int mcu_cols, mcu_rows, h, v, n_images;
+};
+
+__global__ __launch_bounds__(256) void k_jpeg_color_generic(ColorGeneric p)
+{
+    const int w4 = p.mcu_cols * 8 * p.h / 4, hgt = p.mcu_rows * 8 * p.v;
+    const long long per_image = (long long)w4 * hgt, total = per_image * p.n_images;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int img = (int)(t / per_image);
+        const int rem = (int)(t - (long long)img * per_image);
+        const int y = rem / w4, x = (rem - y * w4) * 4;
+        const int my = y / (8 * p.v), i = y - my * 8 * p.v;
+        const int mx = x / (8 * p.h), k0 = x - mx * 8 * p.h;
+        const long long mcu = ((long long)img * p.mcu_rows + my) * p.mcu_cols + mx;
+        const int16_t *Y = p.sy + mcu * p.h * p.v * 64;
+        u32x4 px;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int k = k0 + d;
+            const int16_t yy = Y[((i / 8) * p.h + (k / 8)) * 64 + (i % 8) * 8 + (k % 8)];
+            int su = 0, sv = 0;
+            if (p.su) {
+                su = p.su[mcu * 64 + (i / p.v) * 8 + (k / p.h)];
+                sv = p.sv[mcu * 64 + (i / p.v) * 8 + (k / p.h)];
+            }
+            const int16_t uu = (int16_t)(su - 128), vv = (int16_t)(sv - 128);
+            double dr = (double)yy + 1.280 * (double)vv;
+            double dg = (double)yy - 0.215 * (double)uu;
+            dg = dg - 0.381 * (double)vv;
+            double db = (double)yy + 2.128 * (double)uu;
+            int r = (int)dr, g = (int)dg, b = (int)db;
+            r = r < 0 ? 0 : (r > 255 ? 255 : r);
+            g = g < 0 ? 0 : (g > 255 ? 255 : g);
+            b = b < 0 ? 0 : (b > 255 ? 255 : b);
+            px[d] = (u32)b | ((u32)g << 8) | ((u32)r << 16) | 0xff000000u;
+        }
+        *(u32x4 *)(p.bgra + (long long)img * p.image_stride + (long long)y * p.pitch + (long long)x * 4) = px;
+    }
+}
+
+/* ------------------------------------------------------------------------ host */
+
+static int geom_ok(const ffhip_jpeg_geom *g)
+{
+    if (!g || g->mcu_cols <= 0 || g->mcu_rows <= 0) return 0;
+    if (g->ncomp != 1 && g->ncomp != 3) return 0;
+    if (g->h < 1 || g->h > 2 || g->v < 1 || g->v > 2) return 0;
+    for (int c = 0; c < g->ncomp; c++)
+        if (g->qt_id[c] < 0 || g->qt_id[c] > 3) return 0;
+    return 1;
+}
+
+static int is_fused420(const ffhip_jpeg_geom *g) { return g->ncomp == 3 && g->h == 2 && g->v == 2; }
+
+static int grid_for(long long work_items_per_wg_unit)
+{
+    /* persistent-style grid: enough workgroups to fill 256 CUs several times over,
+     * never more than there is work */
+    long long want = 256LL * 7;
+    if (work_items_per_wg_unit < want) want = work_items_per_wg_unit;
+    return (int)(want < 1 ? 1 : want);
+}
+
+extern "C" size_t ffhip_jpeg_workspace_bytes(const ffhip_jpeg_geom *g, int n_images)
+{
+    if (!geom_ok(g) || n_images <= 0 || is_fused420(g)) return 0;
+    size_t mcus = (size_t)g->mcu_cols * g->mcu_rows * (size_t)n_images;
+    size_t blocks = mcus * (size_t)(g->h * g->v) + (g->ncomp == 3 ? 2 * mcus : 0);
+    return blocks * 64 * sizeof(int16_t);
+}
+
+extern "C" const char *ffhip_jpeg_kernel_name(const ffhip_jpeg_geom *g)
+{
+    if (!geom_ok(g)) return "";
+    return is_fused420(g) ? "k_jpeg420_fused" : "k_jpeg_idct_planes";
+}
+
+extern "C" int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *g, int n_images, const int16_t *d_coef_y,
+                                      const int16_t *d_coef_u, const int16_t *d_coef_v,
+                                      const uint16_t *d_quant, int64_t quant_stride, uint8_t *d_bgra,
+                                      int64_t pitch, int64_t image_stride, void *d_workspace,
+                                      size_t workspace_bytes, void *stream)
+{
+    if (!geom_ok(g) || n_images < 0) return FFHIP_EINVAL;
+    if (n_images == 0) return FFHIP_OK;
+    const int64_t width = (int64_t)g->mcu_cols * 8 * g->h, height = (int64_t)g->mcu_rows * 8 * g->v;
+    if (!d_coef_y || !d_quant || !d_bgra) return FFHIP_EINVAL;
+    if (g->ncomp == 3 && (!d_coef_u || !d_coef_v)) return FFHIP_EINVAL;
+    if (pitch < width * 4 || (pitch & 15) || ((uintptr_t)d_bgra & 15) || (image_stride & 15)) return FFHIP_EINVAL;
+    if (n_images > 1 && image_stride < pitch * height) return FFHIP_EINVAL;
+    if (quant_stride != 0 && quant_stride < 256) return FFHIP_EINVAL;
+    if (((uintptr_t)d_coef_y & 15) || ((uintptr_t)d_coef_u & 15) || ((uintptr_t)d_coef_v & 15) ||
+        ((uintptr_t)d_quant & 15) || (quant_stride & 7))
+        return FFHIP_EINVAL;
+    if (!ffhip_have_device()) return FFHIP_ENODEV;
+    hipStream_t st = (hipStream_t)stream;
+
+    if (is_fused420(g)) {
+        JpegBatch p;
+        p.coef_y = d_coef_y; p.coef_u = d_coef_u; p.coef_v = d_coef_v;
+        p.quant = d_quant; p.quant_stride = quant_stride;
+        p.bgra = d_bgra; p.pitch = pitch; p.image_stride = image_stride;
+        p.mcu_cols = g->mcu_cols; p.mcu_rows = g->mcu_rows;
+        p.quads_per_row = (g->mcu_cols + 3) / 4; p.n_images = n_images;
+        p.qt_y = g->qt_id[0]; p.qt_u = g->qt_id[1]; p.qt_v = g->qt_id[2];
+        long long quads = (long long)p.quads_per_row * p.mcu_rows * n_images;
+        int grid = grid_for((quads + WAVES_PER_WG - 1) / WAVES_PER_WG);
+        hipLaunchKernelGGL(k_jpeg420_fused, dim3(grid), dim3(WG_THREADS), 0, st, p);
+        FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
+        return FFHIP_OK;
+    }
+
+    /* generic geometries: IDCT to sample planes, then colour */
+    const size_t need = ffhip_jpeg_workspace_bytes(g, n_images);
+    if (!d_workspace || workspace_bytes < need || ((uintptr_t)d_workspace & 15)) return FFHIP_EINVAL;
+    const long long mcus = (long long)g->mcu_cols * g->mcu_rows;
+    int16_t *sy = (int16_t *)d_workspace;
+    int16_t *su = sy + mcus * g->h * g->v * 64 * n_images;
+    int16_t *sv = su + mcus * 64 * n_images;
+    for (int comp = 0; comp < g->ncomp; comp++) {
+        IdctPlanes ip;
+        ip.coef = comp == 0 ? d_coef_y : (comp == 1 ? d_coef_u : d_coef_v);
+        ip.samples = comp == 0 ? sy : (comp == 1 ? su : sv);
+        ip.quant = d_quant; ip.quant_stride = quant_stride;
+        ip.blocks_per_image = comp == 0 ? mcus * g->h * g->v : mcus;
+        ip.total_blocks = ip.blocks_per_image * n_images;
+        ip.qt = g->qt_id[comp];
+        long long rounds = (ip.total_blocks + 7) / 8;
+        int grid = grid_for((rounds + WAVES_PER_WG - 1) / WAVES_PER_WG);
+        hipLaunchKernelGGL(k_jpeg_idct_planes, dim3(grid), dim3(WG_THREADS), 0, st, ip);
+        FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
+    }
+    ColorGeneric cg;
+    cg.sy = sy; cg.su = g->ncomp == 3 ? su : nullptr; cg.sv = g->ncomp == 3 ? sv : nullptr;
+    cg.bgra = d_bgra; cg.pitch = pitch; cg.image_stride = image_stride;
+    cg.mcu_cols = g->mcu_cols; cg.mcu_rows = g->mcu_rows; cg.h = g->h; cg.v = g->v; cg.n_images = n_images;
+    long long items = (long long)width / 4 * height * n_images;
+    int grid = grid_for((items + 255) / 256);
+    hipLaunchKernelGGL(k_jpeg_color_generic, dim3(grid), dim3(256), 0, st, cg);
+    FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
+    return FFHIP_OK;
+}
+
+extern "C" int ffhip_jpeg_recon_batch_host(const ffhip_jpeg_geom *g, int n_images, const int16_t *coef_y,
+                                           const int16_t *coef_u, const int16_t *coef_v,
+                                           const uint16_t *quant, int64_t quant_stride, uint8_t *bgra,
+                                           int64_t pitch, int64_t image_stride)
+{
+    if (!geom_ok(g) || n_images < 0) return FFHIP_EINVAL;
+    if (n_images == 0) return FFHIP_OK;
+    if (!ffhip_have_device()) return FFHIP_ENODEV;
+    const size_t mcus = (size_t)g->mcu_cols * g->mcu_rows;
+    const size_t ybytes = mcus * g->h * g->v * 128 * n_images, cbytes = mcus * 128 * n_images;
+    const size_t qbytes = (quant_stride ? (size_t)quant_stride * (n_images - 1) + 256 : 256) * 2;
+    const int64_t height = (int64_t)g->mcu_rows * 8 * g->v;
+    const size_t obytes = (size_t)image_stride * (n_images - 1) + (size_t)pitch * height;
+    const size_t wbytes = ffhip_jpeg_workspace_bytes(g, n_images);
+    void *dy = nullptr, *du = nullptr, *dv = nullptr, *dq = nullptr, *dout = nullptr, *dws = nullptr;
+    int rc = FFHIP_ENOMEM;
+    if (hipMalloc(&dy, ybytes) != hipSuccess) goto done;
+    if (g->ncomp == 3 && (hipMalloc(&du, cbytes) != hipSuccess || hipMalloc(&dv, cbytes) != hipSuccess)) goto done;
+    if (hipMalloc(&dq, qbytes) != hipSuccess || hipMalloc(&dout, obytes) != hipSuccess) goto done;
+    if (wbytes && hipMalloc(&dws, wbytes) != hipSuccess) goto done;
+    rc = FFHIP_EIO;
+    if (hipMemcpy(dy, coef_y, ybytes, hipMemcpyHostToDevice) != hipSuccess) goto done;
+    if (g->ncomp == 3 && (hipMemcpy(du, coef_u, cbytes, hipMemcpyHostToDevice) != hipSuccess ||
+                          hipMemcpy(dv, coef_v, cbytes, hipMemcpyHostToDevice) != hipSuccess))
+        goto done;
+    if (hipMemcpy(dq, quant, qbytes, hipMemcpyHostToDevice) != hipSuccess) goto done;
+    rc = ffhip_jpeg_recon_batch(g, n_images, (const int16_t *)dy, (const int16_t *)du, (const int16_t *)dv,
+                                (const uint16_t *)dq, quant_stride, (uint8_t *)dout, pitch, image_stride, dws,
+                                wbytes, nullptr);
+    if (rc) goto done;
+    rc = FFHIP_EIO;
+    if (hipMemcpy(bgra, dout, obytes, hipMemcpyDeviceToHost) != hipSuccess) goto done;
+    rc = FFHIP_OK;
+done:
+    (void)hipFree(dy); (void)hipFree(du); (void)hipFree(dv); (void)hipFree(dq); (void)hipFree(dout); (void)hipFree(dws);
+    return rc;
+}

@@ -1,0 +1,149 @@
+/*
+ * ffhip_runtime.hip -- device binding, memory/stream/event helpers and the copy
+ * calibration kernel of libffpic_hip.so.  Plain plumbing around the HIP runtime
+ * so that a C11 host (the reference is C) needs no HIP headers.
+ */
+#include "ffhip_internal.h"
+
+#include <stdio.h>
+#include <string.h>
+
+static int g_device = -1;
+static int g_ready = 0;
+static char g_arch[64] = "";
+static char g_last_error[256] = "";
+
+extern "C" void ffhip_note_hip_error(int hip_error, const char *what)
+{
+    snprintf(g_last_error, sizeof g_last_error, "%s: %s", what, hipGetErrorString((hipError_t)hip_error));
+    if (getenv("FFHIP_VERBOSE")) fprintf(stderr, "ffpic_hip: %s\n", g_last_error);
+}
+
+extern "C" int ffhip_have_device(void)
+{
+    if (!g_ready) ffhip_init(g_device < 0 ? 0 : g_device);
+    return g_ready;
+}
+
+extern "C" int ffhip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int ffhip_init(int device)
+{
+    int n = ffhip_device_count();
+    if (device < 0 || device >= n) return FFHIP_ENODEV;
+    FFHIP_CHECK(hipSetDevice(device), FFHIP_ENODEV);
+    hipDeviceProp_t prop;
+    FFHIP_CHECK(hipGetDeviceProperties(&prop, device), FFHIP_ENODEV);
+    strncpy(g_arch, prop.gcnArchName, sizeof g_arch - 1);
+    char *colon = strchr(g_arch, ':');
+    if (colon) *colon = 0;
+    /* the code object only holds gfx950 ISA: refuse anything else up front */
+    if (strcmp(g_arch, "gfx950") != 0) {
+        snprintf(g_last_error, sizeof g_last_error, "device %d is %s, this library is built for gfx950 only", device, g_arch);
+        return FFHIP_ENODEV;
+    }
+    g_device = device;
+    g_ready = 1;
+    return FFHIP_OK;
+}
+
+extern "C" void ffhip_shutdown(void) { g_ready = 0; }
+
+extern "C" const char *ffhip_arch_name(void) { return g_arch; }
+
+extern "C" const char *ffhip_strerror(int code)
+{
+    switch (code) {
+    case FFHIP_OK: return "ok";
+    case FFHIP_EINVAL: return "invalid argument or unsupported geometry";
+    case FFHIP_ENOMEM: return "out of memory";
+    case FFHIP_ENODEV: return g_last_error[0] ? g_last_error : "no usable gfx950 device";
+    case FFHIP_EIO: return g_last_error[0] ? g_last_error : "HIP launch or copy failed";
+    default: return "unknown error";
+    }
+}
+
+extern "C" void *ffhip_malloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (!ffhip_have_device()) return nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void ffhip_free(void *p) { if (p) (void)hipFree(p); }
+
+extern "C" int ffhip_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+    FFHIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream), FFHIP_EIO);
+    return FFHIP_OK;
+}
+extern "C" int ffhip_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream)
+{
+    FFHIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream), FFHIP_EIO);
+    return FFHIP_OK;
+}
+extern "C" int ffhip_memset(void *dst, int value, size_t bytes, void *stream)
+{
+    FFHIP_CHECK(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream), FFHIP_EIO);
+    return FFHIP_OK;
+}
+extern "C" void *ffhip_stream_create(void)
+{
+    hipStream_t s = nullptr;
+    if (!ffhip_have_device()) return nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return (void *)s;
+}
+extern "C" void ffhip_stream_destroy(void *s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
+extern "C" int ffhip_stream_sync(void *s)
+{
+    FFHIP_CHECK(hipStreamSynchronize((hipStream_t)s), FFHIP_EIO);
+    return FFHIP_OK;
+}
+extern "C" void *ffhip_event_create(void)
+{
+    hipEvent_t e = nullptr;
+    if (!ffhip_have_device()) return nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return (void *)e;
+}
+extern "C" void ffhip_event_destroy(void *e) { if (e) (void)hipEventDestroy((hipEvent_t)e); }
+extern "C" int ffhip_event_record(void *e, void *s)
+{
+    FFHIP_CHECK(hipEventRecord((hipEvent_t)e, (hipStream_t)s), FFHIP_EIO);
+    return FFHIP_OK;
+}
+extern "C" float ffhip_event_elapsed_ms(void *start, void *stop)
+{
+    float ms = -1.0f;
+    if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+/* 16 B per lane grid-stride copy: the achievable-HBM yardstick the fused kernel is
+ * compared with in the same process (bench.py). */
+__global__ __launch_bounds__(256) void k_copy_calibrate(u32x4 *dst, const u32x4 *src, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
+extern "C" int ffhip_copy_calibrate(void *d_dst, const void *d_src, size_t bytes, void *stream)
+{
+    if (!d_dst || !d_src || (bytes & 15) || ((uintptr_t)d_dst & 15) || ((uintptr_t)d_src & 15)) return FFHIP_EINVAL;
+    if (!ffhip_have_device()) return FFHIP_ENODEV;
+    size_t n16 = bytes / 16;
+    if (!n16) return FFHIP_OK;
+    size_t want = (n16 + 255) / 256;
+    int grid = (int)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(k_copy_calibrate, dim3(grid), dim3(256), 0, (hipStream_t)stream, (u32x4 *)d_dst,
+                       (const u32x4 *)d_src, n16);
+    FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
+    return FFHIP_OK;
+}

@@ -1,0 +1,172 @@
+/*
+ * ffpic_hip.h -- C ABI of libffpic_hip.so, the MI355X (gfx950) back-end for the
+ * post-entropy reconstruction stage of the ffpic image decoder.
+ *
+ * Everything here is plain C: pointers, sizes, ints.  No C++/torch types.
+ * Three groups of entry points, each citing the reference interface it stands
+ * behind (paths relative to the ffpic source tree):
+ *
+ *  (1) the accelerator registry seam           arch/accl.h:13-35, arch/accl.c:17-62
+ *  (2) the built-in op tables JPEG decodes by  utils/idct.h:14-25, utils/colorspace.h:29-35
+ *  (3) a batched, device-resident extension    (new; the per-block ABI of (1)/(2)
+ *      cannot be fast on a GPU -- arch/opencl/opcl.c:42-88 shows why)
+ *
+ * Error convention of (3): 0 on success, negative errno-style code otherwise
+ * (FFHIP_E*).  (1) and (2) return void like the reference; a back-end that
+ * cannot run does not register (arch/opencl/opcl.c:112-114), callers fall back
+ * to C when the lookup returns NULL (format/webp.c:1173, coding/hevc.c:3913-3919).
+ */
+#ifndef FFPIC_HIP_H
+#define FFPIC_HIP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFHIP_ABI_VERSION 1
+
+/* error codes (negative errno values) */
+#define FFHIP_OK 0
+#define FFHIP_EINVAL (-22)  /* bad argument / unsupported geometry          */
+#define FFHIP_ENOMEM (-12)  /* device or host allocation failed             */
+#define FFHIP_ENODEV (-19)  /* no usable gfx950 device / HIP runtime error  */
+#define FFHIP_EIO    (-5)   /* kernel launch or copy failed                 */
+
+/* ------------------------------------------------------------------ runtime */
+
+/* Number of visible HIP devices (0 when there is no GPU; never fails). */
+int ffhip_device_count(void);
+/* Bind the calling thread's library state to `device` (hipSetDevice) and create
+ * the small internal staging buffers used by the per-block entry points. */
+int ffhip_init(int device);
+void ffhip_shutdown(void);
+const char *ffhip_strerror(int code);
+/* "gfx950" etc. of the bound device, "" if none. */
+const char *ffhip_arch_name(void);
+
+/* Device memory / stream / event helpers so that a pure-C host (the reference is
+ * C11) can drive the batched API without linking the HIP runtime itself. */
+void *ffhip_malloc(size_t bytes);
+void ffhip_free(void *dptr);
+int ffhip_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int ffhip_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int ffhip_memset(void *dst, int value, size_t bytes, void *stream);
+void *ffhip_stream_create(void);
+void ffhip_stream_destroy(void *stream);
+int ffhip_stream_sync(void *stream); /* NULL = the default stream */
+void *ffhip_event_create(void);
+void ffhip_event_destroy(void *event);
+int ffhip_event_record(void *event, void *stream);
+/* milliseconds between two recorded events (synchronises on `stop`); <0 on error */
+float ffhip_event_elapsed_ms(void *start, void *stop);
+
+/* ------------------------------------------- (1) accelerator registry seam */
+
+/* New member of `enum simd_type` (arch/accl.h:13-18 uses 1, 2, 25, 26). */
+#define GPU_TYPE_HIP 27
+
+/* Layout-compatible with `struct accl_ops` (arch/accl.h:20-25) on LP64:
+ * fn ptrs @0,@8; type @16; TAILQ_ENTRY{tqe_next @24, tqe_prev @32}; sizeof 40. */
+struct ffhip_accl_ops {
+    void (*idct_4x4)(int16_t *in, int bitdepth); /* VP8 4x4, == idct_4x4_16 (utils/idct.c:100-151) */
+    void (*idct_8x8)(int16_t *in, int bitdepth); /* JPEG 8x8, == idct_8x8_16 (utils/idct.c:512-534) */
+    int type;                                    /* GPU_TYPE_HIP */
+    struct {
+        struct ffhip_accl_ops *tqe_next;
+        struct ffhip_accl_ops **tqe_prev;
+    } next;
+};
+
+/* Same protocol as x86_sse2_init / opcl_amd_init / vulkan_init (arch/accl.c:21-35):
+ * on success registers the static ops with accl_ops_register() when that symbol
+ * exists in the process (i.e. libffpic is loaded); registers nothing when no
+ * gfx950 device can be initialised.  hip_accl_uninit mirrors opcl_amd_uninit. */
+void hip_accl_init(void);
+void hip_accl_uninit(void);
+/* The ops struct itself, or NULL when no device could be initialised. */
+struct ffhip_accl_ops *ffhip_accl_ops_get(void);
+
+/* ------------------------------------------------ (2) built-in op tables   */
+
+/* Layout-compatible with `struct dct_ops` (utils/idct.h:14-21). */
+struct ffhip_dct_ops {
+    int bitdepth;
+    void (*idct_4x4)(void *in, int bitdepth);
+    void (*idct_8x8)(void *in, int bitdepth);
+    void (*fdct_4x4)(void *in); /* NULL: encoder side, out of scope */
+    void (*fdct_8x8)(void *in); /* NULL */
+};
+/* Layout-compatible with `struct cs_ops` (utils/colorspace.h:29-33). */
+struct ffhip_cs_ops {
+    void (*YUV_to_BGRA32)(uint8_t *dst, int pitch, void *Y, void *U, void *V, int vertical,
+                          int horizontal);
+    void (*YUV420_to_BGRA32)(uint8_t *dst, int pitch, void *Y, void *U, void *V); /* NULL as in the reference */
+};
+/* Replacements for get_dct_ops(16) / get_cs_ops(16) (utils/idct.c:829-832,
+ * utils/colorspace.c:788-791).  Only the 16-bit tables exist (that is what
+ * format/jpg.c:467-468 asks for); NULL for other depths or without a device. */
+const struct ffhip_dct_ops *ffhip_get_dct_ops(int component_bits);
+const struct ffhip_cs_ops *ffhip_get_cs_ops(int component_bits);
+/* HEVC DST-VII 4x4, same signature and rounding as idct_4x4_hevc (utils/idct.h:25,
+ * utils/idct.c:36-55).  Kept as its own entry: the reference back-ends overloaded
+ * accl_ops.idct_4x4 with three different transforms. */
+void ffhip_idct_4x4_hevc(const int16_t *in, int16_t *out, int bitdepth, bool epp);
+
+/* ------------------------------------------ (3) batched device-resident API */
+
+/* One batch = n_images pictures of identical geometry.  Coefficient planes are
+ * what the entropy decoder of format/jpg.c produces per data unit
+ * (decode_data_unit, jpg.c:521-539): quantised, natural order, int16, 64 per
+ * block; blocks of a component are in MCU order,
+ *     block index = mcu * (h_c * v_c) + vi * h_c + hi,   mcu = my * mcu_cols + mx
+ * the per-MCU scratch order the reference feeds to idct_8x8 / YUV_to_BGRA32
+ * (jpg.c:545-547, colorspace.c:148).  Chroma is one block per MCU (the
+ * reference's colour converter supports nothing else, colorspace.c:149-150).
+ * Image i starts at plane + i * blocks_per_image_c * 64. */
+typedef struct ffhip_jpeg_geom {
+    int32_t mcu_cols, mcu_rows; /* MCUs per row / column                     */
+    int32_t ncomp;              /* 1 (grey: U = V = zeros, jpg.c:501,552) or 3 */
+    int32_t h, v;               /* luma sampling factors, each 1 or 2         */
+    int32_t qt_id[3];           /* DQT slot per component, 0..3               */
+} ffhip_jpeg_geom;
+
+/* dequant (jpg.c:247-253) + idct_8x8_16 (idct.c:512-534) + YUV_to_BGRA32_16bit
+ * (colorspace.c:133-172) for a whole batch.  All pointers are DEVICE pointers.
+ *   d_quant       uint16 [4][64] natural order per image (jpg.h:121-130 `dqt.tdata`),
+ *                 image i at d_quant + i*quant_stride (elements); stride 0 = shared
+ *   d_bgra        B,G,R,0xFF bytes; pixel (x,y) of image i at
+ *                 d_bgra + i*image_stride + y*pitch + 4*x ; coded size is
+ *                 (8*h*mcu_cols) x (8*v*mcu_rows); pitch >= 4*width, multiple of 16
+ *   d_workspace   scratch for the non-4:2:0 geometries (ffhip_jpeg_workspace_bytes);
+ *                 may be NULL for ncomp=3,h=v=2 which runs fully fused
+ *   stream        hipStream_t (NULL = default stream); the call only enqueues. */
+int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *geom, int n_images, const int16_t *d_coef_y,
+                           const int16_t *d_coef_u, const int16_t *d_coef_v,
+                           const uint16_t *d_quant, int64_t quant_stride, uint8_t *d_bgra,
+                           int64_t pitch, int64_t image_stride, void *d_workspace,
+                           size_t workspace_bytes, void *stream);
+size_t ffhip_jpeg_workspace_bytes(const ffhip_jpeg_geom *geom, int n_images);
+
+/* Same computation from HOST buffers (allocates, copies in, runs, copies out,
+ * synchronises): what a patched format/jpg.c would call per picture. */
+int ffhip_jpeg_recon_batch_host(const ffhip_jpeg_geom *geom, int n_images, const int16_t *coef_y,
+                                const int16_t *coef_u, const int16_t *coef_v,
+                                const uint16_t *quant, int64_t quant_stride, uint8_t *bgra,
+                                int64_t pitch, int64_t image_stride);
+
+/* Name and timing of the dominant kernel of the last ffhip_jpeg_recon_batch call
+ * geometry class, for bench.py's roofline object. */
+const char *ffhip_jpeg_kernel_name(const ffhip_jpeg_geom *geom);
+
+/* Device-to-device copy kernel (16 B/lane, grid-stride) used by bench.py to
+ * calibrate the achievable HBM rate next to the fused kernel. */
+int ffhip_copy_calibrate(void *d_dst, const void *d_src, size_t bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFPIC_HIP_H */

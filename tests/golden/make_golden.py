@@ -1,0 +1,340 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REFERENCE ITSELF.
+
+Runs only in the build container: it needs /root/reference, from which
+oracle/Makefile builds oracle/_ref/libffpic_ref.so (the reference's own sources,
+compiled -O2 -DNDEBUG -fwrapv -ffp-contract=off).  Every expected output stored
+here was produced by reference code: utils/idct.c, utils/colorspace.c,
+format/jpg.c:247-253, format/webp.c:1067-1106, coding/hevc.c:3743-3956, and
+whole-file decodes through format/file.c -> format/jpg.c.
+
+    python tests/golden/make_golden.py        # rewrites tests/golden/*.npz, *.jpg, MANIFEST.sha256
+
+Fixtures are data only (inputs + expected outputs); no reference source text.
+"""
+import ctypes as C
+import hashlib
+import io
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+
+import oracle_lib as O  # noqa: E402
+from ffpic_amd import synth  # noqa: E402
+import jpeg_entropy  # noqa: E402  (tests/jpeg_entropy.py: baseline Huffman -> MCU-order planes)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"  {name}: " + ", ".join(f"{k}{list(v.shape)}" for k, v in arrays.items()))
+
+
+# ------------------------------------------------------------------ blocks
+
+# the three literal input blocks of the reference's own tests/test_dct.c
+TEST_DCT_4x4 = np.array([117, 115, 112, 112, 110, 108, 103, 101, 117, 115, 113, 113, 111, 108, 103, 99],
+                        dtype=np.int16)                                        # test_dct.c:272-277
+TEST_DCT_8x8 = np.zeros(64, dtype=np.int16)                                    # test_dct.c:384-393
+TEST_DCT_8x8[[0, 1, 2, 8, 9, 10, 11, 15, 16, 18, 28]] = [873, 55, -11, 5, -10, -2, 7, -1, -2, 6, 1]
+
+
+def adversarial(rng, n, size):
+    b = rng.integers(-32768, 32768, size=(n, size), dtype=np.int64).astype(np.int16)
+    k = n // 8
+    b[:k] = 0
+    b[k:2 * k, 1:] = 0
+    b[2 * k:3 * k] = np.where(rng.random((k, size)) < 0.5, 32767, -32768)
+    b[3 * k:4 * k] = rng.integers(-2048, 2048, size=(k, size))
+    b[4 * k:5 * k] = rng.integers(-255, 256, size=(k, size))
+    side = int(round(size ** 0.5))
+    m = np.zeros(size, bool)
+    m[size - side:] = True
+    b[5 * k:6 * k][:, ~m] = 0
+    return b
+
+
+def gen_blocks(R):
+    rng = np.random.default_rng(20251003)
+    # --- JPEG 8x8
+    q = synth.quant_tables()
+    syn = synth._blocks(rng, 256, q[0])
+    adv = adversarial(rng, 256, 64)
+    inp = np.concatenate([TEST_DCT_8x8[None], syn, adv])
+    out = inp.copy()
+    for b in out:
+        R.ref_idct_8x8_16(b)
+    assert list(out[0][:8]) == [245, 243, 240, 240, 238, 236, 231, 228], out[0][:8]
+    # dequant with extreme tables
+    qa = rng.integers(1, 65536, size=(inp.shape[0], 64)).astype(np.uint16)
+    qa[:257] = q[0]
+    dq = np.zeros_like(inp)
+    for i in range(inp.shape[0]):
+        R.ref_jpeg_dequant(dq[i], inp[i].copy(), qa[i].copy(), 63)
+    save("jpeg_blocks.npz", coef=inp, idct=out, quant=qa, dequant=dq)
+
+    # --- VP8 4x4 + WHT
+    v_in = np.concatenate([TEST_DCT_4x4[None], rng.integers(-2048, 2048, size=(255, 16)).astype(np.int16),
+                           adversarial(rng, 256, 16)])
+    v_out = v_in.copy()
+    for b in v_out:
+        R.ref_vp8_idct_4x4(b)
+    assert list(v_out[0][:4]) == [204, -35, 41, 9], v_out[0][:4]
+    w_long = np.zeros((v_in.shape[0], 256), dtype=np.int16)
+    w_fast = np.zeros((v_in.shape[0], 256), dtype=np.int16)
+    for i in range(v_in.shape[0]):
+        R.ref_vp8_iwht_long(v_in[i].copy(), w_long[i])
+        R.ref_vp8_iwht_fast(v_in[i].copy(), w_fast[i])
+    save("vp8_blocks.npz", coef=v_in, idct=v_out, iwht_long=w_long[:, ::16].copy(), iwht_fast=w_fast[:, ::16].copy())
+
+    # --- HEVC DST 4x4 (idct_4x4_hevc), bitdepth 8/10, epp off/on
+    h_in = np.concatenate([TEST_DCT_4x4[None], rng.integers(-512, 512, size=(127, 16)).astype(np.int16),
+                           adversarial(rng, 128, 16)])
+    dst = {}
+    for bd in (8, 10):
+        for epp in (0, 1):
+            o = np.zeros_like(h_in)
+            for i in range(h_in.shape[0]):
+                R.idct_4x4_hevc(h_in[i].copy(), o[i], bd, bool(epp))
+            dst[f"dst_bd{bd}_epp{epp}"] = o
+    assert list(dst["dst_bd8_epp0"][0]) == [12, 1, 3, 1, 0, 0, 0, 0, 3, 0, 1, 0, 2, 0, 0, 0]
+    save("hevc_dst4.npz", coef=h_in, **dst)
+
+    # --- HEVC scale + DCT 4/8/16/32
+    hv = {}
+    for n in (4, 8, 16, 32):
+        nb = 24 if n < 32 else 12
+        lv = np.rint(rng.laplace(0, 6.0, size=(nb, n * n))).astype(np.int16)
+        lv[: nb // 4] = adversarial(rng, nb // 4 if nb // 4 >= 8 else 8, n * n)[: nb // 4]
+        hv[f"level_{n}"] = lv
+        sf = rng.integers(1, 256, size=n * n).astype(np.uint8)
+        hv[f"sfactor_{n}"] = sf
+        for bd in (8, 10):
+            for qp in (0, 22, 37, 51):
+                d_flat = np.zeros_like(lv)
+                d_sf = np.zeros_like(lv)
+                r_out = np.zeros_like(lv)
+                for i in range(nb):
+                    R.ref_hevc_scale(lv[i].copy(), d_flat[i], n, qp, bd, 0, None, 1)
+                    R.ref_hevc_scale(lv[i].copy(), d_sf[i], n, qp, bd, 0, sf.ctypes.data_as(C.c_void_p), 1)
+                    R.ref_hevc_transform(d_flat[i].copy(), r_out[i], n, 0, bd, 0)
+                hv[f"d_{n}_bd{bd}_qp{qp}"] = d_flat
+                hv[f"dsf_{n}_bd{bd}_qp{qp}"] = d_sf
+                hv[f"r_{n}_bd{bd}_qp{qp}"] = r_out
+    save("hevc_transform.npz", **hv)
+
+
+# ------------------------------------------------------------------ colour
+
+def fma_sensitive_triples():
+    """(y,u,v) in [0,255]^3 whose BGRA differs between an FMA-contracting build of the
+    colour expressions and the ISO build.  Found with two throwaway
+    builds of the expressions as the reference writes them (colorspace.c:162-164)."""
+    src = r"""
+#include <stdint.h>
+static int clampi(int v, int M) { return v < 0 ? 0 : v > M ? M : v; }
+void sweep(uint8_t *out) {
+  for (int y = 0; y < 256; y++) for (int u = 0; u < 256; u++) for (int v = 0; v < 256; v++) {
+    int16_t yy = y, uu = u - 128, vv = v - 128;
+    uint8_t *p = out + 3 * ((y * 256 + u) * 256 + v);
+    p[0] = clampi(yy + 1.280 * vv, 255); p[1] = clampi(yy - 0.215 * uu - 0.381 * vv, 255);
+    p[2] = clampi(yy + 2.128 * uu, 255);
+  }
+}
+"""
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "s.c"), "w").write(src)
+        for tag, flags in (("iso", ["-ffp-contract=off"]), ("fma", ["-ffp-contract=fast", "-mfma"])):
+            so = os.path.join(td, tag + ".so")
+            subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", *flags, os.path.join(td, "s.c"), "-o", so])
+            buf = np.zeros(256 ** 3 * 3, dtype=np.uint8)
+            C.CDLL(so).sweep(buf.ctypes.data_as(C.c_void_p))
+            outs.append(buf.reshape(-1, 3))
+    diff = np.nonzero((outs[0] != outs[1]).any(axis=1))[0]
+    y, u, v = diff // 65536, (diff // 256) % 256, diff % 256
+    return np.stack([y, u, v], axis=1).astype(np.int16)
+
+
+def gen_color(R):
+    rng = np.random.default_rng(7)
+    sens = fma_sensitive_triples()
+    print(f"  FMA-sensitive triples on [0,255]^3: {len(sens)}")
+    rnd = rng.integers(0, 256, size=(32768, 3)).astype(np.int16)
+    # IDCT overshoot domain [0, 8191] and full int16 (wrapped) domain
+    wide = rng.integers(0, 8192, size=(16384, 3)).astype(np.int16)
+    full = rng.integers(-32768, 32768, size=(16384, 3)).astype(np.int16)
+    # exact-integer G cases: 215*uu + 381*vv == 0 mod 1000
+    ex = []
+    for uu in range(-128, 1200):
+        for vv in range(-128, 1200):
+            if (215 * uu + 381 * vv) % 1000 == 0:
+                ex.append((uu + 128, vv + 128))
+    ex = np.array(ex, dtype=np.int64)
+    exy = rng.integers(0, 1400, size=len(ex))
+    exact = np.stack([exy, ex[:, 0], ex[:, 1]], axis=1).astype(np.int16)
+    tri = np.concatenate([sens, rnd, wide, full, exact])
+    n = (len(tri) + 63) // 64 * 64
+    tri = np.concatenate([tri, np.zeros((n - len(tri), 3), np.int16)])
+    # run them through the reference per-MCU converter as 1x1 MCUs (64 px per call)
+    out = np.zeros((n, 4), dtype=np.uint8)
+    for i in range(0, n, 64):
+        Y = np.ascontiguousarray(tri[i:i + 64, 0])
+        U = np.ascontiguousarray(tri[i:i + 64, 1])
+        V = np.ascontiguousarray(tri[i:i + 64, 2])
+        o = np.zeros(64 * 4, dtype=np.uint8)
+        R.ref_yuv_to_bgra32_mcu16(o, 32, Y, U, V, 1, 1)
+        out[i:i + 64] = o.reshape(64, 4)
+    save("color_triples.npz", yuv=tri, bgra=out)
+
+    # 4:2:0 MCU (h=v=2) layout check and planar converters
+    Y = rng.integers(0, 256, size=256).astype(np.int16)
+    U = rng.integers(0, 256, size=64).astype(np.int16)
+    V = rng.integers(0, 256, size=64).astype(np.int16)
+    res = {}
+    for (v, h) in ((1, 1), (1, 2), (2, 1), (2, 2)):
+        o = np.zeros((8 * v, 8 * h * 4), dtype=np.uint8)
+        R.ref_yuv_to_bgra32_mcu16(o.reshape(-1), 8 * h * 4, Y, U, V, v, h)
+        res[f"mcu_v{v}h{h}"] = o
+    mbr, mbc = 3, 4
+    y8 = rng.integers(0, 256, size=(16 * mbr, 16 * mbc)).astype(np.uint8)
+    u8 = rng.integers(0, 256, size=(8 * mbr, 8 * mbc)).astype(np.uint8)
+    v8 = rng.integers(0, 256, size=(8 * mbr, 8 * mbc)).astype(np.uint8)
+    pitch = 16 * mbc * 4
+    o = np.zeros((16 * mbr, pitch), dtype=np.uint8)
+    R.YUV420_to_BGRA32(o.reshape(-1), pitch, y8.reshape(-1), u8.reshape(-1), v8.reshape(-1), 16 * mbc, 8 * mbc, mbr, mbc)
+    res.update(p420_y=y8, p420_u=u8, p420_v=v8, p420_bgra=o)
+    y16 = rng.integers(-300, 1300, size=(16 * mbr, 16 * mbc)).astype(np.int16)
+    u16 = rng.integers(-300, 1300, size=(8 * mbr, 8 * mbc)).astype(np.int16)
+    v16 = rng.integers(-300, 1300, size=(8 * mbr, 8 * mbc)).astype(np.int16)
+    o16 = np.zeros((16 * mbr, pitch), dtype=np.uint8)
+    R.YUV420_to_BGRA32_16bit(o16.reshape(-1), pitch, y16.reshape(-1), u16.reshape(-1), v16.reshape(-1),
+                             16 * mbc, 8 * mbc, mbr, mbc, 16)
+    o400 = np.zeros((16 * mbr, pitch), dtype=np.uint8)
+    R.YUV400_to_BGRA32_16bit(o400.reshape(-1), pitch, y16.reshape(-1), 16 * mbc, mbr, mbc, 16)
+    res.update(p16_y=y16, p16_u=u16, p16_v=v16, p16_bgra=o16, p400_bgra=o400, mcu_Y=Y, mcu_U=U, mcu_V=V)
+    save("color_planar.npz", **res)
+
+
+# ------------------------------------------------------------------ whole grids / files
+
+def gen_grids(R):
+    """Small synthetic coefficient grids through the reference MCU loop, all geometries."""
+    q = synth.quant_tables()
+    res = {"quant": q}
+    for tag, (cols, rows, nc, h, v) in {"420": (6, 4, 3, 2, 2), "420tail": (7, 3, 3, 2, 2), "444": (5, 3, 3, 1, 1),
+                                        "422": (5, 3, 3, 2, 1), "440": (5, 3, 3, 1, 2),
+                                        "grey": (5, 3, 1, 1, 1)}.items():
+        g = O.make_geom(cols, rows, nc, h, v)
+        cy, cu, cv = synth.coef_batch(1, cols, rows, nc, h, v)
+        bgra = O.ref_jpeg_recon(g, cy, cu, cv, q)
+        res[f"{tag}_geom"] = g.as_array()
+        res[f"{tag}_bgra"] = bgra
+    # adversarial: full-range levels and quant tables (int16 wrap, mod-2^32 sums)
+    rng = np.random.default_rng(99)
+    g = O.make_geom(8, 4)
+    adv = synth.adversarial_blocks(rng, 8 * 4 * 6)
+    cy = np.ascontiguousarray(adv[:128].reshape(-1))
+    cu = np.ascontiguousarray(adv[128:160].reshape(-1))
+    cv = np.ascontiguousarray(adv[160:].reshape(-1))
+    qa = rng.integers(1, 65536, size=(4, 64)).astype(np.uint16)
+    res.update(adv_geom=g.as_array(), adv_cy=cy, adv_cu=cu, adv_cv=cv, adv_quant=qa,
+               adv_bgra=O.ref_jpeg_recon(g, cy, cu, cv, qa))
+    save("jpeg_grids.npz", **res)
+
+
+def ref_decode_file(R, path):
+    """Decode a file with the reference's own loader (format/file.c:30-113 -> format/jpg.c)."""
+    class Pic(C.Structure):  # struct pic, format/file.h:29-40 (leading fields)
+        _fields_ = [("pixels", C.c_void_p), ("left", C.c_int), ("top", C.c_int), ("width", C.c_int),
+                    ("height", C.c_int), ("depth", C.c_int), ("pitch", C.c_int)]
+    R.file_ops_init.restype = None
+    R.file_probe.restype = C.c_void_p
+    R.file_probe.argtypes = [C.c_char_p]
+    R.file_load.restype = C.POINTER(Pic)
+    R.file_load.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    if not getattr(ref_decode_file, "inited", False):
+        R.file_ops_init()
+        ref_decode_file.inited = True
+    ops = R.file_probe(path.encode())
+    assert ops, "reference did not recognise " + path
+    p = R.file_load(ops, path.encode(), 0).contents
+    buf = np.ctypeslib.as_array(C.cast(p.pixels, C.POINTER(C.c_uint8)), shape=(p.height, p.pitch)).copy()
+    return buf[:, : p.width * 4].reshape(p.height, p.width, 4)
+
+
+def gen_files(R):
+    """BASELINE config 1: PIL-made baseline JPEGs decoded by the reference from the file."""
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    # a smooth 640x480 test card with some noise so every coefficient band is exercised
+    yy, xx = np.mgrid[0:480, 0:640]
+    img = np.stack([127 + 120 * np.sin(xx / 37.0) * np.cos(yy / 23.0),
+                    127 + 100 * np.cos(xx / 11.0 + yy / 53.0),
+                    (xx * 255 / 639 + yy * 255 / 479) / 2], axis=2)
+    img = np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+    res = {}
+    for tag, kw, mode in (("q85_420", dict(quality=85, subsampling=2), "RGB"),
+                          ("q92_444", dict(quality=92, subsampling=0), "RGB"),
+                          ("q75_422", dict(quality=75, subsampling=1), "RGB"),
+                          ("q80_grey", dict(quality=80), "L")):
+        im = Image.fromarray(img).convert(mode)
+        if tag != "q85_420":
+            im = im.crop((0, 0, 160, 96))  # keep the extra fixtures small
+        bio = io.BytesIO()
+        im.save(bio, "JPEG", optimize=False, progressive=False, **kw)
+        data = bio.getvalue()
+        name = f"file_{tag}.jpg"
+        open(os.path.join(HERE, name), "wb").write(data)
+        bgra = ref_decode_file(R, os.path.join(HERE, name))
+        dec = jpeg_entropy.decode(data)
+        g = O.make_geom(dec["mcu_cols"], dec["mcu_rows"], dec["ncomp"], dec["h"], dec["v"], dec["qt_id"])
+        mine = O.ref_jpeg_recon(g, dec["coef"][0], dec["coef"][1], dec["coef"][2], dec["quant"])
+        Hc, Wc = bgra.shape[:2]
+        assert Hc > 0 and Wc > 0
+        # The reference's bit reader can run dry inside the very last data unit of a
+        # scan ("bits longer than expect", utils/bitstream.c:117): entropy-decoder
+        # behaviour, upstream of this path.  Everything before the last MCU must match.
+        same = (mine[:Hc, :Wc] == bgra).all(axis=2)
+        last = np.zeros_like(same)
+        last[(g.mcu_rows - 1) * 8 * g.v:, (g.mcu_cols - 1) * 8 * g.h:] = True
+        assert same[~last].all(), f"{tag}: coefficient dump does not reproduce the file decode"
+        res[f"{tag}_last_mcu_exact"] = np.array(int(same.all()), dtype=np.int32)
+        res[f"{tag}_sha256"] = np.frombuffer(hashlib.sha256(bgra.tobytes()).digest(), dtype=np.uint8)
+        res[f"{tag}_shape"] = np.array(bgra.shape, dtype=np.int32)
+        if tag != "q85_420":
+            res[f"{tag}_bgra"] = bgra
+        print(f"  {name}: {len(data)} B, {bgra.shape}, reference decode == recon from entropy-decoded planes")
+    save("jpeg_files.npz", **res)
+
+
+def manifest():
+    lines = []
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith((".npz", ".jpg")):
+            lines.append(f"{hashlib.sha256(open(os.path.join(HERE, f), 'rb').read()).hexdigest()}  {f}")
+    open(os.path.join(HERE, "MANIFEST.sha256"), "w").write("\n".join(lines) + "\n")
+
+
+def main():
+    if not os.path.isdir("/root/reference"):
+        sys.exit("make_golden.py needs /root/reference (build container only)")
+    O.build_ref()
+    R = O.ref()
+    print("blocks"); gen_blocks(R)
+    print("colour"); gen_color(R)
+    print("grids"); gen_grids(R)
+    print("files"); gen_files(R)
+    manifest()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,83 @@
+"""CPU: the C-ABI library builds, loads without a GPU, exports every symbol that
+include/ffpic_hip.h declares, keeps the reference's struct layouts, and refuses to
+compute (loudly) when no gfx950 device exists -- there is no CPU fallback."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from ffpic_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not os.path.exists(capi.LIB_PATH):
+        capi.build()
+    return capi.lib()
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "ffpic_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(ffhip_[a-z0-9_]+|hip_accl_[a-z]+)\s*\(", text))
+    return names - {"ffhip_accl_ops", "ffhip_dct_ops", "ffhip_cs_ops"}
+
+
+def test_header_and_exports_agree(L):
+    decl = declared_functions()
+    assert decl == set(capi.EXPORTS), (decl ^ set(capi.EXPORTS))
+    for name in decl:
+        assert hasattr(L, name), f"{name} declared in include/ffpic_hip.h but not exported"
+
+
+def test_struct_layouts_match_reference():
+    # struct accl_ops (arch/accl.h:20-25) on LP64: fn ptrs @0,@8; type @16; TAILQ @24,@32; sizeof 40
+    assert C.sizeof(capi.AcclOps) == 40
+    assert capi.AcclOps.idct_4x4.offset == 0 and capi.AcclOps.idct_8x8.offset == 8
+    assert capi.AcclOps.type.offset == 16 and capi.AcclOps.tqe_next.offset == 24 and capi.AcclOps.tqe_prev.offset == 32
+    # struct dct_ops (utils/idct.h:14-21): int @0, four fn ptrs @8..
+    assert C.sizeof(capi.DctOps) == 40 and capi.DctOps.idct_4x4.offset == 8 and capi.DctOps.idct_8x8.offset == 16
+    # struct cs_ops (utils/colorspace.h:29-33)
+    assert C.sizeof(capi.CsOps) == 16
+    assert C.sizeof(capi.JpegGeom) == 32
+
+
+def test_no_silent_cpu_fallback(L):
+    if L.ffhip_device_count() > 0:
+        pytest.skip("a GPU is present; covered by the -m gpu tests")
+    with pytest.raises(capi.FfhipError):
+        capi.require_device()
+    g = capi.jpeg_geom(4, 2)
+    # argument validation comes first, then the device check: never a computed result
+    assert L.ffhip_jpeg_recon_batch(C.byref(g), 1, None, None, None, None, 0, None, 0, 0, None, 0, None) == -22
+    assert not L.ffhip_accl_ops_get()          # back-end that cannot run exposes no ops ...
+    assert not L.ffhip_get_dct_ops(16) and not L.ffhip_get_cs_ops(16)
+    L.hip_accl_init()                          # ... and does not register (arch/opencl/opcl.c:112-114)
+    assert L.ffhip_malloc(1024) is None
+    assert L.ffhip_jpeg_recon_batch_host(C.byref(g), 1, None, None, None, None, 0, None, 0, 0) == -19
+
+
+def test_geometry_validation(L):
+    for bad in (capi.jpeg_geom(0, 2), capi.jpeg_geom(4, 2, ncomp=2), capi.jpeg_geom(4, 2, h=3),
+                capi.jpeg_geom(4, 2, qt_id=(0, 4, 1))):
+        assert L.ffhip_jpeg_recon_batch(C.byref(bad), 1, 16, 16, 16, 16, 0, 16, 4096, 0, None, 0, None) == -22
+        assert L.ffhip_jpeg_workspace_bytes(C.byref(bad), 1) == 0
+    g = capi.jpeg_geom(4, 2)
+    assert L.ffhip_jpeg_recon_batch(C.byref(g), 0, None, None, None, None, 0, None, 0, 0, None, 0, None) == 0  # empty batch
+    assert L.ffhip_jpeg_workspace_bytes(C.byref(g), 8) == 0          # fused path needs none
+    g444 = capi.jpeg_geom(4, 2, h=1, v=1)
+    assert L.ffhip_jpeg_workspace_bytes(C.byref(g444), 2) == 2 * 8 * 3 * 128
+    assert L.ffhip_jpeg_kernel_name(C.byref(g)) == b"k_jpeg420_fused"
+
+
+def test_product_never_touches_the_oracle():
+    """The product tree must not import, link or reference the CPU checker."""
+    pkg = os.path.join(ROOT, "ffpic_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".c", ".cpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text and "libffo" not in text and "ffo_" not in text, os.path.join(dirpath, f)

@@ -1,0 +1,212 @@
+"""GPU parity tests for the JPEG hot path, through the C ABI of libffpic_hip.so.
+Bit-exact (integer/byte work) against the golden vectors and the CPU oracle."""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from ffpic_amd import capi, ops, synth
+from test_oracle_golden import FILES, GRID_TAGS, decode_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def to_capi(g):
+    return capi.jpeg_geom(g.mcu_cols, g.mcu_rows, g.ncomp, g.h, g.v, tuple(g.qt_id))
+
+
+def gpu_recon(geom, n, cy, cu, cv, quant):
+    return ops.jpeg_recon_batch_host(to_capi(geom), n, cy, cu, cv, quant)
+
+
+def test_device_is_gfx950():
+    L = capi.require_device()
+    assert L.ffhip_arch_name() == b"gfx950"
+
+
+@pytest.mark.parametrize("tag", list(GRID_TAGS))
+def test_golden_grids(golden, tag):
+    g = golden("jpeg_grids.npz")
+    cols, rows, nc, h, v = GRID_TAGS[tag]
+    geom = O.make_geom(cols, rows, nc, h, v)
+    cy, cu, cv = synth.coef_batch(1, cols, rows, nc, h, v)
+    out = gpu_recon(geom, 1, cy, cu, cv, g["quant"])[0]
+    assert np.array_equal(out, g[f"{tag}_bgra"])
+
+
+def test_golden_adversarial(golden):
+    """full-range int16 levels x full-range uint16 quant: every int16 truncation point
+    and the mod-2^32 accumulation of the dot products"""
+    g = golden("jpeg_grids.npz")
+    geom = O.make_geom(*[int(x) for x in g["adv_geom"][:5]])
+    out = gpu_recon(geom, 1, g["adv_cy"], g["adv_cu"], g["adv_cv"], g["adv_quant"])[0]
+    assert np.array_equal(out, g["adv_bgra"])
+
+
+@pytest.mark.parametrize("tag", list(FILES))
+def test_golden_files(golden, tag):
+    g = golden("jpeg_files.npz")
+    dec, geom = decode_fixture(tag)
+    out = gpu_recon(geom, 1, dec["coef"][0], dec["coef"][1], dec["coef"][2], dec["quant"])[0]
+    H, W = [int(x) for x in g[f"{tag}_shape"][:2]]
+    out = out[:H, :W]
+    if int(g[f"{tag}_last_mcu_exact"]):
+        assert hashlib.sha256(out.tobytes()).digest() == g[f"{tag}_sha256"].tobytes()
+    else:
+        keep = np.ones((H, W), bool)
+        keep[(geom.mcu_rows - 1) * 8 * geom.v:, (geom.mcu_cols - 1) * 8 * geom.h:] = False
+        assert np.array_equal(out[keep], g[f"{tag}_bgra"][keep])
+
+
+@pytest.mark.parametrize("cols,rows,n", [(1, 1, 1), (2, 1, 3), (3, 2, 2), (4, 4, 1), (5, 1, 4), (13, 7, 3),
+                                         (40, 30, 2), (120, 68, 1)])
+def test_420_vs_oracle(cols, rows, n):
+    """ragged MCU counts (tail quads), several images per batch, per-image quant tables"""
+    geom = O.make_geom(cols, rows)
+    rng = np.random.default_rng(cols * 100 + rows)
+    q = np.stack([synth.quant_tables(int(rng.integers(30, 96))) for _ in range(n)])
+    ys, us, vs = [], [], []
+    for i in range(n):
+        y, u, v = synth.coef_image(i, cols, rows, quant=q[i])
+        ys.append(y); us.append(u); vs.append(v)
+    cy, cu, cv = (np.ascontiguousarray(np.concatenate(a).reshape(-1)) for a in (ys, us, vs))
+    exp = O.oracle_jpeg_recon(geom, cy, cu, cv, q, n_images=n, n_threads=4)
+    out = gpu_recon(geom, n, cy, cu, cv, q)
+    assert np.array_equal(out, exp)
+
+
+@pytest.mark.parametrize("nc,h,v", [(3, 1, 1), (3, 2, 1), (3, 1, 2), (1, 1, 1)])
+def test_other_geometries_vs_oracle(nc, h, v):
+    geom = O.make_geom(11, 6, nc, h, v)
+    q = synth.quant_tables(70)
+    cy, cu, cv = synth.coef_batch(3, 11, 6, nc, h, v, quant=q)
+    exp = O.oracle_jpeg_recon(geom, cy, cu, cv, q, n_images=3)
+    assert np.array_equal(gpu_recon(geom, 3, cy, cu, cv, q), exp)
+
+
+def test_adversarial_random_vs_oracle():
+    rng = np.random.default_rng(2024)
+    geom = O.make_geom(16, 8)
+    blocks = synth.adversarial_blocks(rng, 16 * 8 * 6)
+    rng.shuffle(blocks)
+    cy = np.ascontiguousarray(blocks[:512].reshape(-1))
+    cu = np.ascontiguousarray(blocks[512:640].reshape(-1))
+    cv = np.ascontiguousarray(blocks[640:].reshape(-1))
+    q = rng.integers(1, 65536, size=(4, 64)).astype(np.uint16)
+    exp = O.oracle_jpeg_recon(geom, cy, cu, cv, q)
+    assert np.array_equal(gpu_recon(geom, 1, cy, cu, cv, q), exp)
+
+
+def test_exact_integer_green_branch(golden):
+    """Force the rare fp64 branch of the fused kernel: flat (DC-only) blocks reproduce
+    any sample value s = 128 + dc/8, so every MCU gets a chroma pair with
+    215*uu + 381*vv == 0 (mod 1000) and luma values around the clamp range."""
+    tri = golden("color_triples.npz")["yuv"]
+    uu, vv = tri[:, 1].astype(np.int64) - 128, tri[:, 2].astype(np.int64) - 128
+    sel = ((215 * uu + 381 * vv) % 1000 == 0) & (tri[:, 1] >= 0) & (tri[:, 1] < 4000) & (tri[:, 2] >= 0) & \
+          (tri[:, 2] < 4000) & ((uu != 0) | (vv != 0))
+    pairs = np.unique(tri[sel][:, 1:3], axis=0)
+    assert len(pairs) > 1000
+    cols, rows = 48, 40
+    pairs = pairs[: cols * rows]
+    n = len(pairs)
+    rng = np.random.default_rng(3)
+    geom = O.make_geom(cols, rows)
+    cy = np.zeros((cols * rows * 4, 64), np.int16)
+    cu = np.zeros((cols * rows, 64), np.int16)
+    cv = np.zeros((cols * rows, 64), np.int16)
+    cu[:n, 0] = (pairs[:, 0].astype(np.int64) - 128) * 8
+    cv[:n, 0] = (pairs[:, 1].astype(np.int64) - 128) * 8
+    # luma such that G lands in and around [0, 255]: yy ~ (215 uu + 381 vv)/1000 + U(-3, 258)
+    base = (215 * (pairs[:, 0].astype(np.int64) - 128) + 381 * (pairs[:, 1].astype(np.int64) - 128)) // 1000
+    yy = np.clip(base[:, None] + rng.integers(-3, 259, size=(n, 4)), 0, 4000)
+    cy[: n * 4, 0] = ((yy - 128) * 8).reshape(-1)
+    q = np.ones((4, 64), np.uint16)
+    args = (np.ascontiguousarray(cy.reshape(-1)), np.ascontiguousarray(cu.reshape(-1)),
+            np.ascontiguousarray(cv.reshape(-1)), q)
+    exp = O.oracle_jpeg_recon(geom, *args)
+    out = gpu_recon(geom, 1, *args)
+    assert np.array_equal(out, exp)
+    # the branch really was exercised: the integer form alone would be wrong somewhere
+    s = 215 * (pairs[:, 0].astype(np.int64) - 128) + 381 * (pairs[:, 1].astype(np.int64) - 128)
+    g_int = np.clip(yy - s[:, None] // 1000, 0, 255)
+    g_ref = exp[0].reshape(rows, 16, cols, 16, 4)[:, ::8, :, ::8, 1].transpose(0, 2, 1, 3).reshape(-1, 4)[:n]
+    assert (g_int != g_ref).any()
+
+
+def test_device_pointer_api_and_full_size_properties():
+    """BASELINE config 2 geometry (1920x1088 coded) on device memory: a few images are
+    checked bit-for-bit against the oracle, and the whole batch through size-independent
+    properties: every image's output equals its output when decoded alone (checksum of
+    checksums), the output does not depend on the batch position, and bytes beyond the
+    pitch/stride windows are untouched."""
+    torch = pytest.importorskip("torch")
+    L = capi.require_device()
+    dev = torch.device("cuda:0")
+    cols, rows, n_unique, n = 120, 68, 4, 24
+    geom = O.make_geom(cols, rows)
+    cg = to_capi(geom)
+    q = synth.quant_tables()
+    cy, cu, cv = synth.coef_batch(n_unique, cols, rows)
+    reps = n // n_unique
+    t_y = torch.from_numpy(cy).to(dev).repeat(reps)
+    t_u = torch.from_numpy(cu).to(dev).repeat(reps)
+    t_v = torch.from_numpy(cv).to(dev).repeat(reps)
+    t_q = torch.from_numpy(q.astype(np.int16)).to(dev)
+    H, W = geom.height, geom.width
+    pitch = W * 4 + 256                 # padded pitch
+    stride = pitch * H + 4096           # padded image stride
+    out = torch.full((n * stride,), 0xA5, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    ops.jpeg_recon_batch(cg, n, t_y.data_ptr(), t_u.data_ptr(), t_v.data_ptr(), t_q.data_ptr(), 0, out.data_ptr(),
+                         pitch, stride, None, 0, st)
+    torch.cuda.synchronize()
+    o = out.view(n, stride)
+    img = o[:, : pitch * H].view(n, H, pitch)
+    pix = img[:, :, : W * 4]
+    assert bool((img[:, :, W * 4:] == 0xA5).all()) and bool((o[:, pitch * H:] == 0xA5).all())
+    exp = O.oracle_jpeg_recon(geom, cy, cu, cv, q, n_images=n_unique, n_threads=4)
+    got = pix[:n_unique].cpu().numpy().reshape(n_unique, H, W, 4)
+    assert np.array_equal(got, exp)
+    sums = pix.reshape(n, -1).to(torch.int64).mul(torch.arange(1, 1 + H * W * 4, device=dev) % 251).sum(dim=1)
+    assert bool((sums.view(reps, n_unique) == sums[:n_unique]).all())
+
+
+def test_host_and_device_paths_agree_and_empty_batch():
+    L = capi.require_device()
+    geom = O.make_geom(8, 3)
+    cg = to_capi(geom)
+    assert L.ffhip_jpeg_recon_batch_host(C.byref(cg), 0, None, None, None, None, 0, None, 0, 0) == 0
+    q = synth.quant_tables()
+    cy, cu, cv = synth.coef_batch(2, 8, 3)
+    a = gpu_recon(geom, 2, cy, cu, cv, q)
+    # same data through malloc/memcpy helpers of the C ABI (no torch)
+    H, W = geom.height, geom.width
+    bufs = []
+    for arr in (cy, cu, cv, q):
+        d = L.ffhip_malloc(arr.nbytes)
+        assert d
+        capi.check(L.ffhip_memcpy_h2d(d, arr.ctypes.data, arr.nbytes, None))
+        bufs.append(d)
+    dout = L.ffhip_malloc(2 * H * W * 4)
+    st = L.ffhip_stream_create()
+    e0, e1 = L.ffhip_event_create(), L.ffhip_event_create()
+    capi.check(L.ffhip_stream_sync(None))
+    capi.check(L.ffhip_event_record(e0, st))
+    capi.check(L.ffhip_jpeg_recon_batch(C.byref(cg), 2, bufs[0], bufs[1], bufs[2], bufs[3], 0, dout, W * 4,
+                                        H * W * 4, None, 0, st))
+    capi.check(L.ffhip_event_record(e1, st))
+    assert L.ffhip_event_elapsed_ms(e0, e1) >= 0.0
+    b = np.empty_like(a)
+    capi.check(L.ffhip_memcpy_d2h(b.ctypes.data, dout, b.nbytes, st))
+    capi.check(L.ffhip_stream_sync(st))
+    assert np.array_equal(a, b)
+    for d in bufs + [dout]:
+        L.ffhip_free(d)
+    L.ffhip_event_destroy(e0); L.ffhip_event_destroy(e1); L.ffhip_stream_destroy(st)
+    # misaligned / undersized arguments are refused, not "fixed up"
+    assert L.ffhip_jpeg_recon_batch(C.byref(cg), 1, 16, 16, 16, 16, 0, 16, W * 4 - 16, 0, None, 0, None) == -22
+    assert L.ffhip_jpeg_recon_batch(C.byref(cg), 1, 8, 16, 16, 16, 0, 16, W * 4, 0, None, 0, None) == -22

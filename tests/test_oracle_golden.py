@@ -1,0 +1,191 @@
+"""CPU: the oracle (oracle/libffo.so, our C restatement) against the golden vectors
+that tests/golden/make_golden.py produced from the compiled reference.  This is what
+pins the oracle everywhere /root/reference does not exist (e.g. the GPU box)."""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import jpeg_entropy
+import oracle_lib as O
+from conftest import GOLDEN
+
+
+def test_manifest_intact():
+    for line in open(os.path.join(GOLDEN, "MANIFEST.sha256")):
+        digest, name = line.split()
+        assert hashlib.sha256(open(os.path.join(GOLDEN, name), "rb").read()).hexdigest() == digest, name
+
+
+def test_reference_test_dct_known_answers(golden, ffo):
+    """The three literal blocks of the reference's tests/test_dct.c with the outputs
+    the compiled reference gives for them."""
+    jb, vb, hb = golden("jpeg_blocks.npz"), golden("vp8_blocks.npz"), golden("hevc_dst4.npz")
+    b = jb["coef"][0].copy()
+    ffo.ffo_idct_8x8_16(b)
+    assert list(b[:8]) == [245, 243, 240, 240, 238, 236, 231, 228]
+    assert list(b[56:]) == [246, 246, 245, 239, 233, 227, 226, 225]
+    v = vb["coef"][0].copy()
+    ffo.ffo_vp8_idct_4x4(v)
+    assert list(v[:4]) == [204, -35, 41, 9]
+    o = np.zeros(16, np.int16)
+    ffo.ffo_hevc_idct_4x4_dst(hb["coef"][0].copy(), o, 8, 0)
+    assert list(o) == [12, 1, 3, 1, 0, 0, 0, 0, 3, 0, 1, 0, 2, 0, 0, 0]
+
+
+def test_jpeg_blocks(golden, ffo):
+    g = golden("jpeg_blocks.npz")
+    for i in range(g["coef"].shape[0]):
+        b = g["coef"][i].copy()
+        ffo.ffo_idct_8x8_16(b)
+        assert np.array_equal(b, g["idct"][i]), i
+        d = np.zeros(64, np.int16)
+        ffo.ffo_jpeg_dequant(d, g["coef"][i].copy(), g["quant"][i].copy(), 63)
+        assert np.array_equal(d, g["dequant"][i]), i
+
+
+def test_vp8_blocks(golden, ffo):
+    g = golden("vp8_blocks.npz")
+    for i in range(g["coef"].shape[0]):
+        b = g["coef"][i].copy()
+        ffo.ffo_vp8_idct_4x4(b)
+        assert np.array_equal(b, g["idct"][i]), i
+        wl, wf = np.zeros(256, np.int16), np.zeros(256, np.int16)
+        ffo.ffo_vp8_iwht_long(g["coef"][i].copy(), wl)
+        ffo.ffo_vp8_iwht_fast(g["coef"][i].copy(), wf)
+        assert np.array_equal(wl[::16], g["iwht_long"][i]) and np.array_equal(wf[::16], g["iwht_fast"][i]), i
+        assert not wl.reshape(16, 16)[:, 1:].any()  # only the DC slots are written
+
+
+def test_hevc_dst4(golden, ffo):
+    g = golden("hevc_dst4.npz")
+    for bd in (8, 10):
+        for epp in (0, 1):
+            exp = g[f"dst_bd{bd}_epp{epp}"]
+            for i in range(g["coef"].shape[0]):
+                o = np.zeros(16, np.int16)
+                ffo.ffo_hevc_idct_4x4_dst(g["coef"][i].copy(), o, bd, epp)
+                assert np.array_equal(o, exp[i]), (bd, epp, i)
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_hevc_scale_and_transform(golden, ffo, n):
+    g = golden("hevc_transform.npz")
+    lv, sf = g[f"level_{n}"], g[f"sfactor_{n}"]
+    for bd in (8, 10):
+        for qp in (0, 22, 37, 51):
+            for i in range(lv.shape[0]):
+                d = np.zeros(n * n, np.int16)
+                ffo.ffo_hevc_scale(lv[i].copy(), d, n, qp, bd, 0, None)
+                assert np.array_equal(d, g[f"d_{n}_bd{bd}_qp{qp}"][i]), (n, bd, qp, i)
+                d2 = np.zeros(n * n, np.int16)
+                ffo.ffo_hevc_scale(lv[i].copy(), d2, n, qp, bd, 0, sf.ctypes.data_as(C.c_void_p))
+                assert np.array_equal(d2, g[f"dsf_{n}_bd{bd}_qp{qp}"][i]), (n, bd, qp, i)
+                r = np.zeros(n * n, np.int16)
+                ffo.ffo_hevc_transform(d, r, n, 0, bd, 0)
+                assert np.array_equal(r, g[f"r_{n}_bd{bd}_qp{qp}"][i]), (n, bd, qp, i)
+
+
+def test_color_triples(golden, ffo):
+    """31 250 FMA-sensitive triples, random [0,255]^3, the IDCT overshoot domain, the
+    full wrapped int16 domain and the exact-integer-G cases."""
+    g = golden("color_triples.npz")
+    tri, exp = g["yuv"], g["bgra"]
+    out = np.zeros_like(exp)
+    for i in range(0, tri.shape[0], 64):
+        o = np.zeros(256, np.uint8)
+        ffo.ffo_yuv_to_bgra32_mcu16(o, 32, np.ascontiguousarray(tri[i:i + 64, 0]),
+                                    np.ascontiguousarray(tri[i:i + 64, 1]),
+                                    np.ascontiguousarray(tri[i:i + 64, 2]), 1, 1)
+        out[i:i + 64] = o.reshape(64, 4)
+    assert np.array_equal(out, exp)
+
+
+def test_color_mcu_layouts_and_planar(golden, ffo):
+    g = golden("color_planar.npz")
+    for (v, h) in ((1, 1), (1, 2), (2, 1), (2, 2)):
+        o = np.zeros((8 * v, 8 * h * 4), np.uint8)
+        ffo.ffo_yuv_to_bgra32_mcu16(o.reshape(-1), 8 * h * 4, g["mcu_Y"], g["mcu_U"], g["mcu_V"], v, h)
+        assert np.array_equal(o, g[f"mcu_v{v}h{h}"]), (v, h)
+    mbr, mbc = 3, 4
+    pitch = 16 * mbc * 4
+    o = np.zeros((16 * mbr, pitch), np.uint8)
+    ffo.ffo_yuv420_to_bgra32(o.reshape(-1), pitch, g["p420_y"].reshape(-1), g["p420_u"].reshape(-1),
+                             g["p420_v"].reshape(-1), 16 * mbc, 8 * mbc, mbr, mbc)
+    assert np.array_equal(o, g["p420_bgra"])
+    o = np.zeros((16 * mbr, pitch), np.uint8)
+    ffo.ffo_yuv420_to_bgra32_16bit(o.reshape(-1), pitch, g["p16_y"].reshape(-1), g["p16_u"].reshape(-1),
+                                   g["p16_v"].reshape(-1), 16 * mbc, 8 * mbc, mbr, mbc, 16)
+    assert np.array_equal(o, g["p16_bgra"])
+    o = np.zeros((16 * mbr, pitch), np.uint8)
+    ffo.ffo_yuv400_to_bgra32_16bit(o.reshape(-1), pitch, g["p16_y"].reshape(-1), 16 * mbc, mbr, mbc, 16)
+    assert np.array_equal(o, g["p400_bgra"])
+
+
+GRID_TAGS = {"420": (6, 4, 3, 2, 2), "420tail": (7, 3, 3, 2, 2), "444": (5, 3, 3, 1, 1), "422": (5, 3, 3, 2, 1),
+             "440": (5, 3, 3, 1, 2), "grey": (5, 3, 1, 1, 1)}
+
+
+@pytest.mark.parametrize("tag", list(GRID_TAGS))
+def test_jpeg_grids(golden, tag):
+    from ffpic_amd import synth
+    g = golden("jpeg_grids.npz")
+    cols, rows, nc, h, v = GRID_TAGS[tag]
+    assert list(g[f"{tag}_geom"][:5]) == [cols, rows, nc, h, v]
+    geom = O.make_geom(cols, rows, nc, h, v)
+    cy, cu, cv = synth.coef_batch(1, cols, rows, nc, h, v)
+    out = O.oracle_jpeg_recon(geom, cy, cu, cv, g["quant"])[0]
+    assert np.array_equal(out, g[f"{tag}_bgra"])
+
+
+def test_jpeg_grid_adversarial(golden):
+    g = golden("jpeg_grids.npz")
+    geom = O.make_geom(*[int(x) for x in g["adv_geom"][:5]])
+    out = O.oracle_jpeg_recon(geom, g["adv_cy"], g["adv_cu"], g["adv_cv"], g["adv_quant"])[0]
+    assert np.array_equal(out, g["adv_bgra"])
+
+
+def test_oracle_batch_threads_and_errors():
+    from ffpic_amd import synth
+    geom = O.make_geom(4, 2)
+    q = synth.quant_tables()
+    cy, cu, cv = synth.coef_batch(3, 4, 2)
+    a = O.oracle_jpeg_recon(geom, cy, cu, cv, q, n_images=3, n_threads=1)
+    b = O.oracle_jpeg_recon(geom, cy, cu, cv, q, n_images=3, n_threads=3)
+    assert np.array_equal(a, b)
+    bad = O.make_geom(4, 2, ncomp=2)
+    out = np.zeros(16, np.uint8)
+    assert O.ffo().ffo_jpeg_recon_batch(C.byref(bad), 1, cy, None, None, q, 0, out, 16, 16, 1) == -22
+    assert O.ffo().ffo_jpeg_recon_batch(C.byref(geom), 0, cy, None, None, q, 0, out, 16, 16, 1) == 0
+
+
+FILES = {"q85_420": "file_q85_420.jpg", "q92_444": "file_q92_444.jpg", "q75_422": "file_q75_422.jpg",
+         "q80_grey": "file_q80_grey.jpg"}
+
+
+def decode_fixture(tag):
+    dec = jpeg_entropy.decode(open(os.path.join(GOLDEN, FILES[tag]), "rb").read())
+    geom = O.make_geom(dec["mcu_cols"], dec["mcu_rows"], dec["ncomp"], dec["h"], dec["v"], dec["qt_id"])
+    return dec, geom
+
+
+@pytest.mark.parametrize("tag", list(FILES))
+def test_jpeg_files_config1(golden, tag):
+    """BASELINE config 1: a PIL-made baseline JPEG through the CPU path must reproduce
+    what the reference decoded from the file (sha256 for the 640x480 4:2:0 one)."""
+    g = golden("jpeg_files.npz")
+    dec, geom = decode_fixture(tag)
+    out = O.oracle_jpeg_recon(geom, dec["coef"][0], dec["coef"][1], dec["coef"][2], dec["quant"])[0]
+    H, W = [int(x) for x in g[f"{tag}_shape"][:2]]
+    out = out[:H, :W]
+    if int(g[f"{tag}_last_mcu_exact"]):
+        assert hashlib.sha256(out.tobytes()).digest() == g[f"{tag}_sha256"].tobytes()
+    else:  # reference bit-reader quirk in the final data unit; see make_golden.py
+        exp = g[f"{tag}_bgra"]
+        keep = np.ones((H, W), bool)
+        keep[(geom.mcu_rows - 1) * 8 * geom.v:, (geom.mcu_cols - 1) * 8 * geom.h:] = False
+        assert np.array_equal(out[keep], exp[keep])
+    if tag == "q85_420":
+        assert (H, W) == (480, 640) and int(g[f"{tag}_last_mcu_exact"]) == 1

@@ -1,0 +1,80 @@
+"""CPU, build container only: the oracle against the reference itself
+(oracle/_ref/libffpic_ref.so, compiled from /root/reference by oracle/Makefile) on
+fresh random inputs -- wider than the committed goldens.  Skipped where neither the
+reference sources nor a prebuilt oracle/_ref exist."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from ffpic_amd import synth
+
+pytestmark = pytest.mark.skipif(not O.have_ref(), reason="no /root/reference and no prebuilt oracle/_ref")
+
+
+@pytest.fixture(scope="module")
+def libs():
+    return O.ffo(), O.ref()
+
+
+def test_idct8x8_and_dequant_random(libs):
+    F, R = libs
+    rng = np.random.default_rng(11)
+    blocks = np.concatenate([synth.adversarial_blocks(rng, 2048), synth._blocks(rng, 2048, synth.quant_tables()[0])])
+    q = rng.integers(1, 65536, size=64).astype(np.uint16)
+    for b in blocks:
+        a, r = b.copy(), b.copy()
+        F.ffo_idct_8x8_16(a)
+        R.ref_idct_8x8_16(r)
+        assert np.array_equal(a, r)
+        da, dr = np.zeros(64, np.int16), np.zeros(64, np.int16)
+        F.ffo_jpeg_dequant(da, b.copy(), q, 63)
+        R.ref_jpeg_dequant(dr, b.copy(), q.copy(), 63)
+        assert np.array_equal(da, dr)
+
+
+def test_vp8_random(libs):
+    F, R = libs
+    rng = np.random.default_rng(12)
+    for b in rng.integers(-32768, 32768, size=(4096, 16)).astype(np.int16):
+        a, r = b.copy(), b.copy()
+        F.ffo_vp8_idct_4x4(a)
+        R.ref_vp8_idct_4x4(r)
+        assert np.array_equal(a, r)
+        wa, wr = np.zeros(256, np.int16), np.zeros(256, np.int16)
+        F.ffo_vp8_iwht_long(b.copy(), wa)
+        R.ref_vp8_iwht_long(b.copy(), wr)
+        assert np.array_equal(wa, wr)
+
+
+def test_hevc_random(libs):
+    F, R = libs
+    rng = np.random.default_rng(13)
+    for b in rng.integers(-32768, 32768, size=(1024, 16)).astype(np.int16):
+        for bd, epp in ((8, 0), (10, 0), (12, 1)):
+            a, r = np.zeros(16, np.int16), np.zeros(16, np.int16)
+            F.ffo_hevc_idct_4x4_dst(b.copy(), a, bd, epp)
+            R.idct_4x4_hevc(b.copy(), r, bd, bool(epp))
+            assert np.array_equal(a, r)
+    for n in (4, 8, 16, 32):
+        for _ in range(24):
+            lv = rng.integers(-32768, 32768, size=n * n).astype(np.int16) if rng.random() < 0.3 else \
+                np.rint(rng.laplace(0, 8, size=n * n)).astype(np.int16)
+            qp, bd = int(rng.integers(0, 52)), int(rng.choice([8, 10]))
+            da, dr = np.zeros(n * n, np.int16), np.zeros(n * n, np.int16)
+            F.ffo_hevc_scale(lv.copy(), da, n, qp, bd, 0, None)
+            R.ref_hevc_scale(lv.copy(), dr, n, qp, bd, 0, None, 0)
+            assert np.array_equal(da, dr)
+            ra, rr = np.zeros(n * n, np.int16), np.zeros(n * n, np.int16)
+            F.ffo_hevc_transform(da.copy(), ra, n, 0, bd, 0)
+            R.ref_hevc_transform(dr.copy(), rr, n, 0, bd, 0)
+            assert np.array_equal(ra, rr)
+
+
+@pytest.mark.parametrize("nc,h,v", [(3, 2, 2), (3, 1, 1), (3, 2, 1), (3, 1, 2), (1, 1, 1)])
+def test_jpeg_grid_random(libs, nc, h, v):
+    q = synth.quant_tables(60)
+    g = O.make_geom(9, 5, nc, h, v)
+    cy, cu, cv = synth.coef_batch(1, 9, 5, nc, h, v, quant=q, first=100)
+    assert np.array_equal(O.oracle_jpeg_recon(g, cy, cu, cv, q)[0], O.ref_jpeg_recon(g, cy, cu, cv, q))

@@ -79,6 +79,12 @@ __device__ __forceinline__ void idct8_1d(u32 e0, u32 e1, u32 o0, u32 o1, int rnd
     out[3] = E3 + O3; out[4] = E3 - O3;
 }
 
+__device__ __forceinline__ u32 pk_mul16(u32 a, u32 b)
+{
+    using u16x2 = unsigned short __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(u32, (u16x2)(__builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b)));
+}
+
 /* byte offset of row `u` of block `b` in the 8-block work tile; blocks 2,3,6,7
  * keep their even/odd rows swapped so the transposing reads are conflict-free */
 __device__ __forceinline__ u32 tile_off(u32 b, u32 u) { return b * 128u + ((u ^ ((b >> 1) & 1u)) << 4); }
@@ -120,9 +126,8 @@ __device__ __forceinline__ void idct8x8_round(const WaveCtx &c, u32x4 raw, u32x4
     u32x4 dq;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        using u16x2 = unsigned short __attribute__((ext_vector_type(2)));
-        u16x2 a = __builtin_bit_cast(u16x2, raw[i]), b = __builtin_bit_cast(u16x2, quant[i]);
-        dq[i] = __builtin_bit_cast(u32, (u16x2)(a * b));
+        const u32 a = raw[i], b = quant[i]; /* scalars first: bit_cast of a vector element lvalue miscompiles */
+        dq[i] = pk_mul16(a, b);
     }
     *(u32x4 *)(c.lds + LDS_W + c.wr_off) = dq;                 /* stage A: [block][row u][x] */
     u32x2 ev = lds_tr_read(c, c.tr_even), od = lds_tr_read(c, c.tr_odd);

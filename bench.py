@@ -165,24 +165,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-
-    # parity spot check on this rank's first image (outside the timed region)
+    # parity spot check on this rank's first image, before warmup (outside the timed region;
+    # the CPU-side check idles the GPU, so it must not sit between warmup and timing)
     parity = None
+    step()
+    torch.cuda.synchronize()
     if rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
-        if a.warmup == 0:
-            step()
-            torch.cuda.synchronize()
         mcus = cols * rows
         exp = O.oracle_jpeg_recon(O.make_geom(cols, rows), t_y[:mcus * 256].cpu().numpy(),
                                   t_u[:mcus * 64].cpu().numpy(), t_v[:mcus * 64].cpu().numpy(), q)[0]
         parity = bool(np.array_equal(out[:stride].cpu().numpy().reshape(H, W, 4), exp))
+    shard.gather_status(first, n, 0, device=dev)   # warm the collective / small-copy path too
 
     ev0, ev1 = L.ffhip_event_create(), L.ffhip_event_create()
+    barrier()
+    for _ in range(a.warmup):      # W untimed warmup steps, immediately before the timed K
+        step()
     barrier()
     t0 = time.perf_counter()
     capi.check(L.ffhip_event_record(ev0, stream))

@@ -119,8 +119,9 @@ __device__ __forceinline__ u32x2 lds_tr_read(const WaveCtx &c, u32 off)
 
 /* Dequantise + 2-D IDCT of 8 blocks held one row per lane (lane = 8*block+row).
  * raw/quant: the lane's 8 coefficients / quant factors as packed int16 pairs.
- * Returns in out[0..7] the samples of row c.idx of block c.blk (values 0..8191). */
-__device__ __forceinline__ void idct8x8_round(const WaveCtx &c, u32x4 raw, u32x4 quant, int out[8])
+ * Returns the 8 samples of row c.idx of block c.blk (values 0..8191) as packed
+ * int16 pairs (s0,s1),(s2,s3),(s4,s5),(s6,s7). */
+__device__ __forceinline__ u32x4 idct8x8_round(const WaveCtx &c, u32x4 raw, u32x4 quant)
 {
     /* dequant: low 16 bits of the product = the int16 store of jpg.c:251 */
     u32x4 dq;
@@ -136,18 +137,24 @@ __device__ __forceinline__ void idct8x8_round(const WaveCtx &c, u32x4 raw, u32x4
     u32x4 pk;                                                  /* (v >> 11) stored to int16, idct.c:522 */
 #pragma unroll
     for (int i = 0; i < 4; i++)
-        pk[i] = (((u32)col[2 * i] >> 11) & 0xffffu) | (((u32)col[2 * i + 1] >> 11) << 16);
+        pk[i] = __builtin_amdgcn_perm((u32)col[2 * i + 1] << 5, (u32)col[2 * i] << 5, 0x07060302u);
     *(u32x4 *)(c.lds + LDS_W + tile_off(c.blk, c.idx)) = pk;   /* stage B: [block][col x][y] */
     ev = lds_tr_read(c, c.tr_even);
     od = lds_tr_read(c, c.tr_odd);
+    int out[8];
     idct8_1d(ev[0], ev[1], od[0], od[1], 257 << 17, out);      /* row y = c.idx, all x */
-    /* clamp((v >> 18), 0, 65535): v >> 18 is in [-8192, 8191] so only the lower
-     * clamp can act and the int16 store never wraps (idct.c:531) */
+    /* clamp((v >> 18), 0, 65535): v >> 18 is in [-8192, 8191] so only the lower clamp can
+     * act and the int16 store never wraps (idct.c:531).  Done two samples at a time on
+     * the high halves: (v >> 16) as int16, >> 2, max 0. */
+    u32x4 res;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        int s = out[i] >> 18;
-        out[i] = s < 0 ? 0 : s;
+    for (int i = 0; i < 4; i++) {
+        const u32 hi2 = __builtin_amdgcn_perm((u32)out[2 * i + 1], (u32)out[2 * i], 0x07060302u);
+        s16x2 v = __builtin_bit_cast(s16x2, hi2) >> 2;
+        v = __builtin_elementwise_max(v, (s16x2){0, 0});
+        res[i] = __builtin_bit_cast(u32, v);
     }
+    return res;
 }
 
 __device__ __forceinline__ u32 sat_pk_u8_i16(u32 v)
@@ -181,103 +188,118 @@ struct JpegBatch {
     int qt_y, qt_u, qt_v;
 };
 
+/* exact floor((x)/d) for the small non-negative ranges of the chroma terms:
+ * (int)((float)(2x+1) * fl(1/(2d))) -- verified exhaustively for d = 25, 125,
+ * 1000 over the ranges used below (tests/test_color_forms.py) */
+__device__ __forceinline__ int fdiv_f32(int two_x_plus_1, float inv_2d)
+{
+    return (int)((float)two_x_plus_1 * inv_2d);
+}
+
 /* ------------------------------------------------------------------------
  * Fused kernel, 3 components, h = v = 2.
  * ---------------------------------------------------------------------- */
 __global__ __launch_bounds__(WG_THREADS) void k_jpeg420_fused(JpegBatch p)
 {
     __shared__ __attribute__((aligned(16))) char lds_all[WAVES_PER_WG * LDS_WAVE_BYTES];
-    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 lane = threadIdx.x & 63;
+    /* wave-uniform values are forced into SGPRs: hipcc cannot prove that anything
+     * derived from threadIdx is uniform and would run all the index math per lane */
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveCtx c;
     wave_ctx_init(c, lds_all + wave * LDS_WAVE_BYTES, lane);
 
-    const long long quads_per_image = (long long)p.quads_per_row * p.mcu_rows;
-    const long long total = quads_per_image * p.n_images;
-    const long long n_waves = (long long)gridDim.x * WAVES_PER_WG;
-    const long long mcus_per_image = (long long)p.mcu_cols * p.mcu_rows;
+    /* One quad per wave, one workgroup per 4 consecutive quads of an MCU row:
+     * blockIdx = (quad group, MCU row, image).  A short-lived wave issues all its loads
+     * up front and never waits on its own earlier stores (vmcnt is in-order), which
+     * streams measurably faster on MI355X than a persistent grid-stride loop
+     * (tests/tools/membench.hip: 6.2-6.5 TB/s vs 4.7-5.3 TB/s for a 16 B/lane copy). */
+    const int rows = p.mcu_rows, last = p.mcu_cols - 1;
+    const int qcol = (int)(blockIdx.x * WAVES_PER_WG + wave), mrow = (int)blockIdx.y, img = (int)blockIdx.z;
+    if (qcol >= p.quads_per_row) return; /* wave-uniform; no barriers anywhere in this kernel */
 
-    const u32 row = lane & 7, lblk = lane >> 3; /* load role: block lblk of the round, row `row` */
-    int cur_img = -1;
-    u32x4 q_y, q_c;
-
-    for (long long q = (long long)blockIdx.x * WAVES_PER_WG + wave; q < total; q += n_waves) {
-        const int img = (int)(q / quads_per_image);
-        const int rem = (int)(q - (long long)img * quads_per_image);
-        const int mrow = rem / p.quads_per_row;
-        const int mcu0 = (rem - mrow * p.quads_per_row) * 4;
-
-        if (img != cur_img) { /* wave-uniform */
-            cur_img = img;
-            const uint16_t *qt = p.quant + (long long)img * p.quant_stride;
-            q_y = *(const u32x4 *)(qt + p.qt_y * 64 + row * 8);
-            q_c = *(const u32x4 *)(qt + (lane < 32 ? p.qt_u : p.qt_v) * 64 + row * 8);
-        }
+    /* per-lane roles */
+    const u32 row = lane & 7, lblk = lane >> 3;       /* load: block lblk of the round, row `row` */
+    const u32 ld_c = (lblk & 3) * 128 + row * 16;     /* chroma: byte offset of (MCU lblk&3, row)  */
+    const u32 ld_y = lblk * 128 + row * 16;           /* luma: 8 consecutive blocks                 */
+    const u32 st_lane = (lane >> 3) * (u32)p.pitch + (lane & 7) * 16; /* store: 8 lanes = one 128-B row piece */
+    /* chroma entry role: e = lane = j*8 + m*2 + hf */
+    const u32 ce_rd = (((lane >> 1) & 3) * 8 + (lane >> 3)) * 16 + (lane & 1) * 8;
+    {
+        const int mcu0 = qcol * 4;
+        const uint16_t *qt = p.quant + (long long)img * p.quant_stride;
+        const u32x4 q_y = *(const u32x4 *)(qt + p.qt_y * 64 + row * 8);
+        const u32x4 q_c = *(const u32x4 *)(qt + (lane < 32 ? p.qt_u : p.qt_v) * 64 + row * 8);
 
         /* ---- global loads: one block row (16 B) per lane per round ---- */
-        const long long mcu_base = (long long)img * mcus_per_image + (long long)mrow * p.mcu_cols;
-        const int last = p.mcu_cols - 1;
-        int mc = mcu0 + (int)(lblk & 3);
-        mc = mc > last ? last : mc;
-        const int16_t *cplane = lane < 32 ? p.coef_u : p.coef_v;
-        const u32x4 raw_c = *(const u32x4 *)(cplane + (mcu_base + mc) * 64 + row * 8);
-        int my0 = mcu0 + (int)(lblk >> 2), my1 = my0 + 2;
-        my0 = my0 > last ? last : my0;
-        my1 = my1 > last ? last : my1;
-        const u32x4 raw_y0 = *(const u32x4 *)(p.coef_y + ((mcu_base + my0) * 4 + (lblk & 3)) * 64 + row * 8);
-        const u32x4 raw_y1 = *(const u32x4 *)(p.coef_y + ((mcu_base + my1) * 4 + (lblk & 3)) * 64 + row * 8);
+        const long long mcu_base = ((long long)img * rows + mrow) * p.mcu_cols + mcu0; /* scalar */
+        const bool full = mcu0 + 3 <= last;                                          /* scalar */
+        u32 oc = ld_c, oy0 = ld_y, oy1 = ld_y + 1024;
+        if (!full) { /* ragged right edge: clamp to the last MCU (stores are masked below) */
+            const int rem = last - mcu0; /* 0..2 */
+            int mc = (int)(lblk & 3); mc = mc > rem ? rem : mc;
+            int m0 = (int)(lblk >> 2), m1 = m0 + 2;
+            m0 = m0 > rem ? rem : m0; m1 = m1 > rem ? rem : m1;
+            oc = (u32)mc * 128 + row * 16;
+            oy0 = ((u32)m0 * 4 + (lblk & 3)) * 128 + row * 16;
+            oy1 = ((u32)m1 * 4 + (lblk & 3)) * 128 + row * 16;
+        }
+        const char *bu = (const char *)(p.coef_u + mcu_base * 64);
+        const char *bv = (const char *)(p.coef_v + mcu_base * 64);
+        const char *by = (const char *)(p.coef_y + mcu_base * 256);
+        const u32x4 raw_c = *(const u32x4 *)((lane < 32 ? bu : bv) + oc);
+        const u32x4 raw_y0 = *(const u32x4 *)(by + oy0);
+        const u32x4 raw_y1 = *(const u32x4 *)(by + oy1);
 
-        int s[8];
         /* ---- chroma round: blocks 0-3 = U of MCU 0-3, blocks 4-7 = V ---- */
-        idct8x8_round(c, raw_c, q_c, s);
         {
+            const u32x4 pk = idct8x8_round(c, raw_c, q_c);
             /* samples -> work tile [block][row][8 x int16]; then each lane picks up
-             * U and V of 4 adjacent chroma columns of one chroma row */
-            u32x4 pk;
-#pragma unroll
-            for (int i = 0; i < 4; i++) pk[i] = (u32)s[2 * i] | ((u32)s[2 * i + 1] << 16);
+             * U and V of 4 adjacent chroma columns of one chroma row:
+             * entry e = lane = j*8 + m*2 + hf  (chroma row j, MCU m, column half hf) */
             *(u32x4 *)(c.lds + LDS_W + (c.blk * 8 + c.idx) * 16) = pk;
-            /* entry e = j*8 + m*2 + hf  (chroma row j, MCU m, column half hf) */
-            const u32 e = lane, j = e >> 3, m = (e >> 1) & 3, hf = e & 1;
-            const u32x2 us = *(const u32x2 *)(c.lds + LDS_W + (m * 8 + j) * 16 + hf * 8);
-            const u32x2 vs = *(const u32x2 *)(c.lds + LDS_W + 512 + (m * 8 + j) * 16 + hf * 8);
+            const u32x2 us = *(const u32x2 *)(c.lds + LDS_W + ce_rd);
+            const u32x2 vs = *(const u32x2 *)(c.lds + LDS_W + 512 + ce_rd);
             u32x4 tr, tg, tb, uv;
             u32 mask = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int uu = (int)((us[k >> 1] >> ((k & 1) * 16)) & 0xffffu) - 128; /* colorspace.c:149 */
-                const int vv = (int)((vs[k >> 1] >> ((k & 1) * 16)) & 0xffffu) - 128;
-                const u32 fr = (u32)(32 * vv + 25 * 164) / 25u - 164u;       /* floor(32 vv / 25)   */
-                const u32 fb = (u32)(266 * uu + 125 * 273) / 125u - 273u;    /* floor(266 uu / 125) */
+                const u32 uw = us[k >> 1], vw = vs[k >> 1];
+                const int uu = (int)((k & 1) ? (uw >> 16) : (uw & 0xffffu)) - 128; /* colorspace.c:149 */
+                const int vv = (int)((k & 1) ? (vw >> 16) : (vw & 0xffffu)) - 128;
+                /* floor(32 vv/25), floor(266 uu/125), floor(-(215 uu + 381 vv)/1000), each
+                 * biased to a non-negative numerator x and evaluated as fdiv(2x+1) */
+                const int fr = fdiv_f32(64 * vv + (2 * 25 * 164 + 1), 1.0f / 50.0f) - 164;
+                const int fb = fdiv_f32(532 * uu + (2 * 125 * 273 + 1), 1.0f / 250.0f) - 273;
                 const int sgm = 215 * uu + 381 * vv;
-                const u32 t = (u32)(4806000 - sgm);
-                const u32 tq = t / 1000u;
-                const u32 fg = tq - 4806u;                                   /* floor(-s / 1000)    */
-                if (t - tq * 1000u == 0 && sgm != 0) mask |= 1u << k;
-                tr[k] = (fr & 0xffffu) * 0x10001u;
-                tg[k] = (fg & 0xffffu) * 0x10001u;
-                tb[k] = (fb & 0xffffu) * 0x10001u;
-                uv[k] = PK16(uu, vv);
+                const int t = 4806000 - sgm;
+                const int tq = fdiv_f32(2 * t + 1, 1.0f / 2000.0f);
+                const int fg = tq - 4806;
+                if (t - tq * 1000 == 0 && sgm != 0) mask |= 1u << k; /* exact-integer G: fp64 decides */
+                tr[k] = __builtin_amdgcn_perm((u32)fr, (u32)fr, 0x01000100u);
+                tg[k] = __builtin_amdgcn_perm((u32)fg, (u32)fg, 0x01000100u);
+                tb[k] = __builtin_amdgcn_perm((u32)fb, (u32)fb, 0x01000100u);
+                uv[k] = __builtin_amdgcn_perm((u32)vv, (u32)uu, 0x05040100u);
             }
-            *(u32x4 *)(c.lds + LDS_TR + e * 16) = tr;
-            *(u32x4 *)(c.lds + LDS_TG + e * 16) = tg;
-            *(u32x4 *)(c.lds + LDS_TB + e * 16) = tb;
-            *(u32x4 *)(c.lds + LDS_UV + e * 16) = uv;
-            *(u32 *)(c.lds + LDS_FL + e * 4) = mask;
+            *(u32x4 *)(c.lds + LDS_TR + lane * 16) = tr;
+            *(u32x4 *)(c.lds + LDS_TG + lane * 16) = tg;
+            *(u32x4 *)(c.lds + LDS_TB + lane * 16) = tb;
+            *(u32x4 *)(c.lds + LDS_UV + lane * 16) = uv;
+            *(u32 *)(c.lds + LDS_FL + lane * 4) = mask;
         }
 
+        uint8_t *const orow = p.bgra + (long long)img * p.image_stride + (long long)mrow * 16 * p.pitch +
+                              (long long)mcu0 * 64; /* scalar */
         /* ---- two luma rounds: MCU 0-1 then MCU 2-3 of the quad ---- */
 #pragma unroll
         for (int rnd = 0; rnd < 2; rnd++) {
-            idct8x8_round(c, rnd ? raw_y1 : raw_y0, q_y, s);
             /* stage C: 16 pixel rows x 32 px of int16, 64 B per row, 16-B chunks
              * XOR-swizzled by (row>>1)&3 so that both the writes here and the
              * output-order reads below are bank-conflict free */
             {
+                const u32x4 pk = idct8x8_round(c, rnd ? raw_y1 : raw_y0, q_y);
                 const u32 mloc = c.blk >> 2, vi = (c.blk >> 1) & 1, hi = c.blk & 1;
                 const u32 prow = vi * 8 + c.idx, chunk = mloc * 2 + hi;
-                u32x4 pk;
-#pragma unroll
-                for (int i = 0; i < 4; i++) pk[i] = (u32)s[2 * i] | ((u32)s[2 * i + 1] << 16);
                 *(u32x4 *)(c.lds + LDS_W + prow * 64 + ((chunk ^ ((prow >> 1) & 3)) << 4)) = pk;
             }
 #pragma unroll
@@ -296,9 +318,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg420_fused(JpegBatch p)
                 u32x4 px;
 #pragma unroll
                 for (int h2 = 0; h2 < 2; h2++) {
-                    const u32 r2 = sat_pk_u8_i16(pk_add16(yy[h2], tr[h2]));
-                    const u32 g2 = sat_pk_u8_i16(pk_add16(yy[h2], tg[h2]));
-                    const u32 b2 = sat_pk_u8_i16(pk_add16(yy[h2], tb[h2]));
+                    const u32 y2 = yy[h2];
+                    const u32 r2 = sat_pk_u8_i16(pk_add16(y2, tr[h2]));
+                    const u32 g2 = sat_pk_u8_i16(pk_add16(y2, tg[h2]));
+                    const u32 b2 = sat_pk_u8_i16(pk_add16(y2, tb[h2]));
                     const u32 bg = __builtin_amdgcn_perm(g2, b2, 0x05010400u); /* b0 g0 b1 g1 */
                     px[2 * h2] = __builtin_amdgcn_perm(r2, bg, 0x0d040100u);     /* b0 g0 r0 ff */
                     px[2 * h2 + 1] = __builtin_amdgcn_perm(r2, bg, 0x0d050302u); /* b1 g1 r1 ff */
@@ -308,21 +331,19 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg420_fused(JpegBatch p)
 #pragma unroll
                     for (int h2 = 0; h2 < 2; h2++)
                         if (fl & (1u << h2)) {
-                            const int uu = (int)(short)(uvp[h2] & 0xffffu), vv = (int)(short)(uvp[h2] >> 16);
-                            const u32 g0 = green_fp64((int)(yy[h2] & 0xffffu), uu, vv);
-                            const u32 g1 = green_fp64((int)(yy[h2] >> 16), uu, vv);
+                            const u32 uvw = uvp[h2], y2 = yy[h2];
+                            const int uu = (int)(short)(uvw & 0xffffu), vv = (int)(short)(uvw >> 16);
+                            const u32 g0 = green_fp64((int)(y2 & 0xffffu), uu, vv);
+                            const u32 g1 = green_fp64((int)(y2 >> 16), uu, vv);
                             px[2 * h2] = (px[2 * h2] & 0xffff00ffu) | (g0 << 8);
                             px[2 * h2 + 1] = (px[2 * h2 + 1] & 0xffff00ffu) | (g1 << 8);
                         }
                 }
-                const int mcol = mcu0 + (int)m;
-                if (mcol <= last) {
-                    uint8_t *dst = p.bgra + (long long)img * p.image_stride +
-                                   ((long long)mrow * 16 + prow) * p.pitch + (long long)mcol * 64 + (cg & 3) * 16;
-                    *(u32x4 *)dst = px;
-                }
+                if (full || mcu0 + (int)m <= last)
+                    *(u32x4 *)(orow + (long long)k * 8 * p.pitch + rnd * 128 + st_lane) = px;
             }
         }
+
     }
 }
 
@@ -353,15 +374,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_idct_planes(IdctPlanes p)
         const long long img = b / p.blocks_per_image;
         const u32x4 quant = *(const u32x4 *)(p.quant + img * p.quant_stride + p.qt * 64 + (lane & 7) * 8);
         const u32x4 raw = *(const u32x4 *)(p.coef + b * 64 + (lane & 7) * 8);
-        int s[8];
-        idct8x8_round(c, raw, quant, s);
+        const u32x4 pk = idct8x8_round(c, raw, quant);
         const long long ob = r * 8 + c.blk;
-        if (ob < p.total_blocks) {
-            u32x4 pk;
-#pragma unroll
-            for (int i = 0; i < 4; i++) pk[i] = (u32)s[2 * i] | ((u32)s[2 * i + 1] << 16);
-            *(u32x4 *)(p.samples + ob * 64 + c.idx * 8) = pk;
-        }
+        if (ob < p.total_blocks) *(u32x4 *)(p.samples + ob * 64 + c.idx * 8) = pk;
     }
 }
 
@@ -478,9 +493,22 @@ extern "C" int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *g, int n_images, co
         p.quads_per_row = (g->mcu_cols + 3) / 4; p.n_images = n_images;
         p.qt_y = g->qt_id[0]; p.qt_u = g->qt_id[1]; p.qt_v = g->qt_id[2];
         long long quads = (long long)p.quads_per_row * p.mcu_rows * n_images;
-        int grid = grid_for((quads + WAVES_PER_WG - 1) / WAVES_PER_WG);
-        hipLaunchKernelGGL(k_jpeg420_fused, dim3(grid), dim3(WG_THREADS), 0, st, p);
-        FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
+        if (quads > 0x7fffffffLL || pitch * 16 > 0x7fffffffLL || g->mcu_rows > 65535) return FFHIP_EINVAL;
+        const dim3 grid((p.quads_per_row + WAVES_PER_WG - 1) / WAVES_PER_WG, p.mcu_rows, 1);
+        /* grid.z carries the image index (<= 65535 per launch) */
+        for (int first = 0; first < n_images; first += 65535) {
+            const int cnt = n_images - first < 65535 ? n_images - first : 65535;
+            JpegBatch q = p;
+            const long long mcus = (long long)g->mcu_cols * g->mcu_rows;
+            q.coef_y += (long long)first * mcus * 256;
+            q.coef_u += (long long)first * mcus * 64;
+            q.coef_v += (long long)first * mcus * 64;
+            q.quant += (long long)first * quant_stride;
+            q.bgra += (long long)first * image_stride;
+            q.n_images = cnt;
+            hipLaunchKernelGGL(k_jpeg420_fused, dim3(grid.x, grid.y, cnt), dim3(WG_THREADS), 0, st, q);
+            FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
+        }
         return FFHIP_OK;
     }
 

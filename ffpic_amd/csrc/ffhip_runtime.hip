@@ -126,12 +126,13 @@ extern "C" float ffhip_event_elapsed_ms(void *start, void *stop)
     return ms;
 }
 
-/* 16 B per lane grid-stride copy: the achievable-HBM yardstick the fused kernel is
- * compared with in the same process (bench.py). */
+/* 16 B per lane copy, one element per thread (no loop): the launch shape that streams
+ * fastest on MI355X (tests/tools/membench.hip).  The achievable-HBM yardstick the fused
+ * kernel is compared with in the same process (bench.py). */
 __global__ __launch_bounds__(256) void k_copy_calibrate(u32x4 *dst, const u32x4 *src, size_t n16)
 {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
-        dst[i] = src[i];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
 }
 
 extern "C" int ffhip_copy_calibrate(void *d_dst, const void *d_src, size_t bytes, void *stream)
@@ -140,10 +141,9 @@ extern "C" int ffhip_copy_calibrate(void *d_dst, const void *d_src, size_t bytes
     if (!ffhip_have_device()) return FFHIP_ENODEV;
     size_t n16 = bytes / 16;
     if (!n16) return FFHIP_OK;
-    size_t want = (n16 + 255) / 256;
-    int grid = (int)(want < 2048 ? want : 2048);
-    hipLaunchKernelGGL(k_copy_calibrate, dim3(grid), dim3(256), 0, (hipStream_t)stream, (u32x4 *)d_dst,
-                       (const u32x4 *)d_src, n16);
+    if (n16 > (size_t)0x7fffffff * 256) return FFHIP_EINVAL;
+    hipLaunchKernelGGL(k_copy_calibrate, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (u32x4 *)d_dst, (const u32x4 *)d_src, n16);
     FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
     return FFHIP_OK;
 }

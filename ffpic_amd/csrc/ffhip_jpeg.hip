@@ -37,8 +37,10 @@
 #include "ffhip_internal.h"
 
 #include <errno.h>
+#include <stdlib.h>
 
 #define WAVES_PER_WG 4
+#define FFHIP_JPEG_DEFAULT_VARIANT 13 /* <quads per wave><nt bits> */
 #define WG_THREADS (64 * WAVES_PER_WG)
 
 /* per-wave LDS layout (bytes) */
@@ -199,6 +201,162 @@ __device__ __forceinline__ int fdiv_f32(int two_x_plus_1, float inv_2d)
 /* ------------------------------------------------------------------------
  * Fused kernel, 3 components, h = v = 2.
  * ---------------------------------------------------------------------- */
+
+/* per-lane, quad-independent roles */
+struct LaneRoles {
+    u32 row, lblk;   /* load: block lblk of the round, row `row`                  */
+    u32 st_lane;     /* store: 8 lanes = one 128-B piece of an output row          */
+    u32 ce_rd;       /* chroma entry role: e = lane = j*8 + m*2 + hf               */
+};
+
+struct QuadLoads {
+    u32x4 c, y0, y1;
+};
+
+template <int NT>
+__device__ __forceinline__ u32x4 load16(const char *p)
+{
+    return NT ? __builtin_nontemporal_load((const u32x4 *)p) : *(const u32x4 *)p;
+}
+
+/* issue the three 16-B-per-lane loads of one quad (chroma round, luma MCU 0-1, luma MCU 2-3) */
+template <int NT>
+__device__ __forceinline__ QuadLoads quad_load(const JpegBatch &p, const LaneRoles &r, u32 lane, int img, int mrow,
+                                               int mcu0)
+{
+    const int last = p.mcu_cols - 1;
+    const long long mcu_base = ((long long)img * p.mcu_rows + mrow) * p.mcu_cols + mcu0; /* scalar */
+    u32 oc = (r.lblk & 3) * 128 + r.row * 16, oy0 = r.lblk * 128 + r.row * 16, oy1 = oy0 + 1024;
+    if (mcu0 + 3 > last) { /* ragged right edge: clamp to the last MCU (stores are masked) */
+        const int rem = last - mcu0; /* 0..2 */
+        int mc = (int)(r.lblk & 3); mc = mc > rem ? rem : mc;
+        int m0 = (int)(r.lblk >> 2), m1 = m0 + 2;
+        m0 = m0 > rem ? rem : m0; m1 = m1 > rem ? rem : m1;
+        oc = (u32)mc * 128 + r.row * 16;
+        oy0 = ((u32)m0 * 4 + (r.lblk & 3)) * 128 + r.row * 16;
+        oy1 = ((u32)m1 * 4 + (r.lblk & 3)) * 128 + r.row * 16;
+    }
+    const char *bu = (const char *)(p.coef_u + mcu_base * 64);
+    const char *bv = (const char *)(p.coef_v + mcu_base * 64);
+    const char *by = (const char *)(p.coef_y + mcu_base * 256);
+    QuadLoads q;
+    q.c = load16<NT>((lane < 32 ? bu : bv) + oc);
+    q.y0 = load16<NT>(by + oy0);
+    q.y1 = load16<NT>(by + oy1);
+    return q;
+}
+
+/* reconstruct one quad (64x16 pixels) from its loaded coefficients and store it */
+template <int NT>
+__device__ __forceinline__ void quad_recon(const JpegBatch &p, const WaveCtx &c, const LaneRoles &r, u32 lane,
+                                           const QuadLoads &ld, u32x4 q_y, u32x4 q_c, int img, int mrow, int mcu0)
+{
+    const int last = p.mcu_cols - 1;
+    const bool full = mcu0 + 3 <= last; /* scalar */
+    /* ---- chroma round: blocks 0-3 = U of MCU 0-3, blocks 4-7 = V ---- */
+    {
+        const u32x4 pk = idct8x8_round(c, ld.c, q_c);
+        /* samples -> work tile [block][row][8 x int16]; then each lane picks up
+         * U and V of 4 adjacent chroma columns of one chroma row:
+         * entry e = lane = j*8 + m*2 + hf  (chroma row j, MCU m, column half hf) */
+        *(u32x4 *)(c.lds + LDS_W + (c.blk * 8 + c.idx) * 16) = pk;
+        const u32x2 us = *(const u32x2 *)(c.lds + LDS_W + r.ce_rd);
+        const u32x2 vs = *(const u32x2 *)(c.lds + LDS_W + 512 + r.ce_rd);
+        u32x4 tr, tg, tb, uv;
+        u32 mask = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 uw = us[k >> 1], vw = vs[k >> 1];
+            const int uu = (int)((k & 1) ? (uw >> 16) : (uw & 0xffffu)) - 128; /* colorspace.c:149 */
+            const int vv = (int)((k & 1) ? (vw >> 16) : (vw & 0xffffu)) - 128;
+            /* floor(32 vv/25), floor(266 uu/125), floor(-(215 uu + 381 vv)/1000), each
+             * biased to a non-negative numerator x and evaluated as fdiv(2x+1) */
+            const int fr = fdiv_f32(64 * vv + (2 * 25 * 164 + 1), 1.0f / 50.0f) - 164;
+            const int fb = fdiv_f32(532 * uu + (2 * 125 * 273 + 1), 1.0f / 250.0f) - 273;
+            const int sgm = 215 * uu + 381 * vv;
+            const int t = 4806000 - sgm;
+            const int tq = fdiv_f32(2 * t + 1, 1.0f / 2000.0f);
+            const int fg = tq - 4806;
+            if (t - tq * 1000 == 0 && sgm != 0) mask |= 1u << k; /* exact-integer G: fp64 decides */
+            tr[k] = __builtin_amdgcn_perm((u32)fr, (u32)fr, 0x01000100u);
+            tg[k] = __builtin_amdgcn_perm((u32)fg, (u32)fg, 0x01000100u);
+            tb[k] = __builtin_amdgcn_perm((u32)fb, (u32)fb, 0x01000100u);
+            uv[k] = __builtin_amdgcn_perm((u32)vv, (u32)uu, 0x05040100u);
+        }
+        *(u32x4 *)(c.lds + LDS_TR + lane * 16) = tr;
+        *(u32x4 *)(c.lds + LDS_TG + lane * 16) = tg;
+        *(u32x4 *)(c.lds + LDS_TB + lane * 16) = tb;
+        *(u32x4 *)(c.lds + LDS_UV + lane * 16) = uv;
+        *(u32 *)(c.lds + LDS_FL + lane * 4) = mask;
+    }
+
+    uint8_t *const orow = p.bgra + (long long)img * p.image_stride + (long long)mrow * 16 * p.pitch +
+                          (long long)mcu0 * 64; /* scalar */
+    /* ---- two luma rounds: MCU 0-1 then MCU 2-3 of the quad ---- */
+#pragma unroll
+    for (int rnd = 0; rnd < 2; rnd++) {
+        /* stage C: 16 pixel rows x 32 px of int16, 64 B per row, 16-B chunks
+         * XOR-swizzled by (row>>1)&3 so that both the writes here and the
+         * output-order reads below are bank-conflict free */
+        {
+            const u32x4 pk = idct8x8_round(c, rnd ? ld.y1 : ld.y0, q_y);
+            const u32 mloc = c.blk >> 2, vi = (c.blk >> 1) & 1, hi = c.blk & 1;
+            const u32 prow = vi * 8 + c.idx, chunk = mloc * 2 + hi;
+            *(u32x4 *)(c.lds + LDS_W + prow * 64 + ((chunk ^ ((prow >> 1) & 3)) << 4)) = pk;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            /* output role: 8 lanes cover one 32-px row segment (128 B) */
+            const u32 prow = 8 * k + (lane >> 3), cg = lane & 7;
+            const u32 chunk = cg >> 1;
+            const u32x2 yy = *(const u32x2 *)(c.lds + LDS_W + prow * 64 +
+                                              ((chunk ^ ((prow >> 1) & 3)) << 4) + (cg & 1) * 8);
+            const u32 m = 2 * rnd + (cg >> 2), hf = (cg >> 1) & 1, pp = cg & 1;
+            const u32 e = (prow >> 1) * 8 + m * 2 + hf;
+            const u32x2 tr = *(const u32x2 *)(c.lds + LDS_TR + e * 16 + pp * 8);
+            const u32x2 tg = *(const u32x2 *)(c.lds + LDS_TG + e * 16 + pp * 8);
+            const u32x2 tb = *(const u32x2 *)(c.lds + LDS_TB + e * 16 + pp * 8);
+            const u32 fl = (*(const u32 *)(c.lds + LDS_FL + e * 4) >> (2 * pp)) & 3u;
+            u32x4 px;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; h2++) {
+                const u32 y2 = yy[h2];
+                const u32 r2 = sat_pk_u8_i16(pk_add16(y2, tr[h2]));
+                const u32 g2 = sat_pk_u8_i16(pk_add16(y2, tg[h2]));
+                const u32 b2 = sat_pk_u8_i16(pk_add16(y2, tb[h2]));
+                const u32 bg = __builtin_amdgcn_perm(g2, b2, 0x05010400u); /* b0 g0 b1 g1 */
+                px[2 * h2] = __builtin_amdgcn_perm(r2, bg, 0x0d040100u);     /* b0 g0 r0 ff */
+                px[2 * h2 + 1] = __builtin_amdgcn_perm(r2, bg, 0x0d050302u); /* b1 g1 r1 ff */
+            }
+            if (fl) { /* rare: exact-integer G decided by the fp64 roundings */
+                const u32x2 uvp = *(const u32x2 *)(c.lds + LDS_UV + e * 16 + pp * 8);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; h2++)
+                    if (fl & (1u << h2)) {
+                        const u32 uvw = uvp[h2], y2 = yy[h2];
+                        const int uu = (int)(short)(uvw & 0xffffu), vv = (int)(short)(uvw >> 16);
+                        const u32 g0 = green_fp64((int)(y2 & 0xffffu), uu, vv);
+                        const u32 g1 = green_fp64((int)(y2 >> 16), uu, vv);
+                        px[2 * h2] = (px[2 * h2] & 0xffff00ffu) | (g0 << 8);
+                        px[2 * h2 + 1] = (px[2 * h2 + 1] & 0xffff00ffu) | (g1 << 8);
+                    }
+            }
+            if (full || mcu0 + (int)m <= last) {
+                u32x4 *dst = (u32x4 *)(orow + (long long)k * 8 * p.pitch + rnd * 128 + r.st_lane);
+                if (NT & 2) __builtin_nontemporal_store(px, dst);
+                else *dst = px;
+            }
+        }
+    }
+}
+
+/* QPW quads per wave (adjacent in the MCU row), WAVES_PER_WG waves per workgroup;
+ * blockIdx = (quad group, MCU row, image).  A short-lived wave issues all its loads up
+ * front and never waits on its own earlier stores (vmcnt is in-order), which streams
+ * measurably faster on MI355X than a persistent grid-stride loop (tests/tools/membench.hip:
+ * 6.2-6.5 TB/s vs 4.7-5.3 TB/s for a 16 B/lane copy).  NT bit 0: non-temporal loads,
+ * bit 1: non-temporal stores. */
+template <int QPW, int NT>
 __global__ __launch_bounds__(WG_THREADS) void k_jpeg420_fused(JpegBatch p)
 {
     __shared__ __attribute__((aligned(16))) char lds_all[WAVES_PER_WG * LDS_WAVE_BYTES];
@@ -206,145 +364,30 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg420_fused(JpegBatch p)
     /* wave-uniform values are forced into SGPRs: hipcc cannot prove that anything
      * derived from threadIdx is uniform and would run all the index math per lane */
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qcol0 = (int)(blockIdx.x * WAVES_PER_WG + wave) * QPW, mrow = (int)blockIdx.y, img = (int)blockIdx.z;
+    if (qcol0 >= p.quads_per_row) return; /* wave-uniform; no barriers anywhere in this kernel */
+
     WaveCtx c;
     wave_ctx_init(c, lds_all + wave * LDS_WAVE_BYTES, lane);
+    LaneRoles r;
+    r.row = lane & 7;
+    r.lblk = lane >> 3;
+    r.st_lane = (lane >> 3) * (u32)p.pitch + (lane & 7) * 16;
+    r.ce_rd = (((lane >> 1) & 3) * 8 + (lane >> 3)) * 16 + (lane & 1) * 8;
 
-    /* One quad per wave, one workgroup per 4 consecutive quads of an MCU row:
-     * blockIdx = (quad group, MCU row, image).  A short-lived wave issues all its loads
-     * up front and never waits on its own earlier stores (vmcnt is in-order), which
-     * streams measurably faster on MI355X than a persistent grid-stride loop
-     * (tests/tools/membench.hip: 6.2-6.5 TB/s vs 4.7-5.3 TB/s for a 16 B/lane copy). */
-    const int rows = p.mcu_rows, last = p.mcu_cols - 1;
-    const int qcol = (int)(blockIdx.x * WAVES_PER_WG + wave), mrow = (int)blockIdx.y, img = (int)blockIdx.z;
-    if (qcol >= p.quads_per_row) return; /* wave-uniform; no barriers anywhere in this kernel */
-
-    /* per-lane roles */
-    const u32 row = lane & 7, lblk = lane >> 3;       /* load: block lblk of the round, row `row` */
-    const u32 ld_c = (lblk & 3) * 128 + row * 16;     /* chroma: byte offset of (MCU lblk&3, row)  */
-    const u32 ld_y = lblk * 128 + row * 16;           /* luma: 8 consecutive blocks                 */
-    const u32 st_lane = (lane >> 3) * (u32)p.pitch + (lane & 7) * 16; /* store: 8 lanes = one 128-B row piece */
-    /* chroma entry role: e = lane = j*8 + m*2 + hf */
-    const u32 ce_rd = (((lane >> 1) & 3) * 8 + (lane >> 3)) * 16 + (lane & 1) * 8;
-    {
-        const int mcu0 = qcol * 4;
-        const uint16_t *qt = p.quant + (long long)img * p.quant_stride;
-        const u32x4 q_y = *(const u32x4 *)(qt + p.qt_y * 64 + row * 8);
-        const u32x4 q_c = *(const u32x4 *)(qt + (lane < 32 ? p.qt_u : p.qt_v) * 64 + row * 8);
-
-        /* ---- global loads: one block row (16 B) per lane per round ---- */
-        const long long mcu_base = ((long long)img * rows + mrow) * p.mcu_cols + mcu0; /* scalar */
-        const bool full = mcu0 + 3 <= last;                                          /* scalar */
-        u32 oc = ld_c, oy0 = ld_y, oy1 = ld_y + 1024;
-        if (!full) { /* ragged right edge: clamp to the last MCU (stores are masked below) */
-            const int rem = last - mcu0; /* 0..2 */
-            int mc = (int)(lblk & 3); mc = mc > rem ? rem : mc;
-            int m0 = (int)(lblk >> 2), m1 = m0 + 2;
-            m0 = m0 > rem ? rem : m0; m1 = m1 > rem ? rem : m1;
-            oc = (u32)mc * 128 + row * 16;
-            oy0 = ((u32)m0 * 4 + (lblk & 3)) * 128 + row * 16;
-            oy1 = ((u32)m1 * 4 + (lblk & 3)) * 128 + row * 16;
-        }
-        const char *bu = (const char *)(p.coef_u + mcu_base * 64);
-        const char *bv = (const char *)(p.coef_v + mcu_base * 64);
-        const char *by = (const char *)(p.coef_y + mcu_base * 256);
-        const u32x4 raw_c = *(const u32x4 *)((lane < 32 ? bu : bv) + oc);
-        const u32x4 raw_y0 = *(const u32x4 *)(by + oy0);
-        const u32x4 raw_y1 = *(const u32x4 *)(by + oy1);
-
-        /* ---- chroma round: blocks 0-3 = U of MCU 0-3, blocks 4-7 = V ---- */
-        {
-            const u32x4 pk = idct8x8_round(c, raw_c, q_c);
-            /* samples -> work tile [block][row][8 x int16]; then each lane picks up
-             * U and V of 4 adjacent chroma columns of one chroma row:
-             * entry e = lane = j*8 + m*2 + hf  (chroma row j, MCU m, column half hf) */
-            *(u32x4 *)(c.lds + LDS_W + (c.blk * 8 + c.idx) * 16) = pk;
-            const u32x2 us = *(const u32x2 *)(c.lds + LDS_W + ce_rd);
-            const u32x2 vs = *(const u32x2 *)(c.lds + LDS_W + 512 + ce_rd);
-            u32x4 tr, tg, tb, uv;
-            u32 mask = 0;
+    QuadLoads ld[QPW];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const u32 uw = us[k >> 1], vw = vs[k >> 1];
-                const int uu = (int)((k & 1) ? (uw >> 16) : (uw & 0xffffu)) - 128; /* colorspace.c:149 */
-                const int vv = (int)((k & 1) ? (vw >> 16) : (vw & 0xffffu)) - 128;
-                /* floor(32 vv/25), floor(266 uu/125), floor(-(215 uu + 381 vv)/1000), each
-                 * biased to a non-negative numerator x and evaluated as fdiv(2x+1) */
-                const int fr = fdiv_f32(64 * vv + (2 * 25 * 164 + 1), 1.0f / 50.0f) - 164;
-                const int fb = fdiv_f32(532 * uu + (2 * 125 * 273 + 1), 1.0f / 250.0f) - 273;
-                const int sgm = 215 * uu + 381 * vv;
-                const int t = 4806000 - sgm;
-                const int tq = fdiv_f32(2 * t + 1, 1.0f / 2000.0f);
-                const int fg = tq - 4806;
-                if (t - tq * 1000 == 0 && sgm != 0) mask |= 1u << k; /* exact-integer G: fp64 decides */
-                tr[k] = __builtin_amdgcn_perm((u32)fr, (u32)fr, 0x01000100u);
-                tg[k] = __builtin_amdgcn_perm((u32)fg, (u32)fg, 0x01000100u);
-                tb[k] = __builtin_amdgcn_perm((u32)fb, (u32)fb, 0x01000100u);
-                uv[k] = __builtin_amdgcn_perm((u32)vv, (u32)uu, 0x05040100u);
-            }
-            *(u32x4 *)(c.lds + LDS_TR + lane * 16) = tr;
-            *(u32x4 *)(c.lds + LDS_TG + lane * 16) = tg;
-            *(u32x4 *)(c.lds + LDS_TB + lane * 16) = tb;
-            *(u32x4 *)(c.lds + LDS_UV + lane * 16) = uv;
-            *(u32 *)(c.lds + LDS_FL + lane * 4) = mask;
-        }
-
-        uint8_t *const orow = p.bgra + (long long)img * p.image_stride + (long long)mrow * 16 * p.pitch +
-                              (long long)mcu0 * 64; /* scalar */
-        /* ---- two luma rounds: MCU 0-1 then MCU 2-3 of the quad ---- */
-#pragma unroll
-        for (int rnd = 0; rnd < 2; rnd++) {
-            /* stage C: 16 pixel rows x 32 px of int16, 64 B per row, 16-B chunks
-             * XOR-swizzled by (row>>1)&3 so that both the writes here and the
-             * output-order reads below are bank-conflict free */
-            {
-                const u32x4 pk = idct8x8_round(c, rnd ? raw_y1 : raw_y0, q_y);
-                const u32 mloc = c.blk >> 2, vi = (c.blk >> 1) & 1, hi = c.blk & 1;
-                const u32 prow = vi * 8 + c.idx, chunk = mloc * 2 + hi;
-                *(u32x4 *)(c.lds + LDS_W + prow * 64 + ((chunk ^ ((prow >> 1) & 3)) << 4)) = pk;
-            }
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                /* output role: 8 lanes cover one 32-px row segment (128 B) */
-                const u32 prow = 8 * k + (lane >> 3), cg = lane & 7;
-                const u32 chunk = cg >> 1;
-                const u32x2 yy = *(const u32x2 *)(c.lds + LDS_W + prow * 64 +
-                                                  ((chunk ^ ((prow >> 1) & 3)) << 4) + (cg & 1) * 8);
-                const u32 m = 2 * rnd + (cg >> 2), hf = (cg >> 1) & 1, pp = cg & 1;
-                const u32 e = (prow >> 1) * 8 + m * 2 + hf;
-                const u32x2 tr = *(const u32x2 *)(c.lds + LDS_TR + e * 16 + pp * 8);
-                const u32x2 tg = *(const u32x2 *)(c.lds + LDS_TG + e * 16 + pp * 8);
-                const u32x2 tb = *(const u32x2 *)(c.lds + LDS_TB + e * 16 + pp * 8);
-                const u32 fl = (*(const u32 *)(c.lds + LDS_FL + e * 4) >> (2 * pp)) & 3u;
-                u32x4 px;
-#pragma unroll
-                for (int h2 = 0; h2 < 2; h2++) {
-                    const u32 y2 = yy[h2];
-                    const u32 r2 = sat_pk_u8_i16(pk_add16(y2, tr[h2]));
-                    const u32 g2 = sat_pk_u8_i16(pk_add16(y2, tg[h2]));
-                    const u32 b2 = sat_pk_u8_i16(pk_add16(y2, tb[h2]));
-                    const u32 bg = __builtin_amdgcn_perm(g2, b2, 0x05010400u); /* b0 g0 b1 g1 */
-                    px[2 * h2] = __builtin_amdgcn_perm(r2, bg, 0x0d040100u);     /* b0 g0 r0 ff */
-                    px[2 * h2 + 1] = __builtin_amdgcn_perm(r2, bg, 0x0d050302u); /* b1 g1 r1 ff */
-                }
-                if (fl) { /* rare: exact-integer G decided by the fp64 roundings */
-                    const u32x2 uvp = *(const u32x2 *)(c.lds + LDS_UV + e * 16 + pp * 8);
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; h2++)
-                        if (fl & (1u << h2)) {
-                            const u32 uvw = uvp[h2], y2 = yy[h2];
-                            const int uu = (int)(short)(uvw & 0xffffu), vv = (int)(short)(uvw >> 16);
-                            const u32 g0 = green_fp64((int)(y2 & 0xffffu), uu, vv);
-                            const u32 g1 = green_fp64((int)(y2 >> 16), uu, vv);
-                            px[2 * h2] = (px[2 * h2] & 0xffff00ffu) | (g0 << 8);
-                            px[2 * h2 + 1] = (px[2 * h2 + 1] & 0xffff00ffu) | (g1 << 8);
-                        }
-                }
-                if (full || mcu0 + (int)m <= last)
-                    *(u32x4 *)(orow + (long long)k * 8 * p.pitch + rnd * 128 + st_lane) = px;
-            }
-        }
-
+    for (int i = 0; i < QPW; i++) {
+        int qc = qcol0 + i;
+        qc = qc < p.quads_per_row ? qc : p.quads_per_row - 1; /* duplicate load, never stored */
+        ld[i] = quad_load<NT & 1>(p, r, lane, img, mrow, qc * 4);
     }
+    const uint16_t *qt = p.quant + (long long)img * p.quant_stride;
+    const u32x4 q_y = *(const u32x4 *)(qt + p.qt_y * 64 + r.row * 8);
+    const u32x4 q_c = *(const u32x4 *)(qt + (lane < 32 ? p.qt_u : p.qt_v) * 64 + r.row * 8);
+#pragma unroll
+    for (int i = 0; i < QPW; i++)
+        if (qcol0 + i < p.quads_per_row) quad_recon<NT>(p, c, r, lane, ld[i], q_y, q_c, img, mrow, (qcol0 + i) * 4);
 }
 
 /* ------------------------------------------------------------------------
@@ -439,6 +482,32 @@ static int geom_ok(const ffhip_jpeg_geom *g)
     return 1;
 }
 
+/* kernel variant: quads per wave and cache policy.  FFHIP_JPEG_VARIANT="<qpw><nt>" (e.g. "21")
+ * overrides the default for experiments; every variant computes identical bytes. */
+static int g_variant = -1;
+static void launch_fused(const JpegBatch &q, int n_images, hipStream_t st)
+{
+    if (g_variant < 0) {
+        const char *e = getenv("FFHIP_JPEG_VARIANT");
+        g_variant = (e && e[0] >= '1' && e[0] <= '2' && e[1] >= '0' && e[1] <= '3') ? (e[0] - '0') * 10 + (e[1] - '0')
+                                                                                 : FFHIP_JPEG_DEFAULT_VARIANT;
+    }
+    const int qpw = g_variant / 10;
+    const dim3 grid((q.quads_per_row + WAVES_PER_WG * qpw - 1) / (WAVES_PER_WG * qpw), q.mcu_rows, n_images);
+#define FFHIP_LAUNCH(Q, N) hipLaunchKernelGGL((k_jpeg420_fused<Q, N>), grid, dim3(WG_THREADS), 0, st, q)
+    switch (g_variant) {
+    case 10: FFHIP_LAUNCH(1, 0); break;
+    case 11: FFHIP_LAUNCH(1, 1); break;
+    case 12: FFHIP_LAUNCH(1, 2); break;
+    case 13: FFHIP_LAUNCH(1, 3); break;
+    case 20: FFHIP_LAUNCH(2, 0); break;
+    case 21: FFHIP_LAUNCH(2, 1); break;
+    case 22: FFHIP_LAUNCH(2, 2); break;
+    default: FFHIP_LAUNCH(2, 3); break;
+    }
+#undef FFHIP_LAUNCH
+}
+
 static int is_fused420(const ffhip_jpeg_geom *g) { return g->ncomp == 3 && g->h == 2 && g->v == 2; }
 
 static int grid_for(long long work_items_per_wg_unit)
@@ -494,7 +563,6 @@ extern "C" int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *g, int n_images, co
         p.qt_y = g->qt_id[0]; p.qt_u = g->qt_id[1]; p.qt_v = g->qt_id[2];
         long long quads = (long long)p.quads_per_row * p.mcu_rows * n_images;
         if (quads > 0x7fffffffLL || pitch * 16 > 0x7fffffffLL || g->mcu_rows > 65535) return FFHIP_EINVAL;
-        const dim3 grid((p.quads_per_row + WAVES_PER_WG - 1) / WAVES_PER_WG, p.mcu_rows, 1);
         /* grid.z carries the image index (<= 65535 per launch) */
         for (int first = 0; first < n_images; first += 65535) {
             const int cnt = n_images - first < 65535 ? n_images - first : 65535;
@@ -506,7 +574,7 @@ extern "C" int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *g, int n_images, co
             q.quant += (long long)first * quant_stride;
             q.bgra += (long long)first * image_stride;
             q.n_images = cnt;
-            hipLaunchKernelGGL(k_jpeg420_fused, dim3(grid.x, grid.y, cnt), dim3(WG_THREADS), 0, st, q);
+            launch_fused(q, cnt, st);
             FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
         }
         return FFHIP_OK;

@@ -126,13 +126,13 @@ extern "C" float ffhip_event_elapsed_ms(void *start, void *stop)
     return ms;
 }
 
-/* 16 B per lane copy, one element per thread (no loop): the launch shape that streams
- * fastest on MI355X (tests/tools/membench.hip).  The achievable-HBM yardstick the fused
+/* 16 B per lane non-temporal copy, one element per thread (no loop): the launch shape and
+ * cache policy that stream fastest on MI355X (tests/tools/membench.hip).  The achievable-HBM yardstick the fused
  * kernel is compared with in the same process (bench.py). */
 __global__ __launch_bounds__(256) void k_copy_calibrate(u32x4 *dst, const u32x4 *src, size_t n16)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n16) dst[i] = src[i];
+    if (i < n16) __builtin_nontemporal_store(__builtin_nontemporal_load(&src[i]), &dst[i]);
 }
 
 extern "C" int ffhip_copy_calibrate(void *d_dst, const void *d_src, size_t bytes, void *stream)

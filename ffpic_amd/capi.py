@@ -18,6 +18,7 @@ EXPORTS = [
     "ffhip_get_dct_ops", "ffhip_get_cs_ops", "ffhip_idct_4x4_hevc",
     "ffhip_jpeg_recon_batch", "ffhip_jpeg_workspace_bytes", "ffhip_jpeg_recon_batch_host",
     "ffhip_jpeg_kernel_name", "ffhip_copy_calibrate",
+    "ffhip_yuv420_to_bgra", "ffhip_yuv420_to_bgra_16", "ffhip_yuv400_to_bgra_16",
 ]
 
 
@@ -130,6 +131,10 @@ def lib():
     L.ffhip_jpeg_kernel_name.argtypes = [C.POINTER(JpegGeom)]
     L.ffhip_jpeg_kernel_name.restype = C.c_char_p
     L.ffhip_copy_calibrate.argtypes = [vp, vp, sz, vp]
+    ci = C.c_int
+    L.ffhip_yuv420_to_bgra.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, i64, i64, i64, vp]
+    L.ffhip_yuv420_to_bgra_16.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, i64, i64, i64, vp]
+    L.ffhip_yuv400_to_bgra_16.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, i64, i64, vp]
     _lib = L
     return L
 

@@ -80,3 +80,71 @@ def yuv_to_bgra32(Y, U, V, v, h, pitch=None):
     out = np.zeros((8 * v, pitch), dtype=np.uint8)
     ops.contents.YUV_to_BGRA32(out.ctypes.data, pitch, Y.ctypes.data, U.ctypes.data, V.ctypes.data, v, h)
     return out
+
+
+class DeviceBuffer:
+    """Tiny RAII wrapper over ffhip_malloc/ffhip_free for host-driven calls (no torch)."""
+
+    def __init__(self, host=None, nbytes=None):
+        L = capi.require_device()
+        self.nbytes = host.nbytes if host is not None else nbytes
+        self.ptr = L.ffhip_malloc(max(self.nbytes, 16))
+        if not self.ptr:
+            raise capi.FfhipError("ffhip_malloc failed")
+        if host is not None and host.nbytes:
+            capi.check(L.ffhip_memcpy_h2d(self.ptr, host.ctypes.data, host.nbytes, None), "h2d")
+            capi.check(L.ffhip_stream_sync(None))
+
+    def to_host(self, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        L = capi.lib()
+        capi.check(L.ffhip_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes, None), "d2h")
+        capi.check(L.ffhip_stream_sync(None))
+        return out
+
+    def __del__(self):
+        try:
+            capi.lib().ffhip_free(self.ptr)
+        except Exception:
+            pass
+
+
+def yuv420_to_bgra(y, u, v, mbrows, mbcols, pitch=None):
+    """YUV420_to_BGRA32 (utils/colorspace.c:291-329): uint8 planes [n][H][W], [n][H/2][W/2]."""
+    L = capi.require_device()
+    n, H, W = y.shape
+    assert (H, W) == (16 * mbrows, 16 * mbcols) and u.shape == (n, H // 2, W // 2) == v.shape
+    pitch = pitch or W * 4
+    dy, du, dv = DeviceBuffer(np.ascontiguousarray(y)), DeviceBuffer(np.ascontiguousarray(u)), DeviceBuffer(np.ascontiguousarray(v))
+    do = DeviceBuffer(nbytes=n * H * pitch)
+    capi.check(L.ffhip_memset(do.ptr, 0, do.nbytes, None))
+    capi.check(L.ffhip_yuv420_to_bgra(do.ptr, pitch, dy.ptr, du.ptr, dv.ptr, W, W // 2, mbrows, mbcols, n,
+                                      H * W, H * W // 4, H * pitch, None), "ffhip_yuv420_to_bgra")
+    return do.to_host((n, H, pitch), np.uint8)
+
+
+def yuv420_to_bgra_16(y, u, v, ctbrows, ctbcols, ctbsize, pitch=None):
+    """YUV420_to_BGRA32_16bit (utils/colorspace.c:628-669): int16 planes."""
+    L = capi.require_device()
+    n, H, W = y.shape
+    assert (H, W) == (ctbsize * ctbrows, ctbsize * ctbcols)
+    pitch = pitch or W * 4
+    dy, du, dv = DeviceBuffer(np.ascontiguousarray(y)), DeviceBuffer(np.ascontiguousarray(u)), DeviceBuffer(np.ascontiguousarray(v))
+    do = DeviceBuffer(nbytes=n * H * pitch)
+    capi.check(L.ffhip_memset(do.ptr, 0, do.nbytes, None))
+    capi.check(L.ffhip_yuv420_to_bgra_16(do.ptr, pitch, dy.ptr, du.ptr, dv.ptr, W, W // 2, ctbrows, ctbcols, ctbsize,
+                                         n, H * W, H * W // 4, H * pitch, None), "ffhip_yuv420_to_bgra_16")
+    return do.to_host((n, H, pitch), np.uint8)
+
+
+def yuv400_to_bgra_16(y, ctbrows, ctbcols, ctbsize, pitch=None):
+    """YUV400_to_BGRA32_16bit (utils/colorspace.c:715-742)."""
+    L = capi.require_device()
+    n, H, W = y.shape
+    pitch = pitch or W * 4
+    dy = DeviceBuffer(np.ascontiguousarray(y))
+    do = DeviceBuffer(nbytes=n * H * pitch)
+    capi.check(L.ffhip_memset(do.ptr, 0, do.nbytes, None))
+    capi.check(L.ffhip_yuv400_to_bgra_16(do.ptr, pitch, dy.ptr, W, ctbrows, ctbcols, ctbsize, n, H * W, H * pitch,
+                                         None), "ffhip_yuv400_to_bgra_16")
+    return do.to_host((n, H, pitch), np.uint8)

@@ -162,6 +162,25 @@ int ffhip_jpeg_recon_batch_host(const ffhip_jpeg_geom *geom, int n_images, const
  * geometry class, for bench.py's roofline object. */
 const char *ffhip_jpeg_kernel_name(const ffhip_jpeg_geom *geom);
 
+/* ---- planar YUV -> BGRA (WebP frame / HEVC picture colour conversion) ----
+ * Same arguments as the reference functions, plus a batch dimension; all pointers are
+ * DEVICE pointers, strides in samples (planes) or bytes (pitch, image_stride).
+ *   ffhip_yuv420_to_bgra     == YUV420_to_BGRA32        (utils/colorspace.c:291-329; format/webp.c:1868)
+ *   ffhip_yuv420_to_bgra_16  == YUV420_to_BGRA32_16bit  (utils/colorspace.c:628-669; coding/hevc.c:7260-7270)
+ *   ffhip_yuv400_to_bgra_16  == YUV400_to_BGRA32_16bit  (utils/colorspace.c:715-742; coding/hevc.c:7271-7277)
+ * Image i reads planes at +i*plane_stride_* and writes at d_bgra + i*image_stride. */
+int ffhip_yuv420_to_bgra(uint8_t *d_bgra, int pitch, const uint8_t *d_y, const uint8_t *d_u,
+                         const uint8_t *d_v, int y_stride, int uv_stride, int mbrows, int mbcols,
+                         int n_images, int64_t plane_stride_y, int64_t plane_stride_uv,
+                         int64_t image_stride, void *stream);
+int ffhip_yuv420_to_bgra_16(uint8_t *d_bgra, int pitch, const int16_t *d_y, const int16_t *d_u,
+                            const int16_t *d_v, int y_stride, int uv_stride, int ctbrows, int ctbcols,
+                            int ctbsize, int n_images, int64_t plane_stride_y,
+                            int64_t plane_stride_uv, int64_t image_stride, void *stream);
+int ffhip_yuv400_to_bgra_16(uint8_t *d_bgra, int pitch, const int16_t *d_y, int y_stride,
+                            int ctbrows, int ctbcols, int ctbsize, int n_images,
+                            int64_t plane_stride_y, int64_t image_stride, void *stream);
+
 /* Device-to-device copy kernel (16 B/lane, grid-stride) used by bench.py to
  * calibrate the achievable HBM rate next to the fused kernel. */
 int ffhip_copy_calibrate(void *d_dst, const void *d_src, size_t bytes, void *stream);

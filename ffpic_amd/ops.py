@@ -148,3 +148,16 @@ def yuv400_to_bgra_16(y, ctbrows, ctbcols, ctbsize, pitch=None):
     capi.check(L.ffhip_yuv400_to_bgra_16(do.ptr, pitch, dy.ptr, W, ctbrows, ctbcols, ctbsize, n, H * W, H * pitch,
                                          None), "ffhip_yuv400_to_bgra_16")
     return do.to_host((n, H, pitch), np.uint8)
+
+
+def vp8_residual_batch(levels, mbinfo, quant):
+    """Per-macroblock residual of vp8_decode_residual_block (format/webp.c:1147-1196):
+    levels int16 [n][25][16], mbinfo uint8 [n][32], quant uint16 [4][8] -> int16 [n][384]."""
+    L = capi.require_device()
+    n = levels.shape[0]
+    assert levels.shape == (n, 25, 16) and mbinfo.shape == (n, 32) and quant.shape == (4, 8)
+    dl, di, dq = DeviceBuffer(np.ascontiguousarray(levels)), DeviceBuffer(np.ascontiguousarray(mbinfo)), \
+        DeviceBuffer(np.ascontiguousarray(quant))
+    do = DeviceBuffer(nbytes=n * 384 * 2)
+    capi.check(L.ffhip_vp8_residual_batch(n, dl.ptr, di.ptr, dq.ptr, do.ptr, None), "ffhip_vp8_residual_batch")
+    return do.to_host((n, 384), np.int16)

@@ -95,3 +95,44 @@ def adversarial_blocks(rng, n_blocks):
         m = np.zeros(64, bool); m[7::8] = True
         b[4 * k:5 * k][:, ~m] = 0                   # last column only
     return b
+
+
+# ------------------------------------------------------------------ VP8 (WebP lossy)
+
+def vp8_quant(segments=4, seed=0):
+    """[segments][8] uint16: y1_dc, y1_ac, y2_dc, y2_ac, uv_dc, uv_ac, 0, 0 -- plausible
+    values of read_dequantization (format/webp.c:527-543)."""
+    rng = np.random.default_rng(SEED_BASE + 7000 + seed)
+    q = np.zeros((segments, 8), dtype=np.uint16)
+    for s in range(segments):
+        base = int(rng.integers(4, 158))
+        ac = int(rng.integers(4, 285))
+        q[s, :6] = [base, ac, min(2 * base, 132), max(ac * 155 // 100, 8), base, ac]
+    return q
+
+
+def vp8_macroblocks(n_mb, seed=0, adversarial=False):
+    """Quantised levels [n_mb][25][16] int16 (raster positions, block 24 = Y2) and the
+    per-MB info bytes [n_mb][32]: [0..24] token counts (nz) per block, [25] has_y2,
+    [26] segment id.  ~60 % of the MBs carry a Y2 block."""
+    rng = np.random.default_rng(SEED_BASE + 9000 + seed)
+    if adversarial:
+        lv = rng.integers(-32768, 32768, size=(n_mb, 25, 16)).astype(np.int16)
+    else:
+        scale = 6.0 * np.exp(-np.arange(16) / 4.0)
+        lv = np.rint(rng.laplace(0, 1.0, size=(n_mb, 25, 16)) * scale).astype(np.int16)
+        lv[rng.random((n_mb, 25)) < 0.35] = 0          # empty blocks
+    info = np.zeros((n_mb, 32), dtype=np.uint8)
+    # nz as the entropy decoder would report it: index of the last token + 1, in scan
+    # order; here a random value consistent with "0 tokens => all zero"
+    nzc = (lv != 0).sum(axis=2)
+    info[:, :25] = np.where(nzc == 0, 0, np.minimum(16, nzc + rng.integers(0, 3, size=nzc.shape)))
+    # the reference quirk: a block whose single token is an AC coefficient (nz == 1, DC == 0)
+    k = n_mb // 10
+    if k:
+        lv[:k, 3, :] = 0
+        lv[:k, 3, 5] = 7
+        info[:k, 3] = 1
+    info[:, 25] = rng.random(n_mb) < 0.6
+    info[:, 26] = rng.integers(0, 4, size=n_mb)
+    return lv, info

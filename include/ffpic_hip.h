@@ -181,6 +181,23 @@ int ffhip_yuv400_to_bgra_16(uint8_t *d_bgra, int pitch, const int16_t *d_y, int 
                             int ctbrows, int ctbcols, int ctbsize, int n_images,
                             int64_t plane_stride_y, int64_t image_stride, void *stream);
 
+/* ---- VP8 (WebP lossy) residual stage, batched over macroblocks ----
+ * Replaces, for n_mb macroblocks at once, what vp8_decode_residual_block does between
+ * the token parse and the predictor (format/webp.c:1147-1196): dequantisation (the
+ * `absValue * quant` int16 store of webp.c:1061), IWHT_long / IWHT_fast of the Y2 block
+ * (webp.c:1067-1106) and idct_4x4_16 (utils/idct.c:100-151) of every block that has
+ * more than one token or a non-zero DC (webp.c:1172,1188).  DEVICE pointers:
+ *   d_levels   int16 [n_mb][25][16]  quantised levels at their raster position (zig-zag
+ *              placement done); blocks 0-15 Y, 16-19 U, 20-23 V, 24 Y2
+ *   d_mbinfo   uint8 [n_mb][32]      [0..24] token count per block (the return value of
+ *              vp8_get_coefficients), [25] 1 if intra_y_mode != B_PRED (has Y2),
+ *              [26] segment id (0..3)
+ *   d_quant    uint16 [4][8]         per segment y1_dc,y1_ac,y2_dc,y2_ac,uv_dc,uv_ac,0,0
+ *              (struct WEBP_decoder, format/webp.h:276-287)
+ *   d_residual int16 [n_mb][384]     the `coeffs` array vp8_prerdict_mb consumes */
+int ffhip_vp8_residual_batch(long long n_mb, const int16_t *d_levels, const uint8_t *d_mbinfo,
+                             const uint16_t *d_quant, int16_t *d_residual, void *stream);
+
 /* Device-to-device copy kernel (16 B/lane, grid-stride) used by bench.py to
  * calibrate the achievable HBM rate next to the fused kernel. */
 int ffhip_copy_calibrate(void *d_dst, const void *d_src, size_t bytes, void *stream);

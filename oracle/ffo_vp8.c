@@ -6,6 +6,8 @@
  *   ffo_vp8_idct_4x4    utils/idct.c:100-151    idct_4x4_16 (VP8 4x4 IDCT)
  *   ffo_vp8_iwht_long   format/webp.c:1067-1096 IWHT_long
  *   ffo_vp8_iwht_fast   format/webp.c:1098-1106 IWHT_fast
+ *   ffo_vp8_residual_mb format/webp.c:1061 (dequant at parse), :1147-1196 (per-MB
+ *                       residual assembly in vp8_decode_residual_block)
  */
 #include "ffo.h"
 
@@ -67,4 +69,33 @@ void ffo_vp8_iwht_fast(const int16_t in[16], int16_t *out)
 {
     int16_t dc = (int16_t)((in[0] + 3) >> 3);
     for (int k = 0; k < 16; k++) out[16 * k] = dc;
+}
+
+/* One macroblock from quantised levels to the 384-entry residual the predictor adds.
+ *   levels[25][16]  quantised coefficients already at their raster position (the
+ *                   zig-zag placement of webp.c:1061 done), blocks 0-15 Y, 16-19 U,
+ *                   20-23 V, 24 Y2
+ *   nz[25]          the per-block return value of vp8_get_coefficients (tokens read)
+ *   has_y2          intra_y_mode != B_PRED
+ *   q[6]            y1_dc, y1_ac, y2_dc, y2_ac, uv_dc, uv_ac (struct WEBP_decoder)
+ * Dequantised products are stored to int16 (webp.c:1061, `out` is int16_t*); the IDCT
+ * of a block runs iff nz > 1 or its DC is non-zero (webp.c:1172,1188) -- so a block
+ * whose only token is an AC coefficient keeps that raw value, as in the reference. */
+void ffo_vp8_residual_mb(const int16_t *levels, const uint8_t *nz, int has_y2, const uint16_t q[6],
+                         int16_t out[384])
+{
+    for (int i = 0; i < 384; i++) out[i] = 0; /* webp.c:1209 */
+    if (has_y2) {
+        int16_t dc[16];
+        for (int i = 0; i < 16; i++) dc[i] = (int16_t)(levels[24 * 16 + i] * (int)(i ? q[3] : q[2]));
+        if (nz[24] > 1) ffo_vp8_iwht_long(dc, out);
+        else ffo_vp8_iwht_fast(dc, out);
+    }
+    for (int b = 0; b < 24; b++) {
+        const int dcq = b < 16 ? q[0] : q[4], acq = b < 16 ? q[1] : q[5];
+        int16_t *dst = out + 16 * b;
+        for (int i = (b < 16 && has_y2) ? 1 : 0; i < 16; i++)
+            dst[i] = (int16_t)(levels[b * 16 + i] * (i ? acq : dcq));
+        if (nz[b] > 1 || dst[0] != 0) ffo_vp8_idct_4x4(dst);
+    }
 }

@@ -11,3 +11,26 @@
 void ref_vp8_iwht_long(const int16_t *in, int16_t *out) { IWHT_long(in, out); }
 void ref_vp8_iwht_fast(int16_t *in, int16_t *out) { IWHT_fast(in, out); }
 void ref_vp8_idct_4x4(int16_t *blk) { get_dct_ops(16)->idct_4x4(blk, 8); }
+
+/* Per-MB residual assembly with the control flow of vp8_decode_residual_block
+ * (webp.c:1147-1196) but fed from already-parsed levels instead of the bool decoder:
+ * every arithmetic step is the reference's own code (the int16 store of the dequantised
+ * product at webp.c:1061, IWHT_long / IWHT_fast, get_dct_ops(16)->idct_4x4). */
+void ref_vp8_residual_mb(const int16_t *levels, const uint8_t *nz, int has_y2, const uint16_t *q, int16_t *out)
+{
+    const struct dct_ops *dct = get_dct_ops(16);
+    memset(out, 0, 384 * sizeof(int16_t));
+    int16_t *dst = out;
+    if (has_y2) {
+        int16_t dc[16] = {0};
+        for (int n = 0; n < 16; n++) dc[n] = levels[24 * 16 + n] * (n > 0 ? q[3] : q[2]);
+        if (nz[24] > 1) IWHT_long(dc, dst);
+        else IWHT_fast(dc, dst);
+    }
+    for (int b = 0; b < 24; b++) {
+        const int quant_dc = b < 16 ? q[0] : q[4], quant_ac = b < 16 ? q[1] : q[5];
+        for (int n = (b < 16 && has_y2) ? 1 : 0; n < 16; n++) dst[n] = levels[b * 16 + n] * (n > 0 ? quant_ac : quant_dc);
+        if (nz[b] > 1 || dst[0] != 0) dct->idct_4x4(dst, 8);
+        dst += 16;
+    }
+}

@@ -132,6 +132,21 @@ def gen_blocks(R):
     save("hevc_transform.npz", **hv)
 
 
+def gen_vp8_mbs(R):
+    """Per-macroblock VP8 residual (dequant + WHT + IDCT with the nz rule) through the
+    reference's own functions (oracle/ref_statics_webp.c::ref_vp8_residual_mb)."""
+    q = synth.vp8_quant()
+    res = {"quant": q}
+    for tag, adv, n in (("syn", False, 192), ("adv", True, 64)):
+        lv, info = synth.vp8_macroblocks(n, seed=1, adversarial=adv)
+        out = np.zeros((n, 384), dtype=np.int16)
+        for i in range(n):
+            R.ref_vp8_residual_mb(np.ascontiguousarray(lv[i]).reshape(-1), info[i], int(info[i, 25]),
+                                  np.ascontiguousarray(q[info[i, 26], :6]), out[i])
+        res[f"{tag}_levels"], res[f"{tag}_info"], res[f"{tag}_residual"] = lv, info, out
+    save("vp8_mbs.npz", **res)
+
+
 # ------------------------------------------------------------------ colour
 
 def fma_sensitive_triples():
@@ -330,6 +345,7 @@ def main():
     O.build_ref()
     R = O.ref()
     print("blocks"); gen_blocks(R)
+    print("vp8 macroblocks"); gen_vp8_mbs(R)
     print("colour"); gen_color(R)
     print("grids"); gen_grids(R)
     print("files"); gen_files(R)

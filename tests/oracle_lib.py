@@ -81,6 +81,7 @@ def ffo():
         L.ffo_vp8_idct_4x4.argtypes = [i16p]
         L.ffo_vp8_iwht_long.argtypes = [i16p, i16p]
         L.ffo_vp8_iwht_fast.argtypes = [i16p, i16p]
+        L.ffo_vp8_residual_mb.argtypes = [i16p, u8p, C.c_int, u16p, i16p]
         L.ffo_hevc_idct_4x4_dst.argtypes = [i16p, i16p, C.c_int, C.c_int]
         L.ffo_hevc_scale.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.ffo_hevc_transform.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -110,6 +111,7 @@ def ref():
         L.ref_vp8_idct_4x4.argtypes = [i16p]
         L.ref_vp8_iwht_long.argtypes = [i16p, i16p]
         L.ref_vp8_iwht_fast.argtypes = [i16p, i16p]
+        L.ref_vp8_residual_mb.argtypes = [i16p, u8p, C.c_int, u16p, i16p]
         L.idct_4x4_hevc.argtypes = [i16p, i16p, C.c_int, C.c_bool]
         L.ref_hevc_scale.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.ref_hevc_transform.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int]

@@ -59,6 +59,20 @@ def test_vp8_blocks(golden, ffo):
         assert not wl.reshape(16, 16)[:, 1:].any()  # only the DC slots are written
 
 
+def test_vp8_macroblock_residual(golden, ffo):
+    g = golden("vp8_mbs.npz")
+    for tag in ("syn", "adv"):
+        lv, info, exp = g[f"{tag}_levels"], g[f"{tag}_info"], g[f"{tag}_residual"]
+        for i in range(lv.shape[0]):
+            out = np.zeros(384, np.int16)
+            ffo.ffo_vp8_residual_mb(np.ascontiguousarray(lv[i]).reshape(-1), info[i], int(info[i, 25]),
+                                    np.ascontiguousarray(g["quant"][info[i, 26], :6]), out)
+            assert np.array_equal(out, exp[i]), (tag, i)
+    # the reference quirk is present in the fixture: single AC token, DC 0 -> no IDCT
+    i = 0
+    assert g["syn_info"][i, 3] == 1 and g["syn_levels"][i, 3, 5] == 7
+
+
 def test_hevc_dst4(golden, ffo):
     g = golden("hevc_dst4.npz")
     for bd in (8, 10):

@@ -161,3 +161,17 @@ def vp8_residual_batch(levels, mbinfo, quant):
     do = DeviceBuffer(nbytes=n * 384 * 2)
     capi.check(L.ffhip_vp8_residual_batch(n, dl.ptr, di.ptr, dq.ptr, do.ptr, None), "ffhip_vp8_residual_batch")
     return do.to_host((n, 384), np.int16)
+
+
+def hevc_residual_batch(n, level, tuinfo, bitdepth=8, epp=False, scaling=None):
+    """scale_and_transform (coding/hevc.c:4172-4251) for a batch of n x n TUs:
+    level int16 [n_tu][n*n] row-major, tuinfo uint8 [n_tu][4] -> residual int16 [n_tu][n*n]."""
+    L = capi.require_device()
+    n_tu = level.shape[0]
+    assert level.shape == (n_tu, n * n) and tuinfo.shape == (n_tu, 4)
+    dl, di = DeviceBuffer(np.ascontiguousarray(level)), DeviceBuffer(np.ascontiguousarray(tuinfo))
+    ds = DeviceBuffer(np.ascontiguousarray(scaling)) if scaling is not None else None
+    do = DeviceBuffer(nbytes=max(n_tu * n * n * 2, 16))
+    capi.check(L.ffhip_hevc_residual_batch(n, n_tu, dl.ptr, di.ptr, ds.ptr if ds else None, bitdepth, int(epp),
+                                           do.ptr, None), "ffhip_hevc_residual_batch")
+    return do.to_host((n_tu, n * n), np.int16)

@@ -198,6 +198,26 @@ int ffhip_yuv400_to_bgra_16(uint8_t *d_bgra, int pitch, const int16_t *d_y, int 
 int ffhip_vp8_residual_batch(long long n_mb, const int16_t *d_levels, const uint8_t *d_mbinfo,
                              const uint16_t *d_quant, int16_t *d_residual, void *stream);
 
+/* ---- HEVC residual stage, batched over transform units of one size ----
+ * For n_tu TUs of size nTbS x nTbS (4, 8, 16 or 32): scale_transform_coefficients
+ * (coding/hevc.c:3743-3816) followed by transform_scaled_coeffients (hevc.c:3888-3956,
+ * 1-D kernels of hevc.c:3819-3885), i.e. the non-bypass branch of scale_and_transform
+ * (hevc.c:4224-4240); the bypass and transform-skip branches (hevc.c:4209-4236) are
+ * selected per TU.  DEVICE pointers:
+ *   d_level    int16 [n_tu][nTbS*nTbS]  TransCoeffLevel, row-major x + y*nTbS (the layout
+ *              of the reference's d[] / r[]; its TransCoeffLevel[cIdx][x][y] is x-major)
+ *   d_tuinfo   uint8 [n_tu][4]   [0] qP, [1] flags: 1 = luma intra 4x4 -> idct_4x4_hevc
+ *              (DST-VII, utils/idct.c:36-55), 2 = transform_skip_flag, 4 = cu_transquant_bypass,
+ *              8 = rotateCoeffs; [2] scaling matrixId (0..5); [3] 0
+ *   d_scaling  uint8 [6][nTbS*nTbS] ScalingFactor[sizeId][matrixId] row-major, or NULL for
+ *              scaling_list_enabled_flag == 0 (m = 16)
+ *   bitdepth   BitDepthY or BitDepthC of the component the TUs belong to; epp =
+ *              extended_precision_processing_flag
+ *   d_residual int16 [n_tu][nTbS*nTbS]  r[] as construct_pic_pior_to_filtering consumes it */
+int ffhip_hevc_residual_batch(int nTbS, long long n_tu, const int16_t *d_level, const uint8_t *d_tuinfo,
+                              const uint8_t *d_scaling, int bitdepth, int epp, int16_t *d_residual,
+                              void *stream);
+
 /* Device-to-device copy kernel (16 B/lane, grid-stride) used by bench.py to
  * calibrate the achievable HBM rate next to the fused kernel. */
 int ffhip_copy_calibrate(void *d_dst, const void *d_src, size_t bytes, void *stream);

@@ -8,6 +8,8 @@
  *   ffo_hevc_scale         coding/hevc.c:3743-3816 scale_transform_coefficients
  *   ffo_hevc_transform     coding/hevc.c:3819-3885 transformation
  *                          coding/hevc.c:3888-3956 transform_scaled_coeffients
+ *   ffo_hevc_residual_tu   coding/hevc.c:4209-4236 the bypass / transform-skip / transform
+ *                          branches of scale_and_transform
  *
  * Layouts: every block is row-major, d[x + y*nTbS] (x fastest), the layout
  * the reference uses for d[] and r[] (hevc.c:3793,3951).
@@ -120,4 +122,32 @@ void ffo_hevc_transform(const int16_t *d, int16_t *r, int nTbS, int trType, int 
         for (int x = 0; x < nTbS; x++)
             r[x + y * nTbS] = (int16_t)asr32(e[x] + (1u << (shift2 - 1)), shift2);
     }
+}
+
+/* One transform unit from levels to residual; flags: 1 = luma intra 4x4 (DST entry),
+ * 2 = transform_skip_flag, 4 = cu_transquant_bypass_flag, 8 = rotateCoeffs.
+ * scaling_factor: NULL (flat 16) or uint8 [nTbS*nTbS] row-major for this TU's matrix. */
+void ffo_hevc_residual_tu(const int16_t *level, int16_t *r, int nTbS, int qP, int flags, int bitdepth, int epp,
+                          const uint8_t *scaling_factor)
+{
+    const int n = nTbS, rot = (flags & 8) != 0;
+    if (flags & 4) { /* hevc.c:4209-4222 */
+        for (int y = 0; y < n; y++)
+            for (int x = 0; x < n; x++)
+                r[x + y * n] = rot ? level[(n - x - 1) + (n - y - 1) * n] : level[x + y * n];
+        return;
+    }
+    int16_t d[32 * 32];
+    /* scaling lists are not applied to transform-skipped blocks larger than 4x4 (hevc.c:3786-3787) */
+    ffo_hevc_scale(level, d, n, qP, bitdepth, epp, ((flags & 2) && n > 4) ? 0 : scaling_factor);
+    if (flags & 2) { /* hevc.c:4229-4236 */
+        int ts = 5 + ilog2(n);
+        for (int y = 0; y < n; y++)
+            for (int x = 0; x < n; x++) {
+                int v = rot ? d[(n - x - 1) + (n - y - 1) * n] : d[x + y * n];
+                r[x + y * n] = (int16_t)(uint16_t)((uint32_t)v << ts);
+            }
+        return;
+    }
+    ffo_hevc_transform(d, r, n, (flags & 1) && n == 4, bitdepth, epp);
 }

@@ -85,6 +85,7 @@ def ffo():
         L.ffo_hevc_idct_4x4_dst.argtypes = [i16p, i16p, C.c_int, C.c_int]
         L.ffo_hevc_scale.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.ffo_hevc_transform.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ffo_hevc_residual_tu.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.ffo_yuv420_to_bgra32.argtypes = [u8p, C.c_int, u8p, u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ffo_yuv420_to_bgra32_16bit.argtypes = [u8p, C.c_int, i16p, i16p, i16p, C.c_int, C.c_int, C.c_int,
                                                  C.c_int, C.c_int]

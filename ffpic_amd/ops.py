@@ -175,3 +175,24 @@ def hevc_residual_batch(n, level, tuinfo, bitdepth=8, epp=False, scaling=None):
     capi.check(L.ffhip_hevc_residual_batch(n, n_tu, dl.ptr, di.ptr, ds.ptr if ds else None, bitdepth, int(epp),
                                            do.ptr, None), "ffhip_hevc_residual_batch")
     return do.to_host((n_tu, n * n), np.int16)
+
+
+def vp8_predict_recon(mbcols, mbrows, modes, residual, resmap=None):
+    """vp8_prerdict_mb over whole key frames (format/webp.c:1833-1851, format/predict.c:426-645).
+    modes uint8 [n][n_mb][20], residual int16 [n][rows][384], resmap int32 [n][n_mb] or None.
+    Returns zero-initialised planes after reconstruction: (Y [n][16r][16c], U, V)."""
+    L = capi.require_device()
+    n, n_mb = modes.shape[0], mbcols * mbrows
+    assert modes.shape == (n, n_mb, 20) and residual.shape[0] == n and residual.shape[2] == 384
+    modes = np.ascontiguousarray(modes)
+    dm, dr = DeviceBuffer(modes), DeviceBuffer(np.ascontiguousarray(residual))
+    dmap = DeviceBuffer(np.ascontiguousarray(resmap, dtype=np.int32)) if resmap is not None else None
+    ysz, csz = 256 * n_mb, 64 * n_mb
+    dy, du, dv = DeviceBuffer(nbytes=n * ysz), DeviceBuffer(nbytes=n * csz), DeviceBuffer(nbytes=n * csz)
+    for d in (dy, du, dv):
+        capi.check(L.ffhip_memset(d.ptr, 0, d.nbytes, None))
+    capi.check(L.ffhip_vp8_predict_recon(mbcols, mbrows, n, modes.ctypes.data, dm.ptr, dr.ptr, residual.shape[1] * 384,
+                                         dmap.ptr if dmap else None, dy.ptr, du.ptr, dv.ptr, ysz, csz, None),
+               "ffhip_vp8_predict_recon")
+    return (dy.to_host((n, 16 * mbrows, 16 * mbcols), np.uint8), du.to_host((n, 8 * mbrows, 8 * mbcols), np.uint8),
+            dv.to_host((n, 8 * mbrows, 8 * mbcols), np.uint8))

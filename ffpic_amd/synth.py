@@ -136,3 +136,22 @@ def vp8_macroblocks(n_mb, seed=0, adversarial=False):
     info[:, 25] = rng.random(n_mb) < 0.6
     info[:, 26] = rng.integers(0, 4, size=n_mb)
     return lv, info
+
+
+def vp8_modes(mbcols, mbrows, seed=0, bpred_share=0.4):
+    """Per-MB mode records [n_mb][20] uint8: intra_y_mode (0 DC, 1 TM, 2 V, 3 H, 4 B_PRED),
+    intra_uv_mode (0..3), imodes[16] (0..9), 2 pad bytes."""
+    rng = np.random.default_rng(SEED_BASE + 11000 + seed)
+    n = mbcols * mbrows
+    m = np.zeros((n, 20), dtype=np.uint8)
+    m[:, 0] = np.where(rng.random(n) < bpred_share, 4, rng.integers(0, 4, size=n))
+    m[:, 1] = rng.integers(0, 4, size=n)
+    m[:, 2:18] = rng.integers(0, 10, size=(n, 16))
+    return m
+
+
+def vp8_residual(n_mb, seed=0, amplitude=40):
+    rng = np.random.default_rng(SEED_BASE + 12000 + seed)
+    r = np.rint(rng.laplace(0, amplitude / 3.0, size=(n_mb, 384))).astype(np.int16)
+    r[rng.random(n_mb) < 0.2] = 0
+    return r

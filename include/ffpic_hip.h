@@ -218,6 +218,28 @@ int ffhip_hevc_residual_batch(int nTbS, long long n_tu, const int16_t *d_level, 
                               const uint8_t *d_scaling, int bitdepth, int epp, int16_t *d_residual,
                               void *stream);
 
+/* ---- VP8 intra prediction + residual add for batches of key frames ----
+ * What vp8_prerdict_mb does for every macroblock of vp8_decode's loop (format/webp.c:1833-1851):
+ * pred_luma + pred_chrome (format/predict.c:426-645) with the residual of
+ * ffhip_vp8_residual_batch, written into 8-bit Y/U/V planes of stride 16*mbcols / 8*mbcols.
+ *   h_modes / d_modes  the SAME uint8 [n_images][mbrows*mbcols][20] records on the host (used
+ *                      to schedule the dependency wavefronts) and on the device:
+ *                      [0] intra_y_mode (0 DC, 1 TM, 2 V, 3 H, 4 B_PRED), [1] intra_uv_mode,
+ *                      [2..17] imodes[16] (4x4 modes 0..9), [18..19] 0  (format/webp.h:243-256)
+ *   d_residual         int16 [n_images][.][384], image i at + i*residual_stride (elements)
+ *   d_resmap           int32 [n_images][n_mb] residual row used by each macroblock, or NULL for
+ *                      the identity; the reference keeps the PREVIOUS macroblock's coefficients
+ *                      when mb_skip_coeff is set (webp.c:1207-1223) -- map skipped MBs there
+ *   d_y/d_u/d_v        planes, image i at + i*plane_stride_*; their initial contents and the
+ *                      bytes before them matter exactly where the reference's 16x16 V_PRED /
+ *                      H_PRED read raw memory at the top row / left column (predict.c:338-353):
+ *                      bytes before a plane read as 0.
+ * Enqueues one launch per wavefront level on `stream` (synchronises it once first). */
+int ffhip_vp8_predict_recon(int mbcols, int mbrows, int n_images, const uint8_t *h_modes,
+                            const uint8_t *d_modes, const int16_t *d_residual, int64_t residual_stride,
+                            const int32_t *d_resmap, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
+                            int64_t plane_stride_y, int64_t plane_stride_uv, void *stream);
+
 /* Device-to-device copy kernel (16 B/lane, grid-stride) used by bench.py to
  * calibrate the achievable HBM rate next to the fused kernel. */
 int ffhip_copy_calibrate(void *d_dst, const void *d_src, size_t bytes, void *stream);

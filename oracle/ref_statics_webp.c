@@ -34,3 +34,23 @@ void ref_vp8_residual_mb(const int16_t *levels, const uint8_t *nz, int has_y2, c
         dst += 16;
     }
 }
+
+/* Whole key-frame prediction + reconstruction through the reference's exported pred_luma /
+ * pred_chrome (format/predict.c:426-645), looped like vp8_decode (webp.c:1833-1851).
+ * The planes must be preceded by at least one readable row (the reference's 16x16 V_PRED /
+ * H_PRED read dst - stride and dst[-1], predict.c:338-353). */
+void ref_vp8_recon_frame(int mbcols, int mbrows, const uint8_t *modes, int16_t *residual, const int32_t *resmap,
+                         uint8_t *yp, uint8_t *up, uint8_t *vp)
+{
+    const int y_stride = 16 * mbcols, uv_stride = 8 * mbcols;
+    for (int y = 0; y < mbrows; y++)
+        for (int x = 0; x < mbcols; x++) {
+            const long mb = (long)y * mbcols + x;
+            int16_t *coeffs = residual + 384 * (resmap ? resmap[mb] : mb);
+            uint8_t imodes[16];
+            memcpy(imodes, modes + 20 * mb + 2, 16);
+            pred_luma(coeffs, modes[20 * mb], imodes, yp + y_stride * y * 16 + x * 16, y_stride, x, y);
+            pred_chrome(coeffs + 256, modes[20 * mb + 1], up + 8 * uv_stride * y + x * 8,
+                        vp + 8 * uv_stride * y + x * 8, uv_stride, x, y);
+        }
+}

@@ -147,6 +147,36 @@ def gen_vp8_mbs(R):
     save("vp8_mbs.npz", **res)
 
 
+def gen_vp8_frames(R):
+    """Whole key-frame intra prediction + residual add through the reference's exported
+    pred_luma / pred_chrome (format/predict.c:426-645)."""
+    res = {}
+    for tag, (c, r, seed, share) in {"a": (7, 5, 21, 0.4), "b": (3, 6, 22, 1.0), "c": (6, 3, 23, 0.0)}.items():
+        modes = synth.vp8_modes(c, r, seed, share)
+        resid = synth.vp8_residual(c * r, seed)
+        rm = np.arange(c * r, dtype=np.int32)
+        rm[3] = 2                                  # a "skipped" MB re-using the previous coefficients
+        y, u, v = O.ref_vp8_frame(c, r, modes, resid, rm)
+        res.update({f"{tag}_dims": np.array([c, r], np.int32), f"{tag}_modes": modes, f"{tag}_residual": resid,
+                    f"{tag}_resmap": rm, f"{tag}_y": y, f"{tag}_u": u, f"{tag}_v": v})
+    # every 16x16 / chroma mode at every edge position, every 4x4 mode everywhere (SURVEY 8c (vi))
+    c, r = 4, 3
+    for ym in range(4):
+        modes = synth.vp8_modes(c, r, 30 + ym, 0.0)
+        modes[:, 0] = ym
+        modes[:, 1] = ym
+        resid = synth.vp8_residual(c * r, 30 + ym)
+        y, u, v = O.ref_vp8_frame(c, r, modes, resid)
+        res.update({f"m{ym}_modes": modes, f"m{ym}_residual": resid, f"m{ym}_y": y, f"m{ym}_u": u, f"m{ym}_v": v})
+    for bm in range(10):
+        modes = synth.vp8_modes(c, r, 40 + bm, 1.0)
+        modes[:, 2:18] = bm
+        resid = synth.vp8_residual(c * r, 40 + bm)
+        y, u, v = O.ref_vp8_frame(c, r, modes, resid)
+        res.update({f"b{bm}_modes": modes, f"b{bm}_residual": resid, f"b{bm}_y": y})
+    save("vp8_frames.npz", **res)
+
+
 # ------------------------------------------------------------------ colour
 
 def fma_sensitive_triples():
@@ -266,8 +296,10 @@ def gen_grids(R):
     save("jpeg_grids.npz", **res)
 
 
-def ref_decode_file(R, path):
+def _ref_decode_file_inproc(path, out_npy):
     """Decode a file with the reference's own loader (format/file.c:30-113 -> format/jpg.c)."""
+    R = O.ref()
+
     class Pic(C.Structure):  # struct pic, format/file.h:29-40 (leading fields)
         _fields_ = [("pixels", C.c_void_p), ("left", C.c_int), ("top", C.c_int), ("width", C.c_int),
                     ("height", C.c_int), ("depth", C.c_int), ("pitch", C.c_int)]
@@ -276,14 +308,26 @@ def ref_decode_file(R, path):
     R.file_probe.argtypes = [C.c_char_p]
     R.file_load.restype = C.POINTER(Pic)
     R.file_load.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
-    if not getattr(ref_decode_file, "inited", False):
-        R.file_ops_init()
-        ref_decode_file.inited = True
+    R.file_ops_init()
     ops = R.file_probe(path.encode())
     assert ops, "reference did not recognise " + path
     p = R.file_load(ops, path.encode(), 0).contents
     buf = np.ctypeslib.as_array(C.cast(p.pixels, C.POINTER(C.c_uint8)), shape=(p.height, p.pitch)).copy()
-    return buf[:, : p.width * 4].reshape(p.height, p.width, 4)
+    np.save(out_npy, buf[:, : p.width * 4].reshape(p.height, p.width, 4))
+    os._exit(0)   # skip interpreter teardown: the reference's loader leaves the heap in a fragile state
+
+
+def ref_decode_file(R, path):
+    """Run the reference's whole-file decode in a child process (its Huffman reader overruns its
+    input at the end of some scans -- utils/bitstream.c:117 -- and can take the process down)."""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "bgra.npy")
+        for attempt in range(5):
+            rc = subprocess.call([sys.executable, os.path.abspath(__file__), "--decode", path, out],
+                                 stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            if rc == 0 and os.path.exists(out):
+                return np.load(out)
+        raise RuntimeError(f"reference could not decode {path}")
 
 
 def gen_files(R):
@@ -346,6 +390,7 @@ def main():
     R = O.ref()
     print("blocks"); gen_blocks(R)
     print("vp8 macroblocks"); gen_vp8_mbs(R)
+    print("vp8 frames"); gen_vp8_frames(R)
     print("colour"); gen_color(R)
     print("grids"); gen_grids(R)
     print("files"); gen_files(R)
@@ -353,4 +398,6 @@ def main():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) == 4 and sys.argv[1] == "--decode":
+        _ref_decode_file_inproc(sys.argv[2], sys.argv[3])
     main()

@@ -82,6 +82,7 @@ def ffo():
         L.ffo_vp8_iwht_long.argtypes = [i16p, i16p]
         L.ffo_vp8_iwht_fast.argtypes = [i16p, i16p]
         L.ffo_vp8_residual_mb.argtypes = [i16p, u8p, C.c_int, u16p, i16p]
+        L.ffo_vp8_recon_frame.argtypes = [C.c_int, C.c_int, u8p, i16p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ffo_hevc_idct_4x4_dst.argtypes = [i16p, i16p, C.c_int, C.c_int]
         L.ffo_hevc_scale.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.ffo_hevc_transform.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -113,6 +114,7 @@ def ref():
         L.ref_vp8_iwht_long.argtypes = [i16p, i16p]
         L.ref_vp8_iwht_fast.argtypes = [i16p, i16p]
         L.ref_vp8_residual_mb.argtypes = [i16p, u8p, C.c_int, u16p, i16p]
+        L.ref_vp8_recon_frame.argtypes = [C.c_int, C.c_int, u8p, i16p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.idct_4x4_hevc.argtypes = [i16p, i16p, C.c_int, C.c_bool]
         L.ref_hevc_scale.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.ref_hevc_transform.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -149,3 +151,27 @@ def ref_jpeg_recon(g, coef_y, coef_u, coef_v, quant):
     quant = np.ascontiguousarray(quant, dtype=np.uint16)
     ref().ref_jpeg_recon_image(g.as_array(), coef_y, _vp(coef_u), _vp(coef_v), quant, out.reshape(-1), W * 4)
     return out
+
+
+# ---------------------------------------------------------------- VP8 frame helpers
+
+def _vp8_frame(fn, mbcols, mbrows, modes, residual, resmap, fill=0):
+    """Run a whole-frame predict+recon; planes get one zeroed guard row in front (what the
+    reference's 16x16 V/H predictors may read at the top row / left column)."""
+    ys, uvs = 16 * mbcols, 8 * mbcols
+    yb = np.full((16 * mbrows + 1) * ys, fill, np.uint8)
+    ub = np.full((8 * mbrows + 1) * uvs, fill, np.uint8)
+    vb = np.full((8 * mbrows + 1) * uvs, fill, np.uint8)
+    yb[:ys] = 0; ub[:uvs] = 0; vb[:uvs] = 0
+    rm = None if resmap is None else np.ascontiguousarray(resmap, dtype=np.int32).ctypes.data_as(C.c_void_p)
+    fn(mbcols, mbrows, np.ascontiguousarray(modes), np.ascontiguousarray(residual).reshape(-1), rm,
+       C.c_void_p(yb.ctypes.data + ys), C.c_void_p(ub.ctypes.data + uvs), C.c_void_p(vb.ctypes.data + uvs))
+    return (yb[ys:].reshape(16 * mbrows, ys), ub[uvs:].reshape(8 * mbrows, uvs), vb[uvs:].reshape(8 * mbrows, uvs))
+
+
+def oracle_vp8_frame(mbcols, mbrows, modes, residual, resmap=None):
+    return _vp8_frame(ffo().ffo_vp8_recon_frame, mbcols, mbrows, modes, residual, resmap)
+
+
+def ref_vp8_frame(mbcols, mbrows, modes, residual, resmap=None):
+    return _vp8_frame(ref().ref_vp8_recon_frame, mbcols, mbrows, modes, residual, resmap)

@@ -73,6 +73,22 @@ def test_vp8_macroblock_residual(golden, ffo):
     assert g["syn_info"][i, 3] == 1 and g["syn_levels"][i, 3, 5] == 7
 
 
+def test_vp8_frame_prediction(golden):
+    """pred_luma / pred_chrome + residual add over whole frames: mixed modes with a skipped-MB
+    residual alias, every 16x16/chroma mode and every 4x4 mode at every edge position"""
+    g = golden("vp8_frames.npz")
+    for tag in "abc":
+        c, r = [int(x) for x in g[f"{tag}_dims"]]
+        y, u, v = O.oracle_vp8_frame(c, r, g[f"{tag}_modes"], g[f"{tag}_residual"], g[f"{tag}_resmap"])
+        assert np.array_equal(y, g[f"{tag}_y"]) and np.array_equal(u, g[f"{tag}_u"]) and np.array_equal(v, g[f"{tag}_v"]), tag
+    for ym in range(4):
+        y, u, v = O.oracle_vp8_frame(4, 3, g[f"m{ym}_modes"], g[f"m{ym}_residual"])
+        assert np.array_equal(y, g[f"m{ym}_y"]) and np.array_equal(u, g[f"m{ym}_u"]) and np.array_equal(v, g[f"m{ym}_v"]), ym
+    for bm in range(10):
+        y, _, _ = O.oracle_vp8_frame(4, 3, g[f"b{bm}_modes"], g[f"b{bm}_residual"])
+        assert np.array_equal(y, g[f"b{bm}_y"]), bm
+
+
 def test_hevc_dst4(golden, ffo):
     g = golden("hevc_dst4.npz")
     for bd in (8, 10):

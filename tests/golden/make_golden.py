@@ -343,7 +343,9 @@ def gen_files(R):
     res = {}
     for tag, kw, mode in (("q85_420", dict(quality=85, subsampling=2), "RGB"),
                           ("q92_444", dict(quality=92, subsampling=0), "RGB"),
-                          ("q75_422", dict(quality=75, subsampling=1), "RGB"),
+                          # (a 4:2:2 file is not used: the reference's own whole-file decode of small
+                          #  h2v1 pictures crashes intermittently in its Huffman reader; 4:2:2 is
+                          #  covered at grid level in jpeg_grids.npz)
                           ("q80_grey", dict(quality=80), "L")):
         im = Image.fromarray(img).convert(mode)
         if tag != "q85_420":

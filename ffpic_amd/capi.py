@@ -20,6 +20,7 @@ EXPORTS = [
     "ffhip_jpeg_kernel_name", "ffhip_copy_calibrate",
     "ffhip_yuv420_to_bgra", "ffhip_yuv420_to_bgra_16", "ffhip_yuv400_to_bgra_16",
     "ffhip_vp8_residual_batch", "ffhip_hevc_residual_batch", "ffhip_vp8_predict_recon",
+    "ffhip_hevc_intra_recon",
 ]
 
 
@@ -138,6 +139,7 @@ def lib():
     L.ffhip_yuv400_to_bgra_16.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, i64, i64, vp]
     L.ffhip_vp8_residual_batch.argtypes = [C.c_longlong, vp, vp, vp, vp, vp]
     L.ffhip_hevc_residual_batch.argtypes = [ci, C.c_longlong, vp, vp, vp, ci, ci, vp, vp]
+    L.ffhip_hevc_intra_recon.argtypes = [vp, vp, C.c_longlong, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.ffhip_vp8_predict_recon.argtypes = [ci, ci, ci, vp, vp, vp, i64, vp, vp, vp, vp, i64, i64, vp]
     _lib = L
     return L

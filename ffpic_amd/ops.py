@@ -196,3 +196,24 @@ def vp8_predict_recon(mbcols, mbrows, modes, residual, resmap=None):
                "ffhip_vp8_predict_recon")
     return (dy.to_host((n, 16 * mbrows, 16 * mbcols), np.uint8), du.to_host((n, 8 * mbrows, 8 * mbcols), np.uint8),
             dv.to_host((n, 8 * mbrows, 8 * mbcols), np.uint8))
+
+
+def hevc_intra_recon(tus, residual, width, height, chroma=True, bd_y=8, bd_c=8):
+    """decode_intra_block steps 5-10 (coding/hevc.c:4730-4790) for a TU list in decode order
+    (structured array of dtype synth.HEVC_TU_DTYPE == struct ffhip_hevc_tu); planes start at 0."""
+    L = capi.require_device()
+    tus = np.ascontiguousarray(tus)
+    assert tus.dtype.itemsize == 32
+    dt, dr = DeviceBuffer(tus.view(np.uint8)), DeviceBuffer(np.ascontiguousarray(residual))
+    cw, ch = (width // 2, height // 2) if chroma else (0, 0)
+    dy = DeviceBuffer(nbytes=width * height * 2)
+    du = DeviceBuffer(nbytes=max(cw * ch * 2, 16))
+    dv = DeviceBuffer(nbytes=max(cw * ch * 2, 16))
+    for d in (dy, du, dv):
+        capi.check(L.ffhip_memset(d.ptr, 0, d.nbytes, None))
+    capi.check(L.ffhip_hevc_intra_recon(tus.ctypes.data, dt.ptr, len(tus), dr.ptr, dy.ptr, du.ptr if chroma else None,
+                                        dv.ptr if chroma else None, width, height, width, cw, ch, cw, bd_y, bd_c, None),
+               "ffhip_hevc_intra_recon")
+    if chroma:
+        return dy.to_host((height, width), np.int16), du.to_host((ch, cw), np.int16), dv.to_host((ch, cw), np.int16)
+    return dy.to_host((height, width), np.int16), None, None

@@ -155,3 +155,73 @@ def vp8_residual(n_mb, seed=0, amplitude=40):
     r = np.rint(rng.laplace(0, amplitude / 3.0, size=(n_mb, 384))).astype(np.int16)
     r[rng.random(n_mb) < 0.2] = 0
     return r
+
+
+# ------------------------------------------------------------------ HEVC intra TU lists
+
+HEVC_TU_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2_size", "u1"), ("cidx", "u1"), ("pred_mode", "u1"),
+                          ("flags", "u1"), ("res_offset", "<u4"), ("reserved", "<u4"), ("avail_top", "<u8"),
+                          ("avail_left", "<u8")])   # == struct ffhip_hevc_tu, 32 bytes
+TU_CORNER, TU_RESIDUAL, TU_FILTER, TU_STRONG, TU_NO_BF, TU_NO_DC_BF, TU_RDPCM = 1, 2, 4, 8, 16, 32, 64
+
+
+def _quadtree(rng, x0, y0, size, min_size, max_tu, out):
+    if size > max_tu or (size > min_size and rng.random() < 0.55):
+        h = size // 2
+        for (dx, dy) in ((0, 0), (h, 0), (0, h), (h, h)):          # z-order
+            _quadtree(rng, x0 + dx, y0 + dy, h, min_size, max_tu, out)
+    else:
+        out.append((x0, y0, size))
+
+
+def hevc_intra_tus(width, height, seed=0, ctb=64, chroma=True, min_tu=4, adversarial_masks=False):
+    """A whole intra picture as a list of TUs in decode order (CTBs in raster order, z-order
+    inside a CTB; per CTB: luma TUs, then Cb, then Cr), with z-scan neighbour availability,
+    random modes 0..34 and flags.  Returns (tus structured array, residual int16 flat)."""
+    rng = np.random.default_rng(SEED_BASE + 15000 + seed)
+    assert width % ctb == 0 and height % ctb == 0
+    planes = [(width, height)] + ([(width // 2, height // 2)] * 2 if chroma else [])
+    done = [np.zeros((h, w), bool) for (w, h) in planes]
+    tus, res_parts, off = [], [], 0
+    for cy in range(0, height, ctb):
+        for cx in range(0, width, ctb):
+            for c, (pw, ph) in enumerate(planes):
+                sc = 1 if c == 0 else 2
+                parts = []
+                _quadtree(rng, cx // sc, cy // sc, ctb // sc, max(min_tu, 4), 32, parts)
+                for (x0, y0, n) in parts:
+                    d = done[c]
+                    at = al = 0
+                    for k in range(2 * n):
+                        if y0 > 0 and x0 + k < pw and d[y0 - 1, x0 + k]:
+                            at |= 1 << k
+                        if x0 > 0 and y0 + k < ph and d[y0 + k, x0 - 1]:
+                            al |= 1 << k
+                    fl = TU_CORNER if (x0 > 0 and y0 > 0 and d[y0 - 1, x0 - 1]) else 0
+                    if adversarial_masks and rng.random() < 0.3:       # arbitrary subsets of what exists
+                        at &= int(rng.integers(0, 1 << 62)) | (int(rng.integers(0, 4)) << 62)
+                        al &= int(rng.integers(0, 1 << 62)) | (int(rng.integers(0, 4)) << 62)
+                        if rng.random() < 0.5:
+                            fl = 0
+                    mode = int(rng.integers(0, 35))
+                    if rng.random() < 0.2:
+                        mode = int(rng.choice([0, 1, 10, 26, 2, 18, 34]))
+                    if c == 0 or rng.random() < 0.3:
+                        fl |= TU_FILTER
+                    fl |= TU_STRONG if rng.random() < 0.7 else 0
+                    fl |= TU_NO_BF if rng.random() < 0.15 else 0
+                    fl |= TU_NO_DC_BF if rng.random() < 0.15 else 0
+                    if rng.random() < 0.75:
+                        fl |= TU_RESIDUAL
+                        if mode in (10, 26) and rng.random() < 0.5:
+                            fl |= TU_RDPCM
+                        res_parts.append(np.rint(rng.laplace(0, 12, size=n * n)).astype(np.int16))
+                        ro = off
+                        off += n * n
+                    else:
+                        ro = 0
+                    tus.append((x0, y0, int(np.log2(n)), c, mode, fl, ro, 0, at, al))
+                    d[y0:y0 + n, x0:x0 + n] = True
+    arr = np.array(tus, dtype=HEVC_TU_DTYPE)
+    res = np.concatenate(res_parts) if res_parts else np.zeros(1, np.int16)
+    return arr, res

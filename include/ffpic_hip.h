@@ -240,6 +240,43 @@ int ffhip_vp8_predict_recon(int mbcols, int mbrows, int n_images, const uint8_t 
                             const int32_t *d_resmap, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
                             int64_t plane_stride_y, int64_t plane_stride_uv, void *stream);
 
+/* ---- HEVC intra prediction + reconstruction for a list of transform units ----
+ * decode_intra_block steps 5-10 (coding/hevc.c:4730-4790) for every TU of a picture:
+ * intra_sample_prediction (hevc.c:4542-4662: neighbour gathering, reference_sample_substitution
+ * :4277-4351, filtering_neighbouring_samples :4355-4426, hevc_intra_planar/DC/angular
+ * format/predict.c:651-792), the optional rdpcm residual modification (hevc.c:3960-3977) and
+ * construct_pic_pior_to_filtering (hevc.c:4252-4274) into int16 sample planes laid out like
+ * the reference's picture (hevc.c:7225-7230).  TUs are listed in decode order; what the
+ * reference derives while parsing (neighbour availability by z-scan order / slice / tile,
+ * hevc.c:4570-4608) arrives here as bit masks. */
+typedef struct ffhip_hevc_tu {
+    uint16_t x, y;       /* top-left of the TU in samples of its component plane           */
+    uint8_t log2_size;   /* 2..5                                                            */
+    uint8_t cidx;        /* 0 Y, 1 Cb, 2 Cr                                                 */
+    uint8_t pred_mode;   /* predModeIntra: 0 planar, 1 DC, 2..34 angular                    */
+    uint8_t flags;       /* FFHIP_TU_*                                                      */
+    uint32_t res_offset; /* element offset of the TU's residual block in d_residual         */
+    uint32_t reserved;
+    uint64_t avail_top;  /* bit k: neighbour (x+k, y-1), k = 0..2n-1, is available          */
+    uint64_t avail_left; /* bit k: neighbour (x-1, y+k) is available                        */
+} ffhip_hevc_tu;
+#define FFHIP_TU_CORNER 0x01   /* neighbour (x-1, y-1) available                             */
+#define FFHIP_TU_RESIDUAL 0x02 /* numSigCoeff != 0: add the residual block (hevc.c:4737)      */
+#define FFHIP_TU_FILTER 0x04   /* 8.4.4.2.3 applies: intra_smoothing_disabled_flag == 0 and
+                                  (cIdx == 0 or ChromaArrayType == 3)  (hevc.c:4629-4633)    */
+#define FFHIP_TU_STRONG 0x08   /* sps strong_intra_smoothing_enabled_flag                    */
+#define FFHIP_TU_NO_BF 0x10    /* disableIntraBoundaryFilter (hevc.c:4642-4648)              */
+#define FFHIP_TU_NO_DC_BF 0x20 /* intra_boundary_filtering_disabled_flag (DC edge filter)    */
+#define FFHIP_TU_RDPCM 0x40    /* residualDpcm == 1: 8.6.5 on the residual before the add    */
+/* h_tus / d_tus: the SAME n_tus records on the host (dependency scheduling) and on the device.
+ * d_residual: int16 residual blocks (row-major n*n each) as ffhip_hevc_residual_batch writes
+ * them.  Planes: int16, strides in samples; d_cb/d_cr may be NULL for 4:0:0.  Enqueues one
+ * launch per dependency level on `stream` (synchronises it once first). */
+int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu *d_tus, long long n_tus,
+                           const int16_t *d_residual, int16_t *d_y, int16_t *d_cb, int16_t *d_cr,
+                           int width_y, int height_y, int y_stride, int width_c, int height_c,
+                           int uv_stride, int bitdepth_y, int bitdepth_c, void *stream);
+
 /* Device-to-device copy kernel (16 B/lane, grid-stride) used by bench.py to
  * calibrate the achievable HBM rate next to the fused kernel. */
 int ffhip_copy_calibrate(void *d_dst, const void *d_src, size_t bytes, void *stream);

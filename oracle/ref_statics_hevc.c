@@ -55,3 +55,54 @@ void ref_hevc_transform(int16_t *d, int16_t *r, int nTbS, int luma_intra_4x4, in
     transform_scaled_coeffients(&c->sps, &c->pic, 0, 0, nTbS, luma_intra_4x4 ? 0 : 1, d, r);
     free(c);
 }
+
+/* Neighbour processing + prediction + reconstruction of one TU through the reference's own
+ * reference_sample_substitution (hevc.c:4277-4351), filtering_neighbouring_samples
+ * (hevc.c:4355-4426), hevc_intra_planar/DC/angular (format/predict.c:651-792),
+ * residual_modification_transform_bypass (hevc.c:3960-3977) and
+ * construct_pic_pior_to_filtering (hevc.c:4252-4274).  The gathering loop mirrors
+ * intra_sample_prediction (hevc.c:4570-4608) with the availability decisions supplied by the
+ * caller instead of process_zscan_order_block_availablity.
+ * flags: 1 corner, 2 residual, 4 filter, 8 strong, 16 no_bf, 32 no_dc_bf, 64 rdpcm. */
+void ref_hevc_intra_tu(int x0, int y0, int log2n, int cIdx, int predModeIntra, int flags, uint64_t avail_top,
+                       uint64_t avail_left, int16_t *res_in, int16_t *dst, int stride, int bitdepth_y, int bitdepth_c)
+{
+    struct sps *sps = calloc(1, sizeof *sps);
+    const int nTbS = 1 << log2n;
+    sps->BitDepthY = bitdepth_y;
+    sps->BitDepthC = bitdepth_c;
+    sps->strong_intra_smoothing_enabled_flag = (flags & 8) != 0;
+    int unavaible = 0;
+    int8_t unavaibleL[64] = {0}, unavaibleA[65] = {0};
+    int8_t *unavaibleT = unavaibleA + 1;
+    int16_t left_default[64] = {0};
+    int16_t top_default[65] = {0};
+    int16_t *top = top_default + 1;
+    int16_t *left = left_default;
+    for (int x = -1; x < nTbS * 2; x++) {
+        int ok = x < 0 ? (flags & 1) : (int)((avail_top >> x) & 1);
+        if (!ok) { unavaible++; unavaibleT[x] = 1; }
+        else top[x] = dst[x0 + x + (y0 - 1) * stride];
+    }
+    for (int y = 0; y < nTbS * 2; y++) {
+        if (!((avail_left >> y) & 1)) { unavaible++; unavaibleL[y] = 1; }
+        else left[y] = dst[x0 - 1 + (y0 + y) * stride];
+    }
+    if (unavaible > 0) reference_sample_substitution(sps, left, top, nTbS, cIdx, unavaible, unavaibleL, unavaibleT);
+    if (flags & 4) filtering_neighbouring_samples(sps, predModeIntra, cIdx, nTbS, left, top);
+    int16_t predSamples[64 * 64];
+    int16_t resSamples[32 * 32] = {0};
+    if (predModeIntra == INTRA_PLANAR)
+        hevc_intra_planar((uint16_t *)predSamples, (uint16_t *)left, (uint16_t *)top, nTbS, nTbS);
+    else if (predModeIntra == INTRA_DC)
+        hevc_intra_DC((uint16_t *)predSamples, (uint16_t *)left, (uint16_t *)top, nTbS, nTbS, cIdx, (flags & 32) != 0);
+    else
+        hevc_intra_angular((uint16_t *)predSamples, (uint16_t *)left, (uint16_t *)top, nTbS, nTbS, cIdx,
+                           predModeIntra, (flags & 16) != 0, sps->BitDepthY);
+    if (flags & 2) {
+        memcpy(resSamples, res_in, nTbS * nTbS * sizeof(int16_t));
+        if (flags & 64) residual_modification_transform_bypass(predModeIntra / 26, nTbS, resSamples);
+    }
+    construct_pic_pior_to_filtering(sps, x0, y0, nTbS, nTbS, cIdx, predSamples, resSamples, dst, stride);
+    free(sps);
+}

@@ -177,6 +177,22 @@ def gen_vp8_frames(R):
     save("vp8_frames.npz", **res)
 
 
+def gen_hevc_intra(R):
+    """HEVC intra prediction + reconstruction of whole TU lists through the reference's
+    reference_sample_substitution / filtering_neighbouring_samples / hevc_intra_* /
+    rdpcm / construct_pic (oracle/ref_statics_hevc.c::ref_hevc_intra_tu)."""
+    res = {}
+    for tag, (w, h, seed, adv, bd) in {"a": (128, 64, 11, False, 8), "b": (128, 128, 12, True, 8),
+                                       "c": (64, 128, 13, True, 10)}.items():
+        tus, resid = synth.hevc_intra_tus(w, h, seed, adversarial_masks=adv)
+        if bd == 10:
+            resid = (resid.astype(np.int32) * 3).astype(np.int16)
+        y, u, v = O.ref_hevc_intra(tus, resid, w, h, True, bd, bd)
+        res.update({f"{tag}_dims": np.array([w, h, bd], np.int32), f"{tag}_tus": tus.view(np.uint8).reshape(-1, 32),
+                    f"{tag}_residual": resid, f"{tag}_y": y, f"{tag}_u": u, f"{tag}_v": v})
+    save("hevc_intra.npz", **res)
+
+
 # ------------------------------------------------------------------ colour
 
 def fma_sensitive_triples():
@@ -393,6 +409,7 @@ def main():
     print("blocks"); gen_blocks(R)
     print("vp8 macroblocks"); gen_vp8_mbs(R)
     print("vp8 frames"); gen_vp8_frames(R)
+    print("hevc intra"); gen_hevc_intra(R)
     print("colour"); gen_color(R)
     print("grids"); gen_grids(R)
     print("files"); gen_files(R)

@@ -83,6 +83,8 @@ def ffo():
         L.ffo_vp8_iwht_fast.argtypes = [i16p, i16p]
         L.ffo_vp8_residual_mb.argtypes = [i16p, u8p, C.c_int, u16p, i16p]
         L.ffo_vp8_recon_frame.argtypes = [C.c_int, C.c_int, u8p, i16p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ffo_hevc_intra_tu.argtypes = [C.c_void_p, i16p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.ffo_hevc_intra_recon.argtypes = [C.c_void_p, C.c_long, i16p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ffo_hevc_idct_4x4_dst.argtypes = [i16p, i16p, C.c_int, C.c_int]
         L.ffo_hevc_scale.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.ffo_hevc_transform.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -115,6 +117,7 @@ def ref():
         L.ref_vp8_iwht_fast.argtypes = [i16p, i16p]
         L.ref_vp8_residual_mb.argtypes = [i16p, u8p, C.c_int, u16p, i16p]
         L.ref_vp8_recon_frame.argtypes = [C.c_int, C.c_int, u8p, i16p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_hevc_intra_tu.argtypes = [C.c_int] * 6 + [C.c_uint64, C.c_uint64, i16p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.idct_4x4_hevc.argtypes = [i16p, i16p, C.c_int, C.c_bool]
         L.ref_hevc_scale.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.ref_hevc_transform.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -175,3 +178,37 @@ def oracle_vp8_frame(mbcols, mbrows, modes, residual, resmap=None):
 
 def ref_vp8_frame(mbcols, mbrows, modes, residual, resmap=None):
     return _vp8_frame(ref().ref_vp8_recon_frame, mbcols, mbrows, modes, residual, resmap)
+
+
+# ---------------------------------------------------------------- HEVC intra helpers
+
+def _hevc_planes(width, height, chroma, fill=0):
+    py = np.full((height, width), fill, np.int16)
+    if chroma:
+        return py, np.full((height // 2, width // 2), fill, np.int16), np.full((height // 2, width // 2), fill, np.int16)
+    return py, np.zeros((1, 1), np.int16), np.zeros((1, 1), np.int16)
+
+
+def oracle_hevc_intra(tus, residual, width, height, chroma=True, bd_y=8, bd_c=8):
+    py, pu, pv = _hevc_planes(width, height, chroma)
+    tus = np.ascontiguousarray(tus)
+    ffo().ffo_hevc_intra_recon(tus.ctypes.data_as(C.c_void_p), len(tus), np.ascontiguousarray(residual),
+                               py.ctypes.data_as(C.c_void_p), pu.ctypes.data_as(C.c_void_p),
+                               pv.ctypes.data_as(C.c_void_p), width, max(width // 2, 1), bd_y, bd_c)
+    return py, pu, pv
+
+
+def ref_hevc_intra(tus, residual, width, height, chroma=True, bd_y=8, bd_c=8):
+    py, pu, pv = _hevc_planes(width, height, chroma)
+    R = ref()
+    planes = (py, pu, pv)
+    residual = np.ascontiguousarray(residual)
+    for t in tus:
+        pl = planes[int(t["cidx"])]
+        n = 1 << int(t["log2_size"])
+        ro = int(t["res_offset"])
+        blk = np.ascontiguousarray(residual[ro:ro + n * n]) if int(t["flags"]) & 2 else np.zeros(n * n, np.int16)
+        R.ref_hevc_intra_tu(int(t["x"]), int(t["y"]), int(t["log2_size"]), int(t["cidx"]), int(t["pred_mode"]),
+                            int(t["flags"]), int(t["avail_top"]), int(t["avail_left"]), blk,
+                            pl.ctypes.data_as(C.c_void_p), pl.shape[1], bd_y, bd_c)
+    return py, pu, pv

@@ -89,6 +89,19 @@ def test_vp8_frame_prediction(golden):
         assert np.array_equal(y, g[f"b{bm}_y"]), bm
 
 
+def test_hevc_intra_recon(golden):
+    """planar/DC/angular 2..34 x sizes 4..32 x smoothing on/off x substitution patterns, with
+    rdpcm and residual add, over whole TU lists"""
+    from ffpic_amd import synth
+    g = golden("hevc_intra.npz")
+    for tag in "abc":
+        w, h, bd = [int(x) for x in g[f"{tag}_dims"]]
+        tus = np.ascontiguousarray(g[f"{tag}_tus"]).view(synth.HEVC_TU_DTYPE).reshape(-1)
+        assert set(np.unique(tus["pred_mode"])) == set(range(35)) or len(tus) < 300
+        y, u, v = O.oracle_hevc_intra(tus, g[f"{tag}_residual"], w, h, True, bd, bd)
+        assert np.array_equal(y, g[f"{tag}_y"]) and np.array_equal(u, g[f"{tag}_u"]) and np.array_equal(v, g[f"{tag}_v"]), tag
+
+
 def test_hevc_dst4(golden, ffo):
     g = golden("hevc_dst4.npz")
     for bd in (8, 10):

@@ -21,6 +21,7 @@ EXPORTS = [
     "ffhip_yuv420_to_bgra", "ffhip_yuv420_to_bgra_16", "ffhip_yuv400_to_bgra_16",
     "ffhip_vp8_residual_batch", "ffhip_hevc_residual_batch", "ffhip_vp8_predict_recon",
     "ffhip_hevc_intra_recon",
+    "ffhip_jpeg_probe", "ffhip_jpeg_entropy_decode", "ffhip_jpeg_entropy_batch", "ffhip_bmp_write",
 ]
 
 
@@ -139,6 +140,10 @@ def lib():
     L.ffhip_yuv400_to_bgra_16.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, i64, i64, vp]
     L.ffhip_vp8_residual_batch.argtypes = [C.c_longlong, vp, vp, vp, vp, vp]
     L.ffhip_hevc_residual_batch.argtypes = [ci, C.c_longlong, vp, vp, vp, ci, ci, vp, vp]
+    L.ffhip_jpeg_probe.argtypes = [vp, sz, C.POINTER(JpegGeom), C.POINTER(ci), C.POINTER(ci)]
+    L.ffhip_jpeg_entropy_decode.argtypes = [vp, sz, C.POINTER(JpegGeom), vp, vp, vp, vp]
+    L.ffhip_jpeg_entropy_batch.argtypes = [vp, vp, ci, ci, C.POINTER(JpegGeom), vp, vp, vp, vp, vp]
+    L.ffhip_bmp_write.argtypes = [C.c_char_p, vp, ci, ci, i64]
     L.ffhip_hevc_intra_recon.argtypes = [vp, vp, C.c_longlong, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.ffhip_vp8_predict_recon.argtypes = [ci, ci, ci, vp, vp, vp, i64, vp, vp, vp, vp, i64, i64, vp]
     _lib = L

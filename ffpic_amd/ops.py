@@ -217,3 +217,38 @@ def hevc_intra_recon(tus, residual, width, height, chroma=True, bd_y=8, bd_c=8):
     if chroma:
         return dy.to_host((height, width), np.int16), du.to_host((ch, cw), np.int16), dv.to_host((ch, cw), np.int16)
     return dy.to_host((height, width), np.int16), None, None
+
+
+def jpeg_probe(data):
+    """Geometry of a baseline JPEG file (bytes) -> (JpegGeom, width, height)."""
+    L = capi.lib()
+    g, w, h = capi.JpegGeom(), C.c_int(), C.c_int()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    capi.check(L.ffhip_jpeg_probe(buf.ctypes.data, buf.size, C.byref(g), C.byref(w), C.byref(h)), "ffhip_jpeg_probe")
+    return g, w.value, h.value
+
+
+def jpeg_entropy_batch(files, n_threads=4):
+    """Host-side Huffman decode of same-geometry JPEG files (list of bytes) into the planes the
+    reconstruction reads (format/jpg.c:255-415, 588-655).  Returns (geom, cy, cu, cv, quant[n][4][64])."""
+    L = capi.lib()
+    g, _, _ = jpeg_probe(files[0])
+    n = len(files)
+    bufs = [np.frombuffer(f, dtype=np.uint8) for f in files]
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    lens = (C.c_size_t * n)(*[b.size for b in bufs])
+    cy = np.empty(n * g.y_blocks * 64, np.int16)
+    cu = np.empty(n * g.c_blocks * 64, np.int16) if g.ncomp == 3 else None
+    cv = np.empty(n * g.c_blocks * 64, np.int16) if g.ncomp == 3 else None
+    quant = np.empty((n, 4, 64), np.uint16)
+    status = (C.c_int * n)()
+    capi.check(L.ffhip_jpeg_entropy_batch(ptrs, lens, n, n_threads, C.byref(g), _vp(cy), _vp(cu), _vp(cv), _vp(quant), status),
+               "ffhip_jpeg_entropy_batch")
+    return g, cy, cu, cv, quant
+
+
+def decode_jpeg_files(files, n_threads=4):
+    """transbmp-equivalent core: files -> BGRA [n][H][W][4] (coded size), entropy on the host
+    threads, reconstruction on the GPU."""
+    g, cy, cu, cv, quant = jpeg_entropy_batch(files, n_threads)
+    return g, jpeg_recon_batch_host(g, len(files), cy, cu, cv, quant)

@@ -277,6 +277,24 @@ int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu *d_tu
                            int width_y, int height_y, int y_stride, int width_c, int height_c,
                            int uv_stride, int bitdepth_y, int bitdepth_c, void *stream);
 
+/* ---- host-side JPEG front end and BMP sink (plain C, no GPU) ----
+ * ffhip_jpeg_probe / ffhip_jpeg_entropy_decode stand where the marker loop, read_dqt,
+ * read_compressed_scan and decode_data_unit stand (format/jpg.c:78-105, 255-415, 588-655,
+ * 771-855; coding/huffman.c:92-222): a baseline / extended-sequential Huffman scan becomes the
+ * MCU-order coefficient planes and natural-order quant tables ffhip_jpeg_recon_batch reads.
+ * Progressive, arithmetic, 12-bit, non-interleaved or chroma-subsampling-other-than-1x1 files
+ * return FFHIP_EINVAL (keep the C path).  All pointers are HOST pointers. */
+int ffhip_jpeg_probe(const uint8_t *file, size_t len, ffhip_jpeg_geom *geom, int *width, int *height);
+int ffhip_jpeg_entropy_decode(const uint8_t *file, size_t len, const ffhip_jpeg_geom *expect,
+                              int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, uint16_t *quant /* [4][64] */);
+/* n files of one geometry over n_threads host threads; image i writes planes at
+ * + i*blocks*64 and quant at + i*256; status[i] receives each file's code. */
+int ffhip_jpeg_entropy_batch(const uint8_t *const *files, const size_t *lens, int n, int n_threads,
+                             const ffhip_jpeg_geom *geom, int16_t *coef_y, int16_t *coef_u,
+                             int16_t *coef_v, uint16_t *quant, int *status);
+/* display/bmpwriter.c:19-81: 54-byte header + top-down 32-bit rows; byte-identical files. */
+int ffhip_bmp_write(const char *path, const uint8_t *bgra, int width, int height, int64_t pitch);
+
 /* Device-to-device copy kernel (16 B/lane, grid-stride) used by bench.py to
  * calibrate the achievable HBM rate next to the fused kernel. */
 int ffhip_copy_calibrate(void *d_dst, const void *d_src, size_t bytes, void *stream);

@@ -1,0 +1,105 @@
+"""CPU: the C host-side JPEG front end and the BMP sink (f2).
+
+The entropy decoder must produce exactly the coefficient planes of the fixture decoder
+(tests/jpeg_entropy.py), whose planes in turn reproduce the reference's whole-file decode
+(tests/test_oracle_golden.py::test_jpeg_files_config1); the BMP writer must produce the
+bytes of the reference's display/bmpwriter.c."""
+import ctypes as C
+import io
+import os
+
+import numpy as np
+import pytest
+
+import jpeg_entropy
+import oracle_lib as O
+from conftest import GOLDEN
+from ffpic_amd import capi, ops
+from test_oracle_golden import FILES
+
+
+@pytest.mark.parametrize("tag", list(FILES))
+def test_fixture_files_match_reference_planes(tag):
+    data = open(os.path.join(GOLDEN, FILES[tag]), "rb").read()
+    dec = jpeg_entropy.decode(data)
+    g, cy, cu, cv, quant = ops.jpeg_entropy_batch([data])
+    assert (g.mcu_cols, g.mcu_rows, g.ncomp, g.h, g.v) == (dec["mcu_cols"], dec["mcu_rows"], dec["ncomp"], dec["h"], dec["v"])
+    assert tuple(g.qt_id)[:dec["ncomp"]] == tuple(dec["qt_id"])[:dec["ncomp"]]
+    assert np.array_equal(quant[0], dec["quant"])
+    assert np.array_equal(cy, dec["coef"][0])
+    if dec["ncomp"] == 3:
+        assert np.array_equal(cu, dec["coef"][1]) and np.array_equal(cv, dec["coef"][2])
+
+
+def test_restart_intervals_16bit_dqt_and_batch_threads():
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(3)
+    files = []
+    for i in range(7):
+        img = np.clip(rng.normal(128, 50, size=(96, 128, 3)), 0, 255).astype(np.uint8)
+        bio = io.BytesIO()
+        PIL.fromarray(img).save(bio, "JPEG", quality=60 + 5 * i, subsampling=2, restart_marker_blocks=5)
+        files.append(bio.getvalue())
+    assert b"\xff\xdd" in files[0]          # DRI present
+    g, cy, cu, cv, quant = ops.jpeg_entropy_batch(files, n_threads=3)
+    per = g.y_blocks * 64
+    for i, f in enumerate(files):
+        dec = jpeg_entropy.decode(f)
+        assert np.array_equal(cy[i * per:(i + 1) * per], dec["coef"][0]), i
+        assert np.array_equal(cu[i * per // 4:(i + 1) * per // 4], dec["coef"][1]), i
+        assert np.array_equal(quant[i], dec["quant"]), i
+    # one thread and many threads agree
+    g2, cy2, _, _, _ = ops.jpeg_entropy_batch(files, n_threads=16)
+    assert np.array_equal(cy, cy2)
+
+
+def test_rejects_what_it_does_not_decode():
+    PIL = pytest.importorskip("PIL.Image")
+    L = capi.lib()
+    g = capi.JpegGeom()
+    for bad in (b"", b"\xff\xd8", b"not a jpeg at all", b"\xff\xd8\xff\xd9"):
+        buf = np.frombuffer(bad + b"\0" * 8, dtype=np.uint8)
+        assert L.ffhip_jpeg_probe(buf.ctypes.data, len(bad), C.byref(g), None, None) == -22
+    bio = io.BytesIO()
+    PIL.fromarray(np.zeros((32, 32, 3), np.uint8)).save(bio, "JPEG", progressive=True)
+    buf = np.frombuffer(bio.getvalue(), dtype=np.uint8)
+    assert L.ffhip_jpeg_probe(buf.ctypes.data, buf.size, C.byref(g), None, None) == -22   # SOF2
+    # truncated scan: an error, never a crash
+    data = open(os.path.join(GOLDEN, FILES["q85_420"]), "rb").read()
+    g, w, h = ops.jpeg_probe(data)
+    cy = np.zeros(g.y_blocks * 64, np.int16); cu = np.zeros(g.c_blocks * 64, np.int16); cv = cu.copy()
+    q = np.zeros((4, 64), np.uint16)
+    cut = np.frombuffer(data[: len(data) // 2], dtype=np.uint8)
+    rc = L.ffhip_jpeg_entropy_decode(cut.ctypes.data, cut.size, None, cy.ctypes.data, cu.ctypes.data, cv.ctypes.data, q.ctypes.data)
+    assert rc in (0, -22)
+    # geometry mismatch against the batch geometry
+    other = capi.jpeg_geom(g.mcu_cols + 1, g.mcu_rows)
+    full = np.frombuffer(data, dtype=np.uint8)
+    assert L.ffhip_jpeg_entropy_decode(full.ctypes.data, full.size, C.byref(other), cy.ctypes.data, cu.ctypes.data,
+                                       cv.ctypes.data, q.ctypes.data) == -22
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="needs oracle/_ref for the reference's bmpwriter")
+def test_bmp_bytes_equal_reference_writer(tmp_path):
+    R = O.ref()
+
+    class Display(C.Structure):   # display/display.h:10-19
+        _fields_ = [("name", C.c_char_p), ("width", C.c_int), ("height", C.c_int), ("private", C.c_void_p),
+                    ("init", C.CFUNCTYPE(C.c_int, C.c_char_p, C.c_int, C.c_int)), ("uninit", C.CFUNCTYPE(C.c_int)),
+                    ("draw_pixels", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int))]
+    bw = Display.in_dll(R, "bmp_writer")
+    rng = np.random.default_rng(1)
+    w, h = 40, 24
+    px = rng.integers(0, 256, size=(h, w, 4)).astype(np.uint8)
+    title = str(tmp_path / "ref")
+    bw.init(title.encode(), w, h)
+    bw.draw_pixels(px.ctypes.data, 0, 0, w, h, 32, w * 4, 0)
+    bw.uninit()
+    mine = str(tmp_path / "mine.bmp")
+    capi.check(capi.lib().ffhip_bmp_write(mine.encode(), px.ctypes.data, w, h, w * 4))
+    assert open(mine, "rb").read() == open(title + ".bmp", "rb").read()
+    # a padded pitch writes the same file
+    padded = np.zeros((h, w + 8, 4), np.uint8)
+    padded[:, :w] = px
+    capi.check(capi.lib().ffhip_bmp_write(mine.encode(), padded.ctypes.data, w, h, (w + 8) * 4))
+    assert open(mine, "rb").read() == open(title + ".bmp", "rb").read()

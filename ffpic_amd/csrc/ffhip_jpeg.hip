@@ -39,7 +39,12 @@
 #include <errno.h>
 #include <stdlib.h>
 
+#ifndef WAVES_PER_WG
 #define WAVES_PER_WG 4
+#endif
+#ifndef FFHIP_LDS_PAD
+#define FFHIP_LDS_PAD 0 /* experiment knob: extra LDS per wave to lower occupancy */
+#endif
 #define FFHIP_JPEG_DEFAULT_VARIANT 13 /* <quads per wave><nt bits> */
 #define WG_THREADS (64 * WAVES_PER_WG)
 
@@ -50,7 +55,7 @@
 #define LDS_TB 3072   /* B terms                                             */
 #define LDS_UV 4096   /* raw (uu,vv) pairs for the fp64 fallback             */
 #define LDS_FL 5120   /* sensitivity masks, 64 x 4 B                         */
-#define LDS_WAVE_BYTES 5376
+#define LDS_WAVE_BYTES (5376 + FFHIP_LDS_PAD)
 
 #define PK16(lo, hi) ((u32)(uint16_t)(int16_t)(lo) | ((u32)(uint16_t)(int16_t)(hi) << 16))
 
@@ -64,17 +69,26 @@ __device__ __forceinline__ int dot2(u32 a, u32 b, int c)
 /* One 8-point inverse DCT with the 13-bit basis of utils/idct.c:358-367, inputs
  * as packed int16 pairs e0=(x0,x4) e1=(x2,x6) o0=(x1,x3) o1=(x5,x7); `rnd` is
  * folded into the even part.  All arithmetic mod 2^32 (== the reference's int). */
+/* dot2 with a zero accumulator as the 3-source VOP3P form (inline constant 0): hipcc would pick
+ * the 2-address v_dot2c and spend a v_mov per chain start to zero its accumulator */
+__device__ __forceinline__ int dot2z(u32 a, u32 k)
+{
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "s"(k));
+    return d;
+}
+
 __device__ __forceinline__ void idct8_1d(u32 e0, u32 e1, u32 o0, u32 o1, int rnd, int out[8])
 {
     const int ap = dot2(e0, PK16(8192, 8192), rnd);
     const int am = dot2(e0, PK16(8192, -8192), rnd);
-    const int b0 = dot2(e1, PK16(10703, 4433), 0);
-    const int b1 = dot2(e1, PK16(4433, -10704), 0);
+    const int b0 = dot2z(e1, PK16(10703, 4433));
+    const int b1 = dot2z(e1, PK16(4433, -10704));
     const int E0 = ap + b0, E3 = ap - b0, E1 = am + b1, E2 = am - b1;
-    const int O0 = dot2(o0, PK16(11363, 9633), dot2(o1, PK16(6437, 2260), 0));
-    const int O1 = dot2(o0, PK16(9633, -2259), dot2(o1, PK16(-11362, -6436), 0));
-    const int O2 = dot2(o0, PK16(6437, -11362), dot2(o1, PK16(2261, 9633), 0));
-    const int O3 = dot2(o0, PK16(2260, -6436), dot2(o1, PK16(9633, -11363), 0));
+    const int O0 = dot2(o0, PK16(11363, 9633), dot2z(o1, PK16(6437, 2260)));
+    const int O1 = dot2(o0, PK16(9633, -2259), dot2z(o1, PK16(-11362, -6436)));
+    const int O2 = dot2(o0, PK16(6437, -11362), dot2z(o1, PK16(2261, 9633)));
+    const int O3 = dot2(o0, PK16(2260, -6436), dot2z(o1, PK16(9633, -11363)));
     out[0] = E0 + O0; out[7] = E0 - O0;
     out[1] = E1 + O1; out[6] = E1 - O1;
     out[2] = E2 + O2; out[5] = E2 - O2;
@@ -136,10 +150,12 @@ __device__ __forceinline__ u32x4 idct8x8_round(const WaveCtx &c, u32x4 raw, u32x
     u32x2 ev = lds_tr_read(c, c.tr_even), od = lds_tr_read(c, c.tr_odd);
     int col[8];
     idct8_1d(ev[0], ev[1], od[0], od[1], 1 << 10, col);       /* column x = c.idx, all y */
-    u32x4 pk;                                                  /* (v >> 11) stored to int16, idct.c:522 */
+    /* (v >> 11) stored to int16 (idct.c:522): v_ashrrev_i32 issues at twice the rate of a
+     * left shift on gfx950 (tests/tools/valu_rate.hip), then one byte-permute packs the pair */
+    u32x4 pk;
 #pragma unroll
     for (int i = 0; i < 4; i++)
-        pk[i] = __builtin_amdgcn_perm((u32)col[2 * i + 1] << 5, (u32)col[2 * i] << 5, 0x07060302u);
+        pk[i] = __builtin_amdgcn_perm((u32)(col[2 * i + 1] >> 11), (u32)(col[2 * i] >> 11), 0x05040100u);
     *(u32x4 *)(c.lds + LDS_W + tile_off(c.blk, c.idx)) = pk;   /* stage B: [block][col x][y] */
     ev = lds_tr_read(c, c.tr_even);
     od = lds_tr_read(c, c.tr_odd);
@@ -188,6 +204,8 @@ struct JpegBatch {
     long long pitch, image_stride;
     int mcu_cols, mcu_rows, quads_per_row, n_images;
     int qt_y, qt_u, qt_v;
+    int quads_per_image;   /* quads_per_row * mcu_rows                                  */
+    u32 qpr_magic;         /* floor(2^32 / quads_per_row) + 1: row = mulhi(quad, magic) */
 };
 
 /* exact floor((x)/d) for the small non-negative ranges of the chroma terms:
@@ -202,12 +220,38 @@ __device__ __forceinline__ int fdiv_f32(int two_x_plus_1, float inv_2d)
  * Fused kernel, 3 components, h = v = 2.
  * ---------------------------------------------------------------------- */
 
-/* per-lane, quad-independent roles */
+/* per-lane, quad-independent roles: everything that depends on the lane only is computed
+ * once per wave so the per-quad code addresses LDS as base + compile-time constant */
 struct LaneRoles {
-    u32 row, lblk;   /* load: block lblk of the round, row `row`                  */
-    u32 st_lane;     /* store: 8 lanes = one 128-B piece of an output row          */
-    u32 ce_rd;       /* chroma entry role: e = lane = j*8 + m*2 + hf               */
+    u32 row, lblk;   /* load: block lblk of the round, row `row`                           */
+    u32 st_lane;     /* store: 8 lanes = one 128-B piece of an output row                   */
+    u32 ce_rd;       /* chroma entry role: e = lane = j*8 + m*2 + hf                        */
+    u32 yc_wr;       /* stage-C write offset of the lane's luma row (after pass 2)          */
+    u32 yc_rd;       /* stage-C read offset of the lane's 4 output pixels, + k*512          */
+    u32 term_rd;     /* term read offset, + k*512 + rnd*64                                  */
+    u32 flag_rd;     /* flag read offset, + k*128 + rnd*16                                  */
+    u32 flag_sh;     /* bit position of the lane's two flag bits                            */
+    u32 lane_m;      /* MCU (0/1) of the round the lane's output pixels belong to           */
 };
+
+__device__ __forceinline__ void lane_roles_init(LaneRoles &r, const WaveCtx &c, u32 lane, u32 pitch)
+{
+    r.row = lane & 7;
+    r.lblk = lane >> 3;
+    r.st_lane = (lane >> 3) * pitch + (lane & 7) * 16;
+    r.ce_rd = (((lane >> 1) & 3) * 8 + (lane >> 3)) * 16 + (lane & 1) * 8;
+    {   /* luma row (block c.blk = mloc*4 + vi*2 + hi, row c.idx) -> pixel row, 16-B chunk */
+        const u32 mloc = c.blk >> 2, vi = (c.blk >> 1) & 1, hi = c.blk & 1;
+        const u32 prow = vi * 8 + c.idx, chunk = mloc * 2 + hi;
+        r.yc_wr = prow * 64 + ((chunk ^ ((prow >> 1) & 3)) << 4);
+    }
+    const u32 cg = lane & 7, l3 = lane >> 3; /* output role: pixel row 8k + l3, 4-pixel group cg */
+    r.yc_rd = l3 * 64 + (((cg >> 1) ^ ((l3 >> 1) & 3)) << 4) + (cg & 1) * 8;
+    r.term_rd = (l3 >> 1) * 128 + (cg >> 2) * 32 + ((cg >> 1) & 1) * 16 + (cg & 1) * 8;
+    r.flag_rd = (l3 >> 1) * 32 + (cg >> 2) * 8 + ((cg >> 1) & 1) * 4;
+    r.flag_sh = 2 * (cg & 1);
+    r.lane_m = cg >> 2;
+}
 
 struct QuadLoads {
     u32x4 c, y0, y1;
@@ -227,7 +271,8 @@ __device__ __forceinline__ QuadLoads quad_load(const JpegBatch &p, const LaneRol
     const int last = p.mcu_cols - 1;
     const long long mcu_base = ((long long)img * p.mcu_rows + mrow) * p.mcu_cols + mcu0; /* scalar */
     u32 oc = (r.lblk & 3) * 128 + r.row * 16, oy0 = r.lblk * 128 + r.row * 16, oy1 = oy0 + 1024;
-    if (mcu0 + 3 > last) { /* ragged right edge: clamp to the last MCU (stores are masked) */
+    if (__builtin_expect(mcu0 + 3 > last, 0)) { /* ragged right edge (wave-uniform): clamp to the last MCU */
+        asm volatile("" ::: "memory");          /* keep this a real branch: the common path pays nothing    */
         const int rem = last - mcu0; /* 0..2 */
         int mc = (int)(r.lblk & 3); mc = mc > rem ? rem : mc;
         int m0 = (int)(r.lblk >> 2), m1 = m0 + 2;
@@ -277,7 +322,7 @@ __device__ __forceinline__ void quad_recon(const JpegBatch &p, const WaveCtx &c,
             const int t = 4806000 - sgm;
             const int tq = fdiv_f32(2 * t + 1, 1.0f / 2000.0f);
             const int fg = tq - 4806;
-            if (t - tq * 1000 == 0 && sgm != 0) mask |= 1u << k; /* exact-integer G: fp64 decides */
+            if (t - __mul24(tq, 1000) == 0 && sgm != 0) mask |= 1u << k; /* exact-integer G: fp64 decides */
             tr[k] = __builtin_amdgcn_perm((u32)fr, (u32)fr, 0x01000100u);
             tg[k] = __builtin_amdgcn_perm((u32)fg, (u32)fg, 0x01000100u);
             tb[k] = __builtin_amdgcn_perm((u32)fb, (u32)fb, 0x01000100u);
@@ -300,23 +345,19 @@ __device__ __forceinline__ void quad_recon(const JpegBatch &p, const WaveCtx &c,
          * output-order reads below are bank-conflict free */
         {
             const u32x4 pk = idct8x8_round(c, rnd ? ld.y1 : ld.y0, q_y);
-            const u32 mloc = c.blk >> 2, vi = (c.blk >> 1) & 1, hi = c.blk & 1;
-            const u32 prow = vi * 8 + c.idx, chunk = mloc * 2 + hi;
-            *(u32x4 *)(c.lds + LDS_W + prow * 64 + ((chunk ^ ((prow >> 1) & 3)) << 4)) = pk;
+            *(u32x4 *)(c.lds + LDS_W + r.yc_wr) = pk;
         }
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            /* output role: 8 lanes cover one 32-px row segment (128 B) */
-            const u32 prow = 8 * k + (lane >> 3), cg = lane & 7;
-            const u32 chunk = cg >> 1;
-            const u32x2 yy = *(const u32x2 *)(c.lds + LDS_W + prow * 64 +
-                                              ((chunk ^ ((prow >> 1) & 3)) << 4) + (cg & 1) * 8);
-            const u32 m = 2 * rnd + (cg >> 2), hf = (cg >> 1) & 1, pp = cg & 1;
-            const u32 e = (prow >> 1) * 8 + m * 2 + hf;
-            const u32x2 tr = *(const u32x2 *)(c.lds + LDS_TR + e * 16 + pp * 8);
-            const u32x2 tg = *(const u32x2 *)(c.lds + LDS_TG + e * 16 + pp * 8);
-            const u32x2 tb = *(const u32x2 *)(c.lds + LDS_TB + e * 16 + pp * 8);
-            const u32 fl = (*(const u32 *)(c.lds + LDS_FL + e * 4) >> (2 * pp)) & 3u;
+            /* output role: 8 lanes cover one 32-px row segment (128 B); all LDS addresses are a
+             * per-lane base (LaneRoles) plus a compile-time constant */
+            const u32x2 yy = *(const u32x2 *)(c.lds + LDS_W + k * 512 + r.yc_rd);
+            const u32 toff = k * 512 + rnd * 64 + r.term_rd;
+            const u32x2 tr = *(const u32x2 *)(c.lds + LDS_TR + toff);
+            const u32x2 tg = *(const u32x2 *)(c.lds + LDS_TG + toff);
+            const u32x2 tb = *(const u32x2 *)(c.lds + LDS_TB + toff);
+            const u32 fl = (*(const u32 *)(c.lds + LDS_FL + k * 128 + rnd * 16 + r.flag_rd) >> r.flag_sh) & 3u;
+            const u32 m = 2 * rnd + r.lane_m;
             u32x4 px;
 #pragma unroll
             for (int h2 = 0; h2 < 2; h2++) {
@@ -329,7 +370,7 @@ __device__ __forceinline__ void quad_recon(const JpegBatch &p, const WaveCtx &c,
                 px[2 * h2 + 1] = __builtin_amdgcn_perm(r2, bg, 0x0d050302u); /* b1 g1 r1 ff */
             }
             if (fl) { /* rare: exact-integer G decided by the fp64 roundings */
-                const u32x2 uvp = *(const u32x2 *)(c.lds + LDS_UV + e * 16 + pp * 8);
+                const u32x2 uvp = *(const u32x2 *)(c.lds + LDS_UV + toff);
 #pragma unroll
                 for (int h2 = 0; h2 < 2; h2++)
                     if (fl & (1u << h2)) {
@@ -364,30 +405,35 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg420_fused(JpegBatch p)
     /* wave-uniform values are forced into SGPRs: hipcc cannot prove that anything
      * derived from threadIdx is uniform and would run all the index math per lane */
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int qcol0 = (int)(blockIdx.x * WAVES_PER_WG + wave) * QPW, mrow = (int)blockIdx.y, img = (int)blockIdx.z;
-    if (qcol0 >= p.quads_per_row) return; /* wave-uniform; no barriers anywhere in this kernel */
+    /* blockIdx = (slot group, 0, image); a slot is QPW consecutive quads of the image's
+     * row-major quad sequence, so ragged rows never leave a wave idle */
+    const int qidx0 = (int)(blockIdx.x * WAVES_PER_WG + wave) * QPW, img = (int)blockIdx.z;
+    if (qidx0 >= p.quads_per_image) return; /* wave-uniform; no barriers anywhere in this kernel */
 
     WaveCtx c;
     wave_ctx_init(c, lds_all + wave * LDS_WAVE_BYTES, lane);
     LaneRoles r;
-    r.row = lane & 7;
-    r.lblk = lane >> 3;
-    r.st_lane = (lane >> 3) * (u32)p.pitch + (lane & 7) * 16;
-    r.ce_rd = (((lane >> 1) & 3) * 8 + (lane >> 3)) * 16 + (lane & 1) * 8;
+    lane_roles_init(r, c, lane, (u32)p.pitch);
 
+    int mrow[QPW], qcol[QPW];
     QuadLoads ld[QPW];
 #pragma unroll
     for (int i = 0; i < QPW; i++) {
-        int qc = qcol0 + i;
-        qc = qc < p.quads_per_row ? qc : p.quads_per_row - 1; /* duplicate load, never stored */
-        ld[i] = quad_load<NT & 1>(p, r, lane, img, mrow, qc * 4);
+        int qi = qidx0 + i;
+        qi = qi < p.quads_per_image ? qi : p.quads_per_image - 1; /* duplicate load, never stored */
+        int mr = (int)__umulhi((u32)qi, p.qpr_magic), qc = qi - mr * p.quads_per_row; /* scalar */
+        if (qc < 0) { mr--; qc += p.quads_per_row; }
+        if (qc >= p.quads_per_row) { mr++; qc -= p.quads_per_row; } /* quads_per_row == 1: magic saturates */
+        mrow[i] = mr;
+        qcol[i] = qc;
+        ld[i] = quad_load<NT & 1>(p, r, lane, img, mr, qc * 4);
     }
     const uint16_t *qt = p.quant + (long long)img * p.quant_stride;
     const u32x4 q_y = *(const u32x4 *)(qt + p.qt_y * 64 + r.row * 8);
     const u32x4 q_c = *(const u32x4 *)(qt + (lane < 32 ? p.qt_u : p.qt_v) * 64 + r.row * 8);
 #pragma unroll
     for (int i = 0; i < QPW; i++)
-        if (qcol0 + i < p.quads_per_row) quad_recon<NT>(p, c, r, lane, ld[i], q_y, q_c, img, mrow, (qcol0 + i) * 4);
+        if (qidx0 + i < p.quads_per_image) quad_recon<NT>(p, c, r, lane, ld[i], q_y, q_c, img, mrow[i], qcol[i] * 4);
 }
 
 /* ------------------------------------------------------------------------
@@ -493,7 +539,8 @@ static void launch_fused(const JpegBatch &q, int n_images, hipStream_t st)
                                                                                  : FFHIP_JPEG_DEFAULT_VARIANT;
     }
     const int qpw = g_variant / 10;
-    const dim3 grid((q.quads_per_row + WAVES_PER_WG * qpw - 1) / (WAVES_PER_WG * qpw), q.mcu_rows, n_images);
+    const int slots = (q.quads_per_image + qpw - 1) / qpw;
+    const dim3 grid((slots + WAVES_PER_WG - 1) / WAVES_PER_WG, 1, n_images);
 #define FFHIP_LAUNCH(Q, N) hipLaunchKernelGGL((k_jpeg420_fused<Q, N>), grid, dim3(WG_THREADS), 0, st, q)
     switch (g_variant) {
     case 10: FFHIP_LAUNCH(1, 0); break;
@@ -560,9 +607,12 @@ extern "C" int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *g, int n_images, co
         p.bgra = d_bgra; p.pitch = pitch; p.image_stride = image_stride;
         p.mcu_cols = g->mcu_cols; p.mcu_rows = g->mcu_rows;
         p.quads_per_row = (g->mcu_cols + 3) / 4; p.n_images = n_images;
+        p.quads_per_image = p.quads_per_row * g->mcu_rows;
+        p.qpr_magic = p.quads_per_row == 1 ? 0xffffffffu : (u32)(0x100000000ULL / (unsigned)p.quads_per_row) + 1u;
         p.qt_y = g->qt_id[0]; p.qt_u = g->qt_id[1]; p.qt_v = g->qt_id[2];
         long long quads = (long long)p.quads_per_row * p.mcu_rows * n_images;
-        if (quads > 0x7fffffffLL || pitch * 16 > 0x7fffffffLL || g->mcu_rows > 65535) return FFHIP_EINVAL;
+        if (quads > 0x7fffffffLL || pitch * 16 > 0x7fffffffLL || p.quads_per_image > (1 << 20) || p.quads_per_row > 4096)
+            return FFHIP_EINVAL;
         /* grid.z carries the image index (<= 65535 per launch) */
         for (int first = 0; first < n_images; first += 65535) {
             const int cnt = n_images - first < 65535 ? n_images - first : 65535;

@@ -233,3 +233,22 @@ def test_end_to_end_file_to_bgra(golden, tag, tmp_path):
     capi.check(capi.lib().ffhip_bmp_write(path.encode(), full.ctypes.data, W, H, full.shape[1] * 4))
     raw = open(path, "rb").read()
     assert len(raw) == 54 + W * H * 4 and raw[:2] == b"BM" and raw[54:54 + 16] == img[0, :4].tobytes()
+
+
+def test_c_host_program_transbmp(golden, tmp_path):
+    """examples/transbmp_hip.c: the whole file -> BMP flow from plain C through the C ABI."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "transbmp_hip")
+    subprocess.check_call(["gcc", "-std=c11", "-O2", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "transbmp_hip.c"), "-L" + os.path.join(root, "ffpic_amd"),
+                           "-lffpic_hip", "-Wl,-rpath," + os.path.join(root, "ffpic_amd"), "-o", exe])
+    src = str(tmp_path / "pic.jpg")
+    shutil.copy(os.path.join(root, "tests", "golden", FILES["q85_420"]), src)
+    out = subprocess.run([exe, src], capture_output=True, text=True, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr
+    bmp = open(src + " (640 * 480).bmp", "rb").read()
+    assert len(bmp) == 54 + 640 * 480 * 4
+    g = golden("jpeg_files.npz")
+    assert hashlib.sha256(bmp[54:]).digest() == g["q85_420_sha256"].tobytes()   # == the reference's decode of the file

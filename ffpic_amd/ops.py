@@ -252,3 +252,16 @@ def decode_jpeg_files(files, n_threads=4):
     threads, reconstruction on the GPU."""
     g, cy, cu, cv, quant = jpeg_entropy_batch(files, n_threads)
     return g, jpeg_recon_batch_host(g, len(files), cy, cu, cv, quant)
+
+
+def vp8_loopfilter(mbcols, mbrows, filter_type, modes, filters, y, u, v):
+    """loopfilter over whole key frames (format/webp.c:1686-1752, 1856-1866); planes uint8
+    [n][H][W] are filtered and returned."""
+    L = capi.require_device()
+    n = modes.shape[0]
+    dm, df = DeviceBuffer(np.ascontiguousarray(modes)), DeviceBuffer(np.ascontiguousarray(filters))
+    dy, du, dv = DeviceBuffer(np.ascontiguousarray(y)), DeviceBuffer(np.ascontiguousarray(u)), DeviceBuffer(np.ascontiguousarray(v))
+    n_mb = mbcols * mbrows
+    capi.check(L.ffhip_vp8_loopfilter(mbcols, mbrows, n, filter_type, dm.ptr, df.ptr, dy.ptr, du.ptr, dv.ptr,
+                                      256 * n_mb, 64 * n_mb, None), "ffhip_vp8_loopfilter")
+    return dy.to_host(y.shape, np.uint8), du.to_host(u.shape, np.uint8), dv.to_host(v.shape, np.uint8)

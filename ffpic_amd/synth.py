@@ -225,3 +225,37 @@ def hevc_intra_tus(width, height, seed=0, ctb=64, chroma=True, min_tu=4, adversa
     arr = np.array(tus, dtype=HEVC_TU_DTYPE)
     res = np.concatenate(res_parts) if res_parts else np.zeros(1, np.int16)
     return arr, res
+
+
+def vp8_filters(seed=0):
+    """[4 segments][2 (i16 / i4x4)][3] uint8 = sub_limit, inter_limit, hev_thresh the way
+    calculate_filter_control_parameter (format/webp.c:1756-1803) derives them from a level."""
+    rng = np.random.default_rng(SEED_BASE + 13000 + seed)
+    f = np.zeros((4, 2, 3), dtype=np.uint8)
+    sharp = int(rng.integers(0, 8))
+    for s in range(4):
+        for k in range(2):
+            level = int(rng.integers(0, 64)) if rng.random() < 0.9 else 0
+            if level > 0:
+                il = level
+                if sharp > 0:
+                    il >>= 2 if sharp > 4 else 1
+                    il = min(il, 9 - sharp)
+                il = max(il, 1)
+                f[s, k] = [(level << 1) + il, il, 2 if level >= 40 else (1 if level >= 15 else 0)]
+    return f
+
+
+def vp8_blocky_planes(mbcols, mbrows, seed=0):
+    """Reconstructed-looking 8-bit planes (smooth ramp + per-4x4-block offsets + light noise) on
+    which both the simple and the normal VP8 loop filter fire often."""
+    rng = np.random.default_rng(SEED_BASE + 14000 + seed)
+    out = []
+    for (h, w) in ((16 * mbrows, 16 * mbcols), (8 * mbrows, 8 * mbcols), (8 * mbrows, 8 * mbcols)):
+        yy, xx = np.mgrid[0:h, 0:w]
+        ramp = 60 + 120 * (xx / max(w - 1, 1)) * (yy / max(h - 1, 1)) + 30 * np.sin(xx / 9.0)
+        blk = rng.integers(-9, 10, size=(h // 4 + 1, w // 4 + 1))[yy // 4, xx // 4]
+        mbo = rng.integers(-14, 15, size=(h // 16 + 1, w // 16 + 1))[yy // 16, xx // 16]
+        noise = rng.integers(-1, 2, size=(h, w))
+        out.append(np.clip(ramp + blk + mbo + noise, 0, 255).astype(np.uint8))
+    return out

@@ -198,6 +198,19 @@ int ffhip_yuv400_to_bgra_16(uint8_t *d_bgra, int pitch, const int16_t *d_y, int 
 int ffhip_vp8_residual_batch(long long n_mb, const int16_t *d_levels, const uint8_t *d_mbinfo,
                              const uint16_t *d_quant, int16_t *d_residual, void *stream);
 
+/* ---- VP8 in-loop deblocking filter for batches of key frames ----
+ * The second MB loop of vp8_decode (format/webp.c:1856-1866): loopfilter() (webp.c:1686-1752)
+ * with its simple and normal filters (webp.c:1480-1684) on the 8-bit Y/U/V planes that
+ * ffhip_vp8_predict_recon wrote, before ffhip_yuv420_to_bgra.
+ *   filter_type  0 none, 1 simple, 2 normal  (webp.c:1852-1853)
+ *   d_modes      the same [n_images][n_mb][20] records; [0] intra_y_mode, [18] segment_id
+ *   d_filters    uint8 [4 segments][2 (i16x16, i4x4)][3] = sub_limit, inter_limit, hev_thresh
+ *                (struct vp8_filter as calculate_filter_control_parameter leaves it,
+ *                webp.c:1756-1803, format/webp.h:289-293) */
+int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int filter_type, const uint8_t *d_modes,
+                         const uint8_t *d_filters, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
+                         int64_t plane_stride_y, int64_t plane_stride_uv, void *stream);
+
 /* ---- HEVC residual stage, batched over transform units of one size ----
  * For n_tu TUs of size nTbS x nTbS (4, 8, 16 or 32): scale_transform_coefficients
  * (coding/hevc.c:3743-3816) followed by transform_scaled_coeffients (hevc.c:3888-3956,

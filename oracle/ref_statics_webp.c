@@ -54,3 +54,30 @@ void ref_vp8_recon_frame(int mbcols, int mbrows, const uint8_t *modes, int16_t *
                         vp + 8 * uv_stride * y + x * 8, uv_stride, x, y);
         }
 }
+
+/* Whole-frame in-loop filter through the reference's static loopfilter() (webp.c:1686-1752),
+ * looped like vp8_decode (webp.c:1856-1866).  filters: [4][2][3] = sub_limit, inter_limit,
+ * hev_thresh as calculate_filter_control_parameter (webp.c:1756-1803) would have left them. */
+void ref_vp8_loopfilter_frame(int mbcols, int mbrows, int filter_type, const uint8_t *modes, const uint8_t *filters,
+                              uint8_t *yp, uint8_t *up, uint8_t *vp)
+{
+    WEBP *w = calloc(1, sizeof *w);
+    const int y_stride = 16 * mbcols, uv_stride = 8 * mbcols;
+    for (int s = 0; s < 4; s++)
+        for (int k = 0; k < 2; k++) {
+            w->filters[s][k].sub_limit = filters[(s * 2 + k) * 3];
+            w->filters[s][k].inter_limit = filters[(s * 2 + k) * 3 + 1];
+            w->filters[s][k].hev_thresh = filters[(s * 2 + k) * 3 + 2];
+        }
+    for (int y = 0; y < mbrows; y++)
+        for (int x = 0; x < mbcols; x++) {
+            struct macro_block b;
+            memset(&b, 0, sizeof b);
+            b.intra_y_mode = modes[20 * (y * mbcols + x)];
+            b.segment_id = modes[20 * (y * mbcols + x) + 18] & 3;
+            b.x = x;
+            loopfilter(w, &b, filter_type, y, yp + y_stride * y * 16 + x * 16, up + 8 * uv_stride * y + x * 8,
+                       vp + 8 * uv_stride * y + x * 8, y_stride, uv_stride);
+        }
+    free(w);
+}

@@ -193,6 +193,25 @@ def gen_hevc_intra(R):
     save("hevc_intra.npz", **res)
 
 
+def gen_vp8_loopfilter(R):
+    """VP8 simple + normal in-loop filter over whole frames through the reference's static
+    loopfilter() (oracle/ref_statics_webp.c::ref_vp8_loopfilter_frame)."""
+    res = {}
+    rng = np.random.default_rng(77)
+    for tag, (c, r, seed) in {"a": (6, 5, 51), "b": (9, 4, 52)}.items():
+        modes = synth.vp8_modes(c, r, seed)
+        modes[:, 18] = rng.integers(0, 4, size=c * r)
+        filt = synth.vp8_filters(seed)
+        base = synth.vp8_blocky_planes(c, r, seed)
+        res.update({f"{tag}_dims": np.array([c, r], np.int32), f"{tag}_modes": modes, f"{tag}_filters": filt,
+                    f"{tag}_y": base[0], f"{tag}_u": base[1], f"{tag}_v": base[2]})
+        for ft in (1, 2):
+            p = [b.copy() for b in base]
+            R.ref_vp8_loopfilter_frame(c, r, ft, modes.reshape(-1), filt.reshape(-1), p[0].reshape(-1), p[1].reshape(-1), p[2].reshape(-1))
+            res.update({f"{tag}_f{ft}_y": p[0], f"{tag}_f{ft}_u": p[1], f"{tag}_f{ft}_v": p[2]})
+    save("vp8_loopfilter.npz", **res)
+
+
 # ------------------------------------------------------------------ colour
 
 def fma_sensitive_triples():
@@ -410,6 +429,7 @@ def main():
     print("vp8 macroblocks"); gen_vp8_mbs(R)
     print("vp8 frames"); gen_vp8_frames(R)
     print("hevc intra"); gen_hevc_intra(R)
+    print("vp8 loop filter"); gen_vp8_loopfilter(R)
     print("colour"); gen_color(R)
     print("grids"); gen_grids(R)
     print("files"); gen_files(R)

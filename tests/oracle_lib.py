@@ -83,6 +83,7 @@ def ffo():
         L.ffo_vp8_iwht_fast.argtypes = [i16p, i16p]
         L.ffo_vp8_residual_mb.argtypes = [i16p, u8p, C.c_int, u16p, i16p]
         L.ffo_vp8_recon_frame.argtypes = [C.c_int, C.c_int, u8p, i16p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ffo_vp8_loopfilter_frame.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, u8p, u8p, u8p]
         L.ffo_hevc_intra_tu.argtypes = [C.c_void_p, i16p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.ffo_hevc_intra_recon.argtypes = [C.c_void_p, C.c_long, i16p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ffo_hevc_idct_4x4_dst.argtypes = [i16p, i16p, C.c_int, C.c_int]
@@ -117,6 +118,7 @@ def ref():
         L.ref_vp8_iwht_fast.argtypes = [i16p, i16p]
         L.ref_vp8_residual_mb.argtypes = [i16p, u8p, C.c_int, u16p, i16p]
         L.ref_vp8_recon_frame.argtypes = [C.c_int, C.c_int, u8p, i16p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_vp8_loopfilter_frame.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, u8p, u8p, u8p]
         L.ref_hevc_intra_tu.argtypes = [C.c_int] * 6 + [C.c_uint64, C.c_uint64, i16p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.idct_4x4_hevc.argtypes = [i16p, i16p, C.c_int, C.c_bool]
         L.ref_hevc_scale.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]

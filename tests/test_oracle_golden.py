@@ -102,6 +102,19 @@ def test_hevc_intra_recon(golden):
         assert np.array_equal(y, g[f"{tag}_y"]) and np.array_equal(u, g[f"{tag}_u"]) and np.array_equal(v, g[f"{tag}_v"]), tag
 
 
+def test_vp8_loopfilter(golden, ffo):
+    g = golden("vp8_loopfilter.npz")
+    for tag in "ab":
+        c, r = [int(x) for x in g[f"{tag}_dims"]]
+        for ft in (1, 2):
+            p = [g[f"{tag}_{k}"].copy() for k in "yuv"]
+            ffo.ffo_vp8_loopfilter_frame(c, r, ft, g[f"{tag}_modes"].reshape(-1), g[f"{tag}_filters"].reshape(-1),
+                                         p[0].reshape(-1), p[1].reshape(-1), p[2].reshape(-1))
+            for k, pl in zip("yuv", p):
+                assert np.array_equal(pl, g[f"{tag}_f{ft}_{k}"]), (tag, ft, k)
+            assert (p[0] != g[f"{tag}_y"]).mean() > 0.05          # the filters really fire on this data
+
+
 def test_hevc_dst4(golden, ffo):
     g = golden("hevc_dst4.npz")
     for bd in (8, 10):

@@ -1,0 +1,75 @@
+"""GPU: VP8 in-loop filter against goldens and the oracle, and the whole
+WebP post-entropy chain residual -> predict -> loop filter -> colour against the oracle chain."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from ffpic_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_lf(c, r, ft, modes, filt, planes):
+    p = [np.ascontiguousarray(x).copy() for x in planes]
+    O.ffo().ffo_vp8_loopfilter_frame(c, r, ft, np.ascontiguousarray(modes).reshape(-1), np.ascontiguousarray(filt).reshape(-1),
+                                     p[0].reshape(-1), p[1].reshape(-1), p[2].reshape(-1))
+    return p
+
+
+def test_golden(golden):
+    g = golden("vp8_loopfilter.npz")
+    for tag in "ab":
+        c, r = [int(x) for x in g[f"{tag}_dims"]]
+        for ft in (1, 2):
+            got = ops.vp8_loopfilter(c, r, ft, g[f"{tag}_modes"][None], g[f"{tag}_filters"], g[f"{tag}_y"][None],
+                                     g[f"{tag}_u"][None], g[f"{tag}_v"][None])
+            for k, pl in zip("yuv", got):
+                assert np.array_equal(pl[0], g[f"{tag}_f{ft}_{k}"]), (tag, ft, k)
+
+
+@pytest.mark.parametrize("c,r,ft", [(1, 1, 1), (1, 1, 2), (2, 3, 2), (17, 9, 1), (17, 9, 2), (120, 68, 2)])
+def test_vs_oracle(c, r, ft):
+    rng = np.random.default_rng(c * 10 + r)
+    modes = synth.vp8_modes(c, r, seed=c)
+    modes[:, 18] = rng.integers(0, 4, size=c * r)
+    filt = synth.vp8_filters(seed=c + r)
+    base = synth.vp8_blocky_planes(c, r, seed=r)
+    got = ops.vp8_loopfilter(c, r, ft, modes[None], filt, base[0][None], base[1][None], base[2][None])
+    exp = oracle_lf(c, r, ft, modes, filt, base)
+    for gp, e in zip(got, exp):
+        assert np.array_equal(gp[0], e)
+    if ft == 0:
+        assert np.array_equal(got[0][0], base[0])
+
+
+def test_webp_chain_batch():
+    """levels -> residual -> intra predict/recon -> loop filter -> BGRA for 3 frames, every stage on
+    the GPU, against the same chain of oracle functions"""
+    c, r, n = 10, 7, 3
+    n_mb = c * r
+    q = synth.vp8_quant(seed=2)
+    filt = synth.vp8_filters(seed=2)
+    frames = []
+    for i in range(n):
+        lv, info = synth.vp8_macroblocks(n_mb, seed=100 + i)
+        modes = synth.vp8_modes(c, r, seed=100 + i)
+        modes[:, 18] = info[:, 26]
+        info[:, 25] = modes[:, 0] != 4            # Y2 exactly when the MB is not B_PRED
+        frames.append((lv, info, modes))
+    res_gpu = [ops.vp8_residual_batch(lv, info, q) for lv, info, _ in frames]
+    modes = np.stack([f[2] for f in frames])
+    y, u, v = ops.vp8_predict_recon(c, r, modes, np.stack(res_gpu))
+    y, u, v = ops.vp8_loopfilter(c, r, 2, modes, filt, y, u, v)
+    bgra = ops.yuv420_to_bgra(y, u, v, r, c)
+    F = O.ffo()
+    for i, (lv, info, m) in enumerate(frames):
+        res = np.zeros((n_mb, 384), np.int16)
+        for k in range(n_mb):
+            F.ffo_vp8_residual_mb(np.ascontiguousarray(lv[k]).reshape(-1), info[k], int(info[k, 25]),
+                                  np.ascontiguousarray(q[info[k, 26], :6]), res[k])
+        planes = O.oracle_vp8_frame(c, r, m, res)
+        planes = oracle_lf(c, r, 2, m, filt, planes)
+        out = np.zeros((16 * r, 16 * c * 4), np.uint8)
+        F.ffo_yuv420_to_bgra32(out.reshape(-1), 16 * c * 4, planes[0].reshape(-1), planes[1].reshape(-1),
+                               planes[2].reshape(-1), 16 * c, 8 * c, r, c)
+        assert np.array_equal(bgra[i], out), i

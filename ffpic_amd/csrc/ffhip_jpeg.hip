@@ -206,6 +206,9 @@ struct JpegBatch {
     int qt_y, qt_u, qt_v;
     int quads_per_image;   /* quads_per_row * mcu_rows                                  */
     u32 qpr_magic;         /* floor(2^32 / quads_per_row) + 1: row = mulhi(quad, magic) */
+    int wgs_per_image;     /* workgroups that cover one image                            */
+    u32 wpi_magic;         /* same trick for image = workgroup / wgs_per_image          */
+    int xcd_remap;         /* 1: give each XCD a contiguous chunk of the workgroup sequence */
 };
 
 /* exact floor((x)/d) for the small non-negative ranges of the chroma terms:
@@ -405,9 +408,21 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg420_fused(JpegBatch p)
     /* wave-uniform values are forced into SGPRs: hipcc cannot prove that anything
      * derived from threadIdx is uniform and would run all the index math per lane */
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    /* blockIdx = (slot group, 0, image); a slot is QPW consecutive quads of the image's
-     * row-major quad sequence, so ragged rows never leave a wave idle */
-    const int qidx0 = (int)(blockIdx.x * WAVES_PER_WG + wave) * QPW, img = (int)blockIdx.z;
+    /* 1-D grid over (image, slot group); a slot is QPW consecutive quads of the image's row-major
+     * quad sequence.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), so
+     * the linear id is remapped to give every XCD one contiguous chunk of the sequence: the
+     * pieces of an output row then come from one XCD back to back instead of from eight at
+     * different times (+6 % on the memory-only pattern, tests/tools/membench_jpeg.hip).
+     * Speed only: any placement computes the same bytes. */
+    u32 wg;
+    {
+        const u32 nb = gridDim.x, b = blockIdx.x, base = nb >> 3, extra = nb & 7, xcd = b & 7;
+        wg = p.xcd_remap ? xcd * base + (xcd < extra ? xcd : extra) + (b >> 3) : b;
+    }
+    int img = (int)__umulhi(wg, p.wpi_magic), wgi = (int)wg - img * p.wgs_per_image; /* scalar */
+    if (wgi < 0) { img--; wgi += p.wgs_per_image; }
+    if (wgi >= p.wgs_per_image) { img++; wgi -= p.wgs_per_image; }
+    const int qidx0 = (int)((u32)wgi * WAVES_PER_WG + wave) * QPW;
     if (qidx0 >= p.quads_per_image) return; /* wave-uniform; no barriers anywhere in this kernel */
 
     WaveCtx c;
@@ -531,7 +546,7 @@ static int geom_ok(const ffhip_jpeg_geom *g)
 /* kernel variant: quads per wave and cache policy.  FFHIP_JPEG_VARIANT="<qpw><nt>" (e.g. "21")
  * overrides the default for experiments; every variant computes identical bytes. */
 static int g_variant = -1;
-static void launch_fused(const JpegBatch &q, int n_images, hipStream_t st)
+static void launch_fused(const JpegBatch &q_in, int n_images, hipStream_t st)
 {
     if (g_variant < 0) {
         const char *e = getenv("FFHIP_JPEG_VARIANT");
@@ -539,8 +554,14 @@ static void launch_fused(const JpegBatch &q, int n_images, hipStream_t st)
                                                                                  : FFHIP_JPEG_DEFAULT_VARIANT;
     }
     const int qpw = g_variant / 10;
+    JpegBatch q = q_in;
+    static int remap = -1;
+    if (remap < 0) remap = getenv("FFHIP_JPEG_NO_XCD_REMAP") ? 0 : 1; /* A/B knob; identical bytes either way */
+    q.xcd_remap = remap;
     const int slots = (q.quads_per_image + qpw - 1) / qpw;
-    const dim3 grid((slots + WAVES_PER_WG - 1) / WAVES_PER_WG, 1, n_images);
+    q.wgs_per_image = (slots + WAVES_PER_WG - 1) / WAVES_PER_WG;
+    q.wpi_magic = q.wgs_per_image == 1 ? 0xffffffffu : (u32)(0x100000000ULL / (unsigned)q.wgs_per_image) + 1u;
+    const dim3 grid((unsigned)((long long)q.wgs_per_image * n_images), 1, 1);
 #define FFHIP_LAUNCH(Q, N) hipLaunchKernelGGL((k_jpeg420_fused<Q, N>), grid, dim3(WG_THREADS), 0, st, q)
     switch (g_variant) {
     case 10: FFHIP_LAUNCH(1, 0); break;
@@ -613,9 +634,9 @@ extern "C" int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *g, int n_images, co
         long long quads = (long long)p.quads_per_row * p.mcu_rows * n_images;
         if (quads > 0x7fffffffLL || pitch * 16 > 0x7fffffffLL || p.quads_per_image > (1 << 20) || p.quads_per_row > 4096)
             return FFHIP_EINVAL;
-        /* grid.z carries the image index (<= 65535 per launch) */
-        for (int first = 0; first < n_images; first += 65535) {
-            const int cnt = n_images - first < 65535 ? n_images - first : 65535;
+        const int max_imgs = (int)(0x7fffffffLL / ((p.quads_per_image + WAVES_PER_WG - 1) / WAVES_PER_WG));
+        for (int first = 0; first < n_images; first += max_imgs) {
+            const int cnt = n_images - first < max_imgs ? n_images - first : max_imgs;
             JpegBatch q = p;
             const long long mcus = (long long)g->mcu_cols * g->mcu_rows;
             q.coef_y += (long long)first * mcus * 256;

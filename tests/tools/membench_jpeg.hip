@@ -8,7 +8,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int PAT>
 __global__ __launch_bounds__(256) void k(const char* y, const char* u, const char* v, char* out, int qpr, int rows, long pitch) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int q = blockIdx.x * 4 + wave; const int img = blockIdx.z;
+  int bid = blockIdx.x;
+  if (PAT == 4 || PAT == 5) { /* XCD-aware: blocks b, b+8, ... share an XCD; give each XCD a contiguous chunk */
+    const int nb = gridDim.x, per = (nb + 7) / 8;
+    bid = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (bid >= nb) return;   /* (only exact when nb % 8 == 0; good enough for the experiment) */
+  }
+  int q = bid * 4 + wave; const int img = blockIdx.z;
   if (q >= qpr * rows) return;
   int mrow = q / qpr, qcol = q - mrow * qpr;
   if (PAT == 2) { /* the 4 waves of a workgroup take the same quad column of 4 consecutive MCU rows */
@@ -20,7 +26,7 @@ __global__ __launch_bounds__(256) void k(const char* y, const char* u, const cha
   const u32x4 c = __builtin_nontemporal_load((const u32x4*)((lane < 32 ? u : v) + mcu * 128 + (lane & 31) * 16));
   char* o = out + (long)img * pitch * rows * 16 + (long)mrow * 16 * pitch + (long)qcol * 256;
   const u32x4 s = a ^ b ^ c;
-  if (PAT == 1) { /* 4 rows x 256 B per store instruction */
+  if (PAT == 1 || PAT == 5) { /* 4 rows x 256 B per store instruction */
 #pragma unroll
     for (int kk = 0; kk < 4; kk++)
       __builtin_nontemporal_store(s + (unsigned)kk, (u32x4*)(o + (long)(kk * 4 + (lane >> 4)) * pitch + (lane & 15) * 16));
@@ -55,6 +61,8 @@ int main() {
     RUN(1, ((qpr * rows + 3) / 4, 1, n), "B: 4 rows x 256 B nt stores");
     RUN(2, (qpr * ((rows + 3) / 4), 1, n), "C: WG = 4 MCU rows of one quad column");
     RUN(3, ((qpr * rows + 3) / 4, 1, n), "D: plain stores");
+    RUN(4, ((qpr * rows + 3) / 4, 1, n), "E: XCD-contiguous chunks, nt stores");
+    RUN(5, ((qpr * rows + 3) / 4, 1, n), "F: XCD-contiguous + 256 B rows");
   }
   return 0;
 }

@@ -6,6 +6,38 @@
  * exports thin wrappers around its `static` hot-path functions
  * IWHT_long / IWHT_fast (webp.c:1067-1106).
  */
+#include <stdlib.h>
+#include <string.h>
+
+/* The reference's 16x16 V_PRED / H_PRED read raw memory above / left of the luma plane
+ * (format/predict.c:338-353) and its planes come from plain malloc (webp.c:1818-1821), so what a
+ * whole-file decode shows at the top row / left column depends on heap contents.  To make the
+ * reference deterministic for fixture generation, the picture planes allocated by vp8_decode
+ * are zero-filled and preceded by 8 KiB of zeros -- the same convention the batched API documents
+ * ("bytes before a plane read as 0").  Pure build-recipe plumbing: no reference source is changed. */
+#define REF_GUARD 8192
+/* only the picture planes of vp8_decode (webp.c:1819-1822: w->data, Y, U, V) are guarded; every
+ * other allocation of the file keeps the real malloc/free because other translation units free
+ * them (the bool decoder's buffers, webp.c:1890,1906 -> coding/booldec.c) */
+static void *ref_malloc_at(size_t n, int line)
+{
+    if (line >= 1819 && line <= 1822) {
+        char *p = calloc(1, n + REF_GUARD);
+        return p ? p + REF_GUARD : NULL;
+    }
+    return malloc(n);
+}
+static void ref_free_at(void *p, int line)
+{
+    if (line == 2088) { /* WEBP_free: free(w->data) */
+        if (p) free((char *)p - REF_GUARD);
+        return;
+    }
+    free(p);
+}
+#define malloc(n) ref_malloc_at(n, __LINE__)
+#define free(p) ref_free_at(p, __LINE__)
+
 #include "webp.c" /* the reference's format/webp.c */
 
 void ref_vp8_iwht_long(const int16_t *in, int16_t *out) { IWHT_long(in, out); }
@@ -80,4 +112,21 @@ void ref_vp8_loopfilter_frame(int mbcols, int mbrows, int filter_type, const uin
                        vp + 8 * uv_stride * y + x * 8, y_stride, uv_stride);
         }
     free(w);
+}
+
+/* Loop-filter state of a decoded WEBP (struct pic.pic of WEBP_load, webp.c:2002-2005): out[0] =
+ * loop_filter_level, out[1] = filter_type bit, out[2] = segmentation_enabled, out[3..26] =
+ * filters[4][2] {sub_limit, inter_limit, hev_thresh} (webp.c:1756-1803). */
+void ref_webp_filter_info(void *wp, int *out)
+{
+    WEBP *w = wp;
+    out[0] = w->k.loop_filter_level;
+    out[1] = w->k.filter_type;
+    out[2] = w->k.segmentation.segmentation_enabled;
+    for (int s = 0; s < 4; s++)
+        for (int k = 0; k < 2; k++) {
+            out[3 + (s * 2 + k) * 3] = w->filters[s][k].sub_limit;
+            out[4 + (s * 2 + k) * 3] = w->filters[s][k].inter_limit;
+            out[5 + (s * 2 + k) * 3] = w->filters[s][k].hev_thresh;
+        }
 }

@@ -352,6 +352,79 @@ def _ref_decode_file_inproc(path, out_npy):
     os._exit(0)   # skip interpreter teardown: the reference's loader leaves the heap in a fragile state
 
 
+def _ref_decode_webp_inproc(path, out_npz):
+    """Decode a lossy WebP with the reference's own loader while the recorder
+    (oracle/ref_record_pred.c) captures what its VP8 decoder hands to pred_luma / pred_chrome."""
+    rec = C.CDLL(os.path.join(O.ORACLE_DIR, "_ref", "libref_record.so"), mode=C.RTLD_GLOBAL)   # first: interposes
+    R = C.CDLL(O.REF_SO, mode=C.RTLD_GLOBAL)
+    rec.ref_record_set_real.argtypes = [C.c_void_p, C.c_void_p]
+    rec.ref_record_set_real(C.cast(R.pred_luma, C.c_void_p), C.cast(R.pred_chrome, C.c_void_p))
+
+    class Pic(C.Structure):  # struct pic, format/file.h:29-40
+        _fields_ = [("pixels", C.c_void_p), ("left", C.c_int), ("top", C.c_int), ("width", C.c_int),
+                    ("height", C.c_int), ("depth", C.c_int), ("pitch", C.c_int), ("format", C.c_int),
+                    ("refcnt", C.c_int), ("pic", C.c_void_p)]
+    R.file_ops_init.restype = None
+    R.file_probe.restype = C.c_void_p
+    R.file_probe.argtypes = [C.c_char_p]
+    R.file_load.restype = C.POINTER(Pic)
+    R.file_load.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    R.file_ops_init()
+    p = R.file_load(R.file_probe(path.encode()), path.encode(), 0).contents
+    info = (C.c_int * 27)()
+    R.ref_webp_filter_info.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    R.ref_webp_filter_info(p.pic, info)
+    rec.ref_record_count.restype = C.c_int
+    rec.ref_record_modes.restype = C.POINTER(C.c_uint8)
+    rec.ref_record_residual.restype = C.POINTER(C.c_int16)
+    n = rec.ref_record_count()
+    modes = np.ctypeslib.as_array(rec.ref_record_modes(), shape=(n, 20)).copy()
+    resid = np.ctypeslib.as_array(rec.ref_record_residual(), shape=(n, 384)).copy()
+    bgra = np.ctypeslib.as_array(C.cast(p.pixels, C.POINTER(C.c_uint8)), shape=(p.height, p.pitch)).copy()
+    np.savez(out_npz, modes=modes, residual=resid, bgra=bgra, dims=np.array([p.width, p.height, p.pitch], np.int32),
+             lf=np.array(list(info), np.int32))
+    os._exit(0)
+
+
+def ref_decode_webp(path):
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "webp.npz")
+        for attempt in range(5):
+            rc = subprocess.call([sys.executable, os.path.abspath(__file__), "--decode-webp", path, out],
+                                 stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            if rc == 0 and os.path.exists(out):
+                return dict(np.load(out))
+        raise RuntimeError(f"reference could not decode {path}")
+
+
+def gen_webp_file(R):
+    """BASELINE config 4 at file level: a PIL-made lossy WebP decoded by the
+    reference's own loader, with the per-macroblock modes / residual it passed to its predictors
+    and the final BGRA.  Quality 100 makes libwebp switch the loop filter off, so the reference's
+    pixels are exactly predict + residual + colour."""
+    from PIL import Image
+    rng = np.random.default_rng(8)
+    yy, xx = np.mgrid[0:96, 0:128]
+    img = np.stack([127 + 120 * np.sin(xx / 17.0) * np.cos(yy / 13.0), 127 + 100 * np.cos(xx / 7.0 + yy / 23.0),
+                    (xx * 255 / 127 + yy * 255 / 95) / 2], axis=2)
+    img = np.clip(img + rng.normal(0, 8, img.shape), 0, 255).astype(np.uint8)
+    path = os.path.join(HERE, "file_q100.webp")
+    Image.fromarray(img).save(path, "WEBP", quality=100, method=4)
+    d = ref_decode_webp(path)
+    w, h, pitch = [int(x) for x in d["dims"]]
+    c, r = (w + 15) // 16, (h + 15) // 16
+    assert d["lf"][0] == 0, "loop filter is on: the dump alone cannot reproduce the picture"
+    assert len(d["modes"]) == c * r
+    y, u, v = O.oracle_vp8_frame(c, r, d["modes"], d["residual"])
+    out = np.zeros((16 * r, pitch), np.uint8)
+    O.ffo().ffo_yuv420_to_bgra32(out.reshape(-1), pitch, y.reshape(-1), u.reshape(-1), v.reshape(-1), 16 * c, 8 * c, r, c)
+    same = np.array_equal(out[:h], d["bgra"][:h])
+    print(f"  file_q100.webp: {os.path.getsize(path)} B, {w}x{h}, {c * r} MBs, y-modes {np.bincount(d['modes'][:, 0], minlength=5)}, "
+          f"chain from the dump == reference decode: {same}")
+    assert same, "the recorded modes/residual do not reproduce the reference's pixels"
+    save("webp_file.npz", modes=d["modes"], residual=d["residual"], bgra=d["bgra"][:h], dims=d["dims"], lf=d["lf"])
+
+
 def ref_decode_file(R, path):
     """Run the reference's whole-file decode in a child process (its Huffman reader overruns its
     input at the end of some scans -- utils/bitstream.c:117 -- and can take the process down)."""
@@ -415,7 +488,7 @@ def gen_files(R):
 def manifest():
     lines = []
     for f in sorted(os.listdir(HERE)):
-        if f.endswith((".npz", ".jpg")):
+        if f.endswith((".npz", ".jpg", ".webp")):
             lines.append(f"{hashlib.sha256(open(os.path.join(HERE, f), 'rb').read()).hexdigest()}  {f}")
     open(os.path.join(HERE, "MANIFEST.sha256"), "w").write("\n".join(lines) + "\n")
 
@@ -433,10 +506,13 @@ def main():
     print("colour"); gen_color(R)
     print("grids"); gen_grids(R)
     print("files"); gen_files(R)
+    print("webp file"); gen_webp_file(R)
     manifest()
 
 
 if __name__ == "__main__":
     if len(sys.argv) == 4 and sys.argv[1] == "--decode":
         _ref_decode_file_inproc(sys.argv[2], sys.argv[3])
+    if len(sys.argv) == 4 and sys.argv[1] == "--decode-webp":
+        _ref_decode_webp_inproc(sys.argv[2], sys.argv[3])
     main()

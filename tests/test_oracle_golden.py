@@ -115,6 +115,21 @@ def test_vp8_loopfilter(golden, ffo):
             assert (p[0] != g[f"{tag}_y"]).mean() > 0.05          # the filters really fire on this data
 
 
+def test_webp_file_config4(golden, ffo):
+    """BASELINE config 4 at file level: the modes/residual the reference's own VP8 decoder handed
+    to its predictors for a PIL-made lossy WebP (loop filter off at quality 100), and the BGRA its
+    loader produced; predict + residual add + colour must reproduce it exactly."""
+    g = golden("webp_file.npz")
+    w, h, pitch = [int(x) for x in g["dims"]]
+    c, r = (w + 15) // 16, (h + 15) // 16
+    assert int(g["lf"][0]) == 0 and len(g["modes"]) == c * r
+    assert len(np.unique(g["modes"][:, 0])) == 5            # all five luma modes occur in the file
+    y, u, v = O.oracle_vp8_frame(c, r, g["modes"], g["residual"])
+    out = np.zeros((16 * r, pitch), np.uint8)
+    ffo.ffo_yuv420_to_bgra32(out.reshape(-1), pitch, y.reshape(-1), u.reshape(-1), v.reshape(-1), 16 * c, 8 * c, r, c)
+    assert np.array_equal(out[:h], g["bgra"])
+
+
 def test_hevc_dst4(golden, ffo):
     g = golden("hevc_dst4.npz")
     for bd in (8, 10):

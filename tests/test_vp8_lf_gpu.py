@@ -73,3 +73,15 @@ def test_webp_chain_batch():
         F.ffo_yuv420_to_bgra32(out.reshape(-1), 16 * c * 4, planes[0].reshape(-1), planes[1].reshape(-1),
                                planes[2].reshape(-1), 16 * c, 8 * c, r, c)
         assert np.array_equal(bgra[i], out), i
+
+
+def test_webp_file_config4(golden):
+    """the reference's whole-file decode of a real lossy WebP, reproduced on the GPU from the
+    per-macroblock dump of its own decoder (tests/golden/make_golden.py::gen_webp_file)"""
+    g = golden("webp_file.npz")
+    w, h, pitch = [int(x) for x in g["dims"]]
+    c, r = (w + 15) // 16, (h + 15) // 16
+    y, u, v = ops.vp8_predict_recon(c, r, g["modes"][None], g["residual"][None])
+    y, u, v = ops.vp8_loopfilter(c, r, 0, g["modes"][None], synth.vp8_filters(), y, u, v)   # level 0: a no-op
+    bgra = ops.yuv420_to_bgra(y, u, v, r, c, pitch=pitch)
+    assert np.array_equal(bgra[0][:h], g["bgra"])

@@ -103,3 +103,18 @@ def test_bmp_bytes_equal_reference_writer(tmp_path):
     padded[:, :w] = px
     capi.check(capi.lib().ffhip_bmp_write(mine.encode(), padded.ctypes.data, w, h, (w + 8) * 4))
     assert open(mine, "rb").read() == open(title + ".bmp", "rb").read()
+
+
+def test_front_end_under_sanitizers(tmp_path):
+    """ASan + UBSan build of the C front end against seeded corruptions of the fixture files:
+    bit flips, truncations, marker floods, header mutations (sanitizers run on the CPU build only)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fuzz_entropy")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "tools", "fuzz_entropy.c"),
+                           os.path.join(root, "ffpic_amd", "csrc", "ffhip_entropy.c"), "-lpthread", "-o", exe])
+    files = [os.path.join(GOLDEN, f) for f in FILES.values()]
+    out = subprocess.run([exe, "400"] + files, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "decoded" in out.stdout

@@ -22,11 +22,21 @@ EXPORTS = [
     "ffhip_vp8_residual_batch", "ffhip_hevc_residual_batch", "ffhip_vp8_predict_recon",
     "ffhip_hevc_intra_recon", "ffhip_vp8_loopfilter",
     "ffhip_jpeg_probe", "ffhip_jpeg_entropy_decode", "ffhip_jpeg_entropy_batch", "ffhip_bmp_write",
+    "ffhip_heif_grid_parse", "ffhip_heif_grid_compose",
 ]
+
+
+FFHIP_EINVAL, FFHIP_ENOMEM, FFHIP_ENODEV, FFHIP_EIO = -22, -12, -19, -5     # include/ffpic_hip.h:34-37
 
 
 class FfhipError(RuntimeError):
     pass
+
+
+class HeifGrid(C.Structure):
+    """ffhip_heif_grid"""
+    _fields_ = [("version", C.c_uint8), ("flags", C.c_uint8), ("rows", C.c_uint16), ("cols", C.c_uint16),
+                ("output_width", C.c_uint32), ("output_height", C.c_uint32)]
 
 
 class JpegGeom(C.Structure):
@@ -144,6 +154,8 @@ def lib():
     L.ffhip_jpeg_entropy_decode.argtypes = [vp, sz, C.POINTER(JpegGeom), vp, vp, vp, vp]
     L.ffhip_jpeg_entropy_batch.argtypes = [vp, vp, ci, ci, C.POINTER(JpegGeom), vp, vp, vp, vp, vp]
     L.ffhip_bmp_write.argtypes = [C.c_char_p, vp, ci, ci, i64]
+    L.ffhip_heif_grid_parse.argtypes = [vp, sz, C.POINTER(HeifGrid)]
+    L.ffhip_heif_grid_compose.argtypes = [vp, i64, ci, ci, vp, i64, i64, ci, ci, ci, ci, vp]
     L.ffhip_hevc_intra_recon.argtypes = [vp, vp, C.c_longlong, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.ffhip_vp8_loopfilter.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, i64, i64, vp]
     L.ffhip_vp8_predict_recon.argtypes = [ci, ci, ci, vp, vp, vp, i64, vp, vp, vp, vp, i64, i64, vp]

@@ -6,6 +6,7 @@
  *   filtering_neighbouring_samples coding/hevc.c:4355-4426
  *   hevc_intra_planar / DC / angular  format/predict.c:651-792
  *   residual_modification_transform_bypass (rdpcm)  coding/hevc.c:3960-3977
+ *   residual_modification_transform_cross_prediction coding/hevc.c:3979-3988 (as called at :4750-4756)
  *   construct_pic_pior_to_filtering coding/hevc.c:4252-4274
  *
  * Dependency-bound like every intra decoder: a TU reads reconstructed samples of earlier
@@ -155,6 +156,14 @@ __global__ __launch_bounds__(256) void k_hevc_intra(HevcIntraArgs a)
                     for (int i = n; i < n * n; i++) R[i] = (short)(R[i] + R[i - 1]);
             } else if (lane < n) {
                 for (int y = 1; y < n; y++) R[lane + n * y] = (short)(R[lane + n * y] + R[lane + n * (y - 1)]);
+            }
+            wave_sync();
+        }
+        if (flags & 0x80) { /* 8.6.6 with rY aliased to r, as at hevc.c:4753-4755; products wrap like -fwrapv */
+            const int bdc = a.bitdepth_c, bdy = a.bitdepth_y;
+            for (int i = lane; i < n * n; i += 64) {
+                const int up = (int)((unsigned)(int)R[i] << bdc) >> bdy;
+                R[i] = (short)(R[i] + ((int)((unsigned)t.res_scale * (unsigned)up) >> 3));
             }
             wave_sync();
         }

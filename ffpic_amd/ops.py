@@ -198,14 +198,15 @@ def vp8_predict_recon(mbcols, mbrows, modes, residual, resmap=None):
             dv.to_host((n, 8 * mbrows, 8 * mbcols), np.uint8))
 
 
-def hevc_intra_recon(tus, residual, width, height, chroma=True, bd_y=8, bd_c=8):
+def hevc_intra_recon(tus, residual, width, height, chroma=True, bd_y=8, bd_c=8, csub=2):
     """decode_intra_block steps 5-10 (coding/hevc.c:4730-4790) for a TU list in decode order
-    (structured array of dtype synth.HEVC_TU_DTYPE == struct ffhip_hevc_tu); planes start at 0."""
+    (structured array of dtype synth.HEVC_TU_DTYPE == struct ffhip_hevc_tu); planes start at 0;
+    csub = chroma subsampling divisor (2 for 4:2:0, 1 for 4:4:4)."""
     L = capi.require_device()
     tus = np.ascontiguousarray(tus)
     assert tus.dtype.itemsize == 32
     dt, dr = DeviceBuffer(tus.view(np.uint8)), DeviceBuffer(np.ascontiguousarray(residual))
-    cw, ch = (width // 2, height // 2) if chroma else (0, 0)
+    cw, ch = (width // csub, height // csub) if chroma else (0, 0)
     dy = DeviceBuffer(nbytes=width * height * 2)
     du = DeviceBuffer(nbytes=max(cw * ch * 2, 16))
     dv = DeviceBuffer(nbytes=max(cw * ch * 2, 16))
@@ -265,3 +266,24 @@ def vp8_loopfilter(mbcols, mbrows, filter_type, modes, filters, y, u, v):
     capi.check(L.ffhip_vp8_loopfilter(mbcols, mbrows, n, filter_type, dm.ptr, df.ptr, dy.ptr, du.ptr, dv.ptr,
                                       256 * n_mb, 64 * n_mb, None), "ffhip_vp8_loopfilter")
     return dy.to_host(y.shape, np.uint8), du.to_host(u.shape, np.uint8), dv.to_host(v.shape, np.uint8)
+
+
+def heif_grid_parse(item):
+    """ImageGrid item payload (bytes) -> capi.HeifGrid, as decode_grid_items reads it (format/heif.c:273-298)."""
+    L = capi.lib()
+    g = capi.HeifGrid()
+    buf = (C.c_uint8 * len(item)).from_buffer_copy(bytes(item))
+    capi.check(L.ffhip_heif_grid_parse(C.cast(buf, C.c_void_p), len(item), C.byref(g)), "ffhip_heif_grid_parse")
+    return g
+
+
+def heif_grid_compose(tiles, cols, out_w, out_h):
+    """tiles uint8 [rows*cols][tile_h][tile_w][4] (row-major `dimg` order) -> canvas [out_h][out_w][4]."""
+    L = capi.require_device()
+    tiles = np.ascontiguousarray(tiles)
+    n, th, tw, _ = tiles.shape
+    dt = DeviceBuffer(tiles)
+    dc = DeviceBuffer(nbytes=out_w * out_h * 4)
+    capi.check(L.ffhip_heif_grid_compose(dc.ptr, out_w * 4, out_w, out_h, dt.ptr, tw * 4, tw * th * 4, tw, th, n // cols, cols,
+                                         None), "ffhip_heif_grid_compose")
+    return dc.to_host((out_h, out_w, 4), np.uint8)

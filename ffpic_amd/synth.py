@@ -160,9 +160,9 @@ def vp8_residual(n_mb, seed=0, amplitude=40):
 # ------------------------------------------------------------------ HEVC intra TU lists
 
 HEVC_TU_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2_size", "u1"), ("cidx", "u1"), ("pred_mode", "u1"),
-                          ("flags", "u1"), ("res_offset", "<u4"), ("reserved", "<u4"), ("avail_top", "<u8"),
+                          ("flags", "u1"), ("res_offset", "<u4"), ("res_scale", "<i4"), ("avail_top", "<u8"),
                           ("avail_left", "<u8")])   # == struct ffhip_hevc_tu, 32 bytes
-TU_CORNER, TU_RESIDUAL, TU_FILTER, TU_STRONG, TU_NO_BF, TU_NO_DC_BF, TU_RDPCM = 1, 2, 4, 8, 16, 32, 64
+TU_CORNER, TU_RESIDUAL, TU_FILTER, TU_STRONG, TU_NO_BF, TU_NO_DC_BF, TU_RDPCM, TU_CCP = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 def _quadtree(rng, x0, y0, size, min_size, max_tu, out):
@@ -174,19 +174,24 @@ def _quadtree(rng, x0, y0, size, min_size, max_tu, out):
         out.append((x0, y0, size))
 
 
-def hevc_intra_tus(width, height, seed=0, ctb=64, chroma=True, min_tu=4, adversarial_masks=False):
+def hevc_intra_tus(width, height, seed=0, ctb=64, chroma=True, min_tu=4, adversarial_masks=False, ccp=False,
+                   chroma_444=False):
     """A whole intra picture as a list of TUs in decode order (CTBs in raster order, z-order
     inside a CTB; per CTB: luma TUs, then Cb, then Cr), with z-scan neighbour availability,
-    random modes 0..34 and flags.  Returns (tus structured array, residual int16 flat)."""
+    random modes 0..34 and flags.  ccp=True marks about half of the chroma TUs that carry a residual
+    for cross-component prediction (ResScaleVal in {+-1, +-2, +-4, +-8}); chroma_444=True gives the chroma
+    planes the luma size (ChromaArrayType 3, where the reference enables it).
+    Returns (tus structured array, residual int16 flat)."""
     rng = np.random.default_rng(SEED_BASE + 15000 + seed)
     assert width % ctb == 0 and height % ctb == 0
-    planes = [(width, height)] + ([(width // 2, height // 2)] * 2 if chroma else [])
+    csub = 1 if chroma_444 else 2
+    planes = [(width, height)] + ([(width // csub, height // csub)] * 2 if chroma else [])
     done = [np.zeros((h, w), bool) for (w, h) in planes]
     tus, res_parts, off = [], [], 0
     for cy in range(0, height, ctb):
         for cx in range(0, width, ctb):
             for c, (pw, ph) in enumerate(planes):
-                sc = 1 if c == 0 else 2
+                sc = 1 if c == 0 else csub
                 parts = []
                 _quadtree(rng, cx // sc, cy // sc, ctb // sc, max(min_tu, 4), 32, parts)
                 for (x0, y0, n) in parts:
@@ -220,7 +225,11 @@ def hevc_intra_tus(width, height, seed=0, ctb=64, chroma=True, min_tu=4, adversa
                         off += n * n
                     else:
                         ro = 0
-                    tus.append((x0, y0, int(np.log2(n)), c, mode, fl, ro, 0, at, al))
+                    rsv = 0
+                    if ccp and c > 0 and (fl & TU_RESIDUAL) and rng.random() < 0.5:
+                        fl |= TU_CCP
+                        rsv = int(rng.choice([1, 2, 4, 8])) * int(rng.choice([-1, 1]))
+                    tus.append((x0, y0, int(np.log2(n)), c, mode, fl, ro, rsv, at, al))
                     d[y0:y0 + n, x0:x0 + n] = True
     arr = np.array(tus, dtype=HEVC_TU_DTYPE)
     res = np.concatenate(res_parts) if res_parts else np.zeros(1, np.int16)

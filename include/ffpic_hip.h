@@ -181,6 +181,24 @@ int ffhip_yuv400_to_bgra_16(uint8_t *d_bgra, int pitch, const int16_t *d_y, int 
                             int ctbrows, int ctbcols, int ctbsize, int n_images,
                             int64_t plane_stride_y, int64_t image_stride, void *stream);
 
+/* ---- HEIF image grid ----
+ * ffhip_heif_grid_parse reads the ImageGrid item payload exactly as decode_grid_items does
+ * (format/heif.c:273-298: version, flags, rows_minus_one, columns_minus_one, then 16- or 32-bit
+ * big-endian output_width/height by flags & 1); host only.
+ * ffhip_heif_grid_compose places rows*cols decoded BGRA tiles (tile j of the row-major `dimg`
+ * list at d_tiles + j*tile_stride, tile_pitch bytes per row, all tile_w x tile_h) on the canvas
+ * at (j % cols * tile_w, j / cols * tile_h), cropped to out_w x out_h.  NEW behaviour: the
+ * reference decodes every tile into the same buffer (heif.c:305) and never places them. */
+typedef struct ffhip_heif_grid {
+    uint8_t version, flags;
+    uint16_t rows, cols;
+    uint32_t output_width, output_height;
+} ffhip_heif_grid;
+int ffhip_heif_grid_parse(const uint8_t *item, size_t length, ffhip_heif_grid *out);
+int ffhip_heif_grid_compose(uint8_t *d_canvas, int64_t canvas_pitch, int out_w, int out_h,
+                            const uint8_t *d_tiles, int64_t tile_pitch, int64_t tile_stride,
+                            int tile_w, int tile_h, int rows, int cols, void *stream);
+
 /* ---- VP8 (WebP lossy) residual stage, batched over macroblocks ----
  * Replaces, for n_mb macroblocks at once, what vp8_decode_residual_block does between
  * the token parse and the predictor (format/webp.c:1147-1196): dequantisation (the
@@ -269,7 +287,7 @@ typedef struct ffhip_hevc_tu {
     uint8_t pred_mode;   /* predModeIntra: 0 planar, 1 DC, 2..34 angular                    */
     uint8_t flags;       /* FFHIP_TU_*                                                      */
     uint32_t res_offset; /* element offset of the TU's residual block in d_residual         */
-    uint32_t reserved;
+    int32_t res_scale;   /* ResScaleVal of 8.6.6 (hevc.c:3494-3497: 0, +-1, +-2, +-4, +-8); used with FFHIP_TU_CCP */
     uint64_t avail_top;  /* bit k: neighbour (x+k, y-1), k = 0..2n-1, is available          */
     uint64_t avail_left; /* bit k: neighbour (x-1, y+k) is available                        */
 } ffhip_hevc_tu;
@@ -281,6 +299,9 @@ typedef struct ffhip_hevc_tu {
 #define FFHIP_TU_NO_BF 0x10    /* disableIntraBoundaryFilter (hevc.c:4642-4648)              */
 #define FFHIP_TU_NO_DC_BF 0x20 /* intra_boundary_filtering_disabled_flag (DC edge filter)    */
 #define FFHIP_TU_RDPCM 0x40    /* residualDpcm == 1: 8.6.5 on the residual before the add    */
+#define FFHIP_TU_CCP 0x80      /* 8.6.6 cross-component prediction after 8.6.5, exactly as the reference
+                                  calls it (hevc.c:4750-4756): the "luma" residual it passes is the chroma
+                                  block itself, so r += (res_scale * ((r << BitDepthC) >> BitDepthY)) >> 3 */
 /* h_tus / d_tus: the SAME n_tus records on the host (dependency scheduling) and on the device.
  * d_residual: int16 residual blocks (row-major n*n each) as ffhip_hevc_residual_batch writes
  * them.  Planes: int16, strides in samples; d_cb/d_cr may be NULL for 4:0:0.  Enqueues one

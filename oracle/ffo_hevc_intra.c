@@ -8,6 +8,7 @@
  *   filtering_neighbouring_samples coding/hevc.c:4355-4426
  *   hevc_intra_planar / DC / angular  format/predict.c:651-792
  *   rdpcm residual modification    coding/hevc.c:3960-3977
+ *   cross-component prediction     coding/hevc.c:3979-3988 (as called at :4750-4756)
  *   construct_pic_pior_to_filtering coding/hevc.c:4252-4274
  *
  * The reference derives neighbour availability from z-scan order, slices and tiles while it
@@ -148,6 +149,18 @@ void ffo_hevc_rdpcm(int mdir, int n, int16_t *r)
     }
 }
 
+/* 8.6.6, hevc.c:3979-3988.  Element by element, int arithmetic, int16 store.  The reference's only
+ * call site (hevc.c:4753-4755) passes the chroma block for both rY and r; ry is read before r is
+ * written, so aliasing is well defined.  Products wrap (oracle flags: -fwrapv). */
+void ffo_hevc_cross_component(int res_scale, int n, int bitdepth_y, int bitdepth_c, const int16_t *ry, int16_t *r)
+{
+    for (int i = 0; i < n * n; i++) {
+        const int32_t up = (int32_t)((uint32_t)(int32_t)ry[i] << bitdepth_c) >> bitdepth_y;
+        const int32_t prod = (int32_t)((uint32_t)res_scale * (uint32_t)up);
+        r[i] = (int16_t)(r[i] + (prod >> 3));
+    }
+}
+
 /* One TU: gather, substitute, filter, predict, add residual, clip, write (decode_intra_block
  * steps 5-10, hevc.c:4730-4790). */
 void ffo_hevc_intra_tu(const ffo_hevc_tu *t, const int16_t *residual, int16_t *plane, int stride, int bitdepth_y,
@@ -175,6 +188,7 @@ void ffo_hevc_intra_tu(const ffo_hevc_tu *t, const int16_t *residual, int16_t *p
     if (t->flags & FFO_TU_RESIDUAL) {
         memcpy(res, residual + t->res_offset, (size_t)n * n * sizeof(int16_t));
         if (t->flags & FFO_TU_RDPCM) ffo_hevc_rdpcm(t->pred_mode / 26, n, res);
+        if (t->flags & FFO_TU_CCP) ffo_hevc_cross_component(t->res_scale, n, bitdepth_y, bitdepth_c, res, res);
     } else {
         memset(res, 0, sizeof res);
     }

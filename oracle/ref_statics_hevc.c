@@ -63,9 +63,12 @@ void ref_hevc_transform(int16_t *d, int16_t *r, int nTbS, int luma_intra_4x4, in
  * construct_pic_pior_to_filtering (hevc.c:4252-4274).  The gathering loop mirrors
  * intra_sample_prediction (hevc.c:4570-4608) with the availability decisions supplied by the
  * caller instead of process_zscan_order_block_availablity.
- * flags: 1 corner, 2 residual, 4 filter, 8 strong, 16 no_bf, 32 no_dc_bf, 64 rdpcm. */
+ * flags: 1 corner, 2 residual, 4 filter, 8 strong, 16 no_bf, 32 no_dc_bf, 64 rdpcm,
+ * 128 cross-component prediction through residual_modification_transform_cross_prediction
+ * (hevc.c:3979-3988) with the argument aliasing of its call site (hevc.c:4753-4755). */
 void ref_hevc_intra_tu(int x0, int y0, int log2n, int cIdx, int predModeIntra, int flags, uint64_t avail_top,
-                       uint64_t avail_left, int16_t *res_in, int16_t *dst, int stride, int bitdepth_y, int bitdepth_c)
+                       uint64_t avail_left, int16_t *res_in, int16_t *dst, int stride, int bitdepth_y, int bitdepth_c,
+                       int res_scale)
 {
     struct sps *sps = calloc(1, sizeof *sps);
     const int nTbS = 1 << log2n;
@@ -102,6 +105,12 @@ void ref_hevc_intra_tu(int x0, int y0, int log2n, int cIdx, int predModeIntra, i
     if (flags & 2) {
         memcpy(resSamples, res_in, nTbS * nTbS * sizeof(int16_t));
         if (flags & 64) residual_modification_transform_bypass(predModeIntra / 26, nTbS, resSamples);
+        if (flags & 128) {
+            struct cu *cu = calloc(1, sizeof *cu);
+            cu->ccp[0][0].ResScaleVal[cIdx] = (uint32_t)res_scale;
+            residual_modification_transform_cross_prediction(sps, cu, 0, 0, nTbS, cIdx, resSamples, resSamples);
+            free(cu);
+        }
     }
     construct_pic_pior_to_filtering(sps, x0, y0, nTbS, nTbS, cIdx, predSamples, resSamples, dst, stride);
     free(sps);

@@ -182,13 +182,19 @@ def gen_hevc_intra(R):
     reference_sample_substitution / filtering_neighbouring_samples / hevc_intra_* /
     rdpcm / construct_pic (oracle/ref_statics_hevc.c::ref_hevc_intra_tu)."""
     res = {}
+    # d, e: 4:4:4 with cross-component prediction (hevc.c:4750-4756); e has BitDepthC != BitDepthY
     for tag, (w, h, seed, adv, bd) in {"a": (128, 64, 11, False, 8), "b": (128, 128, 12, True, 8),
-                                       "c": (64, 128, 13, True, 10)}.items():
-        tus, resid = synth.hevc_intra_tus(w, h, seed, adversarial_masks=adv)
+                                       "c": (64, 128, 13, True, 10), "d": (128, 64, 14, False, 8),
+                                       "e": (64, 64, 15, True, 10)}.items():
+        ccp = tag in "de"
+        bdc = 12 if tag == "e" else bd
+        tus, resid = synth.hevc_intra_tus(w, h, seed, adversarial_masks=adv, ccp=ccp, chroma_444=ccp)
         if bd == 10:
             resid = (resid.astype(np.int32) * 3).astype(np.int16)
-        y, u, v = O.ref_hevc_intra(tus, resid, w, h, True, bd, bd)
-        res.update({f"{tag}_dims": np.array([w, h, bd], np.int32), f"{tag}_tus": tus.view(np.uint8).reshape(-1, 32),
+        if tag == "e":      # a few extreme residuals so that the shift/multiply wraps
+            resid[::37] = np.where(np.arange(len(resid[::37])) % 2, 32767, -32768).astype(np.int16)
+        y, u, v = O.ref_hevc_intra(tus, resid, w, h, True, bd, bdc, csub=1 if ccp else 2)
+        res.update({f"{tag}_dims": np.array([w, h, bd, bdc, 1 if ccp else 2], np.int32), f"{tag}_tus": tus.view(np.uint8).reshape(-1, 32),
                     f"{tag}_residual": resid, f"{tag}_y": y, f"{tag}_u": u, f"{tag}_v": v})
     save("hevc_intra.npz", **res)
 
@@ -498,15 +504,14 @@ def main():
         sys.exit("make_golden.py needs /root/reference (build container only)")
     O.build_ref()
     R = O.ref()
-    print("blocks"); gen_blocks(R)
-    print("vp8 macroblocks"); gen_vp8_mbs(R)
-    print("vp8 frames"); gen_vp8_frames(R)
-    print("hevc intra"); gen_hevc_intra(R)
-    print("vp8 loop filter"); gen_vp8_loopfilter(R)
-    print("colour"); gen_color(R)
-    print("grids"); gen_grids(R)
-    print("files"); gen_files(R)
-    print("webp file"); gen_webp_file(R)
+    steps = [("blocks", gen_blocks), ("vp8 macroblocks", gen_vp8_mbs), ("vp8 frames", gen_vp8_frames),
+             ("hevc intra", gen_hevc_intra), ("vp8 loop filter", gen_vp8_loopfilter), ("colour", gen_color),
+             ("grids", gen_grids), ("files", gen_files), ("webp file", gen_webp_file)]
+    only = sys.argv[2] if len(sys.argv) == 3 and sys.argv[1] == "--only" else None   # e.g. --only "hevc intra"
+    for name, fn in steps:
+        if only is None or only == name:
+            print(name)
+            fn(R)
     manifest()
 
 

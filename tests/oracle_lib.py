@@ -119,7 +119,7 @@ def ref():
         L.ref_vp8_residual_mb.argtypes = [i16p, u8p, C.c_int, u16p, i16p]
         L.ref_vp8_recon_frame.argtypes = [C.c_int, C.c_int, u8p, i16p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ref_vp8_loopfilter_frame.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, u8p, u8p, u8p]
-        L.ref_hevc_intra_tu.argtypes = [C.c_int] * 6 + [C.c_uint64, C.c_uint64, i16p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.ref_hevc_intra_tu.argtypes = [C.c_int] * 6 + [C.c_uint64, C.c_uint64, i16p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.idct_4x4_hevc.argtypes = [i16p, i16p, C.c_int, C.c_bool]
         L.ref_hevc_scale.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.ref_hevc_transform.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -184,24 +184,25 @@ def ref_vp8_frame(mbcols, mbrows, modes, residual, resmap=None):
 
 # ---------------------------------------------------------------- HEVC intra helpers
 
-def _hevc_planes(width, height, chroma, fill=0):
+def _hevc_planes(width, height, chroma, fill=0, csub=2):
     py = np.full((height, width), fill, np.int16)
     if chroma:
-        return py, np.full((height // 2, width // 2), fill, np.int16), np.full((height // 2, width // 2), fill, np.int16)
+        return (py, np.full((height // csub, width // csub), fill, np.int16),
+                np.full((height // csub, width // csub), fill, np.int16))
     return py, np.zeros((1, 1), np.int16), np.zeros((1, 1), np.int16)
 
 
-def oracle_hevc_intra(tus, residual, width, height, chroma=True, bd_y=8, bd_c=8):
-    py, pu, pv = _hevc_planes(width, height, chroma)
+def oracle_hevc_intra(tus, residual, width, height, chroma=True, bd_y=8, bd_c=8, csub=2):
+    py, pu, pv = _hevc_planes(width, height, chroma, csub=csub)
     tus = np.ascontiguousarray(tus)
     ffo().ffo_hevc_intra_recon(tus.ctypes.data_as(C.c_void_p), len(tus), np.ascontiguousarray(residual),
                                py.ctypes.data_as(C.c_void_p), pu.ctypes.data_as(C.c_void_p),
-                               pv.ctypes.data_as(C.c_void_p), width, max(width // 2, 1), bd_y, bd_c)
+                               pv.ctypes.data_as(C.c_void_p), width, max(width // csub, 1), bd_y, bd_c)
     return py, pu, pv
 
 
-def ref_hevc_intra(tus, residual, width, height, chroma=True, bd_y=8, bd_c=8):
-    py, pu, pv = _hevc_planes(width, height, chroma)
+def ref_hevc_intra(tus, residual, width, height, chroma=True, bd_y=8, bd_c=8, csub=2):
+    py, pu, pv = _hevc_planes(width, height, chroma, csub=csub)
     R = ref()
     planes = (py, pu, pv)
     residual = np.ascontiguousarray(residual)
@@ -212,5 +213,5 @@ def ref_hevc_intra(tus, residual, width, height, chroma=True, bd_y=8, bd_c=8):
         blk = np.ascontiguousarray(residual[ro:ro + n * n]) if int(t["flags"]) & 2 else np.zeros(n * n, np.int16)
         R.ref_hevc_intra_tu(int(t["x"]), int(t["y"]), int(t["log2_size"]), int(t["cidx"]), int(t["pred_mode"]),
                             int(t["flags"]), int(t["avail_top"]), int(t["avail_left"]), blk,
-                            pl.ctypes.data_as(C.c_void_p), pl.shape[1], bd_y, bd_c)
+                            pl.ctypes.data_as(C.c_void_p), pl.shape[1], bd_y, bd_c, int(t["res_scale"]))
     return py, pu, pv

@@ -10,10 +10,10 @@ pytestmark = pytest.mark.gpu
 
 def test_golden_tu_lists(golden):
     g = golden("hevc_intra.npz")
-    for tag in "abc":
-        w, h, bd = [int(x) for x in g[f"{tag}_dims"]]
+    for tag in "abcde":     # d, e: 4:4:4 with cross-component prediction
+        w, h, bd, bdc, csub = [int(x) for x in g[f"{tag}_dims"]]
         tus = np.ascontiguousarray(g[f"{tag}_tus"]).view(synth.HEVC_TU_DTYPE).reshape(-1)
-        y, u, v = ops.hevc_intra_recon(tus, g[f"{tag}_residual"], w, h, True, bd, bd)
+        y, u, v = ops.hevc_intra_recon(tus, g[f"{tag}_residual"], w, h, True, bd, bdc, csub=csub)
         assert np.array_equal(y, g[f"{tag}_y"]), tag
         assert np.array_equal(u, g[f"{tag}_u"]) and np.array_equal(v, g[f"{tag}_v"]), tag
 
@@ -26,6 +26,20 @@ def test_tu_lists_vs_oracle(w, h, seed, adv, bd):
         res = (res.astype(np.int32) * (1 << (bd - 8))).astype(np.int16)
     got = ops.hevc_intra_recon(tus, res, w, h, True, bd, bd)
     exp = O.oracle_hevc_intra(tus, res, w, h, True, bd, bd)
+    for gp, e, name in zip(got, exp, "YUV"):
+        assert np.array_equal(gp, e), name
+
+
+@pytest.mark.parametrize("w,h,seed,bd,bdc", [(128, 128, 1, 8, 8), (256, 192, 2, 10, 12), (192, 64, 3, 12, 8)])
+def test_cross_component_444_vs_oracle(w, h, seed, bd, bdc):
+    """8.6.6 after rdpcm on 4:4:4 TU lists, with extreme residuals so the shift/multiply wraps"""
+    tus, res = synth.hevc_intra_tus(w, h, seed + 300, adversarial_masks=True, ccp=True, chroma_444=True)
+    res = res.copy()
+    res[::53] = 32767
+    res[7::59] = -32768
+    assert (tus["flags"] & synth.TU_CCP).sum() > 20
+    got = ops.hevc_intra_recon(tus, res, w, h, True, bd, bdc, csub=1)
+    exp = O.oracle_hevc_intra(tus, res, w, h, True, bd, bdc, csub=1)
     for gp, e, name in zip(got, exp, "YUV"):
         assert np.array_equal(gp, e), name
 

@@ -94,11 +94,12 @@ def test_hevc_intra_recon(golden):
     rdpcm and residual add, over whole TU lists"""
     from ffpic_amd import synth
     g = golden("hevc_intra.npz")
-    for tag in "abc":
-        w, h, bd = [int(x) for x in g[f"{tag}_dims"]]
+    for tag in "abcde":     # d, e: 4:4:4 with cross-component prediction (a12), e with BitDepthC != BitDepthY
+        w, h, bd, bdc, csub = [int(x) for x in g[f"{tag}_dims"]]
         tus = np.ascontiguousarray(g[f"{tag}_tus"]).view(synth.HEVC_TU_DTYPE).reshape(-1)
         assert set(np.unique(tus["pred_mode"])) == set(range(35)) or len(tus) < 300
-        y, u, v = O.oracle_hevc_intra(tus, g[f"{tag}_residual"], w, h, True, bd, bd)
+        assert (tag in "de") == bool((tus["flags"] & synth.TU_CCP).any())
+        y, u, v = O.oracle_hevc_intra(tus, g[f"{tag}_residual"], w, h, True, bd, bdc, csub=csub)
         assert np.array_equal(y, g[f"{tag}_y"]) and np.array_equal(u, g[f"{tag}_u"]) and np.array_equal(v, g[f"{tag}_v"]), tag
 
 

@@ -78,3 +78,20 @@ def test_jpeg_grid_random(libs, nc, h, v):
     g = O.make_geom(9, 5, nc, h, v)
     cy, cu, cv = synth.coef_batch(1, 9, 5, nc, h, v, quant=q, first=100)
     assert np.array_equal(O.oracle_jpeg_recon(g, cy, cu, cv, q)[0], O.ref_jpeg_recon(g, cy, cu, cv, q))
+
+
+@pytest.mark.parametrize("seed,bd,bdc,c444", [(21, 8, 8, False), (22, 10, 10, False), (23, 8, 8, True), (24, 12, 9, True)])
+def test_hevc_intra_random_tu_lists(libs, seed, bd, bdc, c444):
+    """fresh TU lists (not the committed ones) through the reference's own neighbour processing,
+    predictors, rdpcm, cross-component prediction and construct_pic vs the restatement"""
+    from ffpic_amd import synth
+    w, h = 128, 128
+    tus, res = synth.hevc_intra_tus(w, h, seed, adversarial_masks=True, ccp=c444, chroma_444=c444)
+    res = res.copy()
+    res[::41] = 32767
+    res[5::43] = -32768
+    csub = 1 if c444 else 2
+    exp = O.ref_hevc_intra(tus, res, w, h, True, bd, bdc, csub=csub)
+    got = O.oracle_hevc_intra(tus, res, w, h, True, bd, bdc, csub=csub)
+    for a, b, name in zip(got, exp, "YUV"):
+        assert np.array_equal(a, b), name

@@ -20,7 +20,16 @@
 #include "ffhip_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
+
+#ifndef FFHIP_HEVC_INTRA_WAVES
+#define FFHIP_HEVC_INTRA_WAVES 1024 /* waves of the grouped form's one launch */
+#endif
+#ifndef FFHIP_HEVC_INTRA_WINDOW_LOG2
+#define FFHIP_HEVC_INTRA_WINDOW_LOG2 5 /* luma window of the grouped form: 32x32 (1080p sweep in profiles/r1_stages.json) */
+#endif
 
 struct HevcIntraArgs {
     const ffhip_hevc_tu *tus;
@@ -29,6 +38,14 @@ struct HevcIntraArgs {
     int16_t *plane[3];
     int stride[3];
     int bitdepth_y, bitdepth_c, count;
+    /* grouped form only */
+    const u32x4 *sched;       /* per schedule slot 3 x 16 B: the TU record (32 B), then {first wait entry,
+                                 wait count | signal << 8 | tile_ok << 9, TU index, 0}               */
+    const u32x4 *groups;      /* per group: {first slot, slot count, log2 window, 0}              */
+    const uint32_t *wait_idx; /* TU indices a slot waits for (TUs of other groups)                */
+    uint32_t *ctrl;           /* [0] next group ticket, [1] abort; done flags per TU from ctrl + 4 */
+    int *async_err;           /* pinned host word (ffhip_async_err_word)                          */
+    int n_groups;
 };
 
 __device__ __forceinline__ void wave_sync()
@@ -47,20 +64,37 @@ __device__ static const short kInvAngle[15] = {-4096, -1638, -910, -630, -482, -
 
 #define NB_MAX 132 /* 4*32 + 1, padded */
 
-__global__ __launch_bounds__(256) void k_hevc_intra(HevcIntraArgs a)
+#define TILE_STRIDE 66 /* shorts per row of the grouped form's window tile: 33 dwords, so a column walk hits 32 different banks */
+
+/* the residual block of a TU, element lane + 64 j in rr[j] (fetched one TU ahead in the grouped form) */
+__device__ __forceinline__ void fetch_residual(const HevcIntraArgs &a, const ffhip_hevc_tu &t, const int lane, short (&rr)[16])
 {
-    __shared__ int nbA[4][NB_MAX], nbB[4][NB_MAX], refs[4][140];
-    __shared__ short resl[4][32 * 32];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int item = blockIdx.x * 4 + w;
-    if (item >= a.count) return;
-    const ffhip_hevc_tu t = a.tus[a.work[item]];
-    const int n = 1 << t.log2_size, lg = t.log2_size, cidx = t.cidx, mode = t.pred_mode, flags = t.flags;
+    if (!(t.flags & 2)) return;
+    const int nn = 1 << (2 * t.log2_size);
+    const int16_t *src = a.residual + t.res_offset;
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if (64 * j < nn) rr[j] = lane + 64 * j < nn ? src[lane + 64 * j] : (short)0;
+}
+
+/* One TU by one wave: steps 5-10 of decode_intra_block.  s, s2: NB_MAX ints each; refbase: 140 ints;
+ * R: 32*32 shorts -- all private to the wave (LDS).
+ * GROUPED: picture samples move with agent-scope accesses, and neighbours inside the group's window
+ * (origin wx0, wy0, size 1 << wl) come from / go to the wave's LDS copy `tile` when tile_ok. */
+template <bool GROUPED, int LG> /* LG = log2 of the TU size: every loop below has a compile-time trip count */
+__device__ __forceinline__ void intra_tu(const HevcIntraArgs &a, const ffhip_hevc_tu &t, const int lane, int *s, int *s2,
+                                         int *refbase, short *R, const short (&rr)[16], short *tile, const int wl,
+                                         const bool tile_ok)
+{
+    const int wx0 = GROUPED ? (t.x >> wl) << wl : 0, wy0 = GROUPED ? (t.y >> wl) << wl : 0, wsz = GROUPED ? 1 << wl : 0;
+    constexpr int n = 1 << LG, lg = LG;
+    const int cidx = t.cidx, mode = t.pred_mode, flags = t.flags;
     const int bd = cidx == 0 ? a.bitdepth_y : a.bitdepth_c;
     int16_t *plane = a.plane[cidx];
     const int stride = a.stride[cidx];
-    const int x0 = t.x, y0 = t.y, cnt = 4 * n + 1;
-    int *s = nbA[w], *s2 = nbB[w], *ref = refs[w] + 34;
+    const int x0 = t.x, y0 = t.y;
+    constexpr int cnt = 4 * n + 1;
+    int *ref = refbase + 34;
 
     /* availability in scan order: i < 2n -> left[2n-1-i]; i == 2n -> corner; i > 2n -> top[i-2n-1] */
     const unsigned long long rl = __brevll(t.avail_left) >> (64 - 2 * n); /* bit i = left[2n-1-i] */
@@ -79,40 +113,42 @@ __global__ __launch_bounds__(256) void k_hevc_intra(HevcIntraArgs a)
     }
     const int n_avail = __popcll(m0) + __popcll(m1) + (int)m2;
 
-    /* ---- 1. gather + 2. substitute ---- */
+    /* ---- 1. gather + 2. substitute, in one pass: in scan order the substitution of 8.4.4.2.2 is
+     * "the nearest available sample at or before me, else the first available one", so each
+     * lane works out WHICH sample it wants from the masks alone and fetches that one ---- */
     for (int i = lane; i < cnt; i += 64) {
+        int j = i;
+        if (n_avail < cnt && n_avail > 0) {
+            j = -1;
+            if (n == 32 && i >= 128 && m2) j = 128;
+            if (n >= 16 && j < 0 && i >= 64) {
+                const unsigned long long mm = i >= 127 ? m1 : (m1 & ((2ull << (i - 64)) - 1));
+                if (mm) j = 127 - __clzll(mm);
+            }
+            if (j < 0) {
+                const unsigned long long mm = i >= 63 ? m0 : (m0 & ((2ull << i) - 1));
+                if (mm) j = 63 - __clzll(mm);
+            }
+            if (j < 0) j = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : 128);
+        }
         int px, py;
-        if (i < 2 * n) { px = x0 - 1; py = y0 + (2 * n - 1 - i); }
-        else if (i == 2 * n) { px = x0 - 1; py = y0 - 1; }
-        else { px = x0 + (i - 2 * n - 1); py = y0 - 1; }
-        const bool av = i < 64 ? (m0 >> i) & 1 : (i < 128 ? (m1 >> (i - 64)) & 1 : m2 & 1);
-        s[i] = av ? (int)plane[(long long)py * stride + px] : 0;
+        if (j < 2 * n) { px = x0 - 1; py = y0 + (2 * n - 1 - j); }
+        else if (j == 2 * n) { px = x0 - 1; py = y0 - 1; }
+        else { px = x0 + (j - 2 * n - 1); py = y0 - 1; }
+        int v = 1 << (bd - 1);
+        if (n_avail > 0) {
+            const int16_t *sp = plane + (long long)py * stride + px;
+            if (GROUPED) {
+                const unsigned tx = (unsigned)(px - wx0), ty = (unsigned)(py - wy0);
+                if (tile_ok && tx < (unsigned)wsz && ty < (unsigned)wsz) v = (int)tile[ty * TILE_STRIDE + tx];
+                else v = (int)__hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                v = (int)*sp;
+            }
+        }
+        s[i] = v;
     }
     wave_sync();
-    if (n_avail < cnt) {
-        for (int i = lane; i < cnt; i += 64) {
-            int v;
-            if (n_avail == 0) v = 1 << (bd - 1);
-            else {
-                /* nearest available index <= i, else the first available one */
-                int j = -1;
-                if (i >= 128 && m2) j = 128;
-                if (j < 0 && i >= 64) {
-                    const unsigned long long mm = i >= 127 ? m1 : (m1 & ((2ull << (i - 64)) - 1));
-                    if (mm) j = 127 - __clzll(mm);
-                }
-                if (j < 0) {
-                    const unsigned long long mm = i >= 63 ? m0 : (m0 & ((2ull << i) - 1));
-                    if (mm) j = 63 - __clzll(mm);
-                }
-                if (j < 0) j = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : 128);
-                v = s[j];
-            }
-            s2[i] = v;
-        }
-        wave_sync();
-        int *tmp = s; s = s2; s2 = tmp;
-    }
     /* handy accessors into the scan-order array */
 #define LEFT(y) s[2 * n - 1 - (y)]
 #define TOP(x) s[2 * n + 1 + (x)] /* TOP(-1) is the corner */
@@ -144,16 +180,40 @@ __global__ __launch_bounds__(256) void k_hevc_intra(HevcIntraArgs a)
     }
 
     /* ---- residual (with the optional rdpcm accumulation of 8.6.5) ---- */
-    short *R = resl[w];
     const bool has_res = (flags & 2) != 0;
     if (has_res) {
-        const int16_t *src = a.residual + t.res_offset;
-        for (int i = lane; i < n * n; i += 64) R[i] = src[i];
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (64 * j < n * n && lane + 64 * j < n * n) R[lane + 64 * j] = rr[j];
         wave_sync();
         if (flags & 0x40) {
-            if (mode / 26 == 0) { /* running sum over the flattened block from index n (hevc.c:3963-3968) */
-                if (lane == 0)
-                    for (int i = n; i < n * n; i++) R[i] = (short)(R[i] + R[i - 1]);
+            if (mode / 26 == 0) {
+                /* running sum over the flattened block from index n (hevc.c:3963-3968):
+                 * R[i] = sum of R[n-1 .. i] mod 2^16 -- a prefix sum: per-lane chunks, then a wave scan of the chunk totals */
+                const int nn = n * n, chunk = nn >= 64 ? nn >> 6 : 1, active = nn / chunk;
+                int loc[16], sum = 0;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    loc[j] = 0;
+                    if (j < chunk && lane < active) {
+                        const int idx = lane * chunk + j;
+                        sum += idx >= n - 1 ? (int)R[idx] : 0;
+                        loc[j] = sum;
+                    }
+                }
+                int incl = sum;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_up(incl, d);
+                    if (lane >= d) incl += o;
+                }
+                const int excl = incl - sum;
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    if (j < chunk && lane < active) {
+                        const int idx = lane * chunk + j;
+                        if (idx >= n - 1) R[idx] = (short)(loc[j] + excl);
+                    }
             } else if (lane < n) {
                 for (int y = 1; y < n; y++) R[lane + n * y] = (short)(R[lane + n * y] + R[lane + n * (y - 1)]);
             }
@@ -218,14 +278,265 @@ __global__ __launch_bounds__(256) void k_hevc_intra(HevcIntraArgs a)
         /* ---- 5. reconstruct: pred is stored as int16 by the reference before the add ---- */
         const int pr = (int)(short)(v & 0xffff);
         const int rs = has_res ? (int)R[p] : 0;
-        plane[(long long)(y0 + y) * stride + x0 + x] = (short)clip3i(0, (1 << bd) - 1, pr + rs);
+        int16_t *dp = plane + (long long)(y0 + y) * stride + x0 + x;
+        const short rec = (short)clip3i(0, (1 << bd) - 1, pr + rs);
+        if (GROUPED) {
+            __hip_atomic_store(dp, rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned tx = (unsigned)(x0 + x - wx0), ty = (unsigned)(y0 + y - wy0);
+            if (tx < (unsigned)wsz && ty < (unsigned)wsz) tile[ty * TILE_STRIDE + tx] = rec;
+        } else {
+            *dp = rec;
+        }
+    }
+#undef LEFT
+#undef TOP
+#undef U16
+}
+
+template <bool GROUPED>
+__device__ __forceinline__ void intra_tu_any(const HevcIntraArgs &a, const ffhip_hevc_tu &t, const int lane, int *s, int *s2,
+                                             int *refbase, short *R, const short (&rr)[16], short *tile, const int wl,
+                                             const bool tile_ok)
+{
+    switch (t.log2_size) {
+    case 2: intra_tu<GROUPED, 2>(a, t, lane, s, s2, refbase, R, rr, tile, wl, tile_ok); break;
+    case 3: intra_tu<GROUPED, 3>(a, t, lane, s, s2, refbase, R, rr, tile, wl, tile_ok); break;
+    case 4: intra_tu<GROUPED, 4>(a, t, lane, s, s2, refbase, R, rr, tile, wl, tile_ok); break;
+    default: intra_tu<GROUPED, 5>(a, t, lane, s, s2, refbase, R, rr, tile, wl, tile_ok); break;
+    }
+}
+
+/* level-synchronous form: one launch per dependency level, one wave per TU */
+__global__ __launch_bounds__(256) void k_hevc_intra(HevcIntraArgs a)
+{
+    __shared__ int nbA[4][NB_MAX], nbB[4][NB_MAX], refs[4][140];
+    __shared__ short resl[4][32 * 32];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + w;
+    if (item >= a.count) return;
+    const ffhip_hevc_tu t = a.tus[a.work[item]];
+    short rr[16];
+    fetch_residual(a, t, lane, rr);
+    intra_tu_any<false>(a, t, lane, nbA[w], nbB[w], refs[w], resl[w], rr, nullptr, 0, false);
+}
+
+/* Grouped form: ONE launch per picture.  The host cuts the TU list into groups -- the TUs whose
+ * top-left corner falls into one window x window tile of one plane, contiguous in decode order
+ * for any window no larger than the CTB -- and a wave takes groups by ticket and walks each in
+ * list order.  Inside a group nothing goes through memory on the critical path: the wave keeps
+ * the window's reconstructed samples in an LDS tile and reads its neighbours from there, has the
+ * group's TU records in LDS (loaded 64 at a time) and fetches each residual block one TU ahead.
+ * Hops between groups go through one done flag per TU.  Picture samples are stored, and
+ * neighbours outside the window gathered, with agent-scope accesses (sc1: served by the
+ * device-coherent level, never by a possibly stale per-XCD L2 line), so publishing a TU needs
+ * only "my stores have completed" (s_waitcnt vmcnt(0)) before the flag store -- no cache-wide
+ * write-back/invalidate.  Every TU a slot waits for lies in a group with a smaller ticket (the
+ * host checks), whose wave is therefore already running or finished: no wave ever waits for
+ * work that has not been picked up; the spin is bounded all the same and reports through the
+ * pinned word ffhip_stream_sync looks at. */
+#define SPIN_LIMIT (1 << 21)
+#define SLOT_CHUNK 64
+
+struct IntraSlot {
+    ffhip_hevc_tu t;
+    unsigned wait_begin, wait_count, signal, tile_ok;
+};
+
+__device__ __forceinline__ IntraSlot read_slot(const u32x4 *slots, int k)
+{
+    const u32x4 q0 = slots[3 * k], q1 = slots[3 * k + 1], q2 = slots[3 * k + 2];
+#define SGPR(v) ((unsigned)__builtin_amdgcn_readfirstlane((int)(v)))
+    const unsigned d0 = SGPR(q0.x), d1 = SGPR(q0.y), d2 = SGPR(q0.z), d3 = SGPR(q0.w);
+    const unsigned d4 = SGPR(q1.x), d5 = SGPR(q1.y), d6 = SGPR(q1.z), d7 = SGPR(q1.w);
+    const unsigned d8 = SGPR(q2.x), d9 = SGPR(q2.y);
+#undef SGPR
+    IntraSlot sl;
+    sl.t.x = (uint16_t)d0; sl.t.y = (uint16_t)(d0 >> 16);
+    sl.t.log2_size = (uint8_t)d1; sl.t.cidx = (uint8_t)(d1 >> 8); sl.t.pred_mode = (uint8_t)(d1 >> 16); sl.t.flags = (uint8_t)(d1 >> 24);
+    sl.t.res_offset = d2; sl.t.res_scale = (int32_t)d3;
+    sl.t.avail_top = (unsigned long long)d4 | ((unsigned long long)d5 << 32);
+    sl.t.avail_left = (unsigned long long)d6 | ((unsigned long long)d7 << 32);
+    sl.wait_begin = d8; sl.wait_count = d9 & 0xff; sl.signal = (d9 >> 8) & 1; sl.tile_ok = (d9 >> 9) & 1;
+    return sl;
+}
+
+__global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
+{
+    __shared__ short tile[64 * TILE_STRIDE];
+    __shared__ int nbA[NB_MAX], nbB[NB_MAX], refs[140];
+    __shared__ short resl[2][32 * 32];
+    __shared__ u32x4 slots[SLOT_CHUNK * 3];
+    const int lane = threadIdx.x;
+    uint32_t *flags = a.ctrl + 4;
+    for (;;) {
+        unsigned ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(&a.ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+        if (ticket >= (unsigned)a.n_groups) return;
+        const u32x4 g = a.groups[ticket];
+        const int wl = (int)g.z;
+        for (unsigned base = 0; base < g.y; base += SLOT_CHUNK) {
+            const int m = (int)(g.y - base < SLOT_CHUNK ? g.y - base : SLOT_CHUNK);
+            for (int i = lane; i < 3 * m; i += 64) slots[i] = a.sched[(size_t)(g.x + base) * 3 + i];
+            wave_sync();
+            IntraSlot cur = read_slot(slots, 0);
+            short rr[16];
+            fetch_residual(a, cur.t, lane, rr);
+            for (int k = 0; k < m; k++) {
+                if (cur.wait_count) { /* wait for the TUs of other groups this one reads (at most 33 of them) */
+                    const uint32_t *fp = flags + a.wait_idx[cur.wait_begin + (lane < (int)cur.wait_count ? lane : 0)];
+                    int spins = 0;
+                    for (;;) {
+                        const unsigned done = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (__builtin_amdgcn_ballot_w64(done == 0) == 0) break;
+                        if (++spins > SPIN_LIMIT || __hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            if (lane == 0) {
+                                __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(a.async_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            }
+                            return;
+                        }
+                        if (spins < 16) __builtin_amdgcn_s_sleep(1);
+                        else __builtin_amdgcn_s_sleep(16); /* far from ready: poll about once per microsecond */
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* ordering only: no cache-wide invalidate */
+                }
+                intra_tu_any<true>(a, cur.t, lane, nbA, nbB, refs, resl[k & 1], rr, tile, wl, cur.tile_ok != 0);
+                if (cur.signal) { /* somebody outside the group reads this TU: publish it once its stores have completed */
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* s_waitcnt vmcnt(0); no L2-wide write-back */
+                    if (lane == 0) __hip_atomic_store(flags + (slots[3 * k + 2].z), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                wave_sync(); /* the next TU reuses the neighbour scratch and reads the tile this one wrote */
+                if (k + 1 < m) {
+                    /* issued behind this TU's stores and consumed half-way into the next TU: the in-order
+                     * vmcnt wait there then covers nothing younger than this fetch */
+                    cur = read_slot(slots, k + 1);
+                    fetch_residual(a, cur.t, lane, rr);
+                }
+            }
+            wave_sync(); /* slots[] is about to be overwritten */
+        }
     }
 }
 
 /* ------------------------------------------------------------------------ host */
 
-static uint32_t *g_work = nullptr;
+static uint32_t *g_work = nullptr; /* words */
 static size_t g_work_cap = 0;
+
+static int reserve_work(size_t words)
+{
+    if (words > g_work_cap) {
+        if (g_work) (void)hipFree(g_work);
+        g_work = nullptr;
+        g_work_cap = 0;
+        FFHIP_CHECK(hipMalloc((void **)&g_work, words * sizeof(uint32_t)), FFHIP_ENOMEM);
+        g_work_cap = words;
+    }
+    return FFHIP_OK;
+}
+
+struct GroupPlan {
+    std::vector<u32x4> sched;  /* 3 per slot */
+    std::vector<u32x4> groups;
+    std::vector<uint32_t> wait;
+};
+
+/* Cut the (validated) list into window-tile groups in order of first appearance and collect, per
+ * TU, the TUs of OTHER groups it reads, whether some other group reads it, and whether all its
+ * available neighbours inside the window were written by its own group (then the kernel may take
+ * them from its LDS tile).  Returns false when some TU would wait for a group with a larger
+ * ticket (window larger than the coding tree block, or an exotic list): the caller then tries a
+ * smaller window or falls back to the level-synchronous form. */
+static bool plan_groups(const ffhip_hevc_tu *tus, long long n_tus, const int pw[3], const int ph[3], const int win_log2[3],
+                        GroupPlan &out)
+{
+    std::vector<int32_t> owner[3], gid_of[3];
+    int bw[3], gw[3];
+    for (int c = 0; c < 3; c++) {
+        bw[c] = (pw[c] + 3) / 4;
+        gw[c] = pw[c] > 0 ? ((pw[c] - 1) >> win_log2[c]) + 1 : 0;
+        owner[c].assign((size_t)bw[c] * (size_t)((ph[c] + 3) / 4), -1);
+        gid_of[c].assign((size_t)gw[c] * (size_t)(ph[c] > 0 ? ((ph[c] - 1) >> win_log2[c]) + 1 : 0), -1);
+    }
+    struct Meta { uint32_t group, wait_begin; uint8_t wait_count, signal, tile_ok; };
+    std::vector<Meta> meta((size_t)n_tus);
+    std::vector<std::vector<uint32_t>> members;
+    std::vector<std::vector<uint32_t>> gdeps; /* per group: the groups it waits for (with repeats) */
+    out.wait.clear();
+    std::vector<int32_t> deps;
+    for (long long i = 0; i < n_tus; i++) {
+        const ffhip_hevc_tu &t = tus[i];
+        const int c = t.cidx, n = 1 << t.log2_size, wl = win_log2[c];
+        int32_t &gslot = gid_of[c][(size_t)(t.y >> wl) * gw[c] + (t.x >> wl)];
+        if (gslot < 0) { gslot = (int32_t)members.size(); members.emplace_back(); gdeps.emplace_back(); }
+        const uint32_t g = (uint32_t)gslot;
+        Meta &m = meta[(size_t)i];
+        m.group = g; m.signal = 0; m.tile_ok = 1;
+        members[g].push_back((uint32_t)i);
+        deps.clear();
+        const int wx0 = (t.x >> wl) << wl, wy0 = (t.y >> wl) << wl, wsz = 1 << wl;
+        auto dep = [&](int px, int py) {
+            const int32_t j = owner[c][(size_t)(py / 4) * bw[c] + px / 4];
+            const bool mine = j >= 0 && meta[(size_t)j].group == g;
+            if (j >= 0 && !mine) deps.push_back(j);
+            if (!mine && px >= wx0 && px < wx0 + wsz && py >= wy0 && py < wy0 + wsz) m.tile_ok = 0; /* not in my LDS copy */
+        };
+        if (t.flags & 1) dep(t.x - 1, t.y - 1);
+        for (int k = 0; k < 2 * n; k += 4) {
+            if ((t.avail_top >> k) & 0xf) dep(t.x + k, t.y - 1);
+            if ((t.avail_left >> k) & 0xf) dep(t.x - 1, t.y + k);
+        }
+        std::sort(deps.begin(), deps.end());
+        deps.erase(std::unique(deps.begin(), deps.end()), deps.end());
+        if (deps.size() > 64) return false;
+        m.wait_begin = (uint32_t)out.wait.size();
+        m.wait_count = (uint8_t)deps.size();
+        for (int32_t j : deps) {
+            if (meta[(size_t)j].group > g) return false;
+            if (gdeps[g].empty() || gdeps[g].back() != meta[(size_t)j].group) gdeps[g].push_back(meta[(size_t)j].group);
+            meta[(size_t)j].signal = 1;
+            out.wait.push_back((uint32_t)j);
+        }
+        for (int by = t.y / 4; by < (t.y + n) / 4; by++)
+            for (int bx = t.x / 4; bx < (t.x + n) / 4; bx++) owner[c][(size_t)by * bw[c] + bx] = (int32_t)i;
+    }
+    out.sched.clear();
+    out.groups.clear();
+    out.sched.reserve((size_t)n_tus * 3);
+    /* Tickets go out in dependency-depth order (ties: decode order), so the waves that hold tickets
+     * are the ones near the ready front rather than thousands of groups ahead of it, polling.
+     * Every group a group waits for has a smaller depth, hence a smaller ticket. */
+    std::vector<uint32_t> depth(members.size(), 0), order(members.size());
+    for (size_t g = 0; g < members.size(); g++) {
+        for (uint32_t d : gdeps[g]) depth[g] = std::max(depth[g], depth[d] + 1);
+        order[g] = (uint32_t)g;
+    }
+    if (!getenv("FFHIP_HEVC_INTRA_DECODE_ORDER"))
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return depth[x] < depth[y]; });
+    for (uint32_t gi : order) {
+        auto &mem = members[gi];
+        u32x4 g;
+        g.x = (uint32_t)(out.sched.size() / 3);
+        g.y = (uint32_t)mem.size();
+        g.z = (uint32_t)win_log2[tus[mem[0]].cidx];
+        g.w = 0;
+        out.groups.push_back(g);
+        for (uint32_t i : mem) {
+            u32x4 q[3];
+            static_assert(sizeof(ffhip_hevc_tu) == 32, "slot layout");
+            memcpy(q, &tus[i], 32);
+            const Meta &m = meta[i];
+            q[2].x = m.wait_begin;
+            q[2].y = (uint32_t)m.wait_count | ((uint32_t)m.signal << 8) | ((uint32_t)m.tile_ok << 9);
+            q[2].z = i;
+            q[2].w = 0;
+            out.sched.push_back(q[0]); out.sched.push_back(q[1]); out.sched.push_back(q[2]);
+        }
+    }
+    if (out.wait.empty()) out.wait.push_back(0);
+    return true;
+}
 
 extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu *d_tus, long long n_tus,
                                       const int16_t *d_residual, int16_t *d_y, int16_t *d_cb, int16_t *d_cr,
@@ -238,14 +549,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
     if (bitdepth_y < 8 || bitdepth_y > 15 || bitdepth_c < 8 || bitdepth_c > 15) return FFHIP_EINVAL;
     if (!ffhip_have_device()) return FFHIP_ENODEV;
     const int pw[3] = {width_y, width_c, width_c}, ph[3] = {height_y, height_c, height_c};
-    /* wavefront levels at 4x4-block granularity, per plane */
-    std::vector<int> lvl[3];
-    int bw[3];
-    for (int c = 0; c < 3; c++) {
-        bw[c] = (pw[c] + 3) / 4;
-        lvl[c].assign((size_t)(c == 0 || (d_cb && d_cr) ? bw[c] * ((ph[c] + 3) / 4) : 0), -1);
-    }
-    std::vector<std::vector<uint32_t>> lists;
+    /* validation: field ranges, the block inside its plane, and no availability bit pointing outside the plane */
     bool has_res = false;
     for (long long i = 0; i < n_tus; i++) {
         const ffhip_hevc_tu &t = h_tus[i];
@@ -253,42 +557,100 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
         if (c > 2 || t.log2_size < 2 || t.log2_size > 5 || t.pred_mode > 34) return FFHIP_EINVAL;
         if (c > 0 && (!d_cb || !d_cr || uv_stride < width_c)) return FFHIP_EINVAL;
         if (t.x + n > pw[c] || t.y + n > ph[c]) return FFHIP_EINVAL;
-        int lv = 0;
-        auto dep = [&](int px, int py) {
-            if (px < 0 || py < 0 || px >= pw[c] || py >= ph[c]) return false; /* a mask bit outside the plane */
-            lv = std::max(lv, lvl[c][(size_t)(py / 4) * bw[c] + px / 4] + 1);
-            return true;
-        };
-        if ((t.flags & 1) && !dep(t.x - 1, t.y - 1)) return FFHIP_EINVAL;
-        for (int k = 0; k < 2 * n; k++) {
-            if (((t.avail_top >> k) & 1) && !dep(t.x + k, t.y - 1)) return FFHIP_EINVAL;
-            if (((t.avail_left >> k) & 1) && !dep(t.x - 1, t.y + k)) return FFHIP_EINVAL;
-        }
-        for (int by = t.y / 4; by < (t.y + n) / 4; by++)
-            for (int bx = t.x / 4; bx < (t.x + n) / 4; bx++) lvl[c][(size_t)by * bw[c] + bx] = lv;
-        if ((size_t)lv >= lists.size()) lists.resize((size_t)lv + 1);
-        lists[(size_t)lv].push_back((uint32_t)i);
+        const unsigned long long span = n == 32 ? ~0ull : (1ull << (2 * n)) - 1;
+        const unsigned long long top = t.avail_top & span, left = t.avail_left & span;
+        const int room_x = pw[c] - t.x, room_y = ph[c] - t.y; /* samples that exist right of x0 / below y0 */
+        if ((top || (t.flags & 1)) && t.y == 0) return FFHIP_EINVAL;
+        if ((left || (t.flags & 1)) && t.x == 0) return FFHIP_EINVAL;
+        if (room_x < 64 && (top >> room_x)) return FFHIP_EINVAL;
+        if (room_y < 64 && (left >> room_y)) return FFHIP_EINVAL;
         has_res |= (t.flags & 2) != 0;
     }
+    /* wavefront levels at 4x4-block granularity, per plane: only the level-synchronous form needs them */
+    std::vector<std::vector<uint32_t>> lists;
+    auto build_levels = [&]() {
+        std::vector<int> lvl[3];
+        int bw[3];
+        for (int c = 0; c < 3; c++) {
+            bw[c] = (pw[c] + 3) / 4;
+            lvl[c].assign((size_t)(c == 0 || (d_cb && d_cr) ? bw[c] * ((ph[c] + 3) / 4) : 0), -1);
+        }
+        for (long long i = 0; i < n_tus; i++) {
+            const ffhip_hevc_tu &t = h_tus[i];
+            const int c = t.cidx, n = 1 << t.log2_size;
+            int lv = 0;
+            auto dep = [&](int px, int py) { lv = std::max(lv, lvl[c][(size_t)(py / 4) * bw[c] + px / 4] + 1); };
+            if (t.flags & 1) dep(t.x - 1, t.y - 1);
+            for (int k = 0; k < 2 * n; k++) {
+                if ((t.avail_top >> k) & 1) dep(t.x + k, t.y - 1);
+                if ((t.avail_left >> k) & 1) dep(t.x - 1, t.y + k);
+            }
+            for (int by = t.y / 4; by < (t.y + n) / 4; by++)
+                for (int bx = t.x / 4; bx < (t.x + n) / 4; bx++) lvl[c][(size_t)by * bw[c] + bx] = lv;
+            if ((size_t)lv >= lists.size()) lists.resize((size_t)lv + 1);
+            lists[(size_t)lv].push_back((uint32_t)i);
+        }
+    };
     if (has_res && !d_residual) return FFHIP_EINVAL;
-    if ((size_t)n_tus > g_work_cap) {
-        if (g_work) (void)hipFree(g_work);
-        g_work = nullptr;
-        g_work_cap = 0;
-        FFHIP_CHECK(hipMalloc((void **)&g_work, (size_t)n_tus * sizeof(uint32_t)), FFHIP_ENOMEM);
-        g_work_cap = (size_t)n_tus;
-    }
-    std::vector<uint32_t> flat;
-    flat.reserve((size_t)n_tus);
-    for (auto &l : lists) flat.insert(flat.end(), l.begin(), l.end());
     hipStream_t st = (hipStream_t)stream;
-    FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO);
-    FFHIP_CHECK(hipMemcpy(g_work, flat.data(), flat.size() * sizeof(uint32_t), hipMemcpyHostToDevice), FFHIP_EIO);
-    HevcIntraArgs a;
+    HevcIntraArgs a = {};
     a.tus = d_tus; a.residual = d_residual;
     a.plane[0] = d_y; a.plane[1] = d_cb; a.plane[2] = d_cr;
     a.stride[0] = y_stride; a.stride[1] = uv_stride; a.stride[2] = uv_stride;
     a.bitdepth_y = bitdepth_y; a.bitdepth_c = bitdepth_c;
+
+    /* grouped single-launch form unless FFHIP_HEVC_INTRA_MODE=levels (diagnostics) or no window works */
+    const char *mode_env = getenv("FFHIP_HEVC_INTRA_MODE");
+    const bool want_groups = !(mode_env && !strcmp(mode_env, "levels"));
+    int *async_err = want_groups ? ffhip_async_err_word() : nullptr;
+    if (want_groups && async_err) {
+        const char *we = getenv("FFHIP_HEVC_INTRA_WINDOW");
+        int wl = we ? atoi(we) : FFHIP_HEVC_INTRA_WINDOW_LOG2;
+        wl = wl < 3 ? 3 : (wl > 6 ? 6 : wl);
+        const int cs = (width_c > 0 && width_c * 2 <= width_y + 1) ? 1 : 0; /* chroma windows cover the same picture area */
+        GroupPlan plan;
+        bool ok = false;
+        for (; wl >= 3 && !ok; wl--) {
+            const int win[3] = {wl, wl - cs, wl - cs};
+            ok = plan_groups(h_tus, n_tus, pw, ph, win, plan);
+        }
+        if (ok) {
+            /* device image: sched | groups | wait | ctrl[4] + one done flag per TU */
+            const size_t w_sched = plan.sched.size() * 4, w_groups = plan.groups.size() * 4, w_wait = plan.wait.size();
+            const size_t w_ctrl = 4 + (size_t)n_tus;
+            const size_t o_groups = w_sched, o_wait = o_groups + w_groups, o_ctrl = (o_wait + w_wait + 3) & ~(size_t)3;
+            FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO); /* the work buffer may still be in use by an earlier call */
+            int rc = reserve_work(o_ctrl + w_ctrl);
+            if (rc) return rc;
+            FFHIP_CHECK(hipMemcpy(g_work, plan.sched.data(), w_sched * 4, hipMemcpyHostToDevice), FFHIP_EIO);
+            FFHIP_CHECK(hipMemcpy(g_work + o_groups, plan.groups.data(), w_groups * 4, hipMemcpyHostToDevice), FFHIP_EIO);
+            FFHIP_CHECK(hipMemcpy(g_work + o_wait, plan.wait.data(), w_wait * 4, hipMemcpyHostToDevice), FFHIP_EIO);
+            FFHIP_CHECK(hipMemsetAsync(g_work + o_ctrl, 0, w_ctrl * 4, st), FFHIP_EIO);
+            a.sched = (const u32x4 *)g_work;
+            a.groups = (const u32x4 *)(g_work + o_groups);
+            a.wait_idx = g_work + o_wait;
+            a.ctrl = g_work + o_ctrl;
+            a.async_err = async_err;
+            a.n_groups = (int)plan.groups.size();
+            const char *wv = getenv("FFHIP_HEVC_INTRA_WAVES");
+            const size_t max_waves = wv ? (size_t)std::max(1, atoi(wv)) : FFHIP_HEVC_INTRA_WAVES;
+            const unsigned wgs = (unsigned)std::min<size_t>(plan.groups.size(), max_waves); /* one wave each; waves loop over tickets */
+            hipLaunchKernelGGL(k_hevc_intra_groups, dim3(wgs), dim3(64), 0, st, a);
+            FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
+            return FFHIP_OK;
+        }
+    }
+
+    build_levels();
+    std::vector<uint32_t> flat;
+    flat.reserve((size_t)n_tus);
+    for (auto &l : lists) flat.insert(flat.end(), l.begin(), l.end());
+    FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO);
+    {
+        int rc = reserve_work((size_t)n_tus);
+        if (rc) return rc;
+    }
+    FFHIP_CHECK(hipMemcpy(g_work, flat.data(), flat.size() * sizeof(uint32_t), hipMemcpyHostToDevice), FFHIP_EIO);
     size_t off = 0;
     for (auto &l : lists) {
         a.work = g_work + off;

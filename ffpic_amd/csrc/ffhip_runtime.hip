@@ -54,6 +54,18 @@ extern "C" int ffhip_init(int device)
 
 extern "C" void ffhip_shutdown(void) { g_ready = 0; }
 
+/* One pinned, device-visible word that a kernel with an in-launch dependency wait writes when it
+ * gives up (its bounded spin ran out); checked and cleared by ffhip_stream_sync. */
+static int *g_async_err = nullptr;
+extern "C" int *ffhip_async_err_word(void)
+{
+    if (!g_async_err && ffhip_have_device()) {
+        if (hipHostMalloc((void **)&g_async_err, 64, hipHostMallocMapped) != hipSuccess) g_async_err = nullptr;
+        else *g_async_err = 0;
+    }
+    return g_async_err;
+}
+
 extern "C" const char *ffhip_arch_name(void) { return g_arch; }
 
 extern "C" const char *ffhip_strerror(int code)
@@ -103,6 +115,11 @@ extern "C" void ffhip_stream_destroy(void *s) { if (s) (void)hipStreamDestroy((h
 extern "C" int ffhip_stream_sync(void *s)
 {
     FFHIP_CHECK(hipStreamSynchronize((hipStream_t)s), FFHIP_EIO);
+    if (g_async_err && *(volatile int *)g_async_err) {
+        snprintf(g_last_error, sizeof g_last_error, "a dependency-scheduled kernel aborted (code %d)", *(volatile int *)g_async_err);
+        *(volatile int *)g_async_err = 0;
+        return FFHIP_EIO;
+    }
     return FFHIP_OK;
 }
 extern "C" void *ffhip_event_create(void)

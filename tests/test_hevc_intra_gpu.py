@@ -67,3 +67,29 @@ def test_every_mode_and_size_isolated():
             got = ops.hevc_intra_recon(tus[i:i + 1], res, w, h, False)[0]
             exp = O.oracle_hevc_intra(tus[i:i + 1], res, w, h, False)[0]
             assert np.array_equal(got, exp), (lg, i)
+
+
+@pytest.mark.parametrize("env", [{"FFHIP_HEVC_INTRA_MODE": "levels"}, {"FFHIP_HEVC_INTRA_WINDOW": "3"},
+                                 {"FFHIP_HEVC_INTRA_WINDOW": "4"}, {"FFHIP_HEVC_INTRA_WINDOW": "5"},
+                                 {"FFHIP_HEVC_INTRA_WINDOW": "6"}])
+def test_schedulers_agree(env, monkeypatch):
+    """the level-synchronous launches and the grouped single launch (any window) give the oracle's picture"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for (w, h, seed, adv, c444) in ((256, 192, 41, False, False), (192, 128, 42, True, False), (128, 128, 43, True, True)):
+        tus, res = synth.hevc_intra_tus(w, h, seed, adversarial_masks=adv, ccp=c444, chroma_444=c444)
+        csub = 1 if c444 else 2
+        got = ops.hevc_intra_recon(tus, res, w, h, True, 8, 8, csub=csub)
+        exp = O.oracle_hevc_intra(tus, res, w, h, True, 8, 8, csub=csub)
+        for gp, e, name in zip(got, exp, "YUV"):
+            assert np.array_equal(gp, e), (env, name)
+
+
+def test_grouped_form_small_ctb_falls_back_to_smaller_window():
+    """a 32x32 coding tree block list with the default 64 window would make groups wait for later
+    groups; the planner has to shrink the window (or fall back) and still be exact"""
+    tus, res = synth.hevc_intra_tus(256, 128, 44, ctb=32)
+    got = ops.hevc_intra_recon(tus, res, 256, 128, True, 8, 8)
+    exp = O.oracle_hevc_intra(tus, res, 256, 128, True, 8, 8)
+    for gp, e, name in zip(got, exp, "YUV"):
+        assert np.array_equal(gp, e), name

@@ -60,14 +60,33 @@ def pred():
 pred(); torch.cuda.synchronize()
 t0 = time.perf_counter(); pred(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
 out["vp8_predict_recon_16x1080p"] = {"wall_ms": round(dt, 3), "Mpx/s": round(nf * 256 * c * r / dt / 1e3, 1), "levels": c + 2 * (r - 1)}
-# --- HEVC intra recon, one 1920x1088 picture
-tus, res = synth.hevc_intra_tus(1920, 1088 + 64 - 1088 % 64 if 1088 % 64 else 1088, seed=1)
-H = 1088 + 64 - 1088 % 64 if 1088 % 64 else 1088
-dtus = torch.from_numpy(tus.view(np.uint8).copy()).to(dev); dres = torch.from_numpy(res).to(dev)
-py = torch.zeros((H, 1920), dtype=torch.int16, device=dev); pu = torch.zeros((H // 2, 960), dtype=torch.int16, device=dev); pv = torch.zeros_like(pu)
-def intra():
-    capi.check(L.ffhip_hevc_intra_recon(tus.ctypes.data, dtus.data_ptr(), len(tus), dres.data_ptr(), py.data_ptr(), pu.data_ptr(), pv.data_ptr(), 1920, H, 1920, 960, H // 2, 960, 8, 8, st))
-intra(); torch.cuda.synchronize()
-t0 = time.perf_counter(); intra(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
-out["hevc_intra_recon_1080p"] = {"wall_ms": round(dt, 3), "tus": int(len(tus)), "Mpx/s": round(1920 * H / dt / 1e3, 1)}
+# --- HEVC intra recon: one 1920x1088 picture, then the 8K picture of config 5, level launches vs grouped single launch
+def intra_case(tag, W, H, seed, envs):
+    tus, res = synth.hevc_intra_tus(W, H, seed=seed)
+    dtus = torch.from_numpy(tus.view(np.uint8).copy()).to(dev); dres = torch.from_numpy(res).to(dev)
+    py = torch.zeros((H, W), dtype=torch.int16, device=dev); pu = torch.zeros((H // 2, W // 2), dtype=torch.int16, device=dev); pv = torch.zeros_like(pu)
+    def intra():
+        capi.check(L.ffhip_hevc_intra_recon(tus.ctypes.data, dtus.data_ptr(), len(tus), dres.data_ptr(), py.data_ptr(), pu.data_ptr(), pv.data_ptr(), W, H, W, W // 2, H // 2, W // 2, 8, 8, st))
+    for name, env in envs:
+        for k in ("FFHIP_HEVC_INTRA_MODE", "FFHIP_HEVC_INTRA_WINDOW", "FFHIP_HEVC_INTRA_WAVES", "FFHIP_HEVC_INTRA_DECODE_ORDER"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        intra(); capi.check(L.ffhip_stream_sync(st))
+        best_wall, best_dev = 1e9, 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            intra()
+            capi.check(L.ffhip_stream_sync(st))
+            best_wall = min(best_wall, (time.perf_counter() - t0) * 1e3)
+        out[f"hevc_intra_recon_{tag}_{name}"] = {"wall_ms": round(best_wall, 3), "tus": int(len(tus)), "Mpx/s": round(W * H / best_wall / 1e3, 1)}
+    for k in ("FFHIP_HEVC_INTRA_MODE", "FFHIP_HEVC_INTRA_WINDOW"):
+        os.environ.pop(k, None)
+envs = [("levels", {"FFHIP_HEVC_INTRA_MODE": "levels"})] + [(f"groups_w{1 << w}", {"FFHIP_HEVC_INTRA_WINDOW": str(w)}) for w in (6, 5, 4, 3)]
+if "--sweep" in sys.argv:
+    envs += [(f"w32_waves{n}", {"FFHIP_HEVC_INTRA_WAVES": str(n)}) for n in (128, 256, 512, 2048, 4096)]
+    envs += [(f"w16_waves{n}", {"FFHIP_HEVC_INTRA_WAVES": str(n), "FFHIP_HEVC_INTRA_WINDOW": "4"}) for n in (512, 2048, 4096)]
+    envs += [("w32_decode_order_4096", {"FFHIP_HEVC_INTRA_WAVES": "4096", "FFHIP_HEVC_INTRA_DECODE_ORDER": "1"})]
+intra_case("1080p", 1920, 1088 + 64 - 1088 % 64 if 1088 % 64 else 1088, 1, envs)
+if "--8k" in sys.argv:
+    intra_case("8K", 7680, 4352, 2, envs)
 print(json.dumps(out, indent=1))

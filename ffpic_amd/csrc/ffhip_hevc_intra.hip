@@ -141,7 +141,7 @@ __device__ __forceinline__ void intra_tu(const HevcIntraArgs &a, const ffhip_hev
             if (GROUPED) {
                 const unsigned tx = (unsigned)(px - wx0), ty = (unsigned)(py - wy0);
                 if (tile_ok && tx < (unsigned)wsz && ty < (unsigned)wsz) v = (int)tile[ty * TILE_STRIDE + tx];
-                else v = (int)__hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else v = ffhip_load_s16_sc1(ffhip_rsrc(plane, 0xffffffffu), (py * stride + px) * 2);
             } else {
                 v = (int)*sp;
             }
@@ -603,7 +603,8 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
     const char *mode_env = getenv("FFHIP_HEVC_INTRA_MODE");
     const bool want_groups = !(mode_env && !strcmp(mode_env, "levels"));
     int *async_err = want_groups ? ffhip_async_err_word() : nullptr;
-    if (want_groups && async_err) {
+    const bool offsets_fit = (long long)y_stride * height_y < (1LL << 30) && (long long)uv_stride * (height_c > 0 ? height_c : 1) < (1LL << 30);
+    if (want_groups && async_err && offsets_fit /* 32-bit byte offsets into a plane */) {
         const char *we = getenv("FFHIP_HEVC_INTRA_WINDOW");
         int wl = we ? atoi(we) : FFHIP_HEVC_INTRA_WINDOW_LOG2;
         wl = wl < 3 ? 3 : (wl > 6 ? 6 : wl);

@@ -32,4 +32,25 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+#ifdef __HIPCC__
+/* Device-coherent ("sc1") loads that are ORDINARY loads to the compiler: a relaxed agent-scope
+ * __hip_atomic_load of a sub-dword type gets an s_waitcnt vmcnt(0) right behind it (its extension
+ * is a separate instruction), which serialises every fetch; a raw buffer load with the sc1 bit in
+ * its cache policy is the same memory operation and is waited for at first use only.
+ * Out-of-range offsets (offset >= bytes, so negative ones too) read as 0. */
+#define FFHIP_AUX_SC1 16
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ffhip_rsrc(const void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ int ffhip_load_u8_sc1(__amdgpu_buffer_rsrc_t r, int byte_off)
+{
+    return (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(r, byte_off, 0, FFHIP_AUX_SC1);
+}
+__device__ __forceinline__ int ffhip_load_s16_sc1(__amdgpu_buffer_rsrc_t r, int byte_off)
+{
+    return (int)(short)__builtin_amdgcn_raw_buffer_load_b16(r, byte_off, 0, FFHIP_AUX_SC1);
+}
+#endif
+
 #endif

@@ -55,3 +55,33 @@ def test_1080p_frame():
     """BASELINE config 4 geometry: 120 x 68 macroblocks"""
     c, r = 120, 68
     check(c, r, synth.vp8_modes(c, r, seed=4), synth.vp8_residual(c * r, seed=4))
+
+
+@pytest.mark.parametrize("env", [{"FFHIP_VP8_PRED_MODE": "levels"}, {"FFHIP_VP8_PRED_WAVES": "3"}, {}])
+def test_schedulers_agree(env, monkeypatch):
+    """level-synchronous launches, and the single row-form launch with few and with many waves"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    c, r, n = 23, 11, 4
+    modes = np.stack([synth.vp8_modes(c, r, seed=170 + i) for i in range(n)])
+    modes[1, np.arange(r) * c, 0] = 3        # H_PRED down the whole left column: every row waits for the full row above
+    resid = np.stack([synth.vp8_residual(c * r, seed=170 + i, amplitude=60) for i in range(n)])
+    got = ops.vp8_predict_recon(c, r, modes, resid)
+    for i in range(n):
+        exp = O.oracle_vp8_frame(c, r, modes[i], resid[i])
+        for gp, e, name in zip(got, exp, "YUV"):
+            assert np.array_equal(gp[i], e), (env, i, name)
+
+
+def test_row_handoff_stress():
+    """many 1080p frames at once, twice over the same planes: every byte of every frame against the
+    oracle -- the row-to-row hand-off (agent-scope stores, progress counters) under uneven load"""
+    c, r, n = 120, 68, 6
+    modes = np.stack([synth.vp8_modes(c, r, seed=300 + i) for i in range(n)])
+    resid = np.stack([synth.vp8_residual(c * r, seed=300 + i, amplitude=70) for i in range(n)])
+    exp = [O.oracle_vp8_frame(c, r, modes[i], resid[i]) for i in range(n)]
+    for _ in range(2):
+        got = ops.vp8_predict_recon(c, r, modes, resid)
+        for i in range(n):
+            for gp, e, name in zip(got, exp[i], "YUV"):
+                assert np.array_equal(gp[i], e), (i, name)

@@ -18,6 +18,9 @@
  */
 #include "ffhip_internal.h"
 
+#include <algorithm>
+#include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 struct Vp8LfArgs {
@@ -27,6 +30,10 @@ struct Vp8LfArgs {
     uint8_t *y, *u, *v;
     long long plane_y, plane_uv;
     int mbcols, mbrows, count, filter_type;
+    /* row form only */
+    uint32_t *ctrl; /* [0] next row ticket, [1] abort; from ctrl + 4: macroblocks finished per (image, row) */
+    int *async_err;
+    int n_images;
 };
 
 __device__ __forceinline__ int sclip1(int v) { return v < -128 ? -128 : (v > 127 ? 127 : v); }
@@ -190,6 +197,192 @@ __global__ __launch_bounds__(256) void k_vp8_loopfilter(Vp8LfArgs a)
         }
 }
 
+/* Row form: ONE launch per batch, the scheme of k_vp8_predict_rows.  A wave owns one macroblock row
+ * of one image; macroblock (x, y) may start once (x + 1, y - 1) is out, which the row above says
+ * through its progress counter.  Going left to right, the 4-pixel left border is simply the right
+ * end of the tile the wave has just filtered, so per macroblock only the new 16 (8) columns are
+ * fetched -- two macroblocks ahead, with device-coherent loads because the four rows above belong
+ * to another wave -- and the filtered columns are stored with agent-scope stores.  The counter moves
+ * when the in-order completion of the wave's memory operations proves those stores done. */
+#define LF_SPIN_LIMIT (1 << 21)
+
+struct LfFetch {
+    u32 d[2];  /* items lane and lane + 64 of: 80 luma dwords (20 rows x 4), then 48 chroma dwords (2 planes x 12 rows x 2) */
+    u32 m0, m4; /* mode bytes 0..3 and 16..19 of the macroblock */
+};
+
+__global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t TL[20 * LS];
+    __shared__ __attribute__((aligned(16))) uint8_t TC[2][12 * CS];
+    __shared__ uint8_t FT[24];
+    const int lane = threadIdx.x;
+    const int n_mb = a.mbcols * a.mbrows;
+    const int ys = 16 * a.mbcols, us = 8 * a.mbcols;
+    const int type = a.filter_type;
+    uint32_t *progress = a.ctrl + 4;
+    if (lane < 24) FT[lane] = a.filters[lane]; /* a read from memory per macroblock would drain the fetches in flight */
+    wave_sync();
+    for (;;) {
+        unsigned ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(&a.ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+        if (ticket >= (unsigned)(a.n_images * a.mbrows)) return;
+        const int y = (int)(ticket / (unsigned)a.n_images), img = (int)(ticket % (unsigned)a.n_images);
+        uint8_t *Y = a.y + (long long)img * a.plane_y;
+        uint8_t *P[2] = {a.u + (long long)img * a.plane_uv, a.v + (long long)img * a.plane_uv};
+        const uint8_t *mrow = a.modes + ((long long)img * n_mb + (long long)y * a.mbcols) * 20;
+        const uint32_t *prog_up = progress + (long long)img * a.mbrows + y - 1;
+        uint32_t *prog_me = progress + (long long)img * a.mbrows + y;
+        unsigned seen = y == 0 ? 0x7fffffffu : 0u;
+        const __amdgpu_buffer_rsrc_t rY = ffhip_rsrc(Y, 256u * (unsigned)n_mb), rU = ffhip_rsrc(P[0], 64u * (unsigned)n_mb),
+                                     rV = ffhip_rsrc(P[1], 64u * (unsigned)n_mb);
+
+        auto fetch = [&](int x1, LfFetch &f) -> bool {
+            const unsigned need = y == 0 ? 0u : (unsigned)(x1 + 2 < a.mbcols ? x1 + 2 : a.mbcols);
+            int spins = 0;
+            while (seen < need) {
+                seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(prog_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (seen >= need) break;
+                if (++spins > LF_SPIN_LIMIT || __hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    if (lane == 0) {
+                        __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(a.async_err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    return false;
+                }
+                if (spins < 16) __builtin_amdgcn_s_sleep(1);
+                else __builtin_amdgcn_s_sleep(16);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* ordering only */
+            const u32 *mp = (const u32 *)(mrow + (long long)x1 * 20);
+            f.m0 = mp[0];
+            f.m4 = mp[4];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int i = lane + 64 * j;
+                u32 v = 0;
+                if (i < 80) { /* rows -4..15 of the 16 new luma columns; offsets before the plane read as 0 and are never used */
+                    v = (u32)__builtin_amdgcn_raw_buffer_load_b32(rY, (y * 16 + (i >> 2) - 4) * ys + x1 * 16 + 4 * (i & 3), 0, FFHIP_AUX_SC1);
+                } else if (type != 1) {
+                    const int k = i - 80, pl = k >= 24, kk = pl ? k - 24 : k;
+                    const int off = (y * 8 + (kk >> 1) - 4) * us + x1 * 8 + 4 * (kk & 1);
+                    v = (u32)__builtin_amdgcn_raw_buffer_load_b32(pl ? rV : rU, off, 0, FFHIP_AUX_SC1);
+                }
+                f.d[j] = v;
+            }
+            return true;
+        };
+
+        LfFetch f, f1;
+        if (!fetch(0, f)) return;
+        f1 = f;
+        if (a.mbcols > 1 && !fetch(1, f1)) return;
+        for (int x = 0; x < a.mbcols; x++) {
+            /* ---- consume: the tile's right end becomes the left border, the fetch the new columns ---- */
+            u32 keepl = 0, keepc = 0;
+            if (lane < 20) keepl = *(const u32 *)(TL + lane * LS + 16);
+            if (lane >= 32 && lane < 56) keepc = *(const u32 *)(TC[(lane - 32) / 12] + ((lane - 32) % 12) * CS + 8);
+            wave_sync();
+            if (lane < 20) *(u32 *)(TL + lane * LS) = keepl;
+            if (lane >= 32 && lane < 56) *(u32 *)(TC[(lane - 32) / 12] + ((lane - 32) % 12) * CS) = keepc;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int i = lane + 64 * j;
+                if (i < 80) *(u32 *)(TL + (i >> 2) * LS + 4 + 4 * (i & 3)) = f.d[j];
+                else if (type != 1) {
+                    const int k = i - 80, pl = k >= 24, kk = pl ? k - 24 : k;
+                    *(u32 *)(TC[pl] + (kk >> 1) * CS + 4 + 4 * (kk & 1)) = f.d[j];
+                }
+            }
+            const u32 m0 = (u32)__builtin_amdgcn_readfirstlane((int)f.m0), m4 = (u32)__builtin_amdgcn_readfirstlane((int)f.m4);
+            wave_sync();
+            /* the fetch just consumed was issued behind the stores of macroblock x - 3: those are done */
+            if (lane == 0 && x >= 3) __hip_atomic_store(prog_me, (unsigned)(x - 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            LfFetch fn = f1;
+            if (x + 2 < a.mbcols && !fetch(x + 2, fn)) return;
+
+            const bool bpred = (m0 & 0xff) == 4;
+            const uint8_t *fp = FT + ((((m4 >> 16) & 3) * 2) + (bpred ? 1 : 0)) * 3;
+            const int sub = __builtin_amdgcn_readfirstlane((int)fp[0]), inter = __builtin_amdgcn_readfirstlane((int)fp[1]),
+                      hevt = __builtin_amdgcn_readfirstlane((int)fp[2]);
+            if (sub) { /* wave-uniform */
+                /* webp.c:1710-1745: inner edges for B_PRED MBs in the simple filter, for the others in the normal one */
+                const bool inner = type == 1 ? bpred : !bpred;
+                /* ---- vertical edges: one pixel row per lane (lanes 0-15 luma, 16-23 U, 24-31 V) ---- */
+                if (lane < 16) {
+                    int line[20];
+                    uint8_t *row = TL + (lane + 4) * LS;
+#pragma unroll
+                    for (int k = 0; k < 20; k++) line[k] = row[k];
+                    filter_line<16>(line, type, x > 0, inner, sub, inter, hevt);
+#pragma unroll
+                    for (int k = 1; k < 19; k++) row[k] = (uint8_t)line[k];
+                } else if (lane < 32 && type != 1) {
+                    int line[12];
+                    uint8_t *row = TC[(lane >> 3) & 1] + ((lane & 7) + 4) * CS;
+#pragma unroll
+                    for (int k = 0; k < 12; k++) line[k] = row[k];
+                    filter_line<8>(line, type, x > 0, inner, sub, inter, hevt);
+#pragma unroll
+                    for (int k = 1; k < 11; k++) row[k] = (uint8_t)line[k];
+                }
+                wave_sync();
+                /* ---- horizontal edges: one pixel column per lane ---- */
+                if (lane < 16) {
+                    int line[20];
+                    uint8_t *col = TL + lane + 4;
+#pragma unroll
+                    for (int k = 0; k < 20; k++) line[k] = col[k * LS];
+                    filter_line<16>(line, type, y > 0, inner, sub, inter, hevt);
+#pragma unroll
+                    for (int k = 1; k < 19; k++) col[k * LS] = (uint8_t)line[k];
+                } else if (lane < 32 && type != 1) {
+                    int line[12];
+                    uint8_t *col = TC[(lane >> 3) & 1] + (lane & 7) + 4;
+#pragma unroll
+                    for (int k = 0; k < 12; k++) line[k] = col[k * CS];
+                    filter_line<8>(line, type, y > 0, inner, sub, inter, hevt);
+#pragma unroll
+                    for (int k = 1; k < 11; k++) col[k * CS] = (uint8_t)line[k];
+                }
+                wave_sync();
+                /* ---- write back rows -4..15, columns -4..15 as dwords (the cells this macroblock did not
+                 * change are rewritten with the value it read: their owners are finished) -- but nothing
+                 * outside the picture ---- */
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int i = lane + 64 * j;
+                    if (i < 100) {
+                        const int row = i / 5, d = i % 5;
+                        if ((row >= 4 || y > 0) && (d > 0 || x > 0))
+                            __hip_atomic_store((u32 *)(Y + (long long)(y * 16 + row - 4) * ys + x * 16 + 4 * d - 4), *(const u32 *)(TL + row * LS + 4 * d),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                if (type != 1) {
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        const int i = lane + 64 * j;
+                        if (i < 72) {
+                            const int pl = i >= 36, k = pl ? i - 36 : i, row = k / 3, d = k % 3;
+                            if ((row >= 4 || y > 0) && (d > 0 || x > 0))
+                                __hip_atomic_store((u32 *)(P[pl] + (long long)(y * 8 + row - 4) * us + x * 8 + 4 * d - 4), *(const u32 *)(TC[pl] + row * CS + 4 * d),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+            }
+            wave_sync();
+            f = f1;
+            f1 = fn;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(prog_me, (unsigned)a.mbcols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 static uint32_t *g_work = nullptr;
 static size_t g_work_cap = 0;
 
@@ -203,6 +396,34 @@ extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int fi
     const long long n_mb = (long long)mbcols * mbrows;
     if (n_mb * n_images > 0x3fffffffLL) return FFHIP_EINVAL;
     if (!ffhip_have_device()) return FFHIP_ENODEV;
+    hipStream_t st = (hipStream_t)stream;
+    /* row form (default): one launch, no host-side scheduling */
+    const char *mode_env = getenv("FFHIP_VP8_LF_MODE");
+    int *async_err = (mode_env && !strcmp(mode_env, "levels")) ? nullptr : ffhip_async_err_word();
+    if (async_err && !((uintptr_t)d_modes & 3) && !(((uintptr_t)d_y | (uintptr_t)d_u | (uintptr_t)d_v | (uintptr_t)plane_stride_y | (uintptr_t)plane_stride_uv) & 3) &&
+        n_mb < (1LL << 23)) {
+        const size_t words = 4 + (size_t)n_images * (size_t)mbrows;
+        if (words > g_work_cap) {
+            FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO);
+            if (g_work) (void)hipFree(g_work);
+            g_work = nullptr;
+            g_work_cap = 0;
+            FFHIP_CHECK(hipMalloc((void **)&g_work, words * sizeof(uint32_t)), FFHIP_ENOMEM);
+            g_work_cap = words;
+        }
+        FFHIP_CHECK(hipMemsetAsync(g_work, 0, words * sizeof(uint32_t), st), FFHIP_EIO);
+        Vp8LfArgs a = {};
+        a.modes = d_modes; a.filters = d_filters; a.y = d_y; a.u = d_u; a.v = d_v;
+        a.plane_y = plane_stride_y; a.plane_uv = plane_stride_uv;
+        a.mbcols = mbcols; a.mbrows = mbrows; a.filter_type = filter_type;
+        a.ctrl = g_work; a.async_err = async_err; a.n_images = n_images;
+        const char *wv = getenv("FFHIP_VP8_LF_WAVES");
+        const long long cap = wv ? std::max(1, atoi(wv)) : 2048;
+        hipLaunchKernelGGL(k_vp8_loopfilter_rows, dim3((unsigned)std::min<long long>((long long)n_images * mbrows, cap)), dim3(64), 0, st, a);
+        FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
+        return FFHIP_OK;
+    }
+
     /* levels x + 2y: the same for every image, no mode-dependent edges here */
     const int n_levels = mbcols + 2 * (mbrows - 1);
     std::vector<std::vector<uint32_t>> lists((size_t)n_levels);
@@ -223,7 +444,6 @@ extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int fi
     std::vector<uint32_t> flat;
     flat.reserve(total);
     for (auto &l : lists) flat.insert(flat.end(), l.begin(), l.end());
-    hipStream_t st = (hipStream_t)stream;
     FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO);
     FFHIP_CHECK(hipMemcpy(g_work, flat.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice), FFHIP_EIO);
     Vp8LfArgs a;

@@ -85,3 +85,37 @@ def test_webp_file_config4(golden):
     y, u, v = ops.vp8_loopfilter(c, r, 0, g["modes"][None], synth.vp8_filters(), y, u, v)   # level 0: a no-op
     bgra = ops.yuv420_to_bgra(y, u, v, r, c, pitch=pitch)
     assert np.array_equal(bgra[0][:h], g["bgra"])
+
+
+@pytest.mark.parametrize("env", [{"FFHIP_VP8_LF_MODE": "levels"}, {"FFHIP_VP8_LF_WAVES": "3"}, {}])
+@pytest.mark.parametrize("ft", [1, 2])
+def test_lf_schedulers_agree(env, ft, monkeypatch):
+    """level-synchronous launches vs the single row-form launch (few / many waves), both filter types"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    c, r, n = 21, 13, 3
+    modes = np.stack([synth.vp8_modes(c, r, seed=500 + i) for i in range(n)])
+    modes[..., 18] = np.random.default_rng(5).integers(0, 4, size=modes[..., 18].shape)
+    flt = synth.vp8_filters(seed=7)
+    planes = [synth.vp8_blocky_planes(c, r, seed=510 + i) for i in range(n)]
+    y = np.stack([p[0] for p in planes]); u = np.stack([p[1] for p in planes]); v = np.stack([p[2] for p in planes])
+    got = ops.vp8_loopfilter(c, r, ft, modes, flt, y, u, v)
+    for i in range(n):
+        exp = oracle_lf(c, r, ft, modes[i], flt, (y[i], u[i], v[i]))
+        for gp, e, name in zip(got, exp, "YUV"):
+            assert np.array_equal(gp[i], e), (env, ft, i, name)
+
+
+def test_lf_row_handoff_stress():
+    """several 1080p frames at once, every byte against the oracle"""
+    c, r, n = 120, 68, 4
+    modes = np.stack([synth.vp8_modes(c, r, seed=600 + i) for i in range(n)])
+    flt = synth.vp8_filters(seed=9)
+    planes = [synth.vp8_blocky_planes(c, r, seed=610 + i) for i in range(n)]
+    y = np.stack([p[0] for p in planes]); u = np.stack([p[1] for p in planes]); v = np.stack([p[2] for p in planes])
+    for ft in (1, 2):
+        got = ops.vp8_loopfilter(c, r, ft, modes, flt, y, u, v)
+        for i in range(n):
+            exp = oracle_lf(c, r, ft, modes[i], flt, (y[i], u[i], v[i]))
+            for gp, e, name in zip(got, exp, "YUV"):
+                assert np.array_equal(gp[i], e), (ft, i, name)

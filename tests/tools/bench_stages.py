@@ -66,6 +66,19 @@ for name, env in (("levels", {"FFHIP_VP8_PRED_MODE": "levels"}), ("rows", {})):
         t0 = time.perf_counter(); pred(); capi.check(L.ffhip_stream_sync(st)); best = min(best, (time.perf_counter() - t0) * 1e3)
     out[f"vp8_predict_recon_16x1080p_{name}"] = {"wall_ms": round(best, 3), "Mpx/s": round(nf * 256 * c * r / best / 1e3, 1)}
 os.environ.pop("FFHIP_VP8_PRED_MODE", None)
+# --- VP8 loop filter, same 16 frames
+flt = torch.from_numpy(synth.vp8_filters(seed=3)).to(dev)
+def lf():
+    capi.check(L.ffhip_vp8_loopfilter(c, r, nf, 2, dm.data_ptr(), flt.data_ptr(), Y.data_ptr(), U.data_ptr(), V.data_ptr(), 256 * c * r, 64 * c * r, st))
+for name, env in (("levels", {"FFHIP_VP8_LF_MODE": "levels"}), ("rows", {})):
+    os.environ.pop("FFHIP_VP8_LF_MODE", None)
+    os.environ.update(env)
+    lf(); capi.check(L.ffhip_stream_sync(st))
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter(); lf(); capi.check(L.ffhip_stream_sync(st)); best = min(best, (time.perf_counter() - t0) * 1e3)
+    out[f"vp8_loopfilter_normal_16x1080p_{name}"] = {"wall_ms": round(best, 3), "Mpx/s": round(nf * 256 * c * r / best / 1e3, 1)}
+os.environ.pop("FFHIP_VP8_LF_MODE", None)
 # --- HEVC intra recon: one 1920x1088 picture, then the 8K picture of config 5, level launches vs grouped single launch
 def intra_case(tag, W, H, seed, envs):
     tus, res = synth.hevc_intra_tus(W, H, seed=seed)

@@ -57,7 +57,8 @@ int ffhip_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
 int ffhip_memset(void *dst, int value, size_t bytes, void *stream);
 void *ffhip_stream_create(void);
 void ffhip_stream_destroy(void *stream);
-int ffhip_stream_sync(void *stream); /* NULL = the default stream */
+int ffhip_stream_sync(void *stream); /* NULL = the default stream; FFHIP_EIO also if a dependency-scheduled
+                                         kernel (VP8 predict / loop filter, HEVC intra) reported an abort */
 void *ffhip_event_create(void);
 void ffhip_event_destroy(void *event);
 int ffhip_event_record(void *event, void *stream);
@@ -265,7 +266,10 @@ int ffhip_hevc_residual_batch(int nTbS, long long n_tu, const int16_t *d_level, 
  *                      bytes before them matter exactly where the reference's 16x16 V_PRED /
  *                      H_PRED read raw memory at the top row / left column (predict.c:338-353):
  *                      bytes before a plane read as 0.
- * Enqueues one launch per wavefront level on `stream` (synchronises it once first). */
+ * Enqueues ONE launch on `stream`: a wave per macroblock row, rows chained through progress
+ * counters inside the launch; should a wave's bounded wait ever run out, the next
+ * ffhip_stream_sync on any stream returns FFHIP_EIO.  FFHIP_VP8_PRED_MODE=levels selects the older
+ * one-launch-per-wavefront-level form.  Not re-entrant: one call at a time per process. */
 int ffhip_vp8_predict_recon(int mbcols, int mbrows, int n_images, const uint8_t *h_modes,
                             const uint8_t *d_modes, const int16_t *d_residual, int64_t residual_stride,
                             const int32_t *d_resmap, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
@@ -304,8 +308,11 @@ typedef struct ffhip_hevc_tu {
                                   block itself, so r += (res_scale * ((r << BitDepthC) >> BitDepthY)) >> 3 */
 /* h_tus / d_tus: the SAME n_tus records on the host (dependency scheduling) and on the device.
  * d_residual: int16 residual blocks (row-major n*n each) as ffhip_hevc_residual_batch writes
- * them.  Planes: int16, strides in samples; d_cb/d_cr may be NULL for 4:0:0.  Enqueues one
- * launch per dependency level on `stream` (synchronises it once first). */
+ * them.  Planes: int16, strides in samples; d_cb/d_cr may be NULL for 4:0:0.  Synchronises
+ * `stream` once (its schedule buffer may be in use), then enqueues ONE launch: TUs grouped by 32x32
+ * window, a wave per group, done flags between groups; a bounded wait that ever
+ * runs out surfaces as FFHIP_EIO from the next ffhip_stream_sync.  FFHIP_HEVC_INTRA_MODE=levels
+ * selects the older one-launch-per-dependency-level form.  Not re-entrant. */
 int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu *d_tus, long long n_tus,
                            const int16_t *d_residual, int16_t *d_y, int16_t *d_cb, int16_t *d_cr,
                            int width_y, int height_y, int y_stride, int width_c, int height_c,

@@ -7,9 +7,10 @@
  *   idct_4x4_hevc (luma intra 4x4) utils/idct.c:9-55, with its `+ (shift-1)` rounding
  *   transform-skip / bypass glue   coding/hevc.c:4209-4236
  *
- * HBM-bound: 2 B of levels in + 2 B of residual out per sample.  One lane owns one row of
- * a TU for loading/scaling/storing and one column (then one row) for the two 1-D passes;
- * a wave holds 64/N TUs.  The transposes go through LDS with ds_read_b64_tr_b16, whose
+ * HBM-bound: 2 B of levels in + 2 B of residual out per sample.  A wave holds 64/N TUs = 64 rows.
+ * Levels come in and residuals go out as linear 16-byte-per-lane copies through the wave's LDS tile
+ * (a row per lane would make every load a 64-lane gather with a 2N-byte stride: 1.5 TB/s at N = 32);
+ * in between one lane owns one column (then one row) for the two 1-D passes.  The transposes go through LDS with ds_read_b64_tr_b16, whose
  * row order is the bit-reversal-like order of the partial butterflies so each lane
  * receives ready-made (x_a, x_b) int16 pairs for v_dot2_i32_i16; the N-point transform is
  * the recursive even/odd decomposition of the H.265 matrix (N/2-point on the even inputs
@@ -123,60 +124,97 @@ __global__ __launch_bounds__(256) void k_hevc_residual(HevcResArgs a)
     if (!live) tu = a.n_tu - 1; /* keep EXEC full for the transposing reads; stores are masked */
 
     const u32 info = *(const u32 *)(a.tuinfo + tu * 4);
-    const int qP = info & 0xff;
-    const u32 flags = (info >> 8) & 0xff, mid = (info >> 16) & 0xff;
+    const u32 flags = (info >> 8) & 0xff;
     const int range = a.epp ? (a.bitdepth + 6 > 15 ? a.bitdepth + 6 : 15) : 15;
     const int cmin = -(1 << range), cmax = (1 << range) - 1;
 
-    /* ---- load the lane's row and scale it (hevc.c:3786-3805) ---- */
-    u32 rowp[W];
-    {
-        const u32 *src = (const u32 *)(a.level + tu * (N * N) + idx * N);
+    /* ---- levels -> scaled coefficients d (hevc.c:3786-3805) -> LDS, as a LINEAR copy: lane L of pass c
+     * takes samples (64c + L)*CH .. +CH of the wave's 64 rows, so every load is 16 (8) contiguous bytes
+     * per lane and the tile in LDS is simply row-major [tu][row][col] ---- */
+    constexpr int CH = N >= 8 ? 8 : 4;  /* samples per lane per pass */
+    constexpr int NCH = N / CH;         /* passes                    */
+    const long long tu0 = ((long long)blockIdx.x * 4 + wave) * TPW;
+    bool chunk_store[NCH];              /* does this chunk's TU take the transform path and exist? */
 #pragma unroll
-        for (int i = 0; i < W; i++) rowp[i] = __builtin_nontemporal_load(src + i);
-    }
-    int d[N];
-    if (flags & TU_BYPASS) {
+    for (int c = 0; c < NCH; c++) {
+        const u32 s0 = (64u * c + lane) * CH, tul = s0 / (N * N), pos = s0 % (N * N);
+        long long tuc = tu0 + tul;
+        const bool livec = tuc < a.n_tu;
+        if (!livec) tuc = a.n_tu - 1;
+        const u32 inf = *(const u32 *)(a.tuinfo + tuc * 4);
+        const int qP = inf & 0xff;
+        const u32 fl = (inf >> 8) & 0xff, mid = (inf >> 16) & 0xff;
+        chunk_store[c] = livec && !(fl & (TU_BYPASS | TU_TSKIP));
+        u32 raw[CH / 2];
+        if (CH == 8) {
+            const u32x4 v = __builtin_nontemporal_load((const u32x4 *)(a.level + tuc * (N * N) + pos));
+            raw[0] = v[0]; raw[1] = v[1]; raw[CH / 2 - 2] = v[2]; raw[CH / 2 - 1] = v[3];
+        } else {
+            const u32x2 v = __builtin_nontemporal_load((const u32x2 *)(a.level + tuc * (N * N) + pos));
+            raw[0] = v[0]; raw[1] = v[1];
+        }
+        u32 outd[CH / 2];
+        if (fl & TU_BYPASS) {
 #pragma unroll
-        for (int i = 0; i < W; i++) { d[2 * i] = (int)(short)(rowp[i] & 0xffffu); d[2 * i + 1] = (int)rowp[i] >> 16; }
-    } else {
-        const int ls = qP % 6 == 0 ? 40 : (qP % 6 == 1 ? 45 : (qP % 6 == 2 ? 51 : (qP % 6 == 3 ? 57 : (qP % 6 == 4 ? 64 : 72))));
-        const int sh = qP / 6;
-        const int bd_shift = a.bitdepth + LOG2N + 10 - range;
-        const u32 rnd = 1u << (bd_shift - 1);
-        const bool flat = a.scaling == nullptr || ((flags & TU_TSKIP) && N > 4);
+            for (int i = 0; i < CH / 2; i++) outd[i] = raw[i];
+        } else {
+            const int ls = qP % 6 == 0 ? 40 : (qP % 6 == 1 ? 45 : (qP % 6 == 2 ? 51 : (qP % 6 == 3 ? 57 : (qP % 6 == 4 ? 64 : 72))));
+            const int sh = qP / 6;
+            const int bd_shift = a.bitdepth + LOG2N + 10 - range;
+            const u32 rnd = 1u << (bd_shift - 1);
+            const bool flat = a.scaling == nullptr || ((fl & TU_TSKIP) && N > 4);
+            u32 mraw[CH / 4] = {};
+            if (!flat) {
 #pragma unroll
-        for (int i = 0; i < N; i++) {
-            const int lv = (i & 1) ? (int)rowp[i >> 1] >> 16 : (int)(short)(rowp[i >> 1] & 0xffffu);
-            const u32 m = flat ? 16u : (u32)a.scaling[mid * (N * N) + idx * N + i];
-            u32 v = (u32)lv * m * (u32)ls;
-            v <<= sh;
-            v += rnd;
-            d[i] = (int)(short)clip3i(cmin, cmax, (int)v >> bd_shift);
+                for (int i = 0; i < CH / 4; i++) mraw[i] = *(const u32 *)(a.scaling + mid * (N * N) + pos + 4 * i);
+            }
+            int dv[CH];
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                const int lv = (i & 1) ? (int)raw[i >> 1] >> 16 : (int)(short)(raw[i >> 1] & 0xffffu);
+                const u32 m = flat ? 16u : (mraw[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                u32 v = (u32)lv * m * (u32)ls;
+                v <<= sh;
+                v += rnd;
+                dv[i] = (int)(short)clip3i(cmin, cmax, (int)v >> bd_shift);
+            }
+#pragma unroll
+            for (int i = 0; i < CH / 2; i++) outd[i] = ((u32)dv[2 * i] & 0xffffu) | ((u32)dv[2 * i + 1] << 16);
+        }
+        if (CH == 8) {
+            u32x4 w;
+            w[0] = outd[0]; w[1] = outd[1]; w[2] = outd[CH / 2 - 2]; w[3] = outd[CH / 2 - 1];
+            *(u32x4 *)(tile + s0 * 2) = w;
+        } else {
+            u32x2 w;
+            w[0] = outd[0]; w[1] = outd[1];
+            *(u32x2 *)(tile + s0 * 2) = w;
         }
     }
-    if (flags & (TU_BYPASS | TU_TSKIP)) {
-        /* no transform: r = level, or d << tsShift; optional 180-degree rotation (hevc.c:4209-4236) */
-        const int ts = (flags & TU_TSKIP) ? 5 + LOG2N : 0;
-        u32 outp[W];
+    u32 *trow = (u32 *)(tile + (tu_l * N + idx) * (N * 2)); /* this lane's row of its TU */
+    if (__builtin_amdgcn_ballot_w64((flags & (TU_BYPASS | TU_TSKIP)) != 0)) {
+        /* no transform for some TU of this wave: r = level, or d << tsShift; optional 180-degree rotation
+         * (hevc.c:4209-4236).  Row-per-lane, rare: the row comes back from LDS */
+        if (flags & (TU_BYPASS | TU_TSKIP)) {
+            const int ts = (flags & TU_TSKIP) ? 5 + LOG2N : 0;
+            int d[N];
 #pragma unroll
-        for (int i = 0; i < W; i++) {
-            const int lo = (flags & TU_ROTATE) ? d[N - 1 - 2 * i] : d[2 * i];
-            const int hi = (flags & TU_ROTATE) ? d[N - 2 - 2 * i] : d[2 * i + 1];
-            outp[i] = ((u32)(lo << ts) & 0xffffu) | ((u32)(hi << ts) << 16);
-        }
-        if (live) {
-            const int orow = (flags & TU_ROTATE) ? N - 1 - (int)idx : (int)idx;
-            u32 *dst = (u32 *)(a.res + tu * (N * N) + orow * N);
+            for (int i = 0; i < W; i++) { const u32 v = trow[i]; d[2 * i] = (int)(short)(v & 0xffffu); d[2 * i + 1] = (int)v >> 16; }
+            u32 outp[W];
 #pragma unroll
-            for (int i = 0; i < W; i++) __builtin_nontemporal_store(outp[i], dst + i);
+            for (int i = 0; i < W; i++) {
+                const int lo = (flags & TU_ROTATE) ? d[N - 1 - 2 * i] : d[2 * i];
+                const int hi = (flags & TU_ROTATE) ? d[N - 2 - 2 * i] : d[2 * i + 1];
+                outp[i] = ((u32)(lo << ts) & 0xffffu) | ((u32)(hi << ts) << 16);
+            }
+            if (live) {
+                const int orow = (flags & TU_ROTATE) ? N - 1 - (int)idx : (int)idx;
+                u32 *dst = (u32 *)(a.res + tu * (N * N) + orow * N);
+#pragma unroll
+                for (int i = 0; i < W; i++) __builtin_nontemporal_store(outp[i], dst + i);
+            }
         }
     }
-    /* every lane takes part in the LDS transposes (EXEC must be full); TUs that skipped the
-     * transform simply discard the result */
-    u32 *trow = (u32 *)(tile + (tu_l * N + idx) * (N * 2));
-#pragma unroll
-    for (int i = 0; i < W; i++) trow[i] = ((u32)d[2 * i] & 0xffffu) | ((u32)d[2 * i + 1] << 16);
 
     /* transposing reads: 16-lane group gq, lane 4q+p supplies row order[4k+q], 4 columns */
     const u32 t16 = lane & 15, q = t16 >> 2, p = t16 & 3, g16 = lane >> 4;
@@ -240,11 +278,17 @@ __global__ __launch_bounds__(256) void k_hevc_residual(HevcResArgs a)
 #pragma unroll
         for (int i = 0; i < N; i++) r[i] >>= sh2;
     }
-    if (live && !(flags & (TU_BYPASS | TU_TSKIP))) {
-        u32 *dstp = (u32 *)(a.res + tu * (N * N) + idx * N);
+    /* ---- rows of r -> LDS -> global as the same linear copy (the stage-2 reads were issued before these writes) ---- */
 #pragma unroll
-        for (int i = 0; i < W; i++)
-            __builtin_nontemporal_store(((u32)r[2 * i] & 0xffffu) | ((u32)r[2 * i + 1] << 16), dstp + i);
+    for (int i = 0; i < W; i++) trow[i] = ((u32)r[2 * i] & 0xffffu) | ((u32)r[2 * i + 1] << 16);
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const u32 s0 = (64u * c + lane) * CH;
+        if (chunk_store[c]) {
+            int16_t *dstp = a.res + tu0 * (N * N) + s0;
+            if (CH == 8) __builtin_nontemporal_store(*(const u32x4 *)(tile + s0 * 2), (u32x4 *)dstp);
+            else __builtin_nontemporal_store(*(const u32x2 *)(tile + s0 * 2), (u32x2 *)dstp);
+        }
     }
 }
 
@@ -255,8 +299,8 @@ extern "C" int ffhip_hevc_residual_batch(int nTbS, long long n_tu, const int16_t
     if (nTbS != 4 && nTbS != 8 && nTbS != 16 && nTbS != 32) return FFHIP_EINVAL;
     if (n_tu < 0 || bitdepth < 8 || bitdepth > 16) return FFHIP_EINVAL;
     if (n_tu == 0) return FFHIP_OK;
-    if (!d_level || !d_tuinfo || !d_residual || ((uintptr_t)d_level & 3) || ((uintptr_t)d_residual & 3) ||
-        ((uintptr_t)d_tuinfo & 3))
+    if (!d_level || !d_tuinfo || !d_residual || ((uintptr_t)d_level & 15) || ((uintptr_t)d_residual & 15) ||
+        ((uintptr_t)d_tuinfo & 3) || ((uintptr_t)d_scaling & 3))
         return FFHIP_EINVAL;
     if (!ffhip_have_device()) return FFHIP_ENODEV;
     HevcResArgs a = {d_level, d_tuinfo, d_scaling, d_residual, n_tu, bitdepth, epp ? 1 : 0};

@@ -20,7 +20,7 @@ EXPORTS = [
     "ffhip_jpeg_kernel_name", "ffhip_copy_calibrate",
     "ffhip_yuv420_to_bgra", "ffhip_yuv420_to_bgra_16", "ffhip_yuv400_to_bgra_16",
     "ffhip_vp8_residual_batch", "ffhip_hevc_residual_batch", "ffhip_vp8_predict_recon",
-    "ffhip_hevc_intra_recon", "ffhip_vp8_loopfilter",
+    "ffhip_hevc_intra_recon", "ffhip_hevc_intra_plan", "ffhip_vp8_loopfilter",
     "ffhip_jpeg_probe", "ffhip_jpeg_entropy_decode", "ffhip_jpeg_entropy_batch", "ffhip_bmp_write",
     "ffhip_heif_grid_parse", "ffhip_heif_grid_compose",
 ]
@@ -156,6 +156,7 @@ def lib():
     L.ffhip_bmp_write.argtypes = [C.c_char_p, vp, ci, ci, i64]
     L.ffhip_heif_grid_parse.argtypes = [vp, sz, C.POINTER(HeifGrid)]
     L.ffhip_heif_grid_compose.argtypes = [vp, i64, ci, ci, vp, i64, i64, ci, ci, ci, ci, vp]
+    L.ffhip_hevc_intra_plan.argtypes = [vp, C.c_longlong, ci, ci, ci, ci, ci, vp, vp, vp]
     L.ffhip_hevc_intra_recon.argtypes = [vp, vp, C.c_longlong, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.ffhip_vp8_loopfilter.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, i64, i64, vp]
     L.ffhip_vp8_predict_recon.argtypes = [ci, ci, ci, vp, vp, vp, i64, vp, vp, vp, vp, i64, i64, vp]

@@ -451,7 +451,11 @@ struct GroupPlan {
 static bool plan_groups(const ffhip_hevc_tu *tus, long long n_tus, const int pw[3], const int ph[3], const int win_log2[3],
                         GroupPlan &out)
 {
-    std::vector<int32_t> owner[3], gid_of[3];
+    /* scratch kept between calls: a picture's worth of maps is reallocated and refilled otherwise */
+    static thread_local std::vector<int32_t> owner[3], gid_of[3];
+    struct Meta { uint32_t group, wait_begin, slot; uint8_t wait_count, signal, tile_ok; };
+    static thread_local std::vector<Meta> meta;
+    static thread_local std::vector<uint32_t> gcount, gdepth, gfirst, order, gbase;
     int bw[3], gw[3];
     for (int c = 0; c < 3; c++) {
         bw[c] = (pw[c] + 3) / 4;
@@ -459,27 +463,44 @@ static bool plan_groups(const ffhip_hevc_tu *tus, long long n_tus, const int pw[
         owner[c].assign((size_t)bw[c] * (size_t)((ph[c] + 3) / 4), -1);
         gid_of[c].assign((size_t)gw[c] * (size_t)(ph[c] > 0 ? ((ph[c] - 1) >> win_log2[c]) + 1 : 0), -1);
     }
-    struct Meta { uint32_t group, wait_begin; uint8_t wait_count, signal, tile_ok; };
-    std::vector<Meta> meta((size_t)n_tus);
-    std::vector<std::vector<uint32_t>> members;
-    std::vector<std::vector<uint32_t>> gdeps; /* per group: the groups it waits for (with repeats) */
+    meta.resize((size_t)n_tus);
+    gcount.clear();
+    gdepth.clear();
+    gfirst.clear();
     out.wait.clear();
-    std::vector<int32_t> deps;
+    out.wait.reserve((size_t)n_tus * 2);
+    bool contiguous = true; /* every group one run of the list: then a group is complete before a later one starts,
+                               and its dependency depth is final when that one looks at it */
+    uint32_t cur_group = ~0u;
     for (long long i = 0; i < n_tus; i++) {
         const ffhip_hevc_tu &t = tus[i];
         const int c = t.cidx, n = 1 << t.log2_size, wl = win_log2[c];
         int32_t &gslot = gid_of[c][(size_t)(t.y >> wl) * gw[c] + (t.x >> wl)];
-        if (gslot < 0) { gslot = (int32_t)members.size(); members.emplace_back(); gdeps.emplace_back(); }
+        if (gslot < 0) {
+            gslot = (int32_t)gcount.size();
+            gcount.push_back(0);
+            gdepth.push_back(0);
+            gfirst.push_back((uint32_t)i);
+        } else if ((uint32_t)gslot != cur_group) {
+            contiguous = false;
+        }
         const uint32_t g = (uint32_t)gslot;
+        cur_group = g;
         Meta &m = meta[(size_t)i];
         m.group = g; m.signal = 0; m.tile_ok = 1;
-        members[g].push_back((uint32_t)i);
-        deps.clear();
+        m.slot = gcount[g]++;
+        int32_t deps[72];
+        int nd = 0;
         const int wx0 = (t.x >> wl) << wl, wy0 = (t.y >> wl) << wl, wsz = 1 << wl;
+        const int32_t *own = owner[c].data();
         auto dep = [&](int px, int py) {
-            const int32_t j = owner[c][(size_t)(py / 4) * bw[c] + px / 4];
+            const int32_t j = own[(size_t)(py >> 2) * bw[c] + (px >> 2)];
             const bool mine = j >= 0 && meta[(size_t)j].group == g;
-            if (j >= 0 && !mine) deps.push_back(j);
+            if (j >= 0 && !mine) {
+                bool dup = false;
+                for (int q = nd - 1; q >= 0 && !dup; q--) dup = deps[q] == j; /* neighbours repeat back to back */
+                if (!dup && nd < 72) deps[nd++] = j;
+            }
             if (!mine && px >= wx0 && px < wx0 + wsz && py >= wy0 && py < wy0 + wsz) m.tile_ok = 0; /* not in my LDS copy */
         };
         if (t.flags & 1) dep(t.x - 1, t.y - 1);
@@ -487,55 +508,99 @@ static bool plan_groups(const ffhip_hevc_tu *tus, long long n_tus, const int pw[
             if ((t.avail_top >> k) & 0xf) dep(t.x + k, t.y - 1);
             if ((t.avail_left >> k) & 0xf) dep(t.x - 1, t.y + k);
         }
-        std::sort(deps.begin(), deps.end());
-        deps.erase(std::unique(deps.begin(), deps.end()), deps.end());
-        if (deps.size() > 64) return false;
+        if (nd > 64) return false;
         m.wait_begin = (uint32_t)out.wait.size();
-        m.wait_count = (uint8_t)deps.size();
-        for (int32_t j : deps) {
-            if (meta[(size_t)j].group > g) return false;
-            if (gdeps[g].empty() || gdeps[g].back() != meta[(size_t)j].group) gdeps[g].push_back(meta[(size_t)j].group);
-            meta[(size_t)j].signal = 1;
-            out.wait.push_back((uint32_t)j);
+        m.wait_count = (uint8_t)nd;
+        uint32_t depth = gdepth[g];
+        for (int q = 0; q < nd; q++) {
+            Meta &mj = meta[(size_t)deps[q]];
+            if (mj.group > g) return false;
+            depth = std::max(depth, gdepth[mj.group] + 1);
+            mj.signal = 1;
+            out.wait.push_back((uint32_t)deps[q]);
         }
-        for (int by = t.y / 4; by < (t.y + n) / 4; by++)
-            for (int bx = t.x / 4; bx < (t.x + n) / 4; bx++) owner[c][(size_t)by * bw[c] + bx] = (int32_t)i;
+        gdepth[g] = depth;
+        int32_t *orow = owner[c].data() + (size_t)(t.y >> 2) * bw[c] + (t.x >> 2);
+        for (int by = 0; by < n / 4; by++, orow += bw[c])
+            for (int bx = 0; bx < n / 4; bx++) orow[bx] = (int32_t)i;
     }
-    out.sched.clear();
-    out.groups.clear();
-    out.sched.reserve((size_t)n_tus * 3);
     /* Tickets go out in dependency-depth order (ties: decode order), so the waves that hold tickets
      * are the ones near the ready front rather than thousands of groups ahead of it, polling.
-     * Every group a group waits for has a smaller depth, hence a smaller ticket. */
-    std::vector<uint32_t> depth(members.size(), 0), order(members.size());
-    for (size_t g = 0; g < members.size(); g++) {
-        for (uint32_t d : gdeps[g]) depth[g] = std::max(depth[g], depth[d] + 1);
-        order[g] = (uint32_t)g;
+     * Every group a group waits for has a smaller depth, hence a smaller ticket.  (Depths are only
+     * trusted for contiguous groups; otherwise decode order, which the check above made valid.) */
+    const size_t ng = gcount.size();
+    order.resize(ng);
+    for (size_t g = 0; g < ng; g++) order[g] = (uint32_t)g;
+    if (contiguous && !getenv("FFHIP_HEVC_INTRA_DECODE_ORDER"))
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return gdepth[x] < gdepth[y]; });
+    gbase.resize(ng);
+    out.groups.resize(ng);
+    uint32_t run = 0;
+    for (size_t k = 0; k < ng; k++) {
+        const uint32_t g = order[k];
+        gbase[g] = run;
+        u32x4 rec;
+        rec.x = run;
+        rec.y = gcount[g];
+        rec.z = (uint32_t)win_log2[tus[gfirst[g]].cidx];
+        rec.w = 0;
+        out.groups[k] = rec;
+        run += gcount[g];
     }
-    if (!getenv("FFHIP_HEVC_INTRA_DECODE_ORDER"))
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return depth[x] < depth[y]; });
-    for (uint32_t gi : order) {
-        auto &mem = members[gi];
-        u32x4 g;
-        g.x = (uint32_t)(out.sched.size() / 3);
-        g.y = (uint32_t)mem.size();
-        g.z = (uint32_t)win_log2[tus[mem[0]].cidx];
-        g.w = 0;
-        out.groups.push_back(g);
-        for (uint32_t i : mem) {
-            u32x4 q[3];
-            static_assert(sizeof(ffhip_hevc_tu) == 32, "slot layout");
-            memcpy(q, &tus[i], 32);
-            const Meta &m = meta[i];
-            q[2].x = m.wait_begin;
-            q[2].y = (uint32_t)m.wait_count | ((uint32_t)m.signal << 8) | ((uint32_t)m.tile_ok << 9);
-            q[2].z = i;
-            q[2].w = 0;
-            out.sched.push_back(q[0]); out.sched.push_back(q[1]); out.sched.push_back(q[2]);
-        }
+    out.sched.resize((size_t)n_tus * 3);
+    static_assert(sizeof(ffhip_hevc_tu) == 32, "slot layout");
+    for (long long i = 0; i < n_tus; i++) {
+        const Meta &m = meta[(size_t)i];
+        u32x4 *q = &out.sched[(size_t)(gbase[m.group] + m.slot) * 3];
+        memcpy(q, &tus[i], 32);
+        q[2].x = m.wait_begin;
+        q[2].y = (uint32_t)m.wait_count | ((uint32_t)m.signal << 8) | ((uint32_t)m.tile_ok << 9);
+        q[2].z = (uint32_t)i;
+        q[2].w = 0;
     }
     if (out.wait.empty()) out.wait.push_back(0);
     return true;
+}
+
+/* the window search both entry points share: the requested (or default) luma window, halved until a
+ * plan exists; chroma windows cover the same picture area */
+static bool plan_with_window_search(const ffhip_hevc_tu *tus, long long n_tus, const int pw[3], const int ph[3], int wl,
+                                    GroupPlan &plan, int *used_wl)
+{
+    wl = wl < 3 ? 3 : (wl > 6 ? 6 : wl);
+    const int cs = (pw[1] > 0 && pw[1] * 2 <= pw[0] + 1) ? 1 : 0;
+    for (; wl >= 3; wl--) {
+        const int win[3] = {wl, wl - cs, wl - cs};
+        if (plan_groups(tus, n_tus, pw, ph, win, plan)) {
+            if (used_wl) *used_wl = wl;
+            return true;
+        }
+    }
+    return false;
+}
+
+/* Host only (no device needed): the schedule ffhip_hevc_intra_recon would build for a VALIDATED list.
+ * out_ticket[i] = ticket of TU i's group, out_wait[i] = number of TUs of other groups it waits for
+ * (either may be NULL); stats = {groups, luma window log2 used, wait entries, TUs that may use the LDS tile}.
+ * Returns FFHIP_EINVAL when no window gives a deadlock-free ticket order (the caller would use levels). */
+extern "C" int ffhip_hevc_intra_plan(const ffhip_hevc_tu *h_tus, long long n_tus, int width_y, int height_y, int width_c,
+                                     int height_c, int window_log2, uint32_t *out_ticket, uint32_t *out_wait, int32_t *stats)
+{
+    if (!h_tus || n_tus <= 0 || width_y <= 0 || height_y <= 0) return FFHIP_EINVAL;
+    const int pw[3] = {width_y, width_c, width_c}, ph[3] = {height_y, height_c, height_c};
+    GroupPlan plan;
+    int wl = 0;
+    if (!plan_with_window_search(h_tus, n_tus, pw, ph, window_log2 ? window_log2 : FFHIP_HEVC_INTRA_WINDOW_LOG2, plan, &wl)) return FFHIP_EINVAL;
+    int tile_ok = 0;
+    for (size_t g = 0; g < plan.groups.size(); g++)
+        for (uint32_t k = 0; k < plan.groups[g].y; k++) {
+            const u32x4 q = plan.sched[(size_t)(plan.groups[g].x + k) * 3 + 2];
+            if (out_ticket) out_ticket[q.z] = (uint32_t)g;
+            if (out_wait) out_wait[q.z] = q.y & 0xff;
+            tile_ok += (q.y >> 9) & 1;
+        }
+    if (stats) { stats[0] = (int32_t)plan.groups.size(); stats[1] = wl; stats[2] = (int32_t)plan.wait.size(); stats[3] = tile_ok; }
+    return FFHIP_OK;
 }
 
 extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu *d_tus, long long n_tus,
@@ -606,16 +671,8 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
     const bool offsets_fit = (long long)y_stride * height_y < (1LL << 30) && (long long)uv_stride * (height_c > 0 ? height_c : 1) < (1LL << 30);
     if (want_groups && async_err && offsets_fit /* 32-bit byte offsets into a plane */) {
         const char *we = getenv("FFHIP_HEVC_INTRA_WINDOW");
-        int wl = we ? atoi(we) : FFHIP_HEVC_INTRA_WINDOW_LOG2;
-        wl = wl < 3 ? 3 : (wl > 6 ? 6 : wl);
-        const int cs = (width_c > 0 && width_c * 2 <= width_y + 1) ? 1 : 0; /* chroma windows cover the same picture area */
         GroupPlan plan;
-        bool ok = false;
-        for (; wl >= 3 && !ok; wl--) {
-            const int win[3] = {wl, wl - cs, wl - cs};
-            ok = plan_groups(h_tus, n_tus, pw, ph, win, plan);
-        }
-        if (ok) {
+        if (plan_with_window_search(h_tus, n_tus, pw, ph, we ? atoi(we) : FFHIP_HEVC_INTRA_WINDOW_LOG2, plan, nullptr)) {
             /* device image: sched | groups | wait | ctrl[4] + one done flag per TU */
             const size_t w_sched = plan.sched.size() * 4, w_groups = plan.groups.size() * 4, w_wait = plan.wait.size();
             const size_t w_ctrl = 4 + (size_t)n_tus;

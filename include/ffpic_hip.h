@@ -313,6 +313,13 @@ typedef struct ffhip_hevc_tu {
  * window, a wave per group, done flags between groups; a bounded wait that ever
  * runs out surfaces as FFHIP_EIO from the next ffhip_stream_sync.  FFHIP_HEVC_INTRA_MODE=levels
  * selects the older one-launch-per-dependency-level form.  Not re-entrant. */
+/* Host only, no device needed: the group schedule ffhip_hevc_intra_recon builds for an already valid
+ * list -- out_ticket[i] = ticket of the group of TU i, out_wait[i] = TUs of other groups it waits for
+ * (either may be NULL), stats[4] = {groups, luma window log2 used, wait entries, TUs served from the
+ * LDS tile}; window_log2 0 = the default.  FFHIP_EINVAL when no window gives a deadlock-free order. */
+int ffhip_hevc_intra_plan(const ffhip_hevc_tu *h_tus, long long n_tus, int width_y, int height_y,
+                          int width_c, int height_c, int window_log2, uint32_t *out_ticket,
+                          uint32_t *out_wait, int32_t *stats);
 int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu *d_tus, long long n_tus,
                            const int16_t *d_residual, int16_t *d_y, int16_t *d_cb, int16_t *d_cr,
                            int width_y, int height_y, int y_stride, int width_c, int height_c,

@@ -396,8 +396,14 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                             }
                             return;
                         }
-                        if (spins < 16) __builtin_amdgcn_s_sleep(1);
-                        else __builtin_amdgcn_s_sleep(16); /* far from ready: poll about once per microsecond */
+#ifndef FFHIP_POLL_FAST
+#define FFHIP_POLL_FAST 16
+#endif
+#ifndef FFHIP_POLL_SLOW_SLEEP
+#define FFHIP_POLL_SLOW_SLEEP 16
+#endif
+                        if (spins < FFHIP_POLL_FAST) __builtin_amdgcn_s_sleep(1);
+                        else __builtin_amdgcn_s_sleep(FFHIP_POLL_SLOW_SLEEP); /* far from ready: poll about once per microsecond */
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* ordering only: no cache-wide invalidate */
                 }

@@ -20,8 +20,12 @@
 #include "ffhip_internal.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #ifndef FFHIP_HEVC_INTRA_WAVES
@@ -469,14 +473,14 @@ static bool plan_groups(const ffhip_hevc_tu *tus, long long n_tus, const int pw[
         owner[c].assign((size_t)bw[c] * (size_t)((ph[c] + 3) / 4), -1);
         gid_of[c].assign((size_t)gw[c] * (size_t)(ph[c] > 0 ? ((ph[c] - 1) >> win_log2[c]) + 1 : 0), -1);
     }
+    const auto T0 = std::chrono::steady_clock::now();
     meta.resize((size_t)n_tus);
     gcount.clear();
-    gdepth.clear();
     gfirst.clear();
-    out.wait.clear();
-    out.wait.reserve((size_t)n_tus * 2);
-    bool contiguous = true; /* every group one run of the list: then a group is complete before a later one starts,
-                               and its dependency depth is final when that one looks at it */
+    /* ---- pass 1 (sequential, light): groups in order of first appearance, slot inside the group, block owners ----
+     * contiguous: every group is one run of the list; then a group is complete before a later one starts,
+     * which is what makes the dependency depths of pass 3 final when they are read */
+    bool contiguous = true;
     uint32_t cur_group = ~0u;
     for (long long i = 0; i < n_tus; i++) {
         const ffhip_hevc_tu &t = tus[i];
@@ -485,55 +489,109 @@ static bool plan_groups(const ffhip_hevc_tu *tus, long long n_tus, const int pw[
         if (gslot < 0) {
             gslot = (int32_t)gcount.size();
             gcount.push_back(0);
-            gdepth.push_back(0);
             gfirst.push_back((uint32_t)i);
         } else if ((uint32_t)gslot != cur_group) {
             contiguous = false;
         }
-        const uint32_t g = (uint32_t)gslot;
-        cur_group = g;
+        cur_group = (uint32_t)gslot;
         Meta &m = meta[(size_t)i];
-        m.group = g; m.signal = 0; m.tile_ok = 1;
-        m.slot = gcount[g]++;
-        int32_t deps[72];
-        int nd = 0;
-        const int wx0 = (t.x >> wl) << wl, wy0 = (t.y >> wl) << wl, wsz = 1 << wl;
-        const int32_t *own = owner[c].data();
-        auto dep = [&](int px, int py) {
-            const int32_t j = own[(size_t)(py >> 2) * bw[c] + (px >> 2)];
-            const bool mine = j >= 0 && meta[(size_t)j].group == g;
-            if (j >= 0 && !mine) {
-                bool dup = false;
-                for (int q = nd - 1; q >= 0 && !dup; q--) dup = deps[q] == j; /* neighbours repeat back to back */
-                if (!dup && nd < 72) deps[nd++] = j;
-            }
-            if (!mine && px >= wx0 && px < wx0 + wsz && py >= wy0 && py < wy0 + wsz) m.tile_ok = 0; /* not in my LDS copy */
-        };
-        if (t.flags & 1) dep(t.x - 1, t.y - 1);
-        for (int k = 0; k < 2 * n; k += 4) {
-            if ((t.avail_top >> k) & 0xf) dep(t.x + k, t.y - 1);
-            if ((t.avail_left >> k) & 0xf) dep(t.x - 1, t.y + k);
-        }
-        if (nd > 64) return false;
-        m.wait_begin = (uint32_t)out.wait.size();
-        m.wait_count = (uint8_t)nd;
-        uint32_t depth = gdepth[g];
-        for (int q = 0; q < nd; q++) {
-            Meta &mj = meta[(size_t)deps[q]];
-            if (mj.group > g) return false;
-            depth = std::max(depth, gdepth[mj.group] + 1);
-            mj.signal = 1;
-            out.wait.push_back((uint32_t)deps[q]);
-        }
-        gdepth[g] = depth;
+        m.group = cur_group; m.signal = 0; m.tile_ok = 1;
+        m.slot = gcount[cur_group]++;
         int32_t *orow = owner[c].data() + (size_t)(t.y >> 2) * bw[c] + (t.x >> 2);
         for (int by = 0; by < n / 4; by++, orow += bw[c])
             for (int bx = 0; bx < n / 4; bx++) orow[bx] = (int32_t)i;
     }
+    const auto T1 = std::chrono::steady_clock::now();
+    /* ---- pass 2 (parallel over TU ranges): who reads whom.  The owner map is complete; a TU only
+     * depends on TUs before it in the list (a block whose owner comes later held older content when
+     * the sequential decoder looked at it) ---- */
+    /* the scratch vectors are thread_local: worker threads must go through pointers taken here */
+    Meta *const mp = meta.data();
+    const int32_t *const ownp[3] = {owner[0].data(), owner[1].data(), owner[2].data()};
+    const char *pt = getenv("FFHIP_PLAN_THREADS");
+    /* one thread unless asked: on the 16-core share of an MI355X box 2-8 threads were no faster
+     * (2.5-5.0 ms against 2.7 ms for this pass on 172k TUs: thread start-up and the shared maps eat the gain) */
+    const int n_threads = pt ? std::max(1, std::min(16, atoi(pt))) : 1;
+    std::vector<std::vector<uint32_t>> waits((size_t)n_threads);
+    std::atomic<bool> bad(false);
+    auto scan = [&](int th) {
+        const long long lo = n_tus * th / n_threads, hi = n_tus * (th + 1) / n_threads;
+        std::vector<uint32_t> &w = waits[(size_t)th];
+        w.reserve((size_t)(hi - lo) * 2);
+        for (long long i = lo; i < hi; i++) {
+            const ffhip_hevc_tu &t = tus[i];
+            const int c = t.cidx, n = 1 << t.log2_size, wl = win_log2[c];
+            Meta &m = mp[(size_t)i];
+            const uint32_t g = m.group;
+            int32_t deps[72];
+            int nd = 0;
+            bool tile_ok = true;
+            const int wx0 = (t.x >> wl) << wl, wy0 = (t.y >> wl) << wl, wsz = 1 << wl;
+            const int32_t *own = ownp[c];
+            auto dep = [&](int px, int py) {
+                int32_t j = own[(size_t)(py >> 2) * bw[c] + (px >> 2)];
+                if (j >= i) j = -1;
+                const bool mine = j >= 0 && mp[(size_t)j].group == g;
+                if (j >= 0 && !mine) {
+                    bool dup = false;
+                    for (int q = nd - 1; q >= 0 && !dup; q--) dup = deps[q] == j; /* neighbours repeat back to back */
+                    if (!dup && nd < 72) deps[nd++] = j;
+                }
+                if (!mine && px >= wx0 && px < wx0 + wsz && py >= wy0 && py < wy0 + wsz) tile_ok = false; /* not in my LDS copy */
+            };
+            if (t.flags & 1) dep(t.x - 1, t.y - 1);
+            for (int k = 0; k < 2 * n; k += 4) {
+                if ((t.avail_top >> k) & 0xf) dep(t.x + k, t.y - 1);
+                if ((t.avail_left >> k) & 0xf) dep(t.x - 1, t.y + k);
+            }
+            if (nd > 64) { bad = true; return; }
+            m.tile_ok = tile_ok;
+            m.wait_count = (uint8_t)nd;
+            m.wait_begin = (uint32_t)w.size(); /* relative to this thread's list until pass 3 */
+            for (int q = 0; q < nd; q++) {
+                Meta &mj = mp[(size_t)deps[q]];
+                if (mj.group > g) { bad = true; return; }
+                __atomic_store_n(&mj.signal, (uint8_t)1, __ATOMIC_RELAXED);
+                w.push_back((uint32_t)deps[q]);
+            }
+        }
+    };
+    if (n_threads == 1) scan(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int th = 1; th < n_threads; th++) pool.emplace_back(scan, th);
+        scan(0);
+        for (auto &th : pool) th.join();
+    }
+    if (bad) return false;
+    const auto T2 = std::chrono::steady_clock::now();
+    /* ---- pass 3 (sequential, light): one wait list, dependency depth per group ---- */
+    size_t total_wait = 0;
+    for (auto &w : waits) total_wait += w.size();
+    out.wait.resize(std::max<size_t>(total_wait, 1));
+    out.wait[0] = 0;
+    gdepth.assign(gcount.size(), 0);
+    {
+        size_t base = 0;
+        for (int th = 0; th < n_threads; th++) {
+            const long long lo = n_tus * th / n_threads, hi = n_tus * (th + 1) / n_threads;
+            const std::vector<uint32_t> &w = waits[(size_t)th];
+            if (!w.empty()) memcpy(out.wait.data() + base, w.data(), w.size() * sizeof(uint32_t));
+            for (long long i = lo; i < hi; i++) {
+                Meta &m = meta[(size_t)i];
+                uint32_t depth = gdepth[m.group];
+                for (unsigned q = 0; q < m.wait_count; q++) depth = std::max(depth, gdepth[meta[w[m.wait_begin + q]].group] + 1);
+                gdepth[m.group] = depth;
+                m.wait_begin += (uint32_t)base;
+            }
+            base += w.size();
+        }
+    }
+    const auto T3 = std::chrono::steady_clock::now();
     /* Tickets go out in dependency-depth order (ties: decode order), so the waves that hold tickets
      * are the ones near the ready front rather than thousands of groups ahead of it, polling.
      * Every group a group waits for has a smaller depth, hence a smaller ticket.  (Depths are only
-     * trusted for contiguous groups; otherwise decode order, which the check above made valid.) */
+     * trusted for contiguous groups; otherwise decode order, which pass 2 checked is valid.) */
     const size_t ng = gcount.size();
     order.resize(ng);
     for (size_t g = 0; g < ng; g++) order[g] = (uint32_t)g;
@@ -555,16 +613,31 @@ static bool plan_groups(const ffhip_hevc_tu *tus, long long n_tus, const int pw[
     }
     out.sched.resize((size_t)n_tus * 3);
     static_assert(sizeof(ffhip_hevc_tu) == 32, "slot layout");
-    for (long long i = 0; i < n_tus; i++) {
-        const Meta &m = meta[(size_t)i];
-        u32x4 *q = &out.sched[(size_t)(gbase[m.group] + m.slot) * 3];
-        memcpy(q, &tus[i], 32);
-        q[2].x = m.wait_begin;
-        q[2].y = (uint32_t)m.wait_count | ((uint32_t)m.signal << 8) | ((uint32_t)m.tile_ok << 9);
-        q[2].z = (uint32_t)i;
-        q[2].w = 0;
+    const uint32_t *const gbasep = gbase.data();
+    auto emit = [&](int th) {
+        const long long lo = n_tus * th / n_threads, hi = n_tus * (th + 1) / n_threads;
+        for (long long i = lo; i < hi; i++) {
+            const Meta &m = mp[(size_t)i];
+            u32x4 *q = &out.sched[(size_t)(gbasep[m.group] + m.slot) * 3];
+            memcpy(q, &tus[i], 32);
+            q[2].x = m.wait_begin;
+            q[2].y = (uint32_t)m.wait_count | ((uint32_t)m.signal << 8) | ((uint32_t)m.tile_ok << 9);
+            q[2].z = (uint32_t)i;
+            q[2].w = 0;
+        }
+    };
+    if (n_threads == 1) emit(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int th = 1; th < n_threads; th++) pool.emplace_back(emit, th);
+        emit(0);
+        for (auto &th : pool) th.join();
     }
-    if (out.wait.empty()) out.wait.push_back(0);
+    if (getenv("FFHIP_PLAN_TIMES")) {
+        const auto T4 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+        fprintf(stderr, "plan: setup+pass1 %ld us, pass2 %ld us, pass3 %ld us, order+emit %ld us (threads %d)\n", us(T0, T1), us(T1, T2), us(T2, T3), us(T3, T4), n_threads);
+    }
     return true;
 }
 

@@ -452,6 +452,166 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg420_fused(JpegBatch p)
 }
 
 /* ------------------------------------------------------------------------
+ * Fused kernel for the other baseline layouts: 4:4:4 (h = v = 1), 4:2:2 (h = 2), 4:4:0 (v = 2),
+ * grey.  One wave reconstructs a strip of 512 pixels -- 8 MCUs of 4:4:4 / grey (64x8), 4 MCUs of
+ * 4:2:2 (64x8) or 4:4:0 (32x16) -- in 1-3 IDCT rounds of 8 blocks, parks the samples as small
+ * int16 planes in LDS and converts 4 pixels per lane and pass with the same exact integer forms
+ * as the 4:2:0 kernel (fp64 only where the G sum is an exact multiple of 1000).  Same launch shape:
+ * short-lived waves, all loads up front, 16-byte non-temporal stores, XCD-contiguous workgroups.
+ * ---------------------------------------------------------------------- */
+#define SM_YP 1024
+#define SM_UP 2048
+#define SM_VP 3072
+#define SM_WAVE_BYTES 4096
+
+struct ChromaTerms {
+    int fr, fg, fb;
+    bool sens;
+};
+__device__ __forceinline__ ChromaTerms chroma_terms(int uu, int vv)
+{
+    ChromaTerms t;
+    t.fr = fdiv_f32(64 * vv + (2 * 25 * 164 + 1), 1.0f / 50.0f) - 164;   /* floor(32 vv / 25)   */
+    t.fb = fdiv_f32(532 * uu + (2 * 125 * 273 + 1), 1.0f / 250.0f) - 273; /* floor(266 uu / 125) */
+    const int sgm = 215 * uu + 381 * vv, tt = 4806000 - sgm;
+    const int tq = fdiv_f32(2 * tt + 1, 1.0f / 2000.0f);
+    t.fg = tq - 4806;                                                      /* floor(-sgm / 1000)  */
+    t.sens = tt - __mul24(tq, 1000) == 0 && sgm != 0;                      /* exact-integer G: fp64 decides */
+    return t;
+}
+__device__ __forceinline__ int clamp255i(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+__device__ __forceinline__ u32 bgra_px(int yy, const ChromaTerms &t, int uu, int vv)
+{
+    const u32 r = (u32)clamp255i(yy + t.fr), b = (u32)clamp255i(yy + t.fb);
+    const u32 g = t.sens ? green_fp64(yy, uu, vv) : (u32)clamp255i(yy + t.fg);
+    return b | (g << 8) | (r << 16) | 0xff000000u;
+}
+
+template <int H, int V, int NC, int NT>
+__global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
+{
+    constexpr int BPM = H * V;                            /* luma blocks per MCU          */
+    constexpr int MPS = (NC == 1 || BPM == 1) ? 8 : 4;   /* MCUs per strip               */
+    constexpr int SW = MPS * 8 * H, SH = 8 * V;          /* strip size in pixels (512)   */
+    constexpr int CW = MPS * 8;                          /* chroma samples per strip row */
+    constexpr int GPR = SW / 4;                          /* 4-pixel groups per pixel row */
+    static_assert(SW * SH == 512 && BPM <= 2, "strip geometry");
+    __shared__ __attribute__((aligned(16))) char lds_all[WAVES_PER_WG * SM_WAVE_BYTES];
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u32 wg;
+    {
+        const u32 nb = gridDim.x, b = blockIdx.x, base = nb >> 3, extra = nb & 7, xcd = b & 7;
+        wg = p.xcd_remap ? xcd * base + (xcd < extra ? xcd : extra) + (b >> 3) : b;
+    }
+    int img = (int)__umulhi(wg, p.wpi_magic), wgi = (int)wg - img * p.wgs_per_image; /* scalar */
+    if (wgi < 0) { img--; wgi += p.wgs_per_image; }
+    if (wgi >= p.wgs_per_image) { img++; wgi -= p.wgs_per_image; }
+    const int sidx = (int)((u32)wgi * WAVES_PER_WG + wave);
+    if (sidx >= p.quads_per_image) return; /* wave-uniform; no barriers in this kernel */
+    int mrow = (int)__umulhi((u32)sidx, p.qpr_magic), scol = sidx - mrow * p.quads_per_row;
+    if (scol < 0) { mrow--; scol += p.quads_per_row; }
+    if (scol >= p.quads_per_row) { mrow++; scol -= p.quads_per_row; }
+    const int mcu0 = scol * MPS, last = p.mcu_cols - 1;
+    const int rem = last - mcu0 < MPS - 1 ? last - mcu0 : MPS - 1; /* MCUs of this strip that exist, minus one */
+
+    WaveCtx c;
+    wave_ctx_init(c, lds_all + wave * SM_WAVE_BYTES, lane);
+    const u32 row = lane & 7, lblk = lane >> 3;
+    const long long mcu_base = ((long long)img * p.mcu_rows + mrow) * p.mcu_cols + mcu0; /* scalar */
+    const uint16_t *qt = p.quant + (long long)img * p.quant_stride;
+
+    /* ---- all loads up front: ragged strips re-read their last MCU, its pixels are never stored ---- */
+    u32x4 ly, lc0, lc1;
+    {
+        int m = (int)lblk / BPM;
+        m = m > rem ? rem : m;
+        ly = load16<NT & 1>((const char *)(p.coef_y + (mcu_base + m) * (64 * BPM) + ((int)lblk % BPM) * 64 + row * 8));
+    }
+    const u32x4 q_y = *(const u32x4 *)(qt + p.qt_y * 64 + row * 8);
+    u32x4 q_c0 = q_y, q_c1 = q_y;
+    if (NC == 3) {
+        if (BPM == 1) { /* two rounds of 8 blocks: U, then V */
+            const int m = (int)lblk > rem ? rem : (int)lblk;
+            lc0 = load16<NT & 1>((const char *)(p.coef_u + (mcu_base + m) * 64 + row * 8));
+            lc1 = load16<NT & 1>((const char *)(p.coef_v + (mcu_base + m) * 64 + row * 8));
+            q_c0 = *(const u32x4 *)(qt + p.qt_u * 64 + row * 8);
+            q_c1 = *(const u32x4 *)(qt + p.qt_v * 64 + row * 8);
+        } else {        /* one round: blocks 0-3 = U of MCU 0-3, blocks 4-7 = V */
+            int m = (int)(lblk & 3);
+            m = m > rem ? rem : m;
+            lc0 = load16<NT & 1>((const char *)((lane < 32 ? p.coef_u : p.coef_v) + (mcu_base + m) * 64 + row * 8));
+            q_c0 = *(const u32x4 *)(qt + (lane < 32 ? p.qt_u : p.qt_v) * 64 + row * 8);
+        }
+    }
+
+    /* ---- IDCT rounds -> sample planes in LDS: luma SH rows x SW, chroma 8 rows x CW (int16) ---- */
+    {
+        const u32x4 pk = idct8x8_round(c, ly, q_y);
+        const u32 m = c.blk / BPM, sub = c.blk % BPM;
+        const u32 pcol = (m * H + (H == 2 ? sub : 0)) * 8, prow = (V == 2 ? sub : 0) * 8 + c.idx;
+        *(u32x4 *)(c.lds + SM_YP + (prow * SW + pcol) * 2) = pk;
+    }
+    if (NC == 3) {
+        if (BPM == 1) {
+            const u32x4 pu = idct8x8_round(c, lc0, q_c0);
+            *(u32x4 *)(c.lds + SM_UP + (c.idx * CW + c.blk * 8) * 2) = pu;
+            const u32x4 pv = idct8x8_round(c, lc1, q_c1);
+            *(u32x4 *)(c.lds + SM_VP + (c.idx * CW + c.blk * 8) * 2) = pv;
+        } else {
+            const u32x4 pc = idct8x8_round(c, lc0, q_c0);
+            *(u32x4 *)(c.lds + (c.blk < 4 ? SM_UP : SM_VP) + (c.idx * CW + (c.blk & 3) * 8) * 2) = pc;
+        }
+    }
+
+    /* ---- colour: 2 passes x 4 pixels per lane; 4/H chroma samples serve them ---- */
+    uint8_t *const obase = p.bgra + (long long)img * p.image_stride + (long long)mrow * SH * p.pitch + (long long)mcu0 * (32 * H);
+    ChromaTerms grey_t = {};
+    if (NC == 1) grey_t = chroma_terms(-128, -128); /* U = V = 0 planes (jpg.c:501,552-554) */
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const u32 prow = it * (64 / GPR) + lane / GPR, pc0 = (lane % GPR) * 4;
+        const u32x2 yy = *(const u32x2 *)(c.lds + SM_YP + (prow * SW + pc0) * 2);
+        u32x4 px;
+        if (NC == 1) {
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const int y1 = (int)((d & 1) ? (yy[d >> 1] >> 16) : (yy[d >> 1] & 0xffffu));
+                px[d] = bgra_px(y1, grey_t, -128, -128);
+            }
+        } else {
+            const u32 crow = prow / V, cc0 = pc0 / H;
+            u32 us[2], vs[2];
+            if (H == 1) {
+                const u32x2 a = *(const u32x2 *)(c.lds + SM_UP + (crow * CW + cc0) * 2), b = *(const u32x2 *)(c.lds + SM_VP + (crow * CW + cc0) * 2);
+                us[0] = a[0]; us[1] = a[1]; vs[0] = b[0]; vs[1] = b[1];
+            } else {
+                us[0] = *(const u32 *)(c.lds + SM_UP + (crow * CW + cc0) * 2);
+                vs[0] = *(const u32 *)(c.lds + SM_VP + (crow * CW + cc0) * 2);
+                us[1] = vs[1] = 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4 / H; k++) {
+                const int uu = (int)((k & 1) ? (us[k >> 1] >> 16) : (us[k >> 1] & 0xffffu)) - 128; /* colorspace.c:149 */
+                const int vv = (int)((k & 1) ? (vs[k >> 1] >> 16) : (vs[k >> 1] & 0xffffu)) - 128;
+                const ChromaTerms t = chroma_terms(uu, vv);
+#pragma unroll
+                for (int e = 0; e < H; e++) {
+                    const int d = k * H + e;
+                    const int y1 = (int)((d & 1) ? (yy[d >> 1] >> 16) : (yy[d >> 1] & 0xffffu));
+                    px[d] = bgra_px(y1, t, uu, vv);
+                }
+            }
+        }
+        if (mcu0 + (int)(pc0 / (8 * H)) <= last) {
+            u32x4 *dst = (u32x4 *)(obase + (long long)prow * p.pitch + pc0 * 4);
+            if (NT & 2) __builtin_nontemporal_store(px, dst);
+            else *dst = px;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------
  * Generic path, kernel 1: dequant + IDCT of one component plane into int16
  * sample planes (same block-major layout as the input).
  * ---------------------------------------------------------------------- */
@@ -577,6 +737,26 @@ static void launch_fused(const JpegBatch &q_in, int n_images, hipStream_t st)
 }
 
 static int is_fused420(const ffhip_jpeg_geom *g) { return g->ncomp == 3 && g->h == 2 && g->v == 2; }
+/* 4:4:4, 4:2:2, 4:4:0, grey: k_jpeg_fused_strip */
+static int is_fused_strip(const ffhip_jpeg_geom *g)
+{
+    return (g->ncomp == 3 && g->h * g->v <= 2) || (g->ncomp == 1 && g->h == 1 && g->v == 1);
+}
+
+static void launch_strip(const ffhip_jpeg_geom *g, const JpegBatch &q_in, int n_images, hipStream_t st)
+{
+    JpegBatch q = q_in;
+    static int remap = -1;
+    if (remap < 0) remap = getenv("FFHIP_JPEG_NO_XCD_REMAP") ? 0 : 1;
+    q.xcd_remap = remap;
+    q.wgs_per_image = (q.quads_per_image + WAVES_PER_WG - 1) / WAVES_PER_WG;
+    q.wpi_magic = q.wgs_per_image == 1 ? 0xffffffffu : (u32)(0x100000000ULL / (unsigned)q.wgs_per_image) + 1u;
+    const dim3 grid((unsigned)((long long)q.wgs_per_image * n_images), 1, 1);
+    if (g->ncomp == 1) hipLaunchKernelGGL((k_jpeg_fused_strip<1, 1, 1, 3>), grid, dim3(WG_THREADS), 0, st, q);
+    else if (g->h == 1 && g->v == 1) hipLaunchKernelGGL((k_jpeg_fused_strip<1, 1, 3, 3>), grid, dim3(WG_THREADS), 0, st, q);
+    else if (g->h == 2) hipLaunchKernelGGL((k_jpeg_fused_strip<2, 1, 3, 3>), grid, dim3(WG_THREADS), 0, st, q);
+    else hipLaunchKernelGGL((k_jpeg_fused_strip<1, 2, 3, 3>), grid, dim3(WG_THREADS), 0, st, q);
+}
 
 static int grid_for(long long work_items_per_wg_unit)
 {
@@ -589,7 +769,7 @@ static int grid_for(long long work_items_per_wg_unit)
 
 extern "C" size_t ffhip_jpeg_workspace_bytes(const ffhip_jpeg_geom *g, int n_images)
 {
-    if (!geom_ok(g) || n_images <= 0 || is_fused420(g)) return 0;
+    if (!geom_ok(g) || n_images <= 0 || is_fused420(g) || is_fused_strip(g)) return 0;
     size_t mcus = (size_t)g->mcu_cols * g->mcu_rows * (size_t)n_images;
     size_t blocks = mcus * (size_t)(g->h * g->v) + (g->ncomp == 3 ? 2 * mcus : 0);
     return blocks * 64 * sizeof(int16_t);
@@ -598,7 +778,7 @@ extern "C" size_t ffhip_jpeg_workspace_bytes(const ffhip_jpeg_geom *g, int n_ima
 extern "C" const char *ffhip_jpeg_kernel_name(const ffhip_jpeg_geom *g)
 {
     if (!geom_ok(g)) return "";
-    return is_fused420(g) ? "k_jpeg420_fused" : "k_jpeg_idct_planes";
+    return is_fused420(g) ? "k_jpeg420_fused" : (is_fused_strip(g) ? "k_jpeg_fused_strip" : "k_jpeg_idct_planes");
 }
 
 extern "C" int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *g, int n_images, const int16_t *d_coef_y,
@@ -651,7 +831,37 @@ extern "C" int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *g, int n_images, co
         return FFHIP_OK;
     }
 
-    /* generic geometries: IDCT to sample planes, then colour */
+    if (is_fused_strip(g)) {
+        const int mps = (g->ncomp == 1 || g->h * g->v == 1) ? 8 : 4, bpm = g->ncomp == 1 ? 1 : g->h * g->v;
+        JpegBatch p = {};
+        p.coef_y = d_coef_y; p.coef_u = d_coef_u; p.coef_v = d_coef_v;
+        p.quant = d_quant; p.quant_stride = quant_stride;
+        p.bgra = d_bgra; p.pitch = pitch; p.image_stride = image_stride;
+        p.mcu_cols = g->mcu_cols; p.mcu_rows = g->mcu_rows;
+        p.quads_per_row = (g->mcu_cols + mps - 1) / mps; p.n_images = n_images;   /* "quad" = strip here */
+        p.quads_per_image = p.quads_per_row * g->mcu_rows;
+        p.qpr_magic = p.quads_per_row == 1 ? 0xffffffffu : (u32)(0x100000000ULL / (unsigned)p.quads_per_row) + 1u;
+        p.qt_y = g->qt_id[0]; p.qt_u = g->qt_id[1]; p.qt_v = g->qt_id[2];
+        const long long strips = (long long)p.quads_per_row * p.mcu_rows * n_images;
+        if (strips > 0x7fffffffLL || pitch * 16 > 0x7fffffffLL || p.quads_per_image > (1 << 20) || p.quads_per_row > 4096)
+            return FFHIP_EINVAL;
+        const int max_imgs = (int)(0x7fffffffLL / ((p.quads_per_image + WAVES_PER_WG - 1) / WAVES_PER_WG));
+        for (int first = 0; first < n_images; first += max_imgs) {
+            const int cnt = n_images - first < max_imgs ? n_images - first : max_imgs;
+            JpegBatch q = p;
+            const long long mcus = (long long)g->mcu_cols * g->mcu_rows;
+            q.coef_y += (long long)first * mcus * 64 * bpm;
+            if (g->ncomp == 3) { q.coef_u += (long long)first * mcus * 64; q.coef_v += (long long)first * mcus * 64; }
+            q.quant += (long long)first * quant_stride;
+            q.bgra += (long long)first * image_stride;
+            q.n_images = cnt;
+            launch_strip(g, q, cnt, st);
+            FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
+        }
+        return FFHIP_OK;
+    }
+
+    /* remaining geometries (grey with h*v > 1): IDCT to sample planes, then colour */
     const size_t need = ffhip_jpeg_workspace_bytes(g, n_images);
     if (!d_workspace || workspace_bytes < need || ((uintptr_t)d_workspace & 15)) return FFHIP_EINVAL;
     const long long mcus = (long long)g->mcu_cols * g->mcu_rows;

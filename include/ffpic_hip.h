@@ -142,8 +142,9 @@ typedef struct ffhip_jpeg_geom {
  *   d_bgra        B,G,R,0xFF bytes; pixel (x,y) of image i at
  *                 d_bgra + i*image_stride + y*pitch + 4*x ; coded size is
  *                 (8*h*mcu_cols) x (8*v*mcu_rows); pitch >= 4*width, multiple of 16
- *   d_workspace   scratch for the non-4:2:0 geometries (ffhip_jpeg_workspace_bytes);
- *                 may be NULL for ncomp=3,h=v=2 which runs fully fused
+ *   d_workspace   scratch of ffhip_jpeg_workspace_bytes(geom, n) bytes: 0 (pass NULL) for every
+ *                 layout an encoder writes -- 4:2:0, 4:4:4, 4:2:2, 4:4:0 and grey run fully
+ *                 fused -- and non-zero only for one component with h*v > 1 blocks per MCU
  *   stream        hipStream_t (NULL = default stream); the call only enqueues. */
 int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *geom, int n_images, const int16_t *d_coef_y,
                            const int16_t *d_coef_u, const int16_t *d_coef_v,

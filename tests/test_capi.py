@@ -69,7 +69,10 @@ def test_geometry_validation(L):
     assert L.ffhip_jpeg_recon_batch(C.byref(g), 0, None, None, None, None, 0, None, 0, 0, None, 0, None) == 0  # empty batch
     assert L.ffhip_jpeg_workspace_bytes(C.byref(g), 8) == 0          # fused path needs none
     g444 = capi.jpeg_geom(4, 2, h=1, v=1)
-    assert L.ffhip_jpeg_workspace_bytes(C.byref(g444), 2) == 2 * 8 * 3 * 128
+    assert L.ffhip_jpeg_workspace_bytes(C.byref(g444), 2) == 0       # 4:4:4 / 4:2:2 / 4:4:0 / grey: fused strip kernel
+    assert L.ffhip_jpeg_kernel_name(C.byref(g444)) == b"k_jpeg_fused_strip"
+    ggrey4 = capi.jpeg_geom(4, 2, ncomp=1, h=2, v=2)                  # the one layout left on the two-pass path
+    assert L.ffhip_jpeg_workspace_bytes(C.byref(ggrey4), 2) == 2 * 8 * 4 * 128
     assert L.ffhip_jpeg_kernel_name(C.byref(g)) == b"k_jpeg420_fused"
 
 

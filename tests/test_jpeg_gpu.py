@@ -252,3 +252,67 @@ def test_c_host_program_transbmp(golden, tmp_path):
     assert len(bmp) == 54 + 640 * 480 * 4
     g = golden("jpeg_files.npz")
     assert hashlib.sha256(bmp[54:]).digest() == g["q85_420_sha256"].tobytes()   # == the reference's decode of the file
+
+
+STRIP_LAYOUTS = [(3, 1, 1), (3, 2, 1), (3, 1, 2), (1, 1, 1)]
+
+
+@pytest.mark.parametrize("nc,h,v", STRIP_LAYOUTS + [(1, 2, 2)])
+@pytest.mark.parametrize("cols,rows,n", [(1, 1, 1), (7, 1, 2), (8, 2, 1), (9, 3, 2), (17, 2, 1), (33, 1, 3)])
+def test_strip_kernel_sizes(nc, h, v, cols, rows, n):
+    """k_jpeg_fused_strip (and, for grey with 2x2 blocks per MCU, the two-pass path): full and ragged strips"""
+    geom = O.make_geom(cols, rows, nc, h, v)
+    q = synth.quant_tables(60 + cols)
+    cy, cu, cv = synth.coef_batch(n, cols, rows, nc, h, v, quant=q, first=cols * 10 + rows)
+    exp = O.oracle_jpeg_recon(geom, cy, cu, cv, q, n_images=n)
+    assert np.array_equal(gpu_recon(geom, n, cy, cu, cv, q), exp)
+
+
+@pytest.mark.parametrize("nc,h,v", STRIP_LAYOUTS)
+def test_strip_kernel_adversarial(nc, h, v):
+    """int16-wrapping coefficients and arbitrary quant factors: samples anywhere in the IDCT's range"""
+    rng = np.random.default_rng(77 + h + 2 * v + nc)
+    cols, rows = 12, 5
+    geom = O.make_geom(cols, rows, nc, h, v)
+    nby = cols * rows * (h * v if nc == 3 else 1)
+    blocks = synth.adversarial_blocks(rng, nby + 2 * cols * rows)
+    rng.shuffle(blocks)
+    cy = np.ascontiguousarray(blocks[:nby].reshape(-1))
+    cu = np.ascontiguousarray(blocks[nby:nby + cols * rows].reshape(-1)) if nc == 3 else None
+    cv = np.ascontiguousarray(blocks[nby + cols * rows:].reshape(-1)) if nc == 3 else None
+    q = rng.integers(1, 65536, size=(4, 64)).astype(np.uint16)
+    exp = O.oracle_jpeg_recon(geom, cy, cu, cv, q)
+    assert np.array_equal(gpu_recon(geom, 1, cy, cu, cv, q), exp)
+
+
+@pytest.mark.parametrize("h,v", [(1, 1), (2, 1), (1, 2)])
+def test_strip_kernel_exact_integer_green(golden, h, v):
+    """flat blocks carrying chroma pairs with 215 uu + 381 vv == 0 (mod 1000): the fp64 branch of the strip kernel"""
+    tri = golden("color_triples.npz")["yuv"]
+    uu, vv = tri[:, 1].astype(np.int64) - 128, tri[:, 2].astype(np.int64) - 128
+    sel = ((215 * uu + 381 * vv) % 1000 == 0) & (tri[:, 1] >= 0) & (tri[:, 1] < 4000) & (tri[:, 2] >= 0) & \
+          (tri[:, 2] < 4000) & ((uu != 0) | (vv != 0))
+    pairs = np.unique(tri[sel][:, 1:3], axis=0)
+    cols, rows = 40, 30
+    pairs = pairs[: cols * rows]
+    n = len(pairs)
+    assert n == cols * rows
+    rng = np.random.default_rng(5)
+    geom = O.make_geom(cols, rows, 3, h, v)
+    bpm = h * v
+    cy = np.zeros((n * bpm, 64), np.int16)
+    cu = np.zeros((n, 64), np.int16)
+    cv = np.zeros((n, 64), np.int16)
+    cu[:, 0] = (pairs[:, 0].astype(np.int64) - 128) * 8
+    cv[:, 0] = (pairs[:, 1].astype(np.int64) - 128) * 8
+    base = (215 * (pairs[:, 0].astype(np.int64) - 128) + 381 * (pairs[:, 1].astype(np.int64) - 128)) // 1000
+    yy = np.clip(base[:, None] + rng.integers(-3, 259, size=(n, bpm)), 0, 4000)
+    cy[:, 0] = ((yy - 128) * 8).reshape(-1)
+    q = np.ones((4, 64), np.uint16)
+    args = (np.ascontiguousarray(cy.reshape(-1)), np.ascontiguousarray(cu.reshape(-1)), np.ascontiguousarray(cv.reshape(-1)), q)
+    exp = O.oracle_jpeg_recon(geom, *args)
+    got = gpu_recon(geom, 1, *args)
+    assert np.array_equal(got, exp)
+    # the branch really is exercised: the integer form alone would differ somewhere
+    g_int = np.clip(yy[:, 0] + (-(215 * (pairs[:, 0].astype(np.int64) - 128) + 381 * (pairs[:, 1].astype(np.int64) - 128))) // 1000, 0, 255)
+    assert (g_int != exp.reshape(rows, 8 * v, cols, 8 * h, 4)[:, 0, :, 0, 1].reshape(-1)).any()

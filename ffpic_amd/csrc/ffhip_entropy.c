@@ -39,6 +39,9 @@ struct huff {
     int32_t valptr[17], mincode[17];
     uint8_t vals[256];
     int present;
+    /* AC tables: when code and magnitude bits both fit into LOOK bits, the whole coefficient in one
+     * look-up: (value << 8) | (run << 4) | (code length + magnitude bits), 0 = take the slow path */
+    int16_t fast[1 << LOOK];
 };
 
 static int huff_build(struct huff *h, const uint8_t counts[16], const uint8_t *vals, int nvals)
@@ -61,6 +64,14 @@ static int huff_build(struct huff *h, const uint8_t counts[16], const uint8_t *v
     }
     h->maxcode[17] = 0x7fffffff;
     h->present = 1;
+    for (int i = 0; i < (1 << LOOK); i++) {
+        const unsigned e = h->look[i];
+        const int len = (int)(e >> 8), run = (int)((e >> 4) & 15), mag = (int)(e & 15);
+        if (!e || !mag || len + mag > LOOK) continue;
+        int k = ((i << len) & ((1 << LOOK) - 1)) >> (LOOK - mag);
+        if (k < (1 << (mag - 1))) k -= (1 << mag) - 1; /* EXTEND of T.81 F.2.2.1 */
+        if (k >= -128 && k <= 127) h->fast[i] = (int16_t)((k * 256) + (run * 16) + len + mag);
+    }
     return 0;
 }
 
@@ -73,6 +84,20 @@ struct bits {
 
 static inline void bits_fill(struct bits *b)
 {
+    if (!b->marker && b->end - b->p >= 8 && b->n <= 56) {
+        /* eight bytes at once when none of them is 0xFF (no stuffing, no marker): the common case */
+        uint64_t w;
+        memcpy(&w, b->p, 8);
+        w = __builtin_bswap64(w);
+        const uint64_t x = ~w; /* a 0xFF byte of w is a zero byte of x */
+        if (!((x - 0x0101010101010101ULL) & ~x & 0x8080808080808080ULL)) {
+            const int nb = (64 - b->n) >> 3;
+            b->acc = nb == 8 ? w : (b->acc << (8 * nb)) | (w >> (64 - 8 * nb));
+            b->p += nb;
+            b->n += 8 * nb;
+            return;
+        }
+    }
     while (b->n <= 56) {
         unsigned c = 0;
         if (!b->marker && b->p < b->end) {
@@ -261,6 +286,15 @@ int ffhip_jpeg_entropy_decode(const uint8_t *file, size_t len, const ffhip_jpeg_
                 pred[c] += extend(bits_get(&b, t), t);
                 blk[0] = (int16_t)pred[c];
                 for (int i = 1; i < 64;) {
+                    if (b.n < 16) bits_fill(&b);
+                    const int f = ha->fast[(b.acc >> (b.n - LOOK)) & ((1u << LOOK) - 1)];
+                    if (f) { /* run, value and all their bits from one look-up */
+                        i += (f >> 4) & 15;
+                        if (i > 63) { rc = FFHIP_EINVAL; break; }
+                        b.n -= f & 15;
+                        blk[k_zigzag[i++]] = (int16_t)(f >> 8);
+                        continue;
+                    }
                     const int rs = huff_decode(&b, ha);
                     if (rs < 0) { rc = FFHIP_EINVAL; break; }
                     const int r = rs >> 4, s = rs & 15;

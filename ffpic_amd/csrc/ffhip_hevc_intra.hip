@@ -431,20 +431,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
 
 /* ------------------------------------------------------------------------ host */
 
-static uint32_t *g_work = nullptr; /* words */
-static size_t g_work_cap = 0;
-
-static int reserve_work(size_t words)
-{
-    if (words > g_work_cap) {
-        if (g_work) (void)hipFree(g_work);
-        g_work = nullptr;
-        g_work_cap = 0;
-        FFHIP_CHECK(hipMalloc((void **)&g_work, words * sizeof(uint32_t)), FFHIP_ENOMEM);
-        g_work_cap = words;
-    }
-    return FFHIP_OK;
-}
+#define SCRATCH_HEVC_INTRA 3
 
 struct GroupPlan {
     std::vector<u32x4> sched;  /* 3 per slot */
@@ -757,8 +744,8 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             const size_t w_ctrl = 4 + (size_t)n_tus;
             const size_t o_groups = w_sched, o_wait = o_groups + w_groups, o_ctrl = (o_wait + w_wait + 3) & ~(size_t)3;
             FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO); /* the work buffer may still be in use by an earlier call */
-            int rc = reserve_work(o_ctrl + w_ctrl);
-            if (rc) return rc;
+            uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, o_ctrl + w_ctrl);
+            if (!g_work) return FFHIP_ENOMEM;
             FFHIP_CHECK(hipMemcpy(g_work, plan.sched.data(), w_sched * 4, hipMemcpyHostToDevice), FFHIP_EIO);
             FFHIP_CHECK(hipMemcpy(g_work + o_groups, plan.groups.data(), w_groups * 4, hipMemcpyHostToDevice), FFHIP_EIO);
             FFHIP_CHECK(hipMemcpy(g_work + o_wait, plan.wait.data(), w_wait * 4, hipMemcpyHostToDevice), FFHIP_EIO);
@@ -783,10 +770,8 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
     flat.reserve((size_t)n_tus);
     for (auto &l : lists) flat.insert(flat.end(), l.begin(), l.end());
     FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO);
-    {
-        int rc = reserve_work((size_t)n_tus);
-        if (rc) return rc;
-    }
+    uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, (size_t)n_tus);
+    if (!g_work) return FFHIP_ENOMEM;
     FFHIP_CHECK(hipMemcpy(g_work, flat.data(), flat.size() * sizeof(uint32_t), hipMemcpyHostToDevice), FFHIP_EIO);
     size_t off = 0;
     for (auto &l : lists) {

@@ -68,6 +68,35 @@ extern "C" int *ffhip_async_err_word(void)
 
 extern "C" const char *ffhip_arch_name(void) { return g_arch; }
 
+/* Device scratch owned by (kind, stream), grown on demand and kept: the dependency-scheduled stages
+ * put their schedules / counters there.  Everything a call enqueues is ordered on its stream, so
+ * the same stream may reuse its buffer call after call without waiting, and calls on different
+ * streams (or threads) never share one.  Growing waits for the stream first: the old buffer may
+ * still be read by what that stream has queued. */
+#include <map>
+#include <mutex>
+#include <utility>
+struct ScratchEntry { uint32_t *dev; size_t words; };
+static std::map<std::pair<int, void *>, ScratchEntry> g_scratch;
+static std::mutex g_scratch_mu;
+extern "C" uint32_t *ffhip_scratch(int kind, void *stream, size_t words)
+{
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    ScratchEntry &e = g_scratch[std::make_pair(kind, stream)];
+    if (words > e.words) {
+        if (e.dev) {
+            if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return nullptr;
+            (void)hipFree(e.dev);
+        }
+        e.dev = nullptr;
+        e.words = 0;
+        const size_t want = words + words / 4 + 1024; /* some headroom: lists of nearly equal size do not reallocate */
+        if (hipMalloc((void **)&e.dev, want * sizeof(uint32_t)) != hipSuccess) { e.dev = nullptr; return nullptr; }
+        e.words = want;
+    }
+    return e.dev;
+}
+
 extern "C" const char *ffhip_strerror(int code)
 {
     switch (code) {

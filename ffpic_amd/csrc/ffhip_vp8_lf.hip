@@ -383,8 +383,7 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
     }
 }
 
-static uint32_t *g_work = nullptr;
-static size_t g_work_cap = 0;
+#define SCRATCH_VP8_LF 2
 
 extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int filter_type, const uint8_t *d_modes,
                                     const uint8_t *d_filters, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
@@ -403,14 +402,8 @@ extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int fi
     if (async_err && !((uintptr_t)d_modes & 3) && !(((uintptr_t)d_y | (uintptr_t)d_u | (uintptr_t)d_v | (uintptr_t)plane_stride_y | (uintptr_t)plane_stride_uv) & 3) &&
         n_mb < (1LL << 23)) {
         const size_t words = 4 + (size_t)n_images * (size_t)mbrows;
-        if (words > g_work_cap) {
-            FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO);
-            if (g_work) (void)hipFree(g_work);
-            g_work = nullptr;
-            g_work_cap = 0;
-            FFHIP_CHECK(hipMalloc((void **)&g_work, words * sizeof(uint32_t)), FFHIP_ENOMEM);
-            g_work_cap = words;
-        }
+        uint32_t *g_work = ffhip_scratch(SCRATCH_VP8_LF, stream, words);
+        if (!g_work) return FFHIP_ENOMEM;
         FFHIP_CHECK(hipMemsetAsync(g_work, 0, words * sizeof(uint32_t), st), FFHIP_EIO);
         Vp8LfArgs a = {};
         a.modes = d_modes; a.filters = d_filters; a.y = d_y; a.u = d_u; a.v = d_v;
@@ -434,13 +427,8 @@ extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int fi
                 lists[(size_t)(x + 2 * y)].push_back((uint32_t)(y * mbcols + x));
             }
     const size_t total = (size_t)(2 * n_mb * n_images);
-    if (total > g_work_cap) {
-        if (g_work) (void)hipFree(g_work);
-        g_work = nullptr;
-        g_work_cap = 0;
-        FFHIP_CHECK(hipMalloc((void **)&g_work, total * sizeof(uint32_t)), FFHIP_ENOMEM);
-        g_work_cap = total;
-    }
+    uint32_t *g_work = ffhip_scratch(SCRATCH_VP8_LF, stream, total);
+    if (!g_work) return FFHIP_ENOMEM;
     std::vector<uint32_t> flat;
     flat.reserve(total);
     for (auto &l : lists) flat.insert(flat.end(), l.begin(), l.end());

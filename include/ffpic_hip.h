@@ -270,7 +270,8 @@ int ffhip_hevc_residual_batch(int nTbS, long long n_tu, const int16_t *d_level, 
  * Enqueues ONE launch on `stream`: a wave per macroblock row, rows chained through progress
  * counters inside the launch; should a wave's bounded wait ever run out, the next
  * ffhip_stream_sync on any stream returns FFHIP_EIO.  FFHIP_VP8_PRED_MODE=levels selects the older
- * one-launch-per-wavefront-level form.  Not re-entrant: one call at a time per process. */
+ * one-launch-per-wavefront-level form.  Scratch is kept per stream: calls on different streams (or
+ * host threads with their own streams) may be in flight together; calls on one stream are ordered. */
 int ffhip_vp8_predict_recon(int mbcols, int mbrows, int n_images, const uint8_t *h_modes,
                             const uint8_t *d_modes, const int16_t *d_residual, int64_t residual_stride,
                             const int32_t *d_resmap, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
@@ -313,7 +314,7 @@ typedef struct ffhip_hevc_tu {
  * `stream` once (its schedule buffer may be in use), then enqueues ONE launch: TUs grouped by 32x32
  * window, a wave per group, done flags between groups; a bounded wait that ever
  * runs out surfaces as FFHIP_EIO from the next ffhip_stream_sync.  FFHIP_HEVC_INTRA_MODE=levels
- * selects the older one-launch-per-dependency-level form.  Not re-entrant. */
+ * selects the older one-launch-per-dependency-level form.  Scratch is kept per stream, as for VP8. */
 /* Host only, no device needed: the group schedule ffhip_hevc_intra_recon builds for an already valid
  * list -- out_ticket[i] = ticket of the group of TU i, out_wait[i] = TUs of other groups it waits for
  * (either may be NULL), stats[4] = {groups, luma window log2 used, wait entries, TUs served from the

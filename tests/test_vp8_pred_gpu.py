@@ -85,3 +85,37 @@ def test_row_handoff_stress():
         for i in range(n):
             for gp, e, name in zip(got, exp[i], "YUV"):
                 assert np.array_equal(gp[i], e), (i, name)
+
+
+def test_two_streams_in_flight():
+    """two batches of different geometry enqueued on two streams before either is waited for: each stream
+    has its own schedule scratch, so neither call disturbs the other's counters"""
+    from ffpic_amd import capi
+    L = capi.require_device()
+    jobs = []
+    for k, (c, r, n) in enumerate(((37, 19, 3), (120, 68, 2))):
+        st = L.ffhip_stream_create()
+        assert st
+        modes = np.stack([synth.vp8_modes(c, r, seed=800 + 10 * k + i) for i in range(n)])
+        resid = np.stack([synth.vp8_residual(c * r, seed=800 + 10 * k + i) for i in range(n)])
+        dm, dr = ops.DeviceBuffer(np.ascontiguousarray(modes)), ops.DeviceBuffer(np.ascontiguousarray(resid))
+        ysz, csz = 256 * c * r, 64 * c * r
+        planes = [ops.DeviceBuffer(nbytes=n * ysz), ops.DeviceBuffer(nbytes=n * csz), ops.DeviceBuffer(nbytes=n * csz)]
+        for d in planes:
+            capi.check(L.ffhip_memset(d.ptr, 0, d.nbytes, st))
+        jobs.append((st, c, r, n, modes, resid, dm, dr, planes))
+    for _ in range(2):      # twice each, interleaved, nothing waited for in between
+        for (st, c, r, n, modes, resid, dm, dr, planes) in jobs:
+            for d in planes:
+                capi.check(L.ffhip_memset(d.ptr, 0, d.nbytes, st))
+            capi.check(L.ffhip_vp8_predict_recon(c, r, n, modes.ctypes.data, dm.ptr, dr.ptr, c * r * 384, None,
+                                                 planes[0].ptr, planes[1].ptr, planes[2].ptr, 256 * c * r, 64 * c * r, st))
+    for (st, c, r, n, modes, resid, dm, dr, planes) in jobs:
+        capi.check(L.ffhip_stream_sync(st))
+        got = (planes[0].to_host((n, 16 * r, 16 * c), np.uint8), planes[1].to_host((n, 8 * r, 8 * c), np.uint8),
+               planes[2].to_host((n, 8 * r, 8 * c), np.uint8))
+        for i in range(n):
+            exp = O.oracle_vp8_frame(c, r, modes[i], resid[i])
+            for gp, e, name in zip(got, exp, "YUV"):
+                assert np.array_equal(gp[i], e), (c, r, i, name)
+        L.ffhip_stream_destroy(st)

@@ -333,8 +333,8 @@ __global__ __launch_bounds__(256) void k_hevc_intra(HevcIntraArgs a)
  * Hops between groups go through one done flag per TU.  Picture samples are stored, and
  * neighbours outside the window gathered, with agent-scope accesses (sc1: served by the
  * device-coherent level, never by a possibly stale per-XCD L2 line), so publishing a TU needs
- * only "my stores have completed" (s_waitcnt vmcnt(0)) before the flag store -- no cache-wide
- * write-back/invalidate.  Every TU a slot waits for lies in a group with a smaller ticket (the
+ * only "my stores have completed" (an explicit s_waitcnt vmcnt(0)) before the flag store -- no
+ * cache-wide write-back/invalidate.  Every TU a slot waits for lies in a group with a smaller ticket (the
  * host checks), whose wave is therefore already running or finished: no wave ever waits for
  * work that has not been picked up; the spin is bounded all the same and reports through the
  * pinned word ffhip_stream_sync looks at. */
@@ -413,7 +413,12 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                 }
                 intra_tu_any<true>(a, cur.t, lane, nbA, nbB, refs, resl[k & 1], rr, tile, wl, cur.tile_ok != 0);
                 if (cur.signal) { /* somebody outside the group reads this TU: publish it once its stores have completed */
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* s_waitcnt vmcnt(0); no L2-wide write-back */
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* compiler ordering; no L2-wide write-back */
+                    /* the fence alone lowers to s_waitcnt lgkmcnt(0): the flag must not overtake the sample stores
+                     * (MI355X_MICROARCH.md: every storing wave drains its vector-memory counter before it signals).
+                     * Sending the flag one TU later instead -- when the next residual, fetched behind these stores,
+                     * has been consumed -- was measured no faster: the reader waits for the flag either way */
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (lane == 0) __hip_atomic_store(flags + (slots[3 * k + 2].z), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 wave_sync(); /* the next TU reuses the neighbour scratch and reads the tile this one wrote */

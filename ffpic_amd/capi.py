@@ -21,7 +21,7 @@ EXPORTS = [
     "ffhip_yuv420_to_bgra", "ffhip_yuv420_to_bgra_16", "ffhip_yuv400_to_bgra_16",
     "ffhip_vp8_residual_batch", "ffhip_hevc_residual_batch", "ffhip_vp8_predict_recon",
     "ffhip_hevc_intra_recon", "ffhip_hevc_intra_plan", "ffhip_vp8_loopfilter",
-    "ffhip_jpeg_probe", "ffhip_jpeg_entropy_decode", "ffhip_jpeg_entropy_batch", "ffhip_bmp_write",
+    "ffhip_jpeg_probe", "ffhip_jpeg_entropy_decode", "ffhip_jpeg_entropy_decode_mt", "ffhip_jpeg_entropy_batch", "ffhip_bmp_write",
     "ffhip_heif_grid_parse", "ffhip_heif_grid_compose",
 ]
 
@@ -152,6 +152,7 @@ def lib():
     L.ffhip_hevc_residual_batch.argtypes = [ci, C.c_longlong, vp, vp, vp, ci, ci, vp, vp]
     L.ffhip_jpeg_probe.argtypes = [vp, sz, C.POINTER(JpegGeom), C.POINTER(ci), C.POINTER(ci)]
     L.ffhip_jpeg_entropy_decode.argtypes = [vp, sz, C.POINTER(JpegGeom), vp, vp, vp, vp]
+    L.ffhip_jpeg_entropy_decode_mt.argtypes = [vp, sz, C.POINTER(JpegGeom), vp, vp, vp, vp, ci]
     L.ffhip_jpeg_entropy_batch.argtypes = [vp, vp, ci, ci, C.POINTER(JpegGeom), vp, vp, vp, vp, vp]
     L.ffhip_bmp_write.argtypes = [C.c_char_p, vp, ci, ci, i64]
     L.ffhip_heif_grid_parse.argtypes = [vp, sz, C.POINTER(HeifGrid)]

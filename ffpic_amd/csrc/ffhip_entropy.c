@@ -247,9 +247,81 @@ int ffhip_jpeg_probe(const uint8_t *file, size_t len, ffhip_jpeg_geom *geom, int
     return rc;
 }
 
-/* one picture: coefficient planes (MCU order, natural order inside a block) + quant tables */
-int ffhip_jpeg_entropy_decode(const uint8_t *file, size_t len, const ffhip_jpeg_geom *expect, int16_t *coef_y,
-                              int16_t *coef_u, int16_t *coef_v, uint16_t *quant /* [4][64] */)
+/* `count` MCUs starting at `mcu`, from a bit reader positioned at the start of their entropy-coded
+ * segment, DC predictors zero (start of scan or just behind an RSTn): the loop of read_compressed_scan /
+ * decode_data_unit (jpg.c:255-415, 588-637).  Zeroes the blocks it is about to fill. */
+static int decode_mcus(const struct jpeg_hdr *j, int16_t *const planes[3], struct bits *b, long mcu, long count)
+{
+    int pred[3] = {0, 0, 0};
+    for (int c = 0; c < j->ncomp; c++) {
+        const size_t per = (size_t)j->h[c] * j->v[c] * 64;
+        memset(planes[c] + (size_t)mcu * per, 0, (size_t)count * per * sizeof(int16_t));
+    }
+    for (const long end = mcu + count; mcu < end; mcu++) {
+        for (int c = 0; c < j->ncomp; c++) {
+            const struct huff *hd = &j->dc[j->td[c]], *ha = &j->ac[j->ta[c]];
+            const int nb = j->h[c] * j->v[c];
+            for (int k = 0; k < nb; k++) {
+                int16_t *blk = planes[c] + (mcu * nb + k) * 64;
+                const int t = huff_decode(b, hd);
+                if (t < 0 || t > 11) return FFHIP_EINVAL;
+                pred[c] += extend(bits_get(b, t), t);
+                blk[0] = (int16_t)pred[c];
+                for (int i = 1; i < 64;) {
+                    if (b->n < 16) bits_fill(b);
+                    const int f = ha->fast[(b->acc >> (b->n - LOOK)) & ((1u << LOOK) - 1)];
+                    if (f) { /* run, value and all their bits from one look-up */
+                        i += (f >> 4) & 15;
+                        if (i > 63) return FFHIP_EINVAL;
+                        b->n -= f & 15;
+                        blk[k_zigzag[i++]] = (int16_t)(f >> 8);
+                        continue;
+                    }
+                    const int rs = huff_decode(b, ha);
+                    if (rs < 0) return FFHIP_EINVAL;
+                    const int r = rs >> 4, s = rs & 15;
+                    if (s == 0) {
+                        if (r == 15) { i += 16; continue; }
+                        break; /* EOB */
+                    }
+                    i += r;
+                    if (i > 63) return FFHIP_EINVAL;
+                    blk[k_zigzag[i]] = (int16_t)extend(bits_get(b, s), s);
+                    i++;
+                }
+            }
+        }
+    }
+    return FFHIP_OK;
+}
+
+/* restart intervals [first, last) of one picture; seg[i] = offset of interval i's first byte in the scan */
+struct interval_job {
+    const struct jpeg_hdr *j;
+    int16_t *planes[3];
+    const size_t *seg;
+    long n_seg, mcus, first, last;
+    int rc;
+};
+static void *interval_worker(void *arg)
+{
+    struct interval_job *w = arg;
+    w->rc = FFHIP_OK;
+    for (long i = w->first; i < w->last && w->rc == FFHIP_OK; i++) {
+        const uint8_t *p = w->j->scan + w->seg[i];
+        const uint8_t *e = i + 1 < w->n_seg ? w->j->scan + w->seg[i + 1] - 2 : w->j->scan + w->j->scan_len; /* stop at the RSTn */
+        struct bits b = {p, e, 0, 0, 0};
+        const long mcu = i * w->j->restart, left = w->mcus - mcu;
+        w->rc = decode_mcus(w->j, w->planes, &b, mcu, left < w->j->restart ? left : w->j->restart);
+    }
+    return NULL;
+}
+
+/* one picture: coefficient planes (MCU order, natural order inside a block) + quant tables.
+ * n_threads > 1 and a DRI segment in the file: the restart intervals (independent by construction,
+ * jpg.c:562-573) are shared out over host threads. */
+int ffhip_jpeg_entropy_decode_mt(const uint8_t *file, size_t len, const ffhip_jpeg_geom *expect, int16_t *coef_y,
+                                 int16_t *coef_u, int16_t *coef_v, uint16_t *quant /* [4][64] */, int n_threads)
 {
     struct jpeg_hdr *j = malloc(sizeof *j);
     if (!j) return FFHIP_ENOMEM;
@@ -260,60 +332,54 @@ int ffhip_jpeg_entropy_decode(const uint8_t *file, size_t len, const ffhip_jpeg_
                    expect->h != j->h[0] || expect->v != j->v[0])) { free(j); return FFHIP_EINVAL; }
     if (j->ncomp == 3 && (!coef_u || !coef_v)) { free(j); return FFHIP_EINVAL; }
     memcpy(quant, j->quant, sizeof j->quant);
-    int16_t *planes[3] = {coef_y, coef_u, coef_v};
     const long mcus = (long)mcu_cols * mcu_rows;
-    for (int c = 0; c < j->ncomp; c++) memset(planes[c], 0, (size_t)mcus * j->h[c] * j->v[c] * 64 * sizeof(int16_t));
-    struct bits b = {j->scan, j->scan + j->scan_len, 0, 0, 0};
-    int pred[3] = {0, 0, 0}, left = j->restart;
-    rc = FFHIP_OK;
-    for (long mcu = 0; mcu < mcus && rc == FFHIP_OK; mcu++) {
-        if (j->restart && left == 0) { /* RSTn: byte-align, skip the marker, reset predictors (jpg.c:562-573) */
-            const uint8_t *q = b.p;
-            while (q + 1 < b.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) q++;
-            if (q + 1 >= b.end) { rc = FFHIP_EINVAL; break; }
-            b.p = q + 2; b.acc = 0; b.n = 0; b.marker = 0;
-            pred[0] = pred[1] = pred[2] = 0;
-            left = j->restart;
-        }
-        left--;
-        for (int c = 0; c < j->ncomp; c++) {
-            const struct huff *hd = &j->dc[j->td[c]], *ha = &j->ac[j->ta[c]];
-            const int nb = j->h[c] * j->v[c];
-            for (int k = 0; k < nb; k++) {
-                int16_t *blk = planes[c] + (mcu * nb + k) * 64;
-                const int t = huff_decode(&b, hd);
-                if (t < 0 || t > 11) { rc = FFHIP_EINVAL; break; }
-                pred[c] += extend(bits_get(&b, t), t);
-                blk[0] = (int16_t)pred[c];
-                for (int i = 1; i < 64;) {
-                    if (b.n < 16) bits_fill(&b);
-                    const int f = ha->fast[(b.acc >> (b.n - LOOK)) & ((1u << LOOK) - 1)];
-                    if (f) { /* run, value and all their bits from one look-up */
-                        i += (f >> 4) & 15;
-                        if (i > 63) { rc = FFHIP_EINVAL; break; }
-                        b.n -= f & 15;
-                        blk[k_zigzag[i++]] = (int16_t)(f >> 8);
-                        continue;
-                    }
-                    const int rs = huff_decode(&b, ha);
-                    if (rs < 0) { rc = FFHIP_EINVAL; break; }
-                    const int r = rs >> 4, s = rs & 15;
-                    if (s == 0) {
-                        if (r == 15) { i += 16; continue; }
-                        break; /* EOB */
-                    }
-                    i += r;
-                    if (i > 63) { rc = FFHIP_EINVAL; break; }
-                    blk[k_zigzag[i]] = (int16_t)extend(bits_get(&b, s), s);
-                    i++;
-                }
-                if (rc) break;
-            }
-            if (rc) break;
-        }
+    struct interval_job base = {j, {coef_y, coef_u, coef_v}, NULL, 1, mcus, 0, 1, FFHIP_OK};
+    if (!j->restart) { /* one segment, one thread */
+        struct bits b = {j->scan, j->scan + j->scan_len, 0, 0, 0};
+        rc = decode_mcus(j, base.planes, &b, 0, mcus);
+        free(j);
+        return rc;
     }
+    /* where every restart interval starts: behind the RSTn markers (0xFF is stuffed inside entropy data,
+     * so FF D0..D7 can only be a marker) */
+    const long n_seg = (mcus + j->restart - 1) / j->restart;
+    size_t *seg = malloc((size_t)n_seg * sizeof *seg);
+    if (!seg) { free(j); return FFHIP_ENOMEM; }
+    long found = 1;
+    seg[0] = 0;
+    for (size_t q = 0; q + 1 < j->scan_len && found < n_seg; q++)
+        if (j->scan[q] == 0xFF && j->scan[q + 1] >= 0xD0 && j->scan[q + 1] <= 0xD7) { seg[found++] = q + 2; q++; }
+    if (found != n_seg) { free(seg); free(j); return FFHIP_EINVAL; } /* a marker is missing: the reference would run dry too */
+    base.seg = seg;
+    base.n_seg = n_seg;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > n_seg) n_threads = (int)n_seg;
+    if (n_threads > 64) n_threads = 64;
+    struct interval_job jobs[64];
+    pthread_t tid[64];
+    int started[64] = {0};
+    for (int t = 0; t < n_threads; t++) {
+        jobs[t] = base;
+        jobs[t].first = n_seg * t / n_threads;
+        jobs[t].last = n_seg * (t + 1) / n_threads;
+        if (t) started[t] = pthread_create(&tid[t], NULL, interval_worker, &jobs[t]) == 0;
+    }
+    interval_worker(&jobs[0]);
+    rc = jobs[0].rc;
+    for (int t = 1; t < n_threads; t++) {
+        if (started[t]) pthread_join(tid[t], NULL);
+        else interval_worker(&jobs[t]); /* could not start a thread: do its share here */
+        if (rc == FFHIP_OK) rc = jobs[t].rc;
+    }
+    free(seg);
     free(j);
     return rc;
+}
+
+int ffhip_jpeg_entropy_decode(const uint8_t *file, size_t len, const ffhip_jpeg_geom *expect, int16_t *coef_y,
+                              int16_t *coef_u, int16_t *coef_v, uint16_t *quant /* [4][64] */)
+{
+    return ffhip_jpeg_entropy_decode_mt(file, len, expect, coef_y, coef_u, coef_v, quant, 1);
 }
 
 struct batch_job {
@@ -344,6 +410,16 @@ int ffhip_jpeg_entropy_batch(const uint8_t *const *files, const size_t *lens, in
     if (n < 0 || !geom || (n > 0 && (!files || !lens || !coef_y || !quant || !status))) return FFHIP_EINVAL;
     if (n == 0) return FFHIP_OK;
     if (n_threads < 1) n_threads = 1;
+    if (n_threads >= 2 * n) { /* more threads than pictures: spend them inside each picture (restart intervals) */
+        const size_t mcus = (size_t)geom->mcu_cols * geom->mcu_rows, yb = mcus * geom->h * geom->v * 64, cb = mcus * 64;
+        int first_err = FFHIP_OK;
+        for (int i = 0; i < n; i++) {
+            status[i] = ffhip_jpeg_entropy_decode_mt(files[i], lens[i], geom, coef_y + (size_t)i * yb, coef_u ? coef_u + (size_t)i * cb : NULL,
+                                                     coef_v ? coef_v + (size_t)i * cb : NULL, quant + (size_t)i * 256, n_threads);
+            if (status[i] && !first_err) first_err = status[i];
+        }
+        return first_err;
+    }
     if (n_threads > n) n_threads = n;
     if (n_threads > 256) n_threads = 256;
     struct batch_job jobs[256];

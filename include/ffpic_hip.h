@@ -337,7 +337,13 @@ int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu *d_tu
 int ffhip_jpeg_probe(const uint8_t *file, size_t len, ffhip_jpeg_geom *geom, int *width, int *height);
 int ffhip_jpeg_entropy_decode(const uint8_t *file, size_t len, const ffhip_jpeg_geom *expect,
                               int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, uint16_t *quant /* [4][64] */);
-/* n files of one geometry over n_threads host threads; image i writes planes at
+/* the same for one picture with n_threads host threads: a file with a DRI segment has independent
+ * restart intervals (jpg.c:562-573), which are shared out; without one it is a single-thread decode */
+int ffhip_jpeg_entropy_decode_mt(const uint8_t *file, size_t len, const ffhip_jpeg_geom *expect,
+                                 int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, uint16_t *quant,
+                                 int n_threads);
+/* n files of one geometry over n_threads host threads (with at least twice as many threads as files
+ * the threads work inside each picture instead, as above); image i writes planes at
  * + i*blocks*64 and quant at + i*256; status[i] receives each file's code. */
 int ffhip_jpeg_entropy_batch(const uint8_t *const *files, const size_t *lens, int n, int n_threads,
                              const ffhip_jpeg_geom *geom, int16_t *coef_y, int16_t *coef_u,

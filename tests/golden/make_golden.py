@@ -460,7 +460,9 @@ def gen_files(R):
                           # (a 4:2:2 file is not used: the reference's own whole-file decode of small
                           #  h2v1 pictures crashes intermittently in its Huffman reader; 4:2:2 is
                           #  covered at grid level in jpeg_grids.npz)
-                          ("q80_grey", dict(quality=80), "L")):
+                          ("q80_grey", dict(quality=80), "L"),
+                          # restart markers (DRI, one MCU row per interval): jpg.c:562-573
+                          ("q85_420_dri", dict(quality=85, subsampling=2, restart_marker_rows=1), "RGB")):
         im = Image.fromarray(img).convert(mode)
         if tag != "q85_420":
             im = im.crop((0, 0, 160, 96))  # keep the extra fixtures small

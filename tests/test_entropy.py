@@ -118,3 +118,36 @@ def test_front_end_under_sanitizers(tmp_path):
     out = subprocess.run([exe, "400"] + files, capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "decoded" in out.stdout
+
+
+@pytest.mark.parametrize("blocks", [1, 7, 40])
+def test_one_picture_over_threads_by_restart_interval(blocks):
+    """ffhip_jpeg_entropy_decode_mt: the restart intervals of ONE picture shared out over host threads give the
+    planes of the single-thread decode and of the fixture decoder, for any thread count"""
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(blocks)
+    yy, xx = np.mgrid[0:300, 0:420]
+    img = np.stack([128 + 100 * np.sin(xx / 17.0), 128 + 90 * np.cos(yy / 13.0), (xx + yy) % 256], axis=2)
+    img = np.clip(img + rng.normal(0, 8, img.shape), 0, 255).astype(np.uint8)
+    bio = io.BytesIO()
+    PIL.fromarray(img).save(bio, "JPEG", quality=88, subsampling=2, restart_marker_blocks=blocks)
+    data = bio.getvalue()
+    dec = jpeg_entropy.decode(data)
+    L = capi.lib()
+    g, _, _ = ops.jpeg_probe(data)
+    buf = np.frombuffer(data, np.uint8)
+    for th in (1, 2, 5, 8, 64):
+        cy = np.full(g.y_blocks * 64, 77, np.int16)
+        cu = np.full(g.c_blocks * 64, 77, np.int16)
+        cv = np.full(g.c_blocks * 64, 77, np.int16)
+        q = np.zeros((4, 64), np.uint16)
+        rc = L.ffhip_jpeg_entropy_decode_mt(buf.ctypes.data, buf.size, C.byref(g), cy.ctypes.data, cu.ctypes.data, cv.ctypes.data, q.ctypes.data, th)
+        assert rc == 0
+        assert np.array_equal(cy, dec["coef"][0]) and np.array_equal(cu, dec["coef"][1]) and np.array_equal(cv, dec["coef"][2]), th
+    # a missing marker is refused, not guessed around
+    broken = bytearray(data)
+    k = data.find(b"\xff\xd1")
+    assert k > 0
+    broken[k + 1] = 0x00
+    bb = np.frombuffer(bytes(broken), np.uint8)
+    assert L.ffhip_jpeg_entropy_decode_mt(bb.ctypes.data, bb.size, C.byref(g), cy.ctypes.data, cu.ctypes.data, cv.ctypes.data, q.ctypes.data, 4) != 0

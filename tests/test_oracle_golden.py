@@ -233,7 +233,8 @@ def test_oracle_batch_threads_and_errors():
     assert O.ffo().ffo_jpeg_recon_batch(C.byref(geom), 0, cy, None, None, q, 0, out, 16, 16, 1) == 0
 
 
-FILES = {"q85_420": "file_q85_420.jpg", "q92_444": "file_q92_444.jpg", "q80_grey": "file_q80_grey.jpg"}
+FILES = {"q85_420": "file_q85_420.jpg", "q92_444": "file_q92_444.jpg", "q80_grey": "file_q80_grey.jpg",
+         "q85_420_dri": "file_q85_420_dri.jpg"}
 
 
 def decode_fixture(tag):

@@ -287,3 +287,41 @@ def heif_grid_compose(tiles, cols, out_w, out_h):
     capi.check(L.ffhip_heif_grid_compose(dc.ptr, out_w * 4, out_w, out_h, dt.ptr, tw * 4, tw * th * 4, tw, th, n // cols, cols,
                                          None), "ffhip_heif_grid_compose")
     return dc.to_host((out_h, out_w, 4), np.uint8)
+
+
+class PinnedArray:
+    """numpy view of pinned host memory (ffhip_host_malloc); keep the object alive while the view is used."""
+
+    def __init__(self, shape, dtype=np.uint8):
+        L = capi.require_device()
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = L.ffhip_host_malloc(self.nbytes)
+        if not self.ptr:
+            raise capi.FfhipError("ffhip_host_malloc failed")
+        self.array = np.frombuffer((C.c_uint8 * self.nbytes).from_address(self.ptr), dtype=dtype).reshape(shape)
+
+    def __del__(self):
+        try:
+            capi.lib().ffhip_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def jpeg_decode_files(files, n_threads=8, chunk=0, out=None):
+    """ffhip_jpeg_decode_files: same-geometry baseline JPEG files (list of bytes) -> (geom, BGRA [n][H][W][4] at the
+    coded size), entropy decode on host threads overlapped with copy + reconstruction on the GPU.  `out`: a
+    preallocated uint8 array [n][H][W][4] (e.g. PinnedArray(...).array, which takes the device copy directly)."""
+    L = capi.require_device()
+    g, _, _ = jpeg_probe(files[0])
+    n = len(files)
+    bufs = [np.frombuffer(f, dtype=np.uint8) for f in files]
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    lens = (C.c_size_t * n)(*[b.size for b in bufs])
+    if out is None:
+        out = np.empty((n, g.height, g.width, 4), np.uint8)
+    assert out.shape == (n, g.height, g.width, 4) and out.dtype == np.uint8 and out.flags.c_contiguous
+    status = (C.c_int * n)()
+    g2 = capi.JpegGeom()
+    capi.check(L.ffhip_jpeg_decode_files(ptrs, lens, n, n_threads, chunk, C.byref(g2), out.ctypes.data, g.width * 4,
+                                         g.width * 4 * g.height, status), "ffhip_jpeg_decode_files")
+    return g2, out

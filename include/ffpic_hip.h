@@ -348,6 +348,22 @@ int ffhip_jpeg_entropy_decode_mt(const uint8_t *file, size_t len, const ffhip_jp
 int ffhip_jpeg_entropy_batch(const uint8_t *const *files, const size_t *lens, int n, int n_threads,
                              const ffhip_jpeg_geom *geom, int16_t *coef_y, int16_t *coef_u,
                              int16_t *coef_v, uint16_t *quant, int *status);
+/* Files in, pixels out (f1 + the hot path + f2's producer side): n baseline JPEG files of ONE geometry are
+ * Huffman-decoded by n_threads host threads into pinned memory, `chunk` pictures at a time (0 = 8), while the
+ * previous chunk is copied to the device, reconstructed by one launch and copied back -- a double-buffered
+ * pipeline whose steady state is the slower of host entropy decode and PCIe.  bgra is HOST memory,
+ * pixel (x, y) of picture i at bgra + i*image_stride + y*pitch + 4*x (coded size, geom_out tells it);
+ * status[i] = per-file code, the return value the first failure.  The layout format/jpg.c:851-852 hands
+ * to struct pic.  Not for single-component files with several blocks per MCU.  A destination in pinned
+ * memory (ffhip_host_malloc, or the caller's own hipHostMalloc / hipHostRegister) receives the device copy
+ * directly; a pageable one goes through pinned staging and a threaded copy.  Buffers are kept between calls;
+ * one call at a time. */
+void *ffhip_host_malloc(size_t bytes); /* pinned host memory */
+void ffhip_host_free(void *p);
+int ffhip_jpeg_decode_files(const uint8_t *const *files, const size_t *lens, int n, int n_threads, int chunk,
+                            ffhip_jpeg_geom *geom_out, uint8_t *bgra, int64_t pitch, int64_t image_stride,
+                            int *status);
+
 /* display/bmpwriter.c:19-81: 54-byte header + top-down 32-bit rows; byte-identical files. */
 int ffhip_bmp_write(const char *path, const uint8_t *bgra, int width, int height, int64_t pitch);
 

@@ -316,3 +316,23 @@ def test_strip_kernel_exact_integer_green(golden, h, v):
     # the branch really is exercised: the integer form alone would differ somewhere
     g_int = np.clip(yy[:, 0] + (-(215 * (pairs[:, 0].astype(np.int64) - 128) + 381 * (pairs[:, 1].astype(np.int64) - 128))) // 1000, 0, 255)
     assert (g_int != exp.reshape(rows, 8 * v, cols, 8 * h, 4)[:, 0, :, 0, 1].reshape(-1)).any()
+
+
+@pytest.mark.parametrize("tag", list(FILES))
+@pytest.mark.parametrize("n,chunk,threads", [(1, 0, 1), (5, 2, 3), (9, 4, 16)])
+def test_files_to_pixels_pipeline(tag, n, chunk, threads):
+    """ffhip_jpeg_decode_files: the double-buffered host-entropy / GPU-reconstruction pipeline gives the bytes of the
+    plain two-step path (entropy batch, then the host-buffer reconstruction) for every fixture file"""
+    data = open(os.path.join(os.path.dirname(__file__), "golden", FILES[tag]), "rb").read()
+    files = [data] * n
+    g, ref = ops.decode_jpeg_files(files[:1], n_threads=1)
+    g2, out = ops.jpeg_decode_files(files, n_threads=threads, chunk=chunk)
+    assert (g2.mcu_cols, g2.mcu_rows, g2.ncomp, g2.h, g2.v) == (g.mcu_cols, g.mcu_rows, g.ncomp, g.h, g.v)
+    ref = np.asarray(ref[0]).reshape(g.height, g.width, 4)
+    for i in range(n):
+        assert np.array_equal(out[i], ref), (tag, i)
+    # a pinned destination takes the device copy directly: same bytes
+    pin = ops.PinnedArray((n, g.height, g.width, 4))
+    pin.array[:] = 0
+    ops.jpeg_decode_files(files, n_threads=threads, chunk=chunk, out=pin.array)
+    assert np.array_equal(pin.array, out)

@@ -1,7 +1,7 @@
 /*
  * transbmp_hip.c -- the reference's app/transbmp.c (file -> BMP) done through the C ABI of
- * libffpic_hip.so only: host-side entropy front end, fused reconstruction on the MI355X, BMP
- * sink.  Plain C11; no HIP headers, no C++.
+ * libffpic_hip.so only: ffhip_jpeg_decode_files (host-side entropy front end overlapped with the fused
+ * reconstruction on the MI355X), then the BMP sink.  Plain C11; no HIP headers, no C++.
  *
  *   gcc -std=c11 -O2 -Iinclude examples/transbmp_hip.c -Lffpic_amd -lffpic_hip \
  *       -Wl,-rpath,$PWD/ffpic_amd -o transbmp_hip
@@ -51,18 +51,12 @@ int main(int argc, char **argv)
         if (i == 0) { g = gi; w0 = w; h0 = h; }
         else if (memcmp(&g, &gi, sizeof g)) { fprintf(stderr, "%s: geometry differs from the first file\n", argv[1 + i]); return 1; }
     }
-    const size_t mcus = (size_t)g.mcu_cols * g.mcu_rows, yb = mcus * g.h * g.v * 64, cb = mcus * 64;
     const int W = g.mcu_cols * 8 * g.h, H = g.mcu_rows * 8 * g.v;
-    int16_t *cy = malloc(n * yb * 2), *cu = malloc(n * cb * 2), *cv = malloc(n * cb * 2);
-    uint16_t *quant = malloc((size_t)n * 256 * 2);
-    uint8_t *bgra = malloc((size_t)n * W * H * 4);
-    if (!cy || !cu || !cv || !quant || !bgra) return 1;
-
-    rc = ffhip_jpeg_entropy_batch(files, lens, n, 8, &g, cy, g.ncomp == 3 ? cu : NULL, g.ncomp == 3 ? cv : NULL, quant, status);
-    if (rc) { fprintf(stderr, "entropy decode failed: %d\n", rc); return 1; }
-    rc = ffhip_jpeg_recon_batch_host(&g, n, cy, g.ncomp == 3 ? cu : NULL, g.ncomp == 3 ? cv : NULL, quant, 256, bgra,
-                                     (int64_t)W * 4, (int64_t)W * H * 4);
-    if (rc) { fprintf(stderr, "reconstruction failed: %s\n", ffhip_strerror(rc)); return 1; }
+    uint8_t *bgra = ffhip_host_malloc((size_t)n * W * H * 4); /* pinned: the device copies straight into it */
+    if (!bgra) return 1;
+    /* Huffman decode on 8 host threads, overlapped chunk by chunk with copy + reconstruction on the GPU */
+    rc = ffhip_jpeg_decode_files(files, lens, n, 8, 0, &g, bgra, (int64_t)W * 4, (int64_t)W * H * 4, status);
+    if (rc) { fprintf(stderr, "decode failed: %s\n", ffhip_strerror(rc)); return 1; }
     for (int i = 0; i < n; i++) {
         char name[1024];
         /* the reference names its output "<file> (<w> * <h>).bmp" with w aligned to 8 (app/transbmp.c, format/jpg.c:794) */

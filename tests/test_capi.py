@@ -58,6 +58,29 @@ def test_no_silent_cpu_fallback(L):
     L.hip_accl_init()                          # ... and does not register (arch/opencl/opcl.c:112-114)
     assert L.ffhip_malloc(1024) is None
     assert L.ffhip_jpeg_recon_batch_host(C.byref(g), 1, None, None, None, None, 0, None, 0, 0) == -19
+    # every later entry point refuses the same way: no device, no result
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    data = np.frombuffer(open(os.path.join(GOLDEN, "file_q80_grey.jpg"), "rb").read(), np.uint8)
+    ptrs, lens, status = (C.c_void_p * 1)(data.ctypes.data), (C.c_size_t * 1)(data.size), (C.c_int * 1)()
+    out = np.zeros(160 * 96 * 4, np.uint8)
+    assert L.ffhip_jpeg_decode_files(ptrs, lens, 1, 2, 0, None, out.ctypes.data, 160 * 4, 160 * 96 * 4, status) == -19
+    assert not out.any()
+    assert L.ffhip_host_malloc(64) is None
+    buf = np.zeros(4096, np.uint8)
+    p = buf.ctypes.data
+    assert L.ffhip_heif_grid_compose(p, 64, 16, 16, p, 64, 1024, 16, 16, 1, 1, None) == -19
+    assert L.ffhip_yuv420_to_bgra(p, 64, p, p, p, 16, 8, 1, 1, 1, 0, 0, 0, None) == -19
+    assert L.ffhip_vp8_residual_batch(1, p, p, p, p, None) == -19
+    assert L.ffhip_hevc_residual_batch(4, 1, p, p, None, 8, 0, p, None) == -19
+    modes = np.zeros(20, np.uint8)
+    assert L.ffhip_vp8_predict_recon(1, 1, 1, modes.ctypes.data, p, p, 384, None, p, p, p, 256, 64, None) == -19
+    assert L.ffhip_vp8_loopfilter(1, 1, 1, 2, p, p, p, p, p, 256, 64, None) == -19
+    tu = np.zeros(32, np.uint8)
+    tu[4] = 2                                   # log2_size
+    assert L.ffhip_hevc_intra_recon(tu.ctypes.data, p, 1, p, p, None, None, 16, 16, 16, 0, 0, 0, 8, 8, None) == -19
+    assert not buf.any()
 
 
 def test_geometry_validation(L):

@@ -21,6 +21,7 @@
  * is not reproduced.
  */
 #include "ffpic_hip.h"
+#include "ffhip_entropy_internal.h"
 
 #include <pthread.h>
 #include <stdio.h>
@@ -31,18 +32,6 @@ static const uint8_t k_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32,
                                      12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
                                      35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
                                      58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-
-#define LOOK 9
-struct huff {
-    uint16_t look[1 << LOOK]; /* (length << 8) | symbol, 0 = not resolvable in LOOK bits */
-    int32_t maxcode[18];      /* per length, -1 if none */
-    int32_t valptr[17], mincode[17];
-    uint8_t vals[256];
-    int present;
-    /* AC tables: when code and magnitude bits both fit into LOOK bits, the whole coefficient in one
-     * look-up: (value << 8) | (run << 4) | (code length + magnitude bits), 0 = take the slow path */
-    int16_t fast[1 << LOOK];
-};
 
 static int huff_build(struct huff *h, const uint8_t counts[16], const uint8_t *vals, int nvals)
 {
@@ -135,15 +124,6 @@ static inline int huff_decode(struct bits *b, const struct huff *h)
 }
 static inline int extend(int v, int t) { return (t && v < (1 << (t - 1))) ? v - (1 << t) + 1 : v; }
 
-struct jpeg_hdr {
-    int width, height, ncomp, restart;
-    int h[3], v[3], tq[3], td[3], ta[3], cid[3];
-    uint16_t quant[4][64];
-    struct huff dc[4], ac[4];
-    const uint8_t *scan;
-    size_t scan_len;
-};
-
 static int parse_headers(const uint8_t *f, size_t len, struct jpeg_hdr *j)
 {
     memset(j, 0, sizeof *j);
@@ -226,6 +206,18 @@ static int parse_headers(const uint8_t *f, size_t len, struct jpeg_hdr *j)
     for (int c = 1; c < j->ncomp; c++)
         if (j->h[c] != 1 || j->v[c] != 1) return FFHIP_EINVAL; /* colorspace.c:149-150: chroma is one block per MCU */
     return FFHIP_OK;
+}
+
+/* for the other translation units of the library (ffhip_huff_gpu.hip) */
+int ffhip_jpeg_parse(const uint8_t *file, size_t len, struct jpeg_hdr *j) { return parse_headers(file, len, j); }
+/* the DRI value of a file this front end accepts (0 = none), -1 if it does not parse */
+int ffhip_jpeg_probe_restart(const uint8_t *file, size_t len)
+{
+    struct jpeg_hdr *j = malloc(sizeof *j);
+    if (!j) return -1;
+    const int r = parse_headers(file, len, j) ? -1 : j->restart;
+    free(j);
+    return r;
 }
 
 int ffhip_jpeg_probe(const uint8_t *file, size_t len, ffhip_jpeg_geom *geom, int *width, int *height)

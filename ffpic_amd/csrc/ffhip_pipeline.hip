@@ -10,6 +10,7 @@
  * is never the number bench.py reports.
  */
 #include "ffhip_internal.h"
+#include "ffhip_entropy_internal.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -117,7 +118,14 @@ extern "C" int ffhip_jpeg_decode_files(const uint8_t *const *files, const size_t
     if (pitch < width * 4 || (pitch & 15) || (n > 1 && image_stride < pitch * height)) return FFHIP_EINVAL;
     if (ffhip_jpeg_workspace_bytes(&g, 1) != 0) return FFHIP_EINVAL; /* one component with several blocks per MCU: not here */
     if (!ffhip_have_device()) return FFHIP_ENODEV;
-    if (chunk <= 0) chunk = 8;
+    /* restart markers in the first file: try the device-side entropy decoder (FFHIP_JPEG_GPU_ENTROPY=0 keeps it off).
+     * Its latency per batch is that of ONE restart interval, so it wants large chunks */
+    const char *ge = getenv("FFHIP_JPEG_GPU_ENTROPY");
+    bool gpu_entropy = !(ge && ge[0] == '0');
+    if (gpu_entropy) {
+        gpu_entropy = ffhip_jpeg_probe_restart(files[0], lens[0]) > 0;
+    }
+    if (chunk <= 0) chunk = gpu_entropy ? 32 : 8;
     if (chunk > n) chunk = n;
     const size_t mcus = (size_t)g.mcu_cols * g.mcu_rows;
     const size_t yb = mcus * g.h * g.v * 64, cb = g.ncomp == 3 ? mcus * 64 : 0; /* int16 elements per picture */
@@ -147,15 +155,27 @@ extern "C" int ffhip_jpeg_decode_files(const uint8_t *const *files, const size_t
         const int cnt = n - first < chunk ? n - first : chunk;
         rc = drain(sl); /* the slot's previous chunk (k - 2) */
         if (rc) break;
-        /* host: entropy decode straight into pinned memory (blocks; chunk k - 1 is on the GPU meanwhile) */
-        const int erc = ffhip_jpeg_entropy_batch(files + first, lens + first, cnt, n_threads, &g, sl.h_y, cb ? sl.h_u : nullptr,
-                                                 cb ? sl.h_v : nullptr, sl.h_q, status + first);
-        if (erc && !result) result = erc; /* per-picture codes are in status[]; bad pictures still occupy their place */
-        hipError_t e = hipMemcpyAsync(sl.d_y, sl.h_y, cnt * yb * 2, hipMemcpyHostToDevice, sl.st);
-        if (e == hipSuccess && cb) e = hipMemcpyAsync(sl.d_u, sl.h_u, cnt * cb * 2, hipMemcpyHostToDevice, sl.st);
-        if (e == hipSuccess && cb) e = hipMemcpyAsync(sl.d_v, sl.h_v, cnt * cb * 2, hipMemcpyHostToDevice, sl.st);
-        if (e == hipSuccess) e = hipMemcpyAsync(sl.d_q, sl.h_q, (size_t)cnt * 512, hipMemcpyHostToDevice, sl.st);
-        if (e != hipSuccess) { rc = FFHIP_EIO; break; }
+        hipError_t e = hipSuccess;
+        /* entropy decode.  Files with restart markers: on the device, one lane per interval, straight into the
+         * device planes (the host only parses headers and finds the markers).  Otherwise, or if that refuses:
+         * host threads into pinned memory, then H2D.  Either way chunk k - 1 is on the GPU meanwhile. */
+        bool on_device = false;
+        if (gpu_entropy) {
+            const int grc = ffhip_jpeg_entropy_batch_gpu(files + first, lens + first, cnt, n_threads, &g, sl.d_y, cb ? sl.d_u : nullptr,
+                                                         cb ? sl.d_v : nullptr, sl.d_q, status + first, sl.st);
+            on_device = grc == FFHIP_OK;
+            if (!on_device && grc != FFHIP_EINVAL) { rc = grc; break; }
+        }
+        if (!on_device) {
+            const int erc = ffhip_jpeg_entropy_batch(files + first, lens + first, cnt, n_threads, &g, sl.h_y, cb ? sl.h_u : nullptr,
+                                                     cb ? sl.h_v : nullptr, sl.h_q, status + first);
+            if (erc && !result) result = erc; /* per-picture codes are in status[]; bad pictures still occupy their place */
+            e = hipMemcpyAsync(sl.d_y, sl.h_y, cnt * yb * 2, hipMemcpyHostToDevice, sl.st);
+            if (e == hipSuccess && cb) e = hipMemcpyAsync(sl.d_u, sl.h_u, cnt * cb * 2, hipMemcpyHostToDevice, sl.st);
+            if (e == hipSuccess && cb) e = hipMemcpyAsync(sl.d_v, sl.h_v, cnt * cb * 2, hipMemcpyHostToDevice, sl.st);
+            if (e == hipSuccess) e = hipMemcpyAsync(sl.d_q, sl.h_q, (size_t)cnt * 512, hipMemcpyHostToDevice, sl.st);
+            if (e != hipSuccess) { rc = FFHIP_EIO; break; }
+        }
         rc = ffhip_jpeg_recon_batch(&g, cnt, sl.d_y, cb ? sl.d_u : nullptr, cb ? sl.d_v : nullptr, sl.d_q, 256, sl.d_out, (int64_t)dev_pitch,
                                     (int64_t)out_b, nullptr, 0, sl.st);
         if (rc) break;

@@ -325,3 +325,25 @@ def jpeg_decode_files(files, n_threads=8, chunk=0, out=None):
     capi.check(L.ffhip_jpeg_decode_files(ptrs, lens, n, n_threads, chunk, C.byref(g2), out.ctypes.data, g.width * 4,
                                          g.width * 4 * g.height, status), "ffhip_jpeg_decode_files")
     return g2, out
+
+
+def jpeg_entropy_batch_gpu(files, n_threads=4):
+    """ffhip_jpeg_entropy_batch_gpu on files with restart markers; planes come back to the host for inspection.
+    Returns (geom, cy, cu, cv, quant[n][4][64]) like jpeg_entropy_batch."""
+    L = capi.require_device()
+    g, _, _ = jpeg_probe(files[0])
+    n = len(files)
+    bufs = [np.frombuffer(f, dtype=np.uint8) for f in files]
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    lens = (C.c_size_t * n)(*[b.size for b in bufs])
+    dy = DeviceBuffer(nbytes=n * g.y_blocks * 128)
+    du = DeviceBuffer(nbytes=max(n * g.c_blocks * 128, 16)) if g.ncomp == 3 else None
+    dv = DeviceBuffer(nbytes=max(n * g.c_blocks * 128, 16)) if g.ncomp == 3 else None
+    dq = DeviceBuffer(nbytes=n * 512)
+    status = (C.c_int * n)()
+    capi.check(L.ffhip_jpeg_entropy_batch_gpu(ptrs, lens, n, n_threads, C.byref(g), dy.ptr, du.ptr if du else None, dv.ptr if dv else None, dq.ptr,
+                                              status, None), "ffhip_jpeg_entropy_batch_gpu")
+    cy = dy.to_host((n * g.y_blocks * 64,), np.int16)
+    cu = du.to_host((n * g.c_blocks * 64,), np.int16) if du else None
+    cv = dv.to_host((n * g.c_blocks * 64,), np.int16) if dv else None
+    return g, cy, cu, cv, dq.to_host((n, 4, 64), np.uint16)

@@ -348,8 +348,18 @@ int ffhip_jpeg_entropy_decode_mt(const uint8_t *file, size_t len, const ffhip_jp
 int ffhip_jpeg_entropy_batch(const uint8_t *const *files, const size_t *lens, int n, int n_threads,
                              const ffhip_jpeg_geom *geom, int16_t *coef_y, int16_t *coef_u,
                              int16_t *coef_v, uint16_t *quant, int *status);
+/* The same front end ON the device for files that carry restart markers (DRI): one lane per restart interval
+ * decodes straight into DEVICE planes (d_coef_*, d_quant [n][4][64]) laid out for ffhip_jpeg_recon_batch with
+ * quant_stride 256; the host only parses headers and finds the RSTn markers.  files/lens/status are HOST
+ * arrays.  FFHIP_EINVAL for a file without DRI (one interval = nothing to spread out; use the host threads)
+ * or of another geometry.  Synchronises `stream` (the per-picture verdicts come back with it). */
+int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const size_t *lens, int n, int n_threads /* host: header
+                                 parsing, marker search, staging */, const ffhip_jpeg_geom *geom, int16_t *d_coef_y, int16_t *d_coef_u, int16_t *d_coef_v, uint16_t *d_quant,
+                                 int *status, void *stream);
+
 /* Files in, pixels out (f1 + the hot path + f2's producer side): n baseline JPEG files of ONE geometry are
- * Huffman-decoded by n_threads host threads into pinned memory, `chunk` pictures at a time (0 = 8), while the
+ * entropy-decoded `chunk` pictures at a time (0 = default) -- on the device when they carry restart markers
+ * (ffhip_jpeg_entropy_batch_gpu), else by n_threads host threads into pinned memory -- while the
  * previous chunk is copied to the device, reconstructed by one launch and copied back -- a double-buffered
  * pipeline whose steady state is the slower of host entropy decode and PCIe.  bgra is HOST memory,
  * pixel (x, y) of picture i at bgra + i*image_stride + y*pitch + 4*x (coded size, geom_out tells it);

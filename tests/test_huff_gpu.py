@@ -1,0 +1,75 @@
+"""GPU: the JPEG entropy front end on the device (one lane per restart interval) against the host decoder,
+whose planes the CPU tests pin to the reference's whole-file decode."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+from ffpic_amd import capi, ops
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def same_planes(files):
+    g, cy, cu, cv, q = ops.jpeg_entropy_batch_gpu(files)
+    g2, hy, hu, hv, hq = ops.jpeg_entropy_batch(files, n_threads=2)
+    assert np.array_equal(q, hq)
+    assert np.array_equal(cy, hy)
+    if g.ncomp == 3:
+        assert np.array_equal(cu, hu) and np.array_equal(cv, hv)
+    return g
+
+
+def test_dri_fixture():
+    data = open(os.path.join(GOLDEN, "file_q85_420_dri.jpg"), "rb").read()
+    same_planes([data])
+    same_planes([data] * 5)
+
+
+def test_files_without_restart_markers_are_refused():
+    data = open(os.path.join(GOLDEN, "file_q85_420.jpg"), "rb").read()
+    with pytest.raises(capi.FfhipError):
+        ops.jpeg_entropy_batch_gpu([data])
+
+
+@pytest.mark.parametrize("sub,mode,blocks,q", [(2, "RGB", 1, 90), (2, "RGB", 7, 60), (0, "RGB", 3, 95), (1, "RGB", 5, 75), (0, "L", 4, 85),
+                                                (2, "RGB", 40, 30), (2, "RGB", 2, 100)])
+def test_generated_files(sub, mode, blocks, q):
+    """PIL-made files: 4:2:0 / 4:4:4 / 4:2:2 / grey, short and long restart intervals, low and high quality
+    (quality 100 exercises long codes and 16-bit-ish magnitudes, quality 30 long zero runs)"""
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(blocks * 100 + q)
+    files = []
+    for i in range(3):
+        yy, xx = np.mgrid[0:200, 0:296]
+        img = np.stack([128 + 100 * np.sin(xx / (9.0 + i)), 128 + 90 * np.cos(yy / 7.0), (xx * 3 + yy * 5) % 256], axis=2)
+        img = np.clip(img + rng.normal(0, 25, img.shape), 0, 255).astype(np.uint8)
+        bio = io.BytesIO()
+        im = PIL.fromarray(img).convert(mode)
+        kw = dict(quality=q, restart_marker_blocks=blocks)
+        if mode == "RGB":
+            kw["subsampling"] = sub
+        im.save(bio, "JPEG", **kw)
+        files.append(bio.getvalue())
+    assert b"\xff\xdd" in files[0]
+    same_planes(files)
+
+
+def test_corrupt_interval_is_reported_not_crashed():
+    """bytes of one interval replaced by noise: that picture is flagged, the call returns an error, nothing faults"""
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(1)
+    img = np.clip(rng.normal(128, 50, (128, 160, 3)), 0, 255).astype(np.uint8)
+    bio = io.BytesIO()
+    PIL.fromarray(img).save(bio, "JPEG", quality=80, subsampling=2, restart_marker_blocks=2)
+    data = bytearray(bio.getvalue())
+    k = bytes(data).find(b"\xff\xd2")
+    assert k > 0
+    noise = rng.integers(0, 255, 40).astype(np.uint8)      # no 0xFF: the marker structure survives
+    data[k + 2:k + 42] = bytes(noise)
+    try:
+        ops.jpeg_entropy_batch_gpu([bytes(data)])
+    except capi.FfhipError:
+        pass                                               # flagged: fine; decoding garbage without a flag is fine too

@@ -16,20 +16,22 @@ img = np.stack([128 + 100 * np.sin(xx / 37.0) * np.cos(yy / 23.0), 128 + 90 * np
 img = np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
 bio = io.BytesIO(); Image.fromarray(img).save(bio, "JPEG", quality=85, subsampling=2, restart_marker_rows=1)
 data = bio.getvalue()
-n = 64
+n = 128
 files = [data] * n
 out = {"file_bytes": len(data), "pictures": n, "coded": [3840, 2160]}
 pageable = np.zeros((n, 2160, 3840, 4), np.uint8)     # touched once: no first-touch page faults in the timing
 pinned = ops.PinnedArray((n, 2160, 3840, 4))
 ops.jpeg_decode_files(files, n_threads=8, chunk=4, out=pageable)
-for dst_name, dst in (("pageable", pageable), ("pinned", pinned.array)):
-    for th in (1, 4, 8, 16):
-        for chunk in (2, 4, 8):
+for dst_name, dst, gpu in (("pageable", pageable, "0"), ("pinned", pinned.array, "0"), ("pinned_gpu_entropy", pinned.array, "1"), ("pageable_gpu_entropy", pageable, "1")):
+    os.environ["FFHIP_JPEG_GPU_ENTROPY"] = gpu
+    for th in ((1, 8, 16) if gpu == "0" else (4, 16)):
+        for chunk in ((4, 8) if gpu == "0" else (16, 32, 64)):
             best = 1e9
             for _ in range(2):
                 t0 = time.perf_counter(); g, px = ops.jpeg_decode_files(files, n_threads=th, chunk=chunk, out=dst); best = min(best, time.perf_counter() - t0)
             out[f"{dst_name}_threads_{th}_chunk_{chunk}"] = {"ms": round(best * 1e3, 1), "Gpx/s": round(n * g.width * g.height / best / 1e9, 2), "files/s": round(n / best, 1)}
 assert np.array_equal(pageable, pinned.array)
+os.environ["FFHIP_JPEG_GPU_ENTROPY"] = "0"
 # the unpipelined two-step path for comparison
 best = 1e9
 for _ in range(2):

@@ -49,12 +49,27 @@ __device__ static const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 1
 __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
 {
     __shared__ uint8_t zz[64];
+    /* the 9-bit tables of the wave's FIRST picture in LDS (a wave's 64 intervals belong to one picture, rarely two):
+     * [0..2] DC look-ups, [3..5] AC look-ups, per component.  (The host decoder's one-look-up run/value path for
+     * small AC coefficients was tried here and lost: lanes that take it and lanes that do not serialise.) */
+    __shared__ uint16_t lt[6][1 << LOOK];
     zz[threadIdx.x] = kZigzag[threadIdx.x];
+    const uint32_t gid0 = blockIdx.x * 64;
+    const uint32_t img0 = a.work[gid0].x; /* gid0 < n_work: the grid is not larger than the work list */
+    {
+        const HuffImage im0 = a.images[img0];
+        for (int t = 0; t < 3; t++)
+            for (int i = threadIdx.x; i < (1 << LOOK); i += 64) {
+                lt[t][i] = a.tabs[im0.tab_dc[t]].look[i];
+                lt[3 + t][i] = a.tabs[im0.tab_ac[t]].look[i];
+            }
+    }
     __syncthreads();
-    const uint32_t gid = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t gid = gid0 + threadIdx.x;
     if (gid >= a.n_work) return;
     const u32x2 w = a.work[gid];
     const HuffImage im = a.images[w.x];
+    const bool in_lds = w.x == img0;
     const uint8_t *base = a.scan + im.scan_off;
     uint32_t p = a.seg[im.seg_base + w.y];
     const uint32_t end = w.y + 1 < im.n_seg ? a.seg[im.seg_base + w.y + 1] - 2 : im.scan_len; /* stop in front of the RSTn */
@@ -103,11 +118,11 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
         }
         const uint32_t cc = c;
         const struct huff *T = k == 0 ? (cc == 0 ? tdc[0] : (cc == 1 ? tdc[1] : tdc[2])) : (cc == 0 ? tac[0] : (cc == 1 ? tac[1] : tac[2]));
+        const unsigned peek = (unsigned)(acc >> (n - LOOK)) & ((1u << LOOK) - 1);
         /* one Huffman symbol (coding/huffman.c:92-222): 9-bit look-up, then the canonical-code walk */
         int sym;
         {
-            const unsigned peek = (unsigned)(acc >> (n - LOOK)) & ((1u << LOOK) - 1);
-            const unsigned e = T->look[peek];
+            const unsigned e = in_lds ? lt[(k == 0 ? 0 : 3) + cc][peek] : T->look[peek];
             if (e) { n -= (int)(e >> 8); sym = (int)(e & 0xff); }
             else {
                 int code = (int)peek, len = LOOK;

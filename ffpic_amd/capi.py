@@ -22,7 +22,7 @@ EXPORTS = [
     "ffhip_vp8_residual_batch", "ffhip_hevc_residual_batch", "ffhip_vp8_predict_recon",
     "ffhip_hevc_intra_recon", "ffhip_hevc_intra_plan", "ffhip_vp8_loopfilter",
     "ffhip_jpeg_probe", "ffhip_jpeg_entropy_decode", "ffhip_jpeg_entropy_decode_mt", "ffhip_jpeg_entropy_batch", "ffhip_bmp_write",
-    "ffhip_heif_grid_parse", "ffhip_heif_grid_compose", "ffhip_jpeg_decode_files", "ffhip_jpeg_entropy_batch_gpu", "ffhip_host_malloc", "ffhip_host_free",
+    "ffhip_heif_grid_parse", "ffhip_heif_grid_compose", "ffhip_jpeg_decode_files", "ffhip_jpeg_decode_files_device", "ffhip_jpeg_entropy_batch_gpu", "ffhip_host_malloc", "ffhip_host_free",
 ]
 
 
@@ -160,6 +160,7 @@ def lib():
     L.ffhip_host_free.argtypes = [vp]
     L.ffhip_host_free.restype = None
     L.ffhip_jpeg_entropy_batch_gpu.argtypes = [vp, vp, ci, ci, C.POINTER(JpegGeom), vp, vp, vp, vp, vp, vp]
+    L.ffhip_jpeg_decode_files_device.argtypes = [vp, vp, ci, ci, C.POINTER(JpegGeom), vp, i64, i64, vp, vp]
     L.ffhip_jpeg_decode_files.argtypes = [vp, vp, ci, ci, ci, C.POINTER(JpegGeom), vp, i64, i64, vp]
     L.ffhip_heif_grid_parse.argtypes = [vp, sz, C.POINTER(HeifGrid)]
     L.ffhip_heif_grid_compose.argtypes = [vp, i64, ci, ci, vp, i64, i64, ci, ci, ci, ci, vp]

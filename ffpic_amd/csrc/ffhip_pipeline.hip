@@ -199,3 +199,51 @@ extern "C" int ffhip_jpeg_decode_files(const uint8_t *const *files, const size_t
     }
     return rc ? rc : result;
 }
+
+/* Files in, pixels out ON THE DEVICE: for consumers that live on the GPU (a resize, an inference pre-processing
+ * stage) nothing but the compressed bytes crosses PCIe.  Coefficient planes are library scratch (kept per stream). */
+#define SCRATCH_FILES_DEV 5
+extern "C" int ffhip_jpeg_decode_files_device(const uint8_t *const *files, const size_t *lens, int n, int n_threads,
+                                              ffhip_jpeg_geom *geom_out, uint8_t *d_bgra, int64_t pitch, int64_t image_stride,
+                                              int *status, void *stream)
+{
+    if (n < 0 || (n > 0 && (!files || !lens || !d_bgra || !status))) return FFHIP_EINVAL;
+    if (n == 0) return FFHIP_OK;
+    ffhip_jpeg_geom g;
+    int w = 0, h = 0;
+    int rc = ffhip_jpeg_probe(files[0], lens[0], &g, &w, &h);
+    if (rc) return rc;
+    if (geom_out) *geom_out = g;
+    if (ffhip_jpeg_workspace_bytes(&g, 1) != 0) return FFHIP_EINVAL;
+    if (!ffhip_have_device()) return FFHIP_ENODEV;
+    const size_t mcus = (size_t)g.mcu_cols * g.mcu_rows;
+    const size_t yb = mcus * g.h * g.v * 64, cb = g.ncomp == 3 ? mcus * 64 : 0; /* int16 elements per picture */
+    const size_t words = ((size_t)n * (yb + 2 * cb) * 2 + (size_t)n * 512 + 64) / 4 + 16;
+    uint8_t *base = (uint8_t *)ffhip_scratch(SCRATCH_FILES_DEV, stream, words);
+    if (!base) return FFHIP_ENOMEM;
+    int16_t *dy = (int16_t *)base, *du = cb ? dy + (size_t)n * yb : nullptr, *dv = cb ? du + (size_t)n * cb : nullptr;
+    uint16_t *dq = (uint16_t *)(base + (((size_t)n * (yb + 2 * cb) * 2 + 15) & ~(size_t)15));
+    hipStream_t st = (hipStream_t)stream;
+    const char *ge = getenv("FFHIP_JPEG_GPU_ENTROPY");
+    bool on_device = false;
+    if (!(ge && ge[0] == '0') && ffhip_jpeg_probe_restart(files[0], lens[0]) > 0) {
+        rc = ffhip_jpeg_entropy_batch_gpu(files, lens, n, n_threads, &g, dy, du, dv, dq, status, stream);
+        on_device = rc == FFHIP_OK;
+        if (!on_device && rc != FFHIP_EINVAL) return rc;
+    }
+    int result = FFHIP_OK;
+    if (!on_device) { /* host threads, then one upload (pageable staging: this path is the fallback) */
+        std::vector<int16_t> hy((size_t)n * yb), hu((size_t)n * cb), hv((size_t)n * cb);
+        std::vector<uint16_t> hq((size_t)n * 256);
+        result = ffhip_jpeg_entropy_batch(files, lens, n, n_threads, &g, hy.data(), cb ? hu.data() : nullptr, cb ? hv.data() : nullptr, hq.data(), status);
+        FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO); /* the scratch may still be read by this stream's previous batch */
+        FFHIP_CHECK(hipMemcpy(dy, hy.data(), hy.size() * 2, hipMemcpyHostToDevice), FFHIP_EIO);
+        if (cb) {
+            FFHIP_CHECK(hipMemcpy(du, hu.data(), hu.size() * 2, hipMemcpyHostToDevice), FFHIP_EIO);
+            FFHIP_CHECK(hipMemcpy(dv, hv.data(), hv.size() * 2, hipMemcpyHostToDevice), FFHIP_EIO);
+        }
+        FFHIP_CHECK(hipMemcpy(dq, hq.data(), hq.size() * 2, hipMemcpyHostToDevice), FFHIP_EIO);
+    }
+    rc = ffhip_jpeg_recon_batch(&g, n, dy, du, dv, dq, 256, d_bgra, pitch, image_stride, nullptr, 0, stream);
+    return rc ? rc : result;
+}

@@ -347,3 +347,20 @@ def jpeg_entropy_batch_gpu(files, n_threads=4):
     cu = du.to_host((n * g.c_blocks * 64,), np.int16) if du else None
     cv = dv.to_host((n * g.c_blocks * 64,), np.int16) if dv else None
     return g, cy, cu, cv, dq.to_host((n, 4, 64), np.uint16)
+
+
+def jpeg_decode_files_device(files, n_threads=8):
+    """ffhip_jpeg_decode_files_device: files -> BGRA left in device memory; returned here as a host copy for checks,
+    together with the DeviceBuffer that holds it: (geom, host array [n][H][W][4], device buffer)."""
+    L = capi.require_device()
+    g, _, _ = jpeg_probe(files[0])
+    n = len(files)
+    bufs = [np.frombuffer(f, dtype=np.uint8) for f in files]
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    lens = (C.c_size_t * n)(*[b.size for b in bufs])
+    dout = DeviceBuffer(nbytes=n * g.width * g.height * 4)
+    status = (C.c_int * n)()
+    g2 = capi.JpegGeom()
+    capi.check(L.ffhip_jpeg_decode_files_device(ptrs, lens, n, n_threads, C.byref(g2), dout.ptr, g.width * 4, g.width * 4 * g.height,
+                                                status, None), "ffhip_jpeg_decode_files_device")
+    return g2, dout.to_host((n, g.height, g.width, 4), np.uint8), dout

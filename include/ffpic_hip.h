@@ -368,6 +368,12 @@ int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const size_t *lens
  * memory (ffhip_host_malloc, or the caller's own hipHostMalloc / hipHostRegister) receives the device copy
  * directly; a pageable one goes through pinned staging and a threaded copy.  Buffers are kept between calls;
  * one call at a time. */
+/* The same with the pixels left ON THE DEVICE (d_bgra, pitch and image_stride as for ffhip_jpeg_recon_batch): for a
+ * consumer that lives on the GPU only the compressed bytes cross PCIe.  One batch, no chunking; the reconstruction
+ * is enqueued on `stream` (the entropy stage in front of it synchronises the stream when it runs on the device). */
+int ffhip_jpeg_decode_files_device(const uint8_t *const *files, const size_t *lens, int n, int n_threads,
+                                   ffhip_jpeg_geom *geom_out, uint8_t *d_bgra, int64_t pitch, int64_t image_stride,
+                                   int *status, void *stream);
 void *ffhip_host_malloc(size_t bytes); /* pinned host memory */
 void ffhip_host_free(void *p);
 int ffhip_jpeg_decode_files(const uint8_t *const *files, const size_t *lens, int n, int n_threads, int chunk,

@@ -336,3 +336,14 @@ def test_files_to_pixels_pipeline(tag, n, chunk, threads):
     pin.array[:] = 0
     ops.jpeg_decode_files(files, n_threads=threads, chunk=chunk, out=pin.array)
     assert np.array_equal(pin.array, out)
+
+
+@pytest.mark.parametrize("tag", list(FILES))
+def test_files_to_device_pixels(tag):
+    """ffhip_jpeg_decode_files_device (entropy on the device for the DRI fixture, on host threads for the others)
+    leaves in device memory what the host-destination pipeline returns"""
+    data = open(os.path.join(os.path.dirname(__file__), "golden", FILES[tag]), "rb").read()
+    files = [data] * 3
+    g, ref = ops.jpeg_decode_files(files, n_threads=2)
+    g2, out, _ = ops.jpeg_decode_files_device(files, n_threads=2)
+    assert np.array_equal(out, ref)

@@ -34,4 +34,23 @@ for rows in (1, 0):     # 0 -> restart every 16 MCUs instead
         for _ in range(3):
             t0 = time.perf_counter(); run(); best = min(best, time.perf_counter() - t0)
         out[f"{'row' if rows else '16mcu'}_intervals_n{n}"] = {"file_bytes": len(data), "ms": round(best * 1e3, 2), "Gpx/s": round(n * g.width * g.height / best / 1e9, 2), "files/s": round(n / best)}
+# files -> BGRA in DEVICE memory (entropy on the device + reconstruction), 256 x 4K
+for rows in (1, 0):
+    bio = io.BytesIO()
+    kw = dict(restart_marker_rows=1) if rows else dict(restart_marker_blocks=16)
+    Image.fromarray(img).save(bio, "JPEG", quality=85, subsampling=2, **kw)
+    data = bio.getvalue(); n = 256
+    files = [data] * n
+    bufs = [np.frombuffer(f, dtype=np.uint8) for f in files]
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs]); lens = (C.c_size_t * n)(*[b.size for b in bufs])
+    dout = ops.DeviceBuffer(nbytes=n * g.width * g.height * 4); status = (C.c_int * n)(); g2 = capi.JpegGeom()
+    def run2():
+        capi.check(L.ffhip_jpeg_decode_files_device(ptrs, lens, n, 16, C.byref(g2), dout.ptr, g.width * 4, g.width * 4 * g.height, status, None))
+        capi.check(L.ffhip_stream_sync(None))
+    run2()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter(); run2(); best = min(best, time.perf_counter() - t0)
+    out[f"files_to_device_pixels_{'row' if rows else '16mcu'}_intervals_n{n}"] = {"ms": round(best * 1e3, 2), "Gpx/s": round(n * g.width * g.height / best / 1e9, 2), "files/s": round(n / best)}
+    del dout
 print(json.dumps(out, indent=1))

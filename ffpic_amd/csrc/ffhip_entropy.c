@@ -120,7 +120,7 @@ static inline int huff_decode(struct bits *b, const struct huff *h)
     }
     if (len > 16) return -1;
     b->n -= len;
-    return h->vals[h->valptr[len] + code - h->mincode[len]];
+    return h->vals[(h->valptr[len] + code - h->mincode[len]) & 255]; /* & 255: a malformed DHT must not index outside the table */
 }
 static inline int extend(int v, int t) { return (t && v < (1 << (t - 1))) ? v - (1 << t) + 1 : v; }
 

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
                 }
                 if (len > 16) { bad = true; break; }
                 n -= len;
-                sym = T->vals[T->valptr[len] + code - T->mincode[len]];
+                sym = T->vals[(T->valptr[len] + code - T->mincode[len]) & 255]; /* & 255: a malformed DHT must not index outside the table */
             }
         }
         const bool dc = k == 0;

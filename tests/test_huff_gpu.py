@@ -73,3 +73,29 @@ def test_corrupt_interval_is_reported_not_crashed():
         ops.jpeg_entropy_batch_gpu([bytes(data)])
     except capi.FfhipError:
         pass                                               # flagged: fine; decoding garbage without a flag is fine too
+
+
+def test_random_corruption_never_faults():
+    """seeded byte corruptions inside the entropy-coded data (markers left alone): every call returns, with or
+    without an error; the device decoder's reads and writes are all bounded by the lane's interval and block"""
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(11)
+    img = np.clip(rng.normal(128, 60, (96, 128, 3)), 0, 255).astype(np.uint8)
+    bio = io.BytesIO()
+    PIL.fromarray(img).save(bio, "JPEG", quality=90, subsampling=2, restart_marker_blocks=3)
+    good = bio.getvalue()
+    sos = good.find(b"\xff\xda")
+    start = sos + 2 + ((good[sos + 2] << 8) | good[sos + 3])
+    files = []
+    for _ in range(24):
+        d = bytearray(good)
+        for _ in range(int(rng.integers(1, 12))):
+            k = int(rng.integers(start, len(d) - 2))
+            if d[k] != 0xFF and d[k - 1] != 0xFF:
+                d[k] = int(rng.integers(0, 255))       # never creates or destroys a 0xFF
+        files.append(bytes(d))
+    try:
+        ops.jpeg_entropy_batch_gpu(files)
+    except capi.FfhipError:
+        pass
+    same_planes([good])                                 # and the device is still fine afterwards

@@ -22,7 +22,7 @@ EXPORTS = [
     "ffhip_vp8_residual_batch", "ffhip_hevc_residual_batch", "ffhip_vp8_predict_recon",
     "ffhip_hevc_intra_recon", "ffhip_hevc_intra_plan", "ffhip_vp8_loopfilter",
     "ffhip_jpeg_probe", "ffhip_jpeg_entropy_decode", "ffhip_jpeg_entropy_decode_mt", "ffhip_jpeg_entropy_batch", "ffhip_bmp_write",
-    "ffhip_heif_grid_parse", "ffhip_heif_grid_compose", "ffhip_jpeg_decode_files", "ffhip_jpeg_decode_files_device", "ffhip_jpeg_entropy_batch_gpu", "ffhip_host_malloc", "ffhip_host_free",
+    "ffhip_heif_grid_parse", "ffhip_heif_grid_compose", "ffhip_hevc_picture_layout", "ffhip_jpeg_decode_files", "ffhip_jpeg_decode_files_device", "ffhip_jpeg_entropy_batch_gpu", "ffhip_host_malloc", "ffhip_host_free",
 ]
 
 
@@ -37,6 +37,12 @@ class HeifGrid(C.Structure):
     """ffhip_heif_grid"""
     _fields_ = [("version", C.c_uint8), ("flags", C.c_uint8), ("rows", C.c_uint16), ("cols", C.c_uint16),
                 ("output_width", C.c_uint32), ("output_height", C.c_uint32)]
+
+
+class HevcLayout(C.Structure):
+    """ffhip_hevc_layout"""
+    _fields_ = [("height", C.c_int32), ("y_stride", C.c_int32), ("uv_stride", C.c_int32), ("size", C.c_int64), ("u_offset", C.c_int64),
+                ("v_offset", C.c_int64), ("pitch", C.c_int32), ("ctbrows", C.c_int32), ("ctbcols", C.c_int32)]
 
 
 class JpegGeom(C.Structure):
@@ -162,6 +168,7 @@ def lib():
     L.ffhip_jpeg_entropy_batch_gpu.argtypes = [vp, vp, ci, ci, C.POINTER(JpegGeom), vp, vp, vp, vp, vp, vp]
     L.ffhip_jpeg_decode_files_device.argtypes = [vp, vp, ci, ci, C.POINTER(JpegGeom), vp, i64, i64, vp, vp]
     L.ffhip_jpeg_decode_files.argtypes = [vp, vp, ci, ci, ci, C.POINTER(JpegGeom), vp, i64, i64, vp]
+    L.ffhip_hevc_picture_layout.argtypes = [ci, ci, ci, C.POINTER(HevcLayout)]
     L.ffhip_heif_grid_parse.argtypes = [vp, sz, C.POINTER(HeifGrid)]
     L.ffhip_heif_grid_compose.argtypes = [vp, i64, ci, ci, vp, i64, i64, ci, ci, ci, ci, vp]
     L.ffhip_hevc_intra_plan.argtypes = [vp, C.c_longlong, ci, ci, ci, ci, ci, vp, vp, vp]

@@ -31,6 +31,22 @@ extern "C" int ffhip_heif_grid_parse(const uint8_t *item, size_t length, ffhip_h
     return out->output_width && out->output_height ? 0 : FFHIP_EINVAL;
 }
 
+extern "C" int ffhip_hevc_picture_layout(int pic_width, int pic_height, int ctb_log2, ffhip_hevc_layout *out)
+{
+    if (!out || pic_width <= 0 || pic_height <= 0 || ctb_log2 < 4 || ctb_log2 > 6) return FFHIP_EINVAL;
+    const int ctb = 1 << ctb_log2;
+    out->height = ((pic_height + 3) >> 2) << 2;      /* hevc.c:7224 */
+    out->y_stride = ((pic_width + 3) >> 2) << 2;     /* hevc.c:7225 */
+    out->uv_stride = out->y_stride >> 1;             /* hevc.c:7226 */
+    out->size = (int64_t)out->height * out->y_stride; /* hevc.c:7228 */
+    out->u_offset = out->size;                       /* hevc.c:7260 */
+    out->v_offset = out->size * 3 / 2;
+    out->pitch = ((out->y_stride * 32 + 32 - 1) >> 5) << 2; /* hevc.c:7259 */
+    out->ctbrows = (out->height + ctb - 1) / ctb;    /* divceil, hevc.c:7260-7261 */
+    out->ctbcols = (pic_width + ctb - 1) / ctb;
+    return FFHIP_OK;
+}
+
 struct GridArgs {
     uint8_t *canvas;
     const uint8_t *tiles;

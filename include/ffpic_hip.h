@@ -191,6 +191,20 @@ int ffhip_yuv400_to_bgra_16(uint8_t *d_bgra, int pitch, const int16_t *d_y, int 
  * list at d_tiles + j*tile_stride, tile_pitch bytes per row, all tile_w x tile_h) on the canvas
  * at (j % cols * tile_w, j / cols * tile_h), cropped to out_w x out_h.  NEW behaviour: the
  * reference decodes every tile into the same buffer (heif.c:305) and never places them. */
+/* The picture buffer the reference's HEVC decoder allocates per slice and hands to the colour converter
+ * (coding/hevc.c:7223-7236, 7258-7277): one int16 buffer of 2*size samples, Y at 0, Cb at `u_offset`, Cr at
+ * `v_offset`; what ffhip_hevc_intra_recon / ffhip_yuv420_to_bgra_16 take as their plane pointers, strides and
+ * ctb counts.  Host only. */
+typedef struct ffhip_hevc_layout {
+    int32_t height;              /* pic_height_in_luma_samples rounded up to 4                      */
+    int32_t y_stride, uv_stride; /* width rounded up to 4; half of it                               */
+    int64_t size;                /* height * y_stride: samples of the luma plane                    */
+    int64_t u_offset, v_offset;  /* size and size * 3 / 2 (samples)                                 */
+    int32_t pitch;               /* BGRA row bytes: ((y_stride * 32 + 31) >> 5) << 2                */
+    int32_t ctbrows, ctbcols;    /* divceil(height, ctb), divceil(width, ctb)                       */
+} ffhip_hevc_layout;
+int ffhip_hevc_picture_layout(int pic_width, int pic_height, int ctb_log2, ffhip_hevc_layout *out);
+
 typedef struct ffhip_heif_grid {
     uint8_t version, flags;
     uint16_t rows, cols;

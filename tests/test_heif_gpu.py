@@ -49,3 +49,20 @@ def test_grid_compose_rejects_bad_geometry():
                  (d.ptr, 100, 64, 64, d.ptr, 128, 128 * 32, 32, 32, 2, 2),
                  (d.ptr + 2, 256, 64, 64, d.ptr, 128, 128 * 32, 32, 32, 2, 2)):
         assert L.ffhip_heif_grid_compose(*args, None) == capi.FFHIP_EINVAL
+
+
+def test_hevc_picture_layout():
+    """the buffer arithmetic of parse_slice_segment_layer (coding/hevc.c:7223-7236, 7258-7277)"""
+    import ctypes as C
+    L = capi.lib()
+    lay = capi.HevcLayout()
+    for (w, h, lg) in ((1920, 1080, 6), (7680, 4320, 6), (1918, 1081, 4), (33, 17, 5)):
+        assert L.ffhip_hevc_picture_layout(w, h, lg, C.byref(lay)) == 0
+        height = ((h + 3) >> 2) << 2
+        ys = ((w + 3) >> 2) << 2
+        assert (lay.height, lay.y_stride, lay.uv_stride) == (height, ys, ys >> 1)
+        assert (lay.size, lay.u_offset, lay.v_offset) == (height * ys, height * ys, height * ys * 3 // 2)
+        assert lay.pitch == ((ys * 32 + 31) >> 5) << 2
+        assert (lay.ctbrows, lay.ctbcols) == (-(-height // (1 << lg)), -(-w // (1 << lg)))
+    assert L.ffhip_hevc_picture_layout(0, 10, 6, C.byref(lay)) == capi.FFHIP_EINVAL
+    assert L.ffhip_hevc_picture_layout(64, 64, 7, C.byref(lay)) == capi.FFHIP_EINVAL

@@ -93,3 +93,45 @@ def test_grouped_form_small_ctb_falls_back_to_smaller_window():
     exp = O.oracle_hevc_intra(tus, res, 256, 128, True, 8, 8)
     for gp, e, name in zip(got, exp, "YUV"):
         assert np.array_equal(gp, e), name
+
+
+@pytest.mark.parametrize("w,h,seed,bd", [(192, 128, 61, 8), (128, 192, 62, 10)])
+def test_heic_chain_levels_to_bgra(w, h, seed, bd):
+    """BASELINE config 5 in small: quantised levels -> ffhip_hevc_residual_batch per TU size -> ffhip_hevc_intra_recon
+    -> ffhip_yuv420_to_bgra_16, against the same chain through the oracle (scale_and_transform, decode_intra_block,
+    YUV420_to_BGRA32_16bit of the reference restated)"""
+    from test_hevc_gpu import oracle_tus
+    from test_color_gpu import oracle_420_16
+    rng = np.random.default_rng(seed)
+    tus, _ = synth.hevc_intra_tus(w, h, seed, adversarial_masks=False)
+    tus = tus.copy()
+    tus["flags"] &= ~np.uint8(synth.TU_RDPCM)                       # rdpcm needs transform-skip TUs: keep the chain plain
+    res_gpu = np.zeros(int(sum(1 << (2 * int(t["log2_size"])) for t in tus)) + 16, np.int16)
+    res_ora = np.zeros_like(res_gpu)
+    off = 0
+    order = {}
+    for i, t in enumerate(tus):
+        n = 1 << int(t["log2_size"])
+        tus["res_offset"][i] = off
+        order.setdefault(n, []).append((i, off))
+        off += n * n
+    for n, items in order.items():                                  # one residual batch per TU size, as a decoder would issue them
+        lv = np.rint(rng.laplace(0, 6, size=(len(items), n * n))).astype(np.int16)
+        info = np.zeros((len(items), 4), np.uint8)
+        info[:, 0] = rng.integers(20, 38, size=len(items))          # qP
+        for k, (i, _) in enumerate(items):
+            if n == 4 and int(tus["cidx"][i]) == 0:
+                info[k, 1] = 1                                      # luma intra 4x4: DST-VII (hevc.c:3911-3920)
+        g = ops.hevc_residual_batch(n, lv, info, bitdepth=bd)
+        o = oracle_tus(n, lv, info, bd, 0, None)
+        for k, (_, o0) in enumerate(items):
+            res_gpu[o0:o0 + n * n] = g[k]
+            res_ora[o0:o0 + n * n] = o[k]
+    assert np.array_equal(res_gpu, res_ora)
+    got = ops.hevc_intra_recon(tus, res_gpu, w, h, True, bd, bd)
+    exp = O.oracle_hevc_intra(tus, res_ora, w, h, True, bd, bd)
+    for gp, e, name in zip(got, exp, "YUV"):
+        assert np.array_equal(gp, e), name
+    ctb = 64
+    bgra = ops.yuv420_to_bgra_16(got[0][None], got[1][None], got[2][None], h // ctb, w // ctb, ctb)[0]
+    assert np.array_equal(bgra, oracle_420_16(exp[0], exp[1], exp[2], h // ctb, w // ctb, ctb))

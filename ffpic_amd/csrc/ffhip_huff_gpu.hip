@@ -5,7 +5,7 @@
  * What the host still does per file: the marker loop and table building of ffhip_entropy.c
  * (format/jpg.c:78-105, 640-655, 771-855) and a scan for the RSTn markers.  What moves to the device:
  * read_compressed_scan / decode_data_unit (format/jpg.c:255-415, 562-573, 588-637) -- ONE LANE per
- * restart interval walks its bytes (FF00 unstuffing, 64-bit bit buffer), decodes symbol after symbol with
+ * restart interval walks its bytes (unstuffed by the host while it stages them; 64-bit bit buffer), decodes symbol after symbol with
  * the same 9-bit look-up tables the host decoder uses (struct huff, uploaded as is) and scatters the
  * coefficients, de-zigzagged, into the MCU-order planes ffhip_jpeg_recon_batch reads.  The decode loop is
  * a flat one-symbol-per-iteration state machine so that lanes in different blocks, components or MCUs
@@ -33,6 +33,7 @@ struct HuffImage {
 struct HuffArgs {
     const uint8_t *scan;
     const struct huff *tabs;
+    const uint16_t *lut; /* per table of `tabs`: LUT_WORDS entries, see build_lut */
     const HuffImage *images;
     const uint32_t *seg;
     const u32x2 *work; /* (picture, interval) per lane */
@@ -46,36 +47,59 @@ __device__ static const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 1
                                                35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
                                                58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
+/* The byte streams the kernel reads are UNSTUFFED (the host removes the 00 behind every FF while it stages the
+ * bytes) and every restart interval starts 4-byte aligned and is followed by zero padding -- what the reference's
+ * reader feeds itself at a marker.  Why the shape below: lanes of a wave advance independently, so any
+ * memory wait inside a data-dependent branch is paid by the whole wave on almost every iteration (with 64 lanes
+ * SOME lane always needs bytes, SOME lane always ends a block).  Hence
+ *  - bytes come from a 256-byte ring per lane in LDS ([dword][lane]: conflict-free), topped up for all lanes at
+ *    once every 16 symbols by aligned 16-byte global loads -- one memory wait per 16 iterations per wave;
+ *  - the next dword of the ring is read at the top of every iteration, needed or not, and spliced into the
+ *    64-bit bit buffer at the bottom: the LDS latency hides behind the symbol decode;
+ *  - what changes per block only (block base, component tables, predictor) is state, not recomputed per symbol. */
+#define LUT_GROUPS 8
+#define LUT_WORDS (512 + 128 * LUT_GROUPS) /* 1536 uint16 = 3 KB per table */
+#define RING_DW 64
+#define REFILL_EVERY 16
+
 __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
 {
     __shared__ uint8_t zz[64];
-    /* the 9-bit tables of the wave's FIRST picture in LDS (a wave's 64 intervals belong to one picture, rarely two):
-     * [0..2] DC look-ups, [3..5] AC look-ups, per component.  (The host decoder's one-look-up run/value path for
-     * small AC coefficients was tried here and lost: lanes that take it and lanes that do not serialise.) */
-    __shared__ uint16_t lt[6][1 << LOOK];
-    zz[threadIdx.x] = kZigzag[threadIdx.x];
+    /* two-level look-up tables of the wave's FIRST picture in LDS (a wave's 64 intervals belong to one picture, rarely
+     * two): [0..2] DC, [3..5] AC, per component.  Two levels, not the host's 9-bit table plus canonical-code walk: a
+     * code that misses sends its lane into a loop of loads from global memory, and with 64 lanes per wave the 2-5 %
+     * of symbols with long codes (JPEG's 16-bit codes mostly) mean the whole wave walks on nearly every symbol.
+     * (A 12-bit single level does not help -- the misses ARE the 15/16-bit codes -- and costs 48 KB of LDS; the host
+     * decoder's one-look-up run/value path for small AC coefficients lost for the same serialisation reason.) */
+    __shared__ uint16_t lt[6][LUT_WORDS];
+    __shared__ uint32_t ring[RING_DW][64];
+    const uint32_t lane = threadIdx.x;
+    zz[lane] = kZigzag[lane];
     const uint32_t gid0 = blockIdx.x * 64;
     const uint32_t img0 = a.work[gid0].x; /* gid0 < n_work: the grid is not larger than the work list */
     {
         const HuffImage im0 = a.images[img0];
-        for (int t = 0; t < 3; t++)
-            for (int i = threadIdx.x; i < (1 << LOOK); i += 64) {
-                lt[t][i] = a.tabs[im0.tab_dc[t]].look[i];
-                lt[3 + t][i] = a.tabs[im0.tab_ac[t]].look[i];
+        for (int t = 0; t < 3; t++) {
+            const u32x4 *sd = (const u32x4 *)(a.lut + (size_t)im0.tab_dc[t] * LUT_WORDS), *sa = (const u32x4 *)(a.lut + (size_t)im0.tab_ac[t] * LUT_WORDS);
+            for (int i = lane; i < LUT_WORDS / 8; i += 64) {
+                ((u32x4 *)lt[t])[i] = sd[i];
+                ((u32x4 *)lt[3 + t])[i] = sa[i];
             }
+        }
     }
     __syncthreads();
-    const uint32_t gid = gid0 + threadIdx.x;
-    if (gid >= a.n_work) return;
-    const u32x2 w = a.work[gid];
+    const uint32_t gid = gid0 + lane;
+    const bool exists = gid < a.n_work;
+    const u32x2 w = a.work[exists ? gid : gid0];
     const HuffImage im = a.images[w.x];
     const bool in_lds = w.x == img0;
-    const uint8_t *base = a.scan + im.scan_off;
-    uint32_t p = a.seg[im.seg_base + w.y];
-    const uint32_t end = w.y + 1 < im.n_seg ? a.seg[im.seg_base + w.y + 1] - 2 : im.scan_len; /* stop in front of the RSTn */
+    /* this lane's byte stream: 16-byte aligned chunks from `src`; reads past the interval see its zero padding,
+     * then (malformed streams only) whatever follows inside the staged buffer, which is padded at its end */
+    const uint32_t start = im.scan_off + a.seg[im.seg_base + w.y]; /* 4-byte aligned */
+    const u32x4 *src = (const u32x4 *)(a.scan + (start & ~15u));
+    uint32_t rd = (start & 15u) >> 2, wr = 0; /* dword cursors into the stream counted from src */
     uint32_t mcu = w.y * im.restart;
     const uint32_t mcu_end = mcu + im.restart < im.mcus ? mcu + im.restart : im.mcus;
-    /* per component: plane pointer of this picture, tables */
     int16_t *pl[3];
     const struct huff *tdc[3], *tac[3];
 #pragma unroll
@@ -84,88 +108,103 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
         tdc[c] = a.tabs + im.tab_dc[c];
         tac[c] = a.tabs + im.tab_ac[c];
     }
-    unsigned long long acc = 0;
+    /* element offset of the next block of each component inside this picture's planes: blocks of one component
+     * are consecutive across MCUs, so a block end is "+ 64" */
+    uint32_t boff[3] = {mcu * im.nb[0] * 64, mcu * im.nb[1] * 64, mcu * im.nb[2] * 64};
+    unsigned long long acc = 0; /* LEFT-aligned: next unread bit is bit 63 */
     int n = 0;
-    bool marker = false, bad = false;
+    bool active = exists && mcu < mcu_end, bad = false;
     int pred[3] = {0, 0, 0};
-    uint32_t c = 0, kb = 0, k = 0;
-    while (mcu < mcu_end) {
-        if (n < 32) { /* refill to more than 56 bits: 8 plain bytes at once, or byte by byte around 0xFF */
-            if (!marker && p + 8 <= end) {
-                const unsigned long long lo = *(const unsigned int *)(base + p), hi = *(const unsigned int *)(base + p + 4); /* unaligned global loads */
-                const unsigned long long le = lo | (hi << 32);
-                const unsigned long long be = ((unsigned long long)__builtin_bswap32((unsigned)le) << 32) | __builtin_bswap32((unsigned)(le >> 32));
-                const unsigned long long x = ~be;
-                if (!((x - 0x0101010101010101ULL) & ~x & 0x8080808080808080ULL)) {
-                    const int nb = (64 - n) >> 3;
-                    acc = nb == 8 ? be : (acc << (8 * nb)) | (be >> (64 - 8 * nb));
-                    p += nb;
-                    n += 8 * nb;
-                }
-            }
-            while (n <= 56) {
-                unsigned cbyte = 0;
-                if (!marker && p < end) {
-                    cbyte = base[p];
-                    if (cbyte == 0xFF) {
-                        if (p + 1 < end && base[p + 1] == 0) p += 2; /* stuffed zero (jpg.c:588-637) */
-                        else { marker = true; cbyte = 0; }
-                    } else p++;
-                }
-                acc = (acc << 8) | cbyte;
-                n += 8;
+    uint32_t c = 0, kb = 0, k = 0, nbc = im.nb[0], row_dc = 0, row_ac = 3;
+    int16_t *blk = pl[0] + boff[0];
+    const struct huff *Tdc = tdc[0], *Tac = tac[0];
+    int pred_cur = 0;
+    auto refill = [&]() { /* all lanes: fetch 16-byte chunks while the ring has room for one */
+        while (__builtin_amdgcn_ballot_w64(wr + 4 <= rd + RING_DW)) {
+            if (wr + 4 <= rd + RING_DW) {
+                const u32x4 v = src[wr >> 2];
+#pragma unroll
+                for (int j = 0; j < 4; j++) ring[(wr + j) & (RING_DW - 1)][lane] = v[j];
+                wr += 4;
             }
         }
-        const uint32_t cc = c;
-        const struct huff *T = k == 0 ? (cc == 0 ? tdc[0] : (cc == 1 ? tdc[1] : tdc[2])) : (cc == 0 ? tac[0] : (cc == 1 ? tac[1] : tac[2]));
-        const unsigned peek = (unsigned)(acc >> (n - LOOK)) & ((1u << LOOK) - 1);
-        /* one Huffman symbol (coding/huffman.c:92-222): 9-bit look-up, then the canonical-code walk */
-        int sym;
-        {
-            const unsigned e = in_lds ? lt[(k == 0 ? 0 : 3) + cc][peek] : T->look[peek];
-            if (e) { n -= (int)(e >> 8); sym = (int)(e & 0xff); }
-            else {
-                int code = (int)peek, len = LOOK;
+    };
+    refill();
+    for (int i = 0; i < 2; i++) { /* 64 bits to start with */
+        const uint32_t d = ring[rd & (RING_DW - 1)][lane];
+        acc = (acc << 32) | __builtin_bswap32(d);
+        rd++;
+    }
+    n = 64;
+    for (uint32_t iter = 1; __builtin_amdgcn_ballot_w64(active); iter++) {
+        if ((iter & (REFILL_EVERY - 1)) == 0) refill(); /* at most 16 x 31 bits = 16 dwords used since the last one */
+        const uint32_t nextdw = ring[rd & (RING_DW - 1)][lane]; /* wanted at the bottom, if at all */
+        if (active) {
+            const bool dc = k == 0;
+            /* one Huffman symbol (coding/huffman.c:92-222): 9-bit look-up, then the canonical-code walk */
+            const unsigned top = (unsigned)(acc >> 32);
+            const unsigned peek = top >> (32 - LOOK);
+            const struct huff *T = dc ? Tdc : Tac;
+            const uint16_t *lut = in_lds ? lt[dc ? row_dc : row_ac] : a.lut + (size_t)(T - a.tabs) * LUT_WORDS; /* LDS or global */
+            unsigned e = lut[peek];
+            if (e & 0x8000u) e = lut[512 + ((e & 0xffu) << 7) + ((top >> (32 - 16)) & 127u)]; /* long code: its group, next 7 bits */
+            int sym = (int)(e & 0xff), len = (int)(e >> 8);
+            if (!e) { /* a table with more long-code groups than the LUT holds, or a code that does not exist */
+                int code = (int)peek;
+                len = LOOK;
                 while (len < 17 && code > T->maxcode[len]) {
                     len++;
-                    code = (int)((acc >> (n - len)) & ((1u << len) - 1));
+                    code = (int)(top >> (32 - len));
                 }
-                if (len > 16) { bad = true; break; }
-                n -= len;
+                if (len > 16) { bad = true; len = 16; }
                 sym = T->vals[(T->valptr[len] + code - T->mincode[len]) & 255]; /* & 255: a malformed DHT must not index outside the table */
             }
-        }
-        const bool dc = k == 0;
-        const int s = dc ? sym : (sym & 15), r = dc ? 0 : (sym >> 4);
-        if (dc && s > 11) { bad = true; break; }
-        if (!dc && s == 0) {
-            k = r == 15 ? k + 16 : 64; /* ZRL / EOB */
-        } else {
-            k += (uint32_t)r;
-            if (k > 63) { bad = true; break; }
-            int v = 0;
-            if (s) {
-                v = (int)((acc >> (n - s)) & ((1u << s) - 1));
-                n -= s;
-                if (v < (1 << (s - 1))) v -= (1 << s) - 1; /* EXTEND, T.81 F.2.2.1 */
+            acc <<= len;
+            n -= len;
+            const int s = dc ? sym : (sym & 15), r = dc ? 0 : (sym >> 4);
+            if (dc && s > 11) bad = true;
+            if (!dc && s == 0) {
+                k = r == 15 ? k + 16 : 64; /* ZRL / EOB */
+            } else {
+                k += (uint32_t)r;
+                if (k > 63) { bad = true; k = 63; }
+                int v = 0;
+                if (s) {
+                    v = (int)((unsigned)(acc >> 32) >> (32 - s));
+                    acc <<= s;
+                    n -= s;
+                    if (v < (1 << (s - 1))) v -= (1 << s) - 1; /* EXTEND, T.81 F.2.2.1 */
+                }
+                if (dc) { pred_cur += v; v = pred_cur; }
+                blk[zz[k]] = (int16_t)v;
+                k++;
             }
-            if (dc) {
-                pred[0] = cc == 0 ? pred[0] + v : pred[0];
-                pred[1] = cc == 1 ? pred[1] + v : pred[1];
-                pred[2] = cc == 2 ? pred[2] + v : pred[2];
-                v = cc == 0 ? pred[0] : (cc == 1 ? pred[1] : pred[2]);
+            if (k >= 64) { /* next block of the MCU, next component, next MCU */
+                k = 0;
+                boff[0] += c == 0 ? 64u : 0u;
+                boff[1] += c == 1 ? 64u : 0u;
+                boff[2] += c == 2 ? 64u : 0u;
+                if (++kb == nbc) {
+                    kb = 0;
+                    pred[0] = c == 0 ? pred_cur : pred[0];
+                    pred[1] = c == 1 ? pred_cur : pred[1];
+                    pred[2] = c == 2 ? pred_cur : pred[2];
+                    if (++c == im.ncomp) { c = 0; mcu++; }
+                    pred_cur = c == 0 ? pred[0] : (c == 1 ? pred[1] : pred[2]);
+                    nbc = c == 0 ? im.nb[0] : (c == 1 ? im.nb[1] : im.nb[2]);
+                    row_dc = c;
+                    row_ac = 3 + c;
+                    Tdc = c == 0 ? tdc[0] : (c == 1 ? tdc[1] : tdc[2]);
+                    Tac = c == 0 ? tac[0] : (c == 1 ? tac[1] : tac[2]);
+                }
+                blk = (c == 0 ? pl[0] : (c == 1 ? pl[1] : pl[2])) + (c == 0 ? boff[0] : (c == 1 ? boff[1] : boff[2]));
+                if (mcu >= mcu_end) active = false;
             }
-            int16_t *P = cc == 0 ? pl[0] : (cc == 1 ? pl[1] : pl[2]);
-            const uint32_t nbc = cc == 0 ? im.nb[0] : (cc == 1 ? im.nb[1] : im.nb[2]);
-            P[((size_t)mcu * nbc + kb) * 64 + zz[k]] = (int16_t)v;
-            k++;
-        }
-        if (k >= 64) { /* next block of the MCU, next component, next MCU */
-            k = 0;
-            const uint32_t nbc = cc == 0 ? im.nb[0] : (cc == 1 ? im.nb[1] : im.nb[2]);
-            if (++kb == nbc) {
-                kb = 0;
-                if (++c == im.ncomp) { c = 0; mcu++; }
+            if (bad) active = false;
+            if (n <= 32) { /* splice the dword read at the top behind the n valid bits */
+                acc |= (unsigned long long)__builtin_bswap32(nextdw) << (32 - n);
+                n += 32;
+                rd++;
             }
         }
     }
@@ -179,6 +218,50 @@ namespace {
 uint8_t *g_stage = nullptr;
 size_t g_stage_cap = 0;
 std::mutex g_huff_mu;
+
+/* entropy-coded bytes without their stuffing (FF 00 -> FF), up to `end` or the first marker; returns the clean length */
+size_t unstuff(uint8_t *dst, const uint8_t *src, const uint8_t *end)
+{
+    uint8_t *d = dst;
+    while (src < end) {
+        const uint8_t *q = (const uint8_t *)memchr(src, 0xFF, (size_t)(end - src));
+        if (!q) { memcpy(d, src, (size_t)(end - src)); d += end - src; break; }
+        memcpy(d, src, (size_t)(q - src));
+        d += q - src;
+        if (q + 1 < end && q[1] == 0) { *d++ = 0xFF; src = q + 2; }
+        else break; /* a marker: the interval ends here */
+    }
+    return (size_t)(d - dst);
+}
+
+/* Two-level table of a canonical Huffman code, LUT_WORDS uint16:
+ *   [0..511]            by the first 9 bits: (length << 8) | symbol for codes of up to 9 bits (the host's look[]);
+ *                       0x8000 | g for a prefix shared by longer codes; 0 = neither
+ *   [512 + 128 g + b]   group g by the NEXT 7 bits: (length << 8) | symbol, lengths 10..16; 0 = no such code
+ * Up to LUT_GROUPS prefixes get a group (the standard tables need 5-7); codes of further prefixes stay 0 in level one
+ * and take the kernel's canonical-code walk. */
+void build_lut(const struct huff &h, uint16_t *out)
+{
+    memset(out, 0, LUT_WORDS * sizeof(uint16_t));
+    memcpy(out, h.look, 512 * sizeof(uint16_t));
+    int groups = 0;
+    for (int len = LOOK + 1; len <= 16; len++) {
+        if (h.maxcode[len] < 0) continue;
+        for (int code = h.mincode[len]; code <= h.maxcode[len]; code++) {
+            const int idx = h.valptr[len] + code - h.mincode[len];
+            if (idx < 0 || idx > 255 || code >= (1 << len)) return; /* a malformed DHT: leave the rest to the walk */
+            const int prefix = code >> (len - LOOK);
+            if (out[prefix] && !(out[prefix] & 0x8000)) return;       /* not prefix-free: leave it to the walk */
+            if (!out[prefix]) {
+                if (groups == LUT_GROUPS) continue;
+                out[prefix] = (uint16_t)(0x8000 | groups++);
+            }
+            const int g = out[prefix] & 0xff;
+            const int rest = (code << (16 - len)) & 127, cnt = 1 << (16 - len); /* the bits behind the prefix, left-aligned in 7 */
+            for (int k = 0; k < cnt; k++) out[512 + 128 * g + rest + k] = (uint16_t)((len << 8) | h.vals[idx]);
+        }
+    }
+}
 
 template <typename F>
 void parallel_for(int n, int n_threads, F f)
@@ -246,21 +329,22 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
             im.tab_dc[c] = (uint32_t)(i * 6 + 2 * c);
             im.tab_ac[c] = (uint32_t)(i * 6 + 2 * c + 1);
         }
-        scan_total += (j.scan_len + 15) & ~(size_t)15;
+        scan_total += (j.scan_len + 8 * (size_t)im.n_seg + 32 + 15) & ~(size_t)15; /* unstuffed, every interval aligned and padded */
         seg_total += im.n_seg;
         if (scan_total > 0x7fffffffu) return FFHIP_EINVAL;
     }
     if (!ffhip_have_device()) return FFHIP_ENODEV;
-    const size_t o_tabs = scan_total + 16, o_img = (o_tabs + (size_t)n * 6 * sizeof(struct huff) + 15) & ~(size_t)15;
+    const size_t o_tabs = scan_total + 16, o_l12 = (o_tabs + (size_t)n * 6 * sizeof(struct huff) + 15) & ~(size_t)15;
+    const size_t o_img = o_l12 + (size_t)n * 6 * LUT_WORDS * 2;
     const size_t o_seg = (o_img + images.size() * sizeof(HuffImage) + 15) & ~(size_t)15, o_work = (o_seg + seg_total * 4 + 15) & ~(size_t)15;
     const size_t o_status = (o_work + seg_total * 8 + 15) & ~(size_t)15, o_quant = (o_status + (size_t)n * 4 + 15) & ~(size_t)15;
     const size_t total = o_quant + (size_t)n * 512;
     std::lock_guard<std::mutex> lock(g_huff_mu);
-    if (total > g_stage_cap) {
+    if (total + 64 > g_stage_cap) {
         if (g_stage) (void)hipHostFree(g_stage);
         g_stage = nullptr;
         g_stage_cap = 0;
-        const size_t want = total + total / 4;
+        const size_t want = total + total / 4 + 64;
         if (hipHostMalloc((void **)&g_stage, want, hipHostMallocDefault) != hipSuccess) { g_stage = nullptr; return FFHIP_ENOMEM; }
         g_stage_cap = want;
     }
@@ -268,12 +352,27 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     parallel_for(n, n_threads, [&](int i) {
         const struct jpeg_hdr &j = hdr[(size_t)i];
         const HuffImage &im = images[(size_t)i];
-        memcpy(stage + im.scan_off, j.scan, j.scan_len);
-        memset(stage + im.scan_off + j.scan_len, 0, (((j.scan_len + 15) & ~(size_t)15) - j.scan_len));
+        /* the picture's bytes, unstuffed, every restart interval 4-byte aligned and followed by >= 4 zero bytes */
+        uint8_t *dst = stage + im.scan_off;
+        size_t off = 0;
+        std::vector<uint32_t> &sgv = segs[(size_t)i];
+        for (uint32_t k = 0; k < im.n_seg; k++) {
+            const uint8_t *b = j.scan + sgv[k], *e = k + 1 < im.n_seg ? j.scan + sgv[k + 1] - 2 : j.scan + j.scan_len;
+            const size_t len = unstuff(dst + off, b, e);
+            sgv[k] = (uint32_t)off; /* from here on: offset of the interval in the CLEAN stream */
+            const size_t padded = ((len + 3) & ~(size_t)3) + 4;
+            memset(dst + off + len, 0, padded - len);
+            off += padded;
+        }
+        memset(dst + off, 0, 16);
         struct huff *tb = (struct huff *)(stage + o_tabs) + (size_t)i * 6;
+        uint16_t *l12 = (uint16_t *)(stage + o_l12) + (size_t)i * 6 * LUT_WORDS;
         for (int c = 0; c < 3; c++) {
             tb[2 * c] = j.dc[c < j.ncomp ? j.td[c] : j.td[0]];
             tb[2 * c + 1] = j.ac[c < j.ncomp ? j.ta[c] : j.ta[0]];
+        }
+        for (int t = 0; t < 6; t++) {
+            build_lut(tb[t], l12 + (size_t)t * LUT_WORDS);
         }
         uint32_t *sg = (uint32_t *)(stage + o_seg) + im.seg_base;
         u32x2 *wk = (u32x2 *)(stage + o_work) + im.seg_base;
@@ -301,6 +400,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     HuffArgs a;
     a.scan = dev;
     a.tabs = (const struct huff *)(dev + o_tabs);
+    a.lut = (const uint16_t *)(dev + o_l12);
     a.images = (const HuffImage *)(dev + o_img);
     a.seg = (const uint32_t *)(dev + o_seg);
     a.work = (const u32x2 *)(dev + o_work);

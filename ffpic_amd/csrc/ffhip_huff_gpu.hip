@@ -313,6 +313,14 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         if (status[i]) return status[i];
     /* ---- layout of the one upload: scan bytes | tables | picture records | interval starts | work list | status ---- */
     std::vector<HuffImage> images((size_t)n);
+    /* pictures of a batch mostly share their Huffman tables (an encoder's defaults): keep one copy of each distinct table */
+    std::vector<const struct huff *> uniq;
+    auto table_id = [&](const struct huff *t) -> uint32_t {
+        for (size_t u = uniq.size(); u-- > 0;) /* newest first: the previous picture's are the likely match */
+            if (uniq[u] == t || !memcmp(uniq[u], t, sizeof(struct huff))) return (uint32_t)u;
+        uniq.push_back(t);
+        return (uint32_t)(uniq.size() - 1);
+    };
     size_t scan_total = 0, seg_total = 0;
     for (int i = 0; i < n; i++) {
         const struct jpeg_hdr &j = hdr[(size_t)i];
@@ -326,16 +334,17 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         im.n_seg = (uint32_t)segs[(size_t)i].size();
         for (int c = 0; c < 3; c++) {
             im.nb[c] = c < j.ncomp ? (uint32_t)(j.h[c] * j.v[c]) : 0;
-            im.tab_dc[c] = (uint32_t)(i * 6 + 2 * c);
-            im.tab_ac[c] = (uint32_t)(i * 6 + 2 * c + 1);
+            im.tab_dc[c] = table_id(&j.dc[c < j.ncomp ? j.td[c] : j.td[0]]);
+            im.tab_ac[c] = table_id(&j.ac[c < j.ncomp ? j.ta[c] : j.ta[0]]);
         }
         scan_total += (j.scan_len + 8 * (size_t)im.n_seg + 32 + 15) & ~(size_t)15; /* unstuffed, every interval aligned and padded */
         seg_total += im.n_seg;
         if (scan_total > 0x7fffffffu) return FFHIP_EINVAL;
     }
     if (!ffhip_have_device()) return FFHIP_ENODEV;
-    const size_t o_tabs = scan_total + 16, o_l12 = (o_tabs + (size_t)n * 6 * sizeof(struct huff) + 15) & ~(size_t)15;
-    const size_t o_img = o_l12 + (size_t)n * 6 * LUT_WORDS * 2;
+    const size_t n_tabs = uniq.size();
+    const size_t o_tabs = scan_total + 16, o_l12 = (o_tabs + n_tabs * sizeof(struct huff) + 15) & ~(size_t)15;
+    const size_t o_img = o_l12 + n_tabs * LUT_WORDS * 2;
     const size_t o_seg = (o_img + images.size() * sizeof(HuffImage) + 15) & ~(size_t)15, o_work = (o_seg + seg_total * 4 + 15) & ~(size_t)15;
     const size_t o_status = (o_work + seg_total * 8 + 15) & ~(size_t)15, o_quant = (o_status + (size_t)n * 4 + 15) & ~(size_t)15;
     const size_t total = o_quant + (size_t)n * 512;
@@ -365,15 +374,6 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
             off += padded;
         }
         memset(dst + off, 0, 16);
-        struct huff *tb = (struct huff *)(stage + o_tabs) + (size_t)i * 6;
-        uint16_t *l12 = (uint16_t *)(stage + o_l12) + (size_t)i * 6 * LUT_WORDS;
-        for (int c = 0; c < 3; c++) {
-            tb[2 * c] = j.dc[c < j.ncomp ? j.td[c] : j.td[0]];
-            tb[2 * c + 1] = j.ac[c < j.ncomp ? j.ta[c] : j.ta[0]];
-        }
-        for (int t = 0; t < 6; t++) {
-            build_lut(tb[t], l12 + (size_t)t * LUT_WORDS);
-        }
         uint32_t *sg = (uint32_t *)(stage + o_seg) + im.seg_base;
         u32x2 *wk = (u32x2 *)(stage + o_work) + im.seg_base;
         for (uint32_t k = 0; k < im.n_seg; k++) {
@@ -384,6 +384,10 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         memcpy(stage + o_quant + (size_t)i * 512, j.quant, 512);
     });
     memset(stage + scan_total, 0, 16);
+    parallel_for((int)n_tabs, n_threads, [&](int u) {
+        ((struct huff *)(stage + o_tabs))[u] = *uniq[(size_t)u];
+        build_lut(*uniq[(size_t)u], (uint16_t *)(stage + o_l12) + (size_t)u * LUT_WORDS);
+    });
     memcpy(stage + o_img, images.data(), images.size() * sizeof(HuffImage));
     memset(stage + o_status, 0, (size_t)n * 4);
     hipStream_t st = (hipStream_t)stream;

@@ -1,0 +1,77 @@
+"""GPU: the in-launch hand-offs (VP8 rows, VP8 loop-filter rows, HEVC groups) under UNEVEN load -- a second stream
+keeps the memory system busy with large copies while the dependency-scheduled kernels run, and every byte is still
+the oracle's.  (MI355X_MICROARCH.md: idle chips and uniform load hide hand-off bugs.)"""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from ffpic_amd import capi, ops, synth
+
+pytestmark = pytest.mark.gpu
+
+
+class Hog:
+    """copies 256 MB back and forth on its own stream until stopped"""
+
+    def __init__(self):
+        self.L = capi.require_device()
+        self.st = self.L.ffhip_stream_create()
+        self.a = ops.DeviceBuffer(nbytes=256 << 20)
+        self.b = ops.DeviceBuffer(nbytes=256 << 20)
+        self.stop = False
+        self.count = 0
+        self.t = threading.Thread(target=self.run, daemon=True)
+
+    def run(self):
+        while not self.stop:
+            for _ in range(8):
+                capi.check(self.L.ffhip_copy_calibrate(self.b.ptr, self.a.ptr, 256 << 20, self.st))
+                capi.check(self.L.ffhip_copy_calibrate(self.a.ptr, self.b.ptr, 256 << 20, self.st))
+            capi.check(self.L.ffhip_stream_sync(self.st))
+            self.count += 16
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop = True
+        self.t.join()
+        self.L.ffhip_stream_destroy(self.st)
+
+
+def test_vp8_rows_and_loopfilter_under_load():
+    c, r, n = 120, 68, 3
+    modes = np.stack([synth.vp8_modes(c, r, seed=900 + i) for i in range(n)])
+    modes[..., 18] = np.random.default_rng(9).integers(0, 4, size=modes[..., 18].shape)
+    resid = np.stack([synth.vp8_residual(c * r, seed=900 + i, amplitude=60) for i in range(n)])
+    flt = synth.vp8_filters(seed=3)
+    exp = [O.oracle_vp8_frame(c, r, modes[i], resid[i]) for i in range(n)]
+    with Hog() as hog:
+        for _ in range(3):
+            got = ops.vp8_predict_recon(c, r, modes, resid)
+            for i in range(n):
+                for gp, e, name in zip(got, exp[i], "YUV"):
+                    assert np.array_equal(gp[i], e), (i, name)
+            lf = ops.vp8_loopfilter(c, r, 2, modes, flt, got[0], got[1], got[2])
+            for i in range(n):
+                p = [np.ascontiguousarray(x).copy() for x in exp[i]]
+                O.ffo().ffo_vp8_loopfilter_frame(c, r, 2, np.ascontiguousarray(modes[i]).reshape(-1), np.ascontiguousarray(flt).reshape(-1),
+                                                 p[0].reshape(-1), p[1].reshape(-1), p[2].reshape(-1))
+                for gp, e, name in zip(lf, p, "YUV"):
+                    assert np.array_equal(gp[i], e), ("lf", i, name)
+    assert hog.count > 0
+
+
+def test_hevc_groups_under_load():
+    w, h = 512, 384
+    tus, res = synth.hevc_intra_tus(w, h, 77, adversarial_masks=True)
+    exp = O.oracle_hevc_intra(tus, res, w, h, True, 8, 8)
+    with Hog() as hog:
+        for _ in range(4):
+            got = ops.hevc_intra_recon(tus, res, w, h, True, 8, 8)
+            for gp, e, name in zip(got, exp, "YUV"):
+                assert np.array_equal(gp, e), name
+    assert hog.count > 0

@@ -12,7 +12,7 @@ dev = torch.device("cuda", 0)
 L = capi.require_device(0)
 st = torch.cuda.current_stream().cuda_stream
 e0, e1 = L.ffhip_event_create(), L.ffhip_event_create()
-n = 64
+n = int(os.environ.get("FFHIP_BENCH_IMAGES", "64"))
 out = {}
 for name, (nc, h, v) in {"420": (3, 2, 2), "444": (3, 1, 1), "422": (3, 2, 1), "440": (3, 1, 2), "grey": (1, 1, 1)}.items():
     W, H = 3840, 2176

@@ -9,8 +9,9 @@
  * the same 9-bit look-up tables the host decoder uses (struct huff, uploaded as is) and scatters the
  * coefficients, de-zigzagged, into the MCU-order planes ffhip_jpeg_recon_batch reads.  The decode loop is
  * a flat one-symbol-per-iteration state machine so that lanes in different blocks, components or MCUs
- * still execute the same instructions.  Files without a DRI segment are refused (FFHIP_EINVAL): they
- * have one interval, i.e. no parallelism to offer, and stay on the host threads.
+ * still execute the same instructions.  A file without a DRI segment is one interval = one lane: accepted,
+ * but only a large batch of such files fills the machine (the callers in ffhip_pipeline.hip send them to the
+ * host threads unless there are a thousand or more).
  */
 #include "ffhip_internal.h"
 #include "ffhip_entropy_internal.h"
@@ -294,11 +295,12 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         status[i] = ffhip_jpeg_parse(files[i], lens[i], &j);
         if (status[i]) return;
         const int mc = (j.width + 8 * j.h[0] - 1) / (8 * j.h[0]), mr = (j.height + 8 * j.v[0] - 1) / (8 * j.v[0]);
-        if (mc != geom->mcu_cols || mr != geom->mcu_rows || j.ncomp != geom->ncomp || j.h[0] != geom->h || j.v[0] != geom->v || !j.restart ||
+        if (mc != geom->mcu_cols || mr != geom->mcu_rows || j.ncomp != geom->ncomp || j.h[0] != geom->h || j.v[0] != geom->v ||
             j.scan_len > 0x7fffffffu) {
-            status[i] = FFHIP_EINVAL; /* another geometry, or no restart intervals to spread over lanes */
+            status[i] = FFHIP_EINVAL; /* another geometry */
             return;
         }
+        if (!j.restart) j.restart = (int)mcus; /* no DRI: the whole scan is one interval = one lane (worth it for large batches only) */
         /* interval starts: behind the RSTn markers (0xFF is stuffed inside entropy data, so FF D0..D7 is a marker) */
         const uint32_t n_seg = (uint32_t)((mcus + j.restart - 1) / j.restart);
         std::vector<uint32_t> &sg = segs[(size_t)i];

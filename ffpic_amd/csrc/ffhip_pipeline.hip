@@ -122,9 +122,8 @@ extern "C" int ffhip_jpeg_decode_files(const uint8_t *const *files, const size_t
      * Its latency per batch is that of ONE restart interval, so it wants large chunks */
     const char *ge = getenv("FFHIP_JPEG_GPU_ENTROPY");
     bool gpu_entropy = !(ge && ge[0] == '0');
-    if (gpu_entropy) {
-        gpu_entropy = ffhip_jpeg_probe_restart(files[0], lens[0]) > 0;
-    }
+    if (gpu_entropy && !(ge && ge[0] == '1')) /* "1" forces it; default: restart markers, or enough files to give every lane one */
+        gpu_entropy = ffhip_jpeg_probe_restart(files[0], lens[0]) > 0 || n >= 1024;
     if (chunk <= 0) chunk = gpu_entropy ? 32 : 8;
     if (chunk > n) chunk = n;
     const size_t mcus = (size_t)g.mcu_cols * g.mcu_rows;
@@ -226,7 +225,7 @@ extern "C" int ffhip_jpeg_decode_files_device(const uint8_t *const *files, const
     hipStream_t st = (hipStream_t)stream;
     const char *ge = getenv("FFHIP_JPEG_GPU_ENTROPY");
     bool on_device = false;
-    if (!(ge && ge[0] == '0') && ffhip_jpeg_probe_restart(files[0], lens[0]) > 0) {
+    if (!(ge && ge[0] == '0') && ((ge && ge[0] == '1') || ffhip_jpeg_probe_restart(files[0], lens[0]) > 0 || n >= 1024)) {
         rc = ffhip_jpeg_entropy_batch_gpu(files, lens, n, n_threads, &g, dy, du, dv, dq, status, stream);
         on_device = rc == FFHIP_OK;
         if (!on_device && rc != FFHIP_EINVAL) return rc;

@@ -365,8 +365,8 @@ int ffhip_jpeg_entropy_batch(const uint8_t *const *files, const size_t *lens, in
 /* The same front end ON the device for files that carry restart markers (DRI): one lane per restart interval
  * decodes straight into DEVICE planes (d_coef_*, d_quant [n][4][64]) laid out for ffhip_jpeg_recon_batch with
  * quant_stride 256; the host only parses headers and finds the RSTn markers.  files/lens/status are HOST
- * arrays.  FFHIP_EINVAL for a file without DRI (one interval = nothing to spread out; use the host threads)
- * or of another geometry.  Synchronises `stream` (the per-picture verdicts come back with it). */
+ * arrays.  A file without DRI is one interval = one lane (worth it for batches of a thousand files or more only);
+ * FFHIP_EINVAL for a file of another geometry.  Synchronises `stream` (the per-picture verdicts come back with it). */
 int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const size_t *lens, int n, int n_threads /* host: header
                                  parsing, marker search, staging */, const ffhip_jpeg_geom *geom, int16_t *d_coef_y, int16_t *d_coef_u, int16_t *d_coef_v, uint16_t *d_quant,
                                  int *status, void *stream);

@@ -28,10 +28,17 @@ def test_dri_fixture():
     same_planes([data] * 5)
 
 
-def test_files_without_restart_markers_are_refused():
-    data = open(os.path.join(GOLDEN, "file_q85_420.jpg"), "rb").read()
+def test_files_without_restart_markers_take_one_lane_each():
+    for name in ("file_q85_420.jpg", "file_q92_444.jpg", "file_q80_grey.jpg"):
+        data = open(os.path.join(GOLDEN, name), "rb").read()
+        same_planes([data] * 3)
+
+
+def test_other_geometry_is_refused():
+    a = open(os.path.join(GOLDEN, "file_q85_420.jpg"), "rb").read()
+    b = open(os.path.join(GOLDEN, "file_q85_420_dri.jpg"), "rb").read()
     with pytest.raises(capi.FfhipError):
-        ops.jpeg_entropy_batch_gpu([data])
+        ops.jpeg_entropy_batch_gpu([a, b])
 
 
 @pytest.mark.parametrize("sub,mode,blocks,q", [(2, "RGB", 1, 90), (2, "RGB", 7, 60), (0, "RGB", 3, 95), (1, "RGB", 5, 75), (0, "L", 4, 85),

@@ -347,3 +347,15 @@ def test_files_to_device_pixels(tag):
     g, ref = ops.jpeg_decode_files(files, n_threads=2)
     g2, out, _ = ops.jpeg_decode_files_device(files, n_threads=2)
     assert np.array_equal(out, ref)
+
+
+def test_pipeline_with_device_entropy_forced_on_plain_files(monkeypatch):
+    """FFHIP_JPEG_GPU_ENTROPY=1: files without restart markers through the device decoder (one lane per file), same bytes"""
+    data = open(os.path.join(os.path.dirname(__file__), "golden", FILES["q85_420"]), "rb").read()
+    files = [data] * 6
+    monkeypatch.setenv("FFHIP_JPEG_GPU_ENTROPY", "0")
+    _, ref = ops.jpeg_decode_files(files, n_threads=2, chunk=4)
+    monkeypatch.setenv("FFHIP_JPEG_GPU_ENTROPY", "1")
+    _, out = ops.jpeg_decode_files(files, n_threads=2, chunk=4)
+    _, dev, _ = ops.jpeg_decode_files_device(files, n_threads=2)
+    assert np.array_equal(out, ref) and np.array_equal(dev, ref)

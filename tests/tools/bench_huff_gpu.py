@@ -53,4 +53,23 @@ for rows in (1, 0):
         t0 = time.perf_counter(); run2(); best = min(best, time.perf_counter() - t0)
     out[f"files_to_device_pixels_{'row' if rows else '16mcu'}_intervals_n{n}"] = {"ms": round(best * 1e3, 2), "Gpx/s": round(n * g.width * g.height / best / 1e9, 2), "files/s": round(n / best)}
     del dout
+# thumbnails WITHOUT restart markers: 4096 x 256x256, one lane per file on the device vs 16 host threads
+small = Image.fromarray(img[:256, :256])
+bio = io.BytesIO(); small.save(bio, "JPEG", quality=85, subsampling=2); data = bio.getvalue(); n = 4096
+gs, _, _ = ops.jpeg_probe(data)
+files = [data] * n
+bufs = [np.frombuffer(f, dtype=np.uint8) for f in files]
+ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs]); lens = (C.c_size_t * n)(*[b.size for b in bufs])
+dout = ops.DeviceBuffer(nbytes=n * gs.width * gs.height * 4); status = (C.c_int * n)(); g2 = capi.JpegGeom()
+for mode in ("0", "1"):
+    os.environ["FFHIP_JPEG_GPU_ENTROPY"] = mode
+    def run3():
+        capi.check(L.ffhip_jpeg_decode_files_device(ptrs, lens, n, 16, C.byref(g2), dout.ptr, gs.width * 4, gs.width * 4 * gs.height, status, None))
+        capi.check(L.ffhip_stream_sync(None))
+    run3()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter(); run3(); best = min(best, time.perf_counter() - t0)
+    out[f"thumbnails_256x256_no_dri_n{n}_{'device' if mode == '1' else 'host16'}_entropy"] = {"file_bytes": len(data), "ms": round(best * 1e3, 2), "Gpx/s": round(n * gs.width * gs.height / best / 1e9, 2), "files/s": round(n / best)}
+os.environ.pop("FFHIP_JPEG_GPU_ENTROPY", None)
 print(json.dumps(out, indent=1))

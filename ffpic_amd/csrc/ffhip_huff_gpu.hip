@@ -102,13 +102,8 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
     uint32_t mcu = w.y * im.restart;
     const uint32_t mcu_end = mcu + im.restart < im.mcus ? mcu + im.restart : im.mcus;
     int16_t *pl[3];
-    const struct huff *tdc[3], *tac[3];
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        pl[c] = a.plane[c] ? a.plane[c] + (size_t)w.x * im.mcus * im.nb[c] * 64 : nullptr;
-        tdc[c] = a.tabs + im.tab_dc[c];
-        tac[c] = a.tabs + im.tab_ac[c];
-    }
+    for (int c = 0; c < 3; c++) pl[c] = a.plane[c] ? a.plane[c] + (size_t)w.x * im.mcus * im.nb[c] * 64 : nullptr;
     /* element offset of the next block of each component inside this picture's planes: blocks of one component
      * are consecutive across MCUs, so a block end is "+ 64" */
     uint32_t boff[3] = {mcu * im.nb[0] * 64, mcu * im.nb[1] * 64, mcu * im.nb[2] * 64};
@@ -118,7 +113,7 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
     int pred[3] = {0, 0, 0};
     uint32_t c = 0, kb = 0, k = 0, nbc = im.nb[0], row_dc = 0, row_ac = 3;
     int16_t *blk = pl[0] + boff[0];
-    const struct huff *Tdc = tdc[0], *Tac = tac[0];
+    uint32_t tix_dc = im.tab_dc[0], tix_ac = im.tab_ac[0];
     int pred_cur = 0;
     auto refill = [&]() { /* all lanes: fetch 16-byte chunks while the ring has room for one */
         while (__builtin_amdgcn_ballot_w64(wr + 4 <= rd + RING_DW)) {
@@ -145,12 +140,20 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
             /* one Huffman symbol (coding/huffman.c:92-222): 9-bit look-up, then the canonical-code walk */
             const unsigned top = (unsigned)(acc >> 32);
             const unsigned peek = top >> (32 - LOOK);
-            const struct huff *T = dc ? Tdc : Tac;
-            const uint16_t *lut = in_lds ? lt[dc ? row_dc : row_ac] : a.lut + (size_t)(T - a.tabs) * LUT_WORDS; /* LDS or global */
-            unsigned e = lut[peek];
-            if (e & 0x8000u) e = lut[512 + ((e & 0xffu) << 7) + ((top >> (32 - 16)) & 127u)]; /* long code: its group, next 7 bits */
+            const uint32_t tix = dc ? tix_dc : tix_ac;
+            unsigned e;
+            if (in_lds) { /* two separate paths, not one pointer into either memory: that would be a flat load per symbol */
+                const uint16_t *l = lt[dc ? row_dc : row_ac];
+                e = l[peek];
+                if (e & 0x8000u) e = l[512 + ((e & 0xffu) << 7) + ((top >> (32 - 16)) & 127u)]; /* long code: its group, next 7 bits */
+            } else {
+                const uint16_t *l = a.lut + (size_t)tix * LUT_WORDS;
+                e = l[peek];
+                if (e & 0x8000u) e = l[512 + ((e & 0xffu) << 7) + ((top >> (32 - 16)) & 127u)];
+            }
             int sym = (int)(e & 0xff), len = (int)(e >> 8);
             if (!e) { /* a table with more long-code groups than the LUT holds, or a code that does not exist */
+                const struct huff *T = a.tabs + tix;
                 int code = (int)peek;
                 len = LOOK;
                 while (len < 17 && code > T->maxcode[len]) {
@@ -195,8 +198,8 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
                     nbc = c == 0 ? im.nb[0] : (c == 1 ? im.nb[1] : im.nb[2]);
                     row_dc = c;
                     row_ac = 3 + c;
-                    Tdc = c == 0 ? tdc[0] : (c == 1 ? tdc[1] : tdc[2]);
-                    Tac = c == 0 ? tac[0] : (c == 1 ? tac[1] : tac[2]);
+                    tix_dc = c == 0 ? im.tab_dc[0] : (c == 1 ? im.tab_dc[1] : im.tab_dc[2]);
+                    tix_ac = c == 0 ? im.tab_ac[0] : (c == 1 ? im.tab_ac[1] : im.tab_ac[2]);
                 }
                 blk = (c == 0 ? pl[0] : (c == 1 ? pl[1] : pl[2])) + (c == 0 ? boff[0] : (c == 1 ? boff[1] : boff[2]));
                 if (mcu >= mcu_end) active = false;

@@ -218,11 +218,6 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
 #define SCRATCH_HUFF 4
 
 namespace {
-/* pinned staging for the one upload per call, kept and grown; calls are serialised (they end in a stream sync) */
-uint8_t *g_stage = nullptr;
-size_t g_stage_cap = 0;
-std::mutex g_huff_mu;
-
 /* entropy-coded bytes without their stuffing (FF 00 -> FF), up to `end` or the first marker; returns the clean length */
 size_t unstuff(uint8_t *dst, const uint8_t *src, const uint8_t *end)
 {
@@ -353,16 +348,9 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     const size_t o_seg = (o_img + images.size() * sizeof(HuffImage) + 15) & ~(size_t)15, o_work = (o_seg + seg_total * 4 + 15) & ~(size_t)15;
     const size_t o_status = (o_work + seg_total * 8 + 15) & ~(size_t)15, o_quant = (o_status + (size_t)n * 4 + 15) & ~(size_t)15;
     const size_t total = o_quant + (size_t)n * 512;
-    std::lock_guard<std::mutex> lock(g_huff_mu);
-    if (total + 64 > g_stage_cap) {
-        if (g_stage) (void)hipHostFree(g_stage);
-        g_stage = nullptr;
-        g_stage_cap = 0;
-        const size_t want = total + total / 4 + 64;
-        if (hipHostMalloc((void **)&g_stage, want, hipHostMallocDefault) != hipSuccess) { g_stage = nullptr; return FFHIP_ENOMEM; }
-        g_stage_cap = want;
-    }
-    uint8_t *stage = g_stage;
+    /* pinned staging and device image are kept per stream: callers on different streams overlap completely */
+    uint8_t *stage = ffhip_pinned_scratch(SCRATCH_HUFF, stream, total + 64);
+    if (!stage) return FFHIP_ENOMEM;
     parallel_for(n, n_threads, [&](int i) {
         const struct jpeg_hdr &j = hdr[(size_t)i];
         const HuffImage &im = images[(size_t)i];

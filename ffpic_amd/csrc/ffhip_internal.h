@@ -21,7 +21,8 @@ extern "C" {
 #endif
 void ffhip_note_hip_error(int hip_error, const char *what);
 int ffhip_have_device(void); /* 1 once ffhip_init succeeded on a gfx950 device */
-uint32_t *ffhip_scratch(int kind, void *stream, size_t words); /* per (kind, stream) device scratch, NULL on failure */
+uint32_t *ffhip_scratch(int kind, void *stream, size_t words);
+uint8_t *ffhip_pinned_scratch(int kind, void *stream, size_t bytes); /* per (kind, stream) pinned host staging, NULL on failure */ /* per (kind, stream) device scratch, NULL on failure */
 int *ffhip_async_err_word(void); /* pinned word kernels report an in-launch abort through; see ffhip_stream_sync */
 #ifdef __cplusplus
 }

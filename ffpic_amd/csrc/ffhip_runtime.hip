@@ -79,6 +79,27 @@ extern "C" const char *ffhip_arch_name(void) { return g_arch; }
 struct ScratchEntry { uint32_t *dev; size_t words; };
 static std::map<std::pair<int, void *>, ScratchEntry> g_scratch;
 static std::mutex g_scratch_mu;
+/* the same for PINNED host memory (staging for uploads): owned by (kind, stream), kept, grown on demand.  The caller
+ * must not refill it before what it enqueued from it on that stream has run (a stream sync, as a rule). */
+static std::map<std::pair<int, void *>, std::pair<uint8_t *, size_t>> g_pinned;
+extern "C" uint8_t *ffhip_pinned_scratch(int kind, void *stream, size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    auto &e = g_pinned[std::make_pair(kind, stream)];
+    if (bytes > e.second) {
+        if (e.first) {
+            if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return nullptr;
+            (void)hipHostFree(e.first);
+        }
+        e.first = nullptr;
+        e.second = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipHostMalloc((void **)&e.first, want, hipHostMallocDefault) != hipSuccess) { e.first = nullptr; return nullptr; }
+        e.second = want;
+    }
+    return e.first;
+}
+
 extern "C" uint32_t *ffhip_scratch(int kind, void *stream, size_t words)
 {
     std::lock_guard<std::mutex> lock(g_scratch_mu);

@@ -53,6 +53,31 @@ for rows in (1, 0):
         t0 = time.perf_counter(); run2(); best = min(best, time.perf_counter() - t0)
     out[f"files_to_device_pixels_{'row' if rows else '16mcu'}_intervals_n{n}"] = {"ms": round(best * 1e3, 2), "Gpx/s": round(n * g.width * g.height / best / 1e9, 2), "files/s": round(n / best)}
     del dout
+# sustained: T caller threads, each with its own stream, decoding batches of 128 4K files (MCU-row intervals) to device pixels
+import threading
+bio = io.BytesIO(); Image.fromarray(img).save(bio, "JPEG", quality=85, subsampling=2, restart_marker_rows=1); data = bio.getvalue()
+nb = 128
+files = [data] * nb
+bufs = [np.frombuffer(f, dtype=np.uint8) for f in files]
+ptrs = (C.c_void_p * nb)(*[b.ctypes.data for b in bufs]); lens = (C.c_size_t * nb)(*[b.size for b in bufs])
+for T in (1, 2, 3):
+    streams = [L.ffhip_stream_create() for _ in range(T)]
+    douts = [ops.DeviceBuffer(nbytes=nb * g.width * g.height * 4) for _ in range(T)]
+    reps = 6
+    def worker(t):
+        status = (C.c_int * nb)(); gg = capi.JpegGeom()
+        for _ in range(reps):
+            capi.check(L.ffhip_jpeg_decode_files_device(ptrs, lens, nb, 8, C.byref(gg), douts[t].ptr, g.width * 4, g.width * 4 * g.height, status, streams[t]))
+        capi.check(L.ffhip_stream_sync(streams[t]))
+    worker(0)
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    t0 = time.perf_counter()
+    for x in th: x.start()
+    for x in th: x.join()
+    dt = time.perf_counter() - t0
+    out[f"sustained_files_to_device_{T}_callers_x_{nb}_files"] = {"files/s": round(T * reps * nb / dt), "Gpx/s": round(T * reps * nb * g.width * g.height / dt / 1e9, 1)}
+    for st_ in streams: L.ffhip_stream_destroy(st_)
+    del douts
 # thumbnails WITHOUT restart markers: 4096 x 256x256, one lane per file on the device vs 16 host threads
 small = Image.fromarray(img[:256, :256])
 bio = io.BytesIO(); small.save(bio, "JPEG", quality=85, subsampling=2); data = bio.getvalue(); n = 4096

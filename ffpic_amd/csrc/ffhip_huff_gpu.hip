@@ -101,19 +101,26 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
     uint32_t rd = (start & 15u) >> 2, wr = 0; /* dword cursors into the stream counted from src */
     uint32_t mcu = w.y * im.restart;
     const uint32_t mcu_end = mcu + im.restart < im.mcus ? mcu + im.restart : im.mcus;
-    int16_t *pl[3];
+    /* ---- what a block change needs, as per-lane tables in LDS, so that it is a few look-ups and not chains of
+     * three-way selects: per block slot of the MCU its component, tables and block count; per component the
+     * predictor and the byte address of the picture's plane ---- */
+    __shared__ uint32_t slotrec[8][64];            /* c | kb << 2 | nb_c << 5 | tix_dc << 8 | tix_ac << 20 */
+    __shared__ int predv[3][64];
+    __shared__ unsigned long long planeb[3][64];
+    uint32_t nbt = 0;
 #pragma unroll
-    for (int c = 0; c < 3; c++) pl[c] = a.plane[c] ? a.plane[c] + (size_t)w.x * im.mcus * im.nb[c] * 64 : nullptr;
-    /* element offset of the next block of each component inside this picture's planes: blocks of one component
-     * are consecutive across MCUs, so a block end is "+ 64" */
-    uint32_t boff[3] = {mcu * im.nb[0] * 64, mcu * im.nb[1] * 64, mcu * im.nb[2] * 64};
+    for (int c = 0; c < 3; c++) {
+        const unsigned long long pb = a.plane[c] ? (unsigned long long)(uintptr_t)(a.plane[c] + (size_t)w.x * im.mcus * im.nb[c] * 64) : 0ull;
+        planeb[c][lane] = pb;
+        predv[c][lane] = 0;
+        for (uint32_t kb0 = 0; kb0 < im.nb[c] && nbt < 8; kb0++)
+            slotrec[nbt++][lane] = (uint32_t)c | (kb0 << 2) | (im.nb[c] << 5) | ((im.tab_dc[c] & 0xfffu) << 8) | ((im.tab_ac[c] & 0xfffu) << 20);
+    }
     unsigned long long acc = 0; /* LEFT-aligned: next unread bit is bit 63 */
     int n = 0;
     bool active = exists && mcu < mcu_end, bad = false;
-    int pred[3] = {0, 0, 0};
-    uint32_t c = 0, kb = 0, k = 0, nbc = im.nb[0], row_dc = 0, row_ac = 3;
-    int16_t *blk = pl[0] + boff[0];
-    uint32_t tix_dc = im.tab_dc[0], tix_ac = im.tab_ac[0];
+    uint32_t slot = 0, k = 0, rec = slotrec[0][lane];
+    int16_t *blk = (int16_t *)(uintptr_t)planeb[0][lane] + (size_t)mcu * im.nb[0] * 64;
     int pred_cur = 0;
     auto refill = [&]() { /* all lanes: fetch 16-byte chunks while the ring has room for one */
         while (__builtin_amdgcn_ballot_w64(wr + 4 <= rd + RING_DW)) {
@@ -137,13 +144,14 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
         const uint32_t nextdw = ring[rd & (RING_DW - 1)][lane]; /* wanted at the bottom, if at all */
         if (active) {
             const bool dc = k == 0;
-            /* one Huffman symbol (coding/huffman.c:92-222): 9-bit look-up, then the canonical-code walk */
+            const uint32_t c = rec & 3u;
+            /* one Huffman symbol (coding/huffman.c:92-222): two-level look-up, canonical-code walk as the last resort */
             const unsigned top = (unsigned)(acc >> 32);
             const unsigned peek = top >> (32 - LOOK);
-            const uint32_t tix = dc ? tix_dc : tix_ac;
+            const uint32_t tix = dc ? (rec >> 8) & 0xfffu : rec >> 20;
             unsigned e;
             if (in_lds) { /* two separate paths, not one pointer into either memory: that would be a flat load per symbol */
-                const uint16_t *l = lt[dc ? row_dc : row_ac];
+                const uint16_t *l = lt[dc ? c : 3 + c];
                 e = l[peek];
                 if (e & 0x8000u) e = l[512 + ((e & 0xffu) << 7) + ((top >> (32 - 16)) & 127u)]; /* long code: its group, next 7 bits */
             } else {
@@ -164,44 +172,31 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
                 sym = T->vals[(T->valptr[len] + code - T->mincode[len]) & 255]; /* & 255: a malformed DHT must not index outside the table */
             }
             acc <<= len;
-            n -= len;
+            /* ---- the rest of the step without branches: run, magnitude bits, EXTEND, predictor, store ---- */
             const int s = dc ? sym : (sym & 15), r = dc ? 0 : (sym >> 4);
-            if (dc && s > 11) bad = true;
-            if (!dc && s == 0) {
-                k = r == 15 ? k + 16 : 64; /* ZRL / EOB */
-            } else {
-                k += (uint32_t)r;
-                if (k > 63) { bad = true; k = 63; }
-                int v = 0;
-                if (s) {
-                    v = (int)((unsigned)(acc >> 32) >> (32 - s));
-                    acc <<= s;
-                    n -= s;
-                    if (v < (1 << (s - 1))) v -= (1 << s) - 1; /* EXTEND, T.81 F.2.2.1 */
-                }
-                if (dc) { pred_cur += v; v = pred_cur; }
-                blk[zz[k]] = (int16_t)v;
-                k++;
-            }
-            if (k >= 64) { /* next block of the MCU, next component, next MCU */
+            const bool skip = !dc && s == 0;                       /* ZRL or EOB: nothing to store */
+            k += skip ? (r == 15 ? 16u : 64u) : (uint32_t)r;       /* EOB: anything that ends the block */
+            const unsigned vb = (unsigned)((acc >> 33) >> (31 - s)); /* the next s bits; s = 0 gives 0 */
+            acc <<= s;
+            n -= len + s;
+            const int lim = (1 << s) >> 1;                         /* 1 << (s - 1), 0 for s = 0 */
+            int v = (int)vb < lim ? (int)vb - (1 << s) + 1 : (int)vb; /* EXTEND, T.81 F.2.2.1 */
+            pred_cur += dc ? v : 0;
+            v = dc ? pred_cur : v;
+            bad |= (dc && s > 11) || (!skip && k > 63);
+            if (!skip && k <= 63) blk[zz[k]] = (int16_t)v;
+            k += skip ? 0u : 1u;
+            if (k >= 64) { /* next block: the MCU's next slot, or the next MCU */
                 k = 0;
-                boff[0] += c == 0 ? 64u : 0u;
-                boff[1] += c == 1 ? 64u : 0u;
-                boff[2] += c == 2 ? 64u : 0u;
-                if (++kb == nbc) {
-                    kb = 0;
-                    pred[0] = c == 0 ? pred_cur : pred[0];
-                    pred[1] = c == 1 ? pred_cur : pred[1];
-                    pred[2] = c == 2 ? pred_cur : pred[2];
-                    if (++c == im.ncomp) { c = 0; mcu++; }
-                    pred_cur = c == 0 ? pred[0] : (c == 1 ? pred[1] : pred[2]);
-                    nbc = c == 0 ? im.nb[0] : (c == 1 ? im.nb[1] : im.nb[2]);
-                    row_dc = c;
-                    row_ac = 3 + c;
-                    tix_dc = c == 0 ? im.tab_dc[0] : (c == 1 ? im.tab_dc[1] : im.tab_dc[2]);
-                    tix_ac = c == 0 ? im.tab_ac[0] : (c == 1 ? im.tab_ac[1] : im.tab_ac[2]);
-                }
-                blk = (c == 0 ? pl[0] : (c == 1 ? pl[1] : pl[2])) + (c == 0 ? boff[0] : (c == 1 ? boff[1] : boff[2]));
+                slot++;
+                const bool wrap = slot == nbt;
+                slot = wrap ? 0u : slot;
+                mcu += wrap ? 1u : 0u;
+                rec = slotrec[slot][lane];
+                const uint32_t c2 = rec & 3u, nbc = (rec >> 5) & 7u, kb = (rec >> 2) & 7u;
+                predv[c][lane] = pred_cur;      /* LDS keeps program order: when c2 == c the read returns this value */
+                pred_cur = predv[c2][lane];
+                blk = (int16_t *)(uintptr_t)planeb[c2][lane] + (size_t)(mcu * nbc + kb) * 64;
                 if (mcu >= mcu_end) active = false;
             }
             if (bad) active = false;
@@ -343,6 +338,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     }
     if (!ffhip_have_device()) return FFHIP_ENODEV;
     const size_t n_tabs = uniq.size();
+    if (n_tabs > 4095) return FFHIP_EINVAL; /* table indices travel in 12 bits */
     const size_t o_tabs = scan_total + 16, o_l12 = (o_tabs + n_tabs * sizeof(struct huff) + 15) & ~(size_t)15;
     const size_t o_img = o_l12 + n_tabs * LUT_WORDS * 2;
     const size_t o_seg = (o_img + images.size() * sizeof(HuffImage) + 15) & ~(size_t)15, o_work = (o_seg + seg_total * 4 + 15) & ~(size_t)15;

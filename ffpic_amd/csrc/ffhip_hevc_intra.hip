@@ -438,6 +438,11 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
 
 #define SCRATCH_HEVC_INTRA 3
 
+extern "C" size_t ffhip_hevc_plan_gpu_words(long long n_tus, const int pw[3], const int ph[3], const int wl[3]);
+extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, const int pw[3], const int ph[3], const int wl[3],
+                                   uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
+                                   int *n_groups);
+
 struct GroupPlan {
     std::vector<u32x4> sched;  /* 3 per slot */
     std::vector<u32x4> groups;
@@ -742,6 +747,33 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
     const bool offsets_fit = (long long)y_stride * height_y < (1LL << 30) && (long long)uv_stride * (height_c > 0 ? height_c : 1) < (1LL << 30);
     if (want_groups && async_err && offsets_fit /* 32-bit byte offsets into a plane */) {
         const char *we = getenv("FFHIP_HEVC_INTRA_WINDOW");
+        const char *wv = getenv("FFHIP_HEVC_INTRA_WAVES");
+        const size_t max_waves = wv ? (size_t)std::max(1, atoi(wv)) : FFHIP_HEVC_INTRA_WAVES;
+        /* the schedule: built on the device (ffhip_hevc_plan_gpu.hip) unless FFHIP_HEVC_PLAN=host; lists whose groups are
+         * not contiguous runs of the decode order come back from there and take the host planner with its window search */
+        const char *pe = getenv("FFHIP_HEVC_PLAN");
+        if (!(pe && !strcmp(pe, "host")) && n_tus >= 64) {
+            int wl = we ? atoi(we) : FFHIP_HEVC_INTRA_WINDOW_LOG2;
+            wl = wl < 3 ? 3 : (wl > 6 ? 6 : wl);
+            const int cs = (pw[1] > 0 && pw[1] * 2 <= pw[0] + 1) ? 1 : 0;
+            const int win[3] = {wl, wl - cs, wl - cs};
+            const int pwc[3] = {pw[0], (d_cb && d_cr) ? pw[1] : 0, (d_cb && d_cr) ? pw[2] : 0};
+            const size_t w_plan = ffhip_hevc_plan_gpu_words(n_tus, pwc, ph, win), w_ctrl = 4 + (size_t)n_tus;
+            uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, w_plan + w_ctrl + 16);
+            if (!g_work) return FFHIP_ENOMEM;
+            int n_groups = 0;
+            const int prc = ffhip_hevc_plan_gpu(d_tus, n_tus, pwc, ph, win, g_work, st, &a.sched, &a.groups, &a.wait_idx, &n_groups);
+            if (prc < 0) return prc;
+            if (prc == 0) {
+                a.ctrl = g_work + ((w_plan + 3) & ~(size_t)3);
+                FFHIP_CHECK(hipMemsetAsync(a.ctrl, 0, w_ctrl * 4, st), FFHIP_EIO);
+                a.async_err = async_err;
+                a.n_groups = n_groups;
+                hipLaunchKernelGGL(k_hevc_intra_groups, dim3((unsigned)std::min<size_t>((size_t)n_groups, max_waves)), dim3(64), 0, st, a);
+                FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
+                return FFHIP_OK;
+            }
+        }
         GroupPlan plan;
         if (plan_with_window_search(h_tus, n_tus, pw, ph, we ? atoi(we) : FFHIP_HEVC_INTRA_WINDOW_LOG2, plan, nullptr)) {
             /* device image: sched | groups | wait | ctrl[4] + one done flag per TU */
@@ -761,8 +793,6 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             a.ctrl = g_work + o_ctrl;
             a.async_err = async_err;
             a.n_groups = (int)plan.groups.size();
-            const char *wv = getenv("FFHIP_HEVC_INTRA_WAVES");
-            const size_t max_waves = wv ? (size_t)std::max(1, atoi(wv)) : FFHIP_HEVC_INTRA_WAVES;
             const unsigned wgs = (unsigned)std::min<size_t>(plan.groups.size(), max_waves); /* one wave each; waves loop over tickets */
             hipLaunchKernelGGL(k_hevc_intra_groups, dim3(wgs), dim3(64), 0, st, a);
             FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);

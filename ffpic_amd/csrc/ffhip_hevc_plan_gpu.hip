@@ -1,0 +1,373 @@
+/*
+ * ffhip_hevc_plan_gpu.hip -- the group schedule of ffhip_hevc_intra_recon built ON the device.
+ *
+ * The host planner (plan_groups in ffhip_hevc_intra.hip) costs ~30 ns per TU on one core: more than the kernel it
+ * feeds once a picture has a few hundred thousand TUs (an 8K picture, a HEIF grid).  Everything it derives is a pure
+ * function of the TU list, one TU at a time, given the map "which TU owns this 4x4 block":
+ *   k_plan_owner   every TU stamps its index on its blocks, and says whether it starts a new RUN (a maximal stretch
+ *                  of consecutive TUs whose top-left corners fall into the same window of the same plane)
+ *   (scan)         run id per TU
+ *   k_plan_count   per TU: the TUs of OTHER runs among its available neighbours (only earlier ones count: a block
+ *                  stamped by a later TU held older content when the sequential decoder looked), whether all its
+ *                  in-window neighbours are its own run's (LDS tile allowed), who must publish a done flag; per run
+ *                  start: its position, and the claim on its window -- a window claimed by two runs means the list
+ *                  is not "groups contiguous in decode order", and the caller falls back to the host planner
+ *   (scan)         first wait entry per TU
+ *   k_plan_emit    wait lists, schedule slots (position = TU index: runs in decode order ARE the ticket order, and a
+ *                  TU an earlier-listed TU of another run precedes lies in a run that started earlier, i.e. has a
+ *                  smaller ticket -- the deadlock-freedom condition of the grouped kernel), group records
+ * Same output layout as the host planner; tickets in decode order (the host's dependency-depth order is a polling
+ * optimisation worth ~3 %).
+ */
+#include "ffhip_internal.h"
+
+#include <hipcub/hipcub.hpp>
+
+struct PlanArgs {
+    const ffhip_hevc_tu *tus;
+    uint32_t n;
+    int pw[3], ph[3], bw[3], gw[3], wl[3];
+    uint32_t owner_off[3], win_off[3]; /* per plane: start inside owner[] / win_run[] */
+    int32_t *owner;        /* TU index per 4x4 block, -1 = none                     */
+    uint32_t *win_run;     /* run that claimed a window, ~0 = none                  */
+    uint32_t *start;       /* 1 where a run starts; after the scan: runs before me  */
+    uint32_t *runid;       /* inclusive scan of start, minus one                    */
+    uint32_t *wcount;      /* wait entries per TU; after the scan: first entry      */
+    uint32_t *wbegin;
+    uint8_t *flags;        /* bit 0 signal, bit 1 tile_ok                           */
+    uint32_t *gstart;      /* TU index where run r starts; [n_runs] = n             */
+    uint32_t *wait_idx;
+    u32x4 *sched, *groups;
+    uint32_t *result;      /* [0] fail, [1] number of runs, [2] wait entries        */
+    uint32_t wait_cap;     /* words reserved for wait_idx                           */
+    uint32_t *cell_claim;  /* per 64x64-luma cell and plane: TU that opened it, ~0 = none (is the CTB 64?) */
+    uint32_t *cell_edges;  /* bit 0 left, 1 above, 2 above-left, 3 above-right: cells this cell's TUs read */
+    uint32_t *cell_depth;  /* longest chain of such edges ending here: the wavefront index of the cell     */
+    uint32_t n_cells, cgh[3];
+    uint32_t cell_off[3], cgw[3];
+    int cshift[3];         /* log2 of the cell size in samples of the plane          */
+    unsigned long long *keys_in, *keys_out; /* (wavefront key << 32 | run) per run    */
+    uint32_t *vals_in, *rank_of;           /* sort payload (run); ticket of a run    */
+};
+
+__device__ __forceinline__ uint32_t win_of(const PlanArgs &a, const ffhip_hevc_tu &t)
+{
+    const int c = t.cidx;
+    return a.win_off[c] + (uint32_t)(t.y >> a.wl[c]) * (uint32_t)a.gw[c] + (uint32_t)(t.x >> a.wl[c]);
+}
+
+__global__ __launch_bounds__(256) void k_plan_owner(PlanArgs a)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const ffhip_hevc_tu t = a.tus[i];
+    const int c = t.cidx, nb = (1 << t.log2_size) >> 2;
+    int32_t *o = a.owner + a.owner_off[c] + (size_t)(t.y >> 2) * a.bw[c] + (t.x >> 2);
+    for (int by = 0; by < nb; by++)
+        for (int bx = 0; bx < nb; bx++) o[(size_t)by * a.bw[c] + bx] = (int32_t)i;
+    const ffhip_hevc_tu tp = a.tus[i ? i - 1 : 0];
+    a.start[i] = (i == 0 || win_of(a, t) != win_of(a, tp)) ? 1u : 0u;
+    /* does the list visit every 64x64 (luma) cell in ONE stretch per plane?  Then the coding tree block is 64 and the
+     * classic wavefront order over cells -- x + 2y -- is a valid ticket order (checked edge by edge in k_plan_emit) */
+    const uint32_t cell = a.cell_off[c] + (uint32_t)(t.y >> a.cshift[c]) * a.cgw[c] + (uint32_t)(t.x >> a.cshift[c]);
+    const uint32_t cellp = a.cell_off[tp.cidx] + (uint32_t)(tp.y >> a.cshift[tp.cidx]) * a.cgw[tp.cidx] + (uint32_t)(tp.x >> a.cshift[tp.cidx]);
+    if (i == 0 || cell != cellp)
+        if (atomicCAS(a.cell_claim + cell, ~0u, i) != ~0u) a.result[3] = 1; /* a cell entered twice: no wavefront keys */
+}
+
+/* longest dependency chain per cell, by relaxation inside ONE workgroup (a few thousand cells, as many rounds as the
+ * longest chain: width + 2 height of a picture, far less for a grid of tiles -- which is the point: every tile's first
+ * cell gets depth 0 and an early ticket, where x + 2y over the whole plane set would queue the tiles one after another) */
+#define CELLS_LDS 16384 /* cells of one plane the LDS form holds: 8K at 64x64 is 8 160 */
+__global__ __launch_bounds__(1024) void k_plan_cell_depth(PlanArgs a)
+{
+    /* one workgroup per plane; edges and depths of the plane in LDS when they fit (global round trips would cost
+     * ~10 us per round otherwise) */
+    __shared__ unsigned short dl[CELLS_LDS];
+    __shared__ unsigned char el[CELLS_LDS];
+    __shared__ int changed;
+    const int c = blockIdx.x;
+    const uint32_t gw = a.cgw[c], cnt = gw * a.cgh[c];
+    if (cnt == 0) return;
+    const bool lds = cnt <= CELLS_LDS;
+    uint32_t *dg = a.cell_depth + a.cell_off[c];
+    const uint32_t *eg = a.cell_edges + a.cell_off[c];
+    if (lds)
+        for (uint32_t k = threadIdx.x; k < cnt; k += 1024) { dl[k] = 0; el[k] = (unsigned char)eg[k]; }
+    __syncthreads();
+    for (uint32_t round = 0; round <= cnt; round++) {
+        if (threadIdx.x == 0) changed = 0;
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < cnt; k += 1024) {
+            const uint32_t e = lds ? el[k] : eg[k], x = k % gw;
+            uint32_t v = 0;
+#define DEPTH(i) (lds ? (uint32_t)dl[i] : dg[i])
+            if ((e & 1u) && x > 0) v = max(v, DEPTH(k - 1) + 1);
+            if ((e & 2u) && k >= gw) v = max(v, DEPTH(k - gw) + 1);
+            if ((e & 4u) && k >= gw && x > 0) v = max(v, DEPTH(k - gw - 1) + 1);
+            if ((e & 8u) && k >= gw && x + 1 < gw) v = max(v, DEPTH(k - gw + 1) + 1);
+            if (v > DEPTH(k)) { /* monotone: in-place updates only speed it up */
+                if (lds) dl[k] = (unsigned short)v;
+                else dg[k] = v;
+                changed = 1;
+            }
+#undef DEPTH
+        }
+        __syncthreads();
+        if (!changed) break;
+        __syncthreads();
+    }
+    if (lds)
+        for (uint32_t k = threadIdx.x; k < cnt; k += 1024) dg[k] = dl[k];
+}
+
+/* per run: its wavefront key.  Runs of one cell share a key and keep their decode order (the run id in the low bits) */
+__global__ __launch_bounds__(256) void k_plan_keys(PlanArgs a)
+{
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.n) return;
+    unsigned long long key = ~0ull; /* beyond the last run: sorts to the end */
+    if (r < a.result[1]) {
+        const ffhip_hevc_tu t = a.tus[a.gstart[r]];
+        const uint32_t cx = (uint32_t)(t.x >> a.cshift[t.cidx]), cy = (uint32_t)(t.y >> a.cshift[t.cidx]);
+        key = ((unsigned long long)(a.result[3] ? 0u : a.cell_depth[a.cell_off[t.cidx] + cy * a.cgw[t.cidx] + cx]) << 32) | r;
+    }
+    a.keys_in[r] = key;
+    a.vals_in[r] = r;
+}
+
+__global__ __launch_bounds__(256) void k_plan_rank(PlanArgs a, const uint32_t *sorted_runs)
+{
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k < a.result[1]) a.rank_of[sorted_runs[k]] = k;
+}
+
+/* the TUs of other runs TU i reads; returns their number (<= 66), fills deps when not NULL */
+__device__ __forceinline__ int gather_deps(const PlanArgs &a, uint32_t i, const ffhip_hevc_tu &t, uint32_t *deps, bool *tile_ok)
+{
+    const int c = t.cidx, n = 1 << t.log2_size, wl = a.wl[c];
+    const uint32_t run = a.runid[i];
+    const int wx0 = (t.x >> wl) << wl, wy0 = (t.y >> wl) << wl, wsz = 1 << wl;
+    const int32_t *own = a.owner + a.owner_off[c];
+    int nd = 0;
+    bool ok = true;
+    uint32_t last = ~0u;
+    auto dep = [&](int px, int py) {
+        int32_t j = own[(size_t)(py >> 2) * a.bw[c] + (px >> 2)];
+        if (j >= (int32_t)i) j = -1;
+        const bool mine = j >= 0 && a.runid[j] == run;
+        if (j >= 0 && !mine && (uint32_t)j != last) {
+            bool dup = false;
+            if (deps)
+                for (int q = 0; q < nd && !dup; q++) dup = deps[q] == (uint32_t)j;
+            if (!dup) {
+                if (deps && nd < 66) deps[nd] = (uint32_t)j;
+                nd++;
+                last = (uint32_t)j;
+            }
+        }
+        if (!mine && px >= wx0 && px < wx0 + wsz && py >= wy0 && py < wy0 + wsz) ok = false;
+    };
+    if (t.flags & 1) dep(t.x - 1, t.y - 1);
+    for (int k = 0; k < 2 * n; k += 4) {
+        if ((t.avail_top >> k) & 0xf) dep(t.x + k, t.y - 1);
+        if ((t.avail_left >> k) & 0xf) dep(t.x - 1, t.y + k);
+    }
+    if (tile_ok) *tile_ok = ok;
+    return nd;
+}
+
+__global__ __launch_bounds__(256) void k_plan_count(PlanArgs a)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const ffhip_hevc_tu t = a.tus[i];
+    uint32_t deps[66];
+    bool ok;
+    const int nd = gather_deps(a, i, t, deps, &ok); /* exact count needs the de-duplication, hence the array */
+    a.wcount[i] = (uint32_t)nd;
+    if (nd > 64) a.result[0] = 1; /* more than the kernel's 64 pollers: leave it to the host planner */
+    atomicOr((unsigned *)(a.flags + (i & ~3u)), (ok ? 2u : 0u) << (8 * (i & 3)));
+    const int c = t.cidx;
+    const int cx = t.x >> a.cshift[c], cy = t.y >> a.cshift[c];
+    unsigned edges = 0;
+    for (int q = 0; q < nd && q < 66; q++) {
+        atomicOr((unsigned *)(a.flags + (deps[q] & ~3u)), 1u << (8 * (deps[q] & 3)));
+        const ffhip_hevc_tu tj = a.tus[deps[q]];
+        const int dx = (tj.x >> a.cshift[c]) - cx, dy = (tj.y >> a.cshift[c]) - cy;
+        if (dx == 0 && dy == 0) continue;
+        if (dx == -1 && dy == 0) edges |= 1u;
+        else if (dx == 0 && dy == -1) edges |= 2u;
+        else if (dx == -1 && dy == -1) edges |= 4u;
+        else if (dx == 1 && dy == -1) edges |= 8u;
+        else a.result[3] = 1; /* a dependency no coding-tree wavefront has: keep decode order */
+    }
+    if (edges) atomicOr(a.cell_edges + a.cell_off[c] + (uint32_t)cy * a.cgw[c] + (uint32_t)cx, edges);
+    const bool starts = i == 0 || a.runid[i] != a.runid[i - 1];
+    if (starts) {
+        a.gstart[a.runid[i]] = i;
+        if (atomicCAS(a.win_run + win_of(a, t), ~0u, a.runid[i]) != ~0u) a.result[0] = 1; /* a window with two runs */
+    }
+    if (i == a.n - 1) {
+        a.gstart[a.runid[i] + 1] = a.n;
+        a.result[1] = a.runid[i] + 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_plan_emit(PlanArgs a)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const ffhip_hevc_tu t = a.tus[i];
+    const uint32_t wb = a.wbegin[i], wc = a.wcount[i];
+    if (wc) {
+        uint32_t deps[66];
+        gather_deps(a, i, t, deps, nullptr);
+        const uint32_t my_ticket = a.rank_of[a.runid[i]];
+        for (uint32_t q = 0; q < wc && q < 66; q++) {
+            if (wb + q < a.wait_cap) a.wait_idx[wb + q] = deps[q]; /* beyond the reservation: the caller sees result[2] and falls back */
+            if (a.rank_of[a.runid[deps[q]]] >= my_ticket) a.result[0] = 1; /* would wait for a later ticket: not with this order */
+        }
+    }
+    const u32x4 *src = (const u32x4 *)(a.tus + i);
+    const uint32_t f = a.flags[i];
+    u32x4 q2;
+    q2.x = wb;
+    q2.y = wc | ((f & 1u) << 8) | (((f >> 1) & 1u) << 9);
+    q2.z = i;
+    q2.w = 0;
+    a.sched[(size_t)i * 3] = src[0];
+    a.sched[(size_t)i * 3 + 1] = src[1];
+    a.sched[(size_t)i * 3 + 2] = q2;
+    if (i == a.n - 1) a.result[2] = wb + wc;
+    const bool starts = i == 0 || a.runid[i] != a.runid[i - 1];
+    if (starts) {
+        const uint32_t r = a.runid[i];
+        u32x4 g;
+        g.x = i;
+        g.y = a.gstart[r + 1] - i;
+        g.z = (uint32_t)a.wl[t.cidx];
+        g.w = 0;
+        a.groups[a.rank_of[r]] = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_plan_runid(uint32_t *runid, const uint32_t *start_excl, const uint32_t *start_flag_src, uint32_t n)
+{
+    /* inclusive - 1 = exclusive + flag - 1 */
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) runid[i] = start_excl[i] + start_flag_src[i] - 1u;
+}
+
+/* Layout of the device scratch the caller provides (32-bit words).  sched / groups / wait_idx sit where the grouped
+ * kernel expects to be told they are; everything else is planner-private. */
+extern "C" size_t ffhip_hevc_plan_gpu_words(long long n_tus, const int pw[3], const int ph[3], const int wl[3])
+{
+    size_t blocks = 0, wins = 0;
+    for (int c = 0; c < 3; c++) {
+        if (pw[c] <= 0) continue;
+        blocks += (size_t)((pw[c] + 3) / 4) * (size_t)((ph[c] + 3) / 4);
+        wins += (size_t)(((pw[c] - 1) >> wl[c]) + 1) * (size_t)(((ph[c] - 1) >> wl[c]) + 1);
+    }
+    const size_t n = (size_t)n_tus;
+    size_t scan_tmp = 0, sort_tmp = 0, cells = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (const uint32_t *)nullptr,
+                                             (uint32_t *)nullptr, (int)n);
+    if (sort_tmp > scan_tmp) scan_tmp = sort_tmp;
+    for (int c = 0; c < 3; c++)
+        if (pw[c] > 0) cells += (size_t)(((pw[c] - 1) >> 4) + 1) * (size_t)(((ph[c] - 1) >> 4) + 1); /* generous: cells of >= 16 samples */
+    /* sched 12n | groups 4(n+1) | wait 66... bounded by 33n in theory: sized by 8n + the fallback check | owner | win | start | startx | runid |
+     * wcount | wbegin | flags | gstart | result | scan temp */
+    return 12 * n + 4 * (n + 1) + 8 * n + blocks + wins + 6 * n + (n + 3) / 4 + 4 + (n + 2) + 16 + (scan_tmp + 3) / 4 + 128 + 3 * cells + 3 * n + 4 * n + 8;
+}
+
+/* Returns 0 when the plan is in place (n_groups, n_wait filled), 1 when the list needs the host planner. */
+extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, const int pw[3], const int ph[3], const int wl[3],
+                                   uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
+                                   int *n_groups)
+{
+    PlanArgs a;
+    const size_t n = (size_t)n_tus;
+    a.tus = d_tus;
+    a.n = (uint32_t)n;
+    size_t blocks = 0, wins = 0;
+    for (int c = 0; c < 3; c++) {
+        a.pw[c] = pw[c]; a.ph[c] = ph[c]; a.wl[c] = wl[c];
+        a.bw[c] = (pw[c] + 3) / 4;
+        a.gw[c] = pw[c] > 0 ? ((pw[c] - 1) >> wl[c]) + 1 : 0;
+        a.owner_off[c] = (uint32_t)blocks;
+        a.win_off[c] = (uint32_t)wins;
+        if (pw[c] > 0) {
+            blocks += (size_t)a.bw[c] * (size_t)((ph[c] + 3) / 4);
+            wins += (size_t)a.gw[c] * (size_t)(((ph[c] - 1) >> wl[c]) + 1);
+        }
+    }
+    size_t scan_tmp = 0, sort_tmp = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (const uint32_t *)nullptr,
+                                             (uint32_t *)nullptr, (int)n);
+    if (sort_tmp > scan_tmp) scan_tmp = sort_tmp;
+    uint32_t *p = scratch;
+    a.sched = (u32x4 *)p; p += 12 * n;
+    a.groups = (u32x4 *)p; p += 4 * (n + 1);
+    const size_t wait_cap = 8 * n;
+    a.wait_cap = (uint32_t)wait_cap;
+    a.wait_idx = p; p += wait_cap;
+    a.owner = (int32_t *)p; p += blocks;
+    a.win_run = p; p += wins;
+    a.start = p; p += n;
+    uint32_t *start_excl = p; p += n;
+    a.runid = p; p += n;
+    a.wcount = p; p += n;
+    a.wbegin = p; p += n;
+    a.gstart = p; p += n + 2;
+    a.flags = (uint8_t *)p; p += (n + 3) / 4 + 4;
+    a.result = p; p += 16;
+    size_t cells = 0;
+    for (int c = 0; c < 3; c++) {
+        a.cshift[c] = c == 0 ? 6 : 6 - ((pw[c] > 0 && pw[c] * 2 <= pw[0] + 1) ? 1 : 0); /* the cell is 64x64 LUMA samples */
+        a.cgw[c] = pw[c] > 0 ? (uint32_t)(((pw[c] - 1) >> a.cshift[c]) + 1) : 0;
+        a.cell_off[c] = (uint32_t)cells;
+        if (pw[c] > 0) cells += (size_t)a.cgw[c] * (size_t)(((ph[c] - 1) >> a.cshift[c]) + 1);
+    }
+    a.cell_claim = p; p += cells;
+    a.cell_edges = p; p += cells;
+    a.cell_depth = p; p += cells;
+    a.n_cells = (uint32_t)cells;
+    for (int c = 0; c < 3; c++) a.cgh[c] = pw[c] > 0 ? (uint32_t)(((ph[c] - 1) >> a.cshift[c]) + 1) : 0;
+    a.vals_in = p; p += n;
+    uint32_t *vals_out = p; p += n;
+    a.rank_of = p; p += n;
+    p = (uint32_t *)(((uintptr_t)p + 7) & ~(uintptr_t)7);
+    a.keys_in = (unsigned long long *)p; p += 2 * n;
+    a.keys_out = (unsigned long long *)p; p += 2 * n;
+    void *tmp = (void *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+    /* owner = -1, win_run = ~0: one memset over both; flags, result = 0 */
+    FFHIP_CHECK(hipMemsetAsync(a.owner, 0xff, (blocks + wins) * 4, st), FFHIP_EIO);
+    FFHIP_CHECK(hipMemsetAsync(a.flags, 0, ((n + 3) / 4 + 4 + 16) * 4, st), FFHIP_EIO);
+    FFHIP_CHECK(hipMemsetAsync(a.cell_claim, 0xff, cells * 4, st), FFHIP_EIO);
+    FFHIP_CHECK(hipMemsetAsync(a.cell_edges, 0, 2 * cells * 4, st), FFHIP_EIO);
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_plan_owner, dim3(grid), dim3(256), 0, st, a);
+    if (hipcub::DeviceScan::ExclusiveSum(tmp, scan_tmp, a.start, start_excl, (int)n, st) != hipSuccess) return FFHIP_EIO;
+    hipLaunchKernelGGL(k_plan_runid, dim3(grid), dim3(256), 0, st, a.runid, start_excl, a.start, (uint32_t)n);
+    hipLaunchKernelGGL(k_plan_count, dim3(grid), dim3(256), 0, st, a);
+    if (hipcub::DeviceScan::ExclusiveSum(tmp, scan_tmp, a.wcount, a.wbegin, (int)n, st) != hipSuccess) return FFHIP_EIO;
+    /* tickets: runs sorted by (wavefront key of their cell, decode order) */
+    hipLaunchKernelGGL(k_plan_cell_depth, dim3(3), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(k_plan_keys, dim3(grid), dim3(256), 0, st, a);
+    if (hipcub::DeviceRadixSort::SortPairs(tmp, scan_tmp, a.keys_in, a.keys_out, a.vals_in, vals_out, (int)n, 0, 64, st) != hipSuccess) return FFHIP_EIO;
+    hipLaunchKernelGGL(k_plan_rank, dim3(grid), dim3(256), 0, st, a, (const uint32_t *)vals_out);
+    hipLaunchKernelGGL(k_plan_emit, dim3(grid), dim3(256), 0, st, a);
+    FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
+    uint32_t res[3] = {1, 0, 0};
+    FFHIP_CHECK(hipMemcpyAsync(res, a.result, sizeof res, hipMemcpyDeviceToHost, st), FFHIP_EIO);
+    FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO);
+    if (res[0] || res[2] > wait_cap) return 1; /* not contiguous, too many pollers, or more wait entries than reserved */
+    *sched = a.sched;
+    *groups = a.groups;
+    *wait_idx = a.wait_idx;
+    *n_groups = (int)res[1];
+    return 0;
+}

@@ -69,7 +69,8 @@ def test_every_mode_and_size_isolated():
             assert np.array_equal(got, exp), (lg, i)
 
 
-@pytest.mark.parametrize("env", [{"FFHIP_HEVC_INTRA_MODE": "levels"}, {"FFHIP_HEVC_INTRA_WINDOW": "3"},
+@pytest.mark.parametrize("env", [{"FFHIP_HEVC_INTRA_MODE": "levels"}, {"FFHIP_HEVC_PLAN": "host"}, {"FFHIP_HEVC_PLAN": "host", "FFHIP_HEVC_INTRA_WINDOW": "4"},
+                                 {"FFHIP_HEVC_INTRA_WINDOW": "3"},
                                  {"FFHIP_HEVC_INTRA_WINDOW": "4"}, {"FFHIP_HEVC_INTRA_WINDOW": "5"},
                                  {"FFHIP_HEVC_INTRA_WINDOW": "6"}])
 def test_schedulers_agree(env, monkeypatch):

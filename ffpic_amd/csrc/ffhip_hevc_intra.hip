@@ -10,9 +10,12 @@
  *   construct_pic_pior_to_filtering coding/hevc.c:4252-4274
  *
  * Dependency-bound like every intra decoder: a TU reads reconstructed samples of earlier
- * TUs.  The host walks the list in decode order, gives each TU a wavefront level (1 + the
- * highest level among the 4x4 blocks its available neighbours lie in) and the library
- * launches one kernel per level; a wave owns one TU.  The 4n+1 neighbours live in LDS in
+ * TUs.  Default form: ONE launch, k_hevc_intra_groups (window groups, done flags per TU, see
+ * there), scheduled by the device-side planner of ffhip_hevc_plan_gpu.hip or, for lists it
+ * hands back, by plan_groups below.  Diagnostic form (FFHIP_HEVC_INTRA_MODE=levels): the host
+ * gives each TU a wavefront level (1 + the highest level among the 4x4 blocks its available
+ * neighbours lie in) and launches k_hevc_intra once per level, a wave per TU.
+ * The TU body is the same in both: the 4n+1 neighbours live in LDS in
  * scan order (left column bottom-up, corner, top row left-to-right): in that order the
  * reference's substitution is "nearest available sample at or before me, else the first
  * available one", and its [1 2 1] smoothing is a 3-tap filter with untouched ends.

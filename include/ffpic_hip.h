@@ -324,9 +324,10 @@ typedef struct ffhip_hevc_tu {
                                   block itself, so r += (res_scale * ((r << BitDepthC) >> BitDepthY)) >> 3 */
 /* h_tus / d_tus: the SAME n_tus records on the host (dependency scheduling) and on the device.
  * d_residual: int16 residual blocks (row-major n*n each) as ffhip_hevc_residual_batch writes
- * them.  Planes: int16, strides in samples; d_cb/d_cr may be NULL for 4:0:0.  Synchronises
- * `stream` once (its schedule buffer may be in use), then enqueues ONE launch: TUs grouped by 32x32
- * window, a wave per group, done flags between groups; a bounded wait that ever
+ * them.  Planes: int16, strides in samples; d_cb/d_cr may be NULL for 4:0:0.  Builds the schedule
+ * on the device (synchronising `stream` once to learn whether the list qualifies; h_tus is only
+ * validated), then enqueues ONE launch: TUs grouped by 32x32 window, a wave per group, done flags
+ * between groups; a bounded wait that ever
  * runs out surfaces as FFHIP_EIO from the next ffhip_stream_sync.  FFHIP_HEVC_INTRA_MODE=levels
  * selects the older one-launch-per-dependency-level form.  Scratch is kept per stream, as for VP8. */
 /* Host only, no device needed: the group schedule ffhip_hevc_intra_recon builds for an already valid

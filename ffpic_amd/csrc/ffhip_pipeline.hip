@@ -94,6 +94,19 @@ void copy_out(uint8_t *bgra, int64_t pitch, int64_t image_stride, const uint8_t 
 }
 } // namespace
 
+extern "C" void ffhip_pipeline_release(void)
+{
+    std::lock_guard<std::mutex> lock(g_pipe_mu);
+    for (int s = 0; s < 2; s++) {
+        Slot &sl = g_slot[s];
+        if (sl.st) (void)hipStreamSynchronize(sl.st);
+        (void)hipHostFree(sl.h_y); (void)hipHostFree(sl.h_u); (void)hipHostFree(sl.h_v); (void)hipHostFree(sl.h_q); (void)hipHostFree(sl.h_out);
+        (void)hipFree(sl.d_y); (void)hipFree(sl.d_u); (void)hipFree(sl.d_v); (void)hipFree(sl.d_q); (void)hipFree(sl.d_out);
+        if (sl.st) (void)hipStreamDestroy(sl.st);
+        sl = Slot();
+    }
+}
+
 extern "C" void *ffhip_host_malloc(size_t bytes)
 {
     void *p = nullptr;

@@ -52,7 +52,19 @@ extern "C" int ffhip_init(int device)
     return FFHIP_OK;
 }
 
-extern "C" void ffhip_shutdown(void) { g_ready = 0; }
+extern "C" void ffhip_release_caches(void); /* below: scratch kept per (stage, stream) */
+extern "C" void ffhip_pipeline_release(void); /* ffhip_pipeline.hip: its two slots of pinned + device buffers */
+/* Nothing of the library's may be in flight.  Frees what the library keeps between calls (device scratch, pinned
+ * staging, the pipeline's buffers); the next compute call binds the device again. */
+extern "C" void ffhip_shutdown(void)
+{
+    if (g_ready) {
+        (void)hipDeviceSynchronize();
+        ffhip_pipeline_release();
+        ffhip_release_caches();
+    }
+    g_ready = 0;
+}
 
 /* One pinned, device-visible word that a kernel with an in-launch dependency wait writes when it
  * gives up (its bounded spin ran out); checked and cleared by ffhip_stream_sync. */
@@ -98,6 +110,18 @@ extern "C" uint8_t *ffhip_pinned_scratch(int kind, void *stream, size_t bytes)
         e.second = want;
     }
     return e.first;
+}
+
+extern "C" void ffhip_release_caches(void)
+{
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    for (auto &e : g_scratch)
+        if (e.second.dev) (void)hipFree(e.second.dev);
+    g_scratch.clear();
+    for (auto &e : g_pinned)
+        if (e.second.first) (void)hipHostFree(e.second.first);
+    g_pinned.clear();
+    if (g_async_err) { (void)hipHostFree(g_async_err); g_async_err = nullptr; }
 }
 
 extern "C" uint32_t *ffhip_scratch(int kind, void *stream, size_t words)

@@ -43,7 +43,8 @@ int ffhip_device_count(void);
 /* Bind the calling thread's library state to `device` (hipSetDevice) and create
  * the small internal staging buffers used by the per-block entry points. */
 int ffhip_init(int device);
-void ffhip_shutdown(void);
+void ffhip_shutdown(void); /* with nothing in flight: frees the scratch, staging and pipeline buffers the library keeps
+                              between calls; a later compute call binds the device again */
 const char *ffhip_strerror(int code);
 /* "gfx950" etc. of the bound device, "" if none. */
 const char *ffhip_arch_name(void);

@@ -359,3 +359,18 @@ def test_pipeline_with_device_entropy_forced_on_plain_files(monkeypatch):
     _, out = ops.jpeg_decode_files(files, n_threads=2, chunk=4)
     _, dev, _ = ops.jpeg_decode_files_device(files, n_threads=2)
     assert np.array_equal(out, ref) and np.array_equal(dev, ref)
+
+
+def test_shutdown_releases_and_rebinds():
+    """ffhip_shutdown frees what the library keeps between calls; the next call starts from scratch and is still exact"""
+    L = capi.require_device()
+    data = open(os.path.join(os.path.dirname(__file__), "golden", FILES["q85_420_dri"]), "rb").read()
+    _, a = ops.jpeg_decode_files([data] * 3, n_threads=2)
+    tus, res = synth.hevc_intra_tus(128, 128, 5)
+    ya = ops.hevc_intra_recon(tus, res, 128, 128)[0]
+    L.ffhip_shutdown()
+    L.ffhip_shutdown()                      # idempotent
+    capi.require_device()
+    _, b = ops.jpeg_decode_files([data] * 3, n_threads=2)
+    yb = ops.hevc_intra_recon(tus, res, 128, 128)[0]
+    assert np.array_equal(a, b) and np.array_equal(ya, yb)

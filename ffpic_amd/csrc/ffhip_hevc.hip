@@ -15,9 +15,15 @@
  * receives ready-made (x_a, x_b) int16 pairs for v_dot2_i32_i16; the N-point transform is
  * the recursive even/odd decomposition of the H.265 matrix (N/2-point on the even inputs
  * plus an N/2 x N/2 odd part), all accumulated mod 2^32 like the reference's int.
- * No MFMA: fixed small integer transforms.
+ * That form is used for N = 4, 8, 16.  At N = 32 the butterflies alone cost 14.5 VALU instructions
+ * per sample, more than the HBM rate leaves room for, so the 32x32 TUs go to the matrix cores instead
+ * (k_hevc_residual32_mfma): both 1-D passes are exact int8 x int8 -> int32 products
+ * (v_mfma_i32_32x32x32_i8) of the H.265 matrix (|entries| <= 90) with the int16 data split into a
+ * high and a low byte.
  */
 #include "ffhip_internal.h"
+#include <cstdlib>
+#include <cstring>
 
 #define PK16(lo, hi) ((u32)(uint16_t)(int16_t)(lo) | ((u32)(uint16_t)(int16_t)(hi) << 16))
 
@@ -99,6 +105,7 @@ struct HevcResArgs {
     int16_t *res;          /* [n_tu][N*N]                                                   */
     long long n_tu;
     int bitdepth, epp;
+    int iters; /* batches per wave */
 };
 
 #define TU_DST 1u    /* trType 1: luma intra 4x4 -> idct_4x4_hevc                     */
@@ -106,80 +113,146 @@ struct HevcResArgs {
 #define TU_BYPASS 4u /* cu_transquant_bypass_flag: r = level                          */
 #define TU_ROTATE 8u /* rotateCoeffs (4x4 intra with transform_skip_rotation_enabled) */
 
-__device__ __forceinline__ int clip3i(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int clip3i(int lo, int hi, int v) /* lo <= hi: the median */
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+}
+/* three-operand form (the compiler picks the accumulate-in-place v_dot2c and pays a v_mov to seed it) */
+__device__ __forceinline__ int dot2_seed(u32 a, u32 b, int c)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
+/* clip to [cmin, cmax] and keep the low 16 bits of both, packed; with the 16-bit coefficient range
+ * (NARROW) that is one saturating v_cvt_pk_i16_i32 */
+template <bool NARROW>
+__device__ __forceinline__ u32 clip_pack(int v0, int v1, int cmin, int cmax)
+{
+    if (NARROW) return __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pk_i16(v0, v1));
+    return __builtin_amdgcn_perm((u32)clip3i(cmin, cmax, v1), (u32)clip3i(cmin, cmax, v0), 0x05040100u);
+}
+
+/* hevc.c:3786-3805 on CH consecutive samples of one TU: d = clip3((level * m * levelScale[qP % 6] << (qP / 6)) + rnd >> bdShift).
+ * |level| < 2^15 and m * levelScale <= 255 * 72, so the product is an exact full-rate v_mul_i32_i24; the shift and the
+ * rounding add are one v_lshl_add_u32 (mod 2^32 like the reference's int) */
+template <int CH, bool NARROW, bool FLAT>
+__device__ __forceinline__ void scale_chunk_f(const u32 *raw, u32 *outd, int ls, u32 sh, const uint8_t *mrow, int bd_shift, int cmin,
+                                              int cmax)
+{
+    u32 rnd = 1u << (bd_shift - 1);
+    asm("" : "+v"(rnd)); /* in a VGPR, so that shift + add is one v_lshl_add_u32 (one SGPR operand per instruction) */
+    u32 mraw[CH / 4] = {};
+    if (!FLAT) {
+#pragma unroll
+        for (int i = 0; i < CH / 4; i++) mraw[i] = *(const u32 *)(mrow + 4 * i);
+    }
+    int dv[CH];
+#pragma unroll
+    for (int i = 0; i < CH; i++) {
+        const int lv = (i & 1) ? (int)raw[i >> 1] >> 16 : (int)(short)(raw[i >> 1] & 0xffffu);
+        int f = FLAT ? 16 * ls : __mul24((int)((mraw[i >> 2] >> (8 * (i & 3))) & 0xffu), ls);
+        if (!FLAT) asm("" : "+v"(f)); /* keep (m * ls) * level: the other association needs a 32-bit multiply */
+        dv[i] = (int)(((u32)__mul24(lv, f) << sh) + rnd) >> bd_shift;
+    }
+#pragma unroll
+    for (int i = 0; i < CH / 2; i++) outd[i] = clip_pack<NARROW>(dv[2 * i], dv[2 * i + 1], cmin, cmax);
+}
+template <int CH, bool NARROW>
+__device__ __forceinline__ void scale_chunk(const u32 *raw, u32 *outd, int qP, bool flat, const uint8_t *mrow, int bd_shift,
+                                            int cmin, int cmax)
+{
+    const int ls = qP % 6 == 0 ? 40 : (qP % 6 == 1 ? 45 : (qP % 6 == 2 ? 51 : (qP % 6 == 3 ? 57 : (qP % 6 == 4 ? 64 : 72))));
+    if (!flat) scale_chunk_f<CH, NARROW, false>(raw, outd, ls, qP / 6, mrow, bd_shift, cmin, cmax);
+    else scale_chunk_f<CH, NARROW, true>(raw, outd, ls, qP / 6, mrow, bd_shift, cmin, cmax);
+}
+
+/* What one lane fetches for one batch of 64 rows: NCH chunks of CH consecutive samples + the chunk's TU descriptor */
 template <int N>
+struct ResFetch {
+    static constexpr int CH = N >= 8 ? 8 : 4, NCH = N / CH;
+    u32 raw[NCH][CH / 2];
+    u32 inf[NCH];
+    __device__ __forceinline__ void issue(const HevcResArgs &a, long long tu0, u32 lane)
+    {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const u32 s0 = (64u * c + lane) * CH, tul = s0 / (N * N), pos = s0 % (N * N);
+            long long tuc = tu0 + tul;
+            if (tuc >= a.n_tu) tuc = a.n_tu - 1;
+            inf[c] = *(const u32 *)(a.tuinfo + tuc * 4);
+            if (CH == 8) {
+                const u32x4 v = __builtin_nontemporal_load((const u32x4 *)(a.level + tuc * (N * N) + pos));
+                raw[c][0] = v[0]; raw[c][1] = v[1]; raw[c][CH / 2 - 2] = v[2]; raw[c][CH / 2 - 1] = v[3];
+            } else {
+                const u32x2 v = __builtin_nontemporal_load((const u32x2 *)(a.level + tuc * (N * N) + pos));
+                raw[c][0] = v[0]; raw[c][1] = v[1];
+            }
+        }
+    }
+};
+
+template <int N, bool NARROW>
 __global__ __launch_bounds__(256) void k_hevc_residual(HevcResArgs a)
 {
     constexpr int W = N / 2;          /* dwords per row                       */
-    constexpr int TPW = 64 / N;       /* TUs per wave                         */
+    constexpr int TPW = 64 / N;       /* TUs per wave and batch               */
     constexpr int LOG2N = N == 4 ? 2 : (N == 8 ? 3 : (N == 16 ? 4 : 5));
+    constexpr int CH = ResFetch<N>::CH, NCH = ResFetch<N>::NCH; /* samples per lane per pass, passes */
     __shared__ __attribute__((aligned(16))) char lds_all[4 * 64 * N * 2];
     const u32 lane = threadIdx.x & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char *tile = lds_all + wave * (64 * N * 2);
-    const u32 tu_l = lane / N, idx = lane % N; /* TU within the wave, row (load/store) or column/row (passes) */
-    long long tu = ((long long)blockIdx.x * 4 + wave) * TPW + tu_l;
-    const bool live = tu < a.n_tu;
-    if (!live) tu = a.n_tu - 1; /* keep EXEC full for the transposing reads; stores are masked */
-
-    const u32 info = *(const u32 *)(a.tuinfo + tu * 4);
-    const u32 flags = (info >> 8) & 0xff;
+    const u32 tu_l = lane / N, idx = lane % N; /* TU within the batch, row (load/store) or column/row (passes) */
     const int range = a.epp ? (a.bitdepth + 6 > 15 ? a.bitdepth + 6 : 15) : 15;
     const int cmin = -(1 << range), cmax = (1 << range) - 1;
+    u32 *trow = (u32 *)(tile + (tu_l * N + idx) * (N * 2)); /* this lane's row of its TU */
+    /* transposing reads: 16-lane group gq, lane 4q+p supplies row order[4k+q], 4 columns */
+    const u32 t16 = lane & 15, q = t16 >> 2, p = t16 & 3, g16 = lane >> 4;
+    u32 col_tu, col_x0;
+    if (N >= 16) { col_tu = g16 / (N / 16 > 0 ? N / 16 : 1); col_x0 = 16 * (g16 % (N / 16 > 0 ? N / 16 : 1)) + 4 * p; }
+    else if (N == 8) { col_tu = 2 * g16 + (p >> 1); col_x0 = 4 * (p & 1); }
+    else { col_tu = 4 * g16 + p; col_x0 = 0; }
+    const char *tr_base = tile + col_tu * (N * N * 2) + col_x0 * 2;
+
+    /* A wave works through a.iters batches of 64 rows, the next batch's levels in flight while this one
+     * is transformed (one batch per wave left the kernel bound by wave launches at the small sizes). */
+    const long long wave_tu0 = ((long long)blockIdx.x * 4 + wave) * TPW * a.iters;
+    ResFetch<N> nxt;
+    if (wave_tu0 < a.n_tu) nxt.issue(a, wave_tu0, lane);
+    for (int it = 0; it < a.iters; it++) {
+    const long long tu0 = wave_tu0 + (long long)it * TPW;
+    if (tu0 >= a.n_tu) break;
+    const ResFetch<N> cur = nxt;
+    if (it + 1 < a.iters && tu0 + TPW < a.n_tu) nxt.issue(a, tu0 + TPW, lane);
+    long long tu = tu0 + tu_l;
+    const bool live = tu < a.n_tu;
+    if (!live) tu = a.n_tu - 1; /* keep EXEC full for the transposing reads; stores are masked */
+    const u32 info = *(const u32 *)(a.tuinfo + tu * 4);
+    const u32 flags = (info >> 8) & 0xff;
 
     /* ---- levels -> scaled coefficients d (hevc.c:3786-3805) -> LDS, as a LINEAR copy: lane L of pass c
-     * takes samples (64c + L)*CH .. +CH of the wave's 64 rows, so every load is 16 (8) contiguous bytes
+     * takes samples (64c + L)*CH .. +CH of the batch's 64 rows, so every load is 16 (8) contiguous bytes
      * per lane and the tile in LDS is simply row-major [tu][row][col] ---- */
-    constexpr int CH = N >= 8 ? 8 : 4;  /* samples per lane per pass */
-    constexpr int NCH = N / CH;         /* passes                    */
-    const long long tu0 = ((long long)blockIdx.x * 4 + wave) * TPW;
     bool chunk_store[NCH];              /* does this chunk's TU take the transform path and exist? */
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
         const u32 s0 = (64u * c + lane) * CH, tul = s0 / (N * N), pos = s0 % (N * N);
-        long long tuc = tu0 + tul;
-        const bool livec = tuc < a.n_tu;
-        if (!livec) tuc = a.n_tu - 1;
-        const u32 inf = *(const u32 *)(a.tuinfo + tuc * 4);
+        const u32 inf = cur.inf[c];
         const int qP = inf & 0xff;
         const u32 fl = (inf >> 8) & 0xff, mid = (inf >> 16) & 0xff;
-        chunk_store[c] = livec && !(fl & (TU_BYPASS | TU_TSKIP));
-        u32 raw[CH / 2];
-        if (CH == 8) {
-            const u32x4 v = __builtin_nontemporal_load((const u32x4 *)(a.level + tuc * (N * N) + pos));
-            raw[0] = v[0]; raw[1] = v[1]; raw[CH / 2 - 2] = v[2]; raw[CH / 2 - 1] = v[3];
-        } else {
-            const u32x2 v = __builtin_nontemporal_load((const u32x2 *)(a.level + tuc * (N * N) + pos));
-            raw[0] = v[0]; raw[1] = v[1];
-        }
+        chunk_store[c] = tu0 + tul < a.n_tu && !(fl & (TU_BYPASS | TU_TSKIP));
         u32 outd[CH / 2];
         if (fl & TU_BYPASS) {
 #pragma unroll
-            for (int i = 0; i < CH / 2; i++) outd[i] = raw[i];
+            for (int i = 0; i < CH / 2; i++) outd[i] = cur.raw[c][i];
         } else {
-            const int ls = qP % 6 == 0 ? 40 : (qP % 6 == 1 ? 45 : (qP % 6 == 2 ? 51 : (qP % 6 == 3 ? 57 : (qP % 6 == 4 ? 64 : 72))));
-            const int sh = qP / 6;
-            const int bd_shift = a.bitdepth + LOG2N + 10 - range;
-            const u32 rnd = 1u << (bd_shift - 1);
             const bool flat = a.scaling == nullptr || ((fl & TU_TSKIP) && N > 4);
-            u32 mraw[CH / 4] = {};
-            if (!flat) {
-#pragma unroll
-                for (int i = 0; i < CH / 4; i++) mraw[i] = *(const u32 *)(a.scaling + mid * (N * N) + pos + 4 * i);
-            }
-            int dv[CH];
-#pragma unroll
-            for (int i = 0; i < CH; i++) {
-                const int lv = (i & 1) ? (int)raw[i >> 1] >> 16 : (int)(short)(raw[i >> 1] & 0xffffu);
-                const u32 m = flat ? 16u : (mraw[i >> 2] >> (8 * (i & 3))) & 0xffu;
-                u32 v = (u32)lv * m * (u32)ls;
-                v <<= sh;
-                v += rnd;
-                dv[i] = (int)(short)clip3i(cmin, cmax, (int)v >> bd_shift);
-            }
-#pragma unroll
-            for (int i = 0; i < CH / 2; i++) outd[i] = ((u32)dv[2 * i] & 0xffffu) | ((u32)dv[2 * i + 1] << 16);
+            scale_chunk<CH, NARROW>(cur.raw[c], outd, qP, flat, a.scaling + mid * (N * N) + pos, a.bitdepth + LOG2N + 10 - range,
+                                    cmin, cmax);
         }
         if (CH == 8) {
             u32x4 w;
@@ -191,7 +264,6 @@ __global__ __launch_bounds__(256) void k_hevc_residual(HevcResArgs a)
             *(u32x2 *)(tile + s0 * 2) = w;
         }
     }
-    u32 *trow = (u32 *)(tile + (tu_l * N + idx) * (N * 2)); /* this lane's row of its TU */
     if (__builtin_amdgcn_ballot_w64((flags & (TU_BYPASS | TU_TSKIP)) != 0)) {
         /* no transform for some TU of this wave: r = level, or d << tsShift; optional 180-degree rotation
          * (hevc.c:4209-4236).  Row-per-lane, rare: the row comes back from LDS */
@@ -215,14 +287,6 @@ __global__ __launch_bounds__(256) void k_hevc_residual(HevcResArgs a)
             }
         }
     }
-
-    /* transposing reads: 16-lane group gq, lane 4q+p supplies row order[4k+q], 4 columns */
-    const u32 t16 = lane & 15, q = t16 >> 2, p = t16 & 3, g16 = lane >> 4;
-    u32 col_tu, col_x0;
-    if (N >= 16) { col_tu = g16 / (N / 16 > 0 ? N / 16 : 1); col_x0 = 16 * (g16 % (N / 16 > 0 ? N / 16 : 1)) + 4 * p; }
-    else if (N == 8) { col_tu = 2 * g16 + (p >> 1); col_x0 = 4 * (p & 1); }
-    else { col_tu = 4 * g16 + p; col_x0 = 0; }
-    const char *tr_base = tile + col_tu * (N * N * 2) + col_x0 * 2;
 
     u32 pairs[W];
     int e[N];
@@ -250,8 +314,7 @@ __global__ __launch_bounds__(256) void k_hevc_residual(HevcResArgs a)
      * transposed tile so the second transposing read hands each lane one row of g */
 #pragma unroll
     for (int i = 0; i < W; i++) {
-        const int g0 = clip3i(cmin, cmax, e[2 * i] >> 7), g1 = clip3i(cmin, cmax, e[2 * i + 1] >> 7);
-        trow[i] = ((u32)g0 & 0xffffu) | ((u32)g1 << 16);
+        trow[i] = clip_pack<NARROW>(e[2 * i] >> 7, e[2 * i + 1] >> 7, cmin, cmax);
     }
     /* ---- second stage: rows (hevc.c:3943-3953) ---- */
 #pragma unroll
@@ -280,7 +343,7 @@ __global__ __launch_bounds__(256) void k_hevc_residual(HevcResArgs a)
     }
     /* ---- rows of r -> LDS -> global as the same linear copy (the stage-2 reads were issued before these writes) ---- */
 #pragma unroll
-    for (int i = 0; i < W; i++) trow[i] = ((u32)r[2 * i] & 0xffffu) | ((u32)r[2 * i + 1] << 16);
+    for (int i = 0; i < W; i++) trow[i] = __builtin_amdgcn_perm((u32)r[2 * i + 1], (u32)r[2 * i], 0x05040100u);
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
         const u32 s0 = (64u * c + lane) * CH;
@@ -289,6 +352,309 @@ __global__ __launch_bounds__(256) void k_hevc_residual(HevcResArgs a)
             if (CH == 8) __builtin_nontemporal_store(*(const u32x4 *)(tile + s0 * 2), (u32x4 *)dstp);
             else __builtin_nontemporal_store(*(const u32x2 *)(tile + s0 * 2), (u32x2 *)dstp);
         }
+    }
+    } /* batches */
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * 32x32 TUs on the matrix cores.
+ *
+ * Both passes of hevc.c:3931-3953 are products with the 32x32 H.265 matrix M[k][i] = dct_coef(k, i):
+ *   stage 1 (columns)  e[y][x] = sum_k M[k][y] d[k][x]      g = clip3((e + 64) >> 7)
+ *   stage 2 (rows)     r[y][x'] = (sum_x g[y][x] M[x][x'] + rnd) >> sh2
+ * computed transposed so that the first product's accumulator tile is the second product's operand with
+ * no lane movement (C/D of a 32x32 MFMA: column on the lane, rows 8(i>>2) + 4h + (i&3) in register i,
+ * h = lane >> 5):
+ *   C1[x][y]  = sum_k A1[x][k] B1[k][y],   A1 = d^T (data),  B1 = M
+ *   C2[x'][y] = sum_x A2[x'][x] B2[x][y],  A2 = M^T,         B2 = g^T = clip(C1)   (sums over C1's ROW index)
+ * The sum index of a product may be permuted freely as long as both operands agree, so element j of
+ * lane half h is k = 8(j>>2) + 4h + (j&3) everywhere: that is the order C1 delivers, B1 and A2 become
+ * the SAME four registers (kTab.m), and one ds_read_b64_tr_b16 of the row-major LDS tile fetches four
+ * consecutive j of A1.
+ * int16 data v is fed as two int8 operands: v = 256 hi + lo' + 128 with hi = v >> 8, lo' = (v & 255) - 128
+ * (byte pattern lo ^ 0x80), so sum M v = 256 (M.hi) + (M.lo') + 128 sum M -- two MFMAs per pass, the
+ * constant (plus the rounding term) preloaded as the C operand of the low one.  Every partial sum is
+ * below 2^27: exact.
+ * One wave owns one TU at a time, so the per-TU flags are wave-uniform: transform-skip and bypass TUs
+ * leave straight from the scaling registers.
+ * ------------------------------------------------------------------------------------------------ */
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+struct Mfma32Tab {
+    u32 m[64][4]; /* lane (h, r): byte j = M[8(j>>2) + 4h + (j&3)][r] */
+    int s[32];    /* 128 * sum_k M[k][i]                                */
+    int c2[2][16]; /* s at the rows register i of lane half h holds     */
+};
+constexpr Mfma32Tab make_mfma32_tab()
+{
+    Mfma32Tab t = {};
+    for (int l = 0; l < 64; l++)
+        for (int j = 0; j < 16; j++) {
+            const int k = 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
+            t.m[l][j >> 2] |= (u32)(uint8_t)(int8_t)dct_coef(k, l & 31) << (8 * (j & 3));
+        }
+    for (int i = 0; i < 32; i++) {
+        int sum = 0;
+        for (int k = 0; k < 32; k++) sum += dct_coef(k, i);
+        t.s[i] = 128 * sum;
+    }
+    for (int h = 0; h < 2; h++)
+        for (int i = 0; i < 16; i++) t.c2[h][i] = t.s[8 * (i >> 2) + 4 * h + (i & 3)];
+    return t;
+}
+__device__ const Mfma32Tab kTab = make_mfma32_tab();
+
+/* int16 pairs (j0,j1), (j2,j3) -> the four high bytes, the four low bytes biased by -128 */
+__device__ __forceinline__ void split_bytes(u32 d0, u32 d1, int &hi, int &lo)
+{
+    hi = (int)__builtin_amdgcn_perm(d1, d0, 0x07050301u);
+    lo = (int)(__builtin_amdgcn_perm(d1, d0, 0x06040200u) ^ 0x80808080u);
+}
+
+template <bool NARROW>
+__global__ __launch_bounds__(256) void k_hevc_residual32_mfma(HevcResArgs a)
+{
+    constexpr int N = 32, TPW = 2, OST = 72; /* TUs per wave; byte stride of the output tile's rows (bank spread) */
+    __shared__ __attribute__((aligned(16))) char lds_in[4][TPW][N * N * 2];
+    __shared__ __attribute__((aligned(16))) char lds_out[4][TPW][N * OST];
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const u32 h = lane >> 5, col = lane & 31;
+    const int range = a.epp ? (a.bitdepth + 6 > 15 ? a.bitdepth + 6 : 15) : 15;
+    const int cmin = -(1 << range), cmax = (1 << range) - 1;
+    const int bd_shift = a.bitdepth + 5 + 10 - range;
+    int sh2 = 20 - a.bitdepth;
+    if (a.epp && sh2 < 11) sh2 = 11;
+    if (sh2 < 0) sh2 = 0;
+    const int rnd2 = sh2 > 0 ? 1 << (sh2 - 1) : 0;
+    const v4i mreg = *(const v4i *)kTab.m[lane];
+    v16i c1, c2;
+    {
+        const int s1 = kTab.s[col] + 64;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { c1[i] = s1; c2[i] = kTab.c2[h][i] + rnd2; }
+    }
+    /* transposing read: lane 4q+p of a 16-lane group supplies row 8t + 4h + q, columns 16(g&1) + 4p .. +3 */
+    const u32 t16 = lane & 15, q = t16 >> 2, p = t16 & 3, g16 = lane >> 4;
+    const u32 tr_off = (4 * h + q) * (N * 2) + (16 * (g16 & 1) + 4 * p) * 2;
+
+    /* a.iters batches of TPW TUs per wave, the next batch's levels in flight during this one's transform */
+    const long long wave_tu0 = ((long long)blockIdx.x * 4 + wave) * TPW * a.iters;
+    u32x4 nraw[TPW][2];
+    auto issue = [&](long long t0) {
+#pragma unroll
+        for (int u = 0; u < TPW; u++) {
+            const long long tu = t0 + u < a.n_tu ? t0 + u : a.n_tu - 1;
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+                nraw[u][c] = __builtin_nontemporal_load((const u32x4 *)(a.level + tu * (N * N) + (64u * c + lane) * 8));
+        }
+    };
+    if (wave_tu0 < a.n_tu) issue(wave_tu0);
+    for (int it = 0; it < a.iters; it++) {
+    const long long tu0 = wave_tu0 + (long long)it * TPW;
+    if (tu0 >= a.n_tu) break;
+    u32x4 craw[TPW][2];
+#pragma unroll
+    for (int u = 0; u < TPW; u++) { craw[u][0] = nraw[u][0]; craw[u][1] = nraw[u][1]; }
+    if (it + 1 < a.iters && tu0 + TPW < a.n_tu) issue(tu0 + TPW);
+
+    /* ---- levels (linear 16 B per lane), scaled; transform TUs go to the LDS tile, the others leave ---- */
+    bool xform[TPW];
+#pragma unroll
+    for (int u = 0; u < TPW; u++) {
+        const long long tu = tu0 + u;
+        xform[u] = false;
+        if (tu >= a.n_tu) continue;
+        const u32 inf = *(const u32 *)(a.tuinfo + tu * 4);
+        const int qP = inf & 0xff;
+        const u32 fl = (inf >> 8) & 0xff, mid = (inf >> 16) & 0xff;
+        xform[u] = !(fl & (TU_BYPASS | TU_TSKIP));
+        const bool flat = a.scaling == nullptr || (fl & TU_TSKIP);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const u32 pos = (64u * c + lane) * 8;
+            const u32x4 v = craw[u][c];
+            u32 raw[4] = {v[0], v[1], v[2], v[3]}, outd[4];
+            if (fl & TU_BYPASS) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) outd[i] = raw[i];
+            } else {
+                scale_chunk<8, NARROW>(raw, outd, qP, flat, a.scaling + mid * (N * N) + pos, bd_shift, cmin, cmax);
+            }
+            if (xform[u]) {
+                *(u32x4 *)(lds_in[wave][u] + pos * 2) = u32x4{outd[0], outd[1], outd[2], outd[3]};
+            } else {
+                /* hevc.c:4209-4236: r = level, or d << tsShift; optional 180-degree rotation = the chunk
+                 * reversed at the mirrored position */
+                const int ts = (fl & TU_TSKIP) ? 5 + 5 : 0;
+                u32 o[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int lo = (int)(short)(outd[i] & 0xffffu) << ts, hi = ((int)outd[i] >> 16) << ts;
+                    o[i] = __builtin_amdgcn_perm((u32)hi, (u32)lo, 0x05040100u);
+                }
+                u32x4 w = {o[0], o[1], o[2], o[3]};
+                u32 opos = pos;
+                if (fl & TU_ROTATE) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) w[i] = __builtin_amdgcn_perm(o[3 - i], o[3 - i], 0x01000302u);
+                    opos = N * N - 8 - pos;
+                }
+                __builtin_nontemporal_store(w, (u32x4 *)(a.res + tu * (N * N) + opos));
+            }
+        }
+    }
+
+#pragma unroll
+    for (int u = 0; u < TPW; u++) {
+        if (!xform[u]) continue;
+        const char *tin = lds_in[wave][u];
+        char *tout = lds_out[wave][u];
+        v4i ah, al;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(tin + tr_off + t * 8 * (N * 2)));
+            const u32x2 vv = __builtin_bit_cast(u32x2, v);
+            int hi, lo;
+            split_bytes(vv[0], vv[1], hi, lo);
+            ah[t] = hi;
+            al[t] = lo;
+        }
+        const v16i zero = {};
+        v16i eh = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah, mreg, zero, 0, 0, 0);
+        v16i el = __builtin_amdgcn_mfma_i32_32x32x32_i8(al, mreg, c1, 0, 0, 0);
+        v4i bh, bl;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            u32 g[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int i0 = 4 * t + 2 * j;
+                g[j] = clip_pack<NARROW>(((eh[i0] << 8) + el[i0]) >> 7, ((eh[i0 + 1] << 8) + el[i0 + 1]) >> 7, cmin, cmax);
+            }
+            int hi, lo;
+            split_bytes(g[0], g[1], hi, lo);
+            bh[t] = hi;
+            bl[t] = lo;
+        }
+        eh = __builtin_amdgcn_mfma_i32_32x32x32_i8(mreg, bh, zero, 0, 0, 0);
+        el = __builtin_amdgcn_mfma_i32_32x32x32_i8(mreg, bl, c2, 0, 0, 0);
+        /* register i of this lane is r[y = col][x' = 8(i>>2) + 4h + (i&3)]: four 8-byte pieces of row y */
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            u32x2 w;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int i0 = 4 * t + 2 * j;
+                w[j] = __builtin_amdgcn_perm((u32)(((eh[i0 + 1] << 8) + el[i0 + 1]) >> sh2), (u32)(((eh[i0] << 8) + el[i0]) >> sh2),
+                                             0x05040100u);
+            }
+            *(u32x2 *)(tout + col * OST + (8 * t + 4 * h) * 2) = w;
+        }
+        /* out as the same linear copy */
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const u32 pos = (64u * c + lane) * 8;
+            const char *src = tout + (pos >> 5) * OST + (pos & 31) * 2;
+            const u32x2 w0 = *(const u32x2 *)src, w1 = *(const u32x2 *)(src + 8);
+            __builtin_nontemporal_store(u32x4{w0[0], w0[1], w1[0], w1[1]}, (u32x4 *)(a.res + (tu0 + u) * (N * N) + pos));
+        }
+    }
+    } /* batches */
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * 4x4 TUs: one TU per lane, everything in registers (32 B in, 32 B out per lane, consecutive lanes ->
+ * consecutive TUs, so the wave's traffic is one linear 2 KB stream each way and there is no LDS).
+ * With 64 rows per wave (k_hevc_residual<4>) a lane had four samples per batch and ~60 instructions
+ * of bookkeeping per sample.  Both 4-point transforms are the same eight dot products with the matrix
+ * picked per lane: DCT (hevc.c:3826-3859 rows 0, 8, 16, 24) or DST-VII (idct.c:11-16).
+ * ------------------------------------------------------------------------------------------------ */
+template <bool NARROW>
+__global__ __launch_bounds__(256) void k_hevc_residual4(HevcResArgs a)
+{
+    const int range = a.epp ? (a.bitdepth + 6 > 15 ? a.bitdepth + 6 : 15) : 15;
+    const int cmin = -(1 << range), cmax = (1 << range) - 1;
+    const int bd_shift = a.bitdepth + 2 + 10 - range;
+    int sh2 = 20 - a.bitdepth;
+    if (a.epp && sh2 < 11) sh2 = 11;
+    if (sh2 < 0) sh2 = 0;
+    {
+        const long long tu = (long long)blockIdx.x * 256 + threadIdx.x;
+        if (tu >= a.n_tu) return;
+        const u32x4 v0 = __builtin_nontemporal_load((const u32x4 *)(a.level + tu * 16));
+        const u32x4 v1 = __builtin_nontemporal_load((const u32x4 *)(a.level + tu * 16 + 8));
+        const u32 inf = *(const u32 *)(a.tuinfo + tu * 4);
+        const int qP = inf & 0xff;
+        const u32 fl = (inf >> 8) & 0xff, mid = (inf >> 16) & 0xff;
+        const u32 raw[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        /* scaling (hevc.c:3786-3805), kept as ints d[x + 4y] */
+        const int ls = qP % 6 == 0 ? 40 : (qP % 6 == 1 ? 45 : (qP % 6 == 2 ? 51 : (qP % 6 == 3 ? 57 : (qP % 6 == 4 ? 64 : 72))));
+        const u32 sh = qP / 6;
+        u32 rnd = 1u << (bd_shift - 1);
+        asm("" : "+v"(rnd));
+        int d[16];
+        if (a.scaling) {
+            const u32x4 mv = *(const u32x4 *)(a.scaling + mid * 16);
+            const u32 m[4] = {mv[0], mv[1], mv[2], mv[3]};
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int lv = (i & 1) ? (int)raw[i >> 1] >> 16 : (int)(short)(raw[i >> 1] & 0xffffu);
+                int f = __mul24((int)((m[i >> 2] >> (8 * (i & 3))) & 0xffu), ls);
+                asm("" : "+v"(f));
+                d[i] = (int)(((u32)__mul24(lv, f) << sh) + rnd) >> bd_shift;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int lv = (i & 1) ? (int)raw[i >> 1] >> 16 : (int)(short)(raw[i >> 1] & 0xffffu);
+                d[i] = (int)(((u32)__mul24(lv, 16 * ls) << sh) + rnd) >> bd_shift;
+            }
+        }
+        const bool dst = (fl & TU_DST) != 0;
+        u32 c0[4], c1[4]; /* c0[i] = (M[0][i], M[2][i]), c1[i] = (M[1][i], M[3][i]) */
+        c0[0] = dst ? PK16(29, 84) : PK16(64, 64);   c1[0] = dst ? PK16(74, 55) : PK16(83, 36);
+        c0[1] = dst ? PK16(55, -29) : PK16(64, -64); c1[1] = dst ? PK16(74, -84) : PK16(36, -83);
+        c0[2] = dst ? PK16(74, -74) : PK16(64, -64); c1[2] = dst ? PK16(0, 74) : PK16(-36, 83);
+        c0[3] = dst ? PK16(84, 55) : PK16(64, 64);   c1[3] = dst ? PK16(-74, -29) : PK16(-83, -36);
+        const int rnd1 = dst ? 6 : 64;                                  /* idct.c:31: + (shift - 1), shift 7 */
+        const int rnd2 = dst ? sh2 - 1 : (sh2 > 0 ? 1 << (sh2 - 1) : 0);
+        const int lo2 = dst ? cmin : (int)0x80000000, hi2 = dst ? cmax : 0x7fffffff; /* DST clips both stages */
+        /* first stage, columns: e[c][y] */
+        int e[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const u32 in0 = clip_pack<NARROW>(d[c], d[8 + c], cmin, cmax), in1 = clip_pack<NARROW>(d[4 + c], d[12 + c], cmin, cmax);
+#pragma unroll
+            for (int i = 0; i < 4; i++) e[c][i] = dot2(in0, c0[i], dot2_seed(in1, c1[i], rnd1)) >> 7;
+        }
+        /* second stage, rows */
+        u32 out[8];
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            const u32 in0 = clip_pack<NARROW>(e[0][y], e[2][y], cmin, cmax), in1 = clip_pack<NARROW>(e[1][y], e[3][y], cmin, cmax);
+            int r[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) r[i] = clip3i(lo2, hi2, dot2(in0, c0[i], dot2_seed(in1, c1[i], rnd2)) >> sh2);
+            out[2 * y] = __builtin_amdgcn_perm((u32)r[1], (u32)r[0], 0x05040100u);
+            out[2 * y + 1] = __builtin_amdgcn_perm((u32)r[3], (u32)r[2], 0x05040100u);
+        }
+        if (fl & (TU_BYPASS | TU_TSKIP)) {
+            /* hevc.c:4209-4236: r = level, or d << tsShift (7 at this size); optional 180-degree rotation */
+            u32 o[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const u32 dp = clip_pack<NARROW>(d[2 * i], d[2 * i + 1], cmin, cmax);
+                const int lo = (int)(short)(dp & 0xffffu) << 7, hi = ((int)dp >> 16) << 7;
+                o[i] = (fl & TU_BYPASS) ? raw[i] : __builtin_amdgcn_perm((u32)hi, (u32)lo, 0x05040100u);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) out[i] = (fl & TU_ROTATE) ? __builtin_amdgcn_perm(o[7 - i], o[7 - i], 0x01000302u) : o[i];
+        }
+        __builtin_nontemporal_store(u32x4{out[0], out[1], out[2], out[3]}, (u32x4 *)(a.res + tu * 16));
+        __builtin_nontemporal_store(u32x4{out[4], out[5], out[6], out[7]}, (u32x4 *)(a.res + tu * 16 + 8));
     }
 }
 
@@ -303,17 +669,47 @@ extern "C" int ffhip_hevc_residual_batch(int nTbS, long long n_tu, const int16_t
         ((uintptr_t)d_tuinfo & 3) || ((uintptr_t)d_scaling & 3))
         return FFHIP_EINVAL;
     if (!ffhip_have_device()) return FFHIP_ENODEV;
-    HevcResArgs a = {d_level, d_tuinfo, d_scaling, d_residual, n_tu, bitdepth, epp ? 1 : 0};
-    const long long per_wg = 4LL * (64 / nTbS);
+    HevcResArgs a = {d_level, d_tuinfo, d_scaling, d_residual, n_tu, bitdepth, epp ? 1 : 0, 1};
+    /* the 32x32 TUs take the matrix-core kernel (two TUs per wave); FFHIP_HEVC_RES32=dot keeps them on the butterflies */
+    const char *e32 = getenv("FFHIP_HEVC_RES32"), *e4 = getenv("FFHIP_HEVC_RES4"), *eit = getenv("FFHIP_HEVC_RES_ITERS");
+    const bool mfma32 = !(e32 && !strcmp(e32, "dot"));
+    /* batches of 64 rows per wave: about 2048 samples' worth, fewer when that would leave the chip short of workgroups */
+    const int iters_env = eit ? atoi(eit) : 0;
+    const bool lane4 = !(e4 && !strcmp(e4, "rows")); /* "rows": the 64-rows-per-wave kernel, for A/B */
+    const long long per_batch = nTbS == 32 && mfma32 ? 8 : (nTbS == 4 && lane4 ? 256 : 4LL * (64 / nTbS));
+    int iters = iters_env > 0 ? iters_env : (nTbS == 4 ? 8 : (nTbS == 8 ? 4 : 2));
+    if (nTbS == 4 && lane4) iters = 1; /* a lane's TUs would be 32 B apart: keep the wave's stream linear */
+    while (iters_env <= 0 && iters > 1 && n_tu / (per_batch * iters) < 4096) iters >>= 1;
+    a.iters = iters;
+    const long long per_wg = per_batch * iters;
     const long long wgs = (n_tu + per_wg - 1) / per_wg;
     if (wgs > 0x7fffffffLL) return FFHIP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    const bool narrow = !epp || bitdepth + 6 <= 15; /* coefficient range is 16 bits: clips are saturating packs */
+#define LAUNCH_RES(KERNEL)                                                                      \
+    do {                                                                                        \
+        if (narrow) hipLaunchKernelGGL((KERNEL<true>), dim3((unsigned)wgs), dim3(256), 0, st, a);  \
+        else hipLaunchKernelGGL((KERNEL<false>), dim3((unsigned)wgs), dim3(256), 0, st, a);        \
+    } while (0)
+#define LAUNCH_RESN(NN)                                                                                    \
+    do {                                                                                                   \
+        if (narrow) hipLaunchKernelGGL((k_hevc_residual<NN, true>), dim3((unsigned)wgs), dim3(256), 0, st, a);  \
+        else hipLaunchKernelGGL((k_hevc_residual<NN, false>), dim3((unsigned)wgs), dim3(256), 0, st, a);        \
+    } while (0)
     switch (nTbS) {
-    case 4: hipLaunchKernelGGL(k_hevc_residual<4>, dim3((unsigned)wgs), dim3(256), 0, st, a); break;
-    case 8: hipLaunchKernelGGL(k_hevc_residual<8>, dim3((unsigned)wgs), dim3(256), 0, st, a); break;
-    case 16: hipLaunchKernelGGL(k_hevc_residual<16>, dim3((unsigned)wgs), dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL(k_hevc_residual<32>, dim3((unsigned)wgs), dim3(256), 0, st, a); break;
+    case 4:
+        if (lane4) LAUNCH_RES(k_hevc_residual4);
+        else LAUNCH_RESN(4);
+        break;
+    case 8: LAUNCH_RESN(8); break;
+    case 16: LAUNCH_RESN(16); break;
+    default:
+        if (mfma32) LAUNCH_RES(k_hevc_residual32_mfma);
+        else LAUNCH_RESN(32);
+        break;
     }
+#undef LAUNCH_RES
+#undef LAUNCH_RESN
     FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
     return FFHIP_OK;
 }

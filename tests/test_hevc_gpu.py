@@ -63,3 +63,39 @@ def test_mixed_flags_vs_oracle(n, n_tu):
     for bd, epp, sc in ((8, False, None), (10, False, scaling), (12, True, scaling)):
         got = ops.hevc_residual_batch(n, lv, info, bitdepth=bd, epp=epp, scaling=sc)
         assert np.array_equal(got, oracle_tus(n, lv, info, bd, epp, sc)), (bd, epp, sc is not None)
+
+
+@pytest.mark.parametrize("env", [{"FFHIP_HEVC_RES_ITERS": "3"}, {"FFHIP_HEVC_RES32": "dot", "FFHIP_HEVC_RES4": "rows"},
+                                 {"FFHIP_HEVC_RES32": "dot", "FFHIP_HEVC_RES4": "rows", "FFHIP_HEVC_RES_ITERS": "2"}])
+@pytest.mark.parametrize("n,n_tu", [(4, 777), (8, 203), (16, 101), (32, 51)])
+def test_kernel_variants_agree(env, n, n_tu, monkeypatch):
+    """Several batches per wave (with the ragged tail inside a wave's run), and the butterfly / rows kernels the
+    32x32 and 4x4 sizes no longer use by default."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(n + n_tu)
+    lv = rng.integers(-32768, 32768, size=(n_tu, n * n)).astype(np.int16)
+    lv[1::2] = np.rint(rng.laplace(0, 6, size=lv[1::2].shape)).astype(np.int16)
+    info = np.zeros((n_tu, 4), np.uint8)
+    info[:, 0] = rng.integers(0, 52, size=n_tu)
+    info[:, 1] = rng.choice([0, 0, 0, 0, 2, 4] + ([1, 1, 2 | 8, 4 | 8] if n == 4 else []), size=n_tu)
+    info[:, 2] = rng.integers(0, 6, size=n_tu)
+    scaling = rng.integers(1, 256, size=(6, n * n)).astype(np.uint8)
+    for bd, epp, sc in ((8, False, scaling), (12, True, None)):
+        got = ops.hevc_residual_batch(n, lv, info, bitdepth=bd, epp=epp, scaling=sc)
+        assert np.array_equal(got, oracle_tus(n, lv, info, bd, epp, sc)), (bd, epp)
+
+
+def test_extreme_coefficients_32():
+    """The 32x32 matrix-core path splits int16 data into bytes: saturated inputs of both signs, every qP."""
+    n = 32
+    pats = [np.full(n * n, 32767), np.full(n * n, -32768), np.where(np.arange(n * n) % 2, 32767, -32768),
+            np.where((np.arange(n * n) // n) % 2, -32768, 32767), np.eye(n).ravel() * 32767, np.full(n * n, 255), np.full(n * n, -256),
+            np.full(n * n, 128), np.full(n * n, -129)]
+    lv = np.stack(pats).astype(np.int16)
+    lv = np.concatenate([lv] * 6)
+    info = np.zeros((lv.shape[0], 4), np.uint8)
+    info[:, 0] = np.repeat(np.array([0, 5, 17, 30, 44, 51], np.uint8), len(pats))
+    for bd, epp in ((8, False), (10, False), (16, True)):
+        got = ops.hevc_residual_batch(n, lv, info, bitdepth=bd, epp=epp)
+        assert np.array_equal(got, oracle_tus(n, lv, info, bd, epp, None)), (bd, epp)

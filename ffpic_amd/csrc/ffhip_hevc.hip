@@ -33,6 +33,21 @@ __device__ __forceinline__ int dot2(u32 a, u32 b, int c)
 {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
 }
+/* Heads of a dot-product chain.  The compiler's choice, the accumulate-in-place v_dot2c (it takes the
+ * coefficient pair as a literal), costs a v_mov to seed every chain; the three-operand form with the
+ * coefficients in an SGPR starts from the inline 0 or from a register that holds the rounding term. */
+__device__ __forceinline__ int dot2_head0(u32 a, u32 coef)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "s"(coef));
+    return r;
+}
+__device__ __forceinline__ int dot2_head(u32 a, u32 coef, int seed)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(coef), "v"(seed));
+    return r;
+}
 
 /* H.265 8.6.4.2: transMatrix[j][i] = c((2i+1) j mod 128), c(n) tabulated for n = 0..32 and
  * extended by c(64-n) = -c(n), c(64+n) = -c(n) */
@@ -69,9 +84,9 @@ struct InvDct {
         constexpr int s = 32 / N;
 #pragma unroll
         for (int i = 0; i < N / 2; i++) {
-            int o = 0;
+            int o = dot2_head0(in[N / 4], PK16(dct_coef(1 * s, i), dct_coef(3 * s, i)));
 #pragma unroll
-            for (int k = 0; k < N / 4; k++) /* odd inputs x[4k+1], x[4k+3] */
+            for (int k = 1; k < N / 4; k++) /* odd inputs x[4k+1], x[4k+3] */
                 o = dot2(in[N / 4 + k], PK16(dct_coef((4 * k + 1) * s, i), dct_coef((4 * k + 3) * s, i)), o);
             out[i] = e[i] + o;
             out[N - 1 - i] = e[i] - o;
@@ -83,8 +98,8 @@ struct InvDct<4> {
     static __device__ __forceinline__ void run(const u32 *in, int *out, int rnd)
     {
         /* in[0] = (x0, x2), in[1] = (x1, x3); matrix rows 0, 8, 16, 24 */
-        const int e0 = dot2(in[0], PK16(64, 64), rnd), e1 = dot2(in[0], PK16(64, -64), rnd);
-        const int o0 = dot2(in[1], PK16(83, 36), 0), o1 = dot2(in[1], PK16(36, -83), 0);
+        const int e0 = dot2_head(in[0], PK16(64, 64), rnd), e1 = dot2_head(in[0], PK16(64, -64), rnd);
+        const int o0 = dot2_head0(in[1], PK16(83, 36)), o1 = dot2_head0(in[1], PK16(36, -83));
         out[0] = e0 + o0; out[1] = e1 + o1; out[2] = e1 - o1; out[3] = e0 - o0;
     }
 };
@@ -176,8 +191,14 @@ struct ResFetch {
     static constexpr int CH = N >= 8 ? 8 : 4, NCH = N / CH;
     u32 raw[NCH][CH / 2];
     u32 inf[NCH];
+    u32 tinf; /* the descriptor of TU tu0 + lane / N: the lane's TU in the two passes */
     __device__ __forceinline__ void issue(const HevcResArgs &a, long long tu0, u32 lane)
     {
+        {
+            long long tu = tu0 + lane / N;
+            if (tu >= a.n_tu) tu = a.n_tu - 1;
+            tinf = *(const u32 *)(a.tuinfo + tu * 4);
+        }
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             const u32 s0 = (64u * c + lane) * CH, tul = s0 / (N * N), pos = s0 % (N * N);
@@ -231,8 +252,7 @@ __global__ __launch_bounds__(256) void k_hevc_residual(HevcResArgs a)
     long long tu = tu0 + tu_l;
     const bool live = tu < a.n_tu;
     if (!live) tu = a.n_tu - 1; /* keep EXEC full for the transposing reads; stores are masked */
-    const u32 info = *(const u32 *)(a.tuinfo + tu * 4);
-    const u32 flags = (info >> 8) & 0xff;
+    const u32 flags = (cur.tinf >> 8) & 0xff;
 
     /* ---- levels -> scaled coefficients d (hevc.c:3786-3805) -> LDS, as a LINEAR copy: lane L of pass c
      * takes samples (64c + L)*CH .. +CH of the batch's 64 rows, so every load is 16 (8) contiguous bytes
@@ -442,10 +462,12 @@ __global__ __launch_bounds__(256) void k_hevc_residual32_mfma(HevcResArgs a)
     /* a.iters batches of TPW TUs per wave, the next batch's levels in flight during this one's transform */
     const long long wave_tu0 = ((long long)blockIdx.x * 4 + wave) * TPW * a.iters;
     u32x4 nraw[TPW][2];
+    u32 ninf[TPW];
     auto issue = [&](long long t0) {
 #pragma unroll
         for (int u = 0; u < TPW; u++) {
             const long long tu = t0 + u < a.n_tu ? t0 + u : a.n_tu - 1;
+            ninf[u] = *(const u32 *)(a.tuinfo + tu * 4);
 #pragma unroll
             for (int c = 0; c < 2; c++)
                 nraw[u][c] = __builtin_nontemporal_load((const u32x4 *)(a.level + tu * (N * N) + (64u * c + lane) * 8));
@@ -456,8 +478,9 @@ __global__ __launch_bounds__(256) void k_hevc_residual32_mfma(HevcResArgs a)
     const long long tu0 = wave_tu0 + (long long)it * TPW;
     if (tu0 >= a.n_tu) break;
     u32x4 craw[TPW][2];
+    u32 cinf[TPW];
 #pragma unroll
-    for (int u = 0; u < TPW; u++) { craw[u][0] = nraw[u][0]; craw[u][1] = nraw[u][1]; }
+    for (int u = 0; u < TPW; u++) { craw[u][0] = nraw[u][0]; craw[u][1] = nraw[u][1]; cinf[u] = ninf[u]; }
     if (it + 1 < a.iters && tu0 + TPW < a.n_tu) issue(tu0 + TPW);
 
     /* ---- levels (linear 16 B per lane), scaled; transform TUs go to the LDS tile, the others leave ---- */
@@ -467,7 +490,7 @@ __global__ __launch_bounds__(256) void k_hevc_residual32_mfma(HevcResArgs a)
         const long long tu = tu0 + u;
         xform[u] = false;
         if (tu >= a.n_tu) continue;
-        const u32 inf = *(const u32 *)(a.tuinfo + tu * 4);
+        const u32 inf = (u32)__builtin_amdgcn_readfirstlane((int)cinf[u]);
         const int qP = inf & 0xff;
         const u32 fl = (inf >> 8) & 0xff, mid = (inf >> 16) & 0xff;
         xform[u] = !(fl & (TU_BYPASS | TU_TSKIP));
@@ -658,6 +681,141 @@ __global__ __launch_bounds__(256) void k_hevc_residual4(HevcResArgs a)
     }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * 16x16 TUs on the matrix cores: the same scheme with v_mfma_i32_16x16x32_i8.  C/D there is "column on
+ * the lane, rows 4g + i in register i" (g = lane >> 4), so element j < 4 of lane group g is sum index
+ * 4g + j in every operand and elements 4..7 (the upper half of the K = 32 the instruction offers) are
+ * zero bytes in the data operand.  A wave takes 64 rows = four TUs per batch like k_hevc_residual<16>
+ * (same linear copies, same prefetch), then runs the TUs one after the other through the four MFMAs.
+ * ------------------------------------------------------------------------------------------------ */
+struct Mfma16Tab {
+    u32 m[64]; /* lane (g, r): byte j = M16[4g + j][r]   */
+    int s[16]; /* 128 * sum_k M16[k][i]                   */
+};
+constexpr Mfma16Tab make_mfma16_tab()
+{
+    Mfma16Tab t = {};
+    for (int l = 0; l < 64; l++)
+        for (int j = 0; j < 4; j++) t.m[l] |= (u32)(uint8_t)(int8_t)dct_coef(2 * (4 * (l >> 4) + j), l & 15) << (8 * j);
+    for (int i = 0; i < 16; i++) {
+        int sum = 0;
+        for (int k = 0; k < 16; k++) sum += dct_coef(2 * k, i);
+        t.s[i] = 128 * sum;
+    }
+    return t;
+}
+__device__ const Mfma16Tab kTab16 = make_mfma16_tab();
+
+template <bool NARROW>
+__global__ __launch_bounds__(256) void k_hevc_residual16_mfma(HevcResArgs a)
+{
+    constexpr int N = 16, TPW = 4, OST = 40; /* TUs per batch; byte stride of the output tile's rows */
+    constexpr int CH = 8, NCH = 2;
+    __shared__ __attribute__((aligned(16))) char lds_in[4][TPW * N * N * 2];
+    __shared__ __attribute__((aligned(16))) char lds_out[4][TPW * N * OST];
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *tin = lds_in[wave], *tout = lds_out[wave];
+    const u32 g = lane >> 4, col = lane & 15;
+    const int range = a.epp ? (a.bitdepth + 6 > 15 ? a.bitdepth + 6 : 15) : 15;
+    const int cmin = -(1 << range), cmax = (1 << range) - 1;
+    const int bd_shift = a.bitdepth + 4 + 10 - range;
+    int sh2 = 20 - a.bitdepth;
+    if (a.epp && sh2 < 11) sh2 = 11;
+    if (sh2 < 0) sh2 = 0;
+    const int rnd2 = sh2 > 0 ? 1 << (sh2 - 1) : 0;
+    const long mreg = (long)(unsigned long)kTab16.m[lane]; /* upper four bytes: the unused half of K */
+    v4i c1, c2;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { c1[i] = kTab16.s[col] + 64; c2[i] = kTab16.s[4 * g + i] + rnd2; }
+    /* transposing read: lane 4q+p of 16-lane group g supplies row 4g + q, columns 4p .. 4p+3 */
+    const u32 q = (lane & 15) >> 2, p = lane & 3;
+    const u32 tr_off = (4 * g + q) * (N * 2) + 4 * p * 2;
+
+    const long long wave_tu0 = ((long long)blockIdx.x * 4 + wave) * TPW * a.iters;
+    ResFetch<N> nxt;
+    if (wave_tu0 < a.n_tu) nxt.issue(a, wave_tu0, lane);
+    for (int it = 0; it < a.iters; it++) {
+        const long long tu0 = wave_tu0 + (long long)it * TPW;
+        if (tu0 >= a.n_tu) break;
+        const ResFetch<N> cur = nxt;
+        if (it + 1 < a.iters && tu0 + TPW < a.n_tu) nxt.issue(a, tu0 + TPW, lane);
+        /* ---- levels (linear 16 B per lane), scaled; transform TUs go to the LDS tile, the others leave ---- */
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const u32 s0 = (64u * c + lane) * CH, tul = s0 / (N * N), pos = s0 % (N * N);
+            const u32 inf = cur.inf[c];
+            const int qP = inf & 0xff;
+            const u32 fl = (inf >> 8) & 0xff, mid = (inf >> 16) & 0xff;
+            u32 outd[4];
+            if (fl & TU_BYPASS) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) outd[i] = cur.raw[c][i];
+            } else {
+                const bool flat = a.scaling == nullptr || (fl & TU_TSKIP);
+                scale_chunk<CH, NARROW>(cur.raw[c], outd, qP, flat, a.scaling + mid * (N * N) + pos, bd_shift, cmin, cmax);
+            }
+            if (!(fl & (TU_BYPASS | TU_TSKIP))) {
+                *(u32x4 *)(tin + s0 * 2) = u32x4{outd[0], outd[1], outd[2], outd[3]};
+            } else if (tu0 + tul < a.n_tu) {
+                /* hevc.c:4209-4236: r = level, or d << tsShift; optional 180-degree rotation = the chunk reversed at the mirrored position */
+                const int ts = (fl & TU_TSKIP) ? 5 + 4 : 0;
+                u32 o[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int lo = (int)(short)(outd[i] & 0xffffu) << ts, hi = ((int)outd[i] >> 16) << ts;
+                    o[i] = __builtin_amdgcn_perm((u32)hi, (u32)lo, 0x05040100u);
+                }
+                u32x4 w = {o[0], o[1], o[2], o[3]};
+                u32 opos = pos;
+                if (fl & TU_ROTATE) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) w[i] = __builtin_amdgcn_perm(o[3 - i], o[3 - i], 0x01000302u);
+                    opos = N * N - 8 - pos;
+                }
+                __builtin_nontemporal_store(w, (u32x4 *)(a.res + (tu0 + tul) * (N * N) + opos));
+            }
+        }
+        /* ---- the four TUs, unconditionally (a TU that does not take the transform leaves stale numbers in its
+         * part of the output tile, which is then not stored): four independent MFMA chains to interleave.  A TU's
+         * flags are wave-uniform here and already in a register: chunk u/2, lanes 32(u&1).. ---- */
+        bool xform[TPW];
+#pragma unroll
+        for (int u = 0; u < TPW; u++) {
+            const u32 inf = (u32)__builtin_amdgcn_readlane((int)cur.inf[u >> 1], (u & 1) * 32);
+            xform[u] = tu0 + u < a.n_tu && !((inf >> 8) & (TU_BYPASS | TU_TSKIP));
+            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(tin + u * (N * N * 2) + tr_off));
+            const u32x2 vv = __builtin_bit_cast(u32x2, v);
+            int hi, lo;
+            split_bytes(vv[0], vv[1], hi, lo);
+            const v4i zero = {};
+            v4i eh = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)(unsigned long)(u32)hi, mreg, zero, 0, 0, 0);
+            v4i el = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)(unsigned long)(u32)lo, mreg, c1, 0, 0, 0);
+            const u32 g0 = clip_pack<NARROW>(((eh[0] << 8) + el[0]) >> 7, ((eh[1] << 8) + el[1]) >> 7, cmin, cmax);
+            const u32 g1 = clip_pack<NARROW>(((eh[2] << 8) + el[2]) >> 7, ((eh[3] << 8) + el[3]) >> 7, cmin, cmax);
+            split_bytes(g0, g1, hi, lo);
+            eh = __builtin_amdgcn_mfma_i32_16x16x32_i8(mreg, (long)(unsigned long)(u32)hi, zero, 0, 0, 0);
+            el = __builtin_amdgcn_mfma_i32_16x16x32_i8(mreg, (long)(unsigned long)(u32)lo, c2, 0, 0, 0);
+            /* register i of this lane is r[y = col][x' = 4g + i]: one 8-byte piece of row y */
+            u32x2 w;
+            w[0] = __builtin_amdgcn_perm((u32)(((eh[1] << 8) + el[1]) >> sh2), (u32)(((eh[0] << 8) + el[0]) >> sh2), 0x05040100u);
+            w[1] = __builtin_amdgcn_perm((u32)(((eh[3] << 8) + el[3]) >> sh2), (u32)(((eh[2] << 8) + el[2]) >> sh2), 0x05040100u);
+            *(u32x2 *)(tout + (u * N + col) * OST + 4 * g * 2) = w;
+        }
+        /* ---- out as the same linear copy ---- */
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const u32 s0 = (64u * c + lane) * CH, tul = s0 / (N * N), pos = s0 % (N * N);
+            const bool st = tul == 0 ? xform[0] : (tul == 1 ? xform[1] : (tul == 2 ? xform[2] : xform[3]));
+            if (st) {
+                const char *src = tout + (tul * N + (pos >> 4)) * OST + (pos & 15) * 2;
+                const u32x2 w0 = *(const u32x2 *)src, w1 = *(const u32x2 *)(src + 8);
+                __builtin_nontemporal_store(u32x4{w0[0], w0[1], w1[0], w1[1]}, (u32x4 *)(a.res + (tu0 + tul) * (N * N) + pos));
+            }
+        }
+    }
+}
+
 extern "C" int ffhip_hevc_residual_batch(int nTbS, long long n_tu, const int16_t *d_level, const uint8_t *d_tuinfo,
                                          const uint8_t *d_scaling, int bitdepth, int epp, int16_t *d_residual,
                                          void *stream)
@@ -671,7 +829,9 @@ extern "C" int ffhip_hevc_residual_batch(int nTbS, long long n_tu, const int16_t
     if (!ffhip_have_device()) return FFHIP_ENODEV;
     HevcResArgs a = {d_level, d_tuinfo, d_scaling, d_residual, n_tu, bitdepth, epp ? 1 : 0, 1};
     /* the 32x32 TUs take the matrix-core kernel (two TUs per wave); FFHIP_HEVC_RES32=dot keeps them on the butterflies */
-    const char *e32 = getenv("FFHIP_HEVC_RES32"), *e4 = getenv("FFHIP_HEVC_RES4"), *eit = getenv("FFHIP_HEVC_RES_ITERS");
+    const char *e32 = getenv("FFHIP_HEVC_RES32"), *e16 = getenv("FFHIP_HEVC_RES16"), *e4 = getenv("FFHIP_HEVC_RES4"),
+               *eit = getenv("FFHIP_HEVC_RES_ITERS");
+    const bool mfma16 = !(e16 && !strcmp(e16, "dot"));
     const bool mfma32 = !(e32 && !strcmp(e32, "dot"));
     /* batches of 64 rows per wave: about 2048 samples' worth, fewer when that would leave the chip short of workgroups */
     const int iters_env = eit ? atoi(eit) : 0;
@@ -702,7 +862,10 @@ extern "C" int ffhip_hevc_residual_batch(int nTbS, long long n_tu, const int16_t
         else LAUNCH_RESN(4);
         break;
     case 8: LAUNCH_RESN(8); break;
-    case 16: LAUNCH_RESN(16); break;
+    case 16:
+        if (mfma16) LAUNCH_RES(k_hevc_residual16_mfma);
+        else LAUNCH_RESN(16);
+        break;
     default:
         if (mfma32) LAUNCH_RES(k_hevc_residual32_mfma);
         else LAUNCH_RESN(32);

@@ -65,8 +65,8 @@ def test_mixed_flags_vs_oracle(n, n_tu):
         assert np.array_equal(got, oracle_tus(n, lv, info, bd, epp, sc)), (bd, epp, sc is not None)
 
 
-@pytest.mark.parametrize("env", [{"FFHIP_HEVC_RES_ITERS": "3"}, {"FFHIP_HEVC_RES32": "dot", "FFHIP_HEVC_RES4": "rows"},
-                                 {"FFHIP_HEVC_RES32": "dot", "FFHIP_HEVC_RES4": "rows", "FFHIP_HEVC_RES_ITERS": "2"}])
+@pytest.mark.parametrize("env", [{"FFHIP_HEVC_RES_ITERS": "3"}, {"FFHIP_HEVC_RES32": "dot", "FFHIP_HEVC_RES16": "dot", "FFHIP_HEVC_RES4": "rows"},
+                                 {"FFHIP_HEVC_RES32": "dot", "FFHIP_HEVC_RES16": "dot", "FFHIP_HEVC_RES4": "rows", "FFHIP_HEVC_RES_ITERS": "2"}])
 @pytest.mark.parametrize("n,n_tu", [(4, 777), (8, 203), (16, 101), (32, 51)])
 def test_kernel_variants_agree(env, n, n_tu, monkeypatch):
     """Several batches per wave (with the ragged tail inside a wave's run), and the butterfly / rows kernels the
@@ -78,7 +78,9 @@ def test_kernel_variants_agree(env, n, n_tu, monkeypatch):
     lv[1::2] = np.rint(rng.laplace(0, 6, size=lv[1::2].shape)).astype(np.int16)
     info = np.zeros((n_tu, 4), np.uint8)
     info[:, 0] = rng.integers(0, 52, size=n_tu)
-    info[:, 1] = rng.choice([0, 0, 0, 0, 2, 4] + ([1, 1, 2 | 8, 4 | 8] if n == 4 else []), size=n_tu)
+    info[:, 1] = rng.choice([0, 0, 0, 0, 2, 4, 2 | 8, 4 | 8] + ([1, 1] if n == 4 else []), size=n_tu)
+    if n != 4:
+        info[:, 1] &= ~np.uint8(8)
     info[:, 2] = rng.integers(0, 6, size=n_tu)
     scaling = rng.integers(1, 256, size=(6, n * n)).astype(np.uint8)
     for bd, epp, sc in ((8, False, scaling), (12, True, None)):

@@ -14,19 +14,29 @@ st = torch.cuda.current_stream().cuda_stream
 e0, e1 = L.ffhip_event_create(), L.ffhip_event_create()
 
 def timeit(fn, reps=20):
-    for _ in range(3): fn()
+    for _ in range(20): fn()
     L.ffhip_event_record(e0, st)
     for _ in range(reps): fn()
     L.ffhip_event_record(e1, st)
     return L.ffhip_event_elapsed_ms(e0, e1) / reps
 
+# the first ~50 ms of GPU work in a process run at lower clocks: spin before timing anything
+_w = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+for _ in range(400): _w.add_(1)
+torch.cuda.synchronize()
 out = {"FFHIP_HEVC_RES32": os.environ.get("FFHIP_HEVC_RES32", "mfma")}
-for n, cnt in ((32, 4 * 240 * 135), (16, 4 * 480 * 270), (8, 4 * 960 * 540), (4, 4 * 1920 * 1080)):
+ORDER = [int(x) for x in os.environ.get("RES_ORDER", "32,16,8,4,32,16,8,4").split(",")]
+# every size is visited twice with fresh tensors and the better pass is kept: the very first buffers a process
+# allocates have measured up to 15 % slower than the same kernel on buffers the caching allocator hands out later
+for n in ORDER:
+    cnt = 4 * (7680 // n) * (4320 // n)
     lvl = torch.randint(-20, 21, (cnt, n * n), device=dev).to(torch.int16)
     info = torch.zeros((cnt, 4), dtype=torch.uint8, device=dev); info[:, 0] = 27
     res = torch.empty_like(lvl)
     sc = torch.randint(1, 256, (6, n * n), device=dev).to(torch.uint8)
     for tag, scp, bd, epp in (("flat_8bit", None, 8, 0), ("list_10bit", sc.data_ptr(), 10, 0), ("flat_12bit_epp", None, 12, 1)):
         ms = timeit(lambda: capi.check(L.ffhip_hevc_residual_batch(n, cnt, lvl.data_ptr(), info.data_ptr(), scp, bd, epp, res.data_ptr(), st)))
-        out[f"{n}x{n}_{tag}"] = {"ms": round(ms, 4), "GB/s": round(4 * cnt * n * n / ms / 1e6, 1)}
+        key = f"{n}x{n}_{tag}"
+        if key not in out or ms < out[key]["ms"]:
+            out[key] = {"ms": round(ms, 4), "GB/s": round(4 * cnt * n * n / ms / 1e6, 1)}
 print(json.dumps(out))

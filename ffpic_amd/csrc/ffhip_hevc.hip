@@ -7,19 +7,21 @@
  *   idct_4x4_hevc (luma intra 4x4) utils/idct.c:9-55, with its `+ (shift-1)` rounding
  *   transform-skip / bypass glue   coding/hevc.c:4209-4236
  *
- * HBM-bound: 2 B of levels in + 2 B of residual out per sample.  A wave holds 64/N TUs = 64 rows.
- * Levels come in and residuals go out as linear 16-byte-per-lane copies through the wave's LDS tile
- * (a row per lane would make every load a 64-lane gather with a 2N-byte stride: 1.5 TB/s at N = 32);
- * in between one lane owns one column (then one row) for the two 1-D passes.  The transposes go through LDS with ds_read_b64_tr_b16, whose
- * row order is the bit-reversal-like order of the partial butterflies so each lane
- * receives ready-made (x_a, x_b) int16 pairs for v_dot2_i32_i16; the N-point transform is
- * the recursive even/odd decomposition of the H.265 matrix (N/2-point on the even inputs
- * plus an N/2 x N/2 odd part), all accumulated mod 2^32 like the reference's int.
- * That form is used for N = 4, 8, 16.  At N = 32 the butterflies alone cost 14.5 VALU instructions
- * per sample, more than the HBM rate leaves room for, so the 32x32 TUs go to the matrix cores instead
- * (k_hevc_residual32_mfma): both 1-D passes are exact int8 x int8 -> int32 products
- * (v_mfma_i32_32x32x32_i8) of the H.265 matrix (|entries| <= 90) with the int16 data split into a
- * high and a low byte.
+ * HBM-bound: 2 B of levels in + 2 B of residual out per sample.  Levels come in and residuals go out as
+ * linear 16-byte-per-lane copies through the wave's LDS tile (a row per lane would make every load a
+ * 64-lane gather with a 2N-byte stride: 1.5 TB/s at N = 32).
+ *
+ * Default kernels:
+ *   32x32, 16x16, 8x8  k_hevc_residual{32,16,8}_mfma: both 1-D passes as exact int8 x int8 -> int32 MFMA
+ *                      products of the H.265 matrix (|entries| <= 90) with the int16 data split into a
+ *                      high and a low byte; the first pass's accumulator tile is the second pass's operand
+ *   4x4                k_hevc_residual4: one TU per lane in registers (DCT or DST-VII picked per lane)
+ * Earlier form, kept for A/B runs (FFHIP_HEVC_RES32/16/8=dot, FFHIP_HEVC_RES4=rows) and tested alike:
+ *   k_hevc_residual<N>: a wave holds 64 rows = 64/N TUs, one lane owns one column (then one row); the
+ *   transposes go through LDS with ds_read_b64_tr_b16, whose row order is the bit-reversal-like order of
+ *   the partial butterflies so each lane receives ready-made (x_a, x_b) int16 pairs for v_dot2_i32_i16;
+ *   the N-point transform is the recursive even/odd decomposition of the H.265 matrix (N/2-point on the
+ *   even inputs plus an N/2 x N/2 odd part), all accumulated mod 2^32 like the reference's int.
  */
 #include "ffhip_internal.h"
 #include <cstdlib>
@@ -816,6 +818,141 @@ __global__ __launch_bounds__(256) void k_hevc_residual16_mfma(HevcResArgs a)
     }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * 8x8 TUs on the matrix cores, four to one 16x16 MFMA.  Number the four TUs (p, q), p, q in {0, 1};
+ * output row m = (p, x), output column n = (q, y), and the sum runs over 16 slots (q', k):
+ *   stage 1  A1[(p,x)][(q',k)] = d_pq'[k][x]            B1[(q',k)][(q,y)] = [q' == q] M8[k][y]
+ *   stage 2  A2[(p,x')][(p',x)] = [p' == p] M8[x][x']   B2[(p',x)][(q,y)] = g_p'q[x][y]
+ * so C1[(p,x)][(q,y)] = sum_k d_pq[k][x] M8[k][y] and C2[(p,x')][(q,y)] = sum_x M8[x][x'] g_pq[x][y]:
+ * all 256 outputs are wanted ones.  C/D keeps rows 4g + i of column n in lane group g, i.e. slot
+ * (g >> 1, 4(g & 1) + i): that is the slot order of every operand (bytes 4..7 of each lane, the upper
+ * half of the instruction's K = 32, are zero in the data operands), and B1 and A2 are again the same
+ * register.  The LDS tile keeps TUs (0, q') and (1, q') side by side as rows of 16 so that one
+ * ds_read_b64_tr_b16 per lane fetches the A1 operand.
+ * ------------------------------------------------------------------------------------------------ */
+struct Mfma8Tab {
+    u32 m[64]; /* lane (g, r): byte j = [(r >> 3) == (g >> 1)] M8[4(g & 1) + j][r & 7] */
+    int s[8];  /* 128 * sum_k M8[k][i] */
+};
+constexpr Mfma8Tab make_mfma8_tab()
+{
+    Mfma8Tab t = {};
+    for (int l = 0; l < 64; l++)
+        for (int j = 0; j < 4; j++) {
+            const int g = l >> 4, r = l & 15;
+            const int v = (r >> 3) == (g >> 1) ? dct_coef(4 * (4 * (g & 1) + j), r & 7) : 0;
+            t.m[l] |= (u32)(uint8_t)(int8_t)v << (8 * j);
+        }
+    for (int i = 0; i < 8; i++) {
+        int sum = 0;
+        for (int k = 0; k < 8; k++) sum += dct_coef(4 * k, i);
+        t.s[i] = 128 * sum;
+    }
+    return t;
+}
+__device__ const Mfma8Tab kTab8 = make_mfma8_tab();
+
+template <bool NARROW>
+__global__ __launch_bounds__(256) void k_hevc_residual8_mfma(HevcResArgs a)
+{
+    constexpr int N = 8, TPW = 8, OST = 24; /* TUs per batch; byte stride of the output tile's 16-byte rows */
+    constexpr int CH = 8;
+    __shared__ __attribute__((aligned(16))) char lds_in[4][TPW * N * N * 2];
+    __shared__ __attribute__((aligned(16))) char lds_out[4][TPW * N * OST];
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *tin = lds_in[wave], *tout = lds_out[wave];
+    const u32 g = lane >> 4, r = lane & 15;
+    const int range = a.epp ? (a.bitdepth + 6 > 15 ? a.bitdepth + 6 : 15) : 15;
+    const int cmin = -(1 << range), cmax = (1 << range) - 1;
+    const int bd_shift = a.bitdepth + 3 + 10 - range;
+    int sh2 = 20 - a.bitdepth;
+    if (a.epp && sh2 < 11) sh2 = 11;
+    if (sh2 < 0) sh2 = 0;
+    const int rnd2 = sh2 > 0 ? 1 << (sh2 - 1) : 0;
+    const long mreg = (long)(unsigned long)kTab8.m[lane];
+    v4i c1, c2;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { c1[i] = kTab8.s[r & 7] + 64; c2[i] = kTab8.s[4 * (g & 1) + i] + rnd2; }
+    /* A TU of the batch is t = 4h + 2q + p (h: which MFMA).  Chunk = one row: lane L holds row L & 7 of TU L >> 3,
+     * written to [h][q][k][p * 8 ..] */
+    const u32 lt = lane >> 3, lk = lane & 7;
+    const u32 in_off = ((lt >> 2) * 512) + (((lt >> 1) & 1) * 256) + lk * 32 + (lt & 1) * 16;
+    /* transposing read: lane 4qq+pp of 16-lane group g supplies row 4(g & 1) + qq of pair q' = g >> 1, columns 4pp .. */
+    const u32 qq = (lane & 15) >> 2, pp = lane & 3;
+    const u32 tr_off = (g >> 1) * 256 + (4 * (g & 1) + qq) * 32 + 4 * pp * 2;
+    /* result: lane (g, n = (q, y)) holds r[y][x' = 4(g & 1) + i] of TU (p = g >> 1, q): 8 bytes of row y */
+    const u32 out_off = ((2 * (r >> 3) + (g >> 1)) * N + (r & 7)) * OST + 4 * (g & 1) * 2; /* + h * 4 * N * OST */
+    const u32 lin_out = (lt * N + lk) * OST;
+
+    const long long wave_tu0 = ((long long)blockIdx.x * 4 + wave) * TPW * a.iters;
+    ResFetch<N> nxt;
+    if (wave_tu0 < a.n_tu) nxt.issue(a, wave_tu0, lane);
+    for (int it = 0; it < a.iters; it++) {
+        const long long tu0 = wave_tu0 + (long long)it * TPW;
+        if (tu0 >= a.n_tu) break;
+        const ResFetch<N> cur = nxt;
+        if (it + 1 < a.iters && tu0 + TPW < a.n_tu) nxt.issue(a, tu0 + TPW, lane);
+        const u32 inf = cur.inf[0];
+        const int qP = inf & 0xff;
+        const u32 fl = (inf >> 8) & 0xff, mid = (inf >> 16) & 0xff;
+        const bool live = tu0 + lt < a.n_tu;
+        const bool xf = !(fl & (TU_BYPASS | TU_TSKIP));
+        u32 outd[4];
+        if (fl & TU_BYPASS) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) outd[i] = cur.raw[0][i];
+        } else {
+            const bool flat = a.scaling == nullptr || (fl & TU_TSKIP);
+            scale_chunk<CH, NARROW>(cur.raw[0], outd, qP, flat, a.scaling + mid * (N * N) + lk * 8, bd_shift, cmin, cmax);
+        }
+        if (xf) {
+            *(u32x4 *)(tin + in_off) = u32x4{outd[0], outd[1], outd[2], outd[3]};
+        } else if (live) {
+            /* hevc.c:4209-4236: r = level, or d << tsShift; optional 180-degree rotation = the row reversed at the mirrored position */
+            const int ts = (fl & TU_TSKIP) ? 5 + 3 : 0;
+            u32 o[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int lo = (int)(short)(outd[i] & 0xffffu) << ts, hi = ((int)outd[i] >> 16) << ts;
+                o[i] = __builtin_amdgcn_perm((u32)hi, (u32)lo, 0x05040100u);
+            }
+            u32x4 w = {o[0], o[1], o[2], o[3]};
+            u32 opos = lk * 8;
+            if (fl & TU_ROTATE) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) w[i] = __builtin_amdgcn_perm(o[3 - i], o[3 - i], 0x01000302u);
+                opos = N * N - 8 - opos;
+            }
+            __builtin_nontemporal_store(w, (u32x4 *)(a.res + (tu0 + lt) * (N * N) + opos));
+        }
+        /* ---- two MFMA groups of four TUs; TUs that do not take the transform leave stale numbers that are not stored ---- */
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(tin + h * 512 + tr_off));
+            const u32x2 vv = __builtin_bit_cast(u32x2, v);
+            int hi, lo;
+            split_bytes(vv[0], vv[1], hi, lo);
+            const v4i zero = {};
+            v4i eh = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)(unsigned long)(u32)hi, mreg, zero, 0, 0, 0);
+            v4i el = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)(unsigned long)(u32)lo, mreg, c1, 0, 0, 0);
+            const u32 g0 = clip_pack<NARROW>(((eh[0] << 8) + el[0]) >> 7, ((eh[1] << 8) + el[1]) >> 7, cmin, cmax);
+            const u32 g1 = clip_pack<NARROW>(((eh[2] << 8) + el[2]) >> 7, ((eh[3] << 8) + el[3]) >> 7, cmin, cmax);
+            split_bytes(g0, g1, hi, lo);
+            eh = __builtin_amdgcn_mfma_i32_16x16x32_i8(mreg, (long)(unsigned long)(u32)hi, zero, 0, 0, 0);
+            el = __builtin_amdgcn_mfma_i32_16x16x32_i8(mreg, (long)(unsigned long)(u32)lo, c2, 0, 0, 0);
+            u32x2 w;
+            w[0] = __builtin_amdgcn_perm((u32)(((eh[1] << 8) + el[1]) >> sh2), (u32)(((eh[0] << 8) + el[0]) >> sh2), 0x05040100u);
+            w[1] = __builtin_amdgcn_perm((u32)(((eh[3] << 8) + el[3]) >> sh2), (u32)(((eh[2] << 8) + el[2]) >> sh2), 0x05040100u);
+            *(u32x2 *)(tout + h * (4 * N * OST) + out_off) = w;
+        }
+        if (xf && live) {
+            const u32x2 w0 = *(const u32x2 *)(tout + lin_out), w1 = *(const u32x2 *)(tout + lin_out + 8);
+            __builtin_nontemporal_store(u32x4{w0[0], w0[1], w1[0], w1[1]}, (u32x4 *)(a.res + (tu0 + lt) * (N * N) + lk * 8));
+        }
+    }
+}
+
 extern "C" int ffhip_hevc_residual_batch(int nTbS, long long n_tu, const int16_t *d_level, const uint8_t *d_tuinfo,
                                          const uint8_t *d_scaling, int bitdepth, int epp, int16_t *d_residual,
                                          void *stream)
@@ -829,8 +966,9 @@ extern "C" int ffhip_hevc_residual_batch(int nTbS, long long n_tu, const int16_t
     if (!ffhip_have_device()) return FFHIP_ENODEV;
     HevcResArgs a = {d_level, d_tuinfo, d_scaling, d_residual, n_tu, bitdepth, epp ? 1 : 0, 1};
     /* the 32x32 TUs take the matrix-core kernel (two TUs per wave); FFHIP_HEVC_RES32=dot keeps them on the butterflies */
-    const char *e32 = getenv("FFHIP_HEVC_RES32"), *e16 = getenv("FFHIP_HEVC_RES16"), *e4 = getenv("FFHIP_HEVC_RES4"),
-               *eit = getenv("FFHIP_HEVC_RES_ITERS");
+    const char *e32 = getenv("FFHIP_HEVC_RES32"), *e16 = getenv("FFHIP_HEVC_RES16"), *e8 = getenv("FFHIP_HEVC_RES8"),
+               *e4 = getenv("FFHIP_HEVC_RES4"), *eit = getenv("FFHIP_HEVC_RES_ITERS");
+    const bool mfma8 = !(e8 && !strcmp(e8, "dot"));
     const bool mfma16 = !(e16 && !strcmp(e16, "dot"));
     const bool mfma32 = !(e32 && !strcmp(e32, "dot"));
     /* batches of 64 rows per wave: about 2048 samples' worth, fewer when that would leave the chip short of workgroups */
@@ -861,7 +999,10 @@ extern "C" int ffhip_hevc_residual_batch(int nTbS, long long n_tu, const int16_t
         if (lane4) LAUNCH_RES(k_hevc_residual4);
         else LAUNCH_RESN(4);
         break;
-    case 8: LAUNCH_RESN(8); break;
+    case 8:
+        if (mfma8) LAUNCH_RES(k_hevc_residual8_mfma);
+        else LAUNCH_RESN(8);
+        break;
     case 16:
         if (mfma16) LAUNCH_RES(k_hevc_residual16_mfma);
         else LAUNCH_RESN(16);

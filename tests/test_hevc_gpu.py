@@ -65,8 +65,8 @@ def test_mixed_flags_vs_oracle(n, n_tu):
         assert np.array_equal(got, oracle_tus(n, lv, info, bd, epp, sc)), (bd, epp, sc is not None)
 
 
-@pytest.mark.parametrize("env", [{"FFHIP_HEVC_RES_ITERS": "3"}, {"FFHIP_HEVC_RES32": "dot", "FFHIP_HEVC_RES16": "dot", "FFHIP_HEVC_RES4": "rows"},
-                                 {"FFHIP_HEVC_RES32": "dot", "FFHIP_HEVC_RES16": "dot", "FFHIP_HEVC_RES4": "rows", "FFHIP_HEVC_RES_ITERS": "2"}])
+@pytest.mark.parametrize("env", [{"FFHIP_HEVC_RES_ITERS": "3"}, {"FFHIP_HEVC_RES32": "dot", "FFHIP_HEVC_RES16": "dot", "FFHIP_HEVC_RES8": "dot", "FFHIP_HEVC_RES4": "rows"},
+                                 {"FFHIP_HEVC_RES32": "dot", "FFHIP_HEVC_RES16": "dot", "FFHIP_HEVC_RES8": "dot", "FFHIP_HEVC_RES4": "rows", "FFHIP_HEVC_RES_ITERS": "2"}])
 @pytest.mark.parametrize("n,n_tu", [(4, 777), (8, 203), (16, 101), (32, 51)])
 def test_kernel_variants_agree(env, n, n_tu, monkeypatch):
     """Several batches per wave (with the ragged tail inside a wave's run), and the butterfly / rows kernels the

@@ -607,11 +607,26 @@ __global__ __launch_bounds__(256) void k_hevc_residual4(HevcResArgs a)
     if (a.epp && sh2 < 11) sh2 = 11;
     if (sh2 < 0) sh2 = 0;
     {
-        const long long tu = (long long)blockIdx.x * 256 + threadIdx.x;
-        if (tu >= a.n_tu) return;
-        const u32x4 v0 = __builtin_nontemporal_load((const u32x4 *)(a.level + tu * 16));
-        const u32x4 v1 = __builtin_nontemporal_load((const u32x4 *)(a.level + tu * 16 + 8));
+        /* the wave's 64 TUs are one 2 KB run: two linear 1 KB loads (16 B per lane), then each lane takes its TU's
+         * 32 bytes back from LDS -- a direct 32-byte-stride load uses half of every 64-byte segment per instruction */
+        __shared__ __attribute__((aligned(16))) char lds4[4][64 * 32];
+        const u32 lane = threadIdx.x & 63;
+        char *tile = lds4[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+        const long long wtu0 = (long long)blockIdx.x * 256 + (threadIdx.x & ~63u);
+        if (wtu0 >= a.n_tu) return;
+        const long long n_samples = a.n_tu * 16;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const long long s0 = wtu0 * 16 + (64 * c + lane) * 8;
+            u32x4 v = {};
+            if (s0 < n_samples) v = __builtin_nontemporal_load((const u32x4 *)(a.level + s0));
+            *(u32x4 *)(tile + (64 * c + lane) * 16) = v;
+        }
+        long long tu = wtu0 + lane;
+        const bool live = tu < a.n_tu;
+        if (!live) tu = a.n_tu - 1;
         const u32 inf = *(const u32 *)(a.tuinfo + tu * 4);
+        const u32x4 v0 = *(const u32x4 *)(tile + lane * 32), v1 = *(const u32x4 *)(tile + lane * 32 + 16);
         const int qP = inf & 0xff;
         const u32 fl = (inf >> 8) & 0xff, mid = (inf >> 16) & 0xff;
         const u32 raw[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -678,8 +693,14 @@ __global__ __launch_bounds__(256) void k_hevc_residual4(HevcResArgs a)
 #pragma unroll
             for (int i = 0; i < 8; i++) out[i] = (fl & TU_ROTATE) ? __builtin_amdgcn_perm(o[7 - i], o[7 - i], 0x01000302u) : o[i];
         }
-        __builtin_nontemporal_store(u32x4{out[0], out[1], out[2], out[3]}, (u32x4 *)(a.res + tu * 16));
-        __builtin_nontemporal_store(u32x4{out[4], out[5], out[6], out[7]}, (u32x4 *)(a.res + tu * 16 + 8));
+        *(u32x4 *)(tile + lane * 32) = u32x4{out[0], out[1], out[2], out[3]};
+        *(u32x4 *)(tile + lane * 32 + 16) = u32x4{out[4], out[5], out[6], out[7]};
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const long long s0 = wtu0 * 16 + (64 * c + lane) * 8;
+            const u32x4 v = *(const u32x4 *)(tile + (64 * c + lane) * 16);
+            if (s0 < n_samples) __builtin_nontemporal_store(v, (u32x4 *)(a.res + s0));
+        }
     }
 }
 

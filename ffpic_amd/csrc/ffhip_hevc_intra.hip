@@ -64,24 +64,52 @@ __device__ __forceinline__ void wave_sync()
 __device__ __forceinline__ int clip3i(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 
-__device__ static const signed char kAngle[33] = {32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
-                                                  -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32};
-__device__ static const short kInvAngle[15] = {-4096, -1638, -910, -630, -482, -390, -315, -256,
-                                               -315, -390, -482, -630, -910, -1638, -4096};
+/* intraPredAngle and invAngle of 8.4.4.2.6 (the tables of format/predict.c) as ALU work on the wave-uniform mode:
+ * a table in memory put a dependent global load (the angle) in front of every angular TU's reference gather and a
+ * second one (the inverse angle) in front of its extension.  |angle| depends on the distance d of the mode from the
+ * nearest of the pure directions 10 (horizontal) and 26 (vertical): {0, 2, 5, 9, 13, 17, 21, 26, 32}, positive on the
+ * outer sides (modes 2-9 and 27-34); invAngle = -round(8192 / |angle|) for d = 1..8. */
+__device__ __forceinline__ int intra_angle(int mode)
+{
+    const int d = mode < 18 ? (mode < 10 ? 10 - mode : mode - 10) : (mode < 26 ? 26 - mode : mode - 26);
+    const unsigned long long mag = 0ull | (2ull << 6) | (5ull << 12) | (9ull << 18) | (13ull << 24) | (17ull << 30) | (21ull << 36) |
+                                   (26ull << 42) | (32ull << 48);
+    const int m = (int)((mag >> (6 * d)) & 63);
+    return (mode < 10 || mode > 26) ? m : -m;
+}
+__device__ __forceinline__ int intra_inv_angle(int mode) /* modes 11..25 */
+{
+    const int d = mode < 18 ? mode - 10 : 26 - mode; /* 1..8 */
+    const unsigned long long lo = 4096ull | (1638ull << 13) | (910ull << 26) | (630ull << 39);
+    const unsigned long long hi = 482ull | (390ull << 13) | (315ull << 26) | (256ull << 39);
+    const unsigned long long w = d <= 4 ? lo >> (13 * (d - 1)) : hi >> (13 * (d - 5));
+    return -(int)(w & 8191);
+}
 
 #define NB_MAX 132 /* 4*32 + 1, padded */
 
 #define TILE_STRIDE 66 /* shorts per row of the grouped form's window tile: 33 dwords, so a column walk hits 32 different banks */
 
-/* the residual block of a TU, element lane + 64 j in rr[j] (fetched one TU ahead in the grouped form) */
-__device__ __forceinline__ void fetch_residual(const HevcIntraArgs &a, const ffhip_hevc_tu &t, const int lane, short (&rr)[16])
+/* The residual block of a TU, fetched one TU ahead in the grouped form: samples 8 lane + 512 j .. +7 in v[j], as
+ * 16-byte loads into registers of their own.  (The first form took one short per lane and pass into a short[16]:
+ * the compiler packs two shorts to a VGPR, so every load was followed by s_waitcnt vmcnt(0) and a v_perm -- up to
+ * sixteen exposed memory latencies per TU instead of a prefetch.)  Blocks that are not 16-byte aligned in
+ * d_residual (odd offsets; no decoder lays residuals out like that) are read when they are used. */
+struct ResPrefetch {
+    u32x4 v[2];
+    bool wide; /* wave-uniform: v[] holds the block */
+};
+__device__ __forceinline__ void fetch_residual(const HevcIntraArgs &a, const ffhip_hevc_tu &t, const int lane, ResPrefetch &rp)
 {
+    rp.wide = false;
     if (!(t.flags & 2)) return;
     const int nn = 1 << (2 * t.log2_size);
     const int16_t *src = a.residual + t.res_offset;
+    if (((uintptr_t)src & 15) != 0) return;
+    rp.wide = true;
 #pragma unroll
-    for (int j = 0; j < 16; j++)
-        if (64 * j < nn) rr[j] = lane + 64 * j < nn ? src[lane + 64 * j] : (short)0;
+    for (int j = 0; j < 2; j++)
+        if (8 * lane + 512 * j < nn) rp.v[j] = *(const u32x4 *)(src + 8 * lane + 512 * j);
 }
 
 /* One TU by one wave: steps 5-10 of decode_intra_block.  s, s2: NB_MAX ints each; refbase: 140 ints;
@@ -90,7 +118,7 @@ __device__ __forceinline__ void fetch_residual(const HevcIntraArgs &a, const ffh
  * (origin wx0, wy0, size 1 << wl) come from / go to the wave's LDS copy `tile` when tile_ok. */
 template <bool GROUPED, int LG> /* LG = log2 of the TU size: every loop below has a compile-time trip count */
 __device__ __forceinline__ void intra_tu(const HevcIntraArgs &a, const ffhip_hevc_tu &t, const int lane, int *s, int *s2,
-                                         int *refbase, short *R, const short (&rr)[16], short *tile, const int wl,
+                                         int *refbase, short *R, const ResPrefetch &rp, short *tile, const int wl,
                                          const bool tile_ok)
 {
     const int wx0 = GROUPED ? (t.x >> wl) << wl : 0, wy0 = GROUPED ? (t.y >> wl) << wl : 0, wsz = GROUPED ? 1 << wl : 0;
@@ -189,9 +217,14 @@ __device__ __forceinline__ void intra_tu(const HevcIntraArgs &a, const ffhip_hev
     /* ---- residual (with the optional rdpcm accumulation of 8.6.5) ---- */
     const bool has_res = (flags & 2) != 0;
     if (has_res) {
+        if (rp.wide) {
 #pragma unroll
-        for (int j = 0; j < 16; j++)
-            if (64 * j < n * n && lane + 64 * j < n * n) R[lane + 64 * j] = rr[j];
+            for (int j = 0; j < 2; j++)
+                if (512 * j < n * n && 8 * lane + 512 * j < n * n) *(u32x4 *)(R + 8 * lane + 512 * j) = rp.v[j];
+        } else {
+            const int16_t *src = a.residual + t.res_offset;
+            for (int i = lane; i < n * n; i += 64) R[i] = src[i];
+        }
         wave_sync();
         if (flags & 0x40) {
             if (mode / 26 == 0) {
@@ -245,14 +278,14 @@ __device__ __forceinline__ void intra_tu(const HevcIntraArgs &a, const ffhip_hev
         for (int i = 0; i < n; i++) sum += (unsigned)U16(LEFT(i)) + (unsigned)U16(TOP(i));
         dc = (int)((sum + (1u << lg)) >> (lg + 1));
     } else if (mode >= 2) {
-        angle = kAngle[mode - 2];
+        angle = intra_angle(mode);
         /* ref[] of 8.4.4.2.6: main = top for modes >= 18, left otherwise; both start at the corner */
         for (int xx = lane; xx <= 2 * n; xx += 64) {
             if (xx == 0) ref[0] = U16(TOP(-1));
             else if (xx <= n || angle >= 0) ref[xx] = mode >= 18 ? U16(TOP(xx - 1)) : U16(LEFT(xx - 1));
         }
         if (angle < 0 && ((n * angle) >> 5) < -1) {
-            const int lo = (angle * n) >> 5, inv = kInvAngle[mode - 11];
+            const int lo = (angle * n) >> 5, inv = intra_inv_angle(mode);
             for (int xx = -1 - lane; xx >= lo; xx -= 64) {
                 const int k = (xx * inv + 128) >> 8;
                 ref[xx] = k == 0 ? U16(TOP(-1)) : (mode >= 18 ? U16(LEFT(k - 1)) : U16(TOP(k - 1)));
@@ -302,14 +335,14 @@ __device__ __forceinline__ void intra_tu(const HevcIntraArgs &a, const ffhip_hev
 
 template <bool GROUPED>
 __device__ __forceinline__ void intra_tu_any(const HevcIntraArgs &a, const ffhip_hevc_tu &t, const int lane, int *s, int *s2,
-                                             int *refbase, short *R, const short (&rr)[16], short *tile, const int wl,
+                                             int *refbase, short *R, const ResPrefetch &rp, short *tile, const int wl,
                                              const bool tile_ok)
 {
     switch (t.log2_size) {
-    case 2: intra_tu<GROUPED, 2>(a, t, lane, s, s2, refbase, R, rr, tile, wl, tile_ok); break;
-    case 3: intra_tu<GROUPED, 3>(a, t, lane, s, s2, refbase, R, rr, tile, wl, tile_ok); break;
-    case 4: intra_tu<GROUPED, 4>(a, t, lane, s, s2, refbase, R, rr, tile, wl, tile_ok); break;
-    default: intra_tu<GROUPED, 5>(a, t, lane, s, s2, refbase, R, rr, tile, wl, tile_ok); break;
+    case 2: intra_tu<GROUPED, 2>(a, t, lane, s, s2, refbase, R, rp, tile, wl, tile_ok); break;
+    case 3: intra_tu<GROUPED, 3>(a, t, lane, s, s2, refbase, R, rp, tile, wl, tile_ok); break;
+    case 4: intra_tu<GROUPED, 4>(a, t, lane, s, s2, refbase, R, rp, tile, wl, tile_ok); break;
+    default: intra_tu<GROUPED, 5>(a, t, lane, s, s2, refbase, R, rp, tile, wl, tile_ok); break;
     }
 }
 
@@ -317,14 +350,14 @@ __device__ __forceinline__ void intra_tu_any(const HevcIntraArgs &a, const ffhip
 __global__ __launch_bounds__(256) void k_hevc_intra(HevcIntraArgs a)
 {
     __shared__ int nbA[4][NB_MAX], nbB[4][NB_MAX], refs[4][140];
-    __shared__ short resl[4][32 * 32];
+    __shared__ __attribute__((aligned(16))) short resl[4][32 * 32];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int item = blockIdx.x * 4 + w;
     if (item >= a.count) return;
     const ffhip_hevc_tu t = a.tus[a.work[item]];
-    short rr[16];
-    fetch_residual(a, t, lane, rr);
-    intra_tu_any<false>(a, t, lane, nbA[w], nbB[w], refs[w], resl[w], rr, nullptr, 0, false);
+    ResPrefetch rp;
+    fetch_residual(a, t, lane, rp);
+    intra_tu_any<false>(a, t, lane, nbA[w], nbB[w], refs[w], resl[w], rp, nullptr, 0, false);
 }
 
 /* Grouped form: ONE launch per picture.  The host cuts the TU list into groups -- the TUs whose
@@ -371,7 +404,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
 {
     __shared__ short tile[64 * TILE_STRIDE];
     __shared__ int nbA[NB_MAX], nbB[NB_MAX], refs[140];
-    __shared__ short resl[2][32 * 32];
+    __shared__ __attribute__((aligned(16))) short resl[2][32 * 32];
     __shared__ u32x4 slots[SLOT_CHUNK * 3];
     const int lane = threadIdx.x;
     uint32_t *flags = a.ctrl + 4;
@@ -387,11 +420,14 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
             for (int i = lane; i < 3 * m; i += 64) slots[i] = a.sched[(size_t)(g.x + base) * 3 + i];
             wave_sync();
             IntraSlot cur = read_slot(slots, 0);
-            short rr[16];
-            fetch_residual(a, cur.t, lane, rr);
+            ResPrefetch rp;
+            fetch_residual(a, cur.t, lane, rp);
+            /* which flag this lane polls for the TU: fetched with the slot, one TU ahead like the residual (fetched at
+             * the wait it was a dependent load in front of the first poll of every cross-group hop) */
+            uint32_t widx = cur.wait_count ? a.wait_idx[cur.wait_begin + (lane < (int)cur.wait_count ? lane : 0)] : 0;
             for (int k = 0; k < m; k++) {
                 if (cur.wait_count) { /* wait for the TUs of other groups this one reads (at most 33 of them) */
-                    const uint32_t *fp = flags + a.wait_idx[cur.wait_begin + (lane < (int)cur.wait_count ? lane : 0)];
+                    const uint32_t *fp = flags + widx;
                     int spins = 0;
                     for (;;) {
                         const unsigned done = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -414,7 +450,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* ordering only: no cache-wide invalidate */
                 }
-                intra_tu_any<true>(a, cur.t, lane, nbA, nbB, refs, resl[k & 1], rr, tile, wl, cur.tile_ok != 0);
+                intra_tu_any<true>(a, cur.t, lane, nbA, nbB, refs, resl[k & 1], rp, tile, wl, cur.tile_ok != 0);
                 if (cur.signal) { /* somebody outside the group reads this TU: publish it once its stores have completed */
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* compiler ordering; no L2-wide write-back */
                     /* the fence alone lowers to s_waitcnt lgkmcnt(0): the flag must not overtake the sample stores
@@ -429,7 +465,8 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                     /* issued behind this TU's stores and consumed half-way into the next TU: the in-order
                      * vmcnt wait there then covers nothing younger than this fetch */
                     cur = read_slot(slots, k + 1);
-                    fetch_residual(a, cur.t, lane, rr);
+                    fetch_residual(a, cur.t, lane, rp);
+                    if (cur.wait_count) widx = a.wait_idx[cur.wait_begin + (lane < (int)cur.wait_count ? lane : 0)];
                 }
             }
             wave_sync(); /* slots[] is about to be overwritten */

@@ -86,6 +86,11 @@ __device__ __forceinline__ int intra_inv_angle(int mode) /* modes 11..25 */
     return -(int)(w & 8191);
 }
 
+/* `for (i = lane; i < LIMIT; i += 64)` with a compile-time LIMIT as a fixed number of predicated passes: the
+ * loop form costs a compare, an exec-mask update and a branch per pass on the scalar unit, which a lone wave
+ * (one instruction per ~9 cycles) feels; 32x32 blocks keep the loop where the passes are many */
+#define LANE_PASSES(LIMIT) (((LIMIT) + 63) / 64)
+
 #define NB_MAX 132 /* 4*32 + 1, padded */
 
 #define TILE_STRIDE 66 /* shorts per row of the grouped form's window tile: 33 dwords, so a column walk hits 32 different banks */
@@ -151,7 +156,10 @@ __device__ __forceinline__ void intra_tu(const HevcIntraArgs &a, const ffhip_hev
     /* ---- 1. gather + 2. substitute, in one pass: in scan order the substitution of 8.4.4.2.2 is
      * "the nearest available sample at or before me, else the first available one", so each
      * lane works out WHICH sample it wants from the masks alone and fetches that one ---- */
-    for (int i = lane; i < cnt; i += 64) {
+#pragma unroll
+    for (int pass = 0; pass < LANE_PASSES(cnt); pass++) {
+        const int i = lane + 64 * pass;
+        if (i >= cnt) break;
         int j = i;
         if (n_avail < cnt && n_avail > 0) {
             j = -1;
@@ -197,7 +205,10 @@ __device__ __forceinline__ void intra_tu(const HevcIntraArgs &a, const ffhip_hev
                             iabs(TOP(-1) + TOP(2 * n - 1) - 2 * TOP(n - 1)) < (1 << (a.bitdepth_y - 5)) &&
                             iabs(TOP(-1) + LEFT(2 * n - 1) - 2 * LEFT(n - 1)) < (1 << (a.bitdepth_y - 5));
             const int corner = TOP(-1), l63 = bi ? LEFT(63) : 0, t63 = bi ? TOP(63) : 0;
-            for (int i = lane; i < cnt; i += 64) {
+#pragma unroll
+            for (int pass = 0; pass < LANE_PASSES(cnt); pass++) {
+                const int i = lane + 64 * pass;
+                if (i >= cnt) break;
                 int v;
                 if (bi) {
                     if (i < 2 * n) { const int y = 2 * n - 1 - i; v = y == 63 ? l63 : (corner * (63 - y) + (y + 1) * l63 + 32) >> 6; }
@@ -261,6 +272,7 @@ __device__ __forceinline__ void intra_tu(const HevcIntraArgs &a, const ffhip_hev
         }
         if (flags & 0x80) { /* 8.6.6 with rY aliased to r, as at hevc.c:4753-4755; products wrap like -fwrapv */
             const int bdc = a.bitdepth_c, bdy = a.bitdepth_y;
+#pragma unroll 4
             for (int i = lane; i < n * n; i += 64) {
                 const int up = (int)((unsigned)(int)R[i] << bdc) >> bdy;
                 R[i] = (short)(R[i] + ((int)((unsigned)t.res_scale * (unsigned)up) >> 3));
@@ -280,13 +292,17 @@ __device__ __forceinline__ void intra_tu(const HevcIntraArgs &a, const ffhip_hev
     } else if (mode >= 2) {
         angle = intra_angle(mode);
         /* ref[] of 8.4.4.2.6: main = top for modes >= 18, left otherwise; both start at the corner */
-        for (int xx = lane; xx <= 2 * n; xx += 64) {
+#pragma unroll
+        for (int pass = 0; pass < LANE_PASSES(2 * n + 1); pass++) {
+            const int xx = lane + 64 * pass;
+            if (xx > 2 * n) break;
             if (xx == 0) ref[0] = U16(TOP(-1));
             else if (xx <= n || angle >= 0) ref[xx] = mode >= 18 ? U16(TOP(xx - 1)) : U16(LEFT(xx - 1));
         }
         if (angle < 0 && ((n * angle) >> 5) < -1) {
             const int lo = (angle * n) >> 5, inv = intra_inv_angle(mode);
-            for (int xx = -1 - lane; xx >= lo; xx -= 64) {
+            const int xx = -1 - lane; /* lo >= -n >= -32: one pass */
+            if (xx >= lo) {
                 const int k = (xx * inv + 128) >> 8;
                 ref[xx] = k == 0 ? U16(TOP(-1)) : (mode >= 18 ? U16(LEFT(k - 1)) : U16(TOP(k - 1)));
             }
@@ -294,6 +310,8 @@ __device__ __forceinline__ void intra_tu(const HevcIntraArgs &a, const ffhip_hev
         wave_sync();
     }
     const bool edge_ok = cidx == 0 && n < 32;
+    constexpr int pred_unroll = n * n <= 256 ? LANE_PASSES(n * n) : 1;
+#pragma unroll pred_unroll
     for (int p = lane; p < n * n; p += 64) {
         const int x = p & (n - 1), y = p >> lg;
         int v;

@@ -101,3 +101,27 @@ def test_extreme_coefficients_32():
     for bd, epp in ((8, False), (10, False), (16, True)):
         got = ops.hevc_residual_batch(n, lv, info, bitdepth=bd, epp=epp)
         assert np.array_equal(got, oracle_tus(n, lv, info, bd, epp, None)), (bd, epp)
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_full_8k_plane_by_pattern_gather(n):
+    """BASELINE config 5 size: every TU of one 7680x4320 luma plane.  The oracle transforms K distinct TUs (levels, qP,
+    flags, matrixId all differ); the plane is those K patterns drawn at random, so the expected output is a gather of
+    K oracle results -- exact parity at full size for the price of K oracle calls.  Runs several batches per wave,
+    the ragged last workgroup and every kernel of the default dispatch."""
+    K = 61
+    rng = np.random.default_rng(8000 + n)
+    pat = np.rint(rng.laplace(0, 12, size=(K, n * n))).astype(np.int16)
+    pat[::9] = rng.integers(-32768, 32768, size=(len(pat[::9]), n * n)).astype(np.int16)
+    pinfo = np.zeros((K, 4), np.uint8)
+    pinfo[:, 0] = rng.integers(0, 52, size=K)
+    pinfo[:, 1] = rng.choice([0, 0, 0, 0, 0, 2, 4] + ([1, 1, 1, 2 | 8] if n == 4 else []), size=K)
+    pinfo[:, 2] = rng.integers(0, 6, size=K)
+    scaling = rng.integers(1, 256, size=(6, n * n)).astype(np.uint8)
+    n_tu = (7680 // n) * (4320 // n) - 3      # not a multiple of anything
+    pick = rng.integers(0, K, size=n_tu)
+    lv, info = pat[pick], pinfo[pick]
+    for bd, epp, sc in ((8, False, None), (10, False, scaling)):
+        want = oracle_tus(n, pat, pinfo, bd, epp, sc)[pick]
+        got = ops.hevc_residual_batch(n, lv, info, bitdepth=bd, epp=epp, scaling=sc)
+        assert np.array_equal(got, want), (n, bd)

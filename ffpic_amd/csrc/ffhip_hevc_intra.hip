@@ -117,6 +117,45 @@ __device__ __forceinline__ void fetch_residual(const HevcIntraArgs &a, const ffh
         if (8 * lane + 512 * j < nn) rp.v[j] = *(const u32x4 *)(src + 8 * lane + 512 * j);
 }
 
+/* rdpcm accumulation of 8.6.5 on the wave's residual block in LDS.  Out of line on purpose: inlined four times (once
+ * per TU size) its unrolled chunk arrays took the kernel to 314 VGPRs and a thousand register moves, and the scalar
+ * registers that cost spilled in the common path; the path itself is rare (range extensions only). */
+template <int LG>
+__device__ __attribute__((noinline)) void rdpcm_accumulate(short *R, const int lane, const int mode)
+{
+    constexpr int n = 1 << LG;
+    if (mode / 26 == 0) {
+        /* running sum over the flattened block from index n (hevc.c:3963-3968):
+         * R[i] = sum of R[n-1 .. i] mod 2^16 -- a prefix sum: per-lane chunks, then a wave scan of the chunk totals */
+        constexpr int nn = n * n, chunk = nn >= 64 ? nn >> 6 : 1, active = nn / chunk;
+        int loc[16], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            loc[j] = 0;
+            if (j < chunk && lane < active) {
+                const int idx = lane * chunk + j;
+                sum += idx >= n - 1 ? (int)R[idx] : 0;
+                loc[j] = sum;
+            }
+        }
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        const int excl = incl - sum;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (j < chunk && lane < active) {
+                const int idx = lane * chunk + j;
+                if (idx >= n - 1) R[idx] = (short)(loc[j] + excl);
+            }
+    } else if (lane < n) {
+        for (int y = 1; y < n; y++) R[lane + n * y] = (short)(R[lane + n * y] + R[lane + n * (y - 1)]);
+    }
+}
+
 /* One TU by one wave: steps 5-10 of decode_intra_block.  s, s2: NB_MAX ints each; refbase: 140 ints;
  * R: 32*32 shorts -- all private to the wave (LDS).
  * GROUPED: picture samples move with agent-scope accesses, and neighbours inside the group's window
@@ -238,36 +277,7 @@ __device__ __forceinline__ void intra_tu(const HevcIntraArgs &a, const ffhip_hev
         }
         wave_sync();
         if (flags & 0x40) {
-            if (mode / 26 == 0) {
-                /* running sum over the flattened block from index n (hevc.c:3963-3968):
-                 * R[i] = sum of R[n-1 .. i] mod 2^16 -- a prefix sum: per-lane chunks, then a wave scan of the chunk totals */
-                const int nn = n * n, chunk = nn >= 64 ? nn >> 6 : 1, active = nn / chunk;
-                int loc[16], sum = 0;
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    loc[j] = 0;
-                    if (j < chunk && lane < active) {
-                        const int idx = lane * chunk + j;
-                        sum += idx >= n - 1 ? (int)R[idx] : 0;
-                        loc[j] = sum;
-                    }
-                }
-                int incl = sum;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int o = __shfl_up(incl, d);
-                    if (lane >= d) incl += o;
-                }
-                const int excl = incl - sum;
-#pragma unroll
-                for (int j = 0; j < 16; j++)
-                    if (j < chunk && lane < active) {
-                        const int idx = lane * chunk + j;
-                        if (idx >= n - 1) R[idx] = (short)(loc[j] + excl);
-                    }
-            } else if (lane < n) {
-                for (int y = 1; y < n; y++) R[lane + n * y] = (short)(R[lane + n * y] + R[lane + n * (y - 1)]);
-            }
+            rdpcm_accumulate<LG>(R, lane, mode); /* rare (range extensions): kept out of line, see there */
             wave_sync();
         }
         if (flags & 0x80) { /* 8.6.6 with rY aliased to r, as at hevc.c:4753-4755; products wrap like -fwrapv */

@@ -136,3 +136,18 @@ def test_heic_chain_levels_to_bgra(w, h, seed, bd):
     ctb = 64
     bgra = ops.yuv420_to_bgra_16(got[0][None], got[1][None], got[2][None], h // ctb, w // ctb, ctb)[0]
     assert np.array_equal(bgra, oracle_420_16(exp[0], exp[1], exp[2], h // ctb, w // ctb, ctb))
+
+
+@pytest.mark.parametrize("shift", [1, 3, 8, 13])
+def test_residual_blocks_at_odd_offsets(shift):
+    """Residual blocks need not be 16-byte aligned in d_residual: the kernel fetches aligned blocks ahead with 16-byte
+    loads and reads the others where they are used.  Same list, every block moved by `shift` samples."""
+    w, h = 192, 128
+    tus, res = synth.hevc_intra_tus(w, h, seed=77)
+    want = ops.hevc_intra_recon(tus, res, w, h, True, 8, 8)
+    moved = tus.copy()
+    moved["res_offset"] += shift
+    res2 = np.concatenate([np.full(shift, 12345, np.int16), res])
+    got = ops.hevc_intra_recon(moved, res2, w, h, True, 8, 8)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)

@@ -135,10 +135,19 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # Rehearsal of the N > 1 path on a one-GPU box (FFHIP_BENCH_REHEARSE=1): every rank on cuda:0, gloo instead of
+    # RCCL (which refuses two ranks on one device).  Exercises sharding, barriers, the status gather and the
+    # rank-0-only legs; its numbers mean nothing and the JSON line says so.
+    rehearse = os.environ.get("FFHIP_BENCH_REHEARSE") == "1" and world > 1
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
     L = capi.require_device(local)                       # raises without gfx950: no CPU fallback
 
     cols, rows, per_gpu, desc = WORKLOADS[a.workload]
@@ -234,7 +243,9 @@ def main():
                          "algorithmic_bytes_per_launch": int(BYTES_PER_PIXEL * px_per_launch),
                          "copy_kernel_GBps": None if copy_gbs is None else round(copy_gbs, 1)},
         }
-        if not a.no_cpu:
+        if rehearse:
+            line["config"]["rehearsal"] = "all ranks on one GPU over gloo: exercises the N > 1 control path only, the value is meaningless"
+        if not a.no_cpu and world == 1:   # the CPU leg is timed on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(cols, rows, t_y, t_u, t_v, q)
         print(json.dumps(line), flush=True)
     if world > 1:

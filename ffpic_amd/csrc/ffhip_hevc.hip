@@ -378,6 +378,16 @@ __global__ __launch_bounds__(256) void k_hevc_residual(HevcResArgs a)
     } /* batches */
 }
 
+/* The six ScalingFactor lists of a TU size (6 N^2 bytes) staged in LDS by the workgroup, so that the per-sample m
+ * is an LDS read behind the one barrier of the kernel instead of a global load that depends on the TU descriptor
+ * and is consumed at once.  LISTED kernels only: the flat ones carry neither the LDS nor the barrier. */
+template <int NN>
+__device__ __forceinline__ void stage_scaling_lists(uint8_t *sl, const uint8_t *scaling)
+{
+    for (int i = threadIdx.x; i < 6 * NN * NN / 4; i += 256) ((u32 *)sl)[i] = ((const u32 *)scaling)[i];
+    __syncthreads();
+}
+
 /* ------------------------------------------------------------------------------------------------
  * 32x32 TUs on the matrix cores.
  *
@@ -434,9 +444,11 @@ __device__ __forceinline__ void split_bytes(u32 d0, u32 d1, int &hi, int &lo)
     lo = (int)(__builtin_amdgcn_perm(d1, d0, 0x06040200u) ^ 0x80808080u);
 }
 
-template <bool NARROW>
+template <bool NARROW, bool LISTED>
 __global__ __launch_bounds__(256) void k_hevc_residual32_mfma(HevcResArgs a)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t sl[LISTED ? 6 * 32 * 32 : 16];
+    if (LISTED) stage_scaling_lists<32>(sl, a.scaling);
     constexpr int N = 32, TPW = 2, OST = 72; /* TUs per wave; byte stride of the output tile's rows (bank spread) */
     __shared__ __attribute__((aligned(16))) char lds_in[4][TPW][N * N * 2];
     __shared__ __attribute__((aligned(16))) char lds_out[4][TPW][N * OST];
@@ -496,7 +508,7 @@ __global__ __launch_bounds__(256) void k_hevc_residual32_mfma(HevcResArgs a)
         const int qP = inf & 0xff;
         const u32 fl = (inf >> 8) & 0xff, mid = (inf >> 16) & 0xff;
         xform[u] = !(fl & (TU_BYPASS | TU_TSKIP));
-        const bool flat = a.scaling == nullptr || (fl & TU_TSKIP);
+        const bool flat = !LISTED || (fl & TU_TSKIP);
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             const u32 pos = (64u * c + lane) * 8;
@@ -506,7 +518,7 @@ __global__ __launch_bounds__(256) void k_hevc_residual32_mfma(HevcResArgs a)
 #pragma unroll
                 for (int i = 0; i < 4; i++) outd[i] = raw[i];
             } else {
-                scale_chunk<8, NARROW>(raw, outd, qP, flat, a.scaling + mid * (N * N) + pos, bd_shift, cmin, cmax);
+                scale_chunk<8, NARROW>(raw, outd, qP, flat, sl + mid * (N * N) + pos, bd_shift, cmin, cmax);
             }
             if (xform[u]) {
                 *(u32x4 *)(lds_in[wave][u] + pos * 2) = u32x4{outd[0], outd[1], outd[2], outd[3]};
@@ -729,9 +741,11 @@ constexpr Mfma16Tab make_mfma16_tab()
 }
 __device__ const Mfma16Tab kTab16 = make_mfma16_tab();
 
-template <bool NARROW>
+template <bool NARROW, bool LISTED>
 __global__ __launch_bounds__(256) void k_hevc_residual16_mfma(HevcResArgs a)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t sl[LISTED ? 6 * 16 * 16 : 16];
+    if (LISTED) stage_scaling_lists<16>(sl, a.scaling);
     constexpr int N = 16, TPW = 4, OST = 40; /* TUs per batch; byte stride of the output tile's rows */
     constexpr int CH = 8, NCH = 2;
     __shared__ __attribute__((aligned(16))) char lds_in[4][TPW * N * N * 2];
@@ -775,8 +789,8 @@ __global__ __launch_bounds__(256) void k_hevc_residual16_mfma(HevcResArgs a)
 #pragma unroll
                 for (int i = 0; i < 4; i++) outd[i] = cur.raw[c][i];
             } else {
-                const bool flat = a.scaling == nullptr || (fl & TU_TSKIP);
-                scale_chunk<CH, NARROW>(cur.raw[c], outd, qP, flat, a.scaling + mid * (N * N) + pos, bd_shift, cmin, cmax);
+                const bool flat = !LISTED || (fl & TU_TSKIP);
+                scale_chunk<CH, NARROW>(cur.raw[c], outd, qP, flat, sl + mid * (N * N) + pos, bd_shift, cmin, cmax);
             }
             if (!(fl & (TU_BYPASS | TU_TSKIP))) {
                 *(u32x4 *)(tin + s0 * 2) = u32x4{outd[0], outd[1], outd[2], outd[3]};
@@ -873,9 +887,11 @@ constexpr Mfma8Tab make_mfma8_tab()
 }
 __device__ const Mfma8Tab kTab8 = make_mfma8_tab();
 
-template <bool NARROW>
+template <bool NARROW, bool LISTED>
 __global__ __launch_bounds__(256) void k_hevc_residual8_mfma(HevcResArgs a)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t sl[LISTED ? 6 * 8 * 8 : 16];
+    if (LISTED) stage_scaling_lists<8>(sl, a.scaling);
     constexpr int N = 8, TPW = 8, OST = 24; /* TUs per batch; byte stride of the output tile's 16-byte rows */
     constexpr int CH = 8;
     __shared__ __attribute__((aligned(16))) char lds_in[4][TPW * N * N * 2];
@@ -924,8 +940,8 @@ __global__ __launch_bounds__(256) void k_hevc_residual8_mfma(HevcResArgs a)
 #pragma unroll
             for (int i = 0; i < 4; i++) outd[i] = cur.raw[0][i];
         } else {
-            const bool flat = a.scaling == nullptr || (fl & TU_TSKIP);
-            scale_chunk<CH, NARROW>(cur.raw[0], outd, qP, flat, a.scaling + mid * (N * N) + lk * 8, bd_shift, cmin, cmax);
+            const bool flat = !LISTED || (fl & TU_TSKIP);
+            scale_chunk<CH, NARROW>(cur.raw[0], outd, qP, flat, sl + mid * (N * N) + lk * 8, bd_shift, cmin, cmax);
         }
         if (xf) {
             *(u32x4 *)(tin + in_off) = u32x4{outd[0], outd[1], outd[2], outd[3]};
@@ -1010,6 +1026,13 @@ extern "C" int ffhip_hevc_residual_batch(int nTbS, long long n_tu, const int16_t
         if (narrow) hipLaunchKernelGGL((KERNEL<true>), dim3((unsigned)wgs), dim3(256), 0, st, a);  \
         else hipLaunchKernelGGL((KERNEL<false>), dim3((unsigned)wgs), dim3(256), 0, st, a);        \
     } while (0)
+#define LAUNCH_RESL(KERNEL)                                                                                    \
+    do {                                                                                                       \
+        if (narrow && d_scaling) hipLaunchKernelGGL((KERNEL<true, true>), dim3((unsigned)wgs), dim3(256), 0, st, a);   \
+        else if (narrow) hipLaunchKernelGGL((KERNEL<true, false>), dim3((unsigned)wgs), dim3(256), 0, st, a);          \
+        else if (d_scaling) hipLaunchKernelGGL((KERNEL<false, true>), dim3((unsigned)wgs), dim3(256), 0, st, a);       \
+        else hipLaunchKernelGGL((KERNEL<false, false>), dim3((unsigned)wgs), dim3(256), 0, st, a);                     \
+    } while (0)
 #define LAUNCH_RESN(NN)                                                                                    \
     do {                                                                                                   \
         if (narrow) hipLaunchKernelGGL((k_hevc_residual<NN, true>), dim3((unsigned)wgs), dim3(256), 0, st, a);  \
@@ -1021,19 +1044,20 @@ extern "C" int ffhip_hevc_residual_batch(int nTbS, long long n_tu, const int16_t
         else LAUNCH_RESN(4);
         break;
     case 8:
-        if (mfma8) LAUNCH_RES(k_hevc_residual8_mfma);
+        if (mfma8) LAUNCH_RESL(k_hevc_residual8_mfma);
         else LAUNCH_RESN(8);
         break;
     case 16:
-        if (mfma16) LAUNCH_RES(k_hevc_residual16_mfma);
+        if (mfma16) LAUNCH_RESL(k_hevc_residual16_mfma);
         else LAUNCH_RESN(16);
         break;
     default:
-        if (mfma32) LAUNCH_RES(k_hevc_residual32_mfma);
+        if (mfma32) LAUNCH_RESL(k_hevc_residual32_mfma);
         else LAUNCH_RESN(32);
         break;
     }
 #undef LAUNCH_RES
+#undef LAUNCH_RESL
 #undef LAUNCH_RESN
     FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
     return FFHIP_OK;

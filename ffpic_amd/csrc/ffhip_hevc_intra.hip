@@ -169,8 +169,10 @@ __device__ __forceinline__ void intra_tu(const HevcIntraArgs &a, const ffhip_hev
     constexpr int n = 1 << LG, lg = LG;
     const int cidx = t.cidx, mode = t.pred_mode, flags = t.flags;
     const int bd = cidx == 0 ? a.bitdepth_y : a.bitdepth_c;
-    int16_t *plane = a.plane[cidx];
-    const int stride = a.stride[cidx];
+    /* selects, not a.plane[cidx]: indexing the kernel-argument arrays with a run-time index is two scalar memory
+     * loads (and their latency) in front of every TU's gather */
+    int16_t *plane = cidx == 0 ? a.plane[0] : (cidx == 1 ? a.plane[1] : a.plane[2]);
+    const int stride = cidx == 0 ? a.stride[0] : (cidx == 1 ? a.stride[1] : a.stride[2]);
     const int x0 = t.x, y0 = t.y;
     constexpr int cnt = 4 * n + 1;
     int *ref = refbase + 34;

@@ -14,6 +14,7 @@
  * host threads unless there are a thousand or more).
  */
 #include "ffhip_internal.h"
+#include <chrono>
 #include "ffhip_entropy_internal.h"
 
 #include <stdlib.h>
@@ -280,6 +281,8 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 64) n_threads = 64;
     const size_t mcus = (size_t)geom->mcu_cols * geom->mcu_rows;
+    const bool times = getenv("FFHIP_HUFF_TIMES") != nullptr; /* host phases on stderr */
+    const auto T0 = std::chrono::steady_clock::now();
     /* ---- host, pictures over threads: headers, tables, restart-interval starts ---- */
     std::vector<struct jpeg_hdr> hdr((size_t)n);
     std::vector<std::vector<uint32_t>> segs((size_t)n);
@@ -306,6 +309,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     });
     for (int i = 0; i < n; i++)
         if (status[i]) return status[i];
+    const auto T1 = std::chrono::steady_clock::now();
     /* ---- layout of the one upload: scan bytes | tables | picture records | interval starts | work list | status ---- */
     std::vector<HuffImage> images((size_t)n);
     /* pictures of a batch mostly share their Huffman tables (an encoder's defaults): keep one copy of each distinct table */
@@ -347,6 +351,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     /* pinned staging and device image are kept per stream: callers on different streams overlap completely */
     uint8_t *stage = ffhip_pinned_scratch(SCRATCH_HUFF, stream, total + 64);
     if (!stage) return FFHIP_ENOMEM;
+    const auto T2 = std::chrono::steady_clock::now();
     parallel_for(n, n_threads, [&](int i) {
         const struct jpeg_hdr &j = hdr[(size_t)i];
         const HuffImage &im = images[(size_t)i];
@@ -373,12 +378,18 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         memcpy(stage + o_quant + (size_t)i * 512, j.quant, 512);
     });
     memset(stage + scan_total, 0, 16);
+    const auto T3 = std::chrono::steady_clock::now();
     parallel_for((int)n_tabs, n_threads, [&](int u) {
         ((struct huff *)(stage + o_tabs))[u] = *uniq[(size_t)u];
         build_lut(*uniq[(size_t)u], (uint16_t *)(stage + o_l12) + (size_t)u * LUT_WORDS);
     });
     memcpy(stage + o_img, images.data(), images.size() * sizeof(HuffImage));
     memset(stage + o_status, 0, (size_t)n * 4);
+    if (times) {
+        const auto T4 = std::chrono::steady_clock::now();
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+        fprintf(stderr, "huff staging: parse+markers %ld us, layout %ld us, unstuff %ld us, tables %ld us (%d files, %zu bytes, %d threads)\n", us(T0, T1), us(T1, T2), us(T2, T3), us(T3, T4), n, total, n_threads);
+    }
     hipStream_t st = (hipStream_t)stream;
     uint8_t *dev = (uint8_t *)ffhip_scratch(SCRATCH_HUFF, stream, (total + 3) / 4);
     if (!dev) return FFHIP_ENOMEM;

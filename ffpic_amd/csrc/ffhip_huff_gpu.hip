@@ -15,6 +15,9 @@
  */
 #include "ffhip_internal.h"
 #include <chrono>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include "ffhip_entropy_internal.h"
 
 #include <stdlib.h>
@@ -214,19 +217,55 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
 #define SCRATCH_HUFF 4
 
 namespace {
-/* entropy-coded bytes without their stuffing (FF 00 -> FF), up to `end` or the first marker; returns the clean length */
-size_t unstuff(uint8_t *dst, const uint8_t *src, const uint8_t *end)
+/* One pass over a picture's entropy-coded segment: the bytes without their stuffing (FF 00 -> FF) into dst, every
+ * restart interval 4-byte aligned and followed by at least 4 zero bytes, seg[k] = offset of interval k in that clean
+ * stream.  RSTn markers separate the intervals; any other marker (or the n_seg-th RSTn) ends the scan.  Returns the
+ * number of intervals found; *clean_len = bytes written.  16 bytes at a time while no 0xFF is in sight (one in 256
+ * bytes is, in entropy-coded data): the first form, memchr + memcpy per run and a separate marker scan before it,
+ * spent its time in call overhead -- 7 ms of staging per 256 4K files on 16 threads, against 12 ms of kernel.
+ * May store up to 15 bytes past the clean length: the caller reserves the slack. */
+uint32_t stage_scan(uint8_t *dst, const uint8_t *src, const uint8_t *end, uint32_t *seg, uint32_t n_seg, size_t *clean_len)
 {
     uint8_t *d = dst;
-    while (src < end) {
-        const uint8_t *q = (const uint8_t *)memchr(src, 0xFF, (size_t)(end - src));
-        if (!q) { memcpy(d, src, (size_t)(end - src)); d += end - src; break; }
-        memcpy(d, src, (size_t)(q - src));
-        d += q - src;
-        if (q + 1 < end && q[1] == 0) { *d++ = 0xFF; src = q + 2; }
-        else break; /* a marker: the interval ends here */
+    uint32_t k = 0;
+    seg[0] = 0;
+    for (;;) {
+#if defined(__SSE2__)
+        const __m128i ff = _mm_set1_epi8((char)0xFF);
+        while (src + 16 <= end) {
+            const __m128i v = _mm_loadu_si128((const __m128i *)src);
+            const unsigned m = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(v, ff));
+            _mm_storeu_si128((__m128i *)d, v);
+            if (m) {
+                const int c = __builtin_ctz(m);
+                src += c;
+                d += c;
+                break;
+            }
+            src += 16;
+            d += 16;
+        }
+#endif
+        while (src < end && *src != 0xFF) *d++ = *src++;
+        if (src + 1 >= end) break; /* end of data (a lone trailing FF is not data) */
+        const uint8_t b = src[1];
+        if (b == 0) { *d++ = 0xFF; src += 2; continue; }
+        if (b < 0xD0 || b > 0xD7 || k + 1 >= n_seg) break; /* another marker, or more RSTn than intervals: the scan ends */
+        {
+            const size_t len = (size_t)(d - dst) - seg[k], padded = ((len + 3) & ~(size_t)3) + 4;
+            memset(d, 0, padded - len);
+            d = dst + seg[k] + padded;
+            seg[++k] = (uint32_t)(d - dst);
+            src += 2;
+        }
     }
-    return (size_t)(d - dst);
+    {
+        const size_t len = (size_t)(d - dst) - seg[k], padded = ((len + 3) & ~(size_t)3) + 4;
+        memset(d, 0, padded - len);
+        d = dst + seg[k] + padded;
+    }
+    *clean_len = (size_t)(d - dst);
+    return k + 1;
 }
 
 /* Two-level table of a canonical Huffman code, LUT_WORDS uint16:
@@ -297,15 +336,8 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
             return;
         }
         if (!j.restart) j.restart = (int)mcus; /* no DRI: the whole scan is one interval = one lane (worth it for large batches only) */
-        /* interval starts: behind the RSTn markers (0xFF is stuffed inside entropy data, so FF D0..D7 is a marker) */
-        const uint32_t n_seg = (uint32_t)((mcus + j.restart - 1) / j.restart);
-        std::vector<uint32_t> &sg = segs[(size_t)i];
-        sg.reserve(n_seg);
-        sg.push_back(0);
-        const uint8_t *s = j.scan, *e = j.scan + j.scan_len;
-        for (const uint8_t *q = s; sg.size() < n_seg && (q = (const uint8_t *)memchr(q, 0xFF, (size_t)(e - q))) != nullptr && q + 1 < e; q++)
-            if (q[1] >= 0xD0 && q[1] <= 0xD7) { sg.push_back((uint32_t)(q + 2 - s)); q++; }
-        if (sg.size() != n_seg) status[i] = FFHIP_EINVAL;
+        /* the interval starts are found while the bytes are staged (stage_scan) */
+        segs[(size_t)i].assign((size_t)((mcus + j.restart - 1) / j.restart), 0u);
     });
     for (int i = 0; i < n; i++)
         if (status[i]) return status[i];
@@ -336,7 +368,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
             im.tab_dc[c] = table_id(&j.dc[c < j.ncomp ? j.td[c] : j.td[0]]);
             im.tab_ac[c] = table_id(&j.ac[c < j.ncomp ? j.ta[c] : j.ta[0]]);
         }
-        scan_total += (j.scan_len + 8 * (size_t)im.n_seg + 32 + 15) & ~(size_t)15; /* unstuffed, every interval aligned and padded */
+        scan_total += (j.scan_len + 8 * (size_t)im.n_seg + 64 + 15) & ~(size_t)15; /* unstuffed, every interval aligned and padded, slack for the 16-byte stores */
         seg_total += im.n_seg;
         if (scan_total > 0x7fffffffu) return FFHIP_EINVAL;
     }
@@ -376,16 +408,9 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         const HuffImage &im = images[(size_t)i];
         /* the picture's bytes, unstuffed, every restart interval 4-byte aligned and followed by >= 4 zero bytes */
         uint8_t *dst = stage + im.scan_off;
-        size_t off = 0;
         std::vector<uint32_t> &sgv = segs[(size_t)i];
-        for (uint32_t k = 0; k < im.n_seg; k++) {
-            const uint8_t *b = j.scan + sgv[k], *e = k + 1 < im.n_seg ? j.scan + sgv[k + 1] - 2 : j.scan + j.scan_len;
-            const size_t len = unstuff(dst + off, b, e);
-            sgv[k] = (uint32_t)off; /* from here on: offset of the interval in the CLEAN stream */
-            const size_t padded = ((len + 3) & ~(size_t)3) + 4;
-            memset(dst + off + len, 0, padded - len);
-            off += padded;
-        }
+        size_t off = 0;
+        if (stage_scan(dst, j.scan, j.scan + j.scan_len, sgv.data(), im.n_seg, &off) != im.n_seg) status[i] = FFHIP_EINVAL;
         memset(dst + off, 0, 16);
         uint32_t *sg = (uint32_t *)(stage + o_seg) + im.seg_base;
         u32x2 *wk = (u32x2 *)(stage + o_work) + im.seg_base;
@@ -401,6 +426,11 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         FFHIP_CHECK(hipMemcpyAsync(dev + b0, stage + b0, b1 - b0, hipMemcpyHostToDevice, st), FFHIP_EIO);
     }
     } /* parts */
+    for (int i = 0; i < n; i++)
+        if (status[i]) { /* a file whose restart markers do not add up: nothing is decoded */
+            (void)hipStreamSynchronize(st);
+            return status[i];
+        }
     memset(stage + scan_total, 0, 16);
     const auto T3 = std::chrono::steady_clock::now();
     parallel_for((int)n_tabs, n_threads, [&](int u) {

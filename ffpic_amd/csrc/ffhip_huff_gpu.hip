@@ -310,6 +310,13 @@ void parallel_for(int n, int n_threads, F f)
 }
 } // namespace
 
+/* Test hook (host only, no device needed): stage_scan on caller memory.  dst must hold len + 8 n_seg + 64 bytes. */
+extern "C" int ffhip_jpeg_stage_scan_test(uint8_t *dst, const uint8_t *src, size_t len, uint32_t *seg, uint32_t n_seg, size_t *clean_len)
+{
+    if (!dst || !src || !seg || !clean_len || n_seg == 0) return FFHIP_EINVAL;
+    return (int)stage_scan(dst, src, src + len, seg, n_seg, clean_len);
+}
+
 extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const size_t *lens, int n, int n_threads,
                                             const ffhip_jpeg_geom *geom, int16_t *d_coef_y, int16_t *d_coef_u, int16_t *d_coef_v,
                                             uint16_t *d_quant, int *status, void *stream)

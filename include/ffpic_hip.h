@@ -364,6 +364,14 @@ int ffhip_jpeg_entropy_decode_mt(const uint8_t *file, size_t len, const ffhip_jp
 int ffhip_jpeg_entropy_batch(const uint8_t *const *files, const size_t *lens, int n, int n_threads,
                              const ffhip_jpeg_geom *geom, int16_t *coef_y, int16_t *coef_u,
                              int16_t *coef_v, uint16_t *quant, int *status);
+/* Test hook for the host staging pass of ffhip_jpeg_entropy_batch_gpu (needs no device): unstuffs the entropy-coded
+ * bytes src[0..len) into dst (FF 00 -> FF), pads every restart interval to 4 bytes + 4 zero bytes, writes the clean
+ * offset of interval k to seg[k] (k < n_seg) and the clean length to *clean_len; returns the number of intervals
+ * found (RSTn-separated; another marker or the n_seg-th RSTn ends the scan), or FFHIP_EINVAL.
+ * dst must hold len + 8 * n_seg + 64 bytes.  The reference's counterpart is the byte loop of read_compressed_scan
+ * (format/jpg.c:588-637). */
+int ffhip_jpeg_stage_scan_test(uint8_t *dst, const uint8_t *src, size_t len, uint32_t *seg, uint32_t n_seg, size_t *clean_len);
+
 /* The same front end ON the device for files that carry restart markers (DRI): one lane per restart interval
  * decodes straight into DEVICE planes (d_coef_*, d_quant [n][4][64]) laid out for ffhip_jpeg_recon_batch with
  * quant_stride 256; the host only parses headers and finds the RSTn markers.  files/lens/status are HOST

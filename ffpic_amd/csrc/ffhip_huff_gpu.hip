@@ -449,7 +449,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     if (times) {
         const auto T4 = std::chrono::steady_clock::now();
         auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
-        fprintf(stderr, "huff staging: parse+markers %ld us, layout %ld us, unstuff %ld us, tables %ld us (%d files, %zu bytes, %d threads)\n", us(T0, T1), us(T1, T2), us(T2, T3), us(T3, T4), n, total, n_threads);
+        fprintf(stderr, "huff staging: header parse %ld us, layout %ld us, unstuff + markers (uploads enqueued by quarters) %ld us, tables %ld us (%d files, %zu bytes, %d threads)\n", us(T0, T1), us(T1, T2), us(T2, T3), us(T3, T4), n, total, n_threads);
     }
     /* the rest of the image: scan padding, tables, picture records, interval lists, status, quantiser tables */
     FFHIP_CHECK(hipMemcpyAsync(dev + scan_total, stage + scan_total, total - scan_total, hipMemcpyHostToDevice, st), FFHIP_EIO);

@@ -43,6 +43,7 @@ static int huff_build(struct huff *h, const uint8_t counts[16], const uint8_t *v
         h->mincode[len] = code;
         for (int i = 0; i < counts[len - 1]; i++, k++, code++) {
             if (k >= nvals) return -1;
+            if (code >= (1 << len)) return -1; /* over-subscribed DHT (Kraft sum > 1): the code does not fit its length */
             if (len <= LOOK) {
                 int first = code << (LOOK - len), n = 1 << (LOOK - len);
                 for (int j = 0; j < n; j++) h->look[first + j] = (uint16_t)((len << 8) | vals[k]);
@@ -69,6 +70,7 @@ struct bits {
     uint64_t acc;
     int n;      /* valid bits in acc */
     int marker; /* a marker was hit: feed zeros */
+    int dry;    /* zero bytes fed behind the end of the data (look-ahead only, in a well-formed stream) */
 };
 
 static inline void bits_fill(struct bits *b)
@@ -89,13 +91,15 @@ static inline void bits_fill(struct bits *b)
     }
     while (b->n <= 56) {
         unsigned c = 0;
+        int real = 0;
         if (!b->marker && b->p < b->end) {
             c = *b->p;
             if (c == 0xFF) {
-                if (b->p + 1 < b->end && b->p[1] == 0) b->p += 2; /* stuffed zero (jpg.c:588-637) */
+                if (b->p + 1 < b->end && b->p[1] == 0) { b->p += 2; real = 1; } /* stuffed zero (jpg.c:588-637) */
                 else { b->marker = 1; c = 0; }
-            } else b->p++;
+            } else { b->p++; real = 1; }
         }
+        b->dry += !real;
         b->acc = (b->acc << 8) | c;
         b->n += 8;
     }
@@ -113,12 +117,11 @@ static inline int huff_decode(struct bits *b, const struct huff *h)
     unsigned peek = (unsigned)((b->acc >> (b->n - LOOK)) & ((1u << LOOK) - 1));
     unsigned e = h->look[peek];
     if (e) { b->n -= (int)(e >> 8); return (int)(e & 0xff); }
-    int code = (int)((b->acc >> (b->n - LOOK)) & ((1u << LOOK) - 1)), len = LOOK;
-    while (len < 17 && code > h->maxcode[len]) {
-        len++;
+    int code = (int)peek, len = LOOK;
+    while (code > h->maxcode[len]) {
+        if (++len > 16) return -1; /* no code of any length matches: corrupt data (b->n >= 16, so no shift below is negative) */
         code = (int)((b->acc >> (b->n - len)) & ((1u << len) - 1));
     }
-    if (len > 16) return -1;
     b->n -= len;
     return h->vals[(h->valptr[len] + code - h->mincode[len]) & 255]; /* & 255: a malformed DHT must not index outside the table */
 }
@@ -170,6 +173,7 @@ static int parse_headers(const uint8_t *f, size_t len, struct jpeg_hdr *j)
             j->width = (s[3] << 8) | s[4];
             j->ncomp = s[5];
             if ((j->ncomp != 1 && j->ncomp != 3) || sl < (size_t)(6 + 3 * j->ncomp)) return FFHIP_EINVAL;
+            if (j->width == 0 || j->height == 0) return FFHIP_EINVAL; /* height 0 = "see DNL": not this path */
             for (int c = 0; c < j->ncomp; c++) {
                 j->cid[c] = s[6 + 3 * c];
                 j->h[c] = s[7 + 3 * c] >> 4;
@@ -284,6 +288,9 @@ static int decode_mcus(const struct jpeg_hdr *j, int16_t *const planes[3], struc
             }
         }
     }
+    /* the bytes fed behind the end of the data are look-ahead; a stream that consumed any of them is truncated
+     * (the reference's reader overruns its buffer there, utils/bitstream.c:117: nothing to be in parity with) */
+    if (b->dry * 8 > b->n) return FFHIP_EINVAL;
     return FFHIP_OK;
 }
 
@@ -302,7 +309,7 @@ static void *interval_worker(void *arg)
     for (long i = w->first; i < w->last && w->rc == FFHIP_OK; i++) {
         const uint8_t *p = w->j->scan + w->seg[i];
         const uint8_t *e = i + 1 < w->n_seg ? w->j->scan + w->seg[i + 1] - 2 : w->j->scan + w->j->scan_len; /* stop at the RSTn */
-        struct bits b = {p, e, 0, 0, 0};
+        struct bits b = {p, e, 0, 0, 0, 0};
         const long mcu = i * w->j->restart, left = w->mcus - mcu;
         w->rc = decode_mcus(w->j, w->planes, &b, mcu, left < w->j->restart ? left : w->j->restart);
     }
@@ -327,7 +334,7 @@ int ffhip_jpeg_entropy_decode_mt(const uint8_t *file, size_t len, const ffhip_jp
     const long mcus = (long)mcu_cols * mcu_rows;
     struct interval_job base = {j, {coef_y, coef_u, coef_v}, NULL, 1, mcus, 0, 1, FFHIP_OK};
     if (!j->restart) { /* one segment, one thread */
-        struct bits b = {j->scan, j->scan + j->scan_len, 0, 0, 0};
+        struct bits b = {j->scan, j->scan + j->scan_len, 0, 0, 0, 0};
         rc = decode_mcus(j, base.planes, &b, 0, mcus);
         free(j);
         return rc;
@@ -383,13 +390,24 @@ struct batch_job {
     uint16_t *quant;
     int *status;
 };
+/* a picture that failed to parse or decode still occupies its place in the batch: its planes must not keep what an
+ * earlier chunk or call left in the (reused, pinned) buffers -- all-zero coefficients reconstruct to a flat picture */
+static void blank_picture(int16_t *y, int16_t *u, int16_t *v, uint16_t *quant, size_t yb, size_t cb)
+{
+    memset(y, 0, yb * sizeof(int16_t));
+    if (u) memset(u, 0, cb * sizeof(int16_t));
+    if (v) memset(v, 0, cb * sizeof(int16_t));
+    for (int i = 0; i < 256; i++) quant[i] = 1;
+}
 static void *batch_worker(void *arg)
 {
     struct batch_job *jb = arg;
     const size_t mcus = (size_t)jb->g->mcu_cols * jb->g->mcu_rows, yb = mcus * jb->g->h * jb->g->v * 64, cb = mcus * 64;
-    for (int i = jb->first; i < jb->last; i++)
+    for (int i = jb->first; i < jb->last; i++) {
         jb->status[i] = ffhip_jpeg_entropy_decode(jb->files[i], jb->lens[i], jb->g, jb->y + i * yb, jb->u ? jb->u + i * cb : NULL,
                                                   jb->v ? jb->v + i * cb : NULL, jb->quant + (size_t)i * 256);
+        if (jb->status[i]) blank_picture(jb->y + i * yb, jb->u ? jb->u + i * cb : NULL, jb->v ? jb->v + i * cb : NULL, jb->quant + (size_t)i * 256, yb, cb);
+    }
     return NULL;
 }
 
@@ -408,6 +426,7 @@ int ffhip_jpeg_entropy_batch(const uint8_t *const *files, const size_t *lens, in
         for (int i = 0; i < n; i++) {
             status[i] = ffhip_jpeg_entropy_decode_mt(files[i], lens[i], geom, coef_y + (size_t)i * yb, coef_u ? coef_u + (size_t)i * cb : NULL,
                                                      coef_v ? coef_v + (size_t)i * cb : NULL, quant + (size_t)i * 256, n_threads);
+            if (status[i]) blank_picture(coef_y + (size_t)i * yb, coef_u ? coef_u + (size_t)i * cb : NULL, coef_v ? coef_v + (size_t)i * cb : NULL, quant + (size_t)i * 256, yb, cb);
             if (status[i] && !first_err) first_err = status[i];
         }
         return first_err;

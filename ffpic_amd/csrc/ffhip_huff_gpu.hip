@@ -29,7 +29,8 @@
 
 struct HuffImage {
     uint32_t scan_off, scan_len; /* this picture's entropy-coded bytes inside `scan` */
-    uint32_t seg_base, n_seg;    /* its restart intervals inside `seg` (offsets relative to scan_off) */
+    uint32_t seg_base, n_seg;    /* its restart intervals inside `seg` (offsets relative to scan_off): n_seg starts and,
+                                  * as entry n_seg, the length of the clean stream = the end of the last interval */
     uint32_t restart, mcus;
     uint32_t ncomp, nb[3];       /* blocks per MCU and component */
     uint32_t tab_dc[3], tab_ac[3]; /* indices into `tabs` */
@@ -98,11 +99,14 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
     const u32x2 w = a.work[exists ? gid : gid0];
     const HuffImage im = a.images[w.x];
     const bool in_lds = w.x == img0;
-    /* this lane's byte stream: 16-byte aligned chunks from `src`; reads past the interval see its zero padding,
-     * then (malformed streams only) whatever follows inside the staged buffer, which is padded at its end */
+    /* this lane's byte stream: 16-byte aligned chunks from `src`, and never a byte that is not the interval's own:
+     * dwords at or behind `lim` (the end of the interval with its zero padding = the start of the next one) read as
+     * zero, as the host reader feeds itself zeros at `end`, and a lane that has taken more than the look-ahead of a
+     * well-formed stream from there is malformed (truncated file, empty interval, DRI larger than the data) and stops */
     const uint32_t start = im.scan_off + a.seg[im.seg_base + w.y]; /* 4-byte aligned */
     const u32x4 *src = (const u32x4 *)(a.scan + (start & ~15u));
     uint32_t rd = (start & 15u) >> 2, wr = 0; /* dword cursors into the stream counted from src */
+    const uint32_t lim = (im.scan_off + a.seg[im.seg_base + w.y + 1] - (start & ~15u)) >> 2; /* seg[n_seg] = clean length */
     uint32_t mcu = w.y * im.restart;
     const uint32_t mcu_end = mcu + im.restart < im.mcus ? mcu + im.restart : im.mcus;
     /* ---- what a block change needs, as per-lane tables in LDS, so that it is a few look-ups and not chains of
@@ -129,9 +133,10 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
     auto refill = [&]() { /* all lanes: fetch 16-byte chunks while the ring has room for one */
         while (__builtin_amdgcn_ballot_w64(wr + 4 <= rd + RING_DW)) {
             if (wr + 4 <= rd + RING_DW) {
-                const u32x4 v = src[wr >> 2];
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (wr < lim) v = src[wr >> 2]; /* a chunk that starts inside the interval ends inside the staged buffer */
 #pragma unroll
-                for (int j = 0; j < 4; j++) ring[(wr + j) & (RING_DW - 1)][lane] = v[j];
+                for (int j = 0; j < 4; j++) ring[(wr + j) & (RING_DW - 1)][lane] = wr + j < lim ? v[j] : 0u;
                 wr += 4;
             }
         }
@@ -203,6 +208,8 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
                 blk = (int16_t *)(uintptr_t)planeb[c2][lane] + (size_t)(mcu * nbc + kb) * 64;
                 if (mcu >= mcu_end) active = false;
             }
+            /* a well-formed interval ends before its padding: rd is at most two dwords ahead of the bits consumed */
+            bad |= rd > lim + 2;
             if (bad) active = false;
             if (n <= 32) { /* splice the dword read at the top behind the n valid bits */
                 acc |= (unsigned long long)__builtin_bswap32(nextdw) << (32 - n);
@@ -326,6 +333,8 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     if (geom->ncomp == 3 && (!d_coef_u || !d_coef_v)) return FFHIP_EINVAL;
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 64) n_threads = 64;
+    if (geom->mcu_cols <= 0 || geom->mcu_rows <= 0 || geom->h < 1 || geom->h > 2 || geom->v < 1 || geom->v > 2 ||
+        (geom->ncomp != 1 && geom->ncomp != 3)) return FFHIP_EINVAL;
     const size_t mcus = (size_t)geom->mcu_cols * geom->mcu_rows;
     const bool times = getenv("FFHIP_HUFF_TIMES") != nullptr; /* host phases on stderr */
     const auto T0 = std::chrono::steady_clock::now();
@@ -377,6 +386,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         }
         scan_total += (j.scan_len + 8 * (size_t)im.n_seg + 64 + 15) & ~(size_t)15; /* unstuffed, every interval aligned and padded, slack for the 16-byte stores */
         seg_total += im.n_seg;
+        im.seg_base += (uint32_t)i; /* one more entry per picture: the end of its last interval */
         if (scan_total > 0x7fffffffu) return FFHIP_EINVAL;
     }
     if (!ffhip_have_device()) return FFHIP_ENODEV;
@@ -384,7 +394,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     if (n_tabs > 4095) return FFHIP_EINVAL; /* table indices travel in 12 bits */
     const size_t o_tabs = scan_total + 16, o_l12 = (o_tabs + n_tabs * sizeof(struct huff) + 15) & ~(size_t)15;
     const size_t o_img = o_l12 + n_tabs * LUT_WORDS * 2;
-    const size_t o_seg = (o_img + images.size() * sizeof(HuffImage) + 15) & ~(size_t)15, o_work = (o_seg + seg_total * 4 + 15) & ~(size_t)15;
+    const size_t o_seg = (o_img + images.size() * sizeof(HuffImage) + 15) & ~(size_t)15, o_work = (o_seg + (seg_total + (size_t)n) * 4 + 15) & ~(size_t)15;
     const size_t o_status = (o_work + seg_total * 8 + 15) & ~(size_t)15, o_quant = (o_status + (size_t)n * 4 + 15) & ~(size_t)15;
     const size_t total = o_quant + (size_t)n * 512;
     /* pinned staging and device image are kept per stream: callers on different streams overlap completely */
@@ -420,12 +430,13 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         if (stage_scan(dst, j.scan, j.scan + j.scan_len, sgv.data(), im.n_seg, &off) != im.n_seg) status[i] = FFHIP_EINVAL;
         memset(dst + off, 0, 16);
         uint32_t *sg = (uint32_t *)(stage + o_seg) + im.seg_base;
-        u32x2 *wk = (u32x2 *)(stage + o_work) + im.seg_base;
+        u32x2 *wk = (u32x2 *)(stage + o_work) + (im.seg_base - (uint32_t)i);
         for (uint32_t k = 0; k < im.n_seg; k++) {
             sg[k] = segs[(size_t)i][k];
             wk[k].x = (uint32_t)i;
             wk[k].y = k;
         }
+        sg[im.n_seg] = (uint32_t)off;
         memcpy(stage + o_quant + (size_t)i * 512, j.quant, 512);
     });
     {

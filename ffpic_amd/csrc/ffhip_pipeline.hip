@@ -129,6 +129,7 @@ extern "C" int ffhip_jpeg_decode_files(const uint8_t *const *files, const size_t
     if (geom_out) *geom_out = g;
     const int64_t width = (int64_t)g.mcu_cols * 8 * g.h, height = (int64_t)g.mcu_rows * 8 * g.v;
     if (pitch < width * 4 || (pitch & 15) || (n > 1 && image_stride < pitch * height)) return FFHIP_EINVAL;
+    if (g.mcu_cols <= 0 || g.mcu_rows <= 0) return FFHIP_EINVAL; /* workspace_bytes is 0 for a geometry it rejects, too */
     if (ffhip_jpeg_workspace_bytes(&g, 1) != 0) return FFHIP_EINVAL; /* one component with several blocks per MCU: not here */
     if (!ffhip_have_device()) return FFHIP_ENODEV;
     /* restart markers in the first file: try the device-side entropy decoder (FFHIP_JPEG_GPU_ENTROPY=0 keeps it off).
@@ -226,7 +227,7 @@ extern "C" int ffhip_jpeg_decode_files_device(const uint8_t *const *files, const
     int rc = ffhip_jpeg_probe(files[0], lens[0], &g, &w, &h);
     if (rc) return rc;
     if (geom_out) *geom_out = g;
-    if (ffhip_jpeg_workspace_bytes(&g, 1) != 0) return FFHIP_EINVAL;
+    if (g.mcu_cols <= 0 || g.mcu_rows <= 0 || ffhip_jpeg_workspace_bytes(&g, 1) != 0) return FFHIP_EINVAL;
     if (!ffhip_have_device()) return FFHIP_ENODEV;
     const size_t mcus = (size_t)g.mcu_cols * g.mcu_rows;
     const size_t yb = mcus * g.h * g.v * 64, cb = g.ncomp == 3 ? mcus * 64 : 0; /* int16 elements per picture */

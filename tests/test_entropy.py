@@ -71,12 +71,59 @@ def test_rejects_what_it_does_not_decode():
     q = np.zeros((4, 64), np.uint16)
     cut = np.frombuffer(data[: len(data) // 2], dtype=np.uint8)
     rc = L.ffhip_jpeg_entropy_decode(cut.ctypes.data, cut.size, None, cy.ctypes.data, cu.ctypes.data, cv.ctypes.data, q.ctypes.data)
-    assert rc in (0, -22)
+    assert rc == -22                        # a stream that runs dry is refused (no zeros decoded as data)
     # geometry mismatch against the batch geometry
     other = capi.jpeg_geom(g.mcu_cols + 1, g.mcu_rows)
     full = np.frombuffer(data, dtype=np.uint8)
     assert L.ffhip_jpeg_entropy_decode(full.ctypes.data, full.size, C.byref(other), cy.ctypes.data, cu.ctypes.data,
                                        cv.ctypes.data, q.ctypes.data) == -22
+
+
+def test_oversubscribed_dht_and_zero_dimensions_are_refused():
+    """A DHT whose code counts violate Kraft's inequality would put canonical codes outside their length (and outside
+    the 9-bit look-up table); a SOF with width or height 0 has no MCUs.  Both are refused at parse time."""
+    L = capi.lib()
+    g = capi.JpegGeom()
+    for counts0 in (3, 200, 255):
+        counts = bytes([counts0]) + bytes(15)
+        dht = b"\xff\xc4" + (2 + 1 + 16 + counts0).to_bytes(2, "big") + b"\x00" + counts + bytes(range(counts0 % 256))[:counts0].ljust(counts0, b"\x01")
+        f = np.frombuffer(b"\xff\xd8" + dht + b"\xff\xd9" + bytes(16), np.uint8)
+        assert L.ffhip_jpeg_probe(f.ctypes.data, f.size - 16, C.byref(g), None, None) == -22
+    data = bytearray(open(os.path.join(GOLDEN, FILES["q85_420"]), "rb").read())
+    k = data.find(b"\xff\xc0")
+    assert k > 0
+    for off in (5, 7):                      # height, width
+        bad = bytearray(data)
+        bad[k + off] = bad[k + off + 1] = 0
+        f = np.frombuffer(bytes(bad), np.uint8)
+        assert L.ffhip_jpeg_probe(f.ctypes.data, f.size, C.byref(g), None, None) == -22
+    # the device front end refuses a degenerate geometry before it divides by its MCU count (no GPU needed to get there)
+    zero = capi.jpeg_geom(0, 4)
+    f = np.frombuffer(bytes(data), np.uint8)
+    files = (C.c_void_p * 1)(f.ctypes.data)
+    lens = (C.c_size_t * 1)(f.size)
+    st = (C.c_int * 1)()
+    assert L.ffhip_jpeg_entropy_batch_gpu(files, lens, 1, 1, C.byref(zero), 8, 8, 8, 8, st, None) == -22
+
+
+def test_failed_picture_does_not_keep_stale_planes():
+    """A rejected file still occupies its place in the batch: its planes come back zeroed, not with what the buffers held."""
+    PIL = pytest.importorskip("PIL.Image")
+    good = open(os.path.join(GOLDEN, FILES["q85_420"]), "rb").read()
+    g, _, _ = ops.jpeg_probe(good)
+    files = [good, good[: len(good) // 2], good]
+    bufs = [np.frombuffer(f, np.uint8) for f in files]
+    arr = (C.c_void_p * 3)(*[b.ctypes.data for b in bufs])
+    lens = (C.c_size_t * 3)(*[b.size for b in bufs])
+    yb, cb = g.y_blocks * 64, g.c_blocks * 64
+    cy = np.full(3 * yb, 77, np.int16); cu = np.full(3 * cb, 77, np.int16); cv = cu.copy()
+    q = np.full((3, 4, 64), 9, np.uint16)
+    st = (C.c_int * 3)()
+    for th in (1, 8):
+        rc = capi.lib().ffhip_jpeg_entropy_batch(arr, lens, 3, th, C.byref(g), cy.ctypes.data, cu.ctypes.data, cv.ctypes.data, q.ctypes.data, st)
+        assert rc == -22 and list(st) == [0, -22, 0]
+        assert not cy[yb:2 * yb].any() and not cu[cb:2 * cb].any() and not cv[cb:2 * cb].any() and (q[1] == 1).all()
+        assert np.array_equal(cy[:yb], cy[2 * yb:]) and cy[:yb].any()
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="needs oracle/_ref for the reference's bmpwriter")

@@ -106,3 +106,71 @@ def test_random_corruption_never_faults():
     except capi.FfhipError:
         pass
     same_planes([good])                                 # and the device is still fine afterwards
+
+
+def _good_dri_file(blocks=3, size=(96, 128)):
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(5)
+    img = np.clip(rng.normal(128, 60, size + (3,)), 0, 255).astype(np.uint8)
+    bio = io.BytesIO()
+    kw = dict(quality=90, subsampling=2)
+    if blocks:
+        kw["restart_marker_blocks"] = blocks
+    PIL.fromarray(img).save(bio, "JPEG", **kw)
+    return bio.getvalue()
+
+
+def test_truncated_file_without_restart_markers_is_refused():
+    """One lane owns the whole scan of a file without DRI.  Cut short, the lane must stop at the end of ITS bytes
+    (zeros behind them, then a flag), not walk on through the next picture's data, the tables and the end of the
+    device scratch."""
+    good = _good_dri_file(blocks=0, size=(256, 320))
+    assert b"\xff\xdd" not in good
+    for keep in (0.5, 0.1):
+        cut = good[: int(len(good) * keep)]
+        with pytest.raises(capi.FfhipError):
+            ops.jpeg_entropy_batch_gpu([cut, good, cut])
+    same_planes([good] * 2)
+
+
+def test_empty_restart_intervals_are_refused():
+    """every RSTn present, but the intervals between two of them carry no data: the lanes of the empty intervals have
+    nothing of their own to read"""
+    good = _good_dri_file(blocks=3)
+    d = bytearray(good)
+    a, b = bytes(d).find(b"\xff\xd1"), bytes(d).find(b"\xff\xd2")
+    assert 0 < a < b
+    del d[a + 2:b]                              # RST1 directly followed by RST2
+    with pytest.raises(capi.FfhipError):
+        ops.jpeg_entropy_batch_gpu([bytes(d)])
+    # all data removed: the scan is nothing but its markers
+    sos = good.find(b"\xff\xda")
+    start = sos + 2 + ((good[sos + 2] << 8) | good[sos + 3])
+    n_rst = sum(good.count(bytes([0xFF, 0xD0 + k])) for k in range(8))
+    hollow = good[:start] + b"".join(bytes([0xFF, 0xD0 + (k & 7)]) for k in range(n_rst)) + b"\xff\xd9"
+    with pytest.raises(capi.FfhipError):
+        ops.jpeg_entropy_batch_gpu([hollow])
+    same_planes([good])
+
+
+def test_hostile_tables_cannot_read_past_the_staged_bytes():
+    """Complete 1-bit codes that map to DC size 11 and AC (run 0, size 15): no symbol ever ends a block early and none is
+    invalid, so a 2048x2048 picture asks for ~30 MB of bits from a 40-byte scan.  With unbounded reads that decoded
+    whatever followed in device memory; now the lane is flagged within a few dwords of its interval's end."""
+    def seg(marker, body):
+        return bytes([0xFF, marker]) + (len(body) + 2).to_bytes(2, "big") + body
+    dqt = seg(0xDB, b"\x00" + bytes([1] * 64))
+    sof = seg(0xC0, b"\x08" + (2048).to_bytes(2, "big") + (2048).to_bytes(2, "big") + b"\x03" + b"\x01\x22\x00\x02\x11\x00\x03\x11\x00")
+    counts = bytes([2]) + bytes(15)
+    dht = seg(0xC4, b"\x00" + counts + b"\x0b\x0b") + seg(0xC4, b"\x10" + counts + b"\x0f\x0f")
+    sos = seg(0xDA, b"\x03\x01\x00\x02\x00\x03\x00\x00\x3f\x00")
+    rng = np.random.default_rng(2)
+    scan = bytes(int(x) for x in rng.integers(0, 255, 40))      # no 0xFF
+    hostile = b"\xff\xd8" + dqt + sof + dht + sos + scan + b"\xff\xd9"
+    g, w, h = ops.jpeg_probe(hostile)
+    assert (g.mcu_cols, g.mcu_rows) == (128, 128)
+    with pytest.raises(capi.FfhipError):
+        ops.jpeg_entropy_batch_gpu([hostile] * 4)
+    with pytest.raises(capi.FfhipError):
+        ops.jpeg_entropy_batch([hostile])                       # the host decoder refuses it as well
+    same_planes([_good_dri_file()])

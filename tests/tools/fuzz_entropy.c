@@ -35,11 +35,20 @@ int main(int argc, char **argv)
         for (int it = 0; it < iters; it++) {
             memcpy(buf, orig, (size_t)n);
             size_t len = (size_t)n;
-            const int kind = it % 4;
+            const int kind = it % 5;
             if (kind == 0) for (int k = 0; k < 1 + (int)(rnd() % 8); k++) buf[rnd() % n] ^= (unsigned char)(1u << (rnd() % 8));
             else if (kind == 1) len = rnd() % (unsigned)n;                               /* truncation */
             else if (kind == 2) { size_t p = rnd() % n, l = rnd() % 64; if (p + l < (size_t)n) memset(buf + p, 0xFF, l); }
-            else { size_t p = 2 + rnd() % 600; if (p < (size_t)n) buf[p] = (unsigned char)rnd(); } /* header bytes */
+            else if (kind == 3) { size_t p = 2 + rnd() % 600; if (p < (size_t)n) buf[p] = (unsigned char)rnd(); } /* header bytes */
+            else { /* the 16 code-length counts of some DHT: over- and under-subscribed canonical codes */
+                size_t hits[16], nh = 0;
+                for (size_t p = 2; p + 21 < (size_t)n && nh < 16; p++)
+                    if (buf[p] == 0xFF && buf[p + 1] == 0xC4) hits[nh++] = p;
+                if (nh) {
+                    const size_t p = hits[rnd() % nh] + 5; /* marker, length, Tc/Th, then the counts */
+                    for (int k = 0; k < 1 + (int)(rnd() % 3); k++) buf[p + rnd() % 16] = (unsigned char)(rnd() % 4 ? rnd() % 8 : rnd());
+                }
+            }
             ffhip_jpeg_geom g;
             int rc = ffhip_jpeg_probe(buf, len, &g, &w, &h);
             /* decode against the ORIGINAL geometry: a corrupted header that changes the geometry must be refused */

@@ -100,13 +100,13 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
     const HuffImage im = a.images[w.x];
     const bool in_lds = w.x == img0;
     /* this lane's byte stream: 16-byte aligned chunks from `src`, and never a byte that is not the interval's own:
-     * dwords at or behind `lim` (the end of the interval with its zero padding = the start of the next one) read as
+     * dwords at or behind `dw_end` (the end of the interval with its zero padding = the start of the next one) read as
      * zero, as the host reader feeds itself zeros at `end`, and a lane that has taken more than the look-ahead of a
      * well-formed stream from there is malformed (truncated file, empty interval, DRI larger than the data) and stops */
     const uint32_t start = im.scan_off + a.seg[im.seg_base + w.y]; /* 4-byte aligned */
     const u32x4 *src = (const u32x4 *)(a.scan + (start & ~15u));
     uint32_t rd = (start & 15u) >> 2, wr = 0; /* dword cursors into the stream counted from src */
-    const uint32_t lim = (im.scan_off + a.seg[im.seg_base + w.y + 1] - (start & ~15u)) >> 2; /* seg[n_seg] = clean length */
+    const uint32_t dw_end = (im.scan_off + a.seg[im.seg_base + w.y + 1] - (start & ~15u)) >> 2; /* seg[n_seg] = clean length */
     uint32_t mcu = w.y * im.restart;
     const uint32_t mcu_end = mcu + im.restart < im.mcus ? mcu + im.restart : im.mcus;
     /* ---- what a block change needs, as per-lane tables in LDS, so that it is a few look-ups and not chains of
@@ -134,9 +134,9 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
         while (__builtin_amdgcn_ballot_w64(wr + 4 <= rd + RING_DW)) {
             if (wr + 4 <= rd + RING_DW) {
                 u32x4 v = {0u, 0u, 0u, 0u};
-                if (wr < lim) v = src[wr >> 2]; /* a chunk that starts inside the interval ends inside the staged buffer */
+                if (wr < dw_end) v = src[wr >> 2]; /* a chunk that starts inside the interval ends inside the staged buffer */
 #pragma unroll
-                for (int j = 0; j < 4; j++) ring[(wr + j) & (RING_DW - 1)][lane] = wr + j < lim ? v[j] : 0u;
+                for (int j = 0; j < 4; j++) ring[(wr + j) & (RING_DW - 1)][lane] = wr + j < dw_end ? v[j] : 0u;
                 wr += 4;
             }
         }
@@ -209,7 +209,10 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
                 if (mcu >= mcu_end) active = false;
             }
             /* a well-formed interval ends before its padding: rd is at most two dwords ahead of the bits consumed */
-            bad |= rd > lim + 2;
+            bad |= rd > dw_end + 2;
+#ifdef HUFF_DEBUG
+            if (rd > dw_end + 2) printf("lane %u img %u seg %u: rd %u lim %u start %u mcu %u/%u k %u n %d\n", gid, w.x, w.y, rd, dw_end, start, mcu, mcu_end, k, n);
+#endif
             if (bad) active = false;
             if (n <= 32) { /* splice the dword read at the top behind the n valid bits */
                 acc |= (unsigned long long)__builtin_bswap32(nextdw) << (32 - n);

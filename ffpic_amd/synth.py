@@ -174,13 +174,28 @@ def _quadtree(rng, x0, y0, size, min_size, max_tu, out):
         out.append((x0, y0, size))
 
 
+def _c5_mix(rng, x0, y0, size, big, out):
+    """every `big` x `big` area is one TU with probability 0.6, else four of half the size (z-order)"""
+    if size > big:
+        h = size // 2
+        for (dx, dy) in ((0, 0), (h, 0), (0, h), (h, h)):
+            _c5_mix(rng, x0 + dx, y0 + dy, h, big, out)
+    elif rng.random() < 0.6:
+        out.append((x0, y0, size))
+    else:
+        h = size // 2
+        out.extend(((x0, y0, h), (x0 + h, y0, h), (x0, y0 + h, h), (x0 + h, y0 + h, h)))
+
+
 def hevc_intra_tus(width, height, seed=0, ctb=64, chroma=True, min_tu=4, adversarial_masks=False, ccp=False,
-                   chroma_444=False):
+                   chroma_444=False, tu_mix=None):
     """A whole intra picture as a list of TUs in decode order (CTBs in raster order, z-order
     inside a CTB; per CTB: luma TUs, then Cb, then Cr), with z-scan neighbour availability,
     random modes 0..34 and flags.  ccp=True marks about half of the chroma TUs that carry a residual
     for cross-component prediction (ResScaleVal in {+-1, +-2, +-4, +-8}); chroma_444=True gives the chroma
     planes the luma size (ChromaArrayType 3, where the reference enables it).
+    tu_mix="c5" replaces the random quadtree by the TU mix SURVEY 8d names for BASELINE config 5: luma 32/16 at
+    60/40, chroma 16/8 at 60/40.
     Returns (tus structured array, residual int16 flat)."""
     rng = np.random.default_rng(SEED_BASE + 15000 + seed)
     assert width % ctb == 0 and height % ctb == 0
@@ -193,7 +208,10 @@ def hevc_intra_tus(width, height, seed=0, ctb=64, chroma=True, min_tu=4, adversa
             for c, (pw, ph) in enumerate(planes):
                 sc = 1 if c == 0 else csub
                 parts = []
-                _quadtree(rng, cx // sc, cy // sc, ctb // sc, max(min_tu, 4), 32, parts)
+                if tu_mix == "c5":
+                    _c5_mix(rng, cx // sc, cy // sc, ctb // sc, 32 // sc, parts)
+                else:
+                    _quadtree(rng, cx // sc, cy // sc, ctb // sc, max(min_tu, 4), 32, parts)
                 for (x0, y0, n) in parts:
                     d = done[c]
                     at = al = 0

@@ -7,7 +7,8 @@
  *   scale_transform_coefficients  (hevc.c:3743-3816)
  *   transform_scaled_coeffients   (hevc.c:3888-3956)
  * building just enough decoder state (one intra CU at the picture origin) for
- * them to run.  Block layout at this interface is row-major d[x + y*nTbS].
+ * them to run, and one around scale_and_transform itself (hevc.c:4172-4251) with the qP
+ * derivation in front of it.  Block layout at this interface is row-major d[x + y*nTbS].
  */
 #include "hevc.c" /* the reference's coding/hevc.c */
 
@@ -114,4 +115,62 @@ void ref_hevc_intra_tu(int x0, int y0, int log2n, int cIdx, int predModeIntra, i
     }
     construct_pic_pior_to_filtering(sps, x0, y0, nTbS, nTbS, cIdx, predSamples, resSamples, dst, stride);
     free(sps);
+}
+
+/* The reference's scale_and_transform (hevc.c:4172-4251) itself, with every branch it has: transquant bypass
+ * (:4209-4222), transform skip with `<< tsShift` (:4229-4236), the 180-degree rotation of 4x4 intra blocks
+ * (rotateCoeffs, :4203-4207), scaling lists dropped for transform-skipped blocks larger than 4x4 (:3786-3787), the
+ * DST entry for intra luma 4x4 (:3907-3921) and the qP derivation of 8.6.1 (:3998-4168) in front of it.
+ * Decoder state: one intra coding unit, one coding tree block, one slice, one tile, the TU at the picture origin;
+ * qp is the SliceQpY + QpBdOffset the test wants for luma; the function returns the qP the reference derived for
+ * cIdx from it (luma: qp; chroma: through its Table 8-10 / min(qPi, 51) mapping, plus QpBdOffsetC).
+ * level, r: row-major [x + y*nTbS]; scaling_factor row-major or NULL (scaling_list_enabled_flag = 0). */
+int ref_hevc_scale_and_transform(const int16_t *level, int16_t *r, int nTbS, int cIdx, int qp, int bitdepth, int epp,
+                                 int bypass, int transform_skip, int rotation_enabled, int chroma_array_type,
+                                 const uint8_t *scaling_factor)
+{
+    struct hevc_param_set *hps = calloc(1, sizeof *hps);
+    struct pps *pps = calloc(1, sizeof *pps);
+    struct sps *sps = calloc(1, sizeof *sps);
+    struct slice_segment_header *slice = calloc(1, sizeof *slice);
+    struct picture *p = calloc(1, sizeof *p);
+    struct cu_info *info = calloc(1, sizeof *info);
+    struct ctu *ctu = calloc(1, sizeof *ctu), *ctus[1] = {ctu};
+    struct cu *cu = calloc(1, sizeof *cu);
+    int zs_col[16] = {0}, *zs[16];
+    for (int i = 0; i < 16; i++) zs[i] = zs_col;
+    hps->pps[0] = pps;
+    hps->sps[0] = sps;
+    sps->BitDepthY = sps->BitDepthC = bitdepth;
+    sps->QpBdOffsetY = sps->QpBdOffsetC = 6 * (bitdepth - 8);
+    sps->sps_range_ext.extended_precision_processing_flag = epp;
+    sps->sps_range_ext.transform_skip_rotation_enabled_flag = rotation_enabled;
+    sps->scaling_list_enabled_flag = scaling_factor != NULL;
+    sps->ChromaArrayType = chroma_array_type;
+    sps->MinCbLog2SizeY = 6;
+    sps->CtbLog2SizeY = 6;
+    sps->CtbSizeY = 64;
+    sps->MinTbLog2SizeY = 2;
+    sps->PicWidthInCtbsY = 1;
+    sps->PicWidthInMinCbsY = 1;
+    sps->pic_width_in_luma_samples = sps->pic_height_in_luma_samples = 64;
+    pps->init_qp_minus26 = qp - 6 * (bitdepth - 8) - 26; /* SliceQpY; slice_qp_delta and CuQpDeltaVal stay 0 */
+    pps->MinTbAddrZs = zs;
+    slice->Log2MinCuQpDeltaSize = 6;
+    info->CuPredMode = MODE_INTRA;
+    p->info = info;
+    p->ctus = ctus;
+    cu->cu_transquant_bypass_flag = bypass;
+    cu->log2CbSize = 6;
+    const int sizeid = log2floor(nTbS) - 2;
+    for (int y = 0; y < nTbS; y++)
+        for (int x = 0; x < nTbS; x++) {
+            cu->tt.TransCoeffLevel[cIdx][x][y] = level[x + y * nTbS];
+            if (scaling_factor) slice->ScalingFactor[sizeid][cIdx][x][y] = scaling_factor[x + y * nTbS];
+        }
+    const struct quant_pixel q = quatization_parameters(0, 0, hps, slice, cu, p);
+    const int qP = cIdx == 0 ? clip3(0, 51 + sps->QpBdOffsetY, q.q_y) : (cIdx == 1 ? q.q_cb : q.q_cr);
+    scale_and_transform(cu, transform_skip, hps, slice, 0, 0, cIdx, nTbS, r, p);
+    free(cu); free(ctu); free(info); free(p); free(slice); free(sps); free(pps); free(hps);
+    return qP;
 }

@@ -4,7 +4,8 @@
  *
  * Compiles the reference's own format/webp.c inside this translation unit and
  * exports thin wrappers around its `static` hot-path functions
- * IWHT_long / IWHT_fast (webp.c:1067-1106).
+ * IWHT_long / IWHT_fast (webp.c:1067-1106), its loop filter, and a driver for vp8_decode_residual_block
+ * itself (webp.c:1125-1199) over synthetic bool-decoder streams.
  */
 #include <stdlib.h>
 #include <string.h>
@@ -129,4 +130,94 @@ void ref_webp_filter_info(void *wp, int *out)
             out[4 + (s * 2 + k) * 3] = w->filters[s][k].inter_limit;
             out[5 + (s * 2 + k) * 3] = w->filters[s][k].hev_thresh;
         }
+}
+
+/* vp8_decode_residual_block ITSELF (webp.c:1125-1199), driven from a synthetic bool-decoder state: the decoder is
+ * initialised over caller-provided bytes (any bytes are a valid VP8 token stream) with caller-provided coefficient
+ * probabilities, and the reference parses n_mb macroblocks of one row from it: token parse, dequantisation at parse
+ * (webp.c:1061), IWHT_long / IWHT_fast by its own "nz > 1" rule, the DC scatter, and idct_4x4 by its own
+ * "nz > 1 || dst[0] != 0" rule.  dst_out [n_mb][384] is what it wrote.
+ * What the reconstruction stage's caller would hand over for the same macroblocks -- the quantised levels and token
+ * counts -- is RECORDED by a second decoder over the same bytes that calls the reference's vp8_get_coefficients in
+ * the same order with quantisers 1 (so out[] is the level itself).  The recorder only replays the parse order and
+ * contexts; if it replayed them wrongly its levels would not reproduce dst_out through the oracle or the GPU.
+ * modes[n_mb]: intra_y_mode per MB (B_PRED = 4 has no Y2 block); seg[n_mb]: segment ids; q: uint16 [4][8] =
+ * y1_dc, y1_ac, y2_dc, y2_ac, uv_dc, uv_ac per segment; probs: uint8 [4][8][3][11].
+ * levels_out int16 [n_mb][25][16] (block 24 = Y2), nz_out uint8 [n_mb][25].  Returns 0. */
+int ref_vp8_residual_blocks_driven(const uint8_t *bytes, int len, int n_mb, const uint8_t *modes, const uint8_t *seg,
+                                   const uint16_t *q, const uint8_t *probs, int16_t *levels_out, uint8_t *nz_out,
+                                   int16_t *dst_out)
+{
+    static const int coeff_bands[16] = {0, 1, 2, 3, 6, 4, 5, 6, 6, 6, 6, 6, 6, 6, 6, 7};
+    WEBP *w = calloc(1, sizeof *w);
+    memcpy(w->k.coeff_prob, probs, sizeof w->k.coeff_prob);
+    for (int s = 0; s < 4; s++) {
+        w->d[s].y1_dc = q[8 * s + 0]; w->d[s].y1_ac = q[8 * s + 1]; w->d[s].y2_dc = q[8 * s + 2];
+        w->d[s].y2_ac = q[8 * s + 3]; w->d[s].uv_dc = q[8 * s + 4]; w->d[s].uv_ac = q[8 * s + 5];
+    }
+    uint8_t *copy_a = malloc((size_t)len + 16), *copy_b = malloc((size_t)len + 16);
+    memset(copy_a, 0, (size_t)len + 16);
+    memcpy(copy_a, bytes, (size_t)len);
+    memcpy(copy_b, copy_a, (size_t)len + 16);
+    bool_dec *bt = bool_dec_init(copy_a, len), *rec = bool_dec_init(copy_b, len);
+    struct context *top = calloc((size_t)n_mb, sizeof *top), *rtop = calloc((size_t)n_mb, sizeof *rtop);
+    struct context left, rleft;
+    memset(&left, 0, sizeof left);
+    memset(&rleft, 0, sizeof rleft);
+    const VP8BandProbas *bands[NUM_TYPES][16];
+    for (int t = 0; t < NUM_TYPES; ++t)
+        for (int b = 0; b < 16; ++b) bands[t][b] = &w->k.coeff_prob[t][coeff_bands[b]];
+    memset(levels_out, 0, (size_t)n_mb * 25 * 16 * sizeof(int16_t));
+    memset(nz_out, 0, (size_t)n_mb * 25);
+    for (int x = 0; x < n_mb; x++) {
+        struct macro_block b;
+        memset(&b, 0, sizeof b);
+        b.intra_y_mode = modes[x];
+        b.segment_id = seg[x] & 3;
+        b.x = x;
+        int16_t *dst = dst_out + 384 * x;
+        memset(dst, 0, 384 * sizeof(int16_t)); /* vp8_decode zeroes the MB's coefficients before the call (webp.c:1844 area) */
+        vp8_decode_residual_block(w, &b, dst, &left, top, bt);
+        /* ---- the recorder: same parse, quantisers 1 ---- */
+        int16_t *lv = levels_out + (size_t)x * 25 * 16;
+        uint8_t *nz = nz_out + (size_t)x * 25;
+        int first = 0;
+        const VP8BandProbas *const *acp = bands[3];
+        if (b.intra_y_mode != B_PRED) {
+            const int ctx = rtop[x].ctx[0] + rleft.ctx[0];
+            const int n = vp8_get_coefficients(rec, lv + 24 * 16, bands[1], 0, ctx, 1, 1);
+            rtop[x].ctx[0] = rleft.ctx[0] = n > 0;
+            nz[24] = (uint8_t)n;
+            first = 1;
+            acp = bands[0];
+        }
+        for (int y = 0; y < 4; y++) {
+            uint8_t l = rleft.ctx[y + 1];
+            for (int xx = 0; xx < 4; xx++) {
+                const int n = vp8_get_coefficients(rec, lv + (y * 4 + xx) * 16, acp, first, rtop[x].ctx[xx + 1] + l, 1, 1);
+                nz[y * 4 + xx] = (uint8_t)n;
+                l = rtop[x].ctx[xx + 1] = n > 0;
+            }
+            rleft.ctx[y + 1] = l;
+        }
+        int blk = 16;
+        for (int ch = 5; ch <= 7; ch += 2)
+            for (int y = 0; y < 2; y++) {
+                uint8_t l = rleft.ctx[y + ch];
+                for (int xx = 0; xx < 2; xx++, blk++) {
+                    const int n = vp8_get_coefficients(rec, lv + blk * 16, bands[2], 0, l + rtop[x].ctx[xx + ch], 1, 1);
+                    nz[blk] = (uint8_t)n;
+                    l = rtop[x].ctx[xx + ch] = n > 0;
+                }
+                rleft.ctx[y + ch] = l;
+            }
+    }
+    /* both decoders must have consumed the same bits: the recorder replayed the reference's parse */
+    const int same = bt->value == rec->value && bt->range == rec->range && bt->count == rec->count;
+    const long used = (long)(bt->bits->ptr - bt->bits->start);
+    bool_dec_free(bt); /* frees the byte buffers too (utils/bitstream.c:40-45) */
+    bool_dec_free(rec);
+    free(top); free(rtop); free(w);
+    if (used + 8 >= len) return -2; /* the caller's bytes ran out: everything behind that point would be padding */
+    return same ? 0 : -1;
 }

@@ -132,6 +132,38 @@ def gen_blocks(R):
     save("hevc_transform.npz", **hv)
 
 
+def gen_hevc_glue(R):
+    """scale_and_transform itself (coding/hevc.c:4172-4251) through oracle/ref_statics_hevc.c::ref_hevc_scale_and_transform:
+    the transquant-bypass copy, transform skip (<< tsShift), the 4x4 rotation, scaling lists dropped for
+    transform-skipped blocks larger than 4x4 (hevc.c:3786-3787), the DST entry of intra luma 4x4 and the chroma qP
+    mapping of 8.6.1.  Keys: <kind>_<n>_c<cIdx>_bd<bd>_qp<qp>[_sf][_epp] = residual, q<same> = the qP the reference derived."""
+    rng = np.random.default_rng(0xA12)
+    hv = {}
+    for n in (4, 8, 16, 32):
+        nb = 12 if n < 32 else 6
+        lv = np.rint(rng.laplace(0, 9.0, size=(nb, n * n))).astype(np.int16)
+        lv[:4] = adversarial(rng, 8, n * n)[[0, 2, 5, 7]][:4]           # zero, +-max, small, full range
+        lv[4] = rng.integers(-32768, 32768, size=n * n)
+        hv[f"level_{n}"] = lv
+        sf = rng.integers(1, 256, size=n * n).astype(np.uint8)
+        hv[f"sfactor_{n}"] = sf
+        kinds = [("bypass", 1, 0, 0), ("ts", 0, 1, 0), ("plain", 0, 0, 0), ("rot_bypass", 1, 0, 1), ("rot_ts", 0, 1, 1),
+                 ("rot_plain", 0, 0, 1)]
+        for kind, bypass, ts, rot in kinds:
+            for (cidx, bd, qp, epp, cat, use_sf) in ((0, 8, 22, 0, 1, 0), (0, 8, 37, 0, 1, 1), (1, 8, 30, 0, 1, 0), (2, 10, 45, 0, 1, 1),
+                                                     (1, 10, 51, 0, 3, 1), (0, 12, 60, 1, 1, 0), (2, 8, 4, 0, 3, 0)):
+                out = np.zeros_like(lv)
+                qps = np.zeros(nb, np.int32)
+                for i in range(nb):
+                    qps[i] = R.ref_hevc_scale_and_transform(lv[i].copy(), out[i], n, cidx, qp, bd, epp, bypass, ts, rot, cat,
+                                                            sf.ctypes.data_as(C.c_void_p) if use_sf else None)
+                assert (qps == qps[0]).all()
+                key = f"{kind}_{n}_c{cidx}_bd{bd}_qp{qp}" + ("_sf" if use_sf else "") + ("_epp" if epp else "") + f"_cat{cat}"
+                hv[key] = out
+                hv["q" + key] = qps[:1]
+    save("hevc_scale_and_transform.npz", **hv)
+
+
 def gen_vp8_mbs(R):
     """Per-macroblock VP8 residual (dequant + WHT + IDCT with the nz rule) through the
     reference's own functions (oracle/ref_statics_webp.c::ref_vp8_residual_mb)."""
@@ -145,6 +177,17 @@ def gen_vp8_mbs(R):
                                   np.ascontiguousarray(q[info[i, 26], :6]), out[i])
         res[f"{tag}_levels"], res[f"{tag}_info"], res[f"{tag}_residual"] = lv, info, out
     save("vp8_mbs.npz", **res)
+
+
+def gen_vp8_driven(R):
+    """vp8_decode_residual_block itself (format/webp.c:1125-1199) parsing synthetic bool-decoder streams: its own
+    token parse, dequantisation, "nz > 1" WHT choice, DC scatter and "nz > 1 || dc != 0" IDCT rule
+    (oracle/ref_statics_webp.c::ref_vp8_residual_blocks_driven records the levels it parsed)."""
+    res = {}
+    for k, regime in enumerate(("random", "sparse", "dense")):
+        lv, info, q, dst = O.ref_vp8_driven(256, seed=10 + k, regime=regime)
+        res.update({f"{regime}_levels": lv, f"{regime}_info": info, f"{regime}_quant": q, f"{regime}_residual": dst})
+    save("vp8_residual_driven.npz", **res)
 
 
 def gen_vp8_frames(R):
@@ -506,8 +549,8 @@ def main():
         sys.exit("make_golden.py needs /root/reference (build container only)")
     O.build_ref()
     R = O.ref()
-    steps = [("blocks", gen_blocks), ("vp8 macroblocks", gen_vp8_mbs), ("vp8 frames", gen_vp8_frames),
-             ("hevc intra", gen_hevc_intra), ("vp8 loop filter", gen_vp8_loopfilter), ("colour", gen_color),
+    steps = [("blocks", gen_blocks), ("vp8 macroblocks", gen_vp8_mbs), ("vp8 driven", gen_vp8_driven), ("vp8 frames", gen_vp8_frames),
+             ("hevc intra", gen_hevc_intra), ("hevc glue", gen_hevc_glue), ("vp8 loop filter", gen_vp8_loopfilter), ("colour", gen_color),
              ("grids", gen_grids), ("files", gen_files), ("webp file", gen_webp_file)]
     only = sys.argv[2] if len(sys.argv) == 3 and sys.argv[1] == "--only" else None   # e.g. --only "hevc intra"
     for name, fn in steps:

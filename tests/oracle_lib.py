@@ -117,12 +117,15 @@ def ref():
         L.ref_vp8_iwht_long.argtypes = [i16p, i16p]
         L.ref_vp8_iwht_fast.argtypes = [i16p, i16p]
         L.ref_vp8_residual_mb.argtypes = [i16p, u8p, C.c_int, u16p, i16p]
+        L.ref_vp8_residual_blocks_driven.argtypes = [u8p, C.c_int, C.c_int, u8p, u8p, u16p, u8p, i16p, u8p, i16p]
         L.ref_vp8_recon_frame.argtypes = [C.c_int, C.c_int, u8p, i16p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ref_vp8_loopfilter_frame.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, u8p, u8p, u8p]
         L.ref_hevc_intra_tu.argtypes = [C.c_int] * 6 + [C.c_uint64, C.c_uint64, i16p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.idct_4x4_hevc.argtypes = [i16p, i16p, C.c_int, C.c_bool]
         L.ref_hevc_scale.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.ref_hevc_transform.argtypes = [i16p, i16p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ref_hevc_scale_and_transform.argtypes = [i16p, i16p] + [C.c_int] * 9 + [C.c_void_p]
+        L.ref_hevc_scale_and_transform.restype = C.c_int
         L.YUV420_to_BGRA32.argtypes = [u8p, C.c_int, u8p, u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.YUV420_to_BGRA32_16bit.argtypes = [u8p, C.c_int, i16p, i16p, i16p, C.c_int, C.c_int, C.c_int,
                                              C.c_int, C.c_int]
@@ -180,6 +183,36 @@ def oracle_vp8_frame(mbcols, mbrows, modes, residual, resmap=None):
 
 def ref_vp8_frame(mbcols, mbrows, modes, residual, resmap=None):
     return _vp8_frame(ref().ref_vp8_recon_frame, mbcols, mbrows, modes, residual, resmap)
+
+
+def ref_vp8_driven(n_mb, seed, regime="random"):
+    """The reference's vp8_decode_residual_block (format/webp.c:1125-1199) run over n_mb macroblocks of one row from a
+    synthetic bool-decoder state (seeded random bytes and coefficient probabilities; oracle/ref_statics_webp.c::
+    ref_vp8_residual_blocks_driven).  Returns what ffhip_vp8_residual_batch takes -- levels [n][25][16], info [n][32],
+    quant [4][8] -- and the residual [n][384] the reference wrote."""
+    from ffpic_amd import synth
+    rng = np.random.default_rng(0x7B8 + seed)
+    by = rng.integers(0, 256, size=n_mb * 4096, dtype=np.uint8)
+    by[0] &= 0x7F                      # a first byte of 255 leaves this bool decoder with value == range for good
+    modes = np.where(rng.random(n_mb) < 0.4, 4, rng.integers(0, 4, size=n_mb)).astype(np.uint8)
+    seg = rng.integers(0, 4, size=n_mb).astype(np.uint8)
+    q = synth.vp8_quant(seed=seed)
+    probs = rng.integers(1, 256, size=(4, 8, 3, 11)).astype(np.uint8)
+    if regime == "sparse":             # node 0 decides "end of block": likely
+        probs[..., 0] = rng.integers(160, 256, size=(4, 8, 3))
+    elif regime == "dense":            # rarely end of block, rarely zero: long blocks with large tokens
+        probs[..., 0] = rng.integers(1, 40, size=(4, 8, 3))
+        probs[..., 1] = rng.integers(1, 80, size=(4, 8, 3))
+    lv = np.zeros((n_mb, 25, 16), np.int16)
+    nz = np.zeros((n_mb, 25), np.uint8)
+    dst = np.zeros((n_mb, 384), np.int16)
+    rc = ref().ref_vp8_residual_blocks_driven(by, by.size, n_mb, modes, seg, q, probs, lv, nz, dst)
+    assert rc == 0, rc
+    info = np.zeros((n_mb, 32), np.uint8)
+    info[:, :25] = nz
+    info[:, 25] = modes != 4
+    info[:, 26] = seg
+    return lv, info, q, dst
 
 
 # ---------------------------------------------------------------- HEVC intra helpers

@@ -47,6 +47,39 @@ def test_golden_dst4(golden):
             assert np.array_equal(got, oracle_tus(4, lv, info, bd, epp, None)), (bd, epp, qp)
 
 
+def test_golden_scale_and_transform_glue(golden):
+    """a12, the golden twin of test_mixed_flags_vs_oracle: residuals the reference's own scale_and_transform
+    (hevc.c:4172-4251) produced on its bypass / transform-skip / rotation branches, per TU size one mixed batch"""
+    from test_oracle_golden import glue_cases
+    g = golden("hevc_scale_and_transform.npz")
+    groups = {}
+    for case in glue_cases(g):
+        key, kind, n, cidx, bd, epp, flags, qp, sf = case
+        groups.setdefault((n, bd, epp), []).append(case)
+    checked = 0
+    for (n, bd, epp), cases in groups.items():
+        lv0 = g[f"level_{n}"]
+        nb = lv0.shape[0]
+        scaling = np.ones((6, n * n), np.uint8)
+        scaling[1] = g[f"sfactor_{n}"]                     # matrixId 1 = the golden list, 0 = a list of ones is NOT flat 16:
+        for with_sf in (False, True):                      # so batches are split by "has a scaling list"
+            sel = [c for c in cases if (c[8] is not None) == with_sf]
+            if not sel:
+                continue
+            lv = np.concatenate([lv0] * len(sel))
+            info = np.zeros((len(lv), 4), np.uint8)
+            exp = np.concatenate([g[c[0]] for c in sel])
+            for k, c in enumerate(sel):
+                info[k * nb:(k + 1) * nb, 0] = c[7]
+                info[k * nb:(k + 1) * nb, 1] = c[6]
+                info[k * nb:(k + 1) * nb, 2] = 1
+            got = ops.hevc_residual_batch(n, lv, info, bitdepth=bd, epp=bool(epp), scaling=scaling if with_sf else None)
+            bad = np.nonzero((got != exp).any(axis=1))[0]
+            assert bad.size == 0, (n, bd, epp, with_sf, [sel[b // nb][0] for b in bad[:4]])
+            checked += len(sel)
+    assert checked == 6 * 7 * 4
+
+
 @pytest.mark.parametrize("n,n_tu", [(4, 1), (4, 1000), (8, 37), (16, 9), (32, 5), (32, 64)])
 def test_mixed_flags_vs_oracle(n, n_tu):
     rng = np.random.default_rng(n * 1000 + n_tu)

@@ -73,6 +73,25 @@ def test_vp8_macroblock_residual(golden, ffo):
     assert g["syn_info"][i, 3] == 1 and g["syn_levels"][i, 3, 5] == 7
 
 
+def test_vp8_residual_block_driven(golden, ffo):
+    """the residual the reference's vp8_decode_residual_block wrote while parsing synthetic streams, from the levels
+    and token counts it parsed: closes the glue the per-MB wrapper restates (nz rule, Y2 -> DC scatter)"""
+    g = golden("vp8_residual_driven.npz")
+    quirk = 0
+    for regime in ("random", "sparse", "dense"):
+        lv, info, q, exp = (g[f"{regime}_{k}"] for k in ("levels", "info", "quant", "residual"))
+        for i in range(lv.shape[0]):
+            out = np.zeros(384, np.int16)
+            ffo.ffo_vp8_residual_mb(np.ascontiguousarray(lv[i]).reshape(-1), info[i], int(info[i, 25]),
+                                    np.ascontiguousarray(q[info[i, 26], :6]), out)
+            assert np.array_equal(out, exp[i]), (regime, i)
+        # blocks of MBs with a Y2 block whose single token is an AC coefficient: IDCT only if the WHT gave them a DC
+        has = info[:, 25] == 1
+        quirk += int(((info[:, :16] == 1) & has[:, None]).sum())
+    assert quirk > 50
+    assert (g["dense_info"][:, :25] == 16).sum() > 1000 and (g["sparse_info"][:, :25] == 0).sum() > 1000
+
+
 def test_vp8_frame_prediction(golden):
     """pred_luma / pred_chrome + residual add over whole frames: mixed modes with a skipped-MB
     residual alias, every 16x16/chroma mode and every 4x4 mode at every edge position"""
@@ -158,6 +177,46 @@ def test_hevc_scale_and_transform(golden, ffo, n):
                 r = np.zeros(n * n, np.int16)
                 ffo.ffo_hevc_transform(d, r, n, 0, bd, 0)
                 assert np.array_equal(r, g[f"r_{n}_bd{bd}_qp{qp}"][i]), (n, bd, qp, i)
+
+
+def glue_cases(g):
+    """(key, kind, n, cIdx, bitdepth, epp, flags, qP, scaling list or None) for every residual of hevc_scale_and_transform.npz"""
+    for key in g:
+        if key.startswith(("q", "level_", "sfactor_")):
+            continue
+        parts = key.split("_")
+        kind = "_".join(parts[:2]) if parts[0] == "rot" else parts[0]
+        rest = parts[2:] if parts[0] == "rot" else parts[1:]
+        n, cidx, bd = int(rest[0]), int(rest[1][1:]), int(rest[2][2:])
+        use_sf, epp = "sf" in rest, "epp" in rest
+        flags = (1 if n == 4 and cidx == 0 else 0) | (2 if kind.endswith("ts") else 0) | (4 if kind.endswith("bypass") else 0) | \
+                (8 if kind.startswith("rot") and n == 4 else 0)      # rotateCoeffs exists for 4x4 only (hevc.c:4203-4207)
+        yield key, kind, n, cidx, bd, int(epp), flags, int(g["q" + key][0]), (g[f"sfactor_{n}"] if use_sf else None)
+
+
+def test_hevc_scale_and_transform_glue(golden, ffo):
+    """a12: the oracle's ffo_hevc_residual_tu against the reference's own scale_and_transform (hevc.c:4172-4251) on
+    the bypass / transform-skip / rotation branches, with and without scaling lists, luma and chroma qP"""
+    g = golden("hevc_scale_and_transform.npz")
+    kinds = set()
+    for key, kind, n, cidx, bd, epp, flags, qp, sf in glue_cases(g):
+        lv = g[f"level_{n}"]
+        for i in range(lv.shape[0]):
+            r = np.zeros(n * n, np.int16)
+            ffo.ffo_hevc_residual_tu(lv[i].copy(), r, n, qp, flags, bd, epp, None if sf is None else sf.ctypes.data_as(C.c_void_p))
+            assert np.array_equal(r, g[key][i]), (key, i)
+        kinds.add(kind)
+    assert kinds == {"bypass", "ts", "plain", "rot_bypass", "rot_ts", "rot_plain"}
+    # the branches are really distinct in the goldens: rotation changes 4x4 results and only those; a scaling list
+    # changes transform-skipped 4x4 blocks but not larger ones (hevc.c:3786-3787)
+    assert not np.array_equal(g["rot_ts_4_c0_bd8_qp22_cat1"], g["ts_4_c0_bd8_qp22_cat1"])
+    assert np.array_equal(g["rot_ts_8_c0_bd8_qp22_cat1"], g["ts_8_c0_bd8_qp22_cat1"])
+    lv4, lv8 = g["level_4"], g["level_8"]
+    flat4, flat8 = np.zeros_like(lv4), np.zeros_like(lv8)
+    for i in range(lv4.shape[0]):
+        ffo.ffo_hevc_residual_tu(lv4[i].copy(), flat4[i], 4, 37, 1 | 2, 8, 0, None)
+        ffo.ffo_hevc_residual_tu(lv8[i].copy(), flat8[i], 8, 37, 2, 8, 0, None)
+    assert not np.array_equal(flat4, g["ts_4_c0_bd8_qp37_sf_cat1"]) and np.array_equal(flat8, g["ts_8_c0_bd8_qp37_sf_cat1"])
 
 
 def test_color_triples(golden, ffo):

@@ -48,6 +48,18 @@ def test_vp8_random(libs):
         assert np.array_equal(wa, wr)
 
 
+@pytest.mark.parametrize("regime", ["random", "sparse", "dense"])
+def test_vp8_residual_block_driven(libs, regime):
+    """ffo_vp8_residual_mb against vp8_decode_residual_block itself (webp.c:1125-1199) on fresh synthetic streams"""
+    F, _ = libs
+    lv, info, q, exp = O.ref_vp8_driven(400, seed=77, regime=regime)
+    for i in range(lv.shape[0]):
+        out = np.zeros(384, np.int16)
+        F.ffo_vp8_residual_mb(np.ascontiguousarray(lv[i]).reshape(-1), info[i], int(info[i, 25]),
+                              np.ascontiguousarray(q[info[i, 26], :6]), out)
+        assert np.array_equal(out, exp[i]), i
+
+
 def test_hevc_random(libs):
     F, R = libs
     rng = np.random.default_rng(13)
@@ -70,6 +82,35 @@ def test_hevc_random(libs):
             F.ffo_hevc_transform(da.copy(), ra, n, 0, bd, 0)
             R.ref_hevc_transform(dr.copy(), rr, n, 0, bd, 0)
             assert np.array_equal(ra, rr)
+
+
+def test_hevc_scale_and_transform_every_branch(libs):
+    """ffo_hevc_residual_tu against the reference's scale_and_transform (hevc.c:4172-4251) called as a whole: random
+    bypass / transform-skip / rotation flags, scaling lists, bit depths, extended precision, luma and chroma (the qP
+    the reference derives in 8.6.1 is handed to the restatement)"""
+    import ctypes as C
+    F, R = libs
+    rng = np.random.default_rng(0xA12)
+    seen = set()
+    for n in (4, 8, 16, 32):
+        for _ in range(150 if n < 32 else 60):
+            lv = rng.integers(-32768, 32768, size=n * n).astype(np.int16) if rng.random() < 0.3 else \
+                np.rint(rng.laplace(0, 8, size=n * n)).astype(np.int16)
+            bd, epp = int(rng.choice([8, 10, 12])), int(rng.random() < 0.2)
+            qp = int(rng.integers(0, 52 + 6 * (bd - 8)))
+            cidx, cat = int(rng.integers(0, 3)), int(rng.choice([1, 3]))
+            bypass, ts, rot = int(rng.random() < 0.25), int(rng.random() < 0.4), int(rng.random() < 0.5)
+            sf = rng.integers(1, 256, size=n * n).astype(np.uint8) if rng.random() < 0.5 else None
+            sfp = None if sf is None else sf.ctypes.data_as(C.c_void_p)
+            r, a = np.zeros(n * n, np.int16), np.zeros(n * n, np.int16)
+            qP = R.ref_hevc_scale_and_transform(lv.copy(), r, n, cidx, qp, bd, epp, bypass, ts, rot, cat, sfp)
+            if cidx == 0:
+                assert qP == qp
+            flags = (1 if n == 4 and cidx == 0 else 0) | (2 if ts else 0) | (4 if bypass else 0) | (8 if rot and n == 4 else 0)
+            F.ffo_hevc_residual_tu(lv.copy(), a, n, qP, flags, bd, epp, sfp)
+            assert np.array_equal(a, r), (n, bd, epp, qp, cidx, cat, bypass, ts, rot, sf is not None)
+            seen.add((bypass, ts, bool(rot and n == 4), sf is not None and n > 4))
+    assert len(seen) == 12          # rotation exists at 4x4 only, the dropped scaling list above 4x4 only
 
 
 @pytest.mark.parametrize("nc,h,v", [(3, 2, 2), (3, 1, 1), (3, 2, 1), (3, 1, 2), (1, 1, 1)])

@@ -24,6 +24,14 @@ def test_golden_macroblocks(golden):
         assert np.array_equal(got, g[f"{tag}_residual"]), tag
 
 
+def test_golden_residual_block_driven(golden):
+    """what the reference's vp8_decode_residual_block (webp.c:1125-1199) itself wrote while parsing synthetic streams"""
+    g = golden("vp8_residual_driven.npz")
+    for regime in ("random", "sparse", "dense"):
+        got = ops.vp8_residual_batch(g[f"{regime}_levels"], g[f"{regime}_info"], g[f"{regime}_quant"])
+        assert np.array_equal(got, g[f"{regime}_residual"]), regime
+
+
 @pytest.mark.parametrize("n,adv", [(1, False), (7, False), (8, True), (9, True), (8160, False), (1000, True)])
 def test_vs_oracle(n, adv):
     """ragged counts (partial workgroups), one 1080p frame worth of macroblocks, full-range levels"""

@@ -5,14 +5,18 @@ on MI355X, the metric BASELINE.json names.
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one batch: per GPU, 256 synthetic
-3840x2160 4:2:0 coefficient grids (BASELINE config 3 geometry) already resident in
-HBM, reconstructed to BGRA in HBM by ONE launch of k_jpeg420_fused.  Images are
-independent, so ranks own disjoint image ranges (weak scaling: per-GPU work fixed);
-the only collective is a tiny all-gather of per-rank status records (RCCL) that
-closes the batch.  Rank 0 prints one JSON line.
+A "step" is one pass of the hot path over one batch: 256 synthetic 3840x2160 4:2:0 coefficient grids
+(BASELINE config 3) already resident in HBM, reconstructed to BGRA in HBM by ONE launch of
+k_jpeg420_fused per GPU.  Images are independent, so ranks own disjoint contiguous image ranges
+(ffhip_shard_range) and the only collective is the batch close: one RCCL all-gather of a 32-byte
+{rank, status, first, count, checksum} record per rank, issued from C (ffhip_batch_close).
+Default scaling is STRONG -- the batch is config 3's 256 images in total, 32 per GPU at N = 8;
+`--scaling weak` keeps 256 images per GPU instead.  Rank 0 prints one JSON line.
 
-PyTorch is plumbing here: device memory, the stream handle and torch.distributed.
+At N = 1 the line also carries `extra`: BASELINE configs 2, 4 and 5 measured the same way (HIP events on the
+launch stream, inputs resident in HBM), each with its own roofline figures, parity flag and CPU baseline.
+
+PyTorch is plumbing here: device memory, the stream handle and torch.distributed for process bootstrap.
 The compute goes through the C ABI of ffpic_amd/libffpic_hip.so.
 """
 import argparse
@@ -32,9 +36,9 @@ import torch.distributed as dist  # noqa: E402
 from ffpic_amd import capi, ops, shard, synth  # noqa: E402
 
 WORKLOADS = {
-    # name: (mcu_cols, mcu_rows, images per GPU, description)
-    "c3": (240, 135, 256, "C3: 256 x 3840x2160 4:2:0 JPEG coefficient grids per GPU"),
-    "c2": (120, 68, 1024, "C2: 1024 x 1920x1088 4:2:0 JPEG coefficient grids per GPU"),
+    # name: (mcu_cols, mcu_rows, images in the batch, description)
+    "c3": (240, 135, 256, "C3: 256 x 3840x2160 4:2:0 JPEG coefficient grids"),
+    "c2": (120, 68, 1024, "C2: 1024 x 1920x1088 4:2:0 JPEG coefficient grids"),
 }
 BYTES_PER_PIXEL = 7.0   # 3 B int16 coefficients (1.5 samples) + 4 B BGRA at 4:2:0
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -68,12 +72,19 @@ def gen_batch_on_device(dev, cols, rows, n_images, seed):
     return plane(mcus * 4, 0), plane(mcus, 1), plane(mcus, 1), q
 
 
+def oracle_lib():
+    """The checker (tests/oracle_lib.py): used only for parity spot checks and the cpu_baseline legs, never timed as
+    the product and never on its path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    return O
+
+
 def cpu_baseline(cols, rows, t_y, t_u, t_v, q, budget_s=20.0):
     """The reference's own C (oracle/_ref, compiled from /root/reference in the build
     container) -- or our bit-exact port when that .so did not travel -- timed on the
     host cores over a bounded sample of the same workload."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
+    O = oracle_lib()
     from concurrent.futures import ThreadPoolExecutor
     mcus = cols * rows
     cores = max(1, min(os.cpu_count() or 1, 16, t_u.numel() // (mcus * 64)))
@@ -109,7 +120,8 @@ def cpu_baseline(cols, rows, t_y, t_u, t_v, q, budget_s=20.0):
 
 def pmc_traffic(workload):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), already
-    corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950, KiB units)."""
+    corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950, KiB units).  A constant read from
+    profiles/latest_pmc.json, not a counter collected in this run (counters need their own rocprofv3 pass)."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
         if rec.get("workload") == workload:
@@ -119,14 +131,261 @@ def pmc_traffic(workload):
     return None
 
 
+class Timer:
+    """HIP events on the launch stream (ffhip_event_*): average duration of `fn` over `reps` back-to-back calls."""
+
+    def __init__(self, L, stream):
+        self.L, self.stream = L, stream
+        self.e0, self.e1 = L.ffhip_event_create(), L.ffhip_event_create()
+
+    def ms(self, fn, reps=10, warm=2):
+        for _ in range(warm):
+            fn()
+        capi.check(self.L.ffhip_event_record(self.e0, self.stream))
+        for _ in range(reps):
+            fn()
+        capi.check(self.L.ffhip_event_record(self.e1, self.stream))
+        capi.check(self.L.ffhip_stream_sync(self.stream))
+        return self.L.ffhip_event_elapsed_ms(self.e0, self.e1) / reps
+
+
+def roof(bytes_per_launch, ms):
+    gbs = bytes_per_launch / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_launch": int(bytes_per_launch), "kernel_ms": round(ms, 4)}
+
+
+# --------------------------------------------------------------------------------------------------------------
+# extra: BASELINE configs 2, 4, 5 (N = 1 only, after the headline timing)
+
+def extra_c2(L, dev, stream, T):
+    """configs[1]: 1024 x 1920x1088 grids, one launch of k_jpeg420_fused"""
+    cols, rows, n = 120, 68, 1024
+    geom = capi.jpeg_geom(cols, rows)
+    H, W = geom.height, geom.width
+    t_y, t_u, t_v, q = gen_batch_on_device(dev, cols, rows, n, seed=77)
+    t_q = torch.from_numpy(q.astype(np.int16)).to(dev)
+    out = torch.empty(n * W * 4 * H, dtype=torch.uint8, device=dev)
+
+    def step():
+        ops.jpeg_recon_batch(geom, n, t_y.data_ptr(), t_u.data_ptr(), t_v.data_ptr(), t_q.data_ptr(), 0, out.data_ptr(), W * 4, W * 4 * H,
+                             None, 0, stream)
+    ms = T.ms(step, reps=10, warm=3)
+    O = oracle_lib()
+    mcus = cols * rows
+    parity = True
+    for i in (0, n - 1):
+        exp = O.oracle_jpeg_recon(O.make_geom(cols, rows), t_y[i * mcus * 256:(i + 1) * mcus * 256].cpu().numpy(),
+                                  t_u[i * mcus * 64:(i + 1) * mcus * 64].cpu().numpy(), t_v[i * mcus * 64:(i + 1) * mcus * 64].cpu().numpy(), q)[0]
+        parity = parity and bool(np.array_equal(out[i * W * 4 * H:(i + 1) * W * 4 * H].cpu().numpy().reshape(H, W, 4), exp))
+    res = {"workload": "C2: 1024 x 1920x1088 4:2:0 JPEG coefficient grids, one launch", "value": round(n * H * W / ms / 1e3, 1), "unit": "Mpixels/s",
+           "ms_per_step": round(ms, 4), "parity_vs_oracle_first_and_last_image": parity,
+           "roofline": dict(roof(BYTES_PER_PIXEL * n * H * W, ms), kernel="k_jpeg420_fused")}
+    del t_y, t_u, t_v, out
+    torch.cuda.empty_cache()
+    return res
+
+
+def extra_c4(L, dev, stream, T, cpu=True):
+    """configs[3]: WebP lossy post-entropy chain on 16 x 1080p key frames: residual (dequant + WHT + 4x4 IDCT) ->
+    intra prediction + residual add -> loop filter (normal) -> YUV420 -> BGRA"""
+    c, r, nf = 120, 68, 16
+    n_mb = c * r
+    q = synth.vp8_quant(seed=2)
+    filt = synth.vp8_filters(seed=2)
+    lv, info, modes = [], [], []
+    for i in range(nf):
+        a, b = synth.vp8_macroblocks(n_mb, seed=100 + i)
+        m = synth.vp8_modes(c, r, seed=100 + i)
+        m[:, 18] = b[:, 26]
+        b[:, 25] = m[:, 0] != 4                 # a Y2 block exactly when the macroblock is not B_PRED
+        lv.append(a); info.append(b); modes.append(m)
+    h_modes = np.ascontiguousarray(np.stack(modes))
+    d_lv = torch.from_numpy(np.concatenate(lv)).to(dev)
+    d_info = torch.from_numpy(np.concatenate(info)).to(dev)
+    d_q = torch.from_numpy(q.astype(np.int16)).to(dev)
+    d_modes = torch.from_numpy(h_modes).to(dev)
+    d_filt = torch.from_numpy(filt).to(dev)
+    d_res = torch.empty((nf * n_mb, 384), dtype=torch.int16, device=dev)
+    Y = torch.zeros((nf, 16 * r, 16 * c), dtype=torch.uint8, device=dev)
+    U = torch.zeros((nf, 8 * r, 8 * c), dtype=torch.uint8, device=dev)
+    V = torch.zeros_like(U)
+    Wp, Hp = 16 * c, 16 * r
+    bgra = torch.empty((nf, Hp, Wp * 4), dtype=torch.uint8, device=dev)
+
+    def s_res():
+        capi.check(L.ffhip_vp8_residual_batch(nf * n_mb, d_lv.data_ptr(), d_info.data_ptr(), d_q.data_ptr(), d_res.data_ptr(), stream))
+
+    def s_pred():
+        capi.check(L.ffhip_vp8_predict_recon(c, r, nf, h_modes.ctypes.data, d_modes.data_ptr(), d_res.data_ptr(), n_mb * 384, None, Y.data_ptr(), U.data_ptr(),
+                                             V.data_ptr(), 256 * n_mb, 64 * n_mb, stream))
+
+    def s_lf():
+        capi.check(L.ffhip_vp8_loopfilter(c, r, nf, 2, d_modes.data_ptr(), d_filt.data_ptr(), Y.data_ptr(), U.data_ptr(), V.data_ptr(), 256 * n_mb, 64 * n_mb, stream))
+
+    def s_col():
+        capi.check(L.ffhip_yuv420_to_bgra(bgra.data_ptr(), Wp * 4, Y.data_ptr(), U.data_ptr(), V.data_ptr(), Wp, Wp // 2, r, c, nf, Hp * Wp, Hp * Wp // 4, Hp * Wp * 4, stream))
+
+    def chain():
+        s_res(); s_pred(); s_lf(); s_col()
+    px = nf * Hp * Wp
+    chain_ms = T.ms(chain, reps=5, warm=2)
+    stages = {}
+    for name, fn, nbytes in (("residual", s_res, nf * n_mb * (800 + 32 + 768)), ("predict_recon", s_pred, nf * n_mb * (768 + 20 + 384)),
+                             ("loopfilter", s_lf, nf * n_mb * (2 * 384 + 20)), ("yuv420_to_bgra", s_col, px * 5.5)):
+        ms = T.ms(fn, reps=5, warm=1)
+        stages[name] = {"ms": round(ms, 4), "GB/s": round(nbytes / ms / 1e6, 1), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                        "algorithmic_bytes": int(nbytes)}
+    stages["predict_recon"]["bound"] = stages["loopfilter"]["bound"] = "dependency chain (a wave per macroblock row), not HBM"
+    for p in (Y, U, V):                           # the reference's wrapped 16x16 H_PRED / V_PRED at the frame edge read what the planes
+        p.zero_()                                 # held before the frame (predict.c:338-353): zeros, as in its freshly allocated planes
+    chain()                                       # leave the planes as ONE pass of the chain makes them
+    capi.check(L.ffhip_stream_sync(stream))
+    res = {"workload": "C4: 16 x 1920x1088 VP8 key frames, residual -> predict -> loop filter (normal) -> BGRA", "chain_ms": round(chain_ms, 4),
+           "value": round(px / chain_ms / 1e3, 1), "unit": "Mpixels/s", "stages": stages,
+           "roofline": dict(roof(nf * n_mb * 1600, stages["residual"]["ms"]), kernel="k_vp8_residual")}
+    if cpu:
+        O = oracle_lib()
+        use_ref = os.path.exists(O.REF_SO)
+        lib = O.ref() if use_ref else O.ffo()
+        pre = "ref_" if use_ref else "ffo_"
+        t0 = time.perf_counter()
+        res0 = np.zeros((n_mb, 384), np.int16)
+        fn = getattr(lib, pre + "vp8_residual_mb")
+        for i in range(n_mb):
+            fn(np.ascontiguousarray(lv[0][i]).reshape(-1), info[0][i], int(info[0][i, 25]), np.ascontiguousarray(q[info[0][i, 26], :6]), res0[i])
+        y, u, v = (O.ref_vp8_frame if use_ref else O.oracle_vp8_frame)(c, r, modes[0], res0)
+        y, u, v = [np.ascontiguousarray(p).copy() for p in (y, u, v)]
+        getattr(lib, pre + "vp8_loopfilter_frame")(c, r, 2, np.ascontiguousarray(modes[0]).reshape(-1), np.ascontiguousarray(filt).reshape(-1),
+                                                   y.reshape(-1), u.reshape(-1), v.reshape(-1))
+        o = np.zeros((Hp, Wp * 4), np.uint8)
+        (lib.YUV420_to_BGRA32 if use_ref else lib.ffo_yuv420_to_bgra32)(o.reshape(-1), Wp * 4, y.reshape(-1), u.reshape(-1), v.reshape(-1), Wp, Wp // 2, r, c)
+        dt = time.perf_counter() - t0
+        res["parity_vs_reference_frame0"] = bool(np.array_equal(bgra[0].cpu().numpy(), o))
+        res["cpu_baseline"] = {"value": round(Hp * Wp / dt / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "reference" if use_ref else "port",
+                               "sample": "frame 0 of the batch (1920x1088) through the same four stages; the residual stage is called per "
+                                         "macroblock through ctypes, which adds ~0.1 s of call overhead"}
+    return res
+
+
+def hevc_chain_inputs(W, H, seed):
+    """One intra picture with SURVEY 8d's config-5 TU mix: the TU list, quantised levels grouped by TU size (as a decoder
+    would hand them to ffhip_hevc_residual_batch) and residual offsets into one buffer laid out [32x32 | 16x16 | 8x8 | 4x4]."""
+    tus, _ = synth.hevc_intra_tus(W, H, seed=seed, tu_mix="c5")
+    tus = tus.copy()
+    tus["flags"] &= ~np.uint8(synth.TU_RDPCM)      # rdpcm belongs to transform-skip / bypass TUs: keep the chain plain
+    rng = np.random.default_rng(seed)
+    has = (tus["flags"] & synth.TU_RESIDUAL) != 0
+    groups, off = {}, 0
+    for n in (32, 16, 8, 4):
+        idx = np.nonzero(has & (tus["log2_size"] == int(np.log2(n))))[0]
+        if idx.size == 0:
+            continue
+        tus["res_offset"][idx] = off + np.arange(idx.size, dtype=np.uint32) * (n * n)
+        lv = np.rint(rng.laplace(0, 6, size=(idx.size, n * n))).astype(np.int16)
+        info = np.zeros((idx.size, 4), np.uint8)
+        info[:, 0] = 27                                                      # qP of SURVEY 8d C5
+        info[:, 1] = ((tus["cidx"][idx] == 0) & (n == 4)).astype(np.uint8)   # intra luma 4x4 takes the DST
+        groups[n] = (idx, lv, info, off)
+        off += idx.size * n * n
+    return tus, groups, off
+
+
+def run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T=None):
+    d_tus = torch.from_numpy(tus.view(np.uint8).copy()).to(dev)
+    d_res = torch.zeros(total + 64, dtype=torch.int16, device=dev)
+    dg = {n: (torch.from_numpy(lv).to(dev), torch.from_numpy(info).to(dev), off, len(idx)) for n, (idx, lv, info, off) in groups.items()}
+    py = torch.zeros((H, W), dtype=torch.int16, device=dev)
+    pu = torch.zeros((H // 2, W // 2), dtype=torch.int16, device=dev)
+    pv = torch.zeros_like(pu)
+    bgra = torch.empty((H, W * 4), dtype=torch.uint8, device=dev)
+
+    def s_res():
+        for n, (lv, info, off, cnt) in dg.items():
+            capi.check(L.ffhip_hevc_residual_batch(n, cnt, lv.data_ptr(), info.data_ptr(), None, 8, 0, d_res.data_ptr() + 2 * off, stream))
+
+    def s_intra():
+        capi.check(L.ffhip_hevc_intra_recon(tus.ctypes.data, d_tus.data_ptr(), len(tus), d_res.data_ptr(), py.data_ptr(), pu.data_ptr(), pv.data_ptr(),
+                                            W, H, W, W // 2, H // 2, W // 2, 8, 8, stream))
+
+    def s_col():
+        capi.check(L.ffhip_yuv420_to_bgra_16(bgra.data_ptr(), W * 4, py.data_ptr(), pu.data_ptr(), pv.data_ptr(), W, W // 2, H // 64, W // 64, 64, 1,
+                                             H * W, H * W // 4, H * W * 4, stream))
+
+    def chain():
+        s_res(); s_intra(); s_col()
+    times = None
+    if T is not None:
+        times = {"chain": T.ms(chain, reps=5, warm=2), "residual": T.ms(s_res, reps=5, warm=1), "intra_recon": T.ms(s_intra, reps=5, warm=1),
+                 "yuv420_to_bgra_16": T.ms(s_col, reps=5, warm=1)}
+    for p in (py, pu, pv):
+        p.zero_()
+    chain()
+    capi.check(L.ffhip_stream_sync(stream))
+    return bgra, (py, pu, pv), d_res, times
+
+
+def extra_c5(L, dev, stream, T, cpu=True):
+    """configs[4]: HEIF/HEVC still, one 8K picture (7680x4352 coded): scaling + inverse transforms per TU size -> intra
+    prediction + reconstruction -> YUV420 16-bit -> BGRA"""
+    W, H = 7680, 4352
+    tus, groups, total = hevc_chain_inputs(W, H, seed=5)
+    _, _, _, t = run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T)
+    px = W * H
+    n_res = sum(len(g[0]) * n * n for n, g in groups.items())
+    stages = {"residual": {"ms": round(t["residual"], 4), "GB/s": round(4 * n_res / t["residual"] / 1e6, 1), "algorithmic_bytes": 4 * n_res,
+                           "frac_of_hbm_peak": round(4 * n_res / t["residual"] / 1e6 / HBM_PEAK_GBS, 4),
+                           "launches": {f"{n}x{n}": int(len(g[0])) for n, g in groups.items()}},
+              "intra_recon": {"ms": round(t["intra_recon"], 4), "GB/s": round(9 * px / t["intra_recon"] / 1e6, 1), "algorithmic_bytes": int(9 * px),
+                              "frac_of_hbm_peak": round(9 * px / t["intra_recon"] / 1e6 / HBM_PEAK_GBS, 5), "tus": int(len(tus)),
+                              "bound": "dependency chain (a wave per 32x32 window group), not HBM"},
+              "yuv420_to_bgra_16": {"ms": round(t["yuv420_to_bgra_16"], 4), "GB/s": round(7 * px / t["yuv420_to_bgra_16"] / 1e6, 1),
+                                    "algorithmic_bytes": int(7 * px), "frac_of_hbm_peak": round(7 * px / t["yuv420_to_bgra_16"] / 1e6 / HBM_PEAK_GBS, 4)}}
+    res = {"workload": "C5: one 7680x4352 HEVC intra picture, TU mix of SURVEY 8d (luma 32/16 at 60/40, chroma 16/8), qP 27", "chain_ms": round(t["chain"], 4),
+           "value": round(px / t["chain"] / 1e3, 1), "unit": "Mpixels/s", "stages": stages,
+           "roofline": dict(roof(9 * px, t["intra_recon"]), kernel="k_hevc_intra_groups",
+                            note="algorithmic bytes 9 B/pixel (3 + 3 in, 3 out); the stage is bound by its dependency chain")}
+    if cpu:
+        # bounded sample: a 1024x512 picture of the same mix through the reference, and the same picture through the GPU chain
+        O = oracle_lib()
+        use_ref = os.path.exists(O.REF_SO)
+        sw, sh = 1024, 512
+        stus, sgroups, stotal = hevc_chain_inputs(sw, sh, seed=6)
+        g_bgra, g_planes, g_res, _ = run_hevc_chain_gpu(L, dev, stream, sw, sh, stus, sgroups, stotal)
+        t0 = time.perf_counter()
+        resid = np.zeros(stotal + 64, np.int16)
+        lib = O.ref() if use_ref else O.ffo()
+        for n, (idx, lv, info, off) in sgroups.items():
+            d = np.zeros(n * n, np.int16)
+            for k in range(len(idx)):
+                r = resid[off + k * n * n: off + (k + 1) * n * n]
+                if use_ref:
+                    lib.ref_hevc_scale(lv[k], d, n, 27, 8, 0, None, int(stus["cidx"][idx[k]]))
+                    lib.ref_hevc_transform(d, r, n, int(info[k, 1]), 8, 0)
+                else:
+                    lib.ffo_hevc_residual_tu(lv[k], r, n, 27, int(info[k, 1]), 8, 0, None)
+        planes = (O.ref_hevc_intra if use_ref else O.oracle_hevc_intra)(stus, resid, sw, sh, True, 8, 8)
+        o = np.zeros((sh, sw * 4), np.uint8)
+        (lib.YUV420_to_BGRA32_16bit if use_ref else lib.ffo_yuv420_to_bgra32_16bit)(o.reshape(-1), sw * 4, planes[0].reshape(-1), planes[1].reshape(-1),
+                                                                                  planes[2].reshape(-1), sw, sw // 2, sh // 64, sw // 64, 64)
+        dt = time.perf_counter() - t0
+        res["parity_vs_reference_sample"] = bool(np.array_equal(g_bgra.cpu().numpy(), o) and np.array_equal(g_res[:stotal].cpu().numpy(), resid[:stotal]))
+        res["cpu_baseline"] = {"value": round(sw * sh / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "reference" if use_ref else "port",
+                               "sample": f"one {sw}x{sh} picture of the same TU mix ({len(stus)} TUs) through the same three stages; one ctypes call per TU"}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--images", type=int, default=0, help="override images per GPU")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--images", type=int, default=0, help="override the number of images (per batch if strong, per GPU if weak)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong: the configuration's batch is shared out over the GPUs (BASELINE config 3: 256 images in total); weak: that many per GPU")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C2 / C4 / C5 measurements of `extra`")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -136,7 +395,7 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     # Rehearsal of the N > 1 path on a one-GPU box (FFHIP_BENCH_REHEARSE=1): every rank on cuda:0, gloo instead of
-    # RCCL (which refuses two ranks on one device).  Exercises sharding, barriers, the status gather and the
+    # RCCL (which refuses two ranks on one device).  Exercises sharding, barriers, the batch close and the
     # rank-0-only legs; its numbers mean nothing and the JSON line says so.
     rehearse = os.environ.get("FFHIP_BENCH_REHEARSE") == "1" and world > 1
     if rehearse:
@@ -147,22 +406,23 @@ def main():
         if rehearse:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm: bootstrap and barriers only
     L = capi.require_device(local)                       # raises without gfx950: no CPU fallback
 
-    cols, rows, per_gpu, desc = WORKLOADS[a.workload]
+    cols, rows, batch_images, desc = WORKLOADS[a.workload]
     if a.images:
-        per_gpu = a.images
-    total_images = per_gpu * world
+        batch_images = a.images
+    total_images = batch_images if a.scaling == "strong" else batch_images * world
     first, last = shard.shard_range(total_images, rank, world)
     n = last - first
     geom = capi.jpeg_geom(cols, rows)
     H, W = geom.height, geom.width
+    batch = shard.Batch(rank, world, dev)                # the C-side communicator for the batch close (RCCL from C when N > 1)
 
-    t_y, t_u, t_v, q = gen_batch_on_device(dev, cols, rows, n, seed=first)
+    t_y, t_u, t_v, q = gen_batch_on_device(dev, cols, rows, max(n, 1), seed=first)
     t_q = torch.from_numpy(q.astype(np.int16)).to(dev)
     pitch, stride = W * 4, W * 4 * H
-    out = torch.empty(n * stride, dtype=torch.uint8, device=dev)
+    out = torch.empty(max(n, 1) * stride, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -174,19 +434,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # parity spot check on this rank's first image, before warmup (outside the timed region;
-    # the CPU-side check idles the GPU, so it must not sit between warmup and timing)
+    # parity spot check on this rank's first AND last image, before warmup (outside the timed region;
+    # the CPU-side check idles the GPU, so it must not sit between warmup and timing), and the per-image
+    # checksums the rank vouches for its output with in the batch close
     parity = None
     step()
+    sums = torch.zeros(max(n, 1), dtype=torch.int64, device=dev)
+    capi.check(L.ffhip_bgra_checksum(out.data_ptr(), pitch, stride, W, H, n, sums.data_ptr(), stream), "ffhip_bgra_checksum")
     torch.cuda.synchronize()
+    checksum = int(sums[:n].sum().item()) & 0xFFFFFFFFFFFFFFFF
     if rank == 0:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as O
+        O = oracle_lib()
         mcus = cols * rows
-        exp = O.oracle_jpeg_recon(O.make_geom(cols, rows), t_y[:mcus * 256].cpu().numpy(),
-                                  t_u[:mcus * 64].cpu().numpy(), t_v[:mcus * 64].cpu().numpy(), q)[0]
-        parity = bool(np.array_equal(out[:stride].cpu().numpy().reshape(H, W, 4), exp))
-    shard.gather_status(first, n, 0, device=dev)   # warm the collective / small-copy path too
+        parity = True
+        for i in sorted({0, n - 1}):
+            exp = O.oracle_jpeg_recon(O.make_geom(cols, rows), t_y[i * mcus * 256:(i + 1) * mcus * 256].cpu().numpy(),
+                                      t_u[i * mcus * 64:(i + 1) * mcus * 64].cpu().numpy(), t_v[i * mcus * 64:(i + 1) * mcus * 64].cpu().numpy(), q)[0]
+            got = out[i * stride:(i + 1) * stride].cpu().numpy().reshape(H, W, 4)
+            words = exp.reshape(-1).view(np.uint32).astype(np.uint64)
+            want = int((words * ((np.arange(words.size, dtype=np.uint64) & np.uint64(0xFFFF)) + np.uint64(1))).sum(dtype=np.uint64))
+            parity = parity and bool(np.array_equal(got, exp)) and (int(sums[i].item()) & 0xFFFFFFFFFFFFFFFF) == want
+    batch.close(first, n, 0, checksum, stream)       # warm the collective / small-copy path too
 
     ev0, ev1 = L.ffhip_event_create(), L.ffhip_event_create()
     barrier()
@@ -198,7 +466,7 @@ def main():
     for _ in range(a.steps):
         step()
     capi.check(L.ffhip_event_record(ev1, stream))
-    records = shard.gather_status(first, n, 0, device=dev)   # closes the batch (RCCL all-gather)
+    records = batch.close(first, n, 0, checksum, stream)     # closes the batch: ncclAllGather of the records, from C
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms = L.ffhip_event_elapsed_ms(ev0, ev1) / max(a.steps, 1)
@@ -220,25 +488,31 @@ def main():
         for _ in range(5):
             capi.check(L.ffhip_copy_calibrate(dst.data_ptr(), src.data_ptr(), nbytes, stream))
         capi.check(L.ffhip_event_record(ev1, stream))
+        capi.check(L.ffhip_stream_sync(stream))
         copy_gbs = 2 * nbytes * 5 / (L.ffhip_event_elapsed_ms(ev0, ev1) * 1e-3) / 1e9
 
     if rank == 0:
         px_per_launch = n * H * W
         achieved = BYTES_PER_PIXEL * px_per_launch / (kernel_ms * 1e-3) / 1e9
+        traffic = pmc_traffic(a.workload) if (a.scaling == "weak" or world == 1) and n == WORKLOADS[a.workload][2] else None
         line = {
             "metric": "Mpixels/s decoded (dequant+IDCT+YUV->BGRA), 4K JPEG batch",
             "value": round(total_images * H * W * a.steps / dt / 1e6, 1),
             "unit": "Mpixels/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / max(a.steps, 1) * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": "int16 coefficients -> int32 accumulate -> u8 BGRA (fp64 only for exact-integer G cases)",
             "data": "synthetic (device RNG; Annex-K q85 tables, Laplace AC / normal DC, SURVEY 8d)",
-            "config": {"workload": desc, "images_per_gpu": per_gpu, "coded_size": f"{W}x{H}",
-                       "subsampling": "4:2:0", "parallelism": f"images sharded over {world} GPU(s), no data-path collective",
-                       "batch_complete": complete, "parity_vs_oracle_first_image": parity},
+            "config": {"workload": desc + (" in total" if a.scaling == "strong" else " per GPU"), "images_total": total_images,
+                       "images_this_rank": n, "coded_size": f"{W}x{H}",
+                       "subsampling": "4:2:0", "parallelism": f"contiguous image ranges over {world} GPU(s) (ffhip_shard_range), no data-path collective",
+                       "batch_close": {"none": "one GPU: stream sync + own record (ffhip_batch_close)", "rccl": "ncclAllGather of 32-byte records from C (ffhip_batch_close)",
+                                       "torch": "records through torch.distributed (RCCL from C unavailable here)"}[batch.transport],
+                       "batch_complete": complete, "parity_vs_oracle_first_and_last_image": parity},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(a.workload),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": None if traffic is None else "profiles/latest_pmc.json (rocprofv3 --pmc passes of this workload, not collected in this run)",
                          "kernel": "k_jpeg420_fused", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": int(BYTES_PER_PIXEL * px_per_launch),
                          "copy_kernel_GBps": None if copy_gbs is None else round(copy_gbs, 1)},
@@ -247,7 +521,20 @@ def main():
             line["config"]["rehearsal"] = "all ranks on one GPU over gloo: exercises the N > 1 control path only, the value is meaningless"
         if not a.no_cpu and world == 1:   # the CPU leg is timed on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(cols, rows, t_y, t_u, t_v, q)
+        if world == 1 and not a.no_extra:
+            del t_y, t_u, t_v, out
+            torch.cuda.empty_cache()
+            T = Timer(L, stream)
+            extra = {}
+            for key, fn in (("c2", lambda: extra_c2(L, dev, stream, T)), ("c4", lambda: extra_c4(L, dev, stream, T, not a.no_cpu)),
+                            ("c5", lambda: extra_c5(L, dev, stream, T, not a.no_cpu))):
+                try:
+                    extra[key] = fn()
+                except Exception as e:   # an extra must never take the headline line with it
+                    extra[key] = {"error": f"{type(e).__name__}: {e}"}
+            line["extra"] = extra
         print(json.dumps(line), flush=True)
+    batch.destroy()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -23,6 +23,8 @@ EXPORTS = [
     "ffhip_hevc_intra_recon", "ffhip_hevc_intra_plan", "ffhip_vp8_loopfilter",
     "ffhip_jpeg_probe", "ffhip_jpeg_entropy_decode", "ffhip_jpeg_entropy_decode_mt", "ffhip_jpeg_entropy_batch", "ffhip_bmp_write",
     "ffhip_heif_grid_parse", "ffhip_heif_grid_compose", "ffhip_hevc_picture_layout", "ffhip_jpeg_decode_files", "ffhip_jpeg_decode_files_device", "ffhip_jpeg_entropy_batch_gpu", "ffhip_jpeg_stage_scan_test", "ffhip_host_malloc", "ffhip_host_free",
+    "ffhip_shard_range", "ffhip_comm_unique_id", "ffhip_comm_init_rank", "ffhip_comm_destroy", "ffhip_batch_close", "ffhip_batch_complete",
+    "ffhip_bgra_checksum",
 ]
 
 
@@ -43,6 +45,11 @@ class HevcLayout(C.Structure):
     """ffhip_hevc_layout"""
     _fields_ = [("height", C.c_int32), ("y_stride", C.c_int32), ("uv_stride", C.c_int32), ("size", C.c_int64), ("u_offset", C.c_int64),
                 ("v_offset", C.c_int64), ("pitch", C.c_int32), ("ctbrows", C.c_int32), ("ctbcols", C.c_int32)]
+
+
+class BatchRecord(C.Structure):
+    """ffhip_batch_record"""
+    _fields_ = [("rank", C.c_int32), ("status", C.c_int32), ("first", C.c_int64), ("count", C.c_int64), ("checksum", C.c_uint64)]
 
 
 class JpegGeom(C.Structure):
@@ -175,6 +182,16 @@ def lib():
     L.ffhip_hevc_intra_recon.argtypes = [vp, vp, C.c_longlong, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.ffhip_vp8_loopfilter.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, i64, i64, vp]
     L.ffhip_vp8_predict_recon.argtypes = [ci, ci, ci, vp, vp, vp, i64, vp, vp, vp, vp, i64, i64, vp]
+    ll = C.c_longlong
+    L.ffhip_shard_range.argtypes = [ll, ci, ci, C.POINTER(ll), C.POINTER(ll)]
+    L.ffhip_comm_unique_id.argtypes = [vp]
+    L.ffhip_comm_init_rank.argtypes = [vp, ci, ci]
+    L.ffhip_comm_init_rank.restype = vp
+    L.ffhip_comm_destroy.argtypes = [vp]
+    L.ffhip_comm_destroy.restype = None
+    L.ffhip_batch_close.argtypes = [vp, ci, ci, ll, ll, ci, C.c_uint64, C.POINTER(BatchRecord), vp]
+    L.ffhip_batch_complete.argtypes = [C.POINTER(BatchRecord), ci, ll]
+    L.ffhip_bgra_checksum.argtypes = [vp, i64, i64, ci, ci, ci, vp, vp]
     _lib = L
     return L
 

@@ -411,6 +411,38 @@ int ffhip_bmp_write(const char *path, const uint8_t *bgra, int width, int height
  * calibrate the achievable HBM rate next to the fused kernel. */
 int ffhip_copy_calibrate(void *d_dst, const void *d_src, size_t bytes, void *stream);
 
+/* ---- batches over the GPUs of one node, from C (ffhip_shard.hip) ----
+ * The reference decodes one image at a time on one thread (format/jpg.c:458-585) and has no collective of any kind
+ * (SURVEY 2.1); images are independent, so a batch shards into contiguous image ranges -- one process and one GPU
+ * per rank -- with no data-path exchange.  The only collective is the batch close: ONE ncclAllGather (RCCL over
+ * xGMI) of a 32-byte record per rank, which is also the batch barrier.  RCCL is bound at run time (dlopen; a copy
+ * already in the process is reused), so one-GPU callers never need it. */
+typedef struct ffhip_batch_record {
+    int32_t rank;      /* who                                                                   */
+    int32_t status;    /* 0, or the FFHIP_E* code of the rank's first failing call              */
+    int64_t first;     /* the rank's image range [first, first + count)                         */
+    int64_t count;
+    uint64_t checksum; /* sum of the rank's per-image checksums (ffhip_bgra_checksum), mod 2^64 */
+} ffhip_batch_record;
+#define FFHIP_COMM_ID_BYTES 128
+/* contiguous image range of `rank` out of `world`; sizes differ by at most one */
+int ffhip_shard_range(long long n_images, int rank, int world, long long *first, long long *count);
+/* rank 0: a fresh communicator id (ncclGetUniqueId); the host program hands its 128 bytes to the other ranks */
+int ffhip_comm_unique_id(void *id128);
+/* every rank, on its own device (after ffhip_init): ncclCommInitRank; NULL on failure */
+void *ffhip_comm_init_rank(const void *id128, int rank, int world);
+void ffhip_comm_destroy(void *comm);
+/* Enqueues the all-gather of this rank's record behind what `stream` holds, synchronises `stream` and fills
+ * h_records[world] in rank order.  comm == NULL with world == 1: the one-GPU case (stream sync + own record). */
+int ffhip_batch_close(void *comm, int rank, int world, long long first, long long count, int status,
+                      uint64_t checksum, ffhip_batch_record *h_records, void *stream);
+/* host only: 1 when the records tile [0, n_images) exactly, record r is rank r's and every status is 0 */
+int ffhip_batch_complete(const ffhip_batch_record *records, int world, long long n_images);
+/* per image the sum over its 32-bit pixels p[i] (row-major over width x height) of p[i] * ((i & 0xffff) + 1), mod
+ * 2^64, into d_sums[n_images] (device): lets a rank vouch for gigabytes of output with 8 bytes per image */
+int ffhip_bgra_checksum(const uint8_t *d_bgra, int64_t pitch, int64_t image_stride, int width, int height,
+                        int n_images, uint64_t *d_sums, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,7 @@ EXPORTS = [
     "ffhip_jpeg_probe", "ffhip_jpeg_entropy_decode", "ffhip_jpeg_entropy_decode_mt", "ffhip_jpeg_entropy_batch", "ffhip_bmp_write",
     "ffhip_heif_grid_parse", "ffhip_heif_grid_compose", "ffhip_hevc_picture_layout", "ffhip_jpeg_decode_files", "ffhip_jpeg_decode_files_device", "ffhip_jpeg_entropy_batch_gpu", "ffhip_jpeg_stage_scan_test", "ffhip_host_malloc", "ffhip_host_free",
     "ffhip_shard_range", "ffhip_comm_unique_id", "ffhip_comm_init_rank", "ffhip_comm_destroy", "ffhip_batch_close", "ffhip_batch_complete",
-    "ffhip_bgra_checksum",
+    "ffhip_bgra_checksum", "ffhip_vp8_filter_params",
 ]
 
 
@@ -50,6 +50,14 @@ class HevcLayout(C.Structure):
 class BatchRecord(C.Structure):
     """ffhip_batch_record"""
     _fields_ = [("rank", C.c_int32), ("status", C.c_int32), ("first", C.c_int64), ("count", C.c_int64), ("checksum", C.c_uint64)]
+
+
+class Vp8FilterHeader(C.Structure):
+    """ffhip_vp8_filter_header"""
+    _fields_ = [("filter_type", C.c_uint8), ("loop_filter_level", C.c_uint8), ("sharpness_level", C.c_uint8),
+                ("segmentation_enabled", C.c_uint8), ("segment_feature_mode", C.c_uint8), ("lf_update_value", C.c_int8 * 4),
+                ("loop_filter_adj_enable", C.c_uint8), ("mode_ref_lf_delta0", C.c_int8), ("mb_mode_delta0", C.c_int8),
+                ("nbr_partitions", C.c_uint8)]
 
 
 class JpegGeom(C.Structure):
@@ -191,6 +199,7 @@ def lib():
     L.ffhip_comm_destroy.restype = None
     L.ffhip_batch_close.argtypes = [vp, ci, ci, ll, ll, ci, C.c_uint64, C.POINTER(BatchRecord), vp]
     L.ffhip_batch_complete.argtypes = [C.POINTER(BatchRecord), ci, ll]
+    L.ffhip_vp8_filter_params.argtypes = [C.POINTER(Vp8FilterHeader), vp, C.POINTER(ci)]
     L.ffhip_bgra_checksum.argtypes = [vp, i64, i64, ci, ci, ci, vp, vp]
     _lib = L
     return L

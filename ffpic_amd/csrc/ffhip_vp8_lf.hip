@@ -448,3 +448,38 @@ extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int fi
     FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
     return FFHIP_OK;
 }
+
+/* calculate_filter_control_parameter (format/webp.c:1756-1803) for the four segments and both macroblock kinds, as
+ * WEBP_read_frame calls it (webp.c:1905-1915: once per DCT partition index, not per segment).  Host arithmetic, no device.  A level of 0 only clears sub_limit
+ * (webp.c:1799); the other two fields keep what the decoder's zero-initialised state held. */
+extern "C" int ffhip_vp8_filter_params(const ffhip_vp8_filter_header *h, uint8_t *filters, int *filter_type)
+{
+    if (!h || !filters || !filter_type || h->loop_filter_level > 63 || h->sharpness_level > 7 ||
+        (h->nbr_partitions != 1 && h->nbr_partitions != 2 && h->nbr_partitions != 4 && h->nbr_partitions != 8)) return FFHIP_EINVAL;
+    const int ft = h->loop_filter_level == 0 ? 0 : (h->filter_type ? 1 : 2);
+    *filter_type = ft;
+    for (int i = 0; i < 24; i++) filters[i] = 0;
+    if (!ft) return FFHIP_OK;
+    auto clamp63 = [](int v) { return v < 0 ? 0 : (v > 63 ? 63 : v); };
+    for (int s = 0; s < 4 && s < h->nbr_partitions; s++)
+        for (int is4 = 0; is4 < 2; is4++) {
+            int base = h->loop_filter_level;
+            if (h->segmentation_enabled) base = h->segment_feature_mode ? h->lf_update_value[s] : base + h->lf_update_value[s];
+            int level = clamp63(base);
+            if (h->loop_filter_adj_enable) level += h->mode_ref_lf_delta0 + (is4 ? h->mb_mode_delta0 : 0);
+            level = clamp63(level);
+            uint8_t *f = filters + (s * 2 + is4) * 3;
+            if (level > 0) {
+                int il = level;
+                if (h->sharpness_level > 0) {
+                    il >>= h->sharpness_level > 4 ? 2 : 1;
+                    if (il > 9 - h->sharpness_level) il = 9 - h->sharpness_level;
+                }
+                if (il < 1) il = 1;
+                f[0] = (uint8_t)((level << 1) + il);
+                f[1] = (uint8_t)il;
+                f[2] = level >= 40 ? 2 : (level >= 15 ? 1 : 0);
+            }
+        }
+    return FFHIP_OK;
+}

@@ -242,6 +242,27 @@ int ffhip_vp8_residual_batch(long long n_mb, const int16_t *d_levels, const uint
  *   d_filters    uint8 [4 segments][2 (i16x16, i4x4)][3] = sub_limit, inter_limit, hev_thresh
  *                (struct vp8_filter as calculate_filter_control_parameter leaves it,
  *                webp.c:1756-1803, format/webp.h:289-293) */
+/* The frame-header fields calculate_filter_control_parameter (format/webp.c:1756-1803) reads, as the reference's
+ * header parser leaves them (format/webp.h:160-230), and the derivation itself on the host: the per-segment
+ * {sub_limit, inter_limit, hev_thresh} triples ffhip_vp8_loopfilter takes as d_filters, and the filter_type
+ * argument (0 none, 1 simple, 2 normal; webp.c:1757-1759, 1852-1853). */
+typedef struct ffhip_vp8_filter_header {
+    uint8_t filter_type;          /* frame header bit: 1 = simple filter, 0 = normal                    */
+    uint8_t loop_filter_level;    /* 0..63, 0 = no filtering                                            */
+    uint8_t sharpness_level;      /* 0..7                                                               */
+    uint8_t segmentation_enabled; /* segmentation.segmentation_enabled                                  */
+    uint8_t segment_feature_mode; /* 1: lf_update_value is absolute, 0: a delta to loop_filter_level    */
+    int8_t lf_update_value[4];    /* segmentation.lf[s].lf_update_value                                 */
+    uint8_t loop_filter_adj_enable;
+    int8_t mode_ref_lf_delta0;    /* mb_lf_adjustments.mode_ref_lf_delta_update[0] (intra frame)        */
+    int8_t mb_mode_delta0;        /* mb_lf_adjustments.mb_mode_delta_update[0] (B_PRED macroblocks)     */
+    uint8_t nbr_partitions;       /* 1, 2, 4 or 8: the reference derives the triples inside its loop over the DCT
+                                     PARTITIONS (webp.c:1905-1915), so only segments 0 .. nbr_partitions-1 get any; the
+                                     others keep zeros = "no filtering" (a reference defect, kept; its write past
+                                     filters[3] with 8 partitions is not reproduced)                            */
+} ffhip_vp8_filter_header;
+/* host only; filters = uint8 [4 segments][2 (i16x16, i4x4)][3], zeroed first like the reference's calloc'ed decoder */
+int ffhip_vp8_filter_params(const ffhip_vp8_filter_header *hdr, uint8_t *filters /* [4][2][3] */, int *filter_type);
 int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int filter_type, const uint8_t *d_modes,
                          const uint8_t *d_filters, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
                          int64_t plane_stride_y, int64_t plane_stride_uv, void *stream);

@@ -20,8 +20,15 @@
 /* only the picture planes of vp8_decode (webp.c:1819-1822: w->data, Y, U, V) are guarded; every
  * other allocation of the file keeps the real malloc/free because other translation units free
  * them (the bool decoder's buffers, webp.c:1890,1906 -> coding/booldec.c) */
+static void *g_ref_blocks;   /* vp8_decode's per-macroblock header array (webp.c:1824; never freed by the reference) */
+static size_t g_ref_blocks_bytes;
 static void *ref_malloc_at(size_t n, int line)
 {
+    if (line == 1824) {
+        g_ref_blocks = malloc(n);
+        g_ref_blocks_bytes = n;
+        return g_ref_blocks;
+    }
     if (line >= 1819 && line <= 1822) {
         char *p = calloc(1, n + REF_GUARD);
         return p ? p + REF_GUARD : NULL;
@@ -118,6 +125,30 @@ void ref_vp8_loopfilter_frame(int mbcols, int mbrows, int filter_type, const uin
 /* Loop-filter state of a decoded WEBP (struct pic.pic of WEBP_load, webp.c:2002-2005): out[0] =
  * loop_filter_level, out[1] = filter_type bit, out[2] = segmentation_enabled, out[3..26] =
  * filters[4][2] {sub_limit, inter_limit, hev_thresh} (webp.c:1756-1803). */
+/* segment_id of every macroblock of the last vp8_decode, in raster order, from its own header array */
+int ref_webp_segment_ids(uint8_t *out, int max)
+{
+    const struct macro_block *b = g_ref_blocks;
+    const int n = (int)(g_ref_blocks_bytes / sizeof *b);
+    for (int i = 0; i < n && i < max; i++) out[i] = b[i].segment_id;
+    return n;
+}
+
+/* out[0..9] = sharpness_level, segment_feature_mode, lf_update_value[4], loop_filter_adj_enable,
+ * mode_ref_lf_delta_update[0], mb_mode_delta_update[0], nbr_partitions: the rest of what
+ * calculate_filter_control_parameter reads */
+void ref_webp_filter_header(void *wp, int *out)
+{
+    WEBP *w = wp;
+    out[0] = w->k.sharpness_level;
+    out[1] = w->k.segmentation.segment_feature_mode;
+    for (int s = 0; s < 4; s++) out[2 + s] = w->k.segmentation.lf[s].lf_update_value;
+    out[6] = w->k.mb_lf_adjustments.loop_filter_adj_enable;
+    out[7] = w->k.mb_lf_adjustments.mode_ref_lf_delta_update[0];
+    out[8] = w->k.mb_lf_adjustments.mb_mode_delta_update[0];
+    out[9] = w->k.nbr_partitions;
+}
+
 void ref_webp_filter_info(void *wp, int *out)
 {
     WEBP *w = wp;
@@ -220,4 +251,34 @@ int ref_vp8_residual_blocks_driven(const uint8_t *bytes, int len, int n_mb, cons
     free(top); free(rtop); free(w);
     if (used + 8 >= len) return -2; /* the caller's bytes ran out: everything behind that point would be padding */
     return same ? 0 : -1;
+}
+
+/* calculate_filter_control_parameter (webp.c:1756-1803) on a zero-initialised decoder with the given frame-header
+ * fields, looped as WEBP_read_frame does (webp.c:1905-1915: over the DCT partition index, hdr[12], capped at 4 here).
+ * hdr: filter_type, loop_filter_level, sharpness_level, segmentation_enabled, segment_feature_mode,
+ * lf_update_value[4], loop_filter_adj_enable, mode_ref_lf_delta_update[0], mb_mode_delta_update[0], nbr_partitions (13 ints).
+ * out[24] = filters[4][2]{sub_limit, inter_limit, hev_thresh}. */
+void ref_webp_filter_params(const int *hdr, int *out)
+{
+    WEBP *w = calloc(1, sizeof *w);
+    w->k.filter_type = hdr[0];
+    w->k.loop_filter_level = hdr[1];
+    w->k.sharpness_level = hdr[2];
+    w->k.segmentation.segmentation_enabled = hdr[3];
+    w->k.segmentation.segment_feature_mode = hdr[4];
+    for (int s = 0; s < 4; s++) w->k.segmentation.lf[s].lf_update_value = hdr[5 + s];
+    w->k.mb_lf_adjustments.loop_filter_adj_enable = hdr[9];
+    w->k.mb_lf_adjustments.mode_ref_lf_delta_update[0] = hdr[10];
+    w->k.mb_lf_adjustments.mb_mode_delta_update[0] = hdr[11];
+    for (int i = 0; i < hdr[12] && i < 4; i++) {
+        calculate_filter_control_parameter(w, i, 0);
+        calculate_filter_control_parameter(w, i, 1);
+    }
+    for (int s = 0; s < 4; s++)
+        for (int k = 0; k < 2; k++) {
+            out[(s * 2 + k) * 3] = w->filters[s][k].sub_limit;
+            out[(s * 2 + k) * 3 + 1] = w->filters[s][k].inter_limit;
+            out[(s * 2 + k) * 3 + 2] = w->filters[s][k].hev_thresh;
+        }
+    free(w);
 }

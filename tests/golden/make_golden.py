@@ -423,6 +423,9 @@ def _ref_decode_webp_inproc(path, out_npz):
     info = (C.c_int * 27)()
     R.ref_webp_filter_info.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     R.ref_webp_filter_info(p.pic, info)
+    hdr = (C.c_int * 10)()
+    R.ref_webp_filter_header.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    R.ref_webp_filter_header(p.pic, hdr)
     rec.ref_record_count.restype = C.c_int
     rec.ref_record_modes.restype = C.POINTER(C.c_uint8)
     rec.ref_record_residual.restype = C.POINTER(C.c_int16)
@@ -430,8 +433,12 @@ def _ref_decode_webp_inproc(path, out_npz):
     modes = np.ctypeslib.as_array(rec.ref_record_modes(), shape=(n, 20)).copy()
     resid = np.ctypeslib.as_array(rec.ref_record_residual(), shape=(n, 384)).copy()
     bgra = np.ctypeslib.as_array(C.cast(p.pixels, C.POINTER(C.c_uint8)), shape=(p.height, p.pitch)).copy()
+    seg = np.zeros(n, np.uint8)
+    R.ref_webp_segment_ids.argtypes = [C.c_void_p, C.c_int]
+    assert R.ref_webp_segment_ids(seg.ctypes.data, n) == n
+    modes[:, 18] = seg                       # the segment id of the MB's own header (webp.c:1292-1296)
     np.savez(out_npz, modes=modes, residual=resid, bgra=bgra, dims=np.array([p.width, p.height, p.pitch], np.int32),
-             lf=np.array(list(info), np.int32))
+             lf=np.array(list(info), np.int32), lf_header=np.array(list(hdr), np.int32))
     os._exit(0)
 
 
@@ -472,6 +479,58 @@ def gen_webp_file(R):
           f"chain from the dump == reference decode: {same}")
     assert same, "the recorded modes/residual do not reproduce the reference's pixels"
     save("webp_file.npz", modes=d["modes"], residual=d["residual"], bgra=d["bgra"][:h], dims=d["dims"], lf=d["lf"])
+
+
+def gen_webp_file_lf(R):
+    """f3 at file level: a PIL-made lossy WebP at a quality where libwebp leaves the loop filter ON, decoded by the
+    reference's own loader.  Recorded: what its decoder passed to pred_luma / pred_chrome, every macroblock's segment id,
+    the frame-header fields calculate_filter_control_parameter reads, the triples it derived, and the final BGRA."""
+    from PIL import Image
+    rng = np.random.default_rng(9)
+    yy, xx = np.mgrid[0:112, 0:144]
+    img = np.stack([127 + 120 * np.sin(xx / 19.0) * np.cos(yy / 11.0), 127 + 100 * np.cos(xx / 9.0 + yy / 21.0),
+                    (xx * 255 / 143 + yy * 255 / 111) / 2], axis=2)
+    img[40:80, 50:110] = rng.integers(0, 256, size=(40, 60, 3))            # a busy patch: several segments, B_PRED macroblocks
+    img = np.clip(img + rng.normal(0, 10, img.shape), 0, 255).astype(np.uint8)
+    res = {}
+    for tag, kw in (("q55", dict(quality=55, method=4)), ("q40", dict(quality=40, method=0))):   # (PIL cannot ask libwebp for the simple filter)
+        path = os.path.join(HERE, f"file_lf_{tag}.webp")
+        Image.fromarray(img).save(path, "WEBP", **kw)
+        d = ref_decode_webp(path)
+        w, h, pitch = [int(x) for x in d["dims"]]
+        c, r = (w + 15) // 16, (h + 15) // 16
+        lf = d["lf"]
+        assert lf[0] > 0, "loop filter is off in this file"
+        ftype = 1 if lf[1] else 2
+        filt = lf[3:27].astype(np.uint8).reshape(4, 2, 3)
+        y, u, v = O.oracle_vp8_frame(c, r, d["modes"], d["residual"])
+        y, u, v = [np.ascontiguousarray(p).copy() for p in (y, u, v)]
+        O.ffo().ffo_vp8_loopfilter_frame(c, r, ftype, np.ascontiguousarray(d["modes"]).reshape(-1), filt.reshape(-1), y.reshape(-1), u.reshape(-1), v.reshape(-1))
+        out = np.zeros((16 * r, pitch), np.uint8)
+        O.ffo().ffo_yuv420_to_bgra32(out.reshape(-1), pitch, y.reshape(-1), u.reshape(-1), v.reshape(-1), 16 * c, 8 * c, r, c)
+        same = np.array_equal(out[:h], d["bgra"][:h])
+        print(f"  file_lf_{tag}.webp: {os.path.getsize(path)} B, {w}x{h}, level {lf[0]}, type {ftype}, segmentation {lf[2]}, header {list(d['lf_header'])}, "
+              f"segments used {np.bincount(d['modes'][:, 18], minlength=4)}, filters {filt.reshape(-1)[:12]}..., chain from the dump == reference decode: {same}")
+        assert same, "the recorded modes/residual/filters do not reproduce the reference's pixels"
+        for k in ("modes", "residual", "dims", "lf", "lf_header"):
+            res[f"{tag}_{k}"] = d[k]
+        res[f"{tag}_bgra"] = d["bgra"][:h]
+    save("webp_file_lf.npz", **res)
+
+
+def gen_vp8_filter_params(R):
+    """calculate_filter_control_parameter (webp.c:1756-1803) over a sweep of header fields (ref_webp_filter_params)"""
+    rng = np.random.default_rng(3)
+    cases = [(ft, lvl, sh, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4) for ft in (0, 1) for lvl in range(64) for sh in range(8)]
+    for _ in range(1000):
+        cases.append((int(rng.integers(0, 2)), int(rng.integers(0, 64)), int(rng.integers(0, 8)), int(rng.integers(0, 2)), int(rng.integers(0, 2)),
+                      *[int(x) for x in rng.integers(-63, 64, size=4)], int(rng.integers(0, 2)), int(rng.integers(-63, 64)),
+                      int(rng.integers(-63, 64)), int(rng.choice([1, 2, 4]))))
+    hdr = np.array(cases, np.int32)
+    out = np.zeros((len(cases), 24), np.int32)
+    for i in range(len(cases)):
+        R.ref_webp_filter_params(np.ascontiguousarray(hdr[i]), out[i])
+    save("vp8_filter_params.npz", header=hdr, filters=out.astype(np.uint8))
 
 
 def ref_decode_file(R, path):
@@ -551,7 +610,7 @@ def main():
     R = O.ref()
     steps = [("blocks", gen_blocks), ("vp8 macroblocks", gen_vp8_mbs), ("vp8 driven", gen_vp8_driven), ("vp8 frames", gen_vp8_frames),
              ("hevc intra", gen_hevc_intra), ("hevc glue", gen_hevc_glue), ("vp8 loop filter", gen_vp8_loopfilter), ("colour", gen_color),
-             ("grids", gen_grids), ("files", gen_files), ("webp file", gen_webp_file)]
+             ("grids", gen_grids), ("files", gen_files), ("webp file", gen_webp_file), ("webp file lf", gen_webp_file_lf), ("vp8 filter params", gen_vp8_filter_params)]
     only = sys.argv[2] if len(sys.argv) == 3 and sys.argv[1] == "--only" else None   # e.g. --only "hevc intra"
     for name, fn in steps:
         if only is None or only == name:

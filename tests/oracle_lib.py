@@ -118,6 +118,7 @@ def ref():
         L.ref_vp8_iwht_fast.argtypes = [i16p, i16p]
         L.ref_vp8_residual_mb.argtypes = [i16p, u8p, C.c_int, u16p, i16p]
         L.ref_vp8_residual_blocks_driven.argtypes = [u8p, C.c_int, C.c_int, u8p, u8p, u16p, u8p, i16p, u8p, i16p]
+        L.ref_webp_filter_params.argtypes = [i32p, i32p]
         L.ref_vp8_recon_frame.argtypes = [C.c_int, C.c_int, u8p, i16p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ref_vp8_loopfilter_frame.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, u8p, u8p, u8p]
         L.ref_hevc_intra_tu.argtypes = [C.c_int] * 6 + [C.c_uint64, C.c_uint64, i16p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]

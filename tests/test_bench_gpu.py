@@ -44,3 +44,56 @@ def test_two_rank_rehearsal(scaling, total):
     assert rec["n_gpus"] == 2 and rec["scaling"] == scaling and "rehearsal" in rec["config"]
     assert rec["config"]["images_total"] == total and rec["config"]["batch_complete"] is True
     assert rec["config"]["parity_vs_oracle_first_and_last_image"] is True and "extra" not in rec
+
+
+_RCCL_SNIPPET = r"""
+import ctypes as C, sys
+sys.path.insert(0, %r)
+if %r:
+    import torch
+    torch.zeros(1, device="cuda:0")           # torch's own RCCL is now mapped: the library must reuse it
+from ffpic_amd import capi
+L = capi.require_device()
+ident = (C.c_uint8 * 128)()
+capi.check(L.ffhip_comm_unique_id(ident), "unique id")
+comm = L.ffhip_comm_init_rank(ident, 0, 1)
+assert comm, "ncclCommInitRank failed"
+st = L.ffhip_stream_create()
+recs = (capi.BatchRecord * 1)()
+for k in range(3):
+    capi.check(L.ffhip_batch_close(comm, 0, 1, 0, 9, 0, 0xABCDEF0123456789 + k, recs, st), "close")
+    assert (recs[0].rank, recs[0].status, recs[0].first, recs[0].count, recs[0].checksum) == (0, 0, 0, 9, 0xABCDEF0123456789 + k)
+assert L.ffhip_batch_complete(recs, 1, 9) == 1
+assert L.ffhip_batch_close(comm, 0, 2, 0, 9, 0, 0, recs, st) == capi.FFHIP_EINVAL      # not this communicator's world
+L.ffhip_comm_destroy(comm)
+L.ffhip_stream_destroy(st)
+print("rccl-from-c ok")
+"""
+
+
+@pytest.mark.parametrize("with_torch", [False, True])
+def test_rccl_batch_close_from_c_single_rank(with_torch):
+    """ffhip_comm_unique_id / ffhip_comm_init_rank / ffhip_batch_close with a real RCCL communicator of one rank: the
+    run-time binding (a fresh dlopen in a plain process, the copy PyTorch already mapped in a torch process), the
+    ncclAllGather on the caller's stream and the record round trip.  More ranks need more GPUs than this box has."""
+    out = subprocess.run([sys.executable, "-c", _RCCL_SNIPPET % (ROOT, with_torch)], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0 and "rccl-from-c ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_bgra_checksum_matches_its_definition():
+    import numpy as np
+    from ffpic_amd import capi, ops
+    L = capi.require_device()
+    rng = np.random.default_rng(4)
+    n, H, W, pitch = 3, 37, 53, 53 * 4 + 16
+    stride = pitch * H + 64
+    buf = rng.integers(0, 256, size=n * stride, dtype=np.uint8)
+    d = ops.DeviceBuffer(buf)
+    s = ops.DeviceBuffer(nbytes=8 * n)
+    capi.check(L.ffhip_bgra_checksum(d.ptr, pitch, stride, W, H, n, s.ptr, None))
+    got = s.to_host((n,), np.uint64)
+    for i in range(n):
+        img = buf[i * stride:i * stride + pitch * H].reshape(H, pitch)[:, :W * 4].copy().view(np.uint32).reshape(-1).astype(np.uint64)
+        want = (img * ((np.arange(img.size, dtype=np.uint64) & np.uint64(0xFFFF)) + np.uint64(1))).sum(dtype=np.uint64)
+        assert int(got[i]) == int(want), i
+    assert L.ffhip_bgra_checksum(d.ptr, W * 4 - 4, stride, W, H, n, s.ptr, None) == capi.FFHIP_EINVAL

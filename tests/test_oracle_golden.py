@@ -150,6 +150,55 @@ def test_webp_file_config4(golden, ffo):
     assert np.array_equal(out[:h], g["bgra"])
 
 
+def vp8_filter_header(lf, hdr):
+    """capi.Vp8FilterHeader from the recorder's arrays: lf = [loop_filter_level, filter_type bit, segmentation_enabled, ...],
+    hdr = [sharpness, segment_feature_mode, lf_update_value[4], adj_enable, mode_ref delta 0, mb_mode delta 0, nbr_partitions]"""
+    from ffpic_amd import capi
+    return capi.Vp8FilterHeader(int(lf[1]), int(lf[0]), int(hdr[0]), int(lf[2]), int(hdr[1]), (C.c_int8 * 4)(*[int(x) for x in hdr[2:6]]),
+                                int(hdr[6]), int(hdr[7]), int(hdr[8]), int(hdr[9]))
+
+
+def test_vp8_filter_params_golden(golden):
+    """f3: the product's host-side ffhip_vp8_filter_params against triples the reference's
+    calculate_filter_control_parameter (webp.c:1756-1803) derived (no GPU, no reference needed)"""
+    from ffpic_amd import capi
+    g = golden("vp8_filter_params.npz")
+    L = capi.lib()
+    for row, exp in zip(g["header"], g["filters"]):
+        h = capi.Vp8FilterHeader(int(row[0]), int(row[1]), int(row[2]), int(row[3]), int(row[4]), (C.c_int8 * 4)(*[int(x) for x in row[5:9]]),
+                                 int(row[9]), int(row[10]), int(row[11]), int(row[12]))
+        got = np.zeros(24, np.uint8)
+        ft = C.c_int(-1)
+        assert L.ffhip_vp8_filter_params(C.byref(h), got.ctypes.data, C.byref(ft)) == 0
+        assert np.array_equal(got, exp), list(row)
+
+
+@pytest.mark.parametrize("tag", ["q55", "q40"])
+def test_webp_file_with_loop_filter(golden, ffo, tag):
+    """f3 at file level: the reference's whole-file decode of a WebP whose loop filter is ON, from the per-macroblock
+    dump of its own decoder; the filter triples come from the product's ffhip_vp8_filter_params fed with the frame
+    header the reference parsed, and must be the ones the reference derived"""
+    from ffpic_amd import capi
+    g = golden("webp_file_lf.npz")
+    w, h, pitch = [int(x) for x in g[f"{tag}_dims"]]
+    c, r = (w + 15) // 16, (h + 15) // 16
+    lf, modes = g[f"{tag}_lf"], g[f"{tag}_modes"]
+    assert lf[0] > 0
+    filt = np.zeros(24, np.uint8)
+    ft = C.c_int(-1)
+    hdr = vp8_filter_header(lf, g[f"{tag}_lf_header"])
+    assert capi.lib().ffhip_vp8_filter_params(C.byref(hdr), filt.ctypes.data, C.byref(ft)) == 0
+    assert np.array_equal(filt.astype(np.int32), lf[3:27]) and ft.value == (1 if lf[1] else 2)
+    y, u, v = O.oracle_vp8_frame(c, r, modes, g[f"{tag}_residual"])
+    y, u, v = [np.ascontiguousarray(p).copy() for p in (y, u, v)]
+    unfiltered = y.copy()
+    ffo.ffo_vp8_loopfilter_frame(c, r, ft.value, np.ascontiguousarray(modes).reshape(-1), filt, y.reshape(-1), u.reshape(-1), v.reshape(-1))
+    assert not np.array_equal(unfiltered, y)                 # the filter really changes this picture
+    out = np.zeros((16 * r, pitch), np.uint8)
+    ffo.ffo_yuv420_to_bgra32(out.reshape(-1), pitch, y.reshape(-1), u.reshape(-1), v.reshape(-1), 16 * c, 8 * c, r, c)
+    assert np.array_equal(out[:h], g[f"{tag}_bgra"])
+
+
 def test_hevc_dst4(golden, ffo):
     g = golden("hevc_dst4.npz")
     for bd in (8, 10):

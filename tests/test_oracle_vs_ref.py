@@ -136,3 +136,36 @@ def test_hevc_intra_random_tu_lists(libs, seed, bd, bdc, c444):
     got = O.oracle_hevc_intra(tus, res, w, h, True, bd, bdc, csub=csub)
     for a, b, name in zip(got, exp, "YUV"):
         assert np.array_equal(a, b), name
+
+
+def test_vp8_filter_params_sweep(libs):
+    """f3: ffhip_vp8_filter_params (host C in the product) against the reference's calculate_filter_control_parameter
+    (webp.c:1756-1803) over every level x sharpness x filter type, with and without segmentation (both feature modes)
+    and loop-filter deltas, for 1, 2 and 4 partitions (the reference derives triples per PARTITION index, webp.c:1905-1915)"""
+    import ctypes as C
+    from ffpic_amd import capi
+    _, R = libs
+    L = capi.lib()
+    rng = np.random.default_rng(3)
+    cases = [(ft, lvl, sh, 0, 0, (0, 0, 0, 0), 0, 0, 0, 4) for ft in (0, 1) for lvl in range(64) for sh in range(8)]
+    for _ in range(3000):
+        cases.append((int(rng.integers(0, 2)), int(rng.integers(0, 64)), int(rng.integers(0, 8)), int(rng.integers(0, 2)), int(rng.integers(0, 2)),
+                      tuple(int(x) for x in rng.integers(-63, 64, size=4)), int(rng.integers(0, 2)), int(rng.integers(-63, 64)),
+                      int(rng.integers(-63, 64)), int(rng.choice([1, 2, 4]))))
+    seen_types = set()
+    for ft, lvl, sh, seg, fmode, lfu, adj, d0, d1, parts in cases:
+        hdr = np.array([ft, lvl, sh, seg, fmode, *lfu, adj, d0, d1, parts], np.int32)
+        exp = np.zeros(24, np.int32)
+        R.ref_webp_filter_params(hdr, exp)
+        h = capi.Vp8FilterHeader(ft, lvl, sh, seg, fmode, (C.c_int8 * 4)(*lfu), adj, d0, d1, parts)
+        got = np.zeros(24, np.uint8)
+        ftype = C.c_int(-1)
+        assert L.ffhip_vp8_filter_params(C.byref(h), got.ctypes.data, C.byref(ftype)) == 0
+        assert np.array_equal(got.astype(np.int32), exp), (ft, lvl, sh, seg, fmode, lfu, adj, d0, d1, parts)
+        assert ftype.value == (0 if lvl == 0 else (1 if ft else 2))
+        seen_types.add(ftype.value)
+    assert seen_types == {0, 1, 2}
+    bad = capi.Vp8FilterHeader(0, 64, 0, 0, 0, (C.c_int8 * 4)(), 0, 0, 0, 1)
+    assert L.ffhip_vp8_filter_params(C.byref(bad), got.ctypes.data, C.byref(ftype)) == capi.FFHIP_EINVAL
+    bad = capi.Vp8FilterHeader(0, 10, 0, 0, 0, (C.c_int8 * 4)(), 0, 0, 0, 3)
+    assert L.ffhip_vp8_filter_params(C.byref(bad), got.ctypes.data, C.byref(ftype)) == capi.FFHIP_EINVAL

@@ -87,6 +87,26 @@ def test_webp_file_config4(golden):
     assert np.array_equal(bgra[0][:h], g["bgra"])
 
 
+@pytest.mark.parametrize("tag", ["q55", "q40"])
+def test_webp_file_with_loop_filter(golden, tag):
+    """f3 at file level on the GPU: predict + reconstruct -> ffhip_vp8_filter_params (host) -> loop filter -> BGRA against
+    the reference's whole-file decode of a WebP whose loop filter is on"""
+    import ctypes as C
+    from ffpic_amd import capi
+    from test_oracle_golden import vp8_filter_header
+    g = golden("webp_file_lf.npz")
+    w, h, pitch = [int(x) for x in g[f"{tag}_dims"]]
+    c, r = (w + 15) // 16, (h + 15) // 16
+    filt = np.zeros((4, 2, 3), np.uint8)
+    ft = C.c_int(-1)
+    hdr = vp8_filter_header(g[f"{tag}_lf"], g[f"{tag}_lf_header"])
+    capi.check(capi.lib().ffhip_vp8_filter_params(C.byref(hdr), filt.ctypes.data, C.byref(ft)))
+    y, u, v = ops.vp8_predict_recon(c, r, g[f"{tag}_modes"][None], g[f"{tag}_residual"][None])
+    y, u, v = ops.vp8_loopfilter(c, r, ft.value, g[f"{tag}_modes"][None], filt, y, u, v)
+    bgra = ops.yuv420_to_bgra(y, u, v, r, c, pitch=pitch)
+    assert np.array_equal(bgra[0][:h], g[f"{tag}_bgra"])
+
+
 @pytest.mark.parametrize("env", [{"FFHIP_VP8_LF_MODE": "levels"}, {"FFHIP_VP8_LF_WAVES": "3"}, {}])
 @pytest.mark.parametrize("ft", [1, 2])
 def test_lf_schedulers_agree(env, ft, monkeypatch):

@@ -10,7 +10,62 @@
  * them to run, and one around scale_and_transform itself (hevc.c:4172-4251) with the qP
  * derivation in front of it.  Block layout at this interface is row-major d[x + y*nTbS].
  */
+
+/* ---- recorder taps on the reference's own decode (used by tests/golden/make_golden.py::gen_hevc_file) ----
+ * The leaf calls of decode_intra_block (hevc.c:4665-4805) are `static`; they are tapped at their CALL SITES by
+ * function-like macros that dispatch on __LINE__ (gcc expands it to the line the invocation starts on): at the line of
+ * the definition the macro yields the function's own name (a macro's own name is not expanded again), at the line of
+ * the call in decode_intra_block it yields the recorder, which notes the arguments and forwards to the real function.
+ * No reference source is changed or copied; the line numbers below are build-recipe knowledge of the pinned tree. */
+#include "hevc.h"
+struct picture;
+struct cu;
+struct sps;
+struct slice_segment_header;
+struct hevc_param_set;
+#define REF_CAT_(a, b) a##b
+#define REF_CAT(a, b) REF_CAT_(a, b)
+static void rec_intra_sample_prediction(struct slice_segment_header *slice, struct hevc_param_set *hps, struct cu *cu, int xTbCmp,
+                                        int yTbCmp, int predModeIntra, int nTbS, int cIdx, int16_t *predSamples, struct picture *p);
+static int rec_scale_and_transform(struct cu *cu, int transform_skip_flag, struct hevc_param_set *hps, struct slice_segment_header *slice,
+                                   int xTbY, int yTbY, int cIdx, int nTbS, int16_t *r, struct picture *p);
+static void rec_scale_transform_coefficients(struct sps *sps, struct cu *cu, struct slice_segment_header *slice, struct picture *p,
+                                             int transform_skip_flag, int xTbY, int yTbY, int nTbS, int cIdx, int qP, int16_t *d);
+static void rec_reference_sample_substitution(struct sps *sps, int16_t *left, int16_t *top, int nTbS, int cIdx, int unavaible,
+                                              int8_t *unavaibleL, int8_t *unavaibleT);
+static void rec_rdpcm(int mDir, int nTbs, int16_t *r);
+static void rec_construct_pic(struct sps *sps, int xCurr, int yCurr, int nCurrSw, int nCurrSh, int cIdx, int16_t *predSamples,
+                              int16_t *resSamples, int16_t *dst, int stride);
+static void rec_yuv420_16(uint8_t *ptr, int pitch, int16_t *y, int16_t *u, int16_t *v, int y_stride, int uv_stride, int ctbrows, int ctbcols, int ctbsize);
+#define intra_sample_prediction(...) REF_CAT(ISP_AT_, __LINE__)(__VA_ARGS__)
+#define ISP_AT_4542(...) intra_sample_prediction(__VA_ARGS__)
+#define ISP_AT_4731(...) rec_intra_sample_prediction(__VA_ARGS__)
+#define scale_and_transform(...) REF_CAT(SAT_AT_, __LINE__)(__VA_ARGS__)
+#define SAT_AT_4172(...) scale_and_transform(__VA_ARGS__)
+#define SAT_AT_4738(...) rec_scale_and_transform(__VA_ARGS__)
+#define scale_transform_coefficients(...) REF_CAT(STC_AT_, __LINE__)(__VA_ARGS__)
+#define STC_AT_3743(...) scale_transform_coefficients(__VA_ARGS__)
+#define STC_AT_4224(...) rec_scale_transform_coefficients(__VA_ARGS__)
+#define reference_sample_substitution(...) REF_CAT(RSS_AT_, __LINE__)(__VA_ARGS__)
+#define RSS_AT_4277(...) reference_sample_substitution(__VA_ARGS__)
+#define RSS_AT_4623(...) rec_reference_sample_substitution(__VA_ARGS__)
+#define residual_modification_transform_bypass(...) REF_CAT(RMB_AT_, __LINE__)(__VA_ARGS__)
+#define RMB_AT_3960(...) residual_modification_transform_bypass(__VA_ARGS__)
+#define RMB_AT_4746(...) rec_rdpcm(__VA_ARGS__)
+#define construct_pic_pior_to_filtering(...) REF_CAT(CPP_AT_, __LINE__)(__VA_ARGS__)
+#define CPP_AT_4256(...) construct_pic_pior_to_filtering(__VA_ARGS__)
+#define CPP_AT_4791(...) rec_construct_pic(__VA_ARGS__)
+#define YUV420_to_BGRA32_16bit(...) REF_CAT(Y16_AT_, __LINE__)(__VA_ARGS__)
+#define Y16_AT_7261(...) rec_yuv420_16(__VA_ARGS__)
 #include "hevc.c" /* the reference's coding/hevc.c */
+#undef intra_sample_prediction
+#undef scale_and_transform
+#undef scale_transform_coefficients
+#undef reference_sample_substitution
+#undef residual_modification_transform_bypass
+#undef construct_pic_pior_to_filtering
+#undef YUV420_to_BGRA32_16bit
+
 
 struct ref_hevc_ctx {
     struct sps sps;
@@ -174,3 +229,166 @@ int ref_hevc_scale_and_transform(const int16_t *level, int16_t *r, int nTbS, int
     free(cu); free(ctu); free(info); free(p); free(slice); free(sps); free(pps); free(hps);
     return qP;
 }
+
+
+/* ------------------------------------------------------------------------------------------------------------
+ * The recorder behind the taps above.  While ref_hevc_record_begin() ... ref_hevc_record_end() brackets a decode, every
+ * leaf transform unit the reference reconstructs leaves one record, in decode order: what ffhip_hevc_residual_batch and
+ * ffhip_hevc_intra_recon take as input (TU geometry, mode, flags, availability, quantised levels, qP) and what the
+ * reference computed from it (the residual block after scale_and_transform, the planes and the BGRA picture). */
+struct rec_tu {
+    int32_t x, y, log2, cidx, mode, flags; /* flags: ffhip FFHIP_TU_* bits */
+    int32_t qp, rflags;                    /* residual stage: qP, 1 = DST (intra luma 4x4), 2 = transform skip, 4 = bypass, 8 = rotate */
+    int32_t level_off;                     /* element offset into the level / residual arrays, -1 = no residual */
+    int32_t pad;
+    uint64_t avail_top, avail_left;
+};
+static struct {
+    int on, open;
+    struct rec_tu cur, *tus;
+    long n_tus, cap_tus;
+    int16_t *levels, *resid;
+    long n_lv, cap_lv;
+    int16_t *planes;  /* copy of the picture planes handed to the colour conversion */
+    long plane_elems;
+    int y_stride, uv_stride, ctbrows, ctbcols, ctbsize, pitch;
+    struct sps *sps;
+    struct cu *cu;
+} g_rec;
+
+static void rec_intra_sample_prediction(struct slice_segment_header *slice, struct hevc_param_set *hps, struct cu *cu, int xTbCmp,
+                                        int yTbCmp, int predModeIntra, int nTbS, int cIdx, int16_t *predSamples, struct picture *p)
+{
+    if (g_rec.on) {
+        struct pps *pps = hps->pps[slice->slice_pic_parameter_set_id];
+        struct sps *sps = hps->sps[pps->pps_seq_parameter_set_id];
+        memset(&g_rec.cur, 0, sizeof g_rec.cur);
+        g_rec.cur.x = xTbCmp; g_rec.cur.y = yTbCmp; g_rec.cur.log2 = log2floor(nTbS); g_rec.cur.cidx = cIdx; g_rec.cur.mode = predModeIntra;
+        g_rec.cur.level_off = -1;
+        g_rec.cur.avail_top = nTbS == 32 ? ~0ull : (1ull << (2 * nTbS)) - 1; /* everything available unless the substitution is invoked */
+        g_rec.cur.avail_left = g_rec.cur.avail_top;
+        int fl = 1; /* corner */
+        if (sps->sps_range_ext.intra_smoothing_disabled_flag == 0 && (cIdx == 0 || sps->ChromaArrayType == 3)) fl |= 4;
+        if (sps->strong_intra_smoothing_enabled_flag) fl |= 8;
+        if (sps->sps_scc_ext.intra_boundary_filtering_disabled_flag == 1) fl |= 16 | 32;
+        else if (sps->sps_range_ext.implicit_rdpcm_enabled_flag == 1 && cu->cu_transquant_bypass_flag == 1) fl |= 16;
+        g_rec.cur.flags = fl;
+        g_rec.open = 1;
+        g_rec.sps = sps;
+        g_rec.cu = cu;
+    }
+    intra_sample_prediction(slice, hps, cu, xTbCmp, yTbCmp, predModeIntra, nTbS, cIdx, predSamples, p);
+}
+
+static void rec_reference_sample_substitution(struct sps *sps, int16_t *left, int16_t *top, int nTbS, int cIdx, int unavaible,
+                                              int8_t *unavaibleL, int8_t *unavaibleT)
+{
+    if (g_rec.on && g_rec.open) {
+        uint64_t at = 0, al = 0;
+        for (int k = 0; k < 2 * nTbS; k++) {
+            if (!unavaibleT[k]) at |= 1ull << k;
+            if (!unavaibleL[k]) al |= 1ull << k;
+        }
+        g_rec.cur.avail_top = at;
+        g_rec.cur.avail_left = al;
+        if (unavaibleT[-1]) g_rec.cur.flags &= ~1;
+    }
+    reference_sample_substitution(sps, left, top, nTbS, cIdx, unavaible, unavaibleL, unavaibleT);
+}
+
+static void rec_scale_transform_coefficients(struct sps *sps, struct cu *cu, struct slice_segment_header *slice, struct picture *p,
+                                             int transform_skip_flag, int xTbY, int yTbY, int nTbS, int cIdx, int qP, int16_t *d)
+{
+    if (g_rec.on && g_rec.open) g_rec.cur.qp = qP;
+    scale_transform_coefficients(sps, cu, slice, p, transform_skip_flag, xTbY, yTbY, nTbS, cIdx, qP, d);
+}
+
+static int rec_scale_and_transform(struct cu *cu, int transform_skip_flag, struct hevc_param_set *hps, struct slice_segment_header *slice,
+                                   int xTbY, int yTbY, int cIdx, int nTbS, int16_t *r, struct picture *p)
+{
+    long off = -1;
+    if (g_rec.on && g_rec.open) {
+        struct pps *pps = hps->pps[slice->slice_pic_parameter_set_id];
+        struct sps *sps = hps->sps[pps->pps_seq_parameter_set_id];
+        const int nn = nTbS * nTbS;
+        if (g_rec.n_lv + nn > g_rec.cap_lv) {
+            g_rec.cap_lv = 2 * (g_rec.cap_lv + nn) + 4096;
+            g_rec.levels = realloc(g_rec.levels, (size_t)g_rec.cap_lv * 2);
+            g_rec.resid = realloc(g_rec.resid, (size_t)g_rec.cap_lv * 2);
+        }
+        off = g_rec.n_lv;
+        struct trans_tree *tt = &cu->tt;
+        for (int y = 0; y < nTbS; y++)
+            for (int x = 0; x < nTbS; x++) g_rec.levels[off + x + y * nTbS] = tt->TransCoeffLevel[cIdx][xTbY + x - tt->xT0][yTbY + y - tt->yT0];
+        g_rec.n_lv += nn;
+        g_rec.cur.level_off = (int32_t)off;
+        g_rec.cur.flags |= 2;
+        const int intra = get_CuPredMode(sps, p, xTbY, yTbY) == MODE_INTRA;
+        g_rec.cur.rflags = ((cIdx == 0 && nTbS == 4 && intra) ? 1 : 0) | (transform_skip_flag ? 2 : 0) | (cu->cu_transquant_bypass_flag ? 4 : 0) |
+                           ((sps->sps_range_ext.transform_skip_rotation_enabled_flag == 1 && nTbS == 4 && intra) ? 8 : 0);
+    }
+    const int rc = scale_and_transform(cu, transform_skip_flag, hps, slice, xTbY, yTbY, cIdx, nTbS, r, p);
+    if (off >= 0) memcpy(g_rec.resid + off, r, (size_t)nTbS * nTbS * 2);
+    return rc;
+}
+
+static void rec_rdpcm(int mDir, int nTbs, int16_t *r)
+{
+    if (g_rec.on && g_rec.open) g_rec.cur.flags |= 64;
+    residual_modification_transform_bypass(mDir, nTbs, r);
+}
+
+static void rec_construct_pic(struct sps *sps, int xCurr, int yCurr, int nCurrSw, int nCurrSh, int cIdx, int16_t *predSamples,
+                              int16_t *resSamples, int16_t *dst, int stride)
+{
+    construct_pic_pior_to_filtering(sps, xCurr, yCurr, nCurrSw, nCurrSh, cIdx, predSamples, resSamples, dst, stride);
+    if (g_rec.on && g_rec.open) {
+        if (g_rec.n_tus == g_rec.cap_tus) {
+            g_rec.cap_tus = 2 * g_rec.cap_tus + 1024;
+            g_rec.tus = realloc(g_rec.tus, (size_t)g_rec.cap_tus * sizeof *g_rec.tus);
+        }
+        if (xCurr != g_rec.cur.x || yCurr != g_rec.cur.y || cIdx != g_rec.cur.cidx || nCurrSw != (1 << g_rec.cur.log2)) g_rec.cur.pad = 1; /* mismatch marker */
+        g_rec.tus[g_rec.n_tus++] = g_rec.cur;
+        g_rec.open = 0;
+    }
+}
+
+static void rec_yuv420_16(uint8_t *ptr, int pitch, int16_t *y, int16_t *u, int16_t *v, int y_stride, int uv_stride, int ctbrows, int ctbcols, int ctbsize)
+{
+    if (g_rec.on) { /* planes: Y at 0, U at size, V at size * 3/2 of one allocation of 2 * size samples (hevc.c:7225-7230) */
+        g_rec.plane_elems = (long)(u - y) * 2;
+        g_rec.planes = realloc(g_rec.planes, (size_t)g_rec.plane_elems * 2);
+        memcpy(g_rec.planes, y, (size_t)g_rec.plane_elems * 2);
+        g_rec.y_stride = y_stride; g_rec.uv_stride = uv_stride; g_rec.ctbrows = ctbrows; g_rec.ctbcols = ctbcols; g_rec.ctbsize = ctbsize; g_rec.pitch = pitch;
+        (void)v;
+    }
+    YUV420_to_BGRA32_16bit(ptr, pitch, y, u, v, y_stride, uv_stride, ctbrows, ctbcols, ctbsize);
+}
+
+void ref_hevc_record_begin(void)
+{
+    g_rec.on = 1; g_rec.open = 0; g_rec.n_tus = 0; g_rec.n_lv = 0;
+}
+/* info[8] = n_tus, n_level_elements, plane elements (Y + U + V region), y_stride, uv_stride, ctbrows, ctbcols, ctbsize */
+void ref_hevc_record_end(long *info)
+{
+    g_rec.on = 0;
+    info[0] = g_rec.n_tus; info[1] = g_rec.n_lv; info[2] = g_rec.plane_elems; info[3] = g_rec.y_stride; info[4] = g_rec.uv_stride;
+    info[5] = g_rec.ctbrows; info[6] = g_rec.ctbcols; info[7] = g_rec.ctbsize;
+}
+void ref_hevc_record_fetch(void *tus, int16_t *levels, int16_t *resid, int16_t *planes)
+{
+    memcpy(tus, g_rec.tus, (size_t)g_rec.n_tus * sizeof *g_rec.tus);
+    memcpy(levels, g_rec.levels, (size_t)g_rec.n_lv * 2);
+    memcpy(resid, g_rec.resid, (size_t)g_rec.n_lv * 2);
+    if (g_rec.plane_elems) memcpy(planes, g_rec.planes, (size_t)g_rec.plane_elems * 2);
+}
+/* sps facts the test needs to size its buffers: out[6] = width, height, BitDepthY, BitDepthC, ChromaArrayType, CtbLog2SizeY */
+void ref_hevc_sps_info(void *hps_, int *out)
+{
+    struct hevc_param_set *hps = hps_;
+    struct sps *sps = hps->sps[0];
+    out[0] = sps->pic_width_in_luma_samples; out[1] = sps->pic_height_in_luma_samples; out[2] = sps->BitDepthY; out[3] = sps->BitDepthC;
+    out[4] = sps->ChromaArrayType; out[5] = sps->CtbLog2SizeY;
+}
+void *ref_hevc_param_set_new(void) { return calloc(1, sizeof(struct hevc_param_set)); }

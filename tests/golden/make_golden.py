@@ -533,6 +533,88 @@ def gen_vp8_filter_params(R):
     save("vp8_filter_params.npz", header=hdr, filters=out.astype(np.uint8))
 
 
+HEVC_REC = np.dtype([("x", "<i4"), ("y", "<i4"), ("log2", "<i4"), ("cidx", "<i4"), ("mode", "<i4"), ("flags", "<i4"), ("qp", "<i4"), ("rflags", "<i4"),
+                     ("level_off", "<i4"), ("pad", "<i4"), ("avail_top", "<u8"), ("avail_left", "<u8")])   # struct rec_tu of oracle/ref_statics_hevc.c
+
+
+def _ref_decode_hevc_inproc(width, height, seed, out_npz):
+    """the reference's parse_nalu (coding/hevc.c:7300) over a hand-assembled stream, with the recorder of
+    oracle/ref_statics_hevc.c on: TU list, levels, residuals, planes, BGRA"""
+    import hevc_bitstream as HB
+    R = O.ref()
+    R.ref_hevc_param_set_new.restype = C.c_void_p
+    R.parse_nalu.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]
+    R.ref_hevc_record_fetch.argtypes = [C.c_void_p] * 4
+    hps = R.ref_hevc_param_set_new()
+    nals = HB.stream(width, height, seed)
+    pix = np.zeros(width * (height + 64) * 4 + 4096, np.uint8)
+    for n in nals[:3]:
+        buf = np.frombuffer(n, np.uint8).copy()
+        dummy = C.c_void_p(0)
+        R.parse_nalu(buf.ctypes.data, buf.size, C.byref(dummy), hps)
+    buf = np.frombuffer(nals[3], np.uint8).copy()
+    pp = C.c_void_p(pix.ctypes.data)
+    R.ref_hevc_record_begin()
+    R.parse_nalu(buf.ctypes.data, buf.size, C.byref(pp), hps)
+    info = (C.c_long * 8)()
+    R.ref_hevc_record_end(info)
+    info = list(info)
+    tus = np.zeros(info[0], HEVC_REC)
+    lv = np.zeros(max(info[1], 1), np.int16)
+    rs = np.zeros(max(info[1], 1), np.int16)
+    pl = np.zeros(max(info[2], 1), np.int16)
+    R.ref_hevc_record_fetch(tus.ctypes.data, lv.ctypes.data, rs.ctypes.data, pl.ctypes.data)
+    np.savez(out_npz, tus=tus.view(np.uint8), levels=lv, resid=rs, planes=pl, info=np.array(info, np.int64), bgra=pix[:width * height * 4],
+             stream=np.frombuffer(b"".join(len(n).to_bytes(4, "big") + n for n in nals), np.uint8))
+    os._exit(0)
+
+
+def gen_hevc_file(R):
+    """f4 / BASELINE config 5 at stream level: HEVC intra pictures decoded by the reference's OWN parser from
+    hand-assembled streams (tests/hevc_bitstream.py: headers written from H.265 7.3, slice data = seeded random bytes).
+    Recorded per leaf TU, in decode order: geometry, mode, flags, availability, the quantised levels and qP it handed to
+    scale_and_transform, the residual it got back; then the planes it passed to the colour conversion and the BGRA."""
+    res = {}
+    for tag, (w, h, seed) in {"a": (128, 128, 1935), "b": (128, 128, 4145), "c": (64, 64, 2732)}.items():
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "hevc.npz")
+            rc = subprocess.call([sys.executable, os.path.abspath(__file__), "--decode-hevc", f"{w},{h},{seed}", out],
+                                 stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            assert rc == 0 and os.path.exists(out), f"the reference did not decode the {w}x{h} stream of seed {seed} to a clean end"
+            d = dict(np.load(out))
+        rec = d["tus"].view(HEVC_REC)
+        luma = rec[rec["cidx"] == 0]
+        assert int((1 << (2 * luma["log2"])).sum()) == w * h and int(rec["pad"].sum()) == 0, "the recorded TUs do not tile the picture"
+        tus = np.zeros(len(rec), synth.HEVC_TU_DTYPE)
+        for k in ("x", "y", "cidx", "flags", "avail_top", "avail_left"):
+            tus[k] = rec[k]
+        tus["log2_size"], tus["pred_mode"] = rec["log2"], rec["mode"]
+        has = rec["level_off"] >= 0
+        tus["res_offset"] = np.where(has, rec["level_off"], 0)
+        size = w * h
+        planes = d["planes"]
+        y, u, v = planes[:size].reshape(h, w), planes[size:size + size // 4].reshape(h // 2, w // 2), planes[size * 3 // 2:size * 3 // 2 + size // 4].reshape(h // 2, w // 2)
+        # the restatement reproduces the reference's decode from the record, stage by stage
+        F = O.ffo()
+        resid = np.zeros_like(d["resid"])
+        for t in rec[has]:
+            n = 1 << int(t["log2"])
+            o = int(t["level_off"])
+            F.ffo_hevc_residual_tu(np.ascontiguousarray(d["levels"][o:o + n * n]), resid[o:o + n * n], n, int(t["qp"]), int(t["rflags"]), 8, 0, None)
+        assert np.array_equal(resid, d["resid"]), "residual stage"
+        oy, ou, ov = O.oracle_hevc_intra(tus, resid, w, h, True, 8, 8)
+        assert np.array_equal(oy, y) and np.array_equal(ou, u) and np.array_equal(ov, v), "intra reconstruction"
+        bgra = d["bgra"].reshape(h, w * 4)
+        print(f"  {tag}: {w}x{h} seed {seed}: {len(rec)} TUs, sizes {np.bincount(rec['log2'])[2:]}, {int(has.sum())} with residual, "
+              f"residual flags {np.bincount(rec['rflags'][has], minlength=8)}, qP {np.unique(rec['qp'][has])}, |level| max {np.abs(d['levels']).max()}")
+        tuinfo = np.zeros((len(rec), 4), np.uint8)
+        tuinfo[:, 0], tuinfo[:, 1] = rec["qp"], rec["rflags"]
+        res.update({f"{tag}_dims": np.array([w, h, seed], np.int32), f"{tag}_tus": tus.view(np.uint8), f"{tag}_tuinfo": tuinfo,
+                    f"{tag}_levels": d["levels"], f"{tag}_resid": d["resid"], f"{tag}_y": y, f"{tag}_u": u, f"{tag}_v": v, f"{tag}_bgra": bgra,
+                    f"{tag}_stream": d["stream"]})
+    save("hevc_file.npz", **res)
+
+
 def ref_decode_file(R, path):
     """Run the reference's whole-file decode in a child process (its Huffman reader overruns its
     input at the end of some scans -- utils/bitstream.c:117 -- and can take the process down)."""
@@ -610,7 +692,7 @@ def main():
     R = O.ref()
     steps = [("blocks", gen_blocks), ("vp8 macroblocks", gen_vp8_mbs), ("vp8 driven", gen_vp8_driven), ("vp8 frames", gen_vp8_frames),
              ("hevc intra", gen_hevc_intra), ("hevc glue", gen_hevc_glue), ("vp8 loop filter", gen_vp8_loopfilter), ("colour", gen_color),
-             ("grids", gen_grids), ("files", gen_files), ("webp file", gen_webp_file), ("webp file lf", gen_webp_file_lf), ("vp8 filter params", gen_vp8_filter_params)]
+             ("grids", gen_grids), ("files", gen_files), ("webp file", gen_webp_file), ("webp file lf", gen_webp_file_lf), ("vp8 filter params", gen_vp8_filter_params), ("hevc file", gen_hevc_file)]
     only = sys.argv[2] if len(sys.argv) == 3 and sys.argv[1] == "--only" else None   # e.g. --only "hevc intra"
     for name, fn in steps:
         if only is None or only == name:
@@ -622,6 +704,8 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) == 4 and sys.argv[1] == "--decode":
         _ref_decode_file_inproc(sys.argv[2], sys.argv[3])
+    if len(sys.argv) == 4 and sys.argv[1] == "--decode-hevc":
+        _ref_decode_hevc_inproc(*[int(x) for x in sys.argv[2].split(",")], sys.argv[3])
     if len(sys.argv) == 4 and sys.argv[1] == "--decode-webp":
         _ref_decode_webp_inproc(sys.argv[2], sys.argv[3])
     main()

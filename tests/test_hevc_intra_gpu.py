@@ -138,6 +138,34 @@ def test_heic_chain_levels_to_bgra(w, h, seed, bd):
     assert np.array_equal(bgra, oracle_420_16(exp[0], exp[1], exp[2], h // ctb, w // ctb, ctb))
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_hevc_file_config5(golden, tag):
+    """f4 / BASELINE config 5 from the reference's own parse: quantised levels and TU lists its decoder recorded while
+    decoding a hand-assembled HEVC stream -> ffhip_hevc_residual_batch per TU size -> ffhip_hevc_intra_recon ->
+    ffhip_yuv420_to_bgra_16, against the residuals, planes and BGRA picture the reference itself produced"""
+    g = golden("hevc_file.npz")
+    w, h, _ = [int(x) for x in g[f"{tag}_dims"]]
+    tus = np.ascontiguousarray(g[f"{tag}_tus"]).view(synth.HEVC_TU_DTYPE).reshape(-1).copy()
+    info, lv = g[f"{tag}_tuinfo"], g[f"{tag}_levels"]
+    has = (tus["flags"] & synth.TU_RESIDUAL) != 0
+    resid = np.zeros(len(lv) + 16, np.int16)
+    for lg in (2, 3, 4, 5):                                   # one residual batch per TU size, as a decoder would issue them
+        idx = np.nonzero(has & (tus["log2_size"] == lg))[0]
+        if idx.size == 0:
+            continue
+        n = 1 << lg
+        offs = tus["res_offset"][idx].astype(np.int64)
+        levels = np.stack([lv[o:o + n * n] for o in offs])
+        got = ops.hevc_residual_batch(n, levels, np.ascontiguousarray(info[idx]), bitdepth=8)
+        for k, o in enumerate(offs):
+            resid[o:o + n * n] = got[k]
+    assert np.array_equal(resid[:len(lv)], g[f"{tag}_resid"])
+    y, u, v = ops.hevc_intra_recon(tus, resid, w, h, True, 8, 8)
+    assert np.array_equal(y, g[f"{tag}_y"]) and np.array_equal(u, g[f"{tag}_u"]) and np.array_equal(v, g[f"{tag}_v"])
+    bgra = ops.yuv420_to_bgra_16(y[None], u[None], v[None], h // 64, w // 64, 64)[0]
+    assert np.array_equal(bgra, g[f"{tag}_bgra"])
+
+
 @pytest.mark.parametrize("shift", [1, 3, 8, 13])
 def test_residual_blocks_at_odd_offsets(shift):
     """Residual blocks need not be 16-byte aligned in d_residual: the kernel fetches aligned blocks ahead with 16-byte

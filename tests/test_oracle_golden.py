@@ -199,6 +199,30 @@ def test_webp_file_with_loop_filter(golden, ffo, tag):
     assert np.array_equal(out[:h], g[f"{tag}_bgra"])
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_hevc_file_config5(golden, ffo, tag):
+    """f4 / config 5 at stream level: intra pictures the reference's OWN parser decoded from hand-assembled HEVC streams
+    (tests/hevc_bitstream.py), reproduced stage by stage from the per-TU record of its decode: residuals
+    (scale_and_transform), planes (decode_intra_block), BGRA (YUV420_to_BGRA32_16bit)"""
+    from ffpic_amd import synth
+    g = golden("hevc_file.npz")
+    w, h, _ = [int(x) for x in g[f"{tag}_dims"]]
+    tus = np.ascontiguousarray(g[f"{tag}_tus"]).view(synth.HEVC_TU_DTYPE).reshape(-1)
+    info, lv = g[f"{tag}_tuinfo"], g[f"{tag}_levels"]
+    resid = np.zeros_like(lv)
+    has = (tus["flags"] & synth.TU_RESIDUAL) != 0
+    assert has.sum() > 100 and len({int(x) for x in info[has, 1]}) >= 5          # DST, transform skip, bypass and plain TUs all occur
+    for i in np.nonzero(has)[0]:
+        n, o = 1 << int(tus["log2_size"][i]), int(tus["res_offset"][i])
+        ffo.ffo_hevc_residual_tu(np.ascontiguousarray(lv[o:o + n * n]), resid[o:o + n * n], n, int(info[i, 0]), int(info[i, 1]), 8, 0, None)
+    assert np.array_equal(resid, g[f"{tag}_resid"])
+    y, u, v = O.oracle_hevc_intra(tus, resid, w, h, True, 8, 8)
+    assert np.array_equal(y, g[f"{tag}_y"]) and np.array_equal(u, g[f"{tag}_u"]) and np.array_equal(v, g[f"{tag}_v"])
+    out = np.zeros((h, w * 4), np.uint8)
+    ffo.ffo_yuv420_to_bgra32_16bit(out.reshape(-1), w * 4, y.reshape(-1), u.reshape(-1), v.reshape(-1), w, w // 2, h // 64, w // 64, 64)
+    assert np.array_equal(out, g[f"{tag}_bgra"])
+
+
 def test_hevc_dst4(golden, ffo):
     g = golden("hevc_dst4.npz")
     for bd in (8, 10):

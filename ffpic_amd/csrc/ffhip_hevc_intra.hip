@@ -53,6 +53,7 @@ struct HevcIntraArgs {
     uint32_t *ctrl;           /* [0] next group ticket, [1] abort; done flags per TU from ctrl + 4 */
     int *async_err;           /* pinned host word (ffhip_async_err_word)                          */
     int n_groups;
+    int debug_withhold;       /* test hook (FFHIP_DEBUG_WITHHOLD_TU): this TU's done flag is never published; -1 = off */
 };
 
 __device__ __forceinline__ void wave_sync()
@@ -488,7 +489,8 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                      * Sending the flag one TU later instead -- when the next residual, fetched behind these stores,
                      * has been consumed -- was measured no faster: the reader waits for the flag either way */
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(flags + (slots[3 * k + 2].z), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0 && (int)slots[3 * k + 2].z != a.debug_withhold)
+                        __hip_atomic_store(flags + (slots[3 * k + 2].z), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 wave_sync(); /* the next TU reuses the neighbour scratch and reads the tile this one wrote */
                 if (k + 1 < m) {
@@ -809,6 +811,10 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
     a.plane[0] = d_y; a.plane[1] = d_cb; a.plane[2] = d_cr;
     a.stride[0] = y_stride; a.stride[1] = uv_stride; a.stride[2] = uv_stride;
     a.bitdepth_y = bitdepth_y; a.bitdepth_c = bitdepth_c;
+    {   /* drives the bounded-spin give-up path in tests: the waiters of that TU run into SPIN_LIMIT and report FFHIP_EIO */
+        const char *dw = getenv("FFHIP_DEBUG_WITHHOLD_TU");
+        a.debug_withhold = dw ? atoi(dw) : -1;
+    }
 
     /* grouped single-launch form unless FFHIP_HEVC_INTRA_MODE=levels (diagnostics) or no window works */
     const char *mode_env = getenv("FFHIP_HEVC_INTRA_MODE");

@@ -892,6 +892,7 @@ extern "C" int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *g, int n_images, co
     return FFHIP_OK;
 }
 
+#define SCRATCH_JPEG_HOST 6
 extern "C" int ffhip_jpeg_recon_batch_host(const ffhip_jpeg_geom *g, int n_images, const int16_t *coef_y,
                                            const int16_t *coef_u, const int16_t *coef_v,
                                            const uint16_t *quant, int64_t quant_stride, uint8_t *bgra,
@@ -906,26 +907,26 @@ extern "C" int ffhip_jpeg_recon_batch_host(const ffhip_jpeg_geom *g, int n_image
     const int64_t height = (int64_t)g->mcu_rows * 8 * g->v;
     const size_t obytes = (size_t)image_stride * (n_images - 1) + (size_t)pitch * height;
     const size_t wbytes = ffhip_jpeg_workspace_bytes(g, n_images);
-    void *dy = nullptr, *du = nullptr, *dv = nullptr, *dq = nullptr, *dout = nullptr, *dws = nullptr;
-    int rc = FFHIP_ENOMEM;
-    if (hipMalloc(&dy, ybytes) != hipSuccess) goto done;
-    if (g->ncomp == 3 && (hipMalloc(&du, cbytes) != hipSuccess || hipMalloc(&dv, cbytes) != hipSuccess)) goto done;
-    if (hipMalloc(&dq, qbytes) != hipSuccess || hipMalloc(&dout, obytes) != hipSuccess) goto done;
-    if (wbytes && hipMalloc(&dws, wbytes) != hipSuccess) goto done;
-    rc = FFHIP_EIO;
-    if (hipMemcpy(dy, coef_y, ybytes, hipMemcpyHostToDevice) != hipSuccess) goto done;
-    if (g->ncomp == 3 && (hipMemcpy(du, coef_u, cbytes, hipMemcpyHostToDevice) != hipSuccess ||
-                          hipMemcpy(dv, coef_v, cbytes, hipMemcpyHostToDevice) != hipSuccess))
-        goto done;
-    if (hipMemcpy(dq, quant, qbytes, hipMemcpyHostToDevice) != hipSuccess) goto done;
-    rc = ffhip_jpeg_recon_batch(g, n_images, (const int16_t *)dy, (const int16_t *)du, (const int16_t *)dv,
-                                (const uint16_t *)dq, quant_stride, (uint8_t *)dout, pitch, image_stride, dws,
-                                wbytes, nullptr);
-    if (rc) goto done;
-    rc = FFHIP_EIO;
-    if (hipMemcpy(bgra, dout, obytes, hipMemcpyDeviceToHost) != hipSuccess) goto done;
-    rc = FFHIP_OK;
-done:
-    (void)hipFree(dy); (void)hipFree(du); (void)hipFree(dv); (void)hipFree(dq); (void)hipFree(dout); (void)hipFree(dws);
-    return rc;
+    /* the device buffers are library scratch kept between calls (one allocation, grown on demand, released by
+     * ffhip_shutdown): this is the per-picture entry a patched format/jpg.c calls, and allocating and freeing ~60 MB of
+     * device memory around every picture cost more than the reconstruction itself.  Calls are serialised by the
+     * synchronous copies on the null stream, like the reference's single-threaded decode loop. */
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_u = up(ybytes), o_v = o_u + up(g->ncomp == 3 ? cbytes : 0), o_q = o_v + up(g->ncomp == 3 ? cbytes : 0);
+    const size_t o_out = o_q + up(qbytes), o_ws = o_out + up(obytes), total = o_ws + up(wbytes);
+    uint8_t *base = (uint8_t *)ffhip_scratch(SCRATCH_JPEG_HOST, nullptr, total / 4 + 64);
+    if (!base) return FFHIP_ENOMEM;
+    void *dy = base, *du = g->ncomp == 3 ? base + o_u : nullptr, *dv = g->ncomp == 3 ? base + o_v : nullptr, *dq = base + o_q, *dout = base + o_out;
+    void *dws = wbytes ? base + o_ws : nullptr;
+    FFHIP_CHECK(hipMemcpy(dy, coef_y, ybytes, hipMemcpyHostToDevice), FFHIP_EIO);
+    if (g->ncomp == 3) {
+        FFHIP_CHECK(hipMemcpy(du, coef_u, cbytes, hipMemcpyHostToDevice), FFHIP_EIO);
+        FFHIP_CHECK(hipMemcpy(dv, coef_v, cbytes, hipMemcpyHostToDevice), FFHIP_EIO);
+    }
+    FFHIP_CHECK(hipMemcpy(dq, quant, qbytes, hipMemcpyHostToDevice), FFHIP_EIO);
+    const int rc = ffhip_jpeg_recon_batch(g, n_images, (const int16_t *)dy, (const int16_t *)du, (const int16_t *)dv,
+                                          (const uint16_t *)dq, quant_stride, (uint8_t *)dout, pitch, image_stride, dws, wbytes, nullptr);
+    if (rc) return rc;
+    FFHIP_CHECK(hipMemcpy(bgra, dout, obytes, hipMemcpyDeviceToHost), FFHIP_EIO);
+    return FFHIP_OK;
 }

@@ -75,3 +75,30 @@ def test_hevc_groups_under_load():
             for gp, e, name in zip(got, exp, "YUV"):
                 assert np.array_equal(gp, e), name
     assert hog.count > 0
+
+
+def test_give_up_path_reports_eio_and_the_library_recovers(monkeypatch):
+    """The bounded spin of the dependency-scheduled kernels: with the done flag of one TU withheld (test hook
+    FFHIP_DEBUG_WITHHOLD_TU), the groups that wait for it run into SPIN_LIMIT, the launch drains (every wave sees the
+    abort word), ffhip_stream_sync returns FFHIP_EIO exactly once, and after ffhip_shutdown the same list decodes to the
+    oracle's picture again."""
+    import oracle_lib as O
+    from ffpic_amd import capi, ops, synth
+    L = capi.require_device()
+    w, h = 256, 192
+    tus, res = synth.hevc_intra_tus(w, h, seed=91)
+    # a TU of the first coding tree block that later groups read: the last luma TU of the first 32x32 window
+    first = [i for i, t in enumerate(tus) if t["cidx"] == 0 and t["x"] < 32 and t["y"] < 32]
+    victim = first[-1]
+    monkeypatch.setenv("FFHIP_DEBUG_WITHHOLD_TU", str(victim))
+    with pytest.raises(capi.FfhipError) as ei:
+        ops.hevc_intra_recon(tus, res, w, h, True, 8, 8)           # the wrapper's stream sync sees the abort
+    assert "-5" in str(ei.value)
+    assert L.ffhip_stream_sync(None) == 0                           # reported once, then clear
+    monkeypatch.delenv("FFHIP_DEBUG_WITHHOLD_TU")
+    L.ffhip_shutdown()
+    capi.require_device()
+    got = ops.hevc_intra_recon(tus, res, w, h, True, 8, 8)
+    exp = O.oracle_hevc_intra(tus, res, w, h, True, 8, 8)
+    for g, e in zip(got, exp):
+        assert np.array_equal(g, e)

@@ -537,7 +537,7 @@ HEVC_REC = np.dtype([("x", "<i4"), ("y", "<i4"), ("log2", "<i4"), ("cidx", "<i4"
                      ("level_off", "<i4"), ("pad", "<i4"), ("avail_top", "<u8"), ("avail_left", "<u8")])   # struct rec_tu of oracle/ref_statics_hevc.c
 
 
-def _ref_decode_hevc_inproc(width, height, seed, out_npz):
+def _ref_decode_hevc_inproc(width, height, seed, n_bytes, out_npz):
     """the reference's parse_nalu (coding/hevc.c:7300) over a hand-assembled stream, with the recorder of
     oracle/ref_statics_hevc.c on: TU list, levels, residuals, planes, BGRA"""
     import hevc_bitstream as HB
@@ -546,7 +546,7 @@ def _ref_decode_hevc_inproc(width, height, seed, out_npz):
     R.parse_nalu.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]
     R.ref_hevc_record_fetch.argtypes = [C.c_void_p] * 4
     hps = R.ref_hevc_param_set_new()
-    nals = HB.stream(width, height, seed)
+    nals = HB.stream(width, height, seed, n_bytes)
     pix = np.zeros(width * (height + 64) * 4 + 4096, np.uint8)
     for n in nals[:3]:
         buf = np.frombuffer(n, np.uint8).copy()
@@ -575,10 +575,11 @@ def gen_hevc_file(R):
     Recorded per leaf TU, in decode order: geometry, mode, flags, availability, the quantised levels and qP it handed to
     scale_and_transform, the residual it got back; then the planes it passed to the colour conversion and the BGRA."""
     res = {}
-    for tag, (w, h, seed) in {"a": (128, 128, 1935), "b": (128, 128, 4145), "c": (64, 64, 2732)}.items():
+    for tag, (w, h, seed, n_bytes) in {"a": (128, 128, 1935, 8000), "b": (128, 128, 4145, 8000), "c": (64, 64, 2732, 8000),
+                                       "d": (256, 192, 2208, 30000)}.items():     # 4, 4, 1 and 12 coding tree blocks
         with tempfile.TemporaryDirectory() as td:
             out = os.path.join(td, "hevc.npz")
-            rc = subprocess.call([sys.executable, os.path.abspath(__file__), "--decode-hevc", f"{w},{h},{seed}", out],
+            rc = subprocess.call([sys.executable, os.path.abspath(__file__), "--decode-hevc", f"{w},{h},{seed},{n_bytes}", out],
                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             assert rc == 0 and os.path.exists(out), f"the reference did not decode the {w}x{h} stream of seed {seed} to a clean end"
             d = dict(np.load(out))

@@ -199,7 +199,7 @@ def test_webp_file_with_loop_filter(golden, ffo, tag):
     assert np.array_equal(out[:h], g[f"{tag}_bgra"])
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_hevc_file_config5(golden, ffo, tag):
     """f4 / config 5 at stream level: intra pictures the reference's OWN parser decoded from hand-assembled HEVC streams
     (tests/hevc_bitstream.py), reproduced stage by stage from the per-TU record of its decode: residuals

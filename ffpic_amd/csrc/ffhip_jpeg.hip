@@ -219,6 +219,33 @@ __device__ __forceinline__ int fdiv_f32(int two_x_plus_1, float inv_2d)
     return (int)((float)two_x_plus_1 * inv_2d);
 }
 
+/* The three chroma terms of one chroma sample pair, from the RAW samples a = uu + 128, b = vv + 128 in [0, 8191], one
+ * v_fma_f32 and one v_add_f32 each: the exact quotient sits at least 0.5/d from a rounding boundary ((x + 0.5)/d - 0.5
+ * form), and adding 2^23 + 65536 - bias rounds it to the integer and leaves the term's two's-complement int16 in the LOW
+ * HALF of the float's bit pattern, ready for the packed 16-bit adds (the high half is garbage).
+ *   r: floor(32 vv / 25), g: floor(-(215 uu + 381 vv) / 1000), b: floor(266 uu / 125);
+ *   sens: 215 uu + 381 vv is a non-zero multiple of 1000 -- the reference's double roundings decide G there.
+ * 12 VALU instructions against 27 for the integer / cvt form it replaces; every a, b enumerated against the integer
+ * definitions in tests/tools/check_color_fma.c (0 mismatches of 67 M pairs). */
+struct TermBits {
+    u32 r, g, b;
+    bool sens;
+};
+__device__ __forceinline__ TermBits chroma_term_bits(u32 a_raw, u32 b_raw)
+{
+    const float af = (float)a_raw, bf = (float)b_raw;
+    TermBits t;
+    t.r = __builtin_bit_cast(u32, __builtin_fmaf(bf, 1.28f, -0.32f) + 8453980.0f);
+    t.b = __builtin_bit_cast(u32, __builtin_fmaf(af, 2.128f, 0.12f) + 8453871.0f);
+    const float sf = __builtin_fmaf(bf, 381.0f, af * 215.0f); /* exact: an integer below 2^24 */
+    const float tf = 4882288.0f - sf;                         /* 4806000 - (215 uu + 381 vv) >= 0, exact */
+    const float tg = __builtin_fmaf(tf, 0.001f, -0.4995f) + 8449338.0f;
+    t.g = __builtin_bit_cast(u32, tg);
+    const float kf = tg - 8449338.0f;                         /* floor(tf / 1000), exact */
+    t.sens = __builtin_fmaf(kf, -1000.0f, tf) == 0.0f && sf != 76288.0f;
+    return t;
+}
+
 /* ------------------------------------------------------------------------
  * Fused kernel, 3 components, h = v = 2.
  * ---------------------------------------------------------------------- */
@@ -315,21 +342,13 @@ __device__ __forceinline__ void quad_recon(const JpegBatch &p, const WaveCtx &c,
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const u32 uw = us[k >> 1], vw = vs[k >> 1];
-            const int uu = (int)((k & 1) ? (uw >> 16) : (uw & 0xffffu)) - 128; /* colorspace.c:149 */
-            const int vv = (int)((k & 1) ? (vw >> 16) : (vw & 0xffffu)) - 128;
-            /* floor(32 vv/25), floor(266 uu/125), floor(-(215 uu + 381 vv)/1000), each
-             * biased to a non-negative numerator x and evaluated as fdiv(2x+1) */
-            const int fr = fdiv_f32(64 * vv + (2 * 25 * 164 + 1), 1.0f / 50.0f) - 164;
-            const int fb = fdiv_f32(532 * uu + (2 * 125 * 273 + 1), 1.0f / 250.0f) - 273;
-            const int sgm = 215 * uu + 381 * vv;
-            const int t = 4806000 - sgm;
-            const int tq = fdiv_f32(2 * t + 1, 1.0f / 2000.0f);
-            const int fg = tq - 4806;
-            if (t - __mul24(tq, 1000) == 0 && sgm != 0) mask |= 1u << k; /* exact-integer G: fp64 decides */
-            tr[k] = __builtin_amdgcn_perm((u32)fr, (u32)fr, 0x01000100u);
-            tg[k] = __builtin_amdgcn_perm((u32)fg, (u32)fg, 0x01000100u);
-            tb[k] = __builtin_amdgcn_perm((u32)fb, (u32)fb, 0x01000100u);
-            uv[k] = __builtin_amdgcn_perm((u32)vv, (u32)uu, 0x05040100u);
+            const u32 ua = (k & 1) ? (uw >> 16) : (uw & 0xffffu), va = (k & 1) ? (vw >> 16) : (vw & 0xffffu); /* raw samples */
+            const TermBits t = chroma_term_bits(ua, va);
+            if (t.sens) mask |= 1u << k; /* exact-integer G: fp64 decides */
+            tr[k] = __builtin_amdgcn_perm(t.r, t.r, 0x01000100u);
+            tg[k] = __builtin_amdgcn_perm(t.g, t.g, 0x01000100u);
+            tb[k] = __builtin_amdgcn_perm(t.b, t.b, 0x01000100u);
+            uv[k] = __builtin_amdgcn_perm(va, ua, 0x05040100u); /* raw (u, v) pair for the fp64 fallback: uu = u - 128 (colorspace.c:149) */
         }
         *(u32x4 *)(c.lds + LDS_TR + lane * 16) = tr;
         *(u32x4 *)(c.lds + LDS_TG + lane * 16) = tg;
@@ -378,7 +397,7 @@ __device__ __forceinline__ void quad_recon(const JpegBatch &p, const WaveCtx &c,
                 for (int h2 = 0; h2 < 2; h2++)
                     if (fl & (1u << h2)) {
                         const u32 uvw = uvp[h2], y2 = yy[h2];
-                        const int uu = (int)(short)(uvw & 0xffffu), vv = (int)(short)(uvw >> 16);
+                        const int uu = (int)(uvw & 0xffffu) - 128, vv = (int)(uvw >> 16) - 128;
                         const u32 g0 = green_fp64((int)(y2 & 0xffffu), uu, vv);
                         const u32 g1 = green_fp64((int)(y2 >> 16), uu, vv);
                         px[2 * h2] = (px[2 * h2] & 0xffff00ffu) | (g0 << 8);
@@ -464,29 +483,6 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg420_fused(JpegBatch p)
 #define SM_VP 3072
 #define SM_WAVE_BYTES 4096
 
-struct ChromaTerms {
-    int fr, fg, fb;
-    bool sens;
-};
-__device__ __forceinline__ ChromaTerms chroma_terms(int uu, int vv)
-{
-    ChromaTerms t;
-    t.fr = fdiv_f32(64 * vv + (2 * 25 * 164 + 1), 1.0f / 50.0f) - 164;   /* floor(32 vv / 25)   */
-    t.fb = fdiv_f32(532 * uu + (2 * 125 * 273 + 1), 1.0f / 250.0f) - 273; /* floor(266 uu / 125) */
-    const int sgm = 215 * uu + 381 * vv, tt = 4806000 - sgm;
-    const int tq = fdiv_f32(2 * tt + 1, 1.0f / 2000.0f);
-    t.fg = tq - 4806;                                                      /* floor(-sgm / 1000)  */
-    t.sens = tt - __mul24(tq, 1000) == 0 && sgm != 0;                      /* exact-integer G: fp64 decides */
-    return t;
-}
-__device__ __forceinline__ int clamp255i(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
-__device__ __forceinline__ u32 bgra_px(int yy, const ChromaTerms &t, int uu, int vv)
-{
-    const u32 r = (u32)clamp255i(yy + t.fr), b = (u32)clamp255i(yy + t.fb);
-    const u32 g = t.sens ? green_fp64(yy, uu, vv) : (u32)clamp255i(yy + t.fg);
-    return b | (g << 8) | (r << 16) | 0xff000000u;
-}
-
 template <int H, int V, int NC, int NT>
 __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
 {
@@ -545,61 +541,111 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
         }
     }
 
-    /* ---- IDCT rounds -> sample planes in LDS: luma SH rows x SW, chroma 8 rows x CW (int16) ---- */
+    /* ---- IDCT rounds -> sample planes in LDS: luma SH rows x SW, chroma 8 rows x CW (int16).  The 16-byte chunks of a
+     * plane row are XOR-swizzled by the row (sw_off) so that the block-row writes here (lanes of one block are 8 rows
+     * apart at the same chunk) and the row-segment reads of the colour passes both touch every bank once: laid out
+     * plainly, the writes were 4-way bank conflicts (175 M conflict cycles per launch at 4:4:4, profiles/r1_jpeg_geoms_pmc.txt) ---- */
+    /* v = 2: the colour passes take rows 2j (pass 0) and 2j + 1 (pass 1) on the same lane, so that the chroma terms the
+     * two rows share are computed once; the luma plane keeps the even rows first, then the odd ones, which keeps the
+     * four rows a pass reads at once in four different bank quarters */
+    auto yrow_pos = [](u32 r) -> u32 { return (r >> 1) + 8 * (r & 1u); };
+    auto sw_off = [](u32 row, u32 col, u32 row_samples) -> u32 { /* byte offset of sample (row, col) in a swizzled plane */
+        const u32 key = row_samples == 64 ? (row & 7u) : ((row >> 2) & 3u);
+        return row * row_samples * 2 + ((((col >> 3) ^ key) & (row_samples / 8 - 1)) << 4) + (col & 7u) * 2;
+    };
     {
         const u32x4 pk = idct8x8_round(c, ly, q_y);
         const u32 m = c.blk / BPM, sub = c.blk % BPM;
         const u32 pcol = (m * H + (H == 2 ? sub : 0)) * 8, prow = (V == 2 ? sub : 0) * 8 + c.idx;
-        *(u32x4 *)(c.lds + SM_YP + (prow * SW + pcol) * 2) = pk;
+        *(u32x4 *)(c.lds + SM_YP + sw_off(V == 2 ? yrow_pos(prow) : prow, pcol, SW)) = pk;
     }
     if (NC == 3) {
         if (BPM == 1) {
             const u32x4 pu = idct8x8_round(c, lc0, q_c0);
-            *(u32x4 *)(c.lds + SM_UP + (c.idx * CW + c.blk * 8) * 2) = pu;
+            *(u32x4 *)(c.lds + SM_UP + sw_off(c.idx, c.blk * 8, CW)) = pu;
             const u32x4 pv = idct8x8_round(c, lc1, q_c1);
-            *(u32x4 *)(c.lds + SM_VP + (c.idx * CW + c.blk * 8) * 2) = pv;
+            *(u32x4 *)(c.lds + SM_VP + sw_off(c.idx, c.blk * 8, CW)) = pv;
         } else {
             const u32x4 pc = idct8x8_round(c, lc0, q_c0);
-            *(u32x4 *)(c.lds + (c.blk < 4 ? SM_UP : SM_VP) + (c.idx * CW + (c.blk & 3) * 8) * 2) = pc;
+            *(u32x4 *)(c.lds + (c.blk < 4 ? SM_UP : SM_VP) + sw_off(c.idx, (c.blk & 3) * 8, CW)) = pc;
         }
     }
 
-    /* ---- colour: 2 passes x 4 pixels per lane; 4/H chroma samples serve them ---- */
+    /* ---- colour: 2 passes x 4 pixels per lane; 4/H chroma samples serve them.  Same packed form as the 4:2:0 kernel:
+     * per pixel PAIR three 16-bit adds, three saturating packs and three byte permutes ---- */
     uint8_t *const obase = p.bgra + (long long)img * p.image_stride + (long long)mrow * SH * p.pitch + (long long)mcu0 * (32 * H);
-    ChromaTerms grey_t = {};
-    if (NC == 1) grey_t = chroma_terms(-128, -128); /* U = V = 0 planes (jpg.c:501,552-554) */
+    TermBits grey_t = {};
+    if (NC == 1) grey_t = chroma_term_bits(0u, 0u); /* U = V = 0 planes (jpg.c:501,552-554): uu = vv = -128, never "sensitive" */
+    u32 tr2[2], tg2[2], tb2[2], ua[4] = {0, 0, 0, 0}, va[4] = {0, 0, 0, 0}, sens = 0;
+    /* per-lane LDS offsets of the two passes, computed once: pass 1 reads 64 / GPR rows (v = 2: 8 row positions) further
+     * on, which flips one bit of the swizzle key -- an XOR and an add instead of a second address computation */
+    const u32 row0 = V == 2 ? 2 * (lane / GPR) : lane / GPR, pc0 = (lane % GPR) * 4;
+    const u32 y_off0 = sw_off(V == 2 ? yrow_pos(row0) : row0, pc0, SW);
+    const u32 y_off1 = SW == 64 ? (y_off0 ^ 0x40u) + 4 * 128 : (y_off0 ^ 0x20u) + 8 * 64;
+    static_assert((SW == 64 && 64 / GPR == 4 && V == 1) || (SW == 32 && V == 2), "pass-1 offset identities");
+    const u32 c_off0 = NC == 3 ? sw_off(row0 / V, pc0 / H, CW) : 0;
+    const u32 c_off1 = V == 2 ? c_off0 : (CW == 64 ? (c_off0 ^ 0x40u) + 4 * 128 : (c_off0 ^ 0x10u) + 4 * 64);
 #pragma unroll
     for (int it = 0; it < 2; it++) {
-        const u32 prow = it * (64 / GPR) + lane / GPR, pc0 = (lane % GPR) * 4;
-        const u32x2 yy = *(const u32x2 *)(c.lds + SM_YP + (prow * SW + pc0) * 2);
-        u32x4 px;
-        if (NC == 1) {
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
-                const int y1 = (int)((d & 1) ? (yy[d >> 1] >> 16) : (yy[d >> 1] & 0xffffu));
-                px[d] = bgra_px(y1, grey_t, -128, -128);
-            }
+        const u32 prow = row0 + (V == 2 ? it : it * (64 / GPR));
+        const u32x2 yy = *(const u32x2 *)(c.lds + SM_YP + (it ? y_off1 : y_off0));
+        if (V == 2 && it == 1) {
+            /* the terms of pass 0 serve this row too */
+        } else if (NC == 1) {
+            tr2[0] = tr2[1] = __builtin_amdgcn_perm(grey_t.r, grey_t.r, 0x01000100u);
+            tg2[0] = tg2[1] = __builtin_amdgcn_perm(grey_t.g, grey_t.g, 0x01000100u);
+            tb2[0] = tb2[1] = __builtin_amdgcn_perm(grey_t.b, grey_t.b, 0x01000100u);
         } else {
-            const u32 crow = prow / V, cc0 = pc0 / H;
+            const u32 c_off = it ? c_off1 : c_off0;
             u32 us[2], vs[2];
             if (H == 1) {
-                const u32x2 a = *(const u32x2 *)(c.lds + SM_UP + (crow * CW + cc0) * 2), b = *(const u32x2 *)(c.lds + SM_VP + (crow * CW + cc0) * 2);
+                const u32x2 a = *(const u32x2 *)(c.lds + SM_UP + c_off), b = *(const u32x2 *)(c.lds + SM_VP + c_off);
                 us[0] = a[0]; us[1] = a[1]; vs[0] = b[0]; vs[1] = b[1];
             } else {
-                us[0] = *(const u32 *)(c.lds + SM_UP + (crow * CW + cc0) * 2);
-                vs[0] = *(const u32 *)(c.lds + SM_VP + (crow * CW + cc0) * 2);
+                us[0] = *(const u32 *)(c.lds + SM_UP + c_off);
+                vs[0] = *(const u32 *)(c.lds + SM_VP + c_off);
                 us[1] = vs[1] = 0;
             }
+            TermBits t[4 / H];
+            sens = 0;
 #pragma unroll
             for (int k = 0; k < 4 / H; k++) {
-                const int uu = (int)((k & 1) ? (us[k >> 1] >> 16) : (us[k >> 1] & 0xffffu)) - 128; /* colorspace.c:149 */
-                const int vv = (int)((k & 1) ? (vs[k >> 1] >> 16) : (vs[k >> 1] & 0xffffu)) - 128;
-                const ChromaTerms t = chroma_terms(uu, vv);
+                ua[k] = (k & 1) ? (us[k >> 1] >> 16) : (us[k >> 1] & 0xffffu); /* raw samples: uu = u - 128 (colorspace.c:149) */
+                va[k] = (k & 1) ? (vs[k >> 1] >> 16) : (vs[k >> 1] & 0xffffu);
+                t[k] = chroma_term_bits(ua[k], va[k]);
+                sens |= t[k].sens ? 1u << k : 0u;
+            }
 #pragma unroll
-                for (int e = 0; e < H; e++) {
-                    const int d = k * H + e;
+            for (int h2 = 0; h2 < 2; h2++) {
+                if (H == 1) { /* one chroma sample per pixel: low halves of two terms side by side */
+                    tr2[h2] = __builtin_amdgcn_perm(t[2 * h2 + 1].r, t[2 * h2].r, 0x05040100u);
+                    tg2[h2] = __builtin_amdgcn_perm(t[2 * h2 + 1].g, t[2 * h2].g, 0x05040100u);
+                    tb2[h2] = __builtin_amdgcn_perm(t[2 * h2 + 1].b, t[2 * h2].b, 0x05040100u);
+                } else {      /* the pair shares its chroma sample */
+                    tr2[h2] = __builtin_amdgcn_perm(t[h2 % (4 / H)].r, t[h2 % (4 / H)].r, 0x01000100u);
+                    tg2[h2] = __builtin_amdgcn_perm(t[h2 % (4 / H)].g, t[h2 % (4 / H)].g, 0x01000100u);
+                    tb2[h2] = __builtin_amdgcn_perm(t[h2 % (4 / H)].b, t[h2 % (4 / H)].b, 0x01000100u);
+                }
+            }
+        }
+        u32x4 px;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++) {
+            const u32 y2 = yy[h2];
+            const u32 r2 = sat_pk_u8_i16(pk_add16(y2, tr2[h2]));
+            const u32 g2 = sat_pk_u8_i16(pk_add16(y2, tg2[h2]));
+            const u32 b2 = sat_pk_u8_i16(pk_add16(y2, tb2[h2]));
+            const u32 bg = __builtin_amdgcn_perm(g2, b2, 0x05010400u); /* b0 g0 b1 g1 */
+            px[2 * h2] = __builtin_amdgcn_perm(r2, bg, 0x0d040100u);     /* b0 g0 r0 ff */
+            px[2 * h2 + 1] = __builtin_amdgcn_perm(r2, bg, 0x0d050302u); /* b1 g1 r1 ff */
+        }
+        if (NC == 3 && sens) { /* rare: exact-integer G decided by the fp64 roundings */
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const int k = d / H;
+                if (sens & (1u << k)) {
                     const int y1 = (int)((d & 1) ? (yy[d >> 1] >> 16) : (yy[d >> 1] & 0xffffu));
-                    px[d] = bgra_px(y1, t, uu, vv);
+                    px[d] = (px[d] & 0xffff00ffu) | (green_fp64(y1, (int)ua[k] - 128, (int)va[k] - 128) << 8);
                 }
             }
         }

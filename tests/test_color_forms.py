@@ -50,3 +50,14 @@ def test_integer_colour_forms_subsampled(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "R mismatches 0, B mismatches 0" in out.stdout
     assert "G mismatches on non-sensitive chroma: 0" in out.stdout
+
+
+def test_fma_term_forms_exhaustive(tmp_path):
+    """the float forms of the chroma terms the JPEG kernels compute (ffhip_jpeg.hip::chroma_term_bits: one fma and one add
+    per term, the int16 result read from the float's low bits) against the integer definitions, for EVERY pair of raw
+    chroma samples in [0, 8191]^2 (67 M pairs, under a second): tests/tools/check_color_fma.c"""
+    exe = tmp_path / "check_color_fma"
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-mfma", "-ffp-contract=off", os.path.join(ROOT, "tests", "tools", "check_color_fma.c"), "-o", str(exe), "-lm"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "fr mismatches 0, fb mismatches 0" in out.stdout and "fg mismatches 0, sensitivity mismatches 0" in out.stdout

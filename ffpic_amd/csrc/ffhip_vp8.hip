@@ -9,9 +9,9 @@
  * token was read or its DC is non-zero (webp.c:1172,1188).
  *
  * HBM-bound byte/integer work: 800 B of levels + 32 B of info in, 768 B of residual out
- * per macroblock (6.25 B/pixel).  32 lanes own one macroblock: lane t < 16 = luma block t,
- * 16..23 = U/V blocks, 24 = the Y2 block; the Y2 lane hands the 16 DC values to the luma
- * lanes of the same wave through LDS (in-order within a wave, no barrier).
+ * per macroblock (6.25 B/pixel).  32 lanes own one macroblock and move its bytes linearly, 16 per lane
+ * and instruction; blocks are assembled inside lane pairs (k_vp8_residual); the Y2 lane hands the 16 DC values
+ * to the luma lanes of the same wave through LDS (in-order within a wave, no barrier).
  */
 #include "ffhip_internal.h"
 
@@ -61,19 +61,55 @@ __device__ __forceinline__ void vp8_idct4x4(u32 p[8])
     }
 }
 
+/* 16 bytes of the even (EVEN_SRC) or odd lane of every lane pair, to both lanes of the pair: DPP quad_perm [0,0,2,2] / [1,1,3,3] */
+template <bool EVEN_SRC>
+__device__ __forceinline__ u32x4 pair_bcast(u32x4 v)
+{
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r[i] = (u32)__builtin_amdgcn_update_dpp(0, (int)v[i], EVEN_SRC ? 0xA0 : 0xF5, 0xf, 0xf, true);
+    return r;
+}
+
+/* 32 lanes own one macroblock.  Memory moves LINEARLY: lane t loads 16-byte chunk t of the macroblock's 800 bytes of
+ * levels and chunk 32 + t (t < 18), and stores chunk t and chunk 32 + t (t < 16) of its 768 bytes of residual, so
+ * every vector memory instruction covers one contiguous run -- with a block (two chunks) per lane straight from
+ * memory, each instruction touched half of every 64-byte segment, which held the kernel at 5.1 TB/s where the same
+ * arithmetic over linear accesses measures 5.7-5.9.  Blocks are then assembled inside lane PAIRS with two DPP
+ * broadcasts: even lane 2b computes luma block b from chunks 2b (its own) and 2b + 1 (its neighbour's); odd lane
+ * 2j + 1 computes block 16 + j (U/V blocks 16-23, the Y2 block 24 on lane 17) from chunks 32 + 2j (its neighbour's
+ * second load) and 32 + 2j + 1 (its own).  The results go back the same way. */
 __global__ __launch_bounds__(256) void k_vp8_residual(Vp8ResArgs a)
 {
     __shared__ __attribute__((aligned(16))) short y2in[8][16];
     __shared__ __attribute__((aligned(16))) int y2t[8][16];
     const int t = threadIdx.x & 31, slot = threadIdx.x >> 5;
     const long long mb = (long long)blockIdx.x * 8 + slot;
-    if (mb >= a.n_mb || t >= 25) return;
-    const uint8_t *info = a.info + mb * 32;
-    const int nz = info[t], nz24 = info[24], has_y2 = info[25] != 0, seg = info[26] & 3;
-    const int qsel = t < 16 ? 0 : (t < 24 ? 4 : 2);
-    const u32 qdc = a.quant[seg * 8 + qsel], qac = a.quant[seg * 8 + qsel + 1];
-    const u32x4 *src = (const u32x4 *)(a.levels + (mb * 25 + t) * 16);
-    const u32x4 l0 = __builtin_nontemporal_load(src), l1 = __builtin_nontemporal_load(src + 1);
+    if (mb >= a.n_mb) return; /* whole 32-lane slots: the lane pairs below are never split */
+    const bool even = (t & 1) == 0;
+    const int blk = even ? t >> 1 : 16 + (t >> 1); /* the block this lane computes; >= 25: none (odd lanes 19..31) */
+    const bool works = blk < 25;
+    const int kb = works ? blk : 0;
+    /* the macroblock's 32 info bytes as two aligned dwords per lane (the one holding nz[blk], and bytes 24-27: nz of the
+     * Y2 block, has_y2, segment) and the quantiser pair as one dword */
+    const u32 *info = (const u32 *)(a.info + mb * 32);
+    const u32 iw = info[kb >> 2], ic = info[6];
+    const int nz = (int)((iw >> (8 * (kb & 3))) & 0xffu), nz24 = (int)(ic & 0xffu), has_y2 = ((ic >> 8) & 0xffu) != 0, seg = (int)((ic >> 16) & 3u);
+    const int qsel = kb < 16 ? 0 : (kb < 24 ? 4 : 2);
+    const u32 qpair = *(const u32 *)(a.quant + seg * 8 + qsel); /* (dc, ac) of this lane's block kind */
+    const u32 qdc = qpair & 0xffffu, qac = qpair >> 16;
+    const u32x4 *src = (const u32x4 *)(a.levels + mb * 400);
+    const u32x4 c1 = __builtin_nontemporal_load(src + t);
+    u32x4 c2 = {0u, 0u, 0u, 0u};
+    if (t < 18) c2 = __builtin_nontemporal_load(src + 32 + t);
+    /* block assembly inside the lane pair */
+    const u32x4 nb_hi = pair_bcast<false>(c1), nb_lo = pair_bcast<true>(c2);
+    u32x4 l0, l1;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        l0[i] = even ? c1[i] : nb_lo[i];
+        l1[i] = even ? nb_hi[i] : c2[i];
+    }
     const u32 lv[8] = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
     u32 pk[8]; /* pk[2r + h] = (c[4r + 2h], c[4r + 2h + 1]) */
 #pragma unroll
@@ -86,32 +122,32 @@ __global__ __launch_bounds__(256) void k_vp8_residual(Vp8ResArgs a)
     }
     /* Y2 -> luma DCs, ACROSS the sixteen luma lanes of the macroblock (webp.c:1067-1106).  Done by the Y2 lane
      * alone the inverse WHT is ~100 instructions that the whole wave pays for one or two working lanes (a third
-     * of this VALU-bound kernel).  Instead lane 24 parks its 16 dequantised coefficients in LDS and luma lane
-     * t = 4r + i computes t[4r + i] of the column pass from column i, parks that, and computes w[4r + i] of the
-     * row pass from row r: each is one of four +- combinations picked by r (then i), and w[t] is exactly the DC
-     * lane t needs.  Writers and readers never sit on two sides of one branch (divergent sides have no defined
+     * of this VALU-bound kernel).  Instead the Y2 lane parks its 16 dequantised coefficients in LDS and the lane of luma
+     * block 4r + i computes t[4r + i] of the column pass from column i, parks that, and computes w[4r + i] of the
+     * row pass from row r: each is one of four +- combinations picked by r (then i), and w[blk] is exactly the DC
+     * that block needs.  Writers and readers never sit on two sides of one branch (divergent sides have no defined
      * order): stores are predicated blocks followed by a wave-level fence; LDS serves a wave in program order. */
-    if (t == 24 && has_y2) {
+    if (blk == 24 && has_y2) {
         *(u32x4 *)&y2in[slot][0] = u32x4{pk[0], pk[1], pk[2], pk[3]};
         *(u32x4 *)&y2in[slot][8] = u32x4{pk[4], pk[5], pk[6], pk[7]};
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (t == 24) return;
-    const int r4 = (t >> 2) & 3, i4 = t & 3;
+    const bool luma = even; /* blk < 16 */
+    const int r4 = (blk >> 2) & 3, i4 = blk & 3;
     int tv = 0;
-    if (t < 16 && has_y2) {
+    if (luma && has_y2) {
         const int v0 = y2in[slot][i4], v1 = y2in[slot][4 + i4], v2 = y2in[slot][8 + i4], v3 = y2in[slot][12 + i4];
         const int a4 = v0 + v3, b4 = v1 + v2, e4 = v1 - v2, f4 = v0 - v3;
         const int p4 = (r4 & 1) ? f4 : a4, q4 = (r4 & 1) ? e4 : b4;
         tv = (r4 & 2) ? p4 - q4 : p4 + q4; /* rows: a+b, f+e, a-b, f-e */
-        y2t[slot][t] = tv;
+        y2t[slot][blk] = tv;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (t < 16 && has_y2) {
+    if (luma && has_y2) {
         const u32x4 row = *(const u32x4 *)&y2t[slot][4 * r4];
         const int t0 = (int)row[0], t1 = (int)row[1], t2 = (int)row[2], t3 = (int)row[3];
         const int a4 = t0 + t3, b4 = t1 + t2, e4 = t1 - t2, f4 = t0 - t3;
@@ -120,11 +156,20 @@ __global__ __launch_bounds__(256) void k_vp8_residual(Vp8ResArgs a)
         const int fast = (short)((y2in[slot][0] + 3) >> 3); /* IWHT_fast, webp.c:1098-1106 */
         pk[0] = __builtin_amdgcn_perm(pk[0], (u32)(nz24 > 1 ? full : fast), 0x07060100u);
     }
-    if (nz > 1 || (pk[0] & 0xffffu) != 0) vp8_idct4x4(pk);
+    if (works && blk != 24 && (nz > 1 || (pk[0] & 0xffffu) != 0)) vp8_idct4x4(pk);
+    /* back to chunks: chunk t = even ? my lower half : my even neighbour's upper half; chunk 32 + t (t < 16) = even ? my odd
+     * neighbour's lower half : my upper half */
     const u32x4 o0 = {pk[0], pk[1], pk[2], pk[3]}, o1 = {pk[4], pk[5], pk[6], pk[7]};
-    u32x4 *dst = (u32x4 *)(a.out + (mb * 24 + t) * 16);
-    __builtin_nontemporal_store(o0, dst);
-    __builtin_nontemporal_store(o1, dst + 1);
+    const u32x4 ev_hi = pair_bcast<true>(o1), od_lo = pair_bcast<false>(o0);
+    u32x4 s1, s2;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        s1[i] = even ? o0[i] : ev_hi[i];
+        s2[i] = even ? od_lo[i] : o1[i];
+    }
+    u32x4 *dst = (u32x4 *)(a.out + mb * 384);
+    __builtin_nontemporal_store(s1, dst + t);
+    if (t < 16) __builtin_nontemporal_store(s2, dst + 32 + t);
 }
 
 extern "C" int ffhip_vp8_residual_batch(long long n_mb, const int16_t *d_levels, const uint8_t *d_mbinfo,
@@ -133,7 +178,8 @@ extern "C" int ffhip_vp8_residual_batch(long long n_mb, const int16_t *d_levels,
     if (n_mb < 0) return FFHIP_EINVAL;
     if (n_mb == 0) return FFHIP_OK;
     if (!d_levels || !d_mbinfo || !d_quant || !d_residual) return FFHIP_EINVAL;
-    if (((uintptr_t)d_levels & 15) || ((uintptr_t)d_residual & 15) || n_mb > 0x7fffffffLL * 8) return FFHIP_EINVAL;
+    if (((uintptr_t)d_levels & 15) || ((uintptr_t)d_residual & 15) || ((uintptr_t)d_mbinfo & 3) || ((uintptr_t)d_quant & 3) || n_mb > 0x7fffffffLL * 8)
+        return FFHIP_EINVAL;
     if (!ffhip_have_device()) return FFHIP_ENODEV;
     Vp8ResArgs a = {d_levels, d_mbinfo, d_quant, d_residual, n_mb};
     hipLaunchKernelGGL(k_vp8_residual, dim3((unsigned)((n_mb + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a);

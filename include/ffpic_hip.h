@@ -229,7 +229,8 @@ int ffhip_heif_grid_compose(uint8_t *d_canvas, int64_t canvas_pitch, int out_w, 
  *              [26] segment id (0..3)
  *   d_quant    uint16 [4][8]         per segment y1_dc,y1_ac,y2_dc,y2_ac,uv_dc,uv_ac,0,0
  *              (struct WEBP_decoder, format/webp.h:276-287)
- *   d_residual int16 [n_mb][384]     the `coeffs` array vp8_prerdict_mb consumes */
+ *   d_residual int16 [n_mb][384]     the `coeffs` array vp8_prerdict_mb consumes
+ * d_levels and d_residual 16-byte aligned, d_mbinfo and d_quant 4-byte aligned. */
 int ffhip_vp8_residual_batch(long long n_mb, const int16_t *d_levels, const uint8_t *d_mbinfo,
                              const uint16_t *d_quant, int16_t *d_residual, void *stream);
 

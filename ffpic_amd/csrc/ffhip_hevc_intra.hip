@@ -54,6 +54,10 @@ struct HevcIntraArgs {
     int *async_err;           /* pinned host word (ffhip_async_err_word)                          */
     int n_groups;
     int debug_withhold;       /* test hook (FFHIP_DEBUG_WITHHOLD_TU): this TU's done flag is never published; -1 = off */
+    /* device-planned launches: the planner's verdict is read by the kernel, not by the host */
+    const uint32_t *plan_result; /* {refused, number of groups, wait entries}; NULL: n_groups above is the truth */
+    uint32_t wait_cap;           /* wait entries the planner had room for                                        */
+    long long n_tus;             /* for the serial path a refused plan takes                                     */
 };
 
 __device__ __forceinline__ void wave_sync()
@@ -300,7 +304,8 @@ __device__ __forceinline__ void intra_tu(const HevcIntraArgs &a, const ffhip_hev
     int angle = 0;
     if (mode == 1) {
         unsigned sum = 0;
-        for (int i = 0; i < n; i++) sum += (unsigned)U16(LEFT(i)) + (unsigned)U16(TOP(i));
+        for (int i = 0; i < n; i++) sum += (unsigned)U16(LEFT(i)) + (unsigned)U16(TOP(i)); /* independent LDS reads: they pipeline (a wave
+                                                                                              butterfly of dependent bpermutes measured slower) */
         dc = (int)((sum + (1u << lg)) >> (lg + 1));
     } else if (mode >= 2) {
         angle = intra_angle(mode);
@@ -439,11 +444,43 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
     __shared__ u32x4 slots[SLOT_CHUNK * 3];
     const int lane = threadIdx.x;
     uint32_t *flags = a.ctrl + 4;
+    int n_groups = a.n_groups;
+    if (a.plan_result) {
+        /* the schedule was built by the kernels in front of this one on the same stream; nobody on the host has looked
+         * at it.  A list the device planner refuses (groups that are not contiguous runs of the decode order for this
+         * window, more than 64 TUs to wait for, an order its ticket rule cannot serve) is still decoded, correctly and
+         * slowly: ONE wave walks it in decode order, which is always a valid order, every neighbour through memory. */
+        const uint32_t refused = a.plan_result[0] | (a.plan_result[2] > a.wait_cap ? 1u : 0u);
+        n_groups = (int)a.plan_result[1];
+        if (__builtin_amdgcn_readfirstlane((int)refused)) {
+            if (blockIdx.x != 0) return;
+            for (long long base = 0; base < a.n_tus; base += SLOT_CHUNK) {
+                const int m = (int)(a.n_tus - base < SLOT_CHUNK ? a.n_tus - base : SLOT_CHUNK);
+                for (int i = lane; i < 3 * m; i += 64) {
+                    const int k = i / 3, part = i - 3 * k;
+                    u32x4 q = {0u, 0u, (uint32_t)(base + k), 0u}; /* no waits, no flag, no tile */
+                    if (part < 2) q = ((const u32x4 *)(a.tus + base + k))[part];
+                    slots[i] = q;
+                }
+                wave_sync();
+                for (int k = 0; k < m; k++) {
+                    const IntraSlot cur = read_slot(slots, k);
+                    ResPrefetch rp;
+                    fetch_residual(a, cur.t, lane, rp);
+                    intra_tu_any<true>(a, cur.t, lane, nbA, nbB, refs, resl[k & 1], rp, tile, 6, false);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the next TU may read these samples back from memory */
+                    wave_sync();
+                }
+                wave_sync();
+            }
+            return;
+        }
+    }
     for (;;) {
         unsigned ticket = 0;
         if (lane == 0) ticket = __hip_atomic_fetch_add(&a.ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
-        if (ticket >= (unsigned)a.n_groups) return;
+        if (ticket >= (unsigned)n_groups) return;
         const u32x4 g = a.groups[ticket];
         const int wl = (int)g.z;
         for (unsigned base = 0; base < g.y; base += SLOT_CHUNK) {
@@ -513,7 +550,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
 extern "C" size_t ffhip_hevc_plan_gpu_words(long long n_tus, const int pw[3], const int ph[3], const int wl[3]);
 extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, const int pw[3], const int ph[3], const int wl[3],
                                    uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
-                                   int *n_groups);
+                                   int *n_groups, const uint32_t **d_result, uint32_t *wait_cap_out);
 
 struct GroupPlan {
     std::vector<u32x4> sched;  /* 3 per slot */
@@ -710,6 +747,32 @@ static bool plan_groups(const ffhip_hevc_tu *tus, long long n_tus, const int pw[
     return true;
 }
 
+/* Are the groups of this window -- the TUs whose top-left corner falls into one window tile of one plane -- contiguous
+ * runs of the list?  (Then a group is complete before a later one starts, the condition of the grouped kernel.)  One
+ * byte map per plane, one pass; scratch kept per thread. */
+static bool groups_contiguous(const ffhip_hevc_tu *tus, long long n_tus, const int pw[3], const int ph[3], const int win_log2[3])
+{
+    static thread_local std::vector<uint8_t> seen[3];
+    int gw[3];
+    for (int c = 0; c < 3; c++) {
+        gw[c] = pw[c] > 0 ? ((pw[c] - 1) >> win_log2[c]) + 1 : 0;
+        seen[c].assign((size_t)gw[c] * (size_t)(ph[c] > 0 ? ((ph[c] - 1) >> win_log2[c]) + 1 : 0), 0);
+    }
+    long long last = -1;
+    int last_c = -1;
+    for (long long i = 0; i < n_tus; i++) {
+        const ffhip_hevc_tu &t = tus[i];
+        const int c = t.cidx;
+        const long long w = (long long)(t.y >> win_log2[c]) * gw[c] + (t.x >> win_log2[c]);
+        if (w == last && c == last_c) continue;
+        if (seen[c][(size_t)w]) return false;
+        seen[c][(size_t)w] = 1;
+        last = w;
+        last_c = c;
+    }
+    return true;
+}
+
 /* the window search both entry points share: the requested (or default) luma window, halved until a
  * plan exists; chroma windows cover the same picture area */
 static bool plan_with_window_search(const ffhip_hevc_tu *tus, long long n_tus, const int pw[3], const int ph[3], int wl,
@@ -828,27 +891,35 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
         /* the schedule: built on the device (ffhip_hevc_plan_gpu.hip) unless FFHIP_HEVC_PLAN=host; lists whose groups are
          * not contiguous runs of the decode order come back from there and take the host planner with its window search */
         const char *pe = getenv("FFHIP_HEVC_PLAN");
-        if (!(pe && !strcmp(pe, "host")) && n_tus >= 64) {
+        if (!(pe && !strcmp(pe, "host"))) {
+            /* NOTHING below waits for the device: the schedule is enqueued, the grouped kernel is enqueued behind it and
+             * reads the planner's verdict itself (a refused list takes its serial path).  The window is chosen here, on
+             * the host, from the list alone: the largest one (up to the requested) whose groups are contiguous runs of
+             * the decode order -- a 16x16 coding tree block stream needs 16, and finding that out on the device would
+             * cost a round trip. */
             int wl = we ? atoi(we) : FFHIP_HEVC_INTRA_WINDOW_LOG2;
             wl = wl < 3 ? 3 : (wl > 6 ? 6 : wl);
             const int cs = (pw[1] > 0 && pw[1] * 2 <= pw[0] + 1) ? 1 : 0;
+            for (; wl > 3; wl--) {
+                const int win[3] = {wl, wl - cs, wl - cs};
+                if (groups_contiguous(h_tus, n_tus, pw, ph, win)) break;
+            }
             const int win[3] = {wl, wl - cs, wl - cs};
             const int pwc[3] = {pw[0], (d_cb && d_cr) ? pw[1] : 0, (d_cb && d_cr) ? pw[2] : 0};
             const size_t w_plan = ffhip_hevc_plan_gpu_words(n_tus, pwc, ph, win), w_ctrl = 4 + (size_t)n_tus;
             uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, w_plan + w_ctrl + 16);
             if (!g_work) return FFHIP_ENOMEM;
             int n_groups = 0;
-            const int prc = ffhip_hevc_plan_gpu(d_tus, n_tus, pwc, ph, win, g_work, st, &a.sched, &a.groups, &a.wait_idx, &n_groups);
+            const int prc = ffhip_hevc_plan_gpu(d_tus, n_tus, pwc, ph, win, g_work, st, &a.sched, &a.groups, &a.wait_idx, &n_groups, &a.plan_result, &a.wait_cap);
             if (prc < 0) return prc;
-            if (prc == 0) {
-                a.ctrl = g_work + ((w_plan + 3) & ~(size_t)3);
-                FFHIP_CHECK(hipMemsetAsync(a.ctrl, 0, w_ctrl * 4, st), FFHIP_EIO);
-                a.async_err = async_err;
-                a.n_groups = n_groups;
-                hipLaunchKernelGGL(k_hevc_intra_groups, dim3((unsigned)std::min<size_t>((size_t)n_groups, max_waves)), dim3(64), 0, st, a);
-                FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
-                return FFHIP_OK;
-            }
+            a.ctrl = g_work + ((w_plan + 3) & ~(size_t)3);
+            FFHIP_CHECK(hipMemsetAsync(a.ctrl, 0, w_ctrl * 4, st), FFHIP_EIO);
+            a.async_err = async_err;
+            a.n_groups = 0;
+            a.n_tus = n_tus;
+            hipLaunchKernelGGL(k_hevc_intra_groups, dim3((unsigned)std::min<size_t>((size_t)n_tus, max_waves)), dim3(64), 0, st, a);
+            FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
+            return FFHIP_OK;
         }
         GroupPlan plan;
         if (plan_with_window_search(h_tus, n_tus, pw, ph, we ? atoi(we) : FFHIP_HEVC_INTRA_WINDOW_LOG2, plan, nullptr)) {

@@ -282,10 +282,13 @@ extern "C" size_t ffhip_hevc_plan_gpu_words(long long n_tus, const int pw[3], co
     return 12 * n + 4 * (n + 1) + 8 * n + blocks + wins + 6 * n + (n + 3) / 4 + 4 + (n + 2) + 16 + (scan_tmp + 3) / 4 + 128 + 3 * cells + 3 * n + 4 * n + 8;
 }
 
-/* Returns 0 when the plan is in place (n_groups, n_wait filled), 1 when the list needs the host planner. */
+/* Returns 0 when the plan is in place (n_groups, n_wait filled), 1 when the list needs the host planner.
+ * With d_result != NULL nothing is waited for: the plan is only ENQUEUED, *d_result points at the device words
+ * {refused, number of groups, wait entries} the grouped kernel reads for itself (with *wait_cap, the reservation the
+ * wait entries must fit), *n_groups is left alone and the return value is 0. */
 extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, const int pw[3], const int ph[3], const int wl[3],
                                    uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
-                                   int *n_groups)
+                                   int *n_groups, const uint32_t **d_result, uint32_t *wait_cap_out)
 {
     PlanArgs a;
     const size_t n = (size_t)n_tus;
@@ -361,6 +364,14 @@ extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, 
     hipLaunchKernelGGL(k_plan_rank, dim3(grid), dim3(256), 0, st, a, (const uint32_t *)vals_out);
     hipLaunchKernelGGL(k_plan_emit, dim3(grid), dim3(256), 0, st, a);
     FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
+    if (d_result) {
+        *sched = a.sched;
+        *groups = a.groups;
+        *wait_idx = a.wait_idx;
+        *d_result = a.result;
+        if (wait_cap_out) *wait_cap_out = (uint32_t)wait_cap;
+        return 0;
+    }
     uint32_t res[3] = {1, 0, 0};
     FFHIP_CHECK(hipMemcpyAsync(res, a.result, sizeof res, hipMemcpyDeviceToHost, st), FFHIP_EIO);
     FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO);

@@ -347,12 +347,13 @@ typedef struct ffhip_hevc_tu {
                                   block itself, so r += (res_scale * ((r << BitDepthC) >> BitDepthY)) >> 3 */
 /* h_tus / d_tus: the SAME n_tus records on the host (dependency scheduling) and on the device.
  * d_residual: int16 residual blocks (row-major n*n each) as ffhip_hevc_residual_batch writes
- * them.  Planes: int16, strides in samples; d_cb/d_cr may be NULL for 4:0:0.  Builds the schedule
- * on the device (synchronising `stream` once to learn whether the list qualifies; h_tus is only
- * validated), then enqueues ONE launch: TUs grouped by 32x32 window, a wave per group, done flags
- * between groups; a bounded wait that ever
- * runs out surfaces as FFHIP_EIO from the next ffhip_stream_sync.  FFHIP_HEVC_INTRA_MODE=levels
- * selects the older one-launch-per-dependency-level form.  Scratch is kept per stream, as for VP8. */
+ * them.  Planes: int16, strides in samples; d_cb/d_cr may be NULL for 4:0:0.  ONLY ENQUEUES: h_tus is validated on
+ * the host (and the scheduling window chosen from it), the schedule is built on the device and ONE launch follows --
+ * TUs grouped by 32x32 window, a wave per group, done flags between groups -- which reads the
+ * planner's verdict itself: a list it refuses is decoded by one wave in decode order inside the same launch (slow,
+ * exact).  A bounded wait that ever runs out surfaces as FFHIP_EIO from the next ffhip_stream_sync.
+ * FFHIP_HEVC_INTRA_MODE=levels selects the older one-launch-per-dependency-level form and FFHIP_HEVC_PLAN=host the
+ * host-side planner (both synchronise the stream).  Scratch is kept per stream, as for VP8. */
 /* Host only, no device needed: the group schedule ffhip_hevc_intra_recon builds for an already valid
  * list -- out_ticket[i] = ticket of the group of TU i, out_wait[i] = TUs of other groups it waits for
  * (either may be NULL), stats[4] = {groups, luma window log2 used, wait entries, TUs served from the

@@ -179,3 +179,31 @@ def test_residual_blocks_at_odd_offsets(shift):
     got = ops.hevc_intra_recon(moved, res2, w, h, True, 8, 8)
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
+
+
+def test_list_the_device_planner_refuses_takes_the_serial_path():
+    """4x4 TUs of a whole picture in RASTER order (not coding-tree order): every scheduling window is entered many times,
+    so no window gives contiguous groups, the device planner refuses the list and the grouped kernel decodes it with one
+    wave in list order -- inside the same launch, nobody on the host having looked at the verdict."""
+    rng = np.random.default_rng(12)
+    w, h = 96, 48
+    recs, parts, off = [], [], 0
+    done = np.zeros((h, w), bool)
+    for y0 in range(0, h, 4):
+        for x0 in range(0, w, 4):
+            at = al = 0
+            for k in range(8):
+                if y0 > 0 and x0 + k < w and done[y0 - 1, x0 + k]:
+                    at |= 1 << k
+                if x0 > 0 and y0 + k < h and done[y0 + k, x0 - 1]:
+                    al |= 1 << k
+            fl = synth.TU_RESIDUAL | synth.TU_FILTER | (synth.TU_CORNER if x0 > 0 and y0 > 0 else 0)
+            recs.append((x0, y0, 2, 0, int(rng.integers(0, 35)), fl, off, 0, at, al))
+            parts.append(np.rint(rng.laplace(0, 12, size=16)).astype(np.int16))
+            off += 16
+            done[y0:y0 + 4, x0:x0 + 4] = True
+    tus = np.array(recs, dtype=synth.HEVC_TU_DTYPE)
+    res = np.concatenate(parts)
+    got = ops.hevc_intra_recon(tus, res, w, h, False)[0]
+    exp = O.oracle_hevc_intra(tus, res, w, h, False)[0]
+    assert np.array_equal(got, exp)

@@ -50,13 +50,11 @@ for n in (4, 8, 16, 32):
         py = torch.zeros((64, 64), dtype=torch.int16, device=dev)
         def run():
             capi.check(L.ffhip_hevc_intra_recon(tus.ctypes.data, dt.data_ptr(), len(tus), dr.data_ptr(), py.data_ptr(), None, None, 64, 64, 64, 0, 0, 0, 8, 8, st))
-        run(); capi.check(L.ffhip_stream_sync(st))
-        best = 1e9
-        for _ in range(3):
-            # the call synchronises and uploads first, so events around it would include host work: time the kernel by sync deltas
-            run()
-            L.ffhip_event_record(e0, st)  # after the launch: marks the kernel end on the stream
-            capi.check(L.ffhip_stream_sync(st))
-        # use rocprof for exact kernel times; here: wall of call + sync as an upper bound
-        t0 = time.perf_counter(); run(); capi.check(L.ffhip_stream_sync(st)); wall = (time.perf_counter() - t0) * 1e6
-        print(f"n={n:2d} {name:14s} tus={len(tus):4d} wall {wall:8.1f} us  -> {wall / len(tus):6.2f} us/TU (incl. ~host)")
+        for _ in range(3): run()
+        capi.check(L.ffhip_stream_sync(st))
+        L.ffhip_event_record(e0, st)
+        for _ in range(20): run()                     # the call only enqueues: planner kernels + the grouped kernel, back to back
+        L.ffhip_event_record(e1, st)
+        capi.check(L.ffhip_stream_sync(st))
+        us = L.ffhip_event_elapsed_ms(e0, e1) / 20 * 1e3
+        print(f"n={n:2d} {name:14s} tus={len(tus):4d} {us:8.1f} us per call (planner + kernel) -> {us / len(tus):6.2f} us/TU")

@@ -328,7 +328,7 @@ __device__ __forceinline__ void intra_tu(const HevcIntraArgs &a, const ffhip_hev
         wave_sync();
     }
     const bool edge_ok = cidx == 0 && n < 32;
-    constexpr int pred_unroll = n * n <= 256 ? LANE_PASSES(n * n) : 1;
+    constexpr int pred_unroll = n * n <= 256 ? LANE_PASSES(n * n) : 4; /* 32x32: four of the sixteen passes in flight, so that their LDS reads overlap */
 #pragma unroll pred_unroll
     for (int p = lane; p < n * n; p += 64) {
         const int x = p & (n - 1), y = p >> lg;
@@ -897,7 +897,13 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
              * the host, from the list alone: the largest one (up to the requested) whose groups are contiguous runs of
              * the decode order -- a 16x16 coding tree block stream needs 16, and finding that out on the device would
              * cost a round trip. */
-            int wl = we ? atoi(we) : FFHIP_HEVC_INTRA_WINDOW_LOG2;
+            /* default window: 32x32 for lists of small TUs, 64x64 when the TUs are large -- a group start costs a chain of
+             * dependent loads (ticket, group record, slots, wait list, flags, neighbours: ~3 us) that a 32x32 TU or four
+             * 16x16 ones do not amortise: SURVEY 8d's config-5 mix at 8K takes 12.5 ms with 32, 8.5 ms with 64; the random
+             * quadtree down to 4x4 is 22 ms either way at 8K and 10 % faster with 32 at 1080p (tests/tools/bench_intra_c5.py) */
+            const long long luma_area = (long long)pw[0] * ph[0];
+            const bool large_tus = n_tus * 4096 < 48 * luma_area; /* fewer than 48 TUs (all planes) per 64x64 luma area */
+            int wl = we ? atoi(we) : (large_tus ? 6 : FFHIP_HEVC_INTRA_WINDOW_LOG2);
             wl = wl < 3 ? 3 : (wl > 6 ? 6 : wl);
             const int cs = (pw[1] > 0 && pw[1] * 2 <= pw[0] + 1) ? 1 : 0;
             for (; wl > 3; wl--) {

@@ -366,7 +366,7 @@ def test_oracle_batch_threads_and_errors():
 
 
 FILES = {"q85_420": "file_q85_420.jpg", "q92_444": "file_q92_444.jpg", "q80_grey": "file_q80_grey.jpg",
-         "q85_420_dri": "file_q85_420_dri.jpg"}
+         "q85_420_dri": "file_q85_420_dri.jpg", "q88_422": "file_q88_422.jpg"}
 
 
 def decode_fixture(tag):

@@ -58,7 +58,21 @@ struct HevcIntraArgs {
     const uint32_t *plan_result; /* {refused, number of groups, wait entries}; NULL: n_groups above is the truth */
     uint32_t wait_cap;           /* wait entries the planner had room for                                        */
     long long n_tus;             /* for the serial path a refused plan takes                                     */
+    /* substitution table (k_hevc_intra_jtable): per TU and scan position the scan position its sample comes from */
+    const uint8_t *jt;
+    int jt_bw[3];                /* 4x4 blocks per row of each plane */
+    uint32_t jt_boff[3];         /* first block of each plane        */
+#ifdef FFHIP_INTRA_TRACE
+    unsigned long long *trace;   /* diagnostics build only (make trace): 8 words per TU, then one per ticket */
+#endif
 };
+#define JT_STRIDE 20 /* table bytes per 4x4 block: a TU of size n owns n/4 consecutive blocks of its first block row, 5n >= 4n + 1 bytes */
+#ifdef FFHIP_INTRA_TRACE
+static unsigned long long *g_intra_trace = nullptr;
+extern "C" void ffhip_debug_intra_trace(void *d_buf) { g_intra_trace = (unsigned long long *)d_buf; }
+#define TRACE_NOW() ((unsigned long long)wall_clock64())
+__shared__ unsigned long long g_stamp[4];
+#endif
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -369,6 +383,260 @@ __device__ __forceinline__ void intra_tu(const HevcIntraArgs &a, const ffhip_hev
 #undef U16
 }
 
+/* ---- the grouped form's TU body -------------------------------------------------------------------------------
+ * Same arithmetic as intra_tu above, with everything that does not depend on SAMPLES taken off the wave's
+ * instruction stream -- a lone wave pays ~6-9 cycles per instruction, and the critical path of a picture is ~10 000
+ * TUs walked one after the other (tests/tools/diag_intra_trace.py):
+ *   - which sample a scan position takes (availability masks, substitution) comes from a table a parallel kernel
+ *     wrote beforehand (k_hevc_intra_jtable), fetched one TU ahead like the residual;
+ *   - the angular predictor reads the scan-order array directly: ref[k] of 8.4.4.2.6 is s[2n + k] (k >= 0) or
+ *     s[2n - ((k * invAngle + 128) >> 8)] (k < 0) for the vertical modes and the mirror image for the horizontal
+ *     ones, so no ref[] array is built (that was an LDS write, a barrier and a dependent read per TU). */
+struct IntraSlot {
+    unsigned x, y, lg, cidx, mode, flags, res_offset;
+    int res_scale;
+    unsigned wait_begin, wait_count, signal, tile_ok, tu_index, jt_off;
+};
+struct JPrefetch {
+    unsigned j[3];
+};
+__device__ __forceinline__ void fetch_jtable(const HevcIntraArgs &a, const IntraSlot &t, const int lane, JPrefetch &jp)
+{
+    const uint8_t *p = a.jt + t.jt_off + lane; /* the table is padded: reading past a small TU's entries is harmless */
+    jp.j[0] = p[0];
+    if (t.lg >= 4) {
+        jp.j[1] = p[64];
+        jp.j[2] = p[128];
+    }
+}
+__device__ __forceinline__ void fetch_residual_g(const HevcIntraArgs &a, const IntraSlot &t, const int lane, ResPrefetch &rp)
+{
+    rp.wide = false;
+    if (!(t.flags & 2)) return;
+    const int nn = 1 << (2 * t.lg);
+    const int16_t *src = a.residual + t.res_offset;
+    if (((uintptr_t)src & 15) != 0) return;
+    rp.wide = true;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+        if (8 * lane + 512 * j < nn) rp.v[j] = *(const u32x4 *)(src + 8 * lane + 512 * j);
+}
+
+template <int LG>
+__device__ __forceinline__ void intra_tu_g(const HevcIntraArgs &a, const IntraSlot &t, const int lane, int *s, int *s2, short *R,
+                                           const ResPrefetch &rp, const JPrefetch &jp, short *tile, const int wl)
+{
+    constexpr int n = 1 << LG, lg = LG, cnt = 4 * n + 1;
+    const int x0 = (int)t.x, y0 = (int)t.y;
+    const int wx0 = (x0 >> wl) << wl, wy0 = (y0 >> wl) << wl, wsz = 1 << wl;
+    const int cidx = (int)t.cidx, mode = (int)t.mode, flags = (int)t.flags;
+    const bool tile_ok = t.tile_ok != 0;
+    const int bd = cidx == 0 ? a.bitdepth_y : a.bitdepth_c;
+    int16_t *plane = cidx == 0 ? a.plane[0] : (cidx == 1 ? a.plane[1] : a.plane[2]);
+    const int stride = cidx == 0 ? a.stride[0] : (cidx == 1 ? a.stride[1] : a.stride[2]);
+    const __amdgpu_buffer_rsrc_t prs = ffhip_rsrc(plane, 0xffffffffu);
+#ifdef FFHIP_INTRA_TRACE
+#define STAMP(k) do { if (lane == 0) g_stamp[k] = TRACE_NOW(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+    /* ---- 1 + 2. gather with the substitution folded in ---- */
+#pragma unroll
+    for (int pass = 0; pass < LANE_PASSES(cnt); pass++) {
+        const int i = lane + 64 * pass;
+        if (i >= cnt) break;
+        const int j = (int)jp.j[pass];
+        int px = x0 - 1, py = y0 - 1; /* the corner, j == 2n */
+        if (j < 2 * n) py = y0 + (2 * n - 1 - j);
+        else if (j > 2 * n) px = x0 + (j - 2 * n - 1);
+        int v = 1 << (bd - 1);
+        if (j != 255) { /* 255: nothing available around this TU (wave-uniform) */
+            const unsigned tx = (unsigned)(px - wx0), ty = (unsigned)(py - wy0);
+            if (tile_ok && tx < (unsigned)wsz && ty < (unsigned)wsz) v = (int)tile[ty * TILE_STRIDE + tx];
+            else v = ffhip_load_s16_sc1(prs, (py * stride + px) * 2);
+        }
+        s[i] = v;
+    }
+    wave_sync();
+    STAMP(0);
+#define LEFT(y) s[2 * n - 1 - (y)]
+#define TOP(x) s[2 * n + 1 + (x)] /* TOP(-1) is the corner */
+
+    /* ---- 3. neighbour smoothing (8.4.4.2.3) ---- */
+    if ((flags & 4) && mode != 1 && n != 4) {
+        const int d26 = iabs(mode - 26), d10 = iabs(mode - 10);
+        const int thr = n == 8 ? 7 : (n == 16 ? 1 : 0);
+        if ((d26 < d10 ? d26 : d10) > thr) {
+            const bool bi = (flags & 8) && cidx == 0 && n == 32 &&
+                            iabs(TOP(-1) + TOP(2 * n - 1) - 2 * TOP(n - 1)) < (1 << (a.bitdepth_y - 5)) &&
+                            iabs(TOP(-1) + LEFT(2 * n - 1) - 2 * LEFT(n - 1)) < (1 << (a.bitdepth_y - 5));
+            const int corner = TOP(-1), l63 = bi ? LEFT(63) : 0, t63 = bi ? TOP(63) : 0;
+#pragma unroll
+            for (int pass = 0; pass < LANE_PASSES(cnt); pass++) {
+                const int i = lane + 64 * pass;
+                if (i >= cnt) break;
+                int v;
+                if (bi) {
+                    if (i < 2 * n) { const int y = 2 * n - 1 - i; v = y == 63 ? l63 : (corner * (63 - y) + (y + 1) * l63 + 32) >> 6; }
+                    else if (i == 2 * n) v = corner;
+                    else { const int x = i - 2 * n - 1; v = x == 63 ? t63 : (corner * (63 - x) + (x + 1) * t63 + 32) >> 6; }
+                    v = (int)(short)v;
+                } else {
+                    v = (i == 0 || i == cnt - 1) ? s[i] : (int)(short)((s[i - 1] + 2 * s[i] + s[i + 1] + 2) >> 2);
+                }
+                s2[i] = v;
+            }
+            wave_sync();
+            int *tmp = s; s = s2; s2 = tmp;
+        }
+    }
+    STAMP(1);
+
+    /* ---- residual (with the optional rdpcm accumulation of 8.6.5) ---- */
+    const bool has_res = (flags & 2) != 0;
+    if (has_res) {
+        if (rp.wide) {
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                if (512 * j < n * n && 8 * lane + 512 * j < n * n) *(u32x4 *)(R + 8 * lane + 512 * j) = rp.v[j];
+        } else {
+            const int16_t *src = a.residual + t.res_offset;
+            for (int i = lane; i < n * n; i += 64) R[i] = src[i];
+        }
+        wave_sync();
+        if (flags & 0x40) {
+            rdpcm_accumulate<LG>(R, lane, mode);
+            wave_sync();
+        }
+        if (flags & 0x80) {
+            const int bdc = a.bitdepth_c, bdy = a.bitdepth_y;
+#pragma unroll 4
+            for (int i = lane; i < n * n; i += 64) {
+                const int up = (int)((unsigned)(int)R[i] << bdc) >> bdy;
+                R[i] = (short)(R[i] + ((int)((unsigned)t.res_scale * (unsigned)up) >> 3));
+            }
+            wave_sync();
+        }
+    }
+
+    STAMP(2);
+    /* ---- 4. prediction (the reference reads the neighbours as uint16_t) ---- */
+#define U16(v) ((int)((unsigned)(v) & 0xffffu))
+    int dc = 0, angle = 0, inv = 0;
+    if (mode == 1) {
+        unsigned sum = 0;
+        for (int i = 0; i < n; i++) sum += (unsigned)U16(LEFT(i)) + (unsigned)U16(TOP(i));
+        dc = (int)((sum + (1u << lg)) >> (lg + 1));
+    } else if (mode >= 2) {
+        angle = intra_angle(mode);
+        if (angle < 0) inv = intra_inv_angle(mode);
+    }
+    const int sg = mode >= 18 ? 1 : -1; /* top row is the main reference: scan positions grow with the ref index */
+    const bool edge_ok = cidx == 0 && n < 32;
+    constexpr int pred_unroll = n * n <= 256 ? LANE_PASSES(n * n) : 4;
+#pragma unroll pred_unroll
+    for (int p = lane; p < n * n; p += 64) {
+        const int x = p & (n - 1), y = p >> lg;
+        int v;
+        if (mode == 0) {
+            v = ((n - 1 - x) * U16(LEFT(y)) + (x + 1) * U16(TOP(n)) + (n - 1 - y) * U16(TOP(x)) + (y + 1) * U16(LEFT(n)) + n) >> (lg + 1);
+        } else if (mode == 1) {
+            v = dc;
+            if (edge_ok && !(flags & 0x20)) {
+                if (x == 0 && y == 0) v = (U16(LEFT(0)) + 2 * dc + U16(TOP(0)) + 2) >> 2;
+                else if (y == 0) v = (U16(TOP(x)) + 3 * dc + 2) >> 2;
+                else if (x == 0) v = (U16(LEFT(y)) + 3 * dc + 2) >> 2;
+            }
+        } else {
+            const int al = mode >= 18 ? y : x, ac = mode >= 18 ? x : y; /* along / across the direction */
+            const int prod = (al + 1) * angle, idx = prod >> 5, fact = prod & 31;
+            const int k0 = ac + idx + 1, k1 = k0 + 1;
+            const int q0 = k0 >= 0 ? k0 : -((k0 * inv + 128) >> 8), q1 = k1 >= 0 ? k1 : -((k1 * inv + 128) >> 8);
+            /* fact == 0: the second tap has weight 0 (it may lie one past the array: any finite value does) */
+            v = ((32 - fact) * U16(s[2 * n + sg * q0]) + fact * U16(s[2 * n + sg * q1]) + 16) >> 5;
+            if (edge_ok && !(flags & 0x10)) {
+                if (mode == 26 && x == 0) v = clip3i(0, (1 << a.bitdepth_y) - 1, U16(TOP(0)) + ((U16(LEFT(y)) - U16(TOP(-1))) >> 1));
+                if (mode == 10 && y == 0) v = clip3i(0, (1 << a.bitdepth_y) - 1, U16(LEFT(0)) + ((U16(TOP(x)) - U16(TOP(-1))) >> 1));
+            }
+        }
+        /* ---- 5. reconstruct: pred is stored as int16 by the reference before the add ---- */
+        const int pr = (int)(short)(v & 0xffff);
+        const int rs = has_res ? (int)R[p] : 0;
+        int16_t *dp = plane + (long long)(y0 + y) * stride + x0 + x;
+        const short rec = (short)clip3i(0, (1 << bd) - 1, pr + rs);
+        __hip_atomic_store(dp, rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned tx = (unsigned)(x0 + x - wx0), ty = (unsigned)(y0 + y - wy0);
+        if (tx < (unsigned)wsz && ty < (unsigned)wsz) tile[ty * TILE_STRIDE + tx] = rec;
+    }
+    STAMP(3);
+#undef LEFT
+#undef TOP
+#undef U16
+}
+
+__device__ __forceinline__ void intra_tu_g_any(const HevcIntraArgs &a, const IntraSlot &t, const int lane, int *s, int *s2, short *R,
+                                               const ResPrefetch &rp, const JPrefetch &jp, short *tile, const int wl)
+{
+    switch (t.lg) {
+    case 2: intra_tu_g<2>(a, t, lane, s, s2, R, rp, jp, tile, wl); break;
+    case 3: intra_tu_g<3>(a, t, lane, s, s2, R, rp, jp, tile, wl); break;
+    case 4: intra_tu_g<4>(a, t, lane, s, s2, R, rp, jp, tile, wl); break;
+    default: intra_tu_g<5>(a, t, lane, s, s2, R, rp, jp, tile, wl); break;
+    }
+}
+
+/* The substitution table: for every TU and every scan position i (left column bottom-up, corner, top row) the scan
+ * position j whose sample position i takes -- "the nearest available one at or before me, else the first available
+ * one" (8.4.4.2.2 in scan order) -- or 255 when nothing around the TU is available.  A pure function of the TU record:
+ * one wave per TU, fully parallel, in front of the dependency-bound kernel. */
+struct JTabArgs {
+    const ffhip_hevc_tu *tus;
+    uint32_t n;
+    uint8_t *jt;
+    int bw[3];
+    uint32_t boff[3];
+};
+__global__ __launch_bounds__(256) void k_hevc_intra_jtable(JTabArgs a)
+{
+    const uint32_t i_tu = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i_tu >= a.n) return;
+    const ffhip_hevc_tu t = a.tus[i_tu];
+    const int n = 1 << t.log2_size, cnt = 4 * n + 1;
+    const unsigned long long rl = __brevll(t.avail_left) >> (64 - 2 * n); /* bit i = left[2n-1-i] */
+    unsigned long long m0, m1;
+    unsigned m2 = 0;
+    const unsigned long long c = (t.flags & 1) ? 1ull : 0ull;
+    const unsigned long long tp = n == 32 ? t.avail_top : (t.avail_top & ((1ull << (2 * n)) - 1));
+    if (n == 32) { /* left 0..63, corner 64, top 65..128 */
+        m0 = rl; m1 = c | (tp << 1); m2 = (unsigned)(tp >> 63);
+    } else {
+        m0 = rl | (c << (2 * n)) | (tp << (2 * n + 1));
+        m1 = tp >> (63 - 2 * n); /* bits that spill past 64 (n = 16: 4n + 1 = 65) */
+    }
+    const int n_avail = __popcll(m0) + __popcll(m1) + (int)m2;
+    uint8_t *out = a.jt + (size_t)(a.boff[t.cidx] + (uint32_t)(t.y >> 2) * (uint32_t)a.bw[t.cidx] + (uint32_t)(t.x >> 2)) * JT_STRIDE;
+    for (int i = lane; i < cnt; i += 64) {
+        int j = i;
+        if (n_avail == 0) j = 255;
+        else if (n_avail < cnt) {
+            j = -1;
+            if (i >= 128 && m2) j = 128;
+            if (j < 0 && i >= 64) {
+                const unsigned long long mm = i >= 127 ? m1 : (m1 & ((2ull << (i - 64)) - 1));
+                if (mm) j = 127 - __clzll(mm);
+            }
+            if (j < 0) {
+                const unsigned long long mm = i >= 63 ? m0 : (m0 & ((2ull << i) - 1));
+                if (mm) j = 63 - __clzll(mm);
+            }
+            if (j < 0) j = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : 128);
+        }
+        out[i] = (uint8_t)j;
+    }
+}
+
 template <bool GROUPED>
 __device__ __forceinline__ void intra_tu_any(const HevcIntraArgs &a, const ffhip_hevc_tu &t, const int lane, int *s, int *s2,
                                              int *refbase, short *R, const ResPrefetch &rp, short *tile, const int wl,
@@ -413,33 +681,26 @@ __global__ __launch_bounds__(256) void k_hevc_intra(HevcIntraArgs a)
 #define SPIN_LIMIT (1 << 21)
 #define SLOT_CHUNK 64
 
-struct IntraSlot {
-    ffhip_hevc_tu t;
-    unsigned wait_begin, wait_count, signal, tile_ok;
-};
-
-__device__ __forceinline__ IntraSlot read_slot(const u32x4 *slots, int k)
+/* slot words -> wave-uniform registers.  q0 = first half of the TU record, q2 = the schedule's own words */
+__device__ __forceinline__ IntraSlot decode_slot(const u32x4 q0, const u32x4 q2)
 {
-    const u32x4 q0 = slots[3 * k], q1 = slots[3 * k + 1], q2 = slots[3 * k + 2];
 #define SGPR(v) ((unsigned)__builtin_amdgcn_readfirstlane((int)(v)))
     const unsigned d0 = SGPR(q0.x), d1 = SGPR(q0.y), d2 = SGPR(q0.z), d3 = SGPR(q0.w);
-    const unsigned d4 = SGPR(q1.x), d5 = SGPR(q1.y), d6 = SGPR(q1.z), d7 = SGPR(q1.w);
-    const unsigned d8 = SGPR(q2.x), d9 = SGPR(q2.y);
+    const unsigned d8 = SGPR(q2.x), d9 = SGPR(q2.y), d10 = SGPR(q2.z), d11 = SGPR(q2.w);
 #undef SGPR
     IntraSlot sl;
-    sl.t.x = (uint16_t)d0; sl.t.y = (uint16_t)(d0 >> 16);
-    sl.t.log2_size = (uint8_t)d1; sl.t.cidx = (uint8_t)(d1 >> 8); sl.t.pred_mode = (uint8_t)(d1 >> 16); sl.t.flags = (uint8_t)(d1 >> 24);
-    sl.t.res_offset = d2; sl.t.res_scale = (int32_t)d3;
-    sl.t.avail_top = (unsigned long long)d4 | ((unsigned long long)d5 << 32);
-    sl.t.avail_left = (unsigned long long)d6 | ((unsigned long long)d7 << 32);
+    sl.x = d0 & 0xffff; sl.y = d0 >> 16;
+    sl.lg = d1 & 0xff; sl.cidx = (d1 >> 8) & 0xff; sl.mode = (d1 >> 16) & 0xff; sl.flags = d1 >> 24;
+    sl.res_offset = d2; sl.res_scale = (int)d3;
     sl.wait_begin = d8; sl.wait_count = d9 & 0xff; sl.signal = (d9 >> 8) & 1; sl.tile_ok = (d9 >> 9) & 1;
+    sl.tu_index = d10; sl.jt_off = d11;
     return sl;
 }
 
 __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
 {
     __shared__ short tile[64 * TILE_STRIDE];
-    __shared__ int nbA[NB_MAX], nbB[NB_MAX], refs[140];
+    __shared__ int nbA[NB_MAX], nbB[NB_MAX];
     __shared__ __attribute__((aligned(16))) short resl[2][32 * 32];
     __shared__ u32x4 slots[SLOT_CHUNK * 3];
     const int lane = threadIdx.x;
@@ -458,16 +719,22 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                 const int m = (int)(a.n_tus - base < SLOT_CHUNK ? a.n_tus - base : SLOT_CHUNK);
                 for (int i = lane; i < 3 * m; i += 64) {
                     const int k = i / 3, part = i - 3 * k;
-                    u32x4 q = {0u, 0u, (uint32_t)(base + k), 0u}; /* no waits, no flag, no tile */
-                    if (part < 2) q = ((const u32x4 *)(a.tus + base + k))[part];
+                    const ffhip_hevc_tu *tp = a.tus + base + k;
+                    const int c = tp->cidx;
+                    const uint32_t blk = (c == 0 ? a.jt_boff[0] : (c == 1 ? a.jt_boff[1] : a.jt_boff[2])) +
+                                         (uint32_t)(tp->y >> 2) * (uint32_t)(c == 0 ? a.jt_bw[0] : (c == 1 ? a.jt_bw[1] : a.jt_bw[2])) + (uint32_t)(tp->x >> 2);
+                    u32x4 q = {0u, 0u, (uint32_t)(base + k), blk * JT_STRIDE}; /* no waits, no flag, no tile */
+                    if (part < 2) q = ((const u32x4 *)tp)[part];
                     slots[i] = q;
                 }
                 wave_sync();
                 for (int k = 0; k < m; k++) {
-                    const IntraSlot cur = read_slot(slots, k);
+                    const IntraSlot cur = decode_slot(slots[3 * k], slots[3 * k + 2]);
                     ResPrefetch rp;
-                    fetch_residual(a, cur.t, lane, rp);
-                    intra_tu_any<true>(a, cur.t, lane, nbA, nbB, refs, resl[k & 1], rp, tile, 6, false);
+                    JPrefetch jp;
+                    fetch_residual_g(a, cur, lane, rp);
+                    fetch_jtable(a, cur, lane, jp);
+                    intra_tu_g_any(a, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, 6);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the next TU may read these samples back from memory */
                     wave_sync();
                 }
@@ -483,18 +750,29 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
         if (ticket >= (unsigned)n_groups) return;
         const u32x4 g = a.groups[ticket];
         const int wl = (int)g.z;
+#ifdef FFHIP_INTRA_TRACE
+        if (a.trace && lane == 0) a.trace[8 * a.n_tus + ticket] = TRACE_NOW();
+#endif
         for (unsigned base = 0; base < g.y; base += SLOT_CHUNK) {
             const int m = (int)(g.y - base < SLOT_CHUNK ? g.y - base : SLOT_CHUNK);
             for (int i = lane; i < 3 * m; i += 64) slots[i] = a.sched[(size_t)(g.x + base) * 3 + i];
             wave_sync();
-            IntraSlot cur = read_slot(slots, 0);
+            IntraSlot cur = decode_slot(slots[0], slots[2]);
             ResPrefetch rp;
-            fetch_residual(a, cur.t, lane, rp);
+            JPrefetch jp;
+            fetch_residual_g(a, cur, lane, rp);
+            fetch_jtable(a, cur, lane, jp);
             /* which flag this lane polls for the TU: fetched with the slot, one TU ahead like the residual (fetched at
              * the wait it was a dependent load in front of the first poll of every cross-group hop) */
             uint32_t widx = cur.wait_count ? a.wait_idx[cur.wait_begin + (lane < (int)cur.wait_count ? lane : 0)] : 0;
             for (int k = 0; k < m; k++) {
-                if (cur.wait_count) { /* wait for the TUs of other groups this one reads (at most 33 of them) */
+                /* the next slot's words leave LDS now and are decoded behind this TU's body */
+                const int kn = k + 1 < m ? k + 1 : k;
+                const u32x4 nq0 = slots[3 * kn], nq2 = slots[3 * kn + 2];
+#ifdef FFHIP_INTRA_TRACE
+                const unsigned long long tr0 = TRACE_NOW();
+#endif
+                if (cur.wait_count) { /* wait for the TUs of other groups this one reads (at most 64 of them) */
                     const uint32_t *fp = flags + widx;
                     int spins = 0;
                     for (;;) {
@@ -518,7 +796,10 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* ordering only: no cache-wide invalidate */
                 }
-                intra_tu_any<true>(a, cur.t, lane, nbA, nbB, refs, resl[k & 1], rp, tile, wl, cur.tile_ok != 0);
+#ifdef FFHIP_INTRA_TRACE
+                const unsigned long long tr1 = TRACE_NOW();
+#endif
+                intra_tu_g_any(a, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, wl);
                 if (cur.signal) { /* somebody outside the group reads this TU: publish it once its stores have completed */
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* compiler ordering; no L2-wide write-back */
                     /* the fence alone lowers to s_waitcnt lgkmcnt(0): the flag must not overtake the sample stores
@@ -526,15 +807,24 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                      * Sending the flag one TU later instead -- when the next residual, fetched behind these stores,
                      * has been consumed -- was measured no faster: the reader waits for the flag either way */
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0 && (int)slots[3 * k + 2].z != a.debug_withhold)
-                        __hip_atomic_store(flags + (slots[3 * k + 2].z), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0 && (int)cur.tu_index != a.debug_withhold)
+                        __hip_atomic_store(flags + cur.tu_index, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+#ifdef FFHIP_INTRA_TRACE
+                if (a.trace && lane == 0) {
+                    unsigned long long *tr = a.trace + 8 * (size_t)cur.tu_index;
+                    tr[0] = tr0; tr[1] = tr1; tr[2] = TRACE_NOW();
+                    tr[3] = ((unsigned long long)ticket << 32) | ((unsigned long long)blockIdx.x << 12) | (unsigned)(base + k);
+                    tr[4] = g_stamp[0]; tr[5] = g_stamp[1]; tr[6] = g_stamp[2]; tr[7] = g_stamp[3];
+                }
+#endif
                 wave_sync(); /* the next TU reuses the neighbour scratch and reads the tile this one wrote */
                 if (k + 1 < m) {
                     /* issued behind this TU's stores and consumed half-way into the next TU: the in-order
                      * vmcnt wait there then covers nothing younger than this fetch */
-                    cur = read_slot(slots, k + 1);
-                    fetch_residual(a, cur.t, lane, rp);
+                    cur = decode_slot(nq0, nq2);
+                    fetch_jtable(a, cur, lane, jp);
+                    fetch_residual_g(a, cur, lane, rp);
                     if (cur.wait_count) widx = a.wait_idx[cur.wait_begin + (lane < (int)cur.wait_count ? lane : 0)];
                 }
             }
@@ -565,7 +855,7 @@ struct GroupPlan {
  * ticket (window larger than the coding tree block, or an exotic list): the caller then tries a
  * smaller window or falls back to the level-synchronous form. */
 static bool plan_groups(const ffhip_hevc_tu *tus, long long n_tus, const int pw[3], const int ph[3], const int win_log2[3],
-                        GroupPlan &out)
+                        GroupPlan &out, const uint32_t jt_boff[3])
 {
     /* scratch kept between calls: a picture's worth of maps is reallocated and refilled otherwise */
     static thread_local std::vector<int32_t> owner[3], gid_of[3];
@@ -729,7 +1019,7 @@ static bool plan_groups(const ffhip_hevc_tu *tus, long long n_tus, const int pw[
             q[2].x = m.wait_begin;
             q[2].y = (uint32_t)m.wait_count | ((uint32_t)m.signal << 8) | ((uint32_t)m.tile_ok << 9);
             q[2].z = (uint32_t)i;
-            q[2].w = 0;
+            q[2].w = (jt_boff[tus[i].cidx] + (uint32_t)(tus[i].y >> 2) * (uint32_t)bw[tus[i].cidx] + (uint32_t)(tus[i].x >> 2)) * JT_STRIDE;
         }
     };
     if (n_threads == 1) emit(0);
@@ -776,13 +1066,13 @@ static bool groups_contiguous(const ffhip_hevc_tu *tus, long long n_tus, const i
 /* the window search both entry points share: the requested (or default) luma window, halved until a
  * plan exists; chroma windows cover the same picture area */
 static bool plan_with_window_search(const ffhip_hevc_tu *tus, long long n_tus, const int pw[3], const int ph[3], int wl,
-                                    GroupPlan &plan, int *used_wl)
+                                    GroupPlan &plan, int *used_wl, const uint32_t jt_boff[3])
 {
     wl = wl < 3 ? 3 : (wl > 6 ? 6 : wl);
     const int cs = (pw[1] > 0 && pw[1] * 2 <= pw[0] + 1) ? 1 : 0;
     for (; wl >= 3; wl--) {
         const int win[3] = {wl, wl - cs, wl - cs};
-        if (plan_groups(tus, n_tus, pw, ph, win, plan)) {
+        if (plan_groups(tus, n_tus, pw, ph, win, plan, jt_boff)) {
             if (used_wl) *used_wl = wl;
             return true;
         }
@@ -801,7 +1091,8 @@ extern "C" int ffhip_hevc_intra_plan(const ffhip_hevc_tu *h_tus, long long n_tus
     const int pw[3] = {width_y, width_c, width_c}, ph[3] = {height_y, height_c, height_c};
     GroupPlan plan;
     int wl = 0;
-    if (!plan_with_window_search(h_tus, n_tus, pw, ph, window_log2 ? window_log2 : FFHIP_HEVC_INTRA_WINDOW_LOG2, plan, &wl)) return FFHIP_EINVAL;
+    const uint32_t no_table[3] = {0, 0, 0};
+    if (!plan_with_window_search(h_tus, n_tus, pw, ph, window_log2 ? window_log2 : FFHIP_HEVC_INTRA_WINDOW_LOG2, plan, &wl, no_table)) return FFHIP_EINVAL;
     int tile_ok = 0;
     for (size_t g = 0; g < plan.groups.size(); g++)
         for (uint32_t k = 0; k < plan.groups[g].y; k++) {
@@ -884,7 +1175,24 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
     const bool want_groups = !(mode_env && !strcmp(mode_env, "levels"));
     int *async_err = want_groups ? ffhip_async_err_word() : nullptr;
     const bool offsets_fit = (long long)y_stride * height_y < (1LL << 30) && (long long)uv_stride * (height_c > 0 ? height_c : 1) < (1LL << 30);
-    if (want_groups && async_err && offsets_fit /* 32-bit byte offsets into a plane */) {
+    /* geometry of the substitution table (and of the device planner's owner map): 4x4 blocks of the planes in use */
+    const int pwc[3] = {pw[0], (d_cb && d_cr) ? pw[1] : 0, (d_cb && d_cr) ? pw[2] : 0};
+    size_t jt_blocks = 0;
+    JTabArgs ja = {};
+    for (int c = 0; c < 3; c++) {
+        ja.bw[c] = (pwc[c] + 3) / 4;
+        ja.boff[c] = (uint32_t)jt_blocks;
+        if (pwc[c] > 0) jt_blocks += (size_t)ja.bw[c] * (size_t)((ph[c] + 3) / 4);
+        a.jt_bw[c] = ja.bw[c];
+        a.jt_boff[c] = ja.boff[c];
+    }
+    const size_t w_jt = (jt_blocks * JT_STRIDE + 256 + 3) / 4; /* padded: the kernel fetches 64 / 192 entries per TU whatever its size */
+    auto enqueue_jtable = [&](uint32_t *words) {
+        ja.tus = d_tus; ja.n = (uint32_t)n_tus; ja.jt = (uint8_t *)words;
+        a.jt = ja.jt;
+        hipLaunchKernelGGL(k_hevc_intra_jtable, dim3((unsigned)((n_tus + 3) / 4)), dim3(256), 0, st, ja);
+    };
+    if (want_groups && async_err && offsets_fit && jt_blocks * JT_STRIDE < (1ull << 32) /* 32-bit byte offsets into a plane and the table */) {
         const char *we = getenv("FFHIP_HEVC_INTRA_WINDOW");
         const char *wv = getenv("FFHIP_HEVC_INTRA_WAVES");
         const size_t max_waves = wv ? (size_t)std::max(1, atoi(wv)) : FFHIP_HEVC_INTRA_WAVES;
@@ -911,10 +1219,10 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
                 if (groups_contiguous(h_tus, n_tus, pw, ph, win)) break;
             }
             const int win[3] = {wl, wl - cs, wl - cs};
-            const int pwc[3] = {pw[0], (d_cb && d_cr) ? pw[1] : 0, (d_cb && d_cr) ? pw[2] : 0};
             const size_t w_plan = ffhip_hevc_plan_gpu_words(n_tus, pwc, ph, win), w_ctrl = 4 + (size_t)n_tus;
-            uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, w_plan + w_ctrl + 16);
+            uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, w_plan + w_ctrl + 16 + w_jt);
             if (!g_work) return FFHIP_ENOMEM;
+            enqueue_jtable(g_work + ((w_plan + 3) & ~(size_t)3) + ((w_ctrl + 3) & ~(size_t)3));
             int n_groups = 0;
             const int prc = ffhip_hevc_plan_gpu(d_tus, n_tus, pwc, ph, win, g_work, st, &a.sched, &a.groups, &a.wait_idx, &n_groups, &a.plan_result, &a.wait_cap);
             if (prc < 0) return prc;
@@ -923,19 +1231,23 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             a.async_err = async_err;
             a.n_groups = 0;
             a.n_tus = n_tus;
+#ifdef FFHIP_INTRA_TRACE
+            a.trace = g_intra_trace;
+#endif
             hipLaunchKernelGGL(k_hevc_intra_groups, dim3((unsigned)std::min<size_t>((size_t)n_tus, max_waves)), dim3(64), 0, st, a);
             FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
             return FFHIP_OK;
         }
         GroupPlan plan;
-        if (plan_with_window_search(h_tus, n_tus, pw, ph, we ? atoi(we) : FFHIP_HEVC_INTRA_WINDOW_LOG2, plan, nullptr)) {
+        if (plan_with_window_search(h_tus, n_tus, pw, ph, we ? atoi(we) : FFHIP_HEVC_INTRA_WINDOW_LOG2, plan, nullptr, ja.boff)) {
             /* device image: sched | groups | wait | ctrl[4] + one done flag per TU */
             const size_t w_sched = plan.sched.size() * 4, w_groups = plan.groups.size() * 4, w_wait = plan.wait.size();
             const size_t w_ctrl = 4 + (size_t)n_tus;
             const size_t o_groups = w_sched, o_wait = o_groups + w_groups, o_ctrl = (o_wait + w_wait + 3) & ~(size_t)3;
             FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO); /* the work buffer may still be in use by an earlier call */
-            uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, o_ctrl + w_ctrl);
+            uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, o_ctrl + w_ctrl + 4 + w_jt);
             if (!g_work) return FFHIP_ENOMEM;
+            enqueue_jtable(g_work + ((o_ctrl + w_ctrl + 3) & ~(size_t)3));
             FFHIP_CHECK(hipMemcpy(g_work, plan.sched.data(), w_sched * 4, hipMemcpyHostToDevice), FFHIP_EIO);
             FFHIP_CHECK(hipMemcpy(g_work + o_groups, plan.groups.data(), w_groups * 4, hipMemcpyHostToDevice), FFHIP_EIO);
             FFHIP_CHECK(hipMemcpy(g_work + o_wait, plan.wait.data(), w_wait * 4, hipMemcpyHostToDevice), FFHIP_EIO);

@@ -227,7 +227,8 @@ __global__ __launch_bounds__(256) void k_plan_emit(PlanArgs a)
     q2.x = wb;
     q2.y = wc | ((f & 1u) << 8) | (((f >> 1) & 1u) << 9);
     q2.z = i;
-    q2.w = 0;
+    q2.w = (a.owner_off[t.cidx] + (uint32_t)(t.y >> 2) * (uint32_t)a.bw[t.cidx] + (uint32_t)(t.x >> 2)) * 20u; /* the TU's stripe of the substitution
+                                                                                                                 table (JT_STRIDE bytes per 4x4 block) */
     a.sched[(size_t)i * 3] = src[0];
     a.sched[(size_t)i * 3 + 1] = src[1];
     a.sched[(size_t)i * 3 + 2] = q2;

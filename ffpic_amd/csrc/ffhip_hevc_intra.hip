@@ -62,6 +62,10 @@ struct HevcIntraArgs {
     const uint8_t *jt;
     int jt_bw[3];                /* 4x4 blocks per row of each plane */
     uint32_t jt_boff[3];         /* first block of each plane        */
+    /* per-pixel programs of the small TUs (k_hevc_intra_program): four LDS cell indices / weights per sample */
+    const uint2 *desc;
+    int desc_w[3];               /* samples per row of each plane in desc */
+    uint32_t desc_off[3];        /* first entry of each plane             */
 #ifdef FFHIP_INTRA_TRACE
     unsigned long long *trace;   /* diagnostics build only (make trace): 8 words per TU, then one per ticket */
 #endif
@@ -72,6 +76,9 @@ static unsigned long long *g_intra_trace = nullptr;
 extern "C" void ffhip_debug_intra_trace(void *d_buf) { g_intra_trace = (unsigned long long *)d_buf; }
 #define TRACE_NOW() ((unsigned long long)wall_clock64())
 __shared__ unsigned long long g_stamp[4];
+#define STAMP(k) do { if (lane == 0) g_stamp[k] = TRACE_NOW(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
 #endif
 
 __device__ __forceinline__ void wave_sync()
@@ -112,7 +119,18 @@ __device__ __forceinline__ int intra_inv_angle(int mode) /* modes 11..25 */
 
 #define NB_MAX 132 /* 4*32 + 1, padded */
 
-#define TILE_STRIDE 66 /* shorts per row of the grouped form's window tile: 33 dwords, so a column walk hits 32 different banks */
+/* The grouped form's LDS copy of its window, WITH a halo: cell (ty, tx) holds picture sample (wy0 - 1 + ty, wx0 - 1 + tx).
+ * Rows 0 .. 64 (the row above the window, then the window; up to 64 more columns to the right for above-right
+ * neighbours) sit at ty * TILE_STRIDE + tx; the left column continues below the window (below-left neighbours) in
+ * TILE_LEFT_EXT; three constant cells follow.  The window itself is written by the wave as it reconstructs; halo cells
+ * are filled from memory by the TUs that need them (see intra_program).  One layout for every window size. */
+#define TILE_STRIDE 130 /* shorts per row: 65 dwords, so a column walk hits 32 different banks */
+#define TILE_ORIGIN (TILE_STRIDE + 1) /* cell of the window's first sample */
+#define TILE_LEFT_EXT (65 * TILE_STRIDE) /* cells (65 + k, 0), k = 0 .. 63 */
+#define TILE_CONST_Y (TILE_LEFT_EXT + 64) /* 1 << (bitdepth_y - 1): what a TU without any neighbour predicts from */
+#define TILE_CONST_C (TILE_LEFT_EXT + 65)
+#define TILE_ZERO (TILE_LEFT_EXT + 66)
+#define TILE_CELLS (TILE_LEFT_EXT + 68)
 
 /* The residual block of a TU, fetched one TU ahead in the grouped form: samples 8 lane + 512 j .. +7 in v[j], as
  * 16-byte loads into registers of their own.  (The first form took one short per lane and pass into a short[16]:
@@ -243,7 +261,7 @@ __device__ __forceinline__ void intra_tu(const HevcIntraArgs &a, const ffhip_hev
             const int16_t *sp = plane + (long long)py * stride + px;
             if (GROUPED) {
                 const unsigned tx = (unsigned)(px - wx0), ty = (unsigned)(py - wy0);
-                if (tile_ok && tx < (unsigned)wsz && ty < (unsigned)wsz) v = (int)tile[ty * TILE_STRIDE + tx];
+                if (tile_ok && tx < (unsigned)wsz && ty < (unsigned)wsz) v = (int)tile[TILE_ORIGIN + ty * TILE_STRIDE + tx];
                 else v = ffhip_load_s16_sc1(ffhip_rsrc(plane, 0xffffffffu), (py * stride + px) * 2);
             } else {
                 v = (int)*sp;
@@ -373,7 +391,7 @@ __device__ __forceinline__ void intra_tu(const HevcIntraArgs &a, const ffhip_hev
         if (GROUPED) {
             __hip_atomic_store(dp, rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned tx = (unsigned)(x0 + x - wx0), ty = (unsigned)(y0 + y - wy0);
-            if (tx < (unsigned)wsz && ty < (unsigned)wsz) tile[ty * TILE_STRIDE + tx] = rec;
+            if (tx < (unsigned)wsz && ty < (unsigned)wsz) tile[TILE_ORIGIN + ty * TILE_STRIDE + tx] = rec;
         } else {
             *dp = rec;
         }
@@ -435,12 +453,6 @@ __device__ __forceinline__ void intra_tu_g(const HevcIntraArgs &a, const IntraSl
     int16_t *plane = cidx == 0 ? a.plane[0] : (cidx == 1 ? a.plane[1] : a.plane[2]);
     const int stride = cidx == 0 ? a.stride[0] : (cidx == 1 ? a.stride[1] : a.stride[2]);
     const __amdgpu_buffer_rsrc_t prs = ffhip_rsrc(plane, 0xffffffffu);
-#ifdef FFHIP_INTRA_TRACE
-#define STAMP(k) do { if (lane == 0) g_stamp[k] = TRACE_NOW(); } while (0)
-#else
-#define STAMP(k) do { } while (0)
-#endif
-
     /* ---- 1 + 2. gather with the substitution folded in ---- */
 #pragma unroll
     for (int pass = 0; pass < LANE_PASSES(cnt); pass++) {
@@ -453,7 +465,7 @@ __device__ __forceinline__ void intra_tu_g(const HevcIntraArgs &a, const IntraSl
         int v = 1 << (bd - 1);
         if (j != 255) { /* 255: nothing available around this TU (wave-uniform) */
             const unsigned tx = (unsigned)(px - wx0), ty = (unsigned)(py - wy0);
-            if (tile_ok && tx < (unsigned)wsz && ty < (unsigned)wsz) v = (int)tile[ty * TILE_STRIDE + tx];
+            if (tile_ok && tx < (unsigned)wsz && ty < (unsigned)wsz) v = (int)tile[TILE_ORIGIN + ty * TILE_STRIDE + tx];
             else v = ffhip_load_s16_sc1(prs, (py * stride + px) * 2);
         }
         s[i] = v;
@@ -567,12 +579,220 @@ __device__ __forceinline__ void intra_tu_g(const HevcIntraArgs &a, const IntraSl
         const short rec = (short)clip3i(0, (1 << bd) - 1, pr + rs);
         __hip_atomic_store(dp, rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned tx = (unsigned)(x0 + x - wx0), ty = (unsigned)(y0 + y - wy0);
-        if (tx < (unsigned)wsz && ty < (unsigned)wsz) tile[ty * TILE_STRIDE + tx] = rec;
+        if (tx < (unsigned)wsz && ty < (unsigned)wsz) tile[TILE_ORIGIN + ty * TILE_STRIDE + tx] = rec;
     }
     STAMP(3);
 #undef LEFT
 #undef TOP
 #undef U16
+}
+
+/* ---- small TUs as per-pixel programs ---------------------------------------------------------------------------
+ * A lone wave pays ~8 cycles per instruction, and ~9 000 of the ~11 000 TUs on the critical path of an 8K picture are
+ * 4x4 and 8x8 ones (tests/tools/diag_intra_trace.py): what such a TU costs is the NUMBER of instructions between
+ * "my neighbours are there" and "my samples are there".  Everything that does not depend on sample VALUES -- which
+ * neighbour a pixel reads (mode, angle, substitution), where that neighbour lives in the wave's LDS tile, its weight,
+ * and every address the TU needs -- is worked out by a parallel kernel in front (k_hevc_intra_program): per pixel four
+ * 16-bit words, per TU four dwords in the slot.  The pixel words and the pixel's own residual are fetched one TU ahead.
+ * What is left on the chain: up to four LDS reads, a dozen VALU operations, one LDS and one global store.  TUs that
+ * qualify: 4x4 and 8x8, no neighbour smoothing (never at 4x4; at 8x8 only planar and modes 2 / 18 / 34 smooth), no
+ * rdpcm / cross-component residual, every neighbour inside the window written by this group.  Neighbours OUTSIDE the
+ * window are copied into the tile's halo first. */
+#define PK_KIND(p) ((p) & 7u)
+#define PROG_GENERIC 0u
+#define PROG_ANGULAR 1u      /* two taps: cells a0, a1, weight a2 of the second                                       */
+#define PROG_PLANAR 2u       /* cells LEFT(y), TOP(x), TOP(n), LEFT(n)                                                */
+#define PROG_DC 3u           /* a2 = the lane's element of the 2n-sample sum, a3 = boundary filter of this pixel      */
+#define PROG_ANGULAR_EDGE 4u /* modes 10 / 26 with the boundary filter: lanes with a3 set take a0 + ((a1 - a2) >> 1) */
+#define PK_LG3 8u
+#define PK_RES 16u
+#define PK_OUTSIDE 32u
+#define PK_SIGNAL 64u
+#define PK_WAIT 128u
+#define PK_END 512u /* the sentinel behind a chunk's last slot */
+#define PK_SLOW 256u /* anything but a plain angular program: generic TU, other kinds, a wait, a flag to publish, halo cells */
+#define PROG_NO_RESIDUAL 0xffffff00u /* res_off of a TU without residual = size of the residual buffer resource: reads 0 */
+struct ProgSlot {
+    unsigned packed;    /* kind, flags above, bits 31:16 = LDS byte address of the TU's first sample in the tile */
+    unsigned res_off;   /* byte offset of the residual block                                                     */
+    unsigned desc_off;  /* byte offset of the TU's first pixel words                                             */
+    unsigned plane_off; /* byte offset of the TU's first sample in its plane                                     */
+};
+struct ProgPrefetch {
+    uint2 d;
+    short res; /* kept as loaded: a conversion at the load would wait for it there */
+};
+/* what is the same for every TU of a group (one window of one plane) */
+struct GroupCtx {
+    __amdgpu_buffer_rsrc_t plane_rs;
+    int cidx, stride, maxv, wl, wx0, wy0;
+    int plane_lane[2], desc_lane[2]; /* per lane, 4x4 / 8x8: byte offset of the lane's pixel from the TU's first one */
+};
+__device__ __forceinline__ int row_sum16(int v) /* every lane: the sum over its row of 16 lanes */
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);  /* quad_perm [1,0,3,2] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);  /* quad_perm [2,3,0,1] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false); /* row_half_mirror    */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false); /* row_mirror         */
+    return v;
+}
+#define LDS_U16(byte_addr) ((int)*(const unsigned short *)((const char *)tile + (byte_addr)))
+template <int LG>
+__device__ __forceinline__ void intra_program(const HevcIntraArgs &a, const GroupCtx &g, const ProgSlot &t, const int lane,
+                                              const ProgPrefetch &pp, short *tile, const int cell_lane)
+{
+    constexpr int n = 1 << LG;
+    if (LG == 3 || lane < n * n) {
+        const unsigned a0 = pp.d.x & 0xffffu, a1 = pp.d.x >> 16, a2 = pp.d.y & 0xffffu, a3 = pp.d.y >> 16;
+        const int r0 = LDS_U16(a0), r1 = LDS_U16(a1);
+        const unsigned kind = PK_KIND(t.packed);
+        int v;
+        if (kind == PROG_ANGULAR) {
+            v = ((32 - (int)a2) * r0 + (int)a2 * r1 + 16) >> 5;
+        } else if (kind == PROG_PLANAR) {
+            const int x = lane & (n - 1), y = lane >> LG;
+            const int r2 = LDS_U16(a2), r3 = LDS_U16(a3);
+            v = ((n - 1 - x) * r0 + (x + 1) * r2 + (n - 1 - y) * r1 + (y + 1) * r3 + n) >> (LG + 1);
+        } else if (kind == PROG_DC) {
+            const int dc = (__builtin_amdgcn_readfirstlane(row_sum16(LDS_U16(a2))) + n) >> (LG + 1);
+            v = dc;
+            if (a3 == 1) v = (r0 + 2 * dc + r1 + 2) >> 2;
+            else if (a3 == 2) v = (r1 + 3 * dc + 2) >> 2;
+            else if (a3 == 3) v = (r0 + 3 * dc + 2) >> 2;
+        } else {
+            const int r2 = LDS_U16(a2);
+            const int vn = ((32 - (int)a2) * r0 + (int)a2 * r1 + 16) >> 5;
+            const int ve = clip3i(0, (1 << a.bitdepth_y) - 1, r0 + ((r1 - r2) >> 1));
+            v = a3 ? ve : vn;
+        }
+        const int pr = (int)(short)(v & 0xffff);
+        const short rec = (short)clip3i(0, g.maxv, pr + (int)pp.res);
+        *(short *)((char *)tile + (t.packed >> 16) + cell_lane) = rec;
+        __builtin_amdgcn_raw_buffer_store_b16(rec, g.plane_rs, g.plane_lane[LG - 2], (int)t.plane_off, FFHIP_AUX_SC1);
+    }
+}
+/* halo: every scan position of a program TU whose (substituted) source lies outside the window comes from memory --
+ * its owner's done flag has been seen.  LDS serves a wave in order: the program's reads need no barrier */
+__device__ __forceinline__ void intra_program_halo(const GroupCtx &g, const int x0, const int y0, const int n, const int lane,
+                                                   const unsigned j, short *tile)
+{
+    const int wsz = 1 << g.wl;
+    if (lane < 4 * n + 1 && j != 255u) {
+        int px = x0 - 1, py = y0 - 1;
+        if ((int)j < 2 * n) py = y0 + (2 * n - 1 - (int)j);
+        else if ((int)j > 2 * n) px = x0 + ((int)j - 2 * n - 1);
+        const int tx = px - g.wx0 + 1, ty = py - g.wy0 + 1;
+        if (tx == 0 || ty == 0 || tx > wsz || ty > wsz) {
+            const int v = ffhip_load_s16_sc1(g.plane_rs, (py * g.stride + px) * 2);
+            tile[ty <= 64 ? ty * TILE_STRIDE + tx : TILE_LEFT_EXT + ty - 65] = (short)v;
+        }
+    }
+}
+
+/* The programs: one wave per schedule slot, in front of the grouped kernel.  Reads the substitution table, decides
+ * whether the TU qualifies, writes the four words of every pixel and the slot's program words (second quarter of the
+ * slot: the availability masks that lived there are in the substitution table now). */
+struct ProgArgs {
+    u32x4 *sched;
+    uint32_t n_slots;
+    const uint8_t *jt;
+    uint2 *desc;
+    int desc_w[3];
+    uint32_t desc_off[3];
+    int wl[3], stride[3];
+    const uint32_t *plan_result;
+    uint32_t wait_cap;
+};
+__global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
+{
+    const uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (k >= a.n_slots) return;
+    if (a.plan_result && (a.plan_result[0] | (a.plan_result[2] > a.wait_cap ? 1u : 0u))) return; /* refused plan: the slots mean nothing */
+    const u32x4 q0 = a.sched[(size_t)k * 3], q2 = a.sched[(size_t)k * 3 + 2];
+    const u32x4 generic = {PK_SLOW, PROG_NO_RESIDUAL, 0u, 0u};
+    const int x0 = (int)(q0.x & 0xffff), y0 = (int)(q0.x >> 16);
+    const int lg = (int)(q0.y & 0xff), cidx = (int)((q0.y >> 8) & 0xff), mode = (int)((q0.y >> 16) & 0xff), flags = (int)(q0.y >> 24);
+    const int n = 1 << lg, wl = a.wl[cidx], wsz = 1 << wl;
+    bool prog = lg <= 3 && n <= wsz && ((q2.y >> 9) & 1) && !(flags & 0xC0) && q0.z < 0x7fff0000u;
+    if (prog && (flags & 4) && mode != 1 && n != 4) { /* neighbour smoothing applies (8.4.4.2.3): the generic body */
+        const int d26 = iabs(mode - 26), d10 = iabs(mode - 10);
+        if ((d26 < d10 ? d26 : d10) > 7) prog = false;
+    }
+    if (!prog) {
+        if (lane == 0) a.sched[(size_t)k * 3 + 1] = generic;
+        return;
+    }
+    const int wx0 = (x0 >> wl) << wl, wy0 = (y0 >> wl) << wl;
+    const uint8_t *jt = a.jt + q2.w;
+    bool ok = true, outside = false;
+    auto cell = [&](int pos) -> unsigned { /* LDS byte address of the sample scan position pos takes */
+        const int j = (int)jt[pos];
+        if (j == 255) return 2u * (cidx == 0 ? TILE_CONST_Y : TILE_CONST_C);
+        int px = x0 - 1, py = y0 - 1;
+        if (j < 2 * n) py = y0 + (2 * n - 1 - j);
+        else if (j > 2 * n) px = x0 + (j - 2 * n - 1);
+        const int tx = px - wx0 + 1, ty = py - wy0 + 1;
+        if (tx == 0 || ty == 0 || tx > wsz || ty > wsz) outside = true;
+        if (tx > TILE_STRIDE - 1 || ty > 128 || (ty > 64 && tx != 0)) ok = false;
+        return 2u * (unsigned)(ty <= 64 ? ty * TILE_STRIDE + tx : TILE_LEFT_EXT + ty - 65);
+    };
+#define POS_LEFT(yy) (2 * n - 1 - (yy))
+#define POS_TOP(xx) (2 * n + 1 + (xx))
+    const bool act = lane < n * n;
+    const int x = lane & (n - 1), y = lane >> lg;
+    unsigned w0 = 0, w1 = 0, w2 = 0, w3 = 0, kind;
+    const bool edge_ok = cidx == 0; /* n < 32 here */
+    if (mode == 0) {
+        kind = PROG_PLANAR;
+        if (act) { w0 = cell(POS_LEFT(y)); w1 = cell(POS_TOP(x)); w2 = cell(POS_TOP(n)); w3 = cell(POS_LEFT(n)); }
+    } else if (mode == 1) {
+        kind = PROG_DC;
+        if (act) {
+            w0 = cell(POS_LEFT(y)); w1 = cell(POS_TOP(x));
+            w2 = lane < n ? cell(POS_LEFT(lane)) : (lane < 2 * n ? cell(POS_TOP(lane - n)) : 2u * TILE_ZERO);
+            if (edge_ok && !(flags & 0x20)) w3 = (x == 0 && y == 0) ? 1u : (y == 0 ? 2u : (x == 0 ? 3u : 0u));
+        }
+    } else {
+        const bool edge_tu = edge_ok && !(flags & 0x10) && (mode == 26 || mode == 10);
+        kind = edge_tu ? PROG_ANGULAR_EDGE : PROG_ANGULAR;
+        if (act) {
+            const int angle = intra_angle(mode), inv = angle < 0 ? intra_inv_angle(mode) : 0, sg = mode >= 18 ? 1 : -1;
+            const int al = mode >= 18 ? y : x, ac = mode >= 18 ? x : y;
+            const int prod = (al + 1) * angle, idx = prod >> 5, fact = prod & 31;
+            const int k0 = ac + idx + 1, k1 = k0 + 1;
+            const int p0 = k0 >= 0 ? k0 : -((k0 * inv + 128) >> 8), p1 = k1 >= 0 ? k1 : -((k1 * inv + 128) >> 8);
+            if (edge_tu && ((mode == 26 && x == 0) || (mode == 10 && y == 0))) {
+                w0 = cell(mode == 26 ? POS_TOP(0) : POS_LEFT(0));
+                w1 = cell(mode == 26 ? POS_LEFT(y) : POS_TOP(x));
+                w2 = cell(2 * n);
+                w3 = 1;
+            } else {
+                w0 = cell(2 * n + sg * p0);
+                w1 = fact ? cell(2 * n + sg * p1) : w0; /* weight 0: any cell does (the true one may lie past the array) */
+                w2 = (unsigned)fact;
+            }
+        }
+    }
+#undef POS_LEFT
+#undef POS_TOP
+    const unsigned long long any_out = __builtin_amdgcn_ballot_w64(outside);
+    if (__builtin_amdgcn_ballot_w64(!ok)) { /* a neighbour the tile layout has no cell for: the generic body */
+        if (lane == 0) a.sched[(size_t)k * 3 + 1] = generic;
+        return;
+    }
+    const uint32_t d_first = a.desc_off[cidx] + (uint32_t)y0 * (uint32_t)a.desc_w[cidx] + (uint32_t)x0;
+    if (act) a.desc[d_first + (uint32_t)y * (uint32_t)a.desc_w[cidx] + (uint32_t)x] = make_uint2(w0 | (w1 << 16), w2 | (w3 << 16));
+    if (lane == 0) {
+        u32x4 q1;
+        q1.x = kind | (lg == 3 ? PK_LG3 : 0u) | ((flags & 2) ? PK_RES : 0u) | (any_out ? PK_OUTSIDE : 0u) | (((q2.y >> 8) & 1) ? PK_SIGNAL : 0u) |
+               ((q2.y & 0xff) ? PK_WAIT : 0u) | ((uint32_t)(2 * (TILE_ORIGIN + (y0 - wy0) * TILE_STRIDE + (x0 - wx0))) << 16);
+        if (kind != PROG_ANGULAR || (q1.x & (PK_OUTSIDE | PK_SIGNAL | PK_WAIT))) q1.x |= PK_SLOW;
+        q1.y = (flags & 2) ? q0.z * 2u : PROG_NO_RESIDUAL;
+        q1.z = d_first * 8u;
+        q1.w = (uint32_t)(y0 * a.stride[cidx] + x0) * 2u;
+        a.sched[(size_t)k * 3 + 1] = q1;
+    }
 }
 
 __device__ __forceinline__ void intra_tu_g_any(const HevcIntraArgs &a, const IntraSlot &t, const int lane, int *s, int *s2, short *R,
@@ -682,12 +902,11 @@ __global__ __launch_bounds__(256) void k_hevc_intra(HevcIntraArgs a)
 #define SLOT_CHUNK 64
 
 /* slot words -> wave-uniform registers.  q0 = first half of the TU record, q2 = the schedule's own words */
+#define SGPR(v) ((unsigned)__builtin_amdgcn_readfirstlane((int)(v)))
 __device__ __forceinline__ IntraSlot decode_slot(const u32x4 q0, const u32x4 q2)
 {
-#define SGPR(v) ((unsigned)__builtin_amdgcn_readfirstlane((int)(v)))
     const unsigned d0 = SGPR(q0.x), d1 = SGPR(q0.y), d2 = SGPR(q0.z), d3 = SGPR(q0.w);
     const unsigned d8 = SGPR(q2.x), d9 = SGPR(q2.y), d10 = SGPR(q2.z), d11 = SGPR(q2.w);
-#undef SGPR
     IntraSlot sl;
     sl.x = d0 & 0xffff; sl.y = d0 >> 16;
     sl.lg = d1 & 0xff; sl.cidx = (d1 >> 8) & 0xff; sl.mode = (d1 >> 16) & 0xff; sl.flags = d1 >> 24;
@@ -699,13 +918,19 @@ __device__ __forceinline__ IntraSlot decode_slot(const u32x4 q0, const u32x4 q2)
 
 __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
 {
-    __shared__ short tile[64 * TILE_STRIDE];
+    __shared__ short tile[TILE_CELLS];
     __shared__ int nbA[NB_MAX], nbB[NB_MAX];
     __shared__ __attribute__((aligned(16))) short resl[2][32 * 32];
-    __shared__ u32x4 slots[SLOT_CHUNK * 3];
+    __shared__ u32x4 slots[(SLOT_CHUNK + 2) * 3];
     const int lane = threadIdx.x;
     uint32_t *flags = a.ctrl + 4;
     int n_groups = a.n_groups;
+    if (lane == 0) {
+        tile[TILE_CONST_Y] = (short)(1 << (a.bitdepth_y - 1));
+        tile[TILE_CONST_C] = (short)(1 << (a.bitdepth_c - 1));
+        tile[TILE_ZERO] = 0;
+    }
+    wave_sync();
     if (a.plan_result) {
         /* the schedule was built by the kernels in front of this one on the same stream; nobody on the host has looked
          * at it.  A list the device planner refuses (groups that are not contiguous runs of the decode order for this
@@ -724,7 +949,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                     const uint32_t blk = (c == 0 ? a.jt_boff[0] : (c == 1 ? a.jt_boff[1] : a.jt_boff[2])) +
                                          (uint32_t)(tp->y >> 2) * (uint32_t)(c == 0 ? a.jt_bw[0] : (c == 1 ? a.jt_bw[1] : a.jt_bw[2])) + (uint32_t)(tp->x >> 2);
                     u32x4 q = {0u, 0u, (uint32_t)(base + k), blk * JT_STRIDE}; /* no waits, no flag, no tile */
-                    if (part < 2) q = ((const u32x4 *)tp)[part];
+                    if (part == 0) q = ((const u32x4 *)tp)[0];
                     slots[i] = q;
                 }
                 wave_sync();
@@ -743,95 +968,209 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
             return;
         }
     }
-    for (;;) {
+    const __amdgpu_buffer_rsrc_t desc_rs = ffhip_rsrc(a.desc, 0xffffffffu), res_rs = ffhip_rsrc(a.residual, PROG_NO_RESIDUAL);
+    const int cell_lane4 = 2 * ((lane >> 2) * TILE_STRIDE + (lane & 3)), cell_lane8 = 2 * ((lane >> 3) * TILE_STRIDE + (lane & 7));
+    bool dead = false; /* a wave that gave up waiting (bounded spin): leaves through the loop heads, not from inside them */
+    while (!dead) {
         unsigned ticket = 0;
         if (lane == 0) ticket = __hip_atomic_fetch_add(&a.ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
-        if (ticket >= (unsigned)n_groups) return;
+        if (ticket >= (unsigned)n_groups) break;
         const u32x4 g = a.groups[ticket];
-        const int wl = (int)g.z;
+        GroupCtx gc;
+        gc.wl = (int)g.z;
 #ifdef FFHIP_INTRA_TRACE
         if (a.trace && lane == 0) a.trace[8 * a.n_tus + ticket] = TRACE_NOW();
 #endif
-        for (unsigned base = 0; base < g.y; base += SLOT_CHUNK) {
+        for (unsigned base = 0; base < g.y && !dead; base += SLOT_CHUNK) {
             const int m = (int)(g.y - base < SLOT_CHUNK ? g.y - base : SLOT_CHUNK);
             for (int i = lane; i < 3 * m; i += 64) slots[i] = a.sched[(size_t)(g.x + base) * 3 + i];
+            if (lane == 0) { /* behind the last slot: sentinels (the fetch runs two TUs ahead) the run of plain programs below stops at */
+                const u32x4 end = {PK_SLOW | PK_END, PROG_NO_RESIDUAL, 0u, 0u};
+                slots[3 * m + 1] = end;
+                slots[3 * m + 4] = end;
+            }
             wave_sync();
-            IntraSlot cur = decode_slot(slots[0], slots[2]);
+            if (base == 0) { /* the group's plane and window, from its first TU */
+                const unsigned d0 = SGPR(slots[0].x), d1 = SGPR(slots[0].y);
+                gc.cidx = (int)((d1 >> 8) & 0xff);
+                gc.wx0 = (int)(((d0 & 0xffff) >> gc.wl) << gc.wl);
+                gc.wy0 = (int)(((d0 >> 16) >> gc.wl) << gc.wl);
+                gc.stride = gc.cidx == 0 ? a.stride[0] : (gc.cidx == 1 ? a.stride[1] : a.stride[2]);
+                gc.maxv = (1 << (gc.cidx == 0 ? a.bitdepth_y : a.bitdepth_c)) - 1;
+                gc.plane_rs = ffhip_rsrc(gc.cidx == 0 ? a.plane[0] : (gc.cidx == 1 ? a.plane[1] : a.plane[2]), 0xffffffffu);
+                const int dw = gc.cidx == 0 ? a.desc_w[0] : (gc.cidx == 1 ? a.desc_w[1] : a.desc_w[2]);
+                gc.plane_lane[0] = 2 * ((lane >> 2) * gc.stride + (lane & 3));
+                gc.plane_lane[1] = 2 * ((lane >> 3) * gc.stride + (lane & 7));
+                gc.desc_lane[0] = 8 * ((lane >> 2) * dw + (lane & 3));
+                gc.desc_lane[1] = 8 * ((lane >> 3) * dw + (lane & 7));
+            }
+            /* Fetched TWO TUs ahead (an L2 hit takes longer than a small TU): the slot's program words, the pixel words
+             * and the pixel's residual of EVERY TU (a generic TU's slot points them at nothing) -- straight-line code: a
+             * taken branch costs a lone wave as much as eight instructions (tests/tools/microbench_lone_wave.hip).  Two
+             * register sets, A for the TU at hand and B for the one behind it; the run of common TUs below is unrolled
+             * by two so that they never move.  Fetched ONE TU ahead, behind one unlikely branch: what the rest needs -- a
+             * generic TU's slot, residual block and substitution table, the flags to poll, the table of a program that
+             * reads halo cells. */
+            ProgSlot psA, psB;
+            ProgPrefetch ppA, ppB;
+            IntraSlot cur;
             ResPrefetch rp;
             JPrefetch jp;
-            fetch_residual_g(a, cur, lane, rp);
-            fetch_jtable(a, cur, lane, jp);
-            /* which flag this lane polls for the TU: fetched with the slot, one TU ahead like the residual (fetched at
-             * the wait it was a dependent load in front of the first poll of every cross-group hop) */
-            uint32_t widx = cur.wait_count ? a.wait_idx[cur.wait_begin + (lane < (int)cur.wait_count ? lane : 0)] : 0;
-            for (int k = 0; k < m; k++) {
-                /* the next slot's words leave LDS now and are decoded behind this TU's body */
-                const int kn = k + 1 < m ? k + 1 : k;
-                const u32x4 nq0 = slots[3 * kn], nq2 = slots[3 * kn + 2];
+            uint32_t widx = 0;
+#define PREFETCH_PROGRAM(ps, pp, kk) do { \
+                const u32x4 q1_ = slots[3 * (kk) + 1]; \
+                ps.packed = SGPR(q1_.x); ps.res_off = SGPR(q1_.y); ps.desc_off = SGPR(q1_.z); ps.plane_off = SGPR(q1_.w); \
+                const bool big_ = (ps.packed & PK_LG3) != 0; \
+                if (big_ || lane < 16) { \
+                    const unsigned long long dd_ = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(desc_rs, big_ ? gc.desc_lane[1] : gc.desc_lane[0], (int)ps.desc_off, 0)); \
+                    pp.d.x = (unsigned)dd_; pp.d.y = (unsigned)(dd_ >> 32); \
+                    /* a TU without residual has res_off = PROG_NO_RESIDUAL, the end of the resource: the load returns 0 */ \
+                    pp.res = (short)__builtin_amdgcn_raw_buffer_load_b16(res_rs, 2 * lane + (int)ps.res_off, 0, 0); \
+                } } while (0)
+            /* for a TU that is not a plain program: its slot, and what it reads besides the pixel words */
+            auto fetch_extras = [&](const ProgSlot &ps, const int j) {
+                cur = decode_slot(slots[3 * j], slots[3 * j + 2]);
+                if (PK_KIND(ps.packed) == PROG_GENERIC) {
+                    fetch_jtable(a, cur, lane, jp);
+                    fetch_residual_g(a, cur, lane, rp);
+                } else if (ps.packed & PK_OUTSIDE) {
+                    fetch_jtable(a, cur, lane, jp);
+                }
+                if (cur.wait_count) widx = a.wait_idx[cur.wait_begin + (lane < (int)cur.wait_count ? lane : 0)];
+            };
+#define PLAIN_PROGRAM(ps, pp) do { \
+                const bool big_ = (ps.packed & PK_LG3) != 0; \
+                if (big_ || lane < 16) { \
+                    const unsigned a0_ = pp.d.x & 0xffffu, a1_ = pp.d.x >> 16; \
+                    const int f_ = (int)(pp.d.y & 0xffffu); \
+                    const int r0_ = LDS_U16(a0_), r1_ = LDS_U16(a1_); \
+                    const int v_ = ((32 - f_) * r0_ + f_ * r1_ + 16) >> 5; \
+                    const short rec_ = (short)clip3i(0, gc.maxv, (int)(short)(v_ & 0xffff) + (int)pp.res); \
+                    *(short *)((char *)tile + (ps.packed >> 16) + (big_ ? cell_lane8 : cell_lane4)) = rec_; \
+                    __builtin_amdgcn_raw_buffer_store_b16(rec_, gc.plane_rs, big_ ? gc.plane_lane[1] : gc.plane_lane[0], (int)SGPR(ps.plane_off), FFHIP_AUX_SC1); \
+                } } while (0)
+#define SWAP_SETS() do { const ProgSlot ts_ = psA; psA = psB; psB = ts_; const ProgPrefetch tp_ = ppA; ppA = ppB; ppB = tp_; } while (0)
 #ifdef FFHIP_INTRA_TRACE
-                const unsigned long long tr0 = TRACE_NOW();
+#define TRACE_TU_BEGIN(ps) const unsigned long long tr0 = TRACE_NOW(); unsigned long long tr1 = tr0; \
+    const unsigned tr_kind = PK_KIND(ps.packed) | ((ps.packed & PK_OUTSIDE) ? 8u : 0u), tr_lg = PK_KIND(ps.packed) ? ((ps.packed & PK_LG3) ? 3u : 2u) : cur.lg
+#define TRACE_TU_END() do { if (a.trace && lane == 0) { \
+        unsigned long long *tr = a.trace + 8 * (size_t)(g.x + base + k); /* by schedule slot */ \
+        tr[0] = tr0; tr[1] = tr1; tr[2] = TRACE_NOW(); \
+        tr[3] = ((unsigned long long)(tr_kind | (tr_lg << 4)) << 56) | ((unsigned long long)ticket << 32) | ((unsigned long long)blockIdx.x << 12) | (unsigned)(base + k); \
+        tr[4] = g_stamp[0]; tr[5] = g_stamp[1]; tr[6] = g_stamp[2]; tr[7] = g_stamp[3]; } } while (0)
+#else
+#define TRACE_TU_BEGIN(ps) do { } while (0)
+#define TRACE_TU_END() do { } while (0)
 #endif
-                if (cur.wait_count) { /* wait for the TUs of other groups this one reads (at most 64 of them) */
-                    const uint32_t *fp = flags + widx;
-                    int spins = 0;
-                    for (;;) {
-                        const unsigned done = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (__builtin_amdgcn_ballot_w64(done == 0) == 0) break;
-                        if (++spins > SPIN_LIMIT || __hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                            if (lane == 0) {
-                                __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                __hip_atomic_store(a.async_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            int k = 0;
+            PREFETCH_PROGRAM(psA, ppA, 0);
+            PREFETCH_PROGRAM(psB, ppB, 1);
+            bool have_extras = false; /* the extras of TU k (set A) are in cur / rp / jp / widx, or on their way */
+            for (;;) {
+                /* invariant: set A = TU k, set B = TU k + 1.
+                 * The run of common TUs: angular programs with nothing to wait for, nobody to tell and no halo cell.
+                 * It goes on while the TU at hand AND the one behind it are such (nothing but the two register sets is
+                 * carried round the loop); the sentinels behind the last slot end it */
+                while (__builtin_expect(((psA.packed | psB.packed) & PK_SLOW) == 0, 1)) {
+                    {
+                        TRACE_TU_BEGIN(psA);
+                        PLAIN_PROGRAM(psA, ppA);
+                        TRACE_TU_END();
+                    }
+                    ++k;
+                    PREFETCH_PROGRAM(psA, ppA, k + 1);
+                    {
+                        TRACE_TU_BEGIN(psB);
+                        PLAIN_PROGRAM(psB, ppB);
+                        TRACE_TU_END();
+                    }
+                    ++k;
+                    PREFETCH_PROGRAM(psB, ppB, k + 1);
+                }
+                if (!(psA.packed & PK_SLOW)) {
+                    /* a plain TU in front of one that is not: the other's extras leave now, one TU ahead */
+                    if (!(psB.packed & PK_END)) fetch_extras(psB, k + 1);
+                    {
+                        TRACE_TU_BEGIN(psA);
+                        PLAIN_PROGRAM(psA, ppA);
+                        TRACE_TU_END();
+                    }
+                    ++k;
+                    PREFETCH_PROGRAM(psA, ppA, k + 1);
+                    SWAP_SETS();
+                    have_extras = true;
+                }
+                if (psA.packed & PK_END) break;
+                if (!have_extras) fetch_extras(psA, k); /* only the first slot of a chunk comes here without them */
+                {
+                    const ProgSlot &ps = psA;
+                    const ProgPrefetch &pp = ppA;
+                    TRACE_TU_BEGIN(ps);
+                    const bool is_prog = PK_KIND(ps.packed) != PROG_GENERIC;
+                    if (cur.wait_count) { /* wait for the TUs of other groups this one reads (at most 64 of them) */
+                        const uint32_t *fp = flags + widx;
+                        int spins = 0;
+                        for (;;) {
+                            const unsigned done = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (__builtin_amdgcn_ballot_w64(done == 0) == 0) break;
+                            if (++spins > SPIN_LIMIT || SGPR(__hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                                if (lane == 0) {
+                                    __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    __hip_atomic_store(a.async_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                }
+                                dead = true;
+                                break;
                             }
-                            return;
-                        }
 #ifndef FFHIP_POLL_FAST
 #define FFHIP_POLL_FAST 16
 #endif
 #ifndef FFHIP_POLL_SLOW_SLEEP
 #define FFHIP_POLL_SLOW_SLEEP 16
 #endif
-                        if (spins < FFHIP_POLL_FAST) __builtin_amdgcn_s_sleep(1);
-                        else __builtin_amdgcn_s_sleep(FFHIP_POLL_SLOW_SLEEP); /* far from ready: poll about once per microsecond */
+                            if (spins < FFHIP_POLL_FAST) __builtin_amdgcn_s_sleep(1);
+                            else __builtin_amdgcn_s_sleep(FFHIP_POLL_SLOW_SLEEP); /* far from ready: poll about once per microsecond */
+                        }
+                        if (dead) break;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* ordering only: no cache-wide invalidate */
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* ordering only: no cache-wide invalidate */
-                }
 #ifdef FFHIP_INTRA_TRACE
-                const unsigned long long tr1 = TRACE_NOW();
+                    tr1 = TRACE_NOW();
 #endif
-                intra_tu_g_any(a, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, wl);
-                if (cur.signal) { /* somebody outside the group reads this TU: publish it once its stores have completed */
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* compiler ordering; no L2-wide write-back */
-                    /* the fence alone lowers to s_waitcnt lgkmcnt(0): the flag must not overtake the sample stores
-                     * (MI355X_MICROARCH.md: every storing wave drains its vector-memory counter before it signals).
-                     * Sending the flag one TU later instead -- when the next residual, fetched behind these stores,
-                     * has been consumed -- was measured no faster: the reader waits for the flag either way */
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0 && (int)cur.tu_index != a.debug_withhold)
-                        __hip_atomic_store(flags + cur.tu_index, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-#ifdef FFHIP_INTRA_TRACE
-                if (a.trace && lane == 0) {
-                    unsigned long long *tr = a.trace + 8 * (size_t)cur.tu_index;
-                    tr[0] = tr0; tr[1] = tr1; tr[2] = TRACE_NOW();
-                    tr[3] = ((unsigned long long)ticket << 32) | ((unsigned long long)blockIdx.x << 12) | (unsigned)(base + k);
-                    tr[4] = g_stamp[0]; tr[5] = g_stamp[1]; tr[6] = g_stamp[2]; tr[7] = g_stamp[3];
-                }
-#endif
-                wave_sync(); /* the next TU reuses the neighbour scratch and reads the tile this one wrote */
-                if (k + 1 < m) {
-                    /* issued behind this TU's stores and consumed half-way into the next TU: the in-order
-                     * vmcnt wait there then covers nothing younger than this fetch */
-                    cur = decode_slot(nq0, nq2);
-                    fetch_jtable(a, cur, lane, jp);
-                    fetch_residual_g(a, cur, lane, rp);
-                    if (cur.wait_count) widx = a.wait_idx[cur.wait_begin + (lane < (int)cur.wait_count ? lane : 0)];
+                    if (is_prog) {
+                        STAMP(0);
+                        if (ps.packed & PK_OUTSIDE) intra_program_halo(gc, (int)cur.x, (int)cur.y, 1 << cur.lg, lane, jp.j[0], tile);
+                        STAMP(1); STAMP(2);
+                        if (ps.packed & PK_LG3) intra_program<3>(a, gc, ps, lane, pp, tile, cell_lane8);
+                        else intra_program<2>(a, gc, ps, lane, pp, tile, cell_lane4);
+                        STAMP(3);
+                    } else {
+                        intra_tu_g_any(a, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, gc.wl);
+                    }
+                    if (cur.signal) { /* somebody outside the group reads this TU: publish it once its stores have completed */
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* compiler ordering; no L2-wide write-back */
+                        /* the fence alone lowers to s_waitcnt lgkmcnt(0): the flag must not overtake the sample stores
+                         * (MI355X_MICROARCH.md: every storing wave drains its vector-memory counter before it signals).
+                         * Sending the flag one TU later instead -- when the next residual, fetched behind these stores,
+                         * has been consumed -- was measured no faster: the reader waits for the flag either way */
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lane == 0 && (int)cur.tu_index != a.debug_withhold)
+                            __hip_atomic_store(flags + cur.tu_index, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (!is_prog) wave_sync(); /* the next TU reuses the neighbour scratch (a program touches only the tile, in order) */
+                    TRACE_TU_END();
+                    ++k;
+                    PREFETCH_PROGRAM(psA, ppA, k + 1); /* set A: TU k + 1, set B: TU k */
+                    SWAP_SETS();
+                    have_extras = (psA.packed & (PK_SLOW | PK_END)) == PK_SLOW;
+                    if (have_extras) fetch_extras(psA, k); /* behind this TU's stores, one TU ahead like the programs of the run */
                 }
             }
             wave_sync(); /* slots[] is about to be overwritten */
         }
     }
 }
+#undef SGPR
 
 /* ------------------------------------------------------------------------ host */
 
@@ -1187,6 +1526,25 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
         a.jt_boff[c] = ja.boff[c];
     }
     const size_t w_jt = (jt_blocks * JT_STRIDE + 256 + 3) / 4; /* padded: the kernel fetches 64 / 192 entries per TU whatever its size */
+    /* the per-pixel programs: 8 bytes per sample of the planes in use */
+    ProgArgs pa = {};
+    size_t desc_px = 0;
+    for (int c = 0; c < 3; c++) {
+        pa.desc_w[c] = pwc[c];
+        pa.desc_off[c] = (uint32_t)desc_px;
+        if (pwc[c] > 0) desc_px += (size_t)pwc[c] * (size_t)ph[c];
+        a.desc_w[c] = pa.desc_w[c];
+        a.desc_off[c] = pa.desc_off[c];
+    }
+    const size_t w_desc = desc_px * 2 + 2;
+    auto enqueue_programs = [&](uint32_t *words, const int win[3], size_t n_slots) {
+        pa.sched = (u32x4 *)a.sched; pa.n_slots = (uint32_t)n_slots; pa.jt = a.jt;
+        pa.desc = (uint2 *)(((uintptr_t)words + 7) & ~(uintptr_t)7);
+        for (int c = 0; c < 3; c++) { pa.wl[c] = win[c]; pa.stride[c] = a.stride[c]; }
+        pa.plan_result = a.plan_result; pa.wait_cap = a.wait_cap;
+        a.desc = pa.desc;
+        hipLaunchKernelGGL(k_hevc_intra_program, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, st, pa);
+    };
     auto enqueue_jtable = [&](uint32_t *words) {
         ja.tus = d_tus; ja.n = (uint32_t)n_tus; ja.jt = (uint8_t *)words;
         a.jt = ja.jt;
@@ -1205,13 +1563,12 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
              * the host, from the list alone: the largest one (up to the requested) whose groups are contiguous runs of
              * the decode order -- a 16x16 coding tree block stream needs 16, and finding that out on the device would
              * cost a round trip. */
-            /* default window: 32x32 for lists of small TUs, 64x64 when the TUs are large -- a group start costs a chain of
-             * dependent loads (ticket, group record, slots, wait list, flags, neighbours: ~3 us) that a 32x32 TU or four
-             * 16x16 ones do not amortise: SURVEY 8d's config-5 mix at 8K takes 12.5 ms with 32, 8.5 ms with 64; the random
-             * quadtree down to 4x4 is 22 ms either way at 8K and 10 % faster with 32 at 1080p (tests/tools/bench_intra_c5.py) */
-            const long long luma_area = (long long)pw[0] * ph[0];
-            const bool large_tus = n_tus * 4096 < 48 * luma_area; /* fewer than 48 TUs (all planes) per 64x64 luma area */
-            int wl = we ? atoi(we) : (large_tus ? 6 : FFHIP_HEVC_INTRA_WINDOW_LOG2);
+            /* default window: 64x64, one group per coding tree block.  A group start costs a chain of dependent loads
+             * (ticket, group record, slots, wait list, flags: ~3 us) and every window edge makes halo TUs; with the small
+             * TUs running as per-pixel programs the longer serial walk through a 64x64 block costs less than that
+             * (8K random quadtree: 14.8 ms against 17.3 with 32x32; the config-5 mix 8.1 against 12.0; 1080p and smaller
+             * pictures are indifferent -- tests/tools/bench_intra_c5.py, bench_intra_sizes.py) */
+            int wl = we ? atoi(we) : 6;
             wl = wl < 3 ? 3 : (wl > 6 ? 6 : wl);
             const int cs = (pw[1] > 0 && pw[1] * 2 <= pw[0] + 1) ? 1 : 0;
             for (; wl > 3; wl--) {
@@ -1220,9 +1577,10 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             }
             const int win[3] = {wl, wl - cs, wl - cs};
             const size_t w_plan = ffhip_hevc_plan_gpu_words(n_tus, pwc, ph, win), w_ctrl = 4 + (size_t)n_tus;
-            uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, w_plan + w_ctrl + 16 + w_jt);
+            uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, w_plan + w_ctrl + 16 + w_jt + w_desc);
             if (!g_work) return FFHIP_ENOMEM;
-            enqueue_jtable(g_work + ((w_plan + 3) & ~(size_t)3) + ((w_ctrl + 3) & ~(size_t)3));
+            uint32_t *const jt_words = g_work + ((w_plan + 3) & ~(size_t)3) + ((w_ctrl + 3) & ~(size_t)3);
+            enqueue_jtable(jt_words);
             int n_groups = 0;
             const int prc = ffhip_hevc_plan_gpu(d_tus, n_tus, pwc, ph, win, g_work, st, &a.sched, &a.groups, &a.wait_idx, &n_groups, &a.plan_result, &a.wait_cap);
             if (prc < 0) return prc;
@@ -1231,6 +1589,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             a.async_err = async_err;
             a.n_groups = 0;
             a.n_tus = n_tus;
+            enqueue_programs(jt_words + w_jt, win, (size_t)n_tus);
 #ifdef FFHIP_INTRA_TRACE
             a.trace = g_intra_trace;
 #endif
@@ -1239,15 +1598,17 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             return FFHIP_OK;
         }
         GroupPlan plan;
-        if (plan_with_window_search(h_tus, n_tus, pw, ph, we ? atoi(we) : FFHIP_HEVC_INTRA_WINDOW_LOG2, plan, nullptr, ja.boff)) {
+        int host_wl = 0;
+        if (plan_with_window_search(h_tus, n_tus, pw, ph, we ? atoi(we) : FFHIP_HEVC_INTRA_WINDOW_LOG2, plan, &host_wl, ja.boff)) {
             /* device image: sched | groups | wait | ctrl[4] + one done flag per TU */
             const size_t w_sched = plan.sched.size() * 4, w_groups = plan.groups.size() * 4, w_wait = plan.wait.size();
             const size_t w_ctrl = 4 + (size_t)n_tus;
             const size_t o_groups = w_sched, o_wait = o_groups + w_groups, o_ctrl = (o_wait + w_wait + 3) & ~(size_t)3;
             FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO); /* the work buffer may still be in use by an earlier call */
-            uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, o_ctrl + w_ctrl + 4 + w_jt);
+            uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, o_ctrl + w_ctrl + 4 + w_jt + w_desc);
             if (!g_work) return FFHIP_ENOMEM;
-            enqueue_jtable(g_work + ((o_ctrl + w_ctrl + 3) & ~(size_t)3));
+            uint32_t *const jt_words = g_work + ((o_ctrl + w_ctrl + 3) & ~(size_t)3);
+            enqueue_jtable(jt_words);
             FFHIP_CHECK(hipMemcpy(g_work, plan.sched.data(), w_sched * 4, hipMemcpyHostToDevice), FFHIP_EIO);
             FFHIP_CHECK(hipMemcpy(g_work + o_groups, plan.groups.data(), w_groups * 4, hipMemcpyHostToDevice), FFHIP_EIO);
             FFHIP_CHECK(hipMemcpy(g_work + o_wait, plan.wait.data(), w_wait * 4, hipMemcpyHostToDevice), FFHIP_EIO);
@@ -1258,6 +1619,11 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             a.ctrl = g_work + o_ctrl;
             a.async_err = async_err;
             a.n_groups = (int)plan.groups.size();
+            {
+                const int cs = (pw[1] > 0 && pw[1] * 2 <= pw[0] + 1) ? 1 : 0;
+                const int win[3] = {host_wl, host_wl - cs, host_wl - cs};
+                enqueue_programs(jt_words + w_jt, win, (size_t)n_tus);
+            }
             const unsigned wgs = (unsigned)std::min<size_t>(plan.groups.size(), max_waves); /* one wave each; waves loop over tickets */
             hipLaunchKernelGGL(k_hevc_intra_groups, dim3(wgs), dim3(64), 0, st, a);
             FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);

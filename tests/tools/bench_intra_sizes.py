@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""ffhip_hevc_intra_recon (planner kernels included) on random-quadtree pictures of several sizes, by scheduling window."""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from ffpic_amd import capi, synth
+dev = torch.device("cuda", 0)
+L = capi.require_device(0)
+st = torch.cuda.current_stream().cuda_stream
+e0, e1 = L.ffhip_event_create(), L.ffhip_event_create()
+out = {}
+for (W, H) in ((1920, 1088), (3840, 2176), (512, 512)):
+    tus, res = synth.hevc_intra_tus(W, H, seed=2)
+    dt = torch.from_numpy(tus.view(np.uint8).copy()).to(dev); dr = torch.from_numpy(res).to(dev)
+    py = torch.zeros((H, W), dtype=torch.int16, device=dev); pu = torch.zeros((H // 2, W // 2), dtype=torch.int16, device=dev); pv = torch.zeros_like(pu)
+    def run():
+        capi.check(L.ffhip_hevc_intra_recon(tus.ctypes.data, dt.data_ptr(), len(tus), dr.data_ptr(), py.data_ptr(), pu.data_ptr(), pv.data_ptr(), W, H, W, W // 2, H // 2, W // 2, 8, 8, st))
+    for wl in sys.argv[1:] or ["6", "5"]:
+        os.environ["FFHIP_HEVC_INTRA_WINDOW"] = wl
+        run(); capi.check(L.ffhip_stream_sync(st))
+        L.ffhip_event_record(e0, st)
+        for _ in range(5): run()
+        L.ffhip_event_record(e1, st)
+        capi.check(L.ffhip_stream_sync(st))
+        out[f"{W}x{H}_w{1 << int(wl)}"] = {"ms": round(L.ffhip_event_elapsed_ms(e0, e1) / 5, 3), "tus": int(len(tus))}
+print(json.dumps(out))

@@ -45,7 +45,8 @@ rec = tr[:8 * n].reshape(n, 8)
 tick = tr[8 * n:]
 t_begin, t_start, t_end, meta = rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3]
 assert (t_end > 0).all(), "some TU left no trace"
-ticket = (meta >> 32).astype(np.int64); wave = ((meta >> 12) & 0xfffff).astype(np.int64); kslot = (meta & 0xfff).astype(np.int64)
+tkind = ((meta >> 56) & 7).astype(np.int64); halo = ((meta >> 59) & 1).astype(np.int64)
+ticket = ((meta >> 32) & 0xffffff).astype(np.int64); wave = ((meta >> 12) & 0xfffff).astype(np.int64); kslot = (meta & 0xfff).astype(np.int64)
 T0 = tick[tick > 0].min()
 us = lambda t: (t - T0) / 100.0
 print(f"{which}: {n} TUs, {int(ticket.max()) + 1} groups, {len(np.unique(wave))} waves used, kernel span {us(t_end.max()):.1f} us")
@@ -86,6 +87,7 @@ def cross_deps(i):
 
 stage_names = ["gather", "filter", "residual", "predict+store", "publish"]
 stage = {l: np.zeros(5) for l in (2, 3, 4, 5)}
+pk = {}   # program TUs on the path: (size, kind, halo) -> [count, body ticks]
 cat = {"body": {2: 0, 3: 0, 4: 0, 5: 0}, "in-group": 0, "hand-off": 0, "start": 0}
 cnt = {"body": {2: 0, 3: 0, 4: 0, 5: 0}, "in-group": 0, "hand-off": 0, "start": 0}
 handoffs = []
@@ -94,6 +96,8 @@ steps = 0
 while cur >= 0:
     steps += 1
     cat["body"][int(lg[cur])] += int(t_end[cur] - t_start[cur]); cnt["body"][int(lg[cur])] += 1
+    if tkind[cur]:
+        e = pk.setdefault((int(lg[cur]), int(tkind[cur]), int(halo[cur])), [0, 0]); e[0] += 1; e[1] += int(t_end[cur] - t_start[cur])
     st4 = rec[cur, 4:8]
     stage[int(lg[cur])] += np.array([st4[0] - t_start[cur], st4[1] - st4[0], st4[2] - st4[1], st4[3] - st4[2], t_end[cur] - st4[3]], dtype=np.float64)
     cands = []
@@ -121,6 +125,9 @@ for l in (2, 3, 4, 5):
 for l in (2, 3, 4, 5):
     if cnt["body"][l]:
         print(f"    stages {1 << l:2d}x{1 << l:<2d} (us each): " + ", ".join(f"{nm} {stage[l][q] / cnt['body'][l] / 100.0:.2f}" for q, nm in enumerate(stage_names)))
+for key in sorted(pk):
+    print(f"    program {1 << key[0]}x{1 << key[0]} kind {key[1]} halo {key[2]}: {pk[key][0]:6d} TUs, {pk[key][1] / pk[key][0] / 100.0:.2f} us each")
+print(f"  programs overall: {int((tkind > 0).sum())} of {n} TUs")
 for k in ("in-group", "hand-off", "start"):
     if cnt[k]:
         print(f"  {k:9s}: {cnt[k]:6d} steps {cat[k] / 100.0:9.1f} us  ({cat[k] / cnt[k] / 100.0:.2f} us each)")

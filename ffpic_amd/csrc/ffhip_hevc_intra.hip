@@ -610,7 +610,7 @@ __device__ __forceinline__ void intra_tu_g(const HevcIntraArgs &a, const IntraSl
 #define PK_SIGNAL 64u
 #define PK_WAIT 128u
 #define PK_END 512u /* the sentinel behind a chunk's last slot */
-#define PK_SLOW 256u /* anything but a plain angular program: generic TU, other kinds, a wait, a flag to publish, halo cells */
+#define PK_SLOW 256u /* anything but a plain program: generic TU, a wait, a flag to publish, halo cells */
 #define PROG_NO_RESIDUAL 0xffffff00u /* res_off of a TU without residual = size of the residual buffer resource: reads 0 */
 struct ProgSlot {
     unsigned packed;    /* kind, flags above, bits 31:16 = LDS byte address of the TU's first sample in the tile */
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
         u32x4 q1;
         q1.x = kind | (lg == 3 ? PK_LG3 : 0u) | ((flags & 2) ? PK_RES : 0u) | (any_out ? PK_OUTSIDE : 0u) | (((q2.y >> 8) & 1) ? PK_SIGNAL : 0u) |
                ((q2.y & 0xff) ? PK_WAIT : 0u) | ((uint32_t)(2 * (TILE_ORIGIN + (y0 - wy0) * TILE_STRIDE + (x0 - wx0))) << 16);
-        if (kind != PROG_ANGULAR || (q1.x & (PK_OUTSIDE | PK_SIGNAL | PK_WAIT))) q1.x |= PK_SLOW;
+        if (q1.x & (PK_OUTSIDE | PK_SIGNAL | PK_WAIT)) q1.x |= PK_SLOW;
         q1.y = (flags & 2) ? q0.z * 2u : PROG_NO_RESIDUAL;
         q1.z = d_first * 8u;
         q1.w = (uint32_t)(y0 * a.stride[cidx] + x0) * 2u;
@@ -970,6 +970,11 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
     }
     const __amdgpu_buffer_rsrc_t desc_rs = ffhip_rsrc(a.desc, 0xffffffffu), res_rs = ffhip_rsrc(a.residual, PROG_NO_RESIDUAL);
     const int cell_lane4 = 2 * ((lane >> 2) * TILE_STRIDE + (lane & 3)), cell_lane8 = 2 * ((lane >> 3) * TILE_STRIDE + (lane & 7));
+    /* the run of plain programs never touches the exec mask (a branch over a load makes the compiler's wait counts
+     * pessimistic: it then waits for the loads it issued a moment ago): on a 4x4 TU lanes 16 .. 63 do what lane 0 does --
+     * same words, same residual, same value to the same addresses */
+    const int lane4 = lane < 16 ? lane : 0;
+    const int cell_alias4 = 2 * ((lane4 >> 2) * TILE_STRIDE + (lane4 & 3));
     bool dead = false; /* a wave that gave up waiting (bounded spin): leaves through the loop heads, not from inside them */
     while (!dead) {
         unsigned ticket = 0;
@@ -978,6 +983,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
         if (ticket >= (unsigned)n_groups) break;
         const u32x4 g = a.groups[ticket];
         GroupCtx gc;
+        int plane_alias4 = 0, desc_alias4 = 0;
         gc.wl = (int)g.z;
 #ifdef FFHIP_INTRA_TRACE
         if (a.trace && lane == 0) a.trace[8 * a.n_tus + ticket] = TRACE_NOW();
@@ -1004,6 +1010,8 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                 gc.plane_lane[1] = 2 * ((lane >> 3) * gc.stride + (lane & 7));
                 gc.desc_lane[0] = 8 * ((lane >> 2) * dw + (lane & 3));
                 gc.desc_lane[1] = 8 * ((lane >> 3) * dw + (lane & 7));
+                plane_alias4 = 2 * ((lane4 >> 2) * gc.stride + (lane4 & 3));
+                desc_alias4 = 8 * ((lane4 >> 2) * dw + (lane4 & 3));
             }
             /* Fetched TWO TUs ahead (an L2 hit takes longer than a small TU): the slot's program words, the pixel words
              * and the pixel's residual of EVERY TU (a generic TU's slot points them at nothing) -- straight-line code: a
@@ -1022,12 +1030,11 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                 const u32x4 q1_ = slots[3 * (kk) + 1]; \
                 ps.packed = SGPR(q1_.x); ps.res_off = SGPR(q1_.y); ps.desc_off = SGPR(q1_.z); ps.plane_off = SGPR(q1_.w); \
                 const bool big_ = (ps.packed & PK_LG3) != 0; \
-                if (big_ || lane < 16) { \
-                    const unsigned long long dd_ = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(desc_rs, big_ ? gc.desc_lane[1] : gc.desc_lane[0], (int)ps.desc_off, 0)); \
-                    pp.d.x = (unsigned)dd_; pp.d.y = (unsigned)(dd_ >> 32); \
-                    /* a TU without residual has res_off = PROG_NO_RESIDUAL, the end of the resource: the load returns 0 */ \
-                    pp.res = (short)__builtin_amdgcn_raw_buffer_load_b16(res_rs, 2 * lane + (int)ps.res_off, 0, 0); \
-                } } while (0)
+                const unsigned long long dd_ = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(desc_rs, big_ ? gc.desc_lane[1] : desc_alias4, (int)ps.desc_off, 0)); \
+                pp.d.x = (unsigned)dd_; pp.d.y = (unsigned)(dd_ >> 32); \
+                /* a TU without residual has res_off = PROG_NO_RESIDUAL, the end of the resource: the load returns 0 */ \
+                pp.res = (short)__builtin_amdgcn_raw_buffer_load_b16(res_rs, 2 * (big_ ? lane : lane4) + (int)ps.res_off, 0, 0); \
+                } while (0)
             /* for a TU that is not a plain program: its slot, and what it reads besides the pixel words */
             auto fetch_extras = [&](const ProgSlot &ps, const int j) {
                 cur = decode_slot(slots[3 * j], slots[3 * j + 2]);
@@ -1041,15 +1048,35 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
             };
 #define PLAIN_PROGRAM(ps, pp) do { \
                 const bool big_ = (ps.packed & PK_LG3) != 0; \
-                if (big_ || lane < 16) { \
-                    const unsigned a0_ = pp.d.x & 0xffffu, a1_ = pp.d.x >> 16; \
-                    const int f_ = (int)(pp.d.y & 0xffffu); \
-                    const int r0_ = LDS_U16(a0_), r1_ = LDS_U16(a1_); \
-                    const int v_ = ((32 - f_) * r0_ + f_ * r1_ + 16) >> 5; \
-                    const short rec_ = (short)clip3i(0, gc.maxv, (int)(short)(v_ & 0xffff) + (int)pp.res); \
-                    *(short *)((char *)tile + (ps.packed >> 16) + (big_ ? cell_lane8 : cell_lane4)) = rec_; \
-                    __builtin_amdgcn_raw_buffer_store_b16(rec_, gc.plane_rs, big_ ? gc.plane_lane[1] : gc.plane_lane[0], (int)SGPR(ps.plane_off), FFHIP_AUX_SC1); \
-                } } while (0)
+                const unsigned a0_ = pp.d.x & 0xffffu, a1_ = pp.d.x >> 16, a2_ = pp.d.y & 0xffffu; \
+                const int r0_ = LDS_U16(a0_), r1_ = LDS_U16(a1_); \
+                int v_; \
+                if (__builtin_expect(PK_KIND(ps.packed) == PROG_ANGULAR, 1)) { \
+                    v_ = ((32 - (int)a2_) * r0_ + (int)a2_ * r1_ + 16) >> 5; \
+                } else { /* the other kinds: rarer, behind one taken branch */ \
+                    const unsigned a3_ = pp.d.y >> 16, kind_ = PK_KIND(ps.packed); \
+                    const int lg_ = big_ ? 3 : 2, n_ = 1 << lg_, le_ = big_ ? lane : lane4; \
+                    if (kind_ == PROG_PLANAR) { \
+                        const int x_ = le_ & (n_ - 1), y_ = le_ >> lg_; \
+                        const int r2_ = LDS_U16(a2_), r3_ = LDS_U16(a3_); \
+                        v_ = ((n_ - 1 - x_) * r0_ + (x_ + 1) * r2_ + (n_ - 1 - y_) * r1_ + (y_ + 1) * r3_ + n_) >> (lg_ + 1); \
+                    } else if (kind_ == PROG_DC) { \
+                        const int dc_ = (__builtin_amdgcn_readfirstlane(row_sum16(LDS_U16(a2_))) + n_) >> (lg_ + 1); \
+                        v_ = dc_; \
+                        if (a3_ == 1) v_ = (r0_ + 2 * dc_ + r1_ + 2) >> 2; \
+                        else if (a3_ == 2) v_ = (r1_ + 3 * dc_ + 2) >> 2; \
+                        else if (a3_ == 3) v_ = (r0_ + 3 * dc_ + 2) >> 2; \
+                    } else { \
+                        const int r2_ = LDS_U16(a2_); \
+                        const int vn_ = ((32 - (int)a2_) * r0_ + (int)a2_ * r1_ + 16) >> 5; \
+                        const int ve_ = clip3i(0, (1 << a.bitdepth_y) - 1, r0_ + ((r1_ - r2_) >> 1)); \
+                        v_ = a3_ ? ve_ : vn_; \
+                    } \
+                } \
+                const short rec_ = (short)clip3i(0, gc.maxv, (int)(short)(v_ & 0xffff) + (int)pp.res); \
+                *(short *)((char *)tile + (ps.packed >> 16) + (big_ ? cell_lane8 : cell_alias4)) = rec_; \
+                __builtin_amdgcn_raw_buffer_store_b16(rec_, gc.plane_rs, big_ ? gc.plane_lane[1] : plane_alias4, (int)SGPR(ps.plane_off), FFHIP_AUX_SC1); \
+                } while (0)
 #define SWAP_SETS() do { const ProgSlot ts_ = psA; psA = psB; psB = ts_; const ProgPrefetch tp_ = ppA; ppA = ppB; ppB = tp_; } while (0)
 #ifdef FFHIP_INTRA_TRACE
 #define TRACE_TU_BEGIN(ps) const unsigned long long tr0 = TRACE_NOW(); unsigned long long tr1 = tr0; \

@@ -87,8 +87,8 @@ def test_give_up_path_reports_eio_and_the_library_recovers(monkeypatch):
     L = capi.require_device()
     w, h = 256, 192
     tus, res = synth.hevc_intra_tus(w, h, seed=91)
-    # a TU of the first coding tree block that later groups read: the last luma TU of the first 32x32 window
-    first = [i for i, t in enumerate(tus) if t["cidx"] == 0 and t["x"] < 32 and t["y"] < 32]
+    # a TU of the first coding tree block that later groups read: the last luma TU of the first 64x64 window (the default scheduling window)
+    first = [i for i, t in enumerate(tus) if t["cidx"] == 0 and t["x"] < 64 and t["y"] < 64]
     victim = first[-1]
     monkeypatch.setenv("FFHIP_DEBUG_WITHHOLD_TU", str(victim))
     with pytest.raises(capi.FfhipError) as ei:

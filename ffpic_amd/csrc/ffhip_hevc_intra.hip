@@ -87,6 +87,14 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+__device__ __forceinline__ int row_sum16(int v) /* every lane: the sum over its row of 16 lanes */
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);  /* quad_perm [1,0,3,2] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);  /* quad_perm [2,3,0,1] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false); /* row_half_mirror    */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false); /* row_mirror         */
+    return v;
+}
 __device__ __forceinline__ int clip3i(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 
@@ -533,53 +541,89 @@ __device__ __forceinline__ void intra_tu_g(const HevcIntraArgs &a, const IntraSl
     }
 
     STAMP(2);
-    /* ---- 4. prediction (the reference reads the neighbours as uint16_t) ---- */
+    /* ---- 4 + 5. prediction and reconstruction, 64 samples a pass (the reference reads the neighbours as uint16_t and
+     * stores the prediction as int16 before the add).  One loop per KIND of mode, chosen once: the first form decided
+     * planar / DC / angular, the direction and the sign of the angle again for every pass, with 32-bit multiplies by
+     * +-1 and 64-bit address arithmetic in between -- ~75 instructions and several taken branches a pass.  Here a pass
+     * of the angular loop is ~30 instructions: what changes from pass to pass moves by additions (rows per pass are
+     * fixed), 24-bit multiplies, tile and plane offsets by immediate / one add. ---- */
 #define U16(v) ((int)((unsigned)(v) & 0xffffu))
-    int dc = 0, angle = 0, inv = 0;
-    if (mode == 1) {
-        unsigned sum = 0;
-        for (int i = 0; i < n; i++) sum += (unsigned)U16(LEFT(i)) + (unsigned)U16(TOP(i));
-        dc = (int)((sum + (1u << lg)) >> (lg + 1));
-    } else if (mode >= 2) {
-        angle = intra_angle(mode);
-        if (angle < 0) inv = intra_inv_angle(mode);
-    }
-    const int sg = mode >= 18 ? 1 : -1; /* top row is the main reference: scan positions grow with the ref index */
-    const bool edge_ok = cidx == 0 && n < 32;
-    constexpr int pred_unroll = n * n <= 256 ? LANE_PASSES(n * n) : 4;
-#pragma unroll pred_unroll
-    for (int p = lane; p < n * n; p += 64) {
-        const int x = p & (n - 1), y = p >> lg;
-        int v;
-        if (mode == 0) {
-            v = ((n - 1 - x) * U16(LEFT(y)) + (x + 1) * U16(TOP(n)) + (n - 1 - y) * U16(TOP(x)) + (y + 1) * U16(LEFT(n)) + n) >> (lg + 1);
-        } else if (mode == 1) {
-            v = dc;
-            if (edge_ok && !(flags & 0x20)) {
-                if (x == 0 && y == 0) v = (U16(LEFT(0)) + 2 * dc + U16(TOP(0)) + 2) >> 2;
-                else if (y == 0) v = (U16(TOP(x)) + 3 * dc + 2) >> 2;
-                else if (x == 0) v = (U16(LEFT(y)) + 3 * dc + 2) >> 2;
-            }
-        } else {
-            const int al = mode >= 18 ? y : x, ac = mode >= 18 ? x : y; /* along / across the direction */
-            const int prod = (al + 1) * angle, idx = prod >> 5, fact = prod & 31;
-            const int k0 = ac + idx + 1, k1 = k0 + 1;
-            const int q0 = k0 >= 0 ? k0 : -((k0 * inv + 128) >> 8), q1 = k1 >= 0 ? k1 : -((k1 * inv + 128) >> 8);
-            /* fact == 0: the second tap has weight 0 (it may lie one past the array: any finite value does) */
-            v = ((32 - fact) * U16(s[2 * n + sg * q0]) + fact * U16(s[2 * n + sg * q1]) + 16) >> 5;
-            if (edge_ok && !(flags & 0x10)) {
-                if (mode == 26 && x == 0) v = clip3i(0, (1 << a.bitdepth_y) - 1, U16(TOP(0)) + ((U16(LEFT(y)) - U16(TOP(-1))) >> 1));
-                if (mode == 10 && y == 0) v = clip3i(0, (1 << a.bitdepth_y) - 1, U16(LEFT(0)) + ((U16(TOP(x)) - U16(TOP(-1))) >> 1));
+    {
+        constexpr int passes = n * n >= 64 ? n * n / 64 : 1, rows = n >= 8 ? 64 / n : 4; /* rows of the block per pass */
+        const bool edge_ok = cidx == 0 && n < 32;
+        const int maxv = (1 << bd) - 1;
+        const int x = lane & (n - 1), yl = lane >> lg; /* the lane's sample in pass 0; later passes: y = yl + pass * rows */
+        const bool whole_in_window = n <= wsz;         /* a TU starts in its window and is aligned to its size */
+        int goff = ((y0 + yl) * stride + x0 + x) * 2;  /* plane byte offset, stepped by gstep per pass */
+        const int gstep = rows * stride * 2;
+        short *const cellp = tile + TILE_ORIGIN + (y0 - wy0 + yl) * TILE_STRIDE + (x0 - wx0 + x);
+#define EMIT(v_, pass_) do { \
+            const int pr_ = (int)(short)((v_) & 0xffff); \
+            const int rs_ = has_res ? (int)R[lane + 64 * (pass_)] : 0; \
+            const short rec_ = (short)clip3i(0, maxv, pr_ + rs_); \
+            __builtin_amdgcn_raw_buffer_store_b16(rec_, prs, goff, 0, FFHIP_AUX_SC1); \
+            goff += gstep; \
+            if (whole_in_window || ((unsigned)(x0 + x - wx0) < (unsigned)wsz && (unsigned)(y0 + yl + (pass_) * rows - wy0) < (unsigned)wsz)) \
+                cellp[(pass_) * rows * TILE_STRIDE] = rec_; \
+        } while (0)
+        if (n >= 8 || lane < 16) {
+            if (mode == 0) {
+                const int tn = U16(TOP(n)), ln = U16(LEFT(n)), tx = U16(TOP(x));
+                const int fixed = (x + 1) * tn + n; /* the part of the sum that does not change from pass to pass */
+#pragma unroll
+                for (int pass = 0; pass < passes; pass++) {
+                    const int y = yl + pass * rows;
+                    const int v = ((n - 1 - x) * U16(LEFT(y)) + fixed + (n - 1 - y) * tx + (y + 1) * ln) >> (lg + 1);
+                    EMIT(v, pass);
+                }
+            } else if (mode == 1) {
+                /* the 2n-sample sum: one element per lane, added across the wave */
+                const int e = lane < n ? U16(LEFT(lane)) : (lane < 2 * n ? U16(TOP(lane - n)) : 0);
+                const int rsum = row_sum16(e); /* n = 4: lanes 8 .. 15 hold 0 */
+                int sum = __builtin_amdgcn_readlane(rsum, 0);
+                if (n >= 16) sum += __builtin_amdgcn_readlane(rsum, 16);
+                if (n == 32) sum += __builtin_amdgcn_readlane(rsum, 32) + __builtin_amdgcn_readlane(rsum, 48);
+                const int dc = (sum + n) >> (lg + 1);
+                const bool edge = edge_ok && !(flags & 0x20);
+                const int tx = edge ? U16(TOP(x)) : 0;
+#pragma unroll
+                for (int pass = 0; pass < passes; pass++) {
+                    int v = dc;
+                    if (edge) {
+                        const int y = yl + pass * rows;
+                        if (x == 0) v = y == 0 ? (U16(LEFT(0)) + 2 * dc + tx + 2) >> 2 : (U16(LEFT(y)) + 3 * dc + 2) >> 2;
+                        else if (pass == 0 && y == 0) v = (tx + 3 * dc + 2) >> 2;
+                    }
+                    EMIT(v, pass);
+                }
+            } else {
+                const int angle = intra_angle(mode), inv = angle < 0 ? intra_inv_angle(mode) : 0;
+                const bool vert = mode >= 18; /* the top row is the main reference: scan positions grow with the ref index */
+                const int sg = vert ? 1 : -1;
+                int al = vert ? yl : x, ac = vert ? x : yl; /* along / across the direction */
+                const int dal = vert ? rows : 0, dac = vert ? 0 : rows;
+                const bool e26 = edge_ok && !(flags & 0x10) && mode == 26, e10 = edge_ok && !(flags & 0x10) && mode == 10;
+                const int *const sc = s + 2 * n; /* the corner: ref[k] is sc[sg * k] for k >= 0 */
+#pragma unroll
+                for (int pass = 0; pass < passes; pass++) {
+                    const int prod = __mul24(al + 1, angle), idx = prod >> 5, fact = prod & 31;
+                    const int k0 = ac + idx + 1;
+                    int q0 = k0, q1 = k0 + 1;
+                    if (angle < 0) { /* 8.4.4.2.6: negative indices come from the other side through the inverse angle */
+                        q0 = k0 >= 0 ? k0 : -((__mul24(k0, inv) + 128) >> 8);
+                        q1 = k0 + 1 >= 0 ? k0 + 1 : -((__mul24(k0 + 1, inv) + 128) >> 8);
+                    }
+                    /* fact == 0: the second tap has weight 0 (it may lie one past the array: any finite value does) */
+                    int v = ((32 - fact) * U16(sc[__mul24(q0, sg)]) + fact * U16(sc[__mul24(q1, sg)]) + 16) >> 5;
+                    if (e26 && x == 0) v = clip3i(0, (1 << a.bitdepth_y) - 1, U16(TOP(0)) + ((U16(LEFT(yl + pass * rows)) - U16(TOP(-1))) >> 1));
+                    if (e10 && pass == 0 && yl == 0) v = clip3i(0, (1 << a.bitdepth_y) - 1, U16(LEFT(0)) + ((U16(TOP(x)) - U16(TOP(-1))) >> 1));
+                    EMIT(v, pass);
+                    al += dal;
+                    ac += dac;
+                }
             }
         }
-        /* ---- 5. reconstruct: pred is stored as int16 by the reference before the add ---- */
-        const int pr = (int)(short)(v & 0xffff);
-        const int rs = has_res ? (int)R[p] : 0;
-        int16_t *dp = plane + (long long)(y0 + y) * stride + x0 + x;
-        const short rec = (short)clip3i(0, (1 << bd) - 1, pr + rs);
-        __hip_atomic_store(dp, rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned tx = (unsigned)(x0 + x - wx0), ty = (unsigned)(y0 + y - wy0);
-        if (tx < (unsigned)wsz && ty < (unsigned)wsz) tile[TILE_ORIGIN + ty * TILE_STRIDE + tx] = rec;
+#undef EMIT
     }
     STAMP(3);
 #undef LEFT
@@ -628,14 +672,6 @@ struct GroupCtx {
     int cidx, stride, maxv, wl, wx0, wy0;
     int plane_lane[2], desc_lane[2]; /* per lane, 4x4 / 8x8: byte offset of the lane's pixel from the TU's first one */
 };
-__device__ __forceinline__ int row_sum16(int v) /* every lane: the sum over its row of 16 lanes */
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);  /* quad_perm [1,0,3,2] */
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);  /* quad_perm [2,3,0,1] */
-    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false); /* row_half_mirror    */
-    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false); /* row_mirror         */
-    return v;
-}
 #define LDS_U16(byte_addr) ((int)*(const unsigned short *)((const char *)tile + (byte_addr)))
 template <int LG>
 __device__ __forceinline__ void intra_program(const HevcIntraArgs &a, const GroupCtx &g, const ProgSlot &t, const int lane,

@@ -450,7 +450,7 @@ __device__ __forceinline__ void fetch_residual_g(const HevcIntraArgs &a, const I
 
 template <int LG>
 __device__ __forceinline__ void intra_tu_g(const HevcIntraArgs &a, const IntraSlot &t, const int lane, int *s, int *s2, short *R,
-                                           const ResPrefetch &rp, const JPrefetch &jp, short *tile, const int wl)
+                                           const ResPrefetch &rp, const JPrefetch &jp, short *tile, const int wl, const short *zero_block)
 {
     constexpr int n = 1 << LG, lg = LG, cnt = 4 * n + 1;
     const int x0 = (int)t.x, y0 = (int)t.y;
@@ -550,27 +550,29 @@ __device__ __forceinline__ void intra_tu_g(const HevcIntraArgs &a, const IntraSl
 #define U16(v) ((int)((unsigned)(v) & 0xffffu))
     {
         constexpr int passes = n * n >= 64 ? n * n / 64 : 1, rows = n >= 8 ? 64 / n : 4; /* rows of the block per pass */
+        constexpr int unroll = passes > 4 ? 4 : passes; /* 32x32: sixteen passes, four to a loop body (the kernel's code must stay inside the instruction cache) */
         const bool edge_ok = cidx == 0 && n < 32;
         const int maxv = (1 << bd) - 1;
         const int x = lane & (n - 1), yl = lane >> lg; /* the lane's sample in pass 0; later passes: y = yl + pass * rows */
-        const bool whole_in_window = n <= wsz;         /* a TU starts in its window and is aligned to its size */
         int goff = ((y0 + yl) * stride + x0 + x) * 2;  /* plane byte offset, stepped by gstep per pass */
         const int gstep = rows * stride * 2;
+        /* the window copy is written without asking whether the sample lies in the window: a TU larger than its window
+         * (it then starts at the window's origin) spills into cells right of and below the window that nobody reads --
+         * halo cells are row 0 and column 0 only -- and the layout has room for a 32x32 block from any window origin */
         short *const cellp = tile + TILE_ORIGIN + (y0 - wy0 + yl) * TILE_STRIDE + (x0 - wx0 + x);
+        const short *const Rr = has_res ? R + lane : zero_block + lane; /* no residual: a block of zeros, no branch per pass */
 #define EMIT(v_, pass_) do { \
             const int pr_ = (int)(short)((v_) & 0xffff); \
-            const int rs_ = has_res ? (int)R[lane + 64 * (pass_)] : 0; \
-            const short rec_ = (short)clip3i(0, maxv, pr_ + rs_); \
+            const short rec_ = (short)clip3i(0, maxv, pr_ + (int)Rr[64 * (pass_)]); \
             __builtin_amdgcn_raw_buffer_store_b16(rec_, prs, goff, 0, FFHIP_AUX_SC1); \
             goff += gstep; \
-            if (whole_in_window || ((unsigned)(x0 + x - wx0) < (unsigned)wsz && (unsigned)(y0 + yl + (pass_) * rows - wy0) < (unsigned)wsz)) \
-                cellp[(pass_) * rows * TILE_STRIDE] = rec_; \
+            cellp[(pass_) * rows * TILE_STRIDE] = rec_; \
         } while (0)
         if (n >= 8 || lane < 16) {
             if (mode == 0) {
                 const int tn = U16(TOP(n)), ln = U16(LEFT(n)), tx = U16(TOP(x));
                 const int fixed = (x + 1) * tn + n; /* the part of the sum that does not change from pass to pass */
-#pragma unroll
+#pragma unroll unroll
                 for (int pass = 0; pass < passes; pass++) {
                     const int y = yl + pass * rows;
                     const int v = ((n - 1 - x) * U16(LEFT(y)) + fixed + (n - 1 - y) * tx + (y + 1) * ln) >> (lg + 1);
@@ -584,43 +586,64 @@ __device__ __forceinline__ void intra_tu_g(const HevcIntraArgs &a, const IntraSl
                 if (n >= 16) sum += __builtin_amdgcn_readlane(rsum, 16);
                 if (n == 32) sum += __builtin_amdgcn_readlane(rsum, 32) + __builtin_amdgcn_readlane(rsum, 48);
                 const int dc = (sum + n) >> (lg + 1);
-                const bool edge = edge_ok && !(flags & 0x20);
-                const int tx = edge ? U16(TOP(x)) : 0;
-#pragma unroll
-                for (int pass = 0; pass < passes; pass++) {
-                    int v = dc;
-                    if (edge) {
+                if (edge_ok && !(flags & 0x20)) {
+                    const int tx = U16(TOP(x));
+#pragma unroll unroll
+                    for (int pass = 0; pass < passes; pass++) {
                         const int y = yl + pass * rows;
+                        int v = dc;
                         if (x == 0) v = y == 0 ? (U16(LEFT(0)) + 2 * dc + tx + 2) >> 2 : (U16(LEFT(y)) + 3 * dc + 2) >> 2;
                         else if (pass == 0 && y == 0) v = (tx + 3 * dc + 2) >> 2;
+                        EMIT(v, pass);
                     }
-                    EMIT(v, pass);
+                } else {
+#pragma unroll unroll
+                    for (int pass = 0; pass < passes; pass++) EMIT(dc, pass);
                 }
             } else {
-                const int angle = intra_angle(mode), inv = angle < 0 ? intra_inv_angle(mode) : 0;
+                const int angle = intra_angle(mode);
                 const bool vert = mode >= 18; /* the top row is the main reference: scan positions grow with the ref index */
-                const int sg = vert ? 1 : -1;
+                const int sg4 = vert ? 4 : -4; /* bytes per step of the ref index in the scan-order array */
                 int al = vert ? yl : x, ac = vert ? x : yl; /* along / across the direction */
                 const int dal = vert ? rows : 0, dac = vert ? 0 : rows;
+                const char *const sc = (const char *)(s + 2 * n); /* the corner: ref[k] is at sc + sg4 * k for k >= 0 */
+#define TAP(q_) U16(*(const int *)(sc + __mul24((q_), sg4)))
                 const bool e26 = edge_ok && !(flags & 0x10) && mode == 26, e10 = edge_ok && !(flags & 0x10) && mode == 10;
-                const int *const sc = s + 2 * n; /* the corner: ref[k] is sc[sg * k] for k >= 0 */
-#pragma unroll
-                for (int pass = 0; pass < passes; pass++) {
-                    const int prod = __mul24(al + 1, angle), idx = prod >> 5, fact = prod & 31;
-                    const int k0 = ac + idx + 1;
-                    int q0 = k0, q1 = k0 + 1;
-                    if (angle < 0) { /* 8.4.4.2.6: negative indices come from the other side through the inverse angle */
-                        q0 = k0 >= 0 ? k0 : -((__mul24(k0, inv) + 128) >> 8);
-                        q1 = k0 + 1 >= 0 ? k0 + 1 : -((__mul24(k0 + 1, inv) + 128) >> 8);
+                if (e26 || e10) { /* pure vertical / horizontal with the boundary filter (angle 0: one tap) */
+                    const int corner = U16(TOP(-1)), first = e26 ? U16(TOP(0)) : U16(LEFT(0));
+#pragma unroll unroll
+                    for (int pass = 0; pass < passes; pass++) {
+                        const int y = yl + pass * rows;
+                        int v = e26 ? U16(TOP(x)) : U16(LEFT(y));
+                        if (e26 && x == 0) v = clip3i(0, (1 << a.bitdepth_y) - 1, first + ((U16(LEFT(y)) - corner) >> 1));
+                        if (e10 && pass == 0 && y == 0) v = clip3i(0, (1 << a.bitdepth_y) - 1, first + ((U16(TOP(x)) - corner) >> 1));
+                        EMIT(v, pass);
                     }
-                    /* fact == 0: the second tap has weight 0 (it may lie one past the array: any finite value does) */
-                    int v = ((32 - fact) * U16(sc[__mul24(q0, sg)]) + fact * U16(sc[__mul24(q1, sg)]) + 16) >> 5;
-                    if (e26 && x == 0) v = clip3i(0, (1 << a.bitdepth_y) - 1, U16(TOP(0)) + ((U16(LEFT(yl + pass * rows)) - U16(TOP(-1))) >> 1));
-                    if (e10 && pass == 0 && yl == 0) v = clip3i(0, (1 << a.bitdepth_y) - 1, U16(LEFT(0)) + ((U16(TOP(x)) - U16(TOP(-1))) >> 1));
-                    EMIT(v, pass);
-                    al += dal;
-                    ac += dac;
+                } else if (angle >= 0) {
+#pragma unroll unroll
+                    for (int pass = 0; pass < passes; pass++) {
+                        const int prod = __mul24(al + 1, angle), fact = prod & 31, k0 = ac + (prod >> 5) + 1;
+                        /* fact == 0: the second tap has weight 0 (it may lie one past the array: any finite value does) */
+                        const int v = ((32 - fact) * TAP(k0) + fact * TAP(k0 + 1) + 16) >> 5;
+                        EMIT(v, pass);
+                        al += dal;
+                        ac += dac;
+                    }
+                } else {
+                    const int inv = intra_inv_angle(mode);
+#pragma unroll unroll
+                    for (int pass = 0; pass < passes; pass++) {
+                        const int prod = __mul24(al + 1, angle), fact = prod & 31, k0 = ac + (prod >> 5) + 1;
+                        /* 8.4.4.2.6: negative indices come from the other side through the inverse angle */
+                        const int q0 = k0 >= 0 ? k0 : -((__mul24(k0, inv) + 128) >> 8);
+                        const int q1 = k0 + 1 >= 0 ? k0 + 1 : -((__mul24(k0 + 1, inv) + 128) >> 8);
+                        const int v = ((32 - fact) * TAP(q0) + fact * TAP(q1) + 16) >> 5;
+                        EMIT(v, pass);
+                        al += dal;
+                        ac += dac;
+                    }
                 }
+#undef TAP
             }
         }
 #undef EMIT
@@ -832,13 +855,13 @@ __global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
 }
 
 __device__ __forceinline__ void intra_tu_g_any(const HevcIntraArgs &a, const IntraSlot &t, const int lane, int *s, int *s2, short *R,
-                                               const ResPrefetch &rp, const JPrefetch &jp, short *tile, const int wl)
+                                               const ResPrefetch &rp, const JPrefetch &jp, short *tile, const int wl, const short *zero_block)
 {
     switch (t.lg) {
-    case 2: intra_tu_g<2>(a, t, lane, s, s2, R, rp, jp, tile, wl); break;
-    case 3: intra_tu_g<3>(a, t, lane, s, s2, R, rp, jp, tile, wl); break;
-    case 4: intra_tu_g<4>(a, t, lane, s, s2, R, rp, jp, tile, wl); break;
-    default: intra_tu_g<5>(a, t, lane, s, s2, R, rp, jp, tile, wl); break;
+    case 2: intra_tu_g<2>(a, t, lane, s, s2, R, rp, jp, tile, wl, zero_block); break;
+    case 3: intra_tu_g<3>(a, t, lane, s, s2, R, rp, jp, tile, wl, zero_block); break;
+    case 4: intra_tu_g<4>(a, t, lane, s, s2, R, rp, jp, tile, wl, zero_block); break;
+    default: intra_tu_g<5>(a, t, lane, s, s2, R, rp, jp, tile, wl, zero_block); break;
     }
 }
 
@@ -957,6 +980,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
     __shared__ short tile[TILE_CELLS];
     __shared__ int nbA[NB_MAX], nbB[NB_MAX];
     __shared__ __attribute__((aligned(16))) short resl[2][32 * 32];
+    __shared__ __attribute__((aligned(16))) short resz[32 * 32]; /* zeros: the residual of a TU without one */
     __shared__ u32x4 slots[(SLOT_CHUNK + 2) * 3];
     const int lane = threadIdx.x;
     uint32_t *flags = a.ctrl + 4;
@@ -966,6 +990,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
         tile[TILE_CONST_C] = (short)(1 << (a.bitdepth_c - 1));
         tile[TILE_ZERO] = 0;
     }
+    for (int i = lane; i < 32 * 32 / 8; i += 64) ((u32x4 *)resz)[i] = u32x4{0u, 0u, 0u, 0u};
     wave_sync();
     if (a.plan_result) {
         /* the schedule was built by the kernels in front of this one on the same stream; nobody on the host has looked
@@ -995,7 +1020,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                     JPrefetch jp;
                     fetch_residual_g(a, cur, lane, rp);
                     fetch_jtable(a, cur, lane, jp);
-                    intra_tu_g_any(a, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, 6);
+                    intra_tu_g_any(a, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, 6, resz);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the next TU may read these samples back from memory */
                     wave_sync();
                 }
@@ -1208,7 +1233,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                         else intra_program<2>(a, gc, ps, lane, pp, tile, cell_lane4);
                         STAMP(3);
                     } else {
-                        intra_tu_g_any(a, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, gc.wl);
+                        intra_tu_g_any(a, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, gc.wl, resz);
                     }
                     if (cur.signal) { /* somebody outside the group reads this TU: publish it once its stores have completed */
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* compiler ordering; no L2-wide write-back */

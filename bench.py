@@ -338,7 +338,7 @@ def extra_c5(L, dev, stream, T, cpu=True):
                            "launches": {f"{n}x{n}": int(len(g[0])) for n, g in groups.items()}},
               "intra_recon": {"ms": round(t["intra_recon"], 4), "GB/s": round(9 * px / t["intra_recon"] / 1e6, 1), "algorithmic_bytes": int(9 * px),
                               "frac_of_hbm_peak": round(9 * px / t["intra_recon"] / 1e6 / HBM_PEAK_GBS, 5), "tus": int(len(tus)),
-                              "bound": "dependency chain (a wave per 32x32 window group), not HBM"},
+                              "bound": "dependency chain (a wave per 64x64 window group), not HBM"},
               "yuv420_to_bgra_16": {"ms": round(t["yuv420_to_bgra_16"], 4), "GB/s": round(7 * px / t["yuv420_to_bgra_16"] / 1e6, 1),
                                     "algorithmic_bytes": int(7 * px), "frac_of_hbm_peak": round(7 * px / t["yuv420_to_bgra_16"] / 1e6 / HBM_PEAK_GBS, 4)}}
     res = {"workload": "C5: one 7680x4352 HEVC intra picture, TU mix of SURVEY 8d (luma 32/16 at 60/40, chroma 16/8), qP 27", "chain_ms": round(t["chain"], 4),

@@ -677,7 +677,7 @@ __device__ __forceinline__ void intra_tu_g(const HevcIntraArgs &a, const IntraSl
 #define PK_SIGNAL 64u
 #define PK_WAIT 128u
 #define PK_END 512u /* the sentinel behind a chunk's last slot */
-#define PK_SLOW 256u /* anything but a plain program: generic TU, a wait, a flag to publish, halo cells */
+#define PK_SLOW 256u /* anything but a plain program: generic TU, a wait, halo cells */
 #define PROG_NO_RESIDUAL 0xffffff00u /* res_off of a TU without residual = size of the residual buffer resource: reads 0 */
 struct ProgSlot {
     unsigned packed;    /* kind, flags above, bits 31:16 = LDS byte address of the TU's first sample in the tile */
@@ -846,7 +846,7 @@ __global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
         u32x4 q1;
         q1.x = kind | (lg == 3 ? PK_LG3 : 0u) | ((flags & 2) ? PK_RES : 0u) | (any_out ? PK_OUTSIDE : 0u) | (((q2.y >> 8) & 1) ? PK_SIGNAL : 0u) |
                ((q2.y & 0xff) ? PK_WAIT : 0u) | ((uint32_t)(2 * (TILE_ORIGIN + (y0 - wy0) * TILE_STRIDE + (x0 - wx0))) << 16);
-        if (q1.x & (PK_OUTSIDE | PK_SIGNAL | PK_WAIT)) q1.x |= PK_SLOW;
+        if (q1.x & (PK_OUTSIDE | PK_WAIT)) q1.x |= PK_SLOW;
         q1.y = (flags & 2) ? q0.z * 2u : PROG_NO_RESIDUAL;
         q1.z = d_first * 8u;
         q1.w = (uint32_t)(y0 * a.stride[cidx] + x0) * 2u;
@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                 }
                 if (cur.wait_count) widx = a.wait_idx[cur.wait_begin + (lane < (int)cur.wait_count ? lane : 0)];
             };
-#define PLAIN_PROGRAM(ps, pp) do { \
+#define PLAIN_PROGRAM(ps, pp, kk) do { \
                 const bool big_ = (ps.packed & PK_LG3) != 0; \
                 const unsigned a0_ = pp.d.x & 0xffffu, a1_ = pp.d.x >> 16, a2_ = pp.d.y & 0xffffu; \
                 const int r0_ = LDS_U16(a0_), r1_ = LDS_U16(a1_); \
@@ -1137,6 +1137,12 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                 const short rec_ = (short)clip3i(0, gc.maxv, (int)(short)(v_ & 0xffff) + (int)pp.res); \
                 *(short *)((char *)tile + (ps.packed >> 16) + (big_ ? cell_lane8 : cell_alias4)) = rec_; \
                 __builtin_amdgcn_raw_buffer_store_b16(rec_, gc.plane_rs, big_ ? gc.plane_lane[1] : plane_alias4, (int)SGPR(ps.plane_off), FFHIP_AUX_SC1); \
+                if (__builtin_expect((ps.packed & PK_SIGNAL) != 0, 0)) { /* somebody outside the group reads this TU: publish it once its stores have completed */ \
+                    const unsigned tu_ = SGPR(slots[3 * (kk) + 2].z); \
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+                    if (lane == 0 && (int)tu_ != a.debug_withhold) __hip_atomic_store(flags + tu_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                } \
                 } while (0)
 #define SWAP_SETS() do { const ProgSlot ts_ = psA; psA = psB; psB = ts_; const ProgPrefetch tp_ = ppA; ppA = ppB; ppB = tp_; } while (0)
 #ifdef FFHIP_INTRA_TRACE
@@ -1163,14 +1169,14 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                 while (__builtin_expect(((psA.packed | psB.packed) & PK_SLOW) == 0, 1)) {
                     {
                         TRACE_TU_BEGIN(psA);
-                        PLAIN_PROGRAM(psA, ppA);
+                        PLAIN_PROGRAM(psA, ppA, k);
                         TRACE_TU_END();
                     }
                     ++k;
                     PREFETCH_PROGRAM(psA, ppA, k + 1);
                     {
                         TRACE_TU_BEGIN(psB);
-                        PLAIN_PROGRAM(psB, ppB);
+                        PLAIN_PROGRAM(psB, ppB, k);
                         TRACE_TU_END();
                     }
                     ++k;
@@ -1181,7 +1187,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                     if (!(psB.packed & PK_END)) fetch_extras(psB, k + 1);
                     {
                         TRACE_TU_BEGIN(psA);
-                        PLAIN_PROGRAM(psA, ppA);
+                        PLAIN_PROGRAM(psA, ppA, k);
                         TRACE_TU_END();
                     }
                     ++k;

@@ -138,7 +138,8 @@ __device__ __forceinline__ int intra_inv_angle(int mode) /* modes 11..25 */
 #define TILE_CONST_Y (TILE_LEFT_EXT + 64) /* 1 << (bitdepth_y - 1): what a TU without any neighbour predicts from */
 #define TILE_CONST_C (TILE_LEFT_EXT + 65)
 #define TILE_ZERO (TILE_LEFT_EXT + 66)
-#define TILE_CELLS (TILE_LEFT_EXT + 68)
+#define TILE_F (TILE_LEFT_EXT + 68) /* 33 cells: the smoothed neighbours of an 8x8 program (8.4.4.2.3), scan order */
+#define TILE_CELLS (TILE_F + 34)
 
 /* The residual block of a TU, fetched one TU ahead in the grouped form: samples 8 lane + 512 j .. +7 in v[j], as
  * 16-byte loads into registers of their own.  (The first form took one short per lane and pass into a short[16]:
@@ -676,6 +677,7 @@ __device__ __forceinline__ void intra_tu_g(const HevcIntraArgs &a, const IntraSl
 #define PK_OUTSIDE 32u
 #define PK_SIGNAL 64u
 #define PK_WAIT 128u
+#define PK_FILTER 1024u /* 8x8 program with neighbour smoothing: the words' fourth field is the lane's scan position source */
 #define PK_END 512u /* the sentinel behind a chunk's last slot */
 #define PK_SLOW 256u /* anything but a plain program: generic TU, a wait, halo cells */
 #define PROG_NO_RESIDUAL 0xffffff00u /* res_off of a TU without residual = size of the residual buffer resource: reads 0 */
@@ -696,15 +698,32 @@ struct GroupCtx {
     int plane_lane[2], desc_lane[2]; /* per lane, 4x4 / 8x8: byte offset of the lane's pixel from the TU's first one */
 };
 #define LDS_U16(byte_addr) ((int)*(const unsigned short *)((const char *)tile + (byte_addr)))
+/* neighbour smoothing of an 8x8 program: lane i < 33 holds scan position i (its cell comes with the pixel words), the
+ * [1 2 1] filter runs across lanes, the ends stay, and the result goes to the TILE_F cells the taps point at */
+__device__ __forceinline__ void program_filter_step(short *tile, const int lane, const unsigned src_cell)
+{
+    const int g = lane < 33 ? (int)*(const short *)((const char *)tile + src_cell) : 0;
+    const int lo = __builtin_amdgcn_update_dpp(0, g, 0x138, 0xf, 0xf, false); /* wave_shr:1 -- lane i - 1 */
+    const int hi = __builtin_amdgcn_update_dpp(0, g, 0x130, 0xf, 0xf, false); /* wave_shl:1 -- lane i + 1 */
+    const int f = (lane == 0 || lane == 32) ? g : (lo + 2 * g + hi + 2) >> 2;
+    if (lane < 33) tile[TILE_F + lane] = (short)f;
+}
 template <int LG>
 __device__ __forceinline__ void intra_program(const HevcIntraArgs &a, const GroupCtx &g, const ProgSlot &t, const int lane,
                                               const ProgPrefetch &pp, short *tile, const int cell_lane)
 {
     constexpr int n = 1 << LG;
+    const bool filt = LG == 3 && (t.packed & PK_FILTER) != 0;
+    if (filt) program_filter_step(tile, lane, pp.d.y >> 16);
     if (LG == 3 || lane < n * n) {
-        const unsigned a0 = pp.d.x & 0xffffu, a1 = pp.d.x >> 16, a2 = pp.d.y & 0xffffu, a3 = pp.d.y >> 16;
-        const int r0 = LDS_U16(a0), r1 = LDS_U16(a1);
+        unsigned a0 = pp.d.x & 0xffffu, a1 = pp.d.x >> 16, a2 = pp.d.y & 0xffffu, a3 = pp.d.y >> 16;
         const unsigned kind = PK_KIND(t.packed);
+        if (filt && kind == PROG_PLANAR) { /* LEFT(y), TOP(x), TOP(n), LEFT(n) among the smoothed cells */
+            const int x = lane & (n - 1), y = lane >> LG;
+            a0 = 2u * (unsigned)(TILE_F + 2 * n - 1 - y); a1 = 2u * (unsigned)(TILE_F + 2 * n + 1 + x);
+            a2 = 2u * (unsigned)(TILE_F + 3 * n + 1); a3 = 2u * (unsigned)(TILE_F + n - 1);
+        }
+        const int r0 = LDS_U16(a0), r1 = LDS_U16(a1);
         int v;
         if (kind == PROG_ANGULAR) {
             v = ((32 - (int)a2) * r0 + (int)a2 * r1 + 16) >> 5;
@@ -774,9 +793,10 @@ __global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
     const int lg = (int)(q0.y & 0xff), cidx = (int)((q0.y >> 8) & 0xff), mode = (int)((q0.y >> 16) & 0xff), flags = (int)(q0.y >> 24);
     const int n = 1 << lg, wl = a.wl[cidx], wsz = 1 << wl;
     bool prog = lg <= 3 && n <= wsz && ((q2.y >> 9) & 1) && !(flags & 0xC0) && q0.z < 0x7fff0000u;
-    if (prog && (flags & 4) && mode != 1 && n != 4) { /* neighbour smoothing applies (8.4.4.2.3): the generic body */
+    bool filt = false; /* neighbour smoothing applies (8.4.4.2.3; at 8x8: planar and modes 2, 18, 34): the taps read the smoothed copy */
+    if (prog && (flags & 4) && mode != 1 && n != 4) {
         const int d26 = iabs(mode - 26), d10 = iabs(mode - 10);
-        if ((d26 < d10 ? d26 : d10) > 7) prog = false;
+        filt = (d26 < d10 ? d26 : d10) > 7;
     }
     if (!prog) {
         if (lane == 0) a.sched[(size_t)k * 3 + 1] = generic;
@@ -785,7 +805,7 @@ __global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
     const int wx0 = (x0 >> wl) << wl, wy0 = (y0 >> wl) << wl;
     const uint8_t *jt = a.jt + q2.w;
     bool ok = true, outside = false;
-    auto cell = [&](int pos) -> unsigned { /* LDS byte address of the sample scan position pos takes */
+    auto src_cell = [&](int pos) -> unsigned { /* LDS byte address of the sample scan position pos takes */
         const int j = (int)jt[pos];
         if (j == 255) return 2u * (cidx == 0 ? TILE_CONST_Y : TILE_CONST_C);
         int px = x0 - 1, py = y0 - 1;
@@ -796,6 +816,7 @@ __global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
         if (tx > TILE_STRIDE - 1 || ty > 128 || (ty > 64 && tx != 0)) ok = false;
         return 2u * (unsigned)(ty <= 64 ? ty * TILE_STRIDE + tx : TILE_LEFT_EXT + ty - 65);
     };
+    auto cell = [&](int pos) -> unsigned { return filt ? 2u * (unsigned)(TILE_F + pos) : src_cell(pos); }; /* what a tap reads */
 #define POS_LEFT(yy) (2 * n - 1 - (yy))
 #define POS_TOP(xx) (2 * n + 1 + (xx))
     const bool act = lane < n * n;
@@ -804,7 +825,7 @@ __global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
     const bool edge_ok = cidx == 0; /* n < 32 here */
     if (mode == 0) {
         kind = PROG_PLANAR;
-        if (act) { w0 = cell(POS_LEFT(y)); w1 = cell(POS_TOP(x)); w2 = cell(POS_TOP(n)); w3 = cell(POS_LEFT(n)); }
+        if (act && !filt) { w0 = cell(POS_LEFT(y)); w1 = cell(POS_TOP(x)); w2 = cell(POS_TOP(n)); w3 = cell(POS_LEFT(n)); }
     } else if (mode == 1) {
         kind = PROG_DC;
         if (act) {
@@ -835,6 +856,7 @@ __global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
     }
 #undef POS_LEFT
 #undef POS_TOP
+    if (filt && lane < 4 * n + 1) w3 = src_cell(lane); /* lane i fetches scan position i for the smoothing step */
     const unsigned long long any_out = __builtin_amdgcn_ballot_w64(outside);
     if (__builtin_amdgcn_ballot_w64(!ok)) { /* a neighbour the tile layout has no cell for: the generic body */
         if (lane == 0) a.sched[(size_t)k * 3 + 1] = generic;
@@ -844,7 +866,7 @@ __global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
     if (act) a.desc[d_first + (uint32_t)y * (uint32_t)a.desc_w[cidx] + (uint32_t)x] = make_uint2(w0 | (w1 << 16), w2 | (w3 << 16));
     if (lane == 0) {
         u32x4 q1;
-        q1.x = kind | (lg == 3 ? PK_LG3 : 0u) | ((flags & 2) ? PK_RES : 0u) | (any_out ? PK_OUTSIDE : 0u) | (((q2.y >> 8) & 1) ? PK_SIGNAL : 0u) |
+        q1.x = kind | (lg == 3 ? PK_LG3 : 0u) | (filt ? PK_FILTER : 0u) | ((flags & 2) ? PK_RES : 0u) | (any_out ? PK_OUTSIDE : 0u) | (((q2.y >> 8) & 1) ? PK_SIGNAL : 0u) |
                ((q2.y & 0xff) ? PK_WAIT : 0u) | ((uint32_t)(2 * (TILE_ORIGIN + (y0 - wy0) * TILE_STRIDE + (x0 - wx0))) << 16);
         if (q1.x & (PK_OUTSIDE | PK_WAIT)) q1.x |= PK_SLOW;
         q1.y = (flags & 2) ? q0.z * 2u : PROG_NO_RESIDUAL;
@@ -1110,7 +1132,8 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
 #define PLAIN_PROGRAM(ps, pp, kk) do { \
                 const bool big_ = (ps.packed & PK_LG3) != 0; \
                 const unsigned a0_ = pp.d.x & 0xffffu, a1_ = pp.d.x >> 16, a2_ = pp.d.y & 0xffffu; \
-                const int r0_ = LDS_U16(a0_), r1_ = LDS_U16(a1_); \
+                if (__builtin_expect((ps.packed & PK_FILTER) != 0, 0)) program_filter_step(tile, lane, pp.d.y >> 16); \
+                int r0_ = LDS_U16(a0_), r1_ = LDS_U16(a1_); \
                 int v_; \
                 if (__builtin_expect(PK_KIND(ps.packed) == PROG_ANGULAR, 1)) { \
                     v_ = ((32 - (int)a2_) * r0_ + (int)a2_ * r1_ + 16) >> 5; \
@@ -1119,7 +1142,13 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                     const int lg_ = big_ ? 3 : 2, n_ = 1 << lg_, le_ = big_ ? lane : lane4; \
                     if (kind_ == PROG_PLANAR) { \
                         const int x_ = le_ & (n_ - 1), y_ = le_ >> lg_; \
-                        const int r2_ = LDS_U16(a2_), r3_ = LDS_U16(a3_); \
+                        int r2_, r3_; \
+                        if (ps.packed & PK_FILTER) { /* LEFT(y), TOP(x), TOP(n), LEFT(n) among the smoothed cells */ \
+                            r0_ = (int)((const unsigned short *)tile)[TILE_F + 15 - y_]; r1_ = (int)((const unsigned short *)tile)[TILE_F + 17 + x_]; \
+                            r2_ = (int)((const unsigned short *)tile)[TILE_F + 25]; r3_ = (int)((const unsigned short *)tile)[TILE_F + 7]; \
+                        } else { \
+                            r2_ = LDS_U16(a2_); r3_ = LDS_U16(a3_); \
+                        } \
                         v_ = ((n_ - 1 - x_) * r0_ + (x_ + 1) * r2_ + (n_ - 1 - y_) * r1_ + (y_ + 1) * r3_ + n_) >> (lg_ + 1); \
                     } else if (kind_ == PROG_DC) { \
                         const int dc_ = (__builtin_amdgcn_readfirstlane(row_sum16(LDS_U16(a2_))) + n_) >> (lg_ + 1); \

@@ -67,7 +67,7 @@ struct HevcIntraArgs {
     int desc_w[3];               /* samples per row of each plane in desc */
     uint32_t desc_off[3];        /* first entry of each plane             */
 #ifdef FFHIP_INTRA_TRACE
-    unsigned long long *trace;   /* diagnostics build only (make trace): 8 words per TU, then one per ticket */
+    unsigned long long *trace;   /* diagnostics build only (make trace): 12 words per TU, then one per ticket */
 #endif
 };
 #define JT_STRIDE 20 /* table bytes per 4x4 block: a TU of size n owns n/4 consecutive blocks of its first block row, 5n >= 4n + 1 bytes */
@@ -75,7 +75,7 @@ struct HevcIntraArgs {
 static unsigned long long *g_intra_trace = nullptr;
 extern "C" void ffhip_debug_intra_trace(void *d_buf) { g_intra_trace = (unsigned long long *)d_buf; }
 #define TRACE_NOW() ((unsigned long long)wall_clock64())
-__shared__ unsigned long long g_stamp[4];
+__shared__ unsigned long long g_stamp[8];
 #define STAMP(k) do { if (lane == 0) g_stamp[k] = TRACE_NOW(); } while (0)
 #else
 #define STAMP(k) do { } while (0)
@@ -427,7 +427,22 @@ struct IntraSlot {
 struct JPrefetch {
     unsigned j[3];
 };
-__device__ __forceinline__ void fetch_jtable(const HevcIntraArgs &a, const IntraSlot &t, const int lane, JPrefetch &jp)
+/* what is the same for every TU of a group (one window of one plane) */
+struct GroupCtx {
+    __amdgpu_buffer_rsrc_t plane_rs;
+    int cidx, stride, maxv, wl, wx0, wy0;
+    int plane_lane[2], desc_lane[2]; /* per lane, 4x4 / 8x8: byte offset of the lane's pixel from the TU's first one */
+};
+/* Kernel arguments the grouped kernel touches for every TU, as values the compiler cannot re-derive: with the scalar
+ * registers it has left it reloaded them from the kernel-argument segment where they were used -- a scalar memory
+ * load and an s_waitcnt lgkmcnt(0) (which also drains the LDS queue) per use, ~0.8 us per generic TU in all. */
+struct HotArgs {
+    const int16_t *residual;
+    const uint8_t *jt;
+    const uint32_t *wait_idx;
+    int bitdepth_y, bitdepth_c;
+};
+__device__ __forceinline__ void fetch_jtable(const HotArgs &a, const IntraSlot &t, const int lane, JPrefetch &jp)
 {
     const uint8_t *p = a.jt + t.jt_off + lane; /* the table is padded: reading past a small TU's entries is harmless */
     jp.j[0] = p[0];
@@ -436,7 +451,7 @@ __device__ __forceinline__ void fetch_jtable(const HevcIntraArgs &a, const Intra
         jp.j[2] = p[128];
     }
 }
-__device__ __forceinline__ void fetch_residual_g(const HevcIntraArgs &a, const IntraSlot &t, const int lane, ResPrefetch &rp)
+__device__ __forceinline__ void fetch_residual_g(const HotArgs &a, const IntraSlot &t, const int lane, ResPrefetch &rp)
 {
     rp.wide = false;
     if (!(t.flags & 2)) return;
@@ -450,18 +465,17 @@ __device__ __forceinline__ void fetch_residual_g(const HevcIntraArgs &a, const I
 }
 
 template <int LG>
-__device__ __forceinline__ void intra_tu_g(const HevcIntraArgs &a, const IntraSlot &t, const int lane, int *s, int *s2, short *R,
-                                           const ResPrefetch &rp, const JPrefetch &jp, short *tile, const int wl, const short *zero_block)
+__device__ __forceinline__ void intra_tu_g(const HotArgs &a, const GroupCtx &g, const IntraSlot &t, const int lane, int *s, int *s2, short *R,
+                                           const ResPrefetch &rp, const JPrefetch &jp, short *tile, const short *zero_block)
 {
     constexpr int n = 1 << LG, lg = LG, cnt = 4 * n + 1;
     const int x0 = (int)t.x, y0 = (int)t.y;
-    const int wx0 = (x0 >> wl) << wl, wy0 = (y0 >> wl) << wl, wsz = 1 << wl;
-    const int cidx = (int)t.cidx, mode = (int)t.mode, flags = (int)t.flags;
+    const int wx0 = g.wx0, wy0 = g.wy0, wsz = 1 << g.wl;
+    const int cidx = g.cidx, mode = (int)t.mode, flags = (int)t.flags;
     const bool tile_ok = t.tile_ok != 0;
     const int bd = cidx == 0 ? a.bitdepth_y : a.bitdepth_c;
-    int16_t *plane = cidx == 0 ? a.plane[0] : (cidx == 1 ? a.plane[1] : a.plane[2]);
-    const int stride = cidx == 0 ? a.stride[0] : (cidx == 1 ? a.stride[1] : a.stride[2]);
-    const __amdgpu_buffer_rsrc_t prs = ffhip_rsrc(plane, 0xffffffffu);
+    const int stride = g.stride;
+    const __amdgpu_buffer_rsrc_t prs = g.plane_rs;
     /* ---- 1 + 2. gather with the substitution folded in ---- */
 #pragma unroll
     for (int pass = 0; pass < LANE_PASSES(cnt); pass++) {
@@ -691,12 +705,6 @@ struct ProgPrefetch {
     uint2 d;
     short res; /* kept as loaded: a conversion at the load would wait for it there */
 };
-/* what is the same for every TU of a group (one window of one plane) */
-struct GroupCtx {
-    __amdgpu_buffer_rsrc_t plane_rs;
-    int cidx, stride, maxv, wl, wx0, wy0;
-    int plane_lane[2], desc_lane[2]; /* per lane, 4x4 / 8x8: byte offset of the lane's pixel from the TU's first one */
-};
 #define LDS_U16(byte_addr) ((int)*(const unsigned short *)((const char *)tile + (byte_addr)))
 /* neighbour smoothing of an 8x8 program: lane i < 33 holds scan position i (its cell comes with the pixel words), the
  * [1 2 1] filter runs across lanes, the ends stay, and the result goes to the TILE_F cells the taps point at */
@@ -709,7 +717,7 @@ __device__ __forceinline__ void program_filter_step(short *tile, const int lane,
     if (lane < 33) tile[TILE_F + lane] = (short)f;
 }
 template <int LG>
-__device__ __forceinline__ void intra_program(const HevcIntraArgs &a, const GroupCtx &g, const ProgSlot &t, const int lane,
+__device__ __forceinline__ void intra_program(const HotArgs &a, const GroupCtx &g, const ProgSlot &t, const int lane,
                                               const ProgPrefetch &pp, short *tile, const int cell_lane)
 {
     constexpr int n = 1 << LG;
@@ -876,14 +884,14 @@ __global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
     }
 }
 
-__device__ __forceinline__ void intra_tu_g_any(const HevcIntraArgs &a, const IntraSlot &t, const int lane, int *s, int *s2, short *R,
-                                               const ResPrefetch &rp, const JPrefetch &jp, short *tile, const int wl, const short *zero_block)
+__device__ __forceinline__ void intra_tu_g_any(const HotArgs &a, const GroupCtx &g, const IntraSlot &t, const int lane, int *s, int *s2, short *R,
+                                               const ResPrefetch &rp, const JPrefetch &jp, short *tile, const short *zero_block)
 {
     switch (t.lg) {
-    case 2: intra_tu_g<2>(a, t, lane, s, s2, R, rp, jp, tile, wl, zero_block); break;
-    case 3: intra_tu_g<3>(a, t, lane, s, s2, R, rp, jp, tile, wl, zero_block); break;
-    case 4: intra_tu_g<4>(a, t, lane, s, s2, R, rp, jp, tile, wl, zero_block); break;
-    default: intra_tu_g<5>(a, t, lane, s, s2, R, rp, jp, tile, wl, zero_block); break;
+    case 2: intra_tu_g<2>(a, g, t, lane, s, s2, R, rp, jp, tile, zero_block); break;
+    case 3: intra_tu_g<3>(a, g, t, lane, s, s2, R, rp, jp, tile, zero_block); break;
+    case 4: intra_tu_g<4>(a, g, t, lane, s, s2, R, rp, jp, tile, zero_block); break;
+    default: intra_tu_g<5>(a, g, t, lane, s, s2, R, rp, jp, tile, zero_block); break;
     }
 }
 
@@ -1014,6 +1022,14 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
     }
     for (int i = lane; i < 32 * 32 / 8; i += 64) ((u32x4 *)resz)[i] = u32x4{0u, 0u, 0u, 0u};
     wave_sync();
+    HotArgs hot;
+    {
+        unsigned long long p_res = (unsigned long long)a.residual, p_jt = (unsigned long long)a.jt, p_wait = (unsigned long long)a.wait_idx;
+        int bdy = a.bitdepth_y, bdc = a.bitdepth_c;
+        asm volatile("" : "+s"(p_res), "+s"(p_jt), "+s"(p_wait), "+s"(bdy), "+s"(bdc));
+        hot.residual = (const int16_t *)p_res; hot.jt = (const uint8_t *)p_jt; hot.wait_idx = (const uint32_t *)p_wait;
+        hot.bitdepth_y = bdy; hot.bitdepth_c = bdc;
+    }
     if (a.plan_result) {
         /* the schedule was built by the kernels in front of this one on the same stream; nobody on the host has looked
          * at it.  A list the device planner refuses (groups that are not contiguous runs of the decode order for this
@@ -1040,9 +1056,13 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                     const IntraSlot cur = decode_slot(slots[3 * k], slots[3 * k + 2]);
                     ResPrefetch rp;
                     JPrefetch jp;
-                    fetch_residual_g(a, cur, lane, rp);
-                    fetch_jtable(a, cur, lane, jp);
-                    intra_tu_g_any(a, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, 6, resz);
+                    fetch_residual_g(hot, cur, lane, rp);
+                    fetch_jtable(hot, cur, lane, jp);
+                    GroupCtx sg = {};
+                    sg.cidx = (int)cur.cidx; sg.wl = 6; sg.wx0 = (int)(cur.x >> 6) << 6; sg.wy0 = (int)(cur.y >> 6) << 6;
+                    sg.stride = sg.cidx == 0 ? a.stride[0] : (sg.cidx == 1 ? a.stride[1] : a.stride[2]);
+                    sg.plane_rs = ffhip_rsrc(sg.cidx == 0 ? a.plane[0] : (sg.cidx == 1 ? a.plane[1] : a.plane[2]), 0xffffffffu);
+                    intra_tu_g_any(hot, sg, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, resz);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the next TU may read these samples back from memory */
                     wave_sync();
                 }
@@ -1051,7 +1071,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
             return;
         }
     }
-    const __amdgpu_buffer_rsrc_t desc_rs = ffhip_rsrc(a.desc, 0xffffffffu), res_rs = ffhip_rsrc(a.residual, PROG_NO_RESIDUAL);
+    const __amdgpu_buffer_rsrc_t desc_rs = ffhip_rsrc(a.desc, 0xffffffffu), res_rs = ffhip_rsrc(hot.residual, PROG_NO_RESIDUAL);
     const int cell_lane4 = 2 * ((lane >> 2) * TILE_STRIDE + (lane & 3)), cell_lane8 = 2 * ((lane >> 3) * TILE_STRIDE + (lane & 7));
     /* the run of plain programs never touches the exec mask (a branch over a load makes the compiler's wait counts
      * pessimistic: it then waits for the loads it issued a moment ago): on a 4x4 TU lanes 16 .. 63 do what lane 0 does --
@@ -1069,7 +1089,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
         int plane_alias4 = 0, desc_alias4 = 0;
         gc.wl = (int)g.z;
 #ifdef FFHIP_INTRA_TRACE
-        if (a.trace && lane == 0) a.trace[8 * a.n_tus + ticket] = TRACE_NOW();
+        if (a.trace && lane == 0) a.trace[12 * a.n_tus + ticket] = TRACE_NOW();
 #endif
         for (unsigned base = 0; base < g.y && !dead; base += SLOT_CHUNK) {
             const int m = (int)(g.y - base < SLOT_CHUNK ? g.y - base : SLOT_CHUNK);
@@ -1086,7 +1106,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                 gc.wx0 = (int)(((d0 & 0xffff) >> gc.wl) << gc.wl);
                 gc.wy0 = (int)(((d0 >> 16) >> gc.wl) << gc.wl);
                 gc.stride = gc.cidx == 0 ? a.stride[0] : (gc.cidx == 1 ? a.stride[1] : a.stride[2]);
-                gc.maxv = (1 << (gc.cidx == 0 ? a.bitdepth_y : a.bitdepth_c)) - 1;
+                gc.maxv = (1 << (gc.cidx == 0 ? hot.bitdepth_y : hot.bitdepth_c)) - 1;
                 gc.plane_rs = ffhip_rsrc(gc.cidx == 0 ? a.plane[0] : (gc.cidx == 1 ? a.plane[1] : a.plane[2]), 0xffffffffu);
                 const int dw = gc.cidx == 0 ? a.desc_w[0] : (gc.cidx == 1 ? a.desc_w[1] : a.desc_w[2]);
                 gc.plane_lane[0] = 2 * ((lane >> 2) * gc.stride + (lane & 3));
@@ -1122,12 +1142,12 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
             auto fetch_extras = [&](const ProgSlot &ps, const int j) {
                 cur = decode_slot(slots[3 * j], slots[3 * j + 2]);
                 if (PK_KIND(ps.packed) == PROG_GENERIC) {
-                    fetch_jtable(a, cur, lane, jp);
-                    fetch_residual_g(a, cur, lane, rp);
+                    fetch_jtable(hot, cur, lane, jp);
+                    fetch_residual_g(hot, cur, lane, rp);
                 } else if (ps.packed & PK_OUTSIDE) {
-                    fetch_jtable(a, cur, lane, jp);
+                    fetch_jtable(hot, cur, lane, jp);
                 }
-                if (cur.wait_count) widx = a.wait_idx[cur.wait_begin + (lane < (int)cur.wait_count ? lane : 0)];
+                if (cur.wait_count) widx = hot.wait_idx[cur.wait_begin + (lane < (int)cur.wait_count ? lane : 0)];
             };
 #define PLAIN_PROGRAM(ps, pp, kk) do { \
                 const bool big_ = (ps.packed & PK_LG3) != 0; \
@@ -1159,7 +1179,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                     } else { \
                         const int r2_ = LDS_U16(a2_); \
                         const int vn_ = ((32 - (int)a2_) * r0_ + (int)a2_ * r1_ + 16) >> 5; \
-                        const int ve_ = clip3i(0, (1 << a.bitdepth_y) - 1, r0_ + ((r1_ - r2_) >> 1)); \
+                        const int ve_ = clip3i(0, (1 << hot.bitdepth_y) - 1, r0_ + ((r1_ - r2_) >> 1)); \
                         v_ = a3_ ? ve_ : vn_; \
                     } \
                 } \
@@ -1178,10 +1198,11 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
 #define TRACE_TU_BEGIN(ps) const unsigned long long tr0 = TRACE_NOW(); unsigned long long tr1 = tr0; \
     const unsigned tr_kind = PK_KIND(ps.packed) | ((ps.packed & PK_OUTSIDE) ? 8u : 0u), tr_lg = PK_KIND(ps.packed) ? ((ps.packed & PK_LG3) ? 3u : 2u) : cur.lg
 #define TRACE_TU_END() do { if (a.trace && lane == 0) { \
-        unsigned long long *tr = a.trace + 8 * (size_t)(g.x + base + k); /* by schedule slot */ \
+        unsigned long long *tr = a.trace + 12 * (size_t)(g.x + base + k); /* by schedule slot */ \
         tr[0] = tr0; tr[1] = tr1; tr[2] = TRACE_NOW(); \
         tr[3] = ((unsigned long long)(tr_kind | (tr_lg << 4)) << 56) | ((unsigned long long)ticket << 32) | ((unsigned long long)blockIdx.x << 12) | (unsigned)(base + k); \
-        tr[4] = g_stamp[0]; tr[5] = g_stamp[1]; tr[6] = g_stamp[2]; tr[7] = g_stamp[3]; } } while (0)
+        tr[4] = g_stamp[0]; tr[5] = g_stamp[1]; tr[6] = g_stamp[2]; tr[7] = g_stamp[3]; \
+        tr[8] = g_stamp[4]; tr[9] = g_stamp[5]; tr[10] = g_stamp[6]; tr[11] = g_stamp[7]; } } while (0)
 #else
 #define TRACE_TU_BEGIN(ps) do { } while (0)
 #define TRACE_TU_END() do { } while (0)
@@ -1264,11 +1285,11 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                         STAMP(0);
                         if (ps.packed & PK_OUTSIDE) intra_program_halo(gc, (int)cur.x, (int)cur.y, 1 << cur.lg, lane, jp.j[0], tile);
                         STAMP(1); STAMP(2);
-                        if (ps.packed & PK_LG3) intra_program<3>(a, gc, ps, lane, pp, tile, cell_lane8);
-                        else intra_program<2>(a, gc, ps, lane, pp, tile, cell_lane4);
+                        if (ps.packed & PK_LG3) intra_program<3>(hot, gc, ps, lane, pp, tile, cell_lane8);
+                        else intra_program<2>(hot, gc, ps, lane, pp, tile, cell_lane4);
                         STAMP(3);
                     } else {
-                        intra_tu_g_any(a, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, gc.wl, resz);
+                        intra_tu_g_any(hot, gc, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, resz);
                     }
                     if (cur.signal) { /* somebody outside the group reads this TU: publish it once its stores have completed */
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* compiler ordering; no L2-wide write-back */
@@ -1282,11 +1303,14 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                     }
                     if (!is_prog) wave_sync(); /* the next TU reuses the neighbour scratch (a program touches only the tile, in order) */
                     TRACE_TU_END();
+                    STAMP(4);
                     ++k;
                     PREFETCH_PROGRAM(psA, ppA, k + 1); /* set A: TU k + 1, set B: TU k */
                     SWAP_SETS();
+                    STAMP(5);
                     have_extras = (psA.packed & (PK_SLOW | PK_END)) == PK_SLOW;
                     if (have_extras) fetch_extras(psA, k); /* behind this TU's stores, one TU ahead like the programs of the run */
+                    STAMP(6);
                 }
             }
             wave_sync(); /* slots[] is about to be overwritten */

@@ -30,7 +30,7 @@ tus, res = synth.hevc_intra_tus(W, H, seed=2 if which == "quadtree" else 5, tu_m
 n = len(tus)
 dt = torch.from_numpy(tus.view(np.uint8).copy()).to(dev); dr = torch.from_numpy(res).to(dev)
 py = torch.zeros((H, W), dtype=torch.int16, device=dev); pu = torch.zeros((H // 2, W // 2), dtype=torch.int16, device=dev); pv = torch.zeros_like(pu)
-trace = torch.zeros(9 * n + 16, dtype=torch.int64, device=dev)
+trace = torch.zeros(13 * n + 16, dtype=torch.int64, device=dev)
 
 
 def run():
@@ -41,8 +41,8 @@ run(); capi.check(L.ffhip_stream_sync(st))
 L.ffhip_debug_intra_trace(trace.data_ptr())
 run(); capi.check(L.ffhip_stream_sync(st))
 tr = trace.cpu().numpy()
-rec = tr[:8 * n].reshape(n, 8)
-tick = tr[8 * n:]
+rec = tr[:12 * n].reshape(n, 12)
+tick = tr[12 * n:]
 t_begin, t_start, t_end, meta = rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3]
 assert (t_end > 0).all(), "some TU left no trace"
 tkind = ((meta >> 56) & 7).astype(np.int64); halo = ((meta >> 59) & 1).astype(np.int64)
@@ -91,6 +91,7 @@ pk = {}   # program TUs on the path: (size, kind, halo) -> [count, body ticks]
 cat = {"body": {2: 0, 3: 0, 4: 0, 5: 0}, "in-group": 0, "hand-off": 0, "start": 0}
 cnt = {"body": {2: 0, 3: 0, 4: 0, 5: 0}, "in-group": 0, "hand-off": 0, "start": 0}
 handoffs = []
+gaps = {}
 cur = int(np.argmax(t_end))
 steps = 0
 while cur >= 0:
@@ -115,6 +116,11 @@ while cur >= 0:
     te, kind, j = max(cands)
     gap = int(t_start[cur]) - te
     cat[kind] += gap; cnt[kind] += 1
+    if kind == "in-group" and tkind[cur] == 0 and tkind[j] == 0:   # generic after generic: the pieces of the gap (stamps 4..6 sit in the later TU's record)
+        g4, g5, g6 = int(rec[cur, 8]), int(rec[cur, 9]), int(rec[cur, 10])
+        if g4 >= te and g6 <= int(t_start[cur]):
+            gg = gaps.setdefault("generic->generic", [0, 0, 0, 0, 0, 0]); gg[0] += 1
+            gg[1] += g4 - te; gg[2] += g5 - g4; gg[3] += g6 - g5; gg[4] += int(t_begin[cur]) - g6; gg[5] += int(t_start[cur]) - int(t_begin[cur])
     if kind == "hand-off": handoffs.append(gap)
     cur = j
 tot = sum(cat["body"].values()) + cat["in-group"] + cat["hand-off"] + cat["start"]
@@ -131,6 +137,9 @@ print(f"  programs overall: {int((tkind > 0).sum())} of {n} TUs")
 for k in ("in-group", "hand-off", "start"):
     if cnt[k]:
         print(f"  {k:9s}: {cnt[k]:6d} steps {cat[k] / 100.0:9.1f} us  ({cat[k] / cnt[k] / 100.0:.2f} us each)")
+for kname, gg in gaps.items():
+    c = gg[0]
+    print(f"  gap {kname}: {c} steps; trace write + sync {gg[1] / c / 100:.2f}, program fetch + swap {gg[2] / c / 100:.2f}, extras fetch {gg[3] / c / 100:.2f}, loop top {gg[4] / c / 100:.2f}, wait {gg[5] / c / 100:.2f} us")
 if handoffs:
     h = np.array(handoffs) / 100.0
     print(f"  hand-off gap percentiles (us): p10 {np.percentile(h, 10):.2f} p50 {np.percentile(h, 50):.2f} p90 {np.percentile(h, 90):.2f} max {h.max():.2f}")

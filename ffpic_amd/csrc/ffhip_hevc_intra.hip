@@ -436,15 +436,15 @@ struct GroupCtx {
 /* Kernel arguments the grouped kernel touches for every TU, as values the compiler cannot re-derive: with the scalar
  * registers it has left it reloaded them from the kernel-argument segment where they were used -- a scalar memory
  * load and an s_waitcnt lgkmcnt(0) (which also drains the LDS queue) per use, ~0.8 us per generic TU in all. */
-struct HotArgs {
-    const int16_t *residual;
-    const uint8_t *jt;
-    const uint32_t *wait_idx;
+struct HotArgs { /* global-memory pointers by type: after the trip through a register the compiler would assume flat addressing */
+    const __attribute__((address_space(1))) int16_t *residual;
+    const __attribute__((address_space(1))) uint8_t *jt;
+    const __attribute__((address_space(1))) uint32_t *wait_idx;
     int bitdepth_y, bitdepth_c;
 };
 __device__ __forceinline__ void fetch_jtable(const HotArgs &a, const IntraSlot &t, const int lane, JPrefetch &jp)
 {
-    const uint8_t *p = a.jt + t.jt_off + lane; /* the table is padded: reading past a small TU's entries is harmless */
+    const __attribute__((address_space(1))) uint8_t *p = a.jt + t.jt_off + lane; /* the table is padded: reading past a small TU's entries is harmless */
     jp.j[0] = p[0];
     if (t.lg >= 4) {
         jp.j[1] = p[64];
@@ -456,12 +456,12 @@ __device__ __forceinline__ void fetch_residual_g(const HotArgs &a, const IntraSl
     rp.wide = false;
     if (!(t.flags & 2)) return;
     const int nn = 1 << (2 * t.lg);
-    const int16_t *src = a.residual + t.res_offset;
+    const __attribute__((address_space(1))) int16_t *src = a.residual + t.res_offset;
     if (((uintptr_t)src & 15) != 0) return;
     rp.wide = true;
 #pragma unroll
     for (int j = 0; j < 2; j++)
-        if (8 * lane + 512 * j < nn) rp.v[j] = *(const u32x4 *)(src + 8 * lane + 512 * j);
+        if (8 * lane + 512 * j < nn) rp.v[j] = *(const __attribute__((address_space(1))) u32x4 *)(src + 8 * lane + 512 * j);
 }
 
 template <int LG>
@@ -536,7 +536,7 @@ __device__ __forceinline__ void intra_tu_g(const HotArgs &a, const GroupCtx &g, 
             for (int j = 0; j < 2; j++)
                 if (512 * j < n * n && 8 * lane + 512 * j < n * n) *(u32x4 *)(R + 8 * lane + 512 * j) = rp.v[j];
         } else {
-            const int16_t *src = a.residual + t.res_offset;
+            const __attribute__((address_space(1))) int16_t *src = a.residual + t.res_offset;
             for (int i = lane; i < n * n; i += 64) R[i] = src[i];
         }
         wave_sync();
@@ -1027,7 +1027,9 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
         unsigned long long p_res = (unsigned long long)a.residual, p_jt = (unsigned long long)a.jt, p_wait = (unsigned long long)a.wait_idx;
         int bdy = a.bitdepth_y, bdc = a.bitdepth_c;
         asm volatile("" : "+s"(p_res), "+s"(p_jt), "+s"(p_wait), "+s"(bdy), "+s"(bdc));
-        hot.residual = (const int16_t *)p_res; hot.jt = (const uint8_t *)p_jt; hot.wait_idx = (const uint32_t *)p_wait;
+        hot.residual = (const __attribute__((address_space(1))) int16_t *)p_res;
+        hot.jt = (const __attribute__((address_space(1))) uint8_t *)p_jt;
+        hot.wait_idx = (const __attribute__((address_space(1))) uint32_t *)p_wait;
         hot.bitdepth_y = bdy; hot.bitdepth_c = bdc;
     }
     if (a.plan_result) {
@@ -1071,7 +1073,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
             return;
         }
     }
-    const __amdgpu_buffer_rsrc_t desc_rs = ffhip_rsrc(a.desc, 0xffffffffu), res_rs = ffhip_rsrc(hot.residual, PROG_NO_RESIDUAL);
+    const __amdgpu_buffer_rsrc_t desc_rs = ffhip_rsrc(a.desc, 0xffffffffu), res_rs = ffhip_rsrc((const void *)hot.residual, PROG_NO_RESIDUAL);
     const int cell_lane4 = 2 * ((lane >> 2) * TILE_STRIDE + (lane & 3)), cell_lane8 = 2 * ((lane >> 3) * TILE_STRIDE + (lane & 7));
     /* the run of plain programs never touches the exec mask (a branch over a load makes the compiler's wait counts
      * pessimistic: it then waits for the loads it issued a moment ago): on a 4x4 TU lanes 16 .. 63 do what lane 0 does --

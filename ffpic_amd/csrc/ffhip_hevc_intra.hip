@@ -1005,6 +1005,60 @@ __device__ __forceinline__ IntraSlot decode_slot(const u32x4 q0, const u32x4 q2)
     return sl;
 }
 
+/* A list the device planner refuses (groups that are not contiguous runs of the decode order for this window, more
+ * than 64 TUs to wait for, an order its ticket rule cannot serve) is still decoded, correctly and slowly: ONE wave walks
+ * it in decode order, which is always a valid order, every neighbour through memory.  A kernel of its own (launched
+ * behind the grouped one, which returns at once in that case; this one returns at once in every other): inlined into the
+ * grouped kernel it doubled that kernel's code, which is as large as the instruction cache as it is. */
+__global__ __launch_bounds__(64) void k_hevc_intra_serial(HevcIntraArgs a)
+{
+    __shared__ short tile[TILE_CELLS];
+    __shared__ int nbA[NB_MAX], nbB[NB_MAX];
+    __shared__ __attribute__((aligned(16))) short resl[2][32 * 32];
+    __shared__ __attribute__((aligned(16))) short resz[32 * 32];
+    __shared__ u32x4 slots[SLOT_CHUNK * 3];
+    const int lane = threadIdx.x;
+    if (!a.plan_result) return;
+    const uint32_t refused = a.plan_result[0] | (a.plan_result[2] > a.wait_cap ? 1u : 0u);
+    if (!__builtin_amdgcn_readfirstlane((int)refused)) return;
+    for (int i = lane; i < 32 * 32 / 8; i += 64) ((u32x4 *)resz)[i] = u32x4{0u, 0u, 0u, 0u};
+    wave_sync();
+    HotArgs hot;
+    hot.residual = (const __attribute__((address_space(1))) int16_t *)(unsigned long long)a.residual;
+    hot.jt = (const __attribute__((address_space(1))) uint8_t *)(unsigned long long)a.jt;
+    hot.wait_idx = nullptr;
+    hot.bitdepth_y = a.bitdepth_y; hot.bitdepth_c = a.bitdepth_c;
+    for (long long base = 0; base < a.n_tus; base += SLOT_CHUNK) {
+        const int m = (int)(a.n_tus - base < SLOT_CHUNK ? a.n_tus - base : SLOT_CHUNK);
+        for (int i = lane; i < 3 * m; i += 64) {
+            const int k = i / 3, part = i - 3 * k;
+            const ffhip_hevc_tu *tp = a.tus + base + k;
+            const int c = tp->cidx;
+            const uint32_t blk = (c == 0 ? a.jt_boff[0] : (c == 1 ? a.jt_boff[1] : a.jt_boff[2])) +
+                                 (uint32_t)(tp->y >> 2) * (uint32_t)(c == 0 ? a.jt_bw[0] : (c == 1 ? a.jt_bw[1] : a.jt_bw[2])) + (uint32_t)(tp->x >> 2);
+            u32x4 q = {0u, 0u, (uint32_t)(base + k), blk * JT_STRIDE}; /* no waits, no flag, no tile */
+            if (part == 0) q = ((const u32x4 *)tp)[0];
+            slots[i] = q;
+        }
+        wave_sync();
+        for (int k = 0; k < m; k++) {
+            const IntraSlot cur = decode_slot(slots[3 * k], slots[3 * k + 2]);
+            ResPrefetch rp;
+            JPrefetch jp;
+            fetch_residual_g(hot, cur, lane, rp);
+            fetch_jtable(hot, cur, lane, jp);
+            GroupCtx sg = {};
+            sg.cidx = (int)cur.cidx; sg.wl = 6; sg.wx0 = (int)(cur.x >> 6) << 6; sg.wy0 = (int)(cur.y >> 6) << 6;
+            sg.stride = sg.cidx == 0 ? a.stride[0] : (sg.cidx == 1 ? a.stride[1] : a.stride[2]);
+            sg.plane_rs = ffhip_rsrc(sg.cidx == 0 ? a.plane[0] : (sg.cidx == 1 ? a.plane[1] : a.plane[2]), 0xffffffffu);
+            intra_tu_g_any(hot, sg, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, resz);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the next TU may read these samples back from memory */
+            wave_sync();
+        }
+        wave_sync();
+    }
+}
+
 __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
 {
     __shared__ short tile[TILE_CELLS];
@@ -1034,44 +1088,10 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
     }
     if (a.plan_result) {
         /* the schedule was built by the kernels in front of this one on the same stream; nobody on the host has looked
-         * at it.  A list the device planner refuses (groups that are not contiguous runs of the decode order for this
-         * window, more than 64 TUs to wait for, an order its ticket rule cannot serve) is still decoded, correctly and
-         * slowly: ONE wave walks it in decode order, which is always a valid order, every neighbour through memory. */
+         * at it.  A list the device planner refuses is decoded by k_hevc_intra_serial, launched behind this kernel */
         const uint32_t refused = a.plan_result[0] | (a.plan_result[2] > a.wait_cap ? 1u : 0u);
         n_groups = (int)a.plan_result[1];
-        if (__builtin_amdgcn_readfirstlane((int)refused)) {
-            if (blockIdx.x != 0) return;
-            for (long long base = 0; base < a.n_tus; base += SLOT_CHUNK) {
-                const int m = (int)(a.n_tus - base < SLOT_CHUNK ? a.n_tus - base : SLOT_CHUNK);
-                for (int i = lane; i < 3 * m; i += 64) {
-                    const int k = i / 3, part = i - 3 * k;
-                    const ffhip_hevc_tu *tp = a.tus + base + k;
-                    const int c = tp->cidx;
-                    const uint32_t blk = (c == 0 ? a.jt_boff[0] : (c == 1 ? a.jt_boff[1] : a.jt_boff[2])) +
-                                         (uint32_t)(tp->y >> 2) * (uint32_t)(c == 0 ? a.jt_bw[0] : (c == 1 ? a.jt_bw[1] : a.jt_bw[2])) + (uint32_t)(tp->x >> 2);
-                    u32x4 q = {0u, 0u, (uint32_t)(base + k), blk * JT_STRIDE}; /* no waits, no flag, no tile */
-                    if (part == 0) q = ((const u32x4 *)tp)[0];
-                    slots[i] = q;
-                }
-                wave_sync();
-                for (int k = 0; k < m; k++) {
-                    const IntraSlot cur = decode_slot(slots[3 * k], slots[3 * k + 2]);
-                    ResPrefetch rp;
-                    JPrefetch jp;
-                    fetch_residual_g(hot, cur, lane, rp);
-                    fetch_jtable(hot, cur, lane, jp);
-                    GroupCtx sg = {};
-                    sg.cidx = (int)cur.cidx; sg.wl = 6; sg.wx0 = (int)(cur.x >> 6) << 6; sg.wy0 = (int)(cur.y >> 6) << 6;
-                    sg.stride = sg.cidx == 0 ? a.stride[0] : (sg.cidx == 1 ? a.stride[1] : a.stride[2]);
-                    sg.plane_rs = ffhip_rsrc(sg.cidx == 0 ? a.plane[0] : (sg.cidx == 1 ? a.plane[1] : a.plane[2]), 0xffffffffu);
-                    intra_tu_g_any(hot, sg, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, resz);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the next TU may read these samples back from memory */
-                    wave_sync();
-                }
-                wave_sync();
-            }
-            return;
-        }
+        if (__builtin_amdgcn_readfirstlane((int)refused)) return;
     }
     const __amdgpu_buffer_rsrc_t desc_rs = ffhip_rsrc(a.desc, 0xffffffffu), res_rs = ffhip_rsrc((const void *)hot.residual, PROG_NO_RESIDUAL);
     const int cell_lane4 = 2 * ((lane >> 2) * TILE_STRIDE + (lane & 3)), cell_lane8 = 2 * ((lane >> 3) * TILE_STRIDE + (lane & 7));
@@ -1743,6 +1763,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             a.trace = g_intra_trace;
 #endif
             hipLaunchKernelGGL(k_hevc_intra_groups, dim3((unsigned)std::min<size_t>((size_t)n_tus, max_waves)), dim3(64), 0, st, a);
+            hipLaunchKernelGGL(k_hevc_intra_serial, dim3(1), dim3(64), 0, st, a); /* does something only for a list the planner refused */
             FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
             return FFHIP_OK;
         }

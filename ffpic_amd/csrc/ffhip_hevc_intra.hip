@@ -464,9 +464,9 @@ __device__ __forceinline__ void fetch_residual_g(const HotArgs &a, const IntraSl
         if (8 * lane + 512 * j < nn) rp.v[j] = *(const __attribute__((address_space(1))) u32x4 *)(src + 8 * lane + 512 * j);
 }
 
-template <int LG>
+template <int LG, class MID>
 __device__ __forceinline__ void intra_tu_g(const HotArgs &a, const GroupCtx &g, const IntraSlot &t, const int lane, int *s, int *s2, short *R,
-                                           const ResPrefetch &rp, const JPrefetch &jp, short *tile, const short *zero_block)
+                                           const ResPrefetch &rp, const JPrefetch &jp, short *tile, const short *zero_block, MID &&mid)
 {
     constexpr int n = 1 << LG, lg = LG, cnt = 4 * n + 1;
     const int x0 = (int)t.x, y0 = (int)t.y;
@@ -495,6 +495,7 @@ __device__ __forceinline__ void intra_tu_g(const HotArgs &a, const GroupCtx &g, 
     }
     wave_sync();
     STAMP(0);
+    mid(); /* the caller's fetches for the NEXT TU: behind this TU's own neighbour loads, with the rest of the TU to arrive in */
 #define LEFT(y) s[2 * n - 1 - (y)]
 #define TOP(x) s[2 * n + 1 + (x)] /* TOP(-1) is the corner */
 
@@ -884,14 +885,15 @@ __global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
     }
 }
 
+template <class MID>
 __device__ __forceinline__ void intra_tu_g_any(const HotArgs &a, const GroupCtx &g, const IntraSlot &t, const int lane, int *s, int *s2, short *R,
-                                               const ResPrefetch &rp, const JPrefetch &jp, short *tile, const short *zero_block)
+                                               const ResPrefetch &rp, const JPrefetch &jp, short *tile, const short *zero_block, MID &&mid)
 {
     switch (t.lg) {
-    case 2: intra_tu_g<2>(a, g, t, lane, s, s2, R, rp, jp, tile, zero_block); break;
-    case 3: intra_tu_g<3>(a, g, t, lane, s, s2, R, rp, jp, tile, zero_block); break;
-    case 4: intra_tu_g<4>(a, g, t, lane, s, s2, R, rp, jp, tile, zero_block); break;
-    default: intra_tu_g<5>(a, g, t, lane, s, s2, R, rp, jp, tile, zero_block); break;
+    case 2: intra_tu_g<2>(a, g, t, lane, s, s2, R, rp, jp, tile, zero_block, mid); break;
+    case 3: intra_tu_g<3>(a, g, t, lane, s, s2, R, rp, jp, tile, zero_block, mid); break;
+    case 4: intra_tu_g<4>(a, g, t, lane, s, s2, R, rp, jp, tile, zero_block, mid); break;
+    default: intra_tu_g<5>(a, g, t, lane, s, s2, R, rp, jp, tile, zero_block, mid); break;
     }
 }
 
@@ -1051,7 +1053,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_serial(HevcIntraArgs a)
             sg.cidx = (int)cur.cidx; sg.wl = 6; sg.wx0 = (int)(cur.x >> 6) << 6; sg.wy0 = (int)(cur.y >> 6) << 6;
             sg.stride = sg.cidx == 0 ? a.stride[0] : (sg.cidx == 1 ? a.stride[1] : a.stride[2]);
             sg.plane_rs = ffhip_rsrc(sg.cidx == 0 ? a.plane[0] : (sg.cidx == 1 ? a.plane[1] : a.plane[2]), 0xffffffffu);
-            intra_tu_g_any(hot, sg, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, resz);
+            intra_tu_g_any(hot, sg, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, resz, [] {});
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the next TU may read these samples back from memory */
             wave_sync();
         }
@@ -1303,6 +1305,29 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
 #ifdef FFHIP_INTRA_TRACE
                     tr1 = TRACE_NOW();
 #endif
+                    /* the extras of the NEXT TU, if it needs any, leave now and land in registers of their own while this TU
+                     * runs; they move into place behind it, when they have long arrived.  (Fetched behind this TU into the
+                     * registers the next one reads them from, the compiler's copies between the call sites of the fetch
+                     * waited for them on the spot: a trip to memory between any two generic TUs.) */
+                    const bool nx_have = (psB.packed & (PK_SLOW | PK_END)) == PK_SLOW;
+                    u32x4 nq0 = {0u, 0u, 0u, 0u}, nq2 = {0u, 0u, 0u, 0u};
+                    JPrefetch jpn;
+                    ResPrefetch rpn;
+                    uint32_t widxn = 0;
+                    jpn.j[0] = jpn.j[1] = jpn.j[2] = 0; rpn.wide = false; rpn.v[0] = rpn.v[1] = nq0;
+                    auto fetch_next_extras = [&]() {
+                        if (nx_have) {
+                            nq0 = slots[3 * (k + 1)]; nq2 = slots[3 * (k + 1) + 2];
+                            const IntraSlot nx = decode_slot(nq0, nq2);
+                            if (PK_KIND(psB.packed) == PROG_GENERIC) {
+                                fetch_jtable(hot, nx, lane, jpn);
+                                fetch_residual_g(hot, nx, lane, rpn);
+                            } else if (psB.packed & PK_OUTSIDE) {
+                                fetch_jtable(hot, nx, lane, jpn);
+                            }
+                            if (nx.wait_count) widxn = hot.wait_idx[nx.wait_begin + (lane < (int)nx.wait_count ? lane : 0)];
+                        }
+                    };
                     if (is_prog) {
                         STAMP(0);
                         if (ps.packed & PK_OUTSIDE) intra_program_halo(gc, (int)cur.x, (int)cur.y, 1 << cur.lg, lane, jp.j[0], tile);
@@ -1310,8 +1335,9 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                         if (ps.packed & PK_LG3) intra_program<3>(hot, gc, ps, lane, pp, tile, cell_lane8);
                         else intra_program<2>(hot, gc, ps, lane, pp, tile, cell_lane4);
                         STAMP(3);
+                        fetch_next_extras(); /* a program is short: behind it */
                     } else {
-                        intra_tu_g_any(hot, gc, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, resz);
+                        intra_tu_g_any(hot, gc, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, resz, fetch_next_extras);
                     }
                     if (cur.signal) { /* somebody outside the group reads this TU: publish it once its stores have completed */
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* compiler ordering; no L2-wide write-back */
@@ -1325,13 +1351,15 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                     }
                     if (!is_prog) wave_sync(); /* the next TU reuses the neighbour scratch (a program touches only the tile, in order) */
                     TRACE_TU_END();
-                    STAMP(4);
                     ++k;
                     PREFETCH_PROGRAM(psA, ppA, k + 1); /* set A: TU k + 1, set B: TU k */
                     SWAP_SETS();
                     STAMP(5);
-                    have_extras = (psA.packed & (PK_SLOW | PK_END)) == PK_SLOW;
-                    if (have_extras) fetch_extras(psA, k); /* behind this TU's stores, one TU ahead like the programs of the run */
+                    have_extras = nx_have;
+                    if (nx_have) { /* set A is the TU the early fetch was for */
+                        cur = decode_slot(nq0, nq2);
+                        jp = jpn; rp = rpn; widx = widxn;
+                    }
                     STAMP(6);
                 }
             }

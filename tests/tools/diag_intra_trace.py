@@ -87,6 +87,7 @@ def cross_deps(i):
 
 stage_names = ["gather", "filter", "residual", "predict+store", "publish"]
 stage = {l: np.zeros(5) for l in (2, 3, 4, 5)}
+stage_n = {l: 0 for l in (2, 3, 4, 5)}
 pk = {}   # program TUs on the path: (size, kind, halo) -> [count, body ticks]
 cat = {"body": {2: 0, 3: 0, 4: 0, 5: 0}, "in-group": 0, "hand-off": 0, "start": 0}
 cnt = {"body": {2: 0, 3: 0, 4: 0, 5: 0}, "in-group": 0, "hand-off": 0, "start": 0}
@@ -99,8 +100,10 @@ while cur >= 0:
     cat["body"][int(lg[cur])] += int(t_end[cur] - t_start[cur]); cnt["body"][int(lg[cur])] += 1
     if tkind[cur]:
         e = pk.setdefault((int(lg[cur]), int(tkind[cur]), int(halo[cur])), [0, 0]); e[0] += 1; e[1] += int(t_end[cur] - t_start[cur])
-    st4 = rec[cur, 4:8]
-    stage[int(lg[cur])] += np.array([st4[0] - t_start[cur], st4[1] - st4[0], st4[2] - st4[1], st4[3] - st4[2], t_end[cur] - st4[3]], dtype=np.float64)
+    if tkind[cur] == 0:   # the stage stamps belong to the generic body
+        st4 = rec[cur, 4:8]
+        stage[int(lg[cur])] += np.array([st4[0] - t_start[cur], st4[1] - st4[0], st4[2] - st4[1], st4[3] - st4[2], t_end[cur] - st4[3]], dtype=np.float64)
+        stage_n[int(lg[cur])] += 1
     cands = []
     p = int(prev_in_group[cur])
     if p >= 0: cands.append((int(t_end[p]), "in-group", p))
@@ -117,10 +120,10 @@ while cur >= 0:
     gap = int(t_start[cur]) - te
     cat[kind] += gap; cnt[kind] += 1
     if kind == "in-group" and tkind[cur] == 0 and tkind[j] == 0:   # generic after generic: the pieces of the gap (stamps 4..6 sit in the later TU's record)
-        g4, g5, g6 = int(rec[cur, 8]), int(rec[cur, 9]), int(rec[cur, 10])
-        if g4 >= te and g6 <= int(t_start[cur]):
-            gg = gaps.setdefault("generic->generic", [0, 0, 0, 0, 0, 0]); gg[0] += 1
-            gg[1] += g4 - te; gg[2] += g5 - g4; gg[3] += g6 - g5; gg[4] += int(t_begin[cur]) - g6; gg[5] += int(t_start[cur]) - int(t_begin[cur])
+        g4, g5, g6, g7 = int(rec[cur, 8]), int(rec[cur, 9]), int(rec[cur, 10]), int(rec[cur, 11])
+        if g5 >= te and g6 <= int(t_start[cur]):
+            gg = gaps.setdefault("generic->generic", [0, 0, 0, 0, 0, 0, 0, 0]); gg[0] += 1
+            gg[2] += g5 - te; gg[3] += g6 - g5; gg[4] += int(t_begin[cur]) - g6; gg[5] += int(t_start[cur]) - int(t_begin[cur])
     if kind == "hand-off": handoffs.append(gap)
     cur = j
 tot = sum(cat["body"].values()) + cat["in-group"] + cat["hand-off"] + cat["start"]
@@ -129,8 +132,8 @@ for l in (2, 3, 4, 5):
     if cnt["body"][l]:
         print(f"  body {1 << l:2d}x{1 << l:<2d}: {cnt['body'][l]:6d} TUs  {cat['body'][l] / 100.0:9.1f} us  ({cat['body'][l] / cnt['body'][l] / 100.0:.2f} us each)")
 for l in (2, 3, 4, 5):
-    if cnt["body"][l]:
-        print(f"    stages {1 << l:2d}x{1 << l:<2d} (us each): " + ", ".join(f"{nm} {stage[l][q] / cnt['body'][l] / 100.0:.2f}" for q, nm in enumerate(stage_names)))
+    if stage_n[l]:
+        print(f"    generic {1 << l:2d}x{1 << l:<2d} ({stage_n[l]} TUs), stages (us each): " + ", ".join(f"{nm} {stage[l][q] / stage_n[l] / 100.0:.2f}" for q, nm in enumerate(stage_names)))
 for key in sorted(pk):
     print(f"    program {1 << key[0]}x{1 << key[0]} kind {key[1]} halo {key[2]}: {pk[key][0]:6d} TUs, {pk[key][1] / pk[key][0] / 100.0:.2f} us each")
 print(f"  programs overall: {int((tkind > 0).sum())} of {n} TUs")
@@ -139,7 +142,7 @@ for k in ("in-group", "hand-off", "start"):
         print(f"  {k:9s}: {cnt[k]:6d} steps {cat[k] / 100.0:9.1f} us  ({cat[k] / cnt[k] / 100.0:.2f} us each)")
 for kname, gg in gaps.items():
     c = gg[0]
-    print(f"  gap {kname}: {c} steps; trace write + sync {gg[1] / c / 100:.2f}, program fetch + swap {gg[2] / c / 100:.2f}, extras fetch {gg[3] / c / 100:.2f}, loop top {gg[4] / c / 100:.2f}, wait {gg[5] / c / 100:.2f} us")
+    print(f"  gap {kname}: {c} steps; trace write + sync + program fetch + swap {gg[2] / c / 100:.2f}, extras into place {gg[3] / c / 100:.2f}, loop top {gg[4] / c / 100:.2f}, wait {gg[5] / c / 100:.2f} us")
 if handoffs:
     h = np.array(handoffs) / 100.0
     print(f"  hand-off gap percentiles (us): p10 {np.percentile(h, 10):.2f} p50 {np.percentile(h, 50):.2f} p90 {np.percentile(h, 90):.2f} max {h.max():.2f}")

@@ -21,7 +21,7 @@ __global__ void k(unsigned long long *out, int seed)
     int s = seed;
     r0 = wall_clock64(); c0 = clock64();
 #pragma unroll 64
-    for (int i = 0; i < N; i++) asm volatile("s_add_u32 %0, %0, 3" : "+s"(s));
+    for (int i = 0; i < N; i++) asm volatile("s_mul_i32 %0, %0, 3" : "+s"(s)); /* no SCC: the loop counter lives there */
     c1 = clock64(); r1 = wall_clock64();
     if (lane == 0) { out[2] = c1 - c0; out[3] = r1 - r0; }
     // (c) dependent LDS read chain
@@ -51,7 +51,7 @@ __global__ void k(unsigned long long *out, int seed)
     if (lane == 0) { out[8] = c1 - c0; out[9] = r1 - r0; }
     // (f) taken branches
     r0 = wall_clock64(); c0 = clock64();
-    for (int i = 0; i < N / 4; i++) { asm volatile("s_add_u32 %0, %0, 1" : "+s"(s)); if (s == 0x7fffffff) break; }
+    for (int i = 0; i < N / 4; i++) { asm volatile("s_mul_i32 %0, %0, 5" : "+s"(s)); if (s == 0x7fffffff) break; } /* not unrolled: one taken branch per trip */
     c1 = clock64(); r1 = wall_clock64();
     if (lane == 0) { out[10] = c1 - c0; out[11] = r1 - r0; out[12] = v + s + p + w0 + w1 + w2 + w3; }
 }
@@ -63,7 +63,7 @@ int main()
         hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d, rep);
         hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
     }
-    const char *names[] = {"dependent VALU", "dependent SALU", "dependent LDS read", "readfirstlane + VALU pair", "independent VALU", "loop iteration (s_add, s_cmp, branch)"};
+    const char *names[] = {"dependent VALU", "dependent SALU", "dependent LDS read", "readfirstlane + VALU pair", "independent VALU", "loop trip (s_mul, s_cmp, taken branch)"};
     const int counts[] = {N, N, N / 4, N / 4, N, N / 4};
     for (int i = 0; i < 6; i++)
         printf("%-40s %7.2f shader cycles, %7.2f ns each (clock64 %llu, 100 MHz ticks %llu)\n", names[i], (double)h[2 * i] / counts[i],

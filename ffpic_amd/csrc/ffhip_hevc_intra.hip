@@ -1271,7 +1271,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                 }
                 if (psA.packed & PK_END) break;
                 if (!have_extras) fetch_extras(psA, k); /* only the first slot of a chunk comes here without them */
-                {
+                do { /* TUs that are not plain programs, one after the other: the extras of each were fetched during the one before */
                     const ProgSlot &ps = psA;
                     const ProgPrefetch &pp = ppA;
                     TRACE_TU_BEGIN(ps);
@@ -1361,7 +1361,8 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                         jp = jpn; rp = rpn; widx = widxn;
                     }
                     STAMP(6);
-                }
+                } while ((psA.packed & (PK_SLOW | PK_END)) == PK_SLOW);
+                if (dead) break;
             }
             wave_sync(); /* slots[] is about to be overwritten */
         }

@@ -96,6 +96,17 @@ def test_grouped_form_small_ctb_falls_back_to_smaller_window():
         assert np.array_equal(gp, e), name
 
 
+@pytest.mark.parametrize("w,h,ctb,seed", [(80, 48, 16, 71), (96, 160, 32, 72), (208, 112, 16, 73)])
+def test_pictures_that_are_not_a_whole_number_of_windows(w, h, ctb, seed):
+    """picture sizes that are multiples of a small coding tree block only: the 64x64 scheduling windows, the per-pixel
+    program words and the substitution table all hang over the picture's edge"""
+    tus, res = synth.hevc_intra_tus(w, h, seed, ctb=ctb, adversarial_masks=True)
+    got = ops.hevc_intra_recon(tus, res, w, h, True, 8, 8)
+    exp = O.oracle_hevc_intra(tus, res, w, h, True, 8, 8)
+    for gp, e, name in zip(got, exp, "YUV"):
+        assert np.array_equal(gp, e), name
+
+
 @pytest.mark.parametrize("w,h,seed,bd", [(192, 128, 61, 8), (128, 192, 62, 10)])
 def test_heic_chain_levels_to_bgra(w, h, seed, bd):
     """BASELINE config 5 in small: quantised levels -> ffhip_hevc_residual_batch per TU size -> ffhip_hevc_intra_recon

@@ -32,7 +32,9 @@
 #include <vector>
 
 #ifndef FFHIP_HEVC_INTRA_WAVES
-#define FFHIP_HEVC_INTRA_WAVES 1024 /* waves of the grouped form's one launch */
+#define FFHIP_HEVC_INTRA_WAVES 256 /* waves of the grouped form's one launch: enough for the widest wavefront of an 8K picture (~200 groups)
+                                      and for a grid of 96 tiles; every further wave only holds a ticket far from its turn and polls
+                                      (1024 waves: config-5 mix 6.5 ms, quadtree 11.7; 256: 6.0 / 11.4; tests/tools/bench_intra_c5.py) */
 #endif
 #ifndef FFHIP_HEVC_INTRA_WINDOW_LOG2
 #define FFHIP_HEVC_INTRA_WINDOW_LOG2 5 /* luma window of the grouped form: 32x32 (1080p sweep in profiles/r1_stages.json) */

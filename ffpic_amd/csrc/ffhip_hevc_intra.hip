@@ -1296,8 +1296,8 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
 #define FFHIP_POLL_FAST 16
 #endif
 #ifndef FFHIP_POLL_SLOW_SLEEP
-#define FFHIP_POLL_SLOW_SLEEP 64 /* ~2 us between polls of a wave far from its turn: at 16 the thousand waiting waves sent 15 M flag reads per
-                                    8K picture through the L2 the working waves use (config-5 mix 6.7 -> 6.35 ms; 127 is no better) */
+#define FFHIP_POLL_SLOW_SLEEP 16 /* ~0.5 us between polls of a wave far from its turn.  With 1024 waves in the launch this sent 15 M flag
+                                    reads per 8K picture through the L2 the working waves use and 64 was better; with 256 waves 8 .. 32 are alike */
 #endif
                             if (spins < FFHIP_POLL_FAST) __builtin_amdgcn_s_sleep(1);
                             else __builtin_amdgcn_s_sleep(FFHIP_POLL_SLOW_SLEEP); /* far from ready */

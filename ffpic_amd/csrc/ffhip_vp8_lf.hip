@@ -411,7 +411,9 @@ extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int fi
         a.mbcols = mbcols; a.mbrows = mbrows; a.filter_type = filter_type;
         a.ctrl = g_work; a.async_err = async_err; a.n_images = n_images;
         const char *wv = getenv("FFHIP_VP8_LF_WAVES");
-        const long long cap = wv ? std::max(1, atoi(wv)) : 2048;
+        /* sixteen rows in flight per image cover its wavefront; a wave beyond that holds a ticket far from its turn and only polls
+         * (16 x 1080p: 2048 waves 5.62 / 2.10 ms, 256 waves 5.48 / 1.96 -- tests/tools/bench_stages.py) */
+        const long long cap = wv ? std::max(1, atoi(wv)) : std::min<long long>(2048, std::max<long long>(256, 16LL * n_images));
         hipLaunchKernelGGL(k_vp8_loopfilter_rows, dim3((unsigned)std::min<long long>((long long)n_images * mbrows, cap)), dim3(64), 0, st, a);
         FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
         return FFHIP_OK;

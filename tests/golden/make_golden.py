@@ -569,6 +569,96 @@ def _ref_decode_hevc_inproc(width, height, seed, n_bytes, out_npz):
     os._exit(0)
 
 
+def _ref_decode_heic_inproc(path, out_npz):
+    """the reference's whole-file HEIF loader (format/heif.c: HEIF_load -> decode_primary_item -> decode_hvc1 -> parse_nalu)
+    with the recorder of oracle/ref_statics_hevc.c on"""
+    R = O.ref()
+
+    class Pic(C.Structure):  # struct pic, format/file.h:29-40 (leading fields)
+        _fields_ = [("pixels", C.c_void_p), ("left", C.c_int), ("top", C.c_int), ("width", C.c_int),
+                    ("height", C.c_int), ("depth", C.c_int), ("pitch", C.c_int)]
+    R.file_ops_init.restype = None
+    R.file_probe.restype = C.c_void_p
+    R.file_probe.argtypes = [C.c_char_p]
+    R.file_load.restype = C.POINTER(Pic)
+    R.file_load.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    R.ref_hevc_record_fetch.argtypes = [C.c_void_p] * 4
+    R.file_ops_init()
+    ops = R.file_probe(path.encode())
+    assert ops, "reference did not recognise " + path
+    R.ref_hevc_record_begin()
+    pp = R.file_load(ops, path.encode(), 0)
+    assert pp, "the reference's HEIF loader returned no picture"
+    p = pp.contents
+    info = (C.c_long * 8)()
+    R.ref_hevc_record_end(info)
+    info = list(info)
+    tus = np.zeros(info[0], HEVC_REC)
+    lv = np.zeros(max(info[1], 1), np.int16)
+    rs = np.zeros(max(info[1], 1), np.int16)
+    pl = np.zeros(max(info[2], 1), np.int16)
+    R.ref_hevc_record_fetch(tus.ctypes.data, lv.ctypes.data, rs.ctypes.data, pl.ctypes.data)
+    buf = np.ctypeslib.as_array(C.cast(p.pixels, C.POINTER(C.c_uint8)), shape=(p.height, p.pitch)).copy()
+    np.savez(out_npz, tus=tus.view(np.uint8), levels=lv, resid=rs, planes=pl, info=np.array(info, np.int64),
+             bgra=buf[:, :p.width * 4].reshape(-1), dims=np.array([p.width, p.height, p.pitch], np.int32))
+    os._exit(0)
+
+
+def _hevc_record_to_fixture(tag, w, h, seed, d, res):
+    """one recorded picture -> the fixture arrays of hevc_file.npz / heic_file.npz, after checking that the restatement
+    reproduces the reference's decode from the record, stage by stage"""
+    rec = d["tus"].view(HEVC_REC)
+    luma = rec[rec["cidx"] == 0]
+    assert int((1 << (2 * luma["log2"])).sum()) == w * h and int(rec["pad"].sum()) == 0, "the recorded TUs do not tile the picture"
+    tus = np.zeros(len(rec), synth.HEVC_TU_DTYPE)
+    for k in ("x", "y", "cidx", "flags", "avail_top", "avail_left"):
+        tus[k] = rec[k]
+    tus["log2_size"], tus["pred_mode"] = rec["log2"], rec["mode"]
+    has = rec["level_off"] >= 0
+    tus["res_offset"] = np.where(has, rec["level_off"], 0)
+    size = w * h
+    planes = d["planes"]
+    y, u, v = planes[:size].reshape(h, w), planes[size:size + size // 4].reshape(h // 2, w // 2), planes[size * 3 // 2:size * 3 // 2 + size // 4].reshape(h // 2, w // 2)
+    F = O.ffo()
+    resid = np.zeros_like(d["resid"])
+    for t in rec[has]:
+        n = 1 << int(t["log2"])
+        o = int(t["level_off"])
+        F.ffo_hevc_residual_tu(np.ascontiguousarray(d["levels"][o:o + n * n]), resid[o:o + n * n], n, int(t["qp"]), int(t["rflags"]), 8, 0, None)
+    assert np.array_equal(resid, d["resid"]), "residual stage"
+    oy, ou, ov = O.oracle_hevc_intra(tus, resid, w, h, True, 8, 8)
+    assert np.array_equal(oy, y) and np.array_equal(ou, u) and np.array_equal(ov, v), "intra reconstruction"
+    bgra = d["bgra"].reshape(h, w * 4)
+    print(f"  {tag}: {w}x{h} seed {seed}: {len(rec)} TUs, sizes {np.bincount(rec['log2'])[2:]}, {int(has.sum())} with residual, "
+          f"residual flags {np.bincount(rec['rflags'][has], minlength=8)}, qP {np.unique(rec['qp'][has])}, |level| max {np.abs(d['levels']).max()}")
+    tuinfo = np.zeros((len(rec), 4), np.uint8)
+    tuinfo[:, 0], tuinfo[:, 1] = rec["qp"], rec["rflags"]
+    res.update({f"{tag}_dims": np.array([w, h, seed], np.int32), f"{tag}_tus": tus.view(np.uint8), f"{tag}_tuinfo": tuinfo,
+                f"{tag}_levels": d["levels"], f"{tag}_resid": d["resid"], f"{tag}_y": y, f"{tag}_u": u, f"{tag}_v": v, f"{tag}_bgra": bgra})
+
+
+def gen_heic_file(R):
+    """f4 at FILE level: a single-image .heic (tests/hevc_bitstream.py::heic -- ISO BMFF boxes written by hand around the
+    hand-assembled HEVC stream) through the reference's whole-file loader, the same recorder running.  Same fixture
+    layout as hevc_file.npz, tag "e"; the container itself is committed as file_e.heic."""
+    import hevc_bitstream as HB
+    w, h, seed, n_bytes = 128, 128, 4145, 8000
+    data = HB.heic(w, h, seed, n_bytes)
+    path = os.path.join(HERE, "file_e.heic")
+    with open(path, "wb") as f:
+        f.write(data)
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "heic.npz")
+        rc = subprocess.call([sys.executable, os.path.abspath(__file__), "--decode-heic", path, out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        assert rc == 0 and os.path.exists(out), "the reference did not decode the .heic file"
+        d = dict(np.load(out))
+    assert tuple(d["dims"][:2]) == (w, h) and int(d["dims"][2]) == w * 4, d["dims"]
+    res = {}
+    _hevc_record_to_fixture("e", w, h, seed, d, res)
+    res["e_stream"] = np.frombuffer(data, np.uint8)
+    save("heic_file.npz", **res)
+
+
 def gen_hevc_file(R):
     """f4 / BASELINE config 5 at stream level: HEVC intra pictures decoded by the reference's OWN parser from
     hand-assembled streams (tests/hevc_bitstream.py: headers written from H.265 7.3, slice data = seeded random bytes).
@@ -690,7 +780,7 @@ def gen_files(R, specs=FILE_SPECS, out_name="jpeg_files.npz"):
 def manifest():
     lines = []
     for f in sorted(os.listdir(HERE)):
-        if f.endswith((".npz", ".jpg", ".webp")):
+        if f.endswith((".npz", ".jpg", ".webp", ".heic")):
             lines.append(f"{hashlib.sha256(open(os.path.join(HERE, f), 'rb').read()).hexdigest()}  {f}")
     open(os.path.join(HERE, "MANIFEST.sha256"), "w").write("\n".join(lines) + "\n")
 
@@ -702,7 +792,7 @@ def main():
     R = O.ref()
     steps = [("blocks", gen_blocks), ("vp8 macroblocks", gen_vp8_mbs), ("vp8 driven", gen_vp8_driven), ("vp8 frames", gen_vp8_frames),
              ("hevc intra", gen_hevc_intra), ("hevc glue", gen_hevc_glue), ("vp8 loop filter", gen_vp8_loopfilter), ("colour", gen_color),
-             ("grids", gen_grids), ("files", gen_files), ("files 422", gen_files_422), ("webp file", gen_webp_file), ("webp file lf", gen_webp_file_lf), ("vp8 filter params", gen_vp8_filter_params), ("hevc file", gen_hevc_file)]
+             ("grids", gen_grids), ("files", gen_files), ("files 422", gen_files_422), ("webp file", gen_webp_file), ("webp file lf", gen_webp_file_lf), ("vp8 filter params", gen_vp8_filter_params), ("hevc file", gen_hevc_file), ("heic file", gen_heic_file)]
     only = sys.argv[2] if len(sys.argv) == 3 and sys.argv[1] == "--only" else None   # e.g. --only "hevc intra"
     for name, fn in steps:
         if only is None or only == name:
@@ -716,6 +806,8 @@ if __name__ == "__main__":
         _ref_decode_file_inproc(sys.argv[2], sys.argv[3])
     if len(sys.argv) == 4 and sys.argv[1] == "--decode-hevc":
         _ref_decode_hevc_inproc(*[int(x) for x in sys.argv[2].split(",")], sys.argv[3])
+    if len(sys.argv) == 4 and sys.argv[1] == "--decode-heic":
+        _ref_decode_heic_inproc(sys.argv[2], sys.argv[3])
     if len(sys.argv) == 4 and sys.argv[1] == "--decode-webp":
         _ref_decode_webp_inproc(sys.argv[2], sys.argv[3])
     main()

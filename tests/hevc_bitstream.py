@@ -108,3 +108,44 @@ def random_slice_data(seed, n_bytes):
 
 def stream(width, height, seed, n_bytes=8000, **pps_kw):
     return [vps(), sps(width, height), pps(**pps_kw), idr_slice(random_slice_data(seed, n_bytes))]
+
+
+# ---- the same stream inside an ISO BMFF / HEIF container (a single-image .heic) -------------------------------------
+# What the reference's loader reads (format/heif.c:466-540, format/basemedia.c): ftyp, then a meta box with hdlr, pitm,
+# iloc, iinf / infe, iprp (ipco with hvcC + ispe, ipma); the coded image item sits in an mdat box as length-prefixed NAL
+# units (decode_hvc1, heif.c:244-257), the parameter sets in the hvcC property (read_hvcc_box, heif.c:78-124).
+
+def _box(fourcc, payload):
+    return (8 + len(payload)).to_bytes(4, "big") + fourcc + payload
+
+
+def _full_box(fourcc, version, flags, payload):
+    return _box(fourcc, bytes([version]) + flags.to_bytes(3, "big") + payload)
+
+
+def heic(width, height, seed, n_bytes=8000, **pps_kw):
+    """bytes of a .heic file whose primary item is the hand-assembled intra picture stream(width, height, seed, ...)"""
+    v, s, p, slice_nal = stream(width, height, seed, n_bytes, **pps_kw)
+    # HEVCDecoderConfigurationRecord (ISO/IEC 14496-15 8.3.3.1): 23 bytes, then the parameter-set arrays
+    cfg = (bytes([1, 0x01]) + (0x60000000).to_bytes(4, "big") + bytes([0x90, 0, 0, 0, 0, 0]) + bytes([120]) +
+           bytes([0xF0, 0x00, 0xFC, 0xFD, 0xF8, 0xF8, 0x00, 0x00, 0x0F, 3]))
+    assert len(cfg) == 23
+    arrays = b"".join(bytes([0x80 | t]) + (1).to_bytes(2, "big") + len(n).to_bytes(2, "big") + n for t, n in ((32, v), (33, s), (34, p)))
+    hvcc = _box(b"hvcC", cfg + arrays)
+    ispe = _full_box(b"ispe", 0, 0, width.to_bytes(4, "big") + height.to_bytes(4, "big"))
+    ipma = _full_box(b"ipma", 0, 0, (1).to_bytes(4, "big") + (1).to_bytes(2, "big") + bytes([2, 0x81, 0x02]))   # item 1: hvcC (essential), ispe
+    iprp = _box(b"iprp", _box(b"ipco", hvcc + ispe) + ipma)
+    hdlr = _full_box(b"hdlr", 0, 0, bytes(4) + b"pict" + bytes(12) + b"\0")
+    pitm = _full_box(b"pitm", 0, 0, (1).to_bytes(2, "big"))
+    iinf = _full_box(b"iinf", 0, 0, (1).to_bytes(2, "big") + _full_box(b"infe", 2, 0, (1).to_bytes(2, "big") + bytes(2) + b"hvc1" + b"\0"))
+    payload = len(slice_nal).to_bytes(4, "big") + slice_nal
+    ftyp = (24).to_bytes(4, "big") + b"ftyp" + b"heic" + bytes(4) + b"mif1" + b"heic"
+
+    def meta_with(offset):
+        iloc = _full_box(b"iloc", 0, 0, bytes([0x44, 0x00]) + (1).to_bytes(2, "big") +                      # offset / length 4 bytes, no base offset
+                         (1).to_bytes(2, "big") + bytes(2) + (1).to_bytes(2, "big") + offset.to_bytes(4, "big") + len(payload).to_bytes(4, "big"))
+        return _full_box(b"meta", 0, 0, hdlr + pitm + iloc + iinf + iprp)
+
+    meta = meta_with(0)
+    meta = meta_with(len(ftyp) + len(meta) + 8)     # the item's absolute file offset: behind ftyp, meta and the mdat header
+    return ftyp + meta + _box(b"mdat", payload)

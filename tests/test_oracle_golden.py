@@ -199,7 +199,7 @@ def test_webp_file_with_loop_filter(golden, ffo, tag):
     assert np.array_equal(out[:h], g[f"{tag}_bgra"])
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])     # "e": through the reference's HEIF loader, from tests/golden/file_e.heic
 def test_hevc_file_config5(golden, ffo, tag):
     """f4 / config 5 at stream level: intra pictures the reference's OWN parser decoded from hand-assembled HEVC streams
     (tests/hevc_bitstream.py), reproduced stage by stage from the per-TU record of its decode: residuals
@@ -393,3 +393,22 @@ def test_jpeg_files_config1(golden, tag):
         assert np.array_equal(out[keep], exp[keep])
     if tag == "q85_420":
         assert (H, W) == (480, 640) and int(g[f"{tag}_last_mcu_exact"]) == 1
+
+
+def test_heic_fixture_is_the_container_the_generator_writes(golden):
+    """file_e.heic (what the reference's HEIF loader decoded for tag "e" of the HEVC file fixtures) is exactly what
+    tests/hevc_bitstream.py::heic assembles: ftyp / meta (hdlr, pitm, iloc, iinf, iprp with hvcC + ispe) / mdat around the
+    hand-written parameter sets and the seeded slice data; the iloc extent points at the length-prefixed slice NAL unit"""
+    import hevc_bitstream as HB
+    g = golden("hevc_file.npz")
+    w, h, seed = [int(x) for x in g["e_dims"]]
+    data = open(os.path.join(GOLDEN, "file_e.heic"), "rb").read()
+    assert data == bytes(g["e_stream"]) == HB.heic(w, h, seed, 8000)
+    assert data[4:12] == b"ftypheic" and data[24 + 4:24 + 8] == b"meta"
+    nals = HB.stream(w, h, seed, 8000)
+    i = data.index(b"mdat") + 4
+    assert int.from_bytes(data[i:i + 4], "big") == len(nals[3]) and data[i + 4:] == nals[3]
+    iloc = data.index(b"iloc")
+    assert int.from_bytes(data[iloc + 4 + 4 + 2 + 2 + 2 + 2 + 2:][:4], "big") == i      # version/flags, sizes, count, id, dref, extents -> offset
+    for n in nals[:3]:
+        assert n in data[:i]          # the parameter sets sit in the hvcC property

@@ -656,6 +656,21 @@ def gen_heic_file(R):
     res = {}
     _hevc_record_to_fixture("e", w, h, seed, d, res)
     res["e_stream"] = np.frombuffer(data, np.uint8)
+    # tag "f": a 1 x 1 grid item over one tile (decode_grid_items, heif.c:273-313): the grid payload is what ffhip_heif_grid_parse reads
+    w, h, seed, n_bytes = 64, 64, 2732, 8000
+    data, grid = HB.heic_grid_1x1(w, h, seed, n_bytes)
+    path = os.path.join(HERE, "file_f_grid.heic")
+    with open(path, "wb") as f:
+        f.write(data)
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "heic.npz")
+        rc = subprocess.call([sys.executable, os.path.abspath(__file__), "--decode-heic", path, out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        assert rc == 0 and os.path.exists(out), "the reference did not decode the grid .heic file"
+        d = dict(np.load(out))
+    assert tuple(d["dims"][:2]) == (w, h) and int(d["dims"][2]) == w * 4, d["dims"]
+    _hevc_record_to_fixture("f", w, h, seed, d, res)
+    res["f_stream"] = np.frombuffer(data, np.uint8)
+    res["f_grid"] = np.frombuffer(grid, np.uint8)
     save("heic_file.npz", **res)
 
 

@@ -149,3 +149,36 @@ def heic(width, height, seed, n_bytes=8000, **pps_kw):
     meta = meta_with(0)
     meta = meta_with(len(ftyp) + len(meta) + 8)     # the item's absolute file offset: behind ftyp, meta and the mdat header
     return ftyp + meta + _box(b"mdat", payload)
+
+
+def heic_grid_1x1(width, height, seed, n_bytes=8000, **pps_kw):
+    """bytes of a .heic file whose primary item is a 1 x 1 `grid` (decode_grid_items, heif.c:273-313) over ONE tile item:
+    item 1 = the grid (8-byte ImageGrid payload in mdat, `dimg` reference to item 2), item 2 = the hvc1 tile.  With one
+    tile the reference's "every tile into the same buffer" (heif.c:305) and a real compositor agree.
+    Returns (file bytes, grid payload)."""
+    v, s, p, slice_nal = stream(width, height, seed, n_bytes, **pps_kw)
+    cfg = (bytes([1, 0x01]) + (0x60000000).to_bytes(4, "big") + bytes([0x90, 0, 0, 0, 0, 0]) + bytes([120]) +
+           bytes([0xF0, 0x00, 0xFC, 0xFD, 0xF8, 0xF8, 0x00, 0x00, 0x0F, 3]))
+    arrays = b"".join(bytes([0x80 | t]) + (1).to_bytes(2, "big") + len(n).to_bytes(2, "big") + n for t, n in ((32, v), (33, s), (34, p)))
+    hvcc = _box(b"hvcC", cfg + arrays)
+    ispe = _full_box(b"ispe", 0, 0, width.to_bytes(4, "big") + height.to_bytes(4, "big"))
+    # properties: 1 = hvcC, 2 = ispe (tile), 3 = ispe (grid output, the same size); item 1 (grid): ispe 3; item 2 (tile): hvcC + ispe 2
+    ipma = _full_box(b"ipma", 0, 0, (2).to_bytes(4, "big") + (1).to_bytes(2, "big") + bytes([1, 0x03]) + (2).to_bytes(2, "big") + bytes([2, 0x81, 0x02]))
+    iprp = _box(b"iprp", _box(b"ipco", hvcc + ispe + ispe) + ipma)
+    hdlr = _full_box(b"hdlr", 0, 0, bytes(4) + b"pict" + bytes(12) + b"\0")
+    pitm = _full_box(b"pitm", 0, 0, (1).to_bytes(2, "big"))
+    infe = lambda item_id, typ: _full_box(b"infe", 2, 0, item_id.to_bytes(2, "big") + bytes(2) + typ + b"\0")
+    iinf = _full_box(b"iinf", 0, 0, (2).to_bytes(2, "big") + infe(1, b"grid") + infe(2, b"hvc1"))
+    iref = _full_box(b"iref", 0, 0, _box(b"dimg", (1).to_bytes(2, "big") + (1).to_bytes(2, "big") + (2).to_bytes(2, "big")))
+    grid = bytes([0, 0, 0, 0]) + width.to_bytes(2, "big") + height.to_bytes(2, "big")   # version, flags (16-bit sizes), rows - 1, columns - 1, output size
+    tile = len(slice_nal).to_bytes(4, "big") + slice_nal
+    ftyp = (24).to_bytes(4, "big") + b"ftyp" + b"heic" + bytes(4) + b"mif1" + b"heic"
+
+    def meta_with(off):
+        item = lambda item_id, o, n: item_id.to_bytes(2, "big") + bytes(2) + (1).to_bytes(2, "big") + o.to_bytes(4, "big") + n.to_bytes(4, "big")
+        iloc = _full_box(b"iloc", 0, 0, bytes([0x44, 0x00]) + (2).to_bytes(2, "big") + item(1, off, len(grid)) + item(2, off + len(grid), len(tile)))
+        return _full_box(b"meta", 0, 0, hdlr + pitm + iloc + iinf + iref + iprp)
+
+    meta = meta_with(0)
+    meta = meta_with(len(ftyp) + len(meta) + 8)
+    return ftyp + meta + _box(b"mdat", grid + tile), grid

@@ -66,3 +66,17 @@ def test_hevc_picture_layout():
         assert (lay.ctbrows, lay.ctbcols) == (-(-height // (1 << lg)), -(-w // (1 << lg)))
     assert L.ffhip_hevc_picture_layout(0, 10, 6, C.byref(lay)) == capi.FFHIP_EINVAL
     assert L.ffhip_hevc_picture_layout(64, 64, 7, C.byref(lay)) == capi.FFHIP_EINVAL
+
+
+@pytest.mark.gpu
+def test_grid_item_of_the_reference_decoded_heic(golden):
+    """the ImageGrid payload of tests/golden/file_f_grid.heic -- a file the reference's own HEIF loader decoded through
+    decode_grid_items -- parsed by ffhip_heif_grid_parse, and its one tile composed by ffhip_heif_grid_compose: the canvas is
+    the reference's picture"""
+    g = golden("hevc_file.npz")
+    w, h, _ = [int(x) for x in g["f_dims"]]
+    grid = ops.heif_grid_parse(bytes(g["f_grid"]))
+    assert (grid.rows, grid.cols, grid.output_width, grid.output_height) == (1, 1, w, h)
+    tile = np.ascontiguousarray(g["f_bgra"]).reshape(1, h, w, 4)
+    got = ops.heif_grid_compose(tile, grid.cols, grid.output_width, grid.output_height)
+    assert np.array_equal(np.asarray(got).reshape(h, w * 4), g["f_bgra"])

@@ -149,7 +149,7 @@ def test_heic_chain_levels_to_bgra(w, h, seed, bd):
     assert np.array_equal(bgra, oracle_420_16(exp[0], exp[1], exp[2], h // ctb, w // ctb, ctb))
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])     # "e": through the reference's HEIF loader, from tests/golden/file_e.heic
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])     # "e", "f": through the reference's HEIF loader, from tests/golden/file_e.heic (one image item) and file_f_grid.heic (a 1 x 1 grid item)
 def test_hevc_file_config5(golden, tag):
     """f4 / BASELINE config 5 from the reference's own parse: quantised levels and TU lists its decoder recorded while
     decoding a hand-assembled HEVC stream -> ffhip_hevc_residual_batch per TU size -> ffhip_hevc_intra_recon ->

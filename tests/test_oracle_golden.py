@@ -199,7 +199,7 @@ def test_webp_file_with_loop_filter(golden, ffo, tag):
     assert np.array_equal(out[:h], g[f"{tag}_bgra"])
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])     # "e": through the reference's HEIF loader, from tests/golden/file_e.heic
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])     # "e", "f": through the reference's HEIF loader, from tests/golden/file_e.heic (one image item) and file_f_grid.heic (a 1 x 1 grid item)
 def test_hevc_file_config5(golden, ffo, tag):
     """f4 / config 5 at stream level: intra pictures the reference's OWN parser decoded from hand-assembled HEVC streams
     (tests/hevc_bitstream.py), reproduced stage by stage from the per-TU record of its decode: residuals
@@ -412,3 +412,17 @@ def test_heic_fixture_is_the_container_the_generator_writes(golden):
     assert int.from_bytes(data[iloc + 4 + 4 + 2 + 2 + 2 + 2 + 2:][:4], "big") == i      # version/flags, sizes, count, id, dref, extents -> offset
     for n in nals[:3]:
         assert n in data[:i]          # the parameter sets sit in the hvcC property
+
+
+def test_heic_grid_fixture(golden):
+    """file_f_grid.heic: primary item = a 1 x 1 `grid` whose `dimg` reference names the hvc1 tile; the reference went
+    through decode_grid_items (heif.c:273-313) for it"""
+    import hevc_bitstream as HB
+    g = golden("hevc_file.npz")
+    w, h, seed = [int(x) for x in g["f_dims"]]
+    data = open(os.path.join(GOLDEN, "file_f_grid.heic"), "rb").read()
+    built, grid = HB.heic_grid_1x1(w, h, seed, 8000)
+    assert data == bytes(g["f_stream"]) == built and bytes(g["f_grid"]) == grid == bytes([0, 0, 0, 0]) + w.to_bytes(2, "big") + h.to_bytes(2, "big")
+    assert b"grid" in data and b"dimg" in data and b"iref" in data
+    i = data.index(b"mdat") + 4
+    assert data[i:i + 8] == grid

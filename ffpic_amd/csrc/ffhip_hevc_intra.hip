@@ -1751,7 +1751,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
         a.jt = ja.jt;
         hipLaunchKernelGGL(k_hevc_intra_jtable, dim3((unsigned)((n_tus + 3) / 4)), dim3(256), 0, st, ja);
     };
-    if (want_groups && async_err && offsets_fit && jt_blocks * JT_STRIDE < (1ull << 32) /* 32-bit byte offsets into a plane and the table */) {
+    if (want_groups && async_err && offsets_fit && jt_blocks * JT_STRIDE < (1ull << 32) && desc_px < (1ull << 29) /* 32-bit byte offsets into a plane, the table and the pixel words */) {
         const char *we = getenv("FFHIP_HEVC_INTRA_WINDOW");
         const char *wv = getenv("FFHIP_HEVC_INTRA_WAVES");
         const size_t max_waves = wv ? (size_t)std::max(1, atoi(wv)) : FFHIP_HEVC_INTRA_WAVES;

@@ -85,24 +85,34 @@ __global__ __launch_bounds__(256) void k_plan_owner(PlanArgs a)
 __global__ __launch_bounds__(1024) void k_plan_cell_depth(PlanArgs a)
 {
     __shared__ unsigned short dl[CELLS_LDS];
+    __shared__ unsigned char el[CELLS_LDS]; /* the cells' edge bits: read once, not once per diagonal step (a trip to memory each) */
     const int c = blockIdx.x;
     const uint32_t gw = a.cgw[c], gh = a.cgh[c], cnt = gw * gh;
     if (cnt == 0) return;
     const bool lds = cnt <= CELLS_LDS;
     uint32_t *dg = a.cell_depth + a.cell_off[c];
     const uint32_t *eg = a.cell_edges + a.cell_off[c];
+    if (lds) {
+#pragma unroll 8
+        for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) el[k] = (unsigned char)eg[k]; /* eight loads in flight per lane */
+        __syncthreads();
+    }
     for (uint32_t K = 0; K <= (gw - 1) + 2 * (gh - 1); K++) {
-        for (uint32_t y = threadIdx.x; y < gh && 2 * y <= K; y += 1024) {
+        for (uint32_t y = threadIdx.x; y < gh && 2 * y <= K; y += blockDim.x) {
             const uint32_t x = K - 2 * y;
             if (x >= gw) continue;
-            const uint32_t k = y * gw + x, e = eg[k];
-            uint32_t v = 0;
+            const uint32_t k = y * gw + x, e = lds ? (uint32_t)el[k] : eg[k];
 #define DEPTH(i) (lds ? (uint32_t)dl[i] : dg[i])
-            if ((e & 1u) && x > 0) v = max(v, DEPTH(k - 1) + 1);
-            if ((e & 2u) && y > 0) v = max(v, DEPTH(k - gw) + 1);
-            if ((e & 4u) && y > 0 && x > 0) v = max(v, DEPTH(k - gw - 1) + 1);
-            if ((e & 8u) && y > 0 && x + 1 < gw) v = max(v, DEPTH(k - gw + 1) + 1);
+            /* the four neighbours at once (a cell without that neighbour reads itself and ignores it): one LDS latency per
+             * step instead of four dependent ones */
+            const bool hl = x > 0, hu = y > 0, hr = y > 0 && x + 1 < gw;
+            const uint32_t dl_ = DEPTH(hl ? k - 1 : k), du_ = DEPTH(hu ? k - gw : k), dul_ = DEPTH(hl && hu ? k - gw - 1 : k), dur_ = DEPTH(hr ? k - gw + 1 : k);
 #undef DEPTH
+            uint32_t v = 0;
+            if ((e & 1u) && hl) v = max(v, dl_ + 1);
+            if ((e & 2u) && hu) v = max(v, du_ + 1);
+            if ((e & 4u) && hl && hu) v = max(v, dul_ + 1);
+            if ((e & 8u) && hr) v = max(v, dur_ + 1);
             if (lds) dl[k] = (unsigned short)v;
             else dg[k] = v;
         }
@@ -110,7 +120,7 @@ __global__ __launch_bounds__(1024) void k_plan_cell_depth(PlanArgs a)
         __syncthreads();
     }
     if (lds)
-        for (uint32_t k = threadIdx.x; k < cnt; k += 1024) dg[k] = dl[k];
+        for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) dg[k] = dl[k];
 }
 
 /* per run: its wavefront key.  Runs of one cell share a key and keep their decode order (the run id in the low bits) */
@@ -351,7 +361,12 @@ extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, 
     hipLaunchKernelGGL(k_plan_count, dim3(grid), dim3(256), 0, st, a);
     if (hipcub::DeviceScan::ExclusiveSum(tmp, scan_tmp, a.wcount, a.wbegin, (int)n, st) != hipSuccess) return FFHIP_EIO;
     /* tickets: runs sorted by (wavefront key of their cell, decode order) */
-    hipLaunchKernelGGL(k_plan_cell_depth, dim3(3), dim3(1024), 0, st, a);
+    {   /* one diagonal per step, at most one cell per row of cells: a picture of up to 64 rows of cells is swept by ONE wave per
+         * plane (a wave-local barrier per step), larger ones by 1024 threads so that a step stays one pass */
+        uint32_t max_gh = 0;
+        for (int c = 0; c < 3; c++) max_gh = a.cgh[c] > max_gh ? a.cgh[c] : max_gh;
+        hipLaunchKernelGGL(k_plan_cell_depth, dim3(3), dim3(max_gh <= 64 ? 64 : 1024), 0, st, a);
+    }
     hipLaunchKernelGGL(k_plan_keys, dim3(grid), dim3(256), 0, st, a);
     if (hipcub::DeviceRadixSort::SortPairs(tmp, scan_tmp, a.keys_in, a.keys_out, a.vals_in, vals_out, (int)n, 0, 64, st) != hipSuccess) return FFHIP_EIO;
     hipLaunchKernelGGL(k_plan_rank, dim3(grid), dim3(256), 0, st, a, (const uint32_t *)vals_out);

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void k_vp8_loopfilter(Vp8LfArgs a)
  * of one image; macroblock (x, y) may start once (x + 1, y - 1) is out, which the row above says
  * through its progress counter.  Going left to right, the 4-pixel left border is simply the right
  * end of the tile the wave has just filtered, so per macroblock only the new 16 (8) columns are
- * fetched -- two macroblocks ahead, with device-coherent loads because the four rows above belong
+ * fetched -- one macroblock ahead, with device-coherent loads because the four rows above belong
  * to another wave -- and the filtered columns are stored with agent-scope stores.  The counter moves
  * when the in-order completion of the wave's memory operations proves those stores done. */
 #define LF_SPIN_LIMIT (1 << 21)
@@ -274,10 +274,11 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
             return true;
         };
 
-        LfFetch f, f1;
+        /* fetches run ONE macroblock ahead, into the registers the consumed fetch has just left (two ahead through register
+         * sets rotated by copies, as in the first form, made every macroblock wait for the loads it had just issued: a copy of
+         * a register with a load in flight waits for the load) */
+        LfFetch f;
         if (!fetch(0, f)) return;
-        f1 = f;
-        if (a.mbcols > 1 && !fetch(1, f1)) return;
         for (int x = 0; x < a.mbcols; x++) {
             /* ---- consume: the tile's right end becomes the left border, the fetch the new columns ---- */
             u32 keepl = 0, keepc = 0;
@@ -297,10 +298,9 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
             }
             const u32 m0 = (u32)__builtin_amdgcn_readfirstlane((int)f.m0), m4 = (u32)__builtin_amdgcn_readfirstlane((int)f.m4);
             wave_sync();
-            /* the fetch just consumed was issued behind the stores of macroblock x - 3: those are done */
-            if (lane == 0 && x >= 3) __hip_atomic_store(prog_me, (unsigned)(x - 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            LfFetch fn = f1;
-            if (x + 2 < a.mbcols && !fetch(x + 2, fn)) return;
+            /* the fetch just consumed was issued behind the stores of macroblock x - 2: those are done */
+            if (lane == 0 && x >= 2) __hip_atomic_store(prog_me, (unsigned)(x - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (x + 1 < a.mbcols && !fetch(x + 1, f)) return;
 
             const bool bpred = (m0 & 0xff) == 4;
             const uint8_t *fp = FT + ((((m4 >> 16) & 3) * 2) + (bpred ? 1 : 0)) * 3;
@@ -374,8 +374,6 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
                 }
             }
             wave_sync();
-            f = f1;
-            f1 = fn;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

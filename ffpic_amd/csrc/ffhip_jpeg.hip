@@ -78,13 +78,22 @@ __device__ __forceinline__ int dot2z(u32 a, u32 k)
     return d;
 }
 
+/* 3-address VOP3P form with the accumulator in a VGPR: the even part chains its four outputs off ap / am directly
+ * (E0 = ap + b0 and E3 = ap - b0 as two dot2 with negated constants: 6 instructions for the even part instead of 8), and
+ * the rounding constant lives in a VGPR for the whole kernel instead of a v_mov per chain start */
+__device__ __forceinline__ int dot2a(u32 a, u32 k, int acc)
+{
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(acc));
+    return d;
+}
+
 __device__ __forceinline__ void idct8_1d(u32 e0, u32 e1, u32 o0, u32 o1, int rnd, int out[8])
 {
-    const int ap = dot2(e0, PK16(8192, 8192), rnd);
-    const int am = dot2(e0, PK16(8192, -8192), rnd);
-    const int b0 = dot2z(e1, PK16(10703, 4433));
-    const int b1 = dot2z(e1, PK16(4433, -10704));
-    const int E0 = ap + b0, E3 = ap - b0, E1 = am + b1, E2 = am - b1;
+    const int ap = dot2a(e0, PK16(8192, 8192), rnd);
+    const int am = dot2a(e0, PK16(8192, -8192), rnd);
+    const int E0 = dot2a(e1, PK16(10703, 4433), ap), E3 = dot2a(e1, PK16(-10703, -4433), ap);
+    const int E1 = dot2a(e1, PK16(4433, -10704), am), E2 = dot2a(e1, PK16(-4433, 10704), am);
     const int O0 = dot2(o0, PK16(11363, 9633), dot2z(o1, PK16(6437, 2260)));
     const int O1 = dot2(o0, PK16(9633, -2259), dot2z(o1, PK16(-11362, -6436)));
     const int O2 = dot2(o0, PK16(6437, -11362), dot2z(o1, PK16(2261, 9633)));
@@ -93,6 +102,15 @@ __device__ __forceinline__ void idct8_1d(u32 e0, u32 e1, u32 o0, u32 o1, int rnd
     out[1] = E1 + O1; out[6] = E1 - O1;
     out[2] = E2 + O2; out[5] = E2 - O2;
     out[3] = E3 + O3; out[4] = E3 - O3;
+}
+
+/* low 16 bits of (b >> 11) into the high half of d, low half kept: with a plain shift of the pair's first value before
+ * it, two instructions per packed pair instead of two shifts and a byte permute */
+__device__ __forceinline__ u32 pack_shr11(int a, int b)
+{
+    u32 d = (u32)(a >> 11);
+    asm("v_ashrrev_i32_sdwa %0, 11, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(d) : "v"(b));
+    return d;
 }
 
 __device__ __forceinline__ u32 pk_mul16(u32 a, u32 b)
@@ -112,6 +130,7 @@ struct WaveCtx {
     u32 tr_even;    /* byte offsets this lane supplies to the transposing     */
     u32 tr_odd;     /*   reads (even rows 0,4,2,6 / odd rows 1,3,5,7)         */
     u32 blk, idx;   /* after a transposing read: block and column/row index   */
+    int rnd1, rnd2; /* the two passes' rounding constants, held in VGPRs               */
 };
 
 __device__ __forceinline__ void wave_ctx_init(WaveCtx &c, char *lds, u32 lane)
@@ -125,6 +144,9 @@ __device__ __forceinline__ void wave_ctx_init(WaveCtx &c, char *lds, u32 lane)
     c.tr_odd = tile_off(b, 2 * q + 1) + (p & 1) * 8;
     c.blk = 2 * g + (t >> 3);
     c.idx = t & 7;
+    c.rnd1 = 1 << 10;
+    c.rnd2 = 257 << 17;
+    asm volatile("" : "+v"(c.rnd1), "+v"(c.rnd2)); /* opaque: otherwise rematerialised at every use */
 }
 
 __device__ __forceinline__ u32x2 lds_tr_read(const WaveCtx &c, u32 off)
@@ -149,18 +171,17 @@ __device__ __forceinline__ u32x4 idct8x8_round(const WaveCtx &c, u32x4 raw, u32x
     *(u32x4 *)(c.lds + LDS_W + c.wr_off) = dq;                 /* stage A: [block][row u][x] */
     u32x2 ev = lds_tr_read(c, c.tr_even), od = lds_tr_read(c, c.tr_odd);
     int col[8];
-    idct8_1d(ev[0], ev[1], od[0], od[1], 1 << 10, col);       /* column x = c.idx, all y */
-    /* (v >> 11) stored to int16 (idct.c:522): v_ashrrev_i32 issues at twice the rate of a
-     * left shift on gfx950 (tests/tools/valu_rate.hip), then one byte-permute packs the pair */
+    idct8_1d(ev[0], ev[1], od[0], od[1], c.rnd1, col);       /* column x = c.idx, all y */
+    /* (v >> 11) stored to int16 (idct.c:522) */
     u32x4 pk;
 #pragma unroll
     for (int i = 0; i < 4; i++)
-        pk[i] = __builtin_amdgcn_perm((u32)(col[2 * i + 1] >> 11), (u32)(col[2 * i] >> 11), 0x05040100u);
+        pk[i] = pack_shr11(col[2 * i], col[2 * i + 1]);
     *(u32x4 *)(c.lds + LDS_W + tile_off(c.blk, c.idx)) = pk;   /* stage B: [block][col x][y] */
     ev = lds_tr_read(c, c.tr_even);
     od = lds_tr_read(c, c.tr_odd);
     int out[8];
-    idct8_1d(ev[0], ev[1], od[0], od[1], 257 << 17, out);      /* row y = c.idx, all x */
+    idct8_1d(ev[0], ev[1], od[0], od[1], c.rnd2, out);      /* row y = c.idx, all x */
     /* clamp((v >> 18), 0, 65535): v >> 18 is in [-8192, 8191] so only the lower clamp can
      * act and the int16 store never wraps (idct.c:531).  Done two samples at a time on
      * the high halves: (v >> 16) as int16, >> 2, max 0. */
@@ -244,6 +265,22 @@ __device__ __forceinline__ TermBits chroma_term_bits(u32 a_raw, u32 b_raw)
     const float kf = tg - 8449338.0f;                         /* floor(tf / 1000), exact */
     t.sens = __builtin_fmaf(kf, -1000.0f, tf) == 0.0f && sf != 76288.0f;
     return t;
+}
+
+/* blockIdx.x -> position in the workgroup sequence.  mode 0: as dispatched (round-robin over the XCDs); 1: every XCD
+ * gets one contiguous eighth of the sequence; k >= 2: the XCDs take chunks of 2^k workgroups in turn (the part of the grid
+ * that is not a whole number of 8 * 2^k stays as dispatched).  Speed only: any placement computes the same bytes. */
+__device__ __forceinline__ u32 xcd_remap_wg(int mode)
+{
+    const u32 nb = gridDim.x, b = blockIdx.x, xcd = b & 7, s = b >> 3;
+    if (mode == 0) return b;
+    if (mode == 1) {
+        const u32 base = nb >> 3, extra = nb & 7;
+        return xcd * base + (xcd < extra ? xcd : extra) + s;
+    }
+    const u32 k = (u32)mode, whole = (nb >> (k + 3)) << (k + 3);
+    if (b >= whole) return b;
+    return ((s >> k) << (k + 3)) + (xcd << k) + (s & ((1u << k) - 1u));
 }
 
 /* ------------------------------------------------------------------------
@@ -435,8 +472,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg420_fused(JpegBatch p)
      * Speed only: any placement computes the same bytes. */
     u32 wg;
     {
-        const u32 nb = gridDim.x, b = blockIdx.x, base = nb >> 3, extra = nb & 7, xcd = b & 7;
-        wg = p.xcd_remap ? xcd * base + (xcd < extra ? xcd : extra) + (b >> 3) : b;
+        wg = xcd_remap_wg(p.xcd_remap);
     }
     int img = (int)__umulhi(wg, p.wpi_magic), wgi = (int)wg - img * p.wgs_per_image; /* scalar */
     if (wgi < 0) { img--; wgi += p.wgs_per_image; }
@@ -497,8 +533,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     u32 wg;
     {
-        const u32 nb = gridDim.x, b = blockIdx.x, base = nb >> 3, extra = nb & 7, xcd = b & 7;
-        wg = p.xcd_remap ? xcd * base + (xcd < extra ? xcd : extra) + (b >> 3) : b;
+        wg = xcd_remap_wg(p.xcd_remap);
     }
     int img = (int)__umulhi(wg, p.wpi_magic), wgi = (int)wg - img * p.wgs_per_image; /* scalar */
     if (wgi < 0) { img--; wgi += p.wgs_per_image; }
@@ -751,6 +786,14 @@ static int geom_ok(const ffhip_jpeg_geom *g)
 
 /* kernel variant: quads per wave and cache policy.  FFHIP_JPEG_VARIANT="<qpw><nt>" (e.g. "21")
  * overrides the default for experiments; every variant computes identical bytes. */
+/* A/B knobs; identical bytes either way.  FFHIP_JPEG_XCD_CHUNK_LOG2=k (2..20): the XCDs take chunks of 2^k workgroups in turn */
+static int jpeg_remap_mode(void)
+{
+    if (getenv("FFHIP_JPEG_NO_XCD_REMAP")) return 0;
+    const char *e = getenv("FFHIP_JPEG_XCD_CHUNK_LOG2");
+    if (e) { const int k = atoi(e); if (k >= 2 && k <= 20) return k; }
+    return 1;
+}
 static int g_variant = -1;
 static void launch_fused(const JpegBatch &q_in, int n_images, hipStream_t st)
 {
@@ -762,7 +805,7 @@ static void launch_fused(const JpegBatch &q_in, int n_images, hipStream_t st)
     const int qpw = g_variant / 10;
     JpegBatch q = q_in;
     static int remap = -1;
-    if (remap < 0) remap = getenv("FFHIP_JPEG_NO_XCD_REMAP") ? 0 : 1; /* A/B knob; identical bytes either way */
+    if (remap < 0) remap = jpeg_remap_mode();
     q.xcd_remap = remap;
     const int slots = (q.quads_per_image + qpw - 1) / qpw;
     q.wgs_per_image = (slots + WAVES_PER_WG - 1) / WAVES_PER_WG;
@@ -793,7 +836,7 @@ static void launch_strip(const ffhip_jpeg_geom *g, const JpegBatch &q_in, int n_
 {
     JpegBatch q = q_in;
     static int remap = -1;
-    if (remap < 0) remap = getenv("FFHIP_JPEG_NO_XCD_REMAP") ? 0 : 1;
+    if (remap < 0) remap = jpeg_remap_mode();
     q.xcd_remap = remap;
     q.wgs_per_image = (q.quads_per_image + WAVES_PER_WG - 1) / WAVES_PER_WG;
     q.wpi_magic = q.wgs_per_image == 1 ? 0xffffffffu : (u32)(0x100000000ULL / (unsigned)q.wgs_per_image) + 1u;

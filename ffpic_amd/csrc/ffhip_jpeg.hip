@@ -797,7 +797,9 @@ static int jpeg_remap_mode(void)
 static int g_variant = -1;
 static void launch_fused(const JpegBatch &q_in, int n_images, hipStream_t st)
 {
-    if (g_variant < 0) {
+    static int dynamic = -1; /* FFHIP_JPEG_VARIANT_DYNAMIC: re-read the knob at every launch (diagnostics switch variants inside one process) */
+    if (dynamic < 0) dynamic = getenv("FFHIP_JPEG_VARIANT_DYNAMIC") ? 1 : 0;
+    if (g_variant < 0 || dynamic) {
         const char *e = getenv("FFHIP_JPEG_VARIANT");
         g_variant = (e && e[0] >= '1' && e[0] <= '2' && e[1] >= '0' && e[1] <= '3') ? (e[0] - '0') * 10 + (e[1] - '0')
                                                                                  : FFHIP_JPEG_DEFAULT_VARIANT;

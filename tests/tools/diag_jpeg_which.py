@@ -22,6 +22,14 @@ def mk(name):
     return torch.empty(n * W * 4 * H, dtype=torch.uint8, device=dev)
 B = {k: mk(k) for k in ("ty", "tu", "tv", "out")}
 def measure():
+    if os.environ.get("VARIANTS"):
+        r = []
+        for v in os.environ["VARIANTS"].split(","):
+            os.environ["FFHIP_JPEG_VARIANT"] = v
+            r.append(measure1())
+        return r
+    return measure1()
+def measure1():
     def step():
         ops.jpeg_recon_batch(geom, n, B["ty"].data_ptr(), B["tu"].data_ptr(), B["tv"].data_ptr(), q.data_ptr(), 0, B["out"].data_ptr(), W * 4, W * 4 * H, None, 0, st)
     ts = []
@@ -31,7 +39,7 @@ def measure():
     return round(sum(ts[-10:]) / 10, 3)
 print("start", measure(), {k: hex(v.data_ptr()) for k, v in B.items()}, flush=True)
 trial = 0
-for which in ("out", "ty", "tu", "tv", "out", "ty"):
+for which in os.environ.get("WHICH", "out,ty,tu,tv,out,ty").split(","):
     for rep in range(5):
         trial += 1
         old = B[which]; B[which] = None; del old

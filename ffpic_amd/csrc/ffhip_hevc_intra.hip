@@ -478,57 +478,73 @@ __device__ __forceinline__ void intra_tu_g(const HotArgs &a, const GroupCtx &g, 
     const int bd = cidx == 0 ? a.bitdepth_y : a.bitdepth_c;
     const int stride = g.stride;
     const __amdgpu_buffer_rsrc_t prs = g.plane_rs;
-    /* ---- 1 + 2. gather with the substitution folded in ---- */
+    /* ---- 1 + 2. gather with the substitution folded in; the samples stay in registers (scan position 64 * pass + lane)
+     * until the smoothing has been applied: through LDS (write, read three, write again, two barriers and a swap of the
+     * two scratch arrays that made every later address dynamic) the smoothing cost 0.55 - 0.65 us per TU ---- */
+    constexpr int P = LANE_PASSES(cnt);
+    int gv[P];
 #pragma unroll
-    for (int pass = 0; pass < LANE_PASSES(cnt); pass++) {
+    for (int pass = 0; pass < P; pass++) {
         const int i = lane + 64 * pass;
-        if (i >= cnt) break;
-        const int j = (int)jp.j[pass];
-        int px = x0 - 1, py = y0 - 1; /* the corner, j == 2n */
-        if (j < 2 * n) py = y0 + (2 * n - 1 - j);
-        else if (j > 2 * n) px = x0 + (j - 2 * n - 1);
         int v = 1 << (bd - 1);
-        if (j != 255) { /* 255: nothing available around this TU (wave-uniform) */
-            const unsigned tx = (unsigned)(px - wx0), ty = (unsigned)(py - wy0);
-            if (tile_ok && tx < (unsigned)wsz && ty < (unsigned)wsz) v = (int)tile[TILE_ORIGIN + ty * TILE_STRIDE + tx];
-            else v = ffhip_load_s16_sc1(prs, (py * stride + px) * 2);
+        if (i < cnt) {
+            const int j = (int)jp.j[pass];
+            int px = x0 - 1, py = y0 - 1; /* the corner, j == 2n */
+            if (j < 2 * n) py = y0 + (2 * n - 1 - j);
+            else if (j > 2 * n) px = x0 + (j - 2 * n - 1);
+            if (j != 255) { /* 255: nothing available around this TU (wave-uniform) */
+                const unsigned tx = (unsigned)(px - wx0), ty = (unsigned)(py - wy0);
+                if (tile_ok && tx < (unsigned)wsz && ty < (unsigned)wsz) v = (int)tile[TILE_ORIGIN + ty * TILE_STRIDE + tx];
+                else v = ffhip_load_s16_sc1(prs, (py * stride + px) * 2);
+            }
         }
-        s[i] = v;
+        gv[pass] = v;
     }
-    wave_sync();
     STAMP(0);
     mid(); /* the caller's fetches for the NEXT TU: behind this TU's own neighbour loads, with the rest of the TU to arrive in */
 #define LEFT(y) s[2 * n - 1 - (y)]
 #define TOP(x) s[2 * n + 1 + (x)] /* TOP(-1) is the corner */
 
-    /* ---- 3. neighbour smoothing (8.4.4.2.3) ---- */
+    /* ---- 3. neighbour smoothing (8.4.4.2.3), across lanes: position i - 1 / i + 1 is the lane below / above (DPP
+     * wave_shr / wave_shl), across a pass boundary lane 63 of the pass before / lane 0 of the pass behind ---- */
+    bool smooth = false;
     if ((flags & 4) && mode != 1 && n != 4) {
         const int d26 = iabs(mode - 26), d10 = iabs(mode - 10);
         const int thr = n == 8 ? 7 : (n == 16 ? 1 : 0);
-        if ((d26 < d10 ? d26 : d10) > thr) {
-            const bool bi = (flags & 8) && cidx == 0 && n == 32 &&
-                            iabs(TOP(-1) + TOP(2 * n - 1) - 2 * TOP(n - 1)) < (1 << (a.bitdepth_y - 5)) &&
-                            iabs(TOP(-1) + LEFT(2 * n - 1) - 2 * LEFT(n - 1)) < (1 << (a.bitdepth_y - 5));
-            const int corner = TOP(-1), l63 = bi ? LEFT(63) : 0, t63 = bi ? TOP(63) : 0;
+        smooth = (d26 < d10 ? d26 : d10) > thr;
+    }
+    if (smooth) {
+        bool bi = false;
+        int corner = 0, l63 = 0, t63 = 0;
+        if (n == 32 && (flags & 8) && cidx == 0) { /* TOP(-1) = position 64, TOP(63) = 128, TOP(31) = 96, LEFT(63) = 0, LEFT(31) = 32 */
+            corner = __builtin_amdgcn_readlane(gv[P > 1 ? 1 : 0], 0); l63 = __builtin_amdgcn_readlane(gv[0], 0); t63 = __builtin_amdgcn_readlane(gv[P - 1], 0);
+            const int l31 = __builtin_amdgcn_readlane(gv[0], 32), t31 = __builtin_amdgcn_readlane(gv[P > 1 ? 1 : 0], 32);
+            bi = iabs(corner + t63 - 2 * t31) < (1 << (a.bitdepth_y - 5)) && iabs(corner + l63 - 2 * l31) < (1 << (a.bitdepth_y - 5));
+        }
 #pragma unroll
-            for (int pass = 0; pass < LANE_PASSES(cnt); pass++) {
-                const int i = lane + 64 * pass;
-                if (i >= cnt) break;
-                int v;
-                if (bi) {
-                    if (i < 2 * n) { const int y = 2 * n - 1 - i; v = y == 63 ? l63 : (corner * (63 - y) + (y + 1) * l63 + 32) >> 6; }
-                    else if (i == 2 * n) v = corner;
-                    else { const int x = i - 2 * n - 1; v = x == 63 ? t63 : (corner * (63 - x) + (x + 1) * t63 + 32) >> 6; }
-                    v = (int)(short)v;
-                } else {
-                    v = (i == 0 || i == cnt - 1) ? s[i] : (int)(short)((s[i - 1] + 2 * s[i] + s[i + 1] + 2) >> 2);
-                }
-                s2[i] = v;
+        for (int pass = 0; pass < P; pass++) {
+            const int i = lane + 64 * pass, g0 = gv[pass];
+            int lo = __builtin_amdgcn_update_dpp(0, g0, 0x138, 0xf, 0xf, false); /* wave_shr:1 -- lane i - 1 */
+            int hi = __builtin_amdgcn_update_dpp(0, g0, 0x130, 0xf, 0xf, false); /* wave_shl:1 -- lane i + 1 */
+            if (pass > 0) lo = lane == 0 ? __builtin_amdgcn_readlane(gv[pass - 1], 63) : lo;
+            if (pass + 1 < P) hi = lane == 63 ? __builtin_amdgcn_readlane(gv[pass + 1 < P ? pass + 1 : pass], 0) : hi;
+            int f = (i == 0 || i == cnt - 1) ? g0 : (int)(short)((lo + 2 * g0 + hi + 2) >> 2);
+            if (n == 32 && bi) {
+                if (i < 2 * n) { const int y = 2 * n - 1 - i; f = y == 63 ? l63 : (corner * (63 - y) + (y + 1) * l63 + 32) >> 6; }
+                else if (i == 2 * n) f = corner;
+                else { const int x = i - 2 * n - 1; f = x == 63 ? t63 : (corner * (63 - x) + (x + 1) * t63 + 32) >> 6; }
+                f = (int)(short)f;
             }
-            wave_sync();
-            int *tmp = s; s = s2; s2 = tmp;
+            if (i < cnt) s[i] = f;
+        }
+    } else {
+#pragma unroll
+        for (int pass = 0; pass < P; pass++) {
+            const int i = lane + 64 * pass;
+            if (i < cnt) s[i] = gv[pass];
         }
     }
+    wave_sync();
     STAMP(1);
 
     /* ---- residual (with the optional rdpcm accumulation of 8.6.5) ---- */

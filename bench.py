@@ -244,6 +244,55 @@ def extra_c4(L, dev, stream, T, cpu=True):
     res = {"workload": "C4: 16 x 1920x1088 VP8 key frames, residual -> predict -> loop filter (normal) -> BGRA", "chain_ms": round(chain_ms, 4),
            "value": round(px / chain_ms / 1e3, 1), "unit": "Mpixels/s", "stages": stages,
            "roofline": dict(roof(nf * n_mb * 1600, stages["residual"]["ms"]), kernel="k_vp8_residual")}
+    # The same chain on a REAL encoder's syntax elements (tests/golden/webp_file_1080p.npz: libwebp on a photograph mosaic,
+    # decoded by the reference; 16 copies of the frame): the uniformly random modes above put H_PRED into column 0 of one
+    # row in five, where the reference's wrapped read chains the row to the END of the row above -- libwebp never
+    # chooses it there.  Checked against the reference's own whole-file decode (per-row checksums of its BGRA).
+    fx = os.path.join(ROOT, "tests", "golden", "webp_file_1080p.npz")
+    if os.path.exists(fx):
+        import ctypes as C
+        g = np.load(fx)
+        e_modes = np.ascontiguousarray(np.broadcast_to(g["modes"], (nf,) + g["modes"].shape))
+        de_modes = torch.from_numpy(e_modes).to(dev)
+        de_res = torch.from_numpy(np.ascontiguousarray(g["residual"])).to(dev).repeat(nf, 1)
+        e_filt = np.zeros((4, 2, 3), np.uint8)
+        ft = C.c_int(-1)
+        lfv, lh = g["lf"], g["lf_header"]
+        # lf = [level, filter-type bit, segmentation_enabled, triples...], lf_header = [sharpness, segment_feature_mode, lf_update_value[4],
+        # adj_enable, mode_ref delta 0, mb_mode delta 0, partitions] as the recorder wrote them (tests/golden/make_golden.py)
+        hdr = capi.Vp8FilterHeader(int(lfv[1]), int(lfv[0]), int(lh[0]), int(lfv[2]), int(lh[1]), (C.c_int8 * 4)(*[int(x) for x in lh[2:6]]),
+                                   int(lh[6]), int(lh[7]), int(lh[8]), int(lh[9]))
+        capi.check(L.ffhip_vp8_filter_params(C.byref(hdr), e_filt.ctypes.data, C.byref(ft)))
+        de_filt = torch.from_numpy(e_filt).to(dev)
+
+        def e_pred():
+            capi.check(L.ffhip_vp8_predict_recon(c, r, nf, e_modes.ctypes.data, de_modes.data_ptr(), de_res.data_ptr(), n_mb * 384, None, Y.data_ptr(), U.data_ptr(),
+                                                 V.data_ptr(), 256 * n_mb, 64 * n_mb, stream))
+
+        def e_lf():
+            capi.check(L.ffhip_vp8_loopfilter(c, r, nf, ft.value, de_modes.data_ptr(), de_filt.data_ptr(), Y.data_ptr(), U.data_ptr(), V.data_ptr(), 256 * n_mb, 64 * n_mb, stream))
+
+        def e_chain():
+            s_res(); e_pred(); e_lf(); s_col()
+        e_ms = T.ms(e_chain, reps=5, warm=2)
+        e_stage = {"predict_recon_ms": round(T.ms(e_pred, reps=5, warm=1), 4), "loopfilter_ms": round(T.ms(e_lf, reps=5, warm=1), 4)}
+        for pl in (Y, U, V):
+            pl.zero_()
+        e_chain()
+        capi.check(L.ffhip_stream_sync(stream))
+        ok = True
+        for i in (0, nf - 1):
+            rows = bgra[i].cpu().numpy().reshape(Hp, -1).view(np.uint32).astype(np.uint64)
+            sums = (rows * (np.arange(rows.shape[1], dtype=np.uint64) + np.uint64(1))).sum(axis=1, dtype=np.uint64)
+            ok = ok and bool(np.array_equal(sums, g["bgra_row_sums"]))
+        res["encoder_stream"] = {"workload": "the same chain on 16 copies of a libwebp-encoded 1920x1088 photograph mosaic (quality 75: loop filter level "
+                                             f"{int(lfv[0])}, {round(float((g['modes'][:, 0] == 4).mean()) * 100)} % B_PRED macroblocks), syntax elements as the reference's decoder recorded them",
+                                 "chain_ms": round(e_ms, 4), "value": round(px / e_ms / 1e3, 1), "unit": "Mpixels/s", **e_stage,
+                                 "parity_vs_reference_whole_file_decode": ok}
+        for pl in (Y, U, V):
+            pl.zero_()
+        chain()                                   # back to the synthetic batch for the check below
+        capi.check(L.ffhip_stream_sync(stream))
     if cpu:
         O = oracle_lib()
         use_ref = os.path.exists(O.REF_SO)

@@ -518,6 +518,49 @@ def gen_webp_file_lf(R):
     save("webp_file_lf.npz", **res)
 
 
+def gen_webp_file_1080p(R):
+    """BASELINE config 4 at its own size from a REAL encoder's stream: a 1920x1088 mosaic of the two photographs
+    scikit-learn ships (china.jpg, flower.jpg at their native resolution, so the mode statistics are a photograph's),
+    encoded by libwebp (PIL, quality 75, method 4: loop filter on, segments, 54 % B_PRED macroblocks), decoded by the
+    reference's own loader.  Kept: the modes, filter parameters and residual it passed on, per-row checksums of its BGRA
+    and the first 32 rows of it.  (Round 1's verdict: the uniformly random mode mix of the benches is not an encoder's.)"""
+    from PIL import Image
+    from sklearn.datasets import load_sample_images
+    imgs = load_sample_images().images
+    W, H = 1920, 1088
+    canvas = np.zeros((H, W, 3), np.uint8)
+    k = 0
+    for y in range(0, H, 427):
+        for x in range(0, W, 640):
+            im = imgs[k % 2]; k += 1
+            h, w = min(427, H - y), min(640, W - x)
+            canvas[y:y + h, x:x + w] = im[:h, :w]
+    path = os.path.join(HERE, "file_1080p_q75.webp")
+    Image.fromarray(canvas).save(path, "WEBP", quality=75, method=4)
+    d = ref_decode_webp(path)
+    w, h, pitch = [int(x) for x in d["dims"]]
+    c, r = (w + 15) // 16, (h + 15) // 16
+    lf = d["lf"]
+    assert lf[0] > 0 and (w, h) == (W, H)
+    ftype = 1 if lf[1] else 2
+    filt = lf[3:27].astype(np.uint8).reshape(4, 2, 3)
+    y, u, v = O.oracle_vp8_frame(c, r, d["modes"], d["residual"])
+    y, u, v = [np.ascontiguousarray(p).copy() for p in (y, u, v)]
+    O.ffo().ffo_vp8_loopfilter_frame(c, r, ftype, np.ascontiguousarray(d["modes"]).reshape(-1), filt.reshape(-1), y.reshape(-1), u.reshape(-1), v.reshape(-1))
+    out = np.zeros((16 * r, pitch), np.uint8)
+    O.ffo().ffo_yuv420_to_bgra32(out.reshape(-1), pitch, y.reshape(-1), u.reshape(-1), v.reshape(-1), 16 * c, 8 * c, r, c)
+    same = np.array_equal(out[:h], d["bgra"][:h])
+    m = d["modes"]
+    print(f"  file_1080p_q75.webp: {os.path.getsize(path)} B, {w}x{h}, level {lf[0]}, type {ftype}, y-modes {np.bincount(m[:, 0], minlength=5)}, "
+          f"H_PRED in column 0: {int((m[::c, 0] == 3).sum())} of {r} rows, chain from the dump == reference decode: {same}")
+    assert same, "the recorded modes/residual/filters do not reproduce the reference's pixels"
+    rows = d["bgra"][:h].reshape(h, -1).view(np.uint32).astype(np.uint64)
+    row_sums = (rows * (np.arange(rows.shape[1], dtype=np.uint64) + np.uint64(1))).sum(axis=1, dtype=np.uint64)
+    os.remove(path)   # 245 KB of stream nobody reads again: the recorded syntax elements are the fixture
+    save("webp_file_1080p.npz", modes=m, residual=d["residual"], dims=d["dims"], lf=lf, lf_header=d["lf_header"],
+         bgra_row_sums=row_sums, bgra_head=d["bgra"][:32])
+
+
 def gen_vp8_filter_params(R):
     """calculate_filter_control_parameter (webp.c:1756-1803) over a sweep of header fields (ref_webp_filter_params)"""
     rng = np.random.default_rng(3)
@@ -807,7 +850,7 @@ def main():
     R = O.ref()
     steps = [("blocks", gen_blocks), ("vp8 macroblocks", gen_vp8_mbs), ("vp8 driven", gen_vp8_driven), ("vp8 frames", gen_vp8_frames),
              ("hevc intra", gen_hevc_intra), ("hevc glue", gen_hevc_glue), ("vp8 loop filter", gen_vp8_loopfilter), ("colour", gen_color),
-             ("grids", gen_grids), ("files", gen_files), ("files 422", gen_files_422), ("webp file", gen_webp_file), ("webp file lf", gen_webp_file_lf), ("vp8 filter params", gen_vp8_filter_params), ("hevc file", gen_hevc_file), ("heic file", gen_heic_file)]
+             ("grids", gen_grids), ("files", gen_files), ("files 422", gen_files_422), ("webp file", gen_webp_file), ("webp file lf", gen_webp_file_lf), ("webp file 1080p", gen_webp_file_1080p), ("vp8 filter params", gen_vp8_filter_params), ("hevc file", gen_hevc_file), ("heic file", gen_heic_file)]
     only = sys.argv[2] if len(sys.argv) == 3 and sys.argv[1] == "--only" else None   # e.g. --only "hevc intra"
     for name, fn in steps:
         if only is None or only == name:

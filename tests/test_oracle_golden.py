@@ -199,6 +199,31 @@ def test_webp_file_with_loop_filter(golden, ffo, tag):
     assert np.array_equal(out[:h], g[f"{tag}_bgra"])
 
 
+def test_webp_file_1080p_real_encoder(golden, ffo):
+    """config 4 at its own size from a real encoder's stream (libwebp on a photograph mosaic): the oracle's stage chain
+    from the reference decoder's per-macroblock dump reproduces every row of the reference's whole-file decode"""
+    from ffpic_amd import capi
+    g = golden("webp_file_1080p.npz")
+    w, h, pitch = [int(x) for x in g["dims"]]
+    c, r = (w + 15) // 16, (h + 15) // 16
+    lf, modes = g["lf"], g["modes"]
+    assert (c, r) == (120, 68) and lf[0] > 0 and (modes[:, 0] == 4).mean() > 0.4
+    filt = np.zeros(24, np.uint8)
+    ft = C.c_int(-1)
+    hdr = vp8_filter_header(lf, g["lf_header"])
+    assert capi.lib().ffhip_vp8_filter_params(C.byref(hdr), filt.ctypes.data, C.byref(ft)) == 0
+    assert np.array_equal(filt.astype(np.int32), lf[3:27]) and ft.value == (1 if lf[1] else 2)
+    y, u, v = O.oracle_vp8_frame(c, r, modes, g["residual"])
+    y, u, v = [np.ascontiguousarray(p).copy() for p in (y, u, v)]
+    ffo.ffo_vp8_loopfilter_frame(c, r, ft.value, np.ascontiguousarray(modes).reshape(-1), filt, y.reshape(-1), u.reshape(-1), v.reshape(-1))
+    out = np.zeros((16 * r, pitch), np.uint8)
+    ffo.ffo_yuv420_to_bgra32(out.reshape(-1), pitch, y.reshape(-1), u.reshape(-1), v.reshape(-1), 16 * c, 8 * c, r, c)
+    assert np.array_equal(out[:32], g["bgra_head"])
+    rows = out[:h].reshape(h, -1).view(np.uint32).astype(np.uint64)
+    sums = (rows * (np.arange(rows.shape[1], dtype=np.uint64) + np.uint64(1))).sum(axis=1, dtype=np.uint64)
+    assert np.array_equal(sums, g["bgra_row_sums"])
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])     # "e", "f": through the reference's HEIF loader, from tests/golden/file_e.heic (one image item) and file_f_grid.heic (a 1 x 1 grid item)
 def test_hevc_file_config5(golden, ffo, tag):
     """f4 / config 5 at stream level: intra pictures the reference's OWN parser decoded from hand-assembled HEVC streams

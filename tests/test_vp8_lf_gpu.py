@@ -107,6 +107,31 @@ def test_webp_file_with_loop_filter(golden, tag):
     assert np.array_equal(bgra[0][:h], g[f"{tag}_bgra"])
 
 
+def test_webp_file_1080p_real_encoder(golden):
+    """BASELINE config 4 at its own size from a real encoder's stream (libwebp on a photograph mosaic, loop filter on,
+    54 % B_PRED macroblocks): residual dump -> predict + reconstruct -> filter parameters (host) -> loop filter -> BGRA,
+    every row against the reference's whole-file decode (per-row checksums, the first 32 rows byte by byte)"""
+    import ctypes as C
+    from ffpic_amd import capi
+    from test_oracle_golden import vp8_filter_header
+    g = golden("webp_file_1080p.npz")
+    w, h, pitch = [int(x) for x in g["dims"]]
+    c, r = (w + 15) // 16, (h + 15) // 16
+    assert (c, r) == (120, 68)
+    filt = np.zeros((4, 2, 3), np.uint8)
+    ft = C.c_int(-1)
+    hdr = vp8_filter_header(g["lf"], g["lf_header"])
+    capi.check(capi.lib().ffhip_vp8_filter_params(C.byref(hdr), filt.ctypes.data, C.byref(ft)))
+    y, u, v = ops.vp8_predict_recon(c, r, g["modes"][None], g["residual"][None])
+    y, u, v = ops.vp8_loopfilter(c, r, ft.value, g["modes"][None], filt, y, u, v)
+    bgra = ops.yuv420_to_bgra(y, u, v, r, c, pitch=pitch)[0][:h]
+    assert np.array_equal(bgra[:32], g["bgra_head"])
+    rows = np.ascontiguousarray(bgra).reshape(h, -1).view(np.uint32).astype(np.uint64)
+    sums = (rows * (np.arange(rows.shape[1], dtype=np.uint64) + np.uint64(1))).sum(axis=1, dtype=np.uint64)
+    bad = np.nonzero(sums != g["bgra_row_sums"])[0]
+    assert bad.size == 0, f"{bad.size} rows differ, first {bad[:5]}"
+
+
 @pytest.mark.parametrize("env", [{"FFHIP_VP8_LF_MODE": "levels"}, {"FFHIP_VP8_LF_WAVES": "3"}, {}])
 @pytest.mark.parametrize("ft", [1, 2])
 def test_lf_schedulers_agree(env, ft, monkeypatch):

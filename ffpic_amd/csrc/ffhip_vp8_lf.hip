@@ -104,13 +104,53 @@ __device__ __forceinline__ void filter_line(int *line, int type, bool outer, boo
 }
 
 #define LS 24 /* luma tile row stride (4 + 16, padded)   */
-#define CS 16 /* chroma tile row stride (4 + 8, padded)  */
+#define CS 24 /* chroma tile row stride (4 + 8, padded to the luma stride: the row kernel walks luma and chroma columns with the same offsets) */
 
 __device__ __forceinline__ void wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* The row kernel filters the 16 luma lines and the 2 x 8 chroma lines of a macroblock with ONE instruction stream: lanes
+ * 0-15 hold a luma line (edges at 0, 4, 8, 12), lanes 16-31 a chroma line (edges at 0 and 4; the normal filter only).
+ * As two branches of an if / else the chroma lines ran behind the luma lines: half as much again per phase. */
+__device__ __forceinline__ void filter_line_mixed(int *line, int type, bool outer, bool inner, bool lum, int sub, int inter, int hevt)
+{
+    const int mb = sub + 4;
+    if (outer) {
+        if (type == 1) edge_simple(line, mb);
+        else edge_normal(line, mb, inter, hevt, true);
+    }
+    if (inner) {
+        if (type == 1) edge_simple(line + 4, sub);
+        else edge_normal(line + 4, sub, inter, hevt, false);
+        if (lum) {
+#pragma unroll
+            for (int k = 8; k < 16; k += 4) {
+                if (type == 1) edge_simple(line + k, sub);
+                else edge_normal(line + k, sub, inter, hevt, false);
+            }
+        }
+    }
+}
+/* STRIDE 1: the line is a pixel row (vertical edges); STRIDE LS (== CS): a pixel column (horizontal edges) */
+template <int STRIDE>
+__device__ __forceinline__ void filter_phase(uint8_t *base, const bool active, const bool lum, int type, bool outer, bool inner, int sub, int inter, int hevt)
+{
+    if (active) {
+        int line[20];
+#pragma unroll
+        for (int k = 0; k < 20; k++) line[k] = base[k * STRIDE]; /* a chroma lane's k >= 12 reads cells of its own tile array or the bytes behind it: never used */
+        filter_line_mixed(line, type, outer, inner, lum, sub, inter, hevt);
+#pragma unroll
+        for (int k = 1; k < 11; k++) base[k * STRIDE] = (uint8_t)line[k];
+        if (lum) {
+#pragma unroll
+            for (int k = 11; k < 19; k++) base[k * STRIDE] = (uint8_t)line[k];
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_vp8_loopfilter(Vp8LfArgs a)
@@ -214,8 +254,9 @@ struct LfFetch {
 __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t TL[20 * LS];
-    __shared__ __attribute__((aligned(16))) uint8_t TC[2][12 * CS];
+    __shared__ __attribute__((aligned(16))) uint8_t TC[2][20 * CS]; /* 12 rows in use; 20 so that filter_phase's unused reads of a chroma column stay inside */
     __shared__ uint8_t FT[24];
+    static_assert(LS == CS, "filter_phase walks luma and chroma tiles with one stride");
     const int lane = threadIdx.x;
     const int n_mb = a.mbcols * a.mbrows;
     const int ys = 16 * a.mbcols, us = 8 * a.mbcols;
@@ -309,43 +350,14 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
             if (sub) { /* wave-uniform */
                 /* webp.c:1710-1745: inner edges for B_PRED MBs in the simple filter, for the others in the normal one */
                 const bool inner = type == 1 ? bpred : !bpred;
-                /* ---- vertical edges: one pixel row per lane (lanes 0-15 luma, 16-23 U, 24-31 V) ---- */
-                if (lane < 16) {
-                    int line[20];
-                    uint8_t *row = TL + (lane + 4) * LS;
-#pragma unroll
-                    for (int k = 0; k < 20; k++) line[k] = row[k];
-                    filter_line<16>(line, type, x > 0, inner, sub, inter, hevt);
-#pragma unroll
-                    for (int k = 1; k < 19; k++) row[k] = (uint8_t)line[k];
-                } else if (lane < 32 && type != 1) {
-                    int line[12];
-                    uint8_t *row = TC[(lane >> 3) & 1] + ((lane & 7) + 4) * CS;
-#pragma unroll
-                    for (int k = 0; k < 12; k++) line[k] = row[k];
-                    filter_line<8>(line, type, x > 0, inner, sub, inter, hevt);
-#pragma unroll
-                    for (int k = 1; k < 11; k++) row[k] = (uint8_t)line[k];
-                }
+                /* ---- vertical edges: one pixel row per lane (lanes 0-15 luma, 16-23 U, 24-31 V), then horizontal edges: one
+                 * pixel column per lane ---- */
+                const bool lum = lane < 16, active = lane < 16 || (lane < 32 && type != 1);
+                uint8_t *const mine = lum ? TL : TC[(lane >> 3) & 1];
+                const int li = lum ? lane : (lane & 7);
+                filter_phase<1>(mine + (li + 4) * LS, active, lum, type, x > 0, inner, sub, inter, hevt);
                 wave_sync();
-                /* ---- horizontal edges: one pixel column per lane ---- */
-                if (lane < 16) {
-                    int line[20];
-                    uint8_t *col = TL + lane + 4;
-#pragma unroll
-                    for (int k = 0; k < 20; k++) line[k] = col[k * LS];
-                    filter_line<16>(line, type, y > 0, inner, sub, inter, hevt);
-#pragma unroll
-                    for (int k = 1; k < 19; k++) col[k * LS] = (uint8_t)line[k];
-                } else if (lane < 32 && type != 1) {
-                    int line[12];
-                    uint8_t *col = TC[(lane >> 3) & 1] + (lane & 7) + 4;
-#pragma unroll
-                    for (int k = 0; k < 12; k++) line[k] = col[k * CS];
-                    filter_line<8>(line, type, y > 0, inner, sub, inter, hevt);
-#pragma unroll
-                    for (int k = 1; k < 11; k++) col[k * CS] = (uint8_t)line[k];
-                }
+                filter_phase<LS>(mine + li + 4, active, lum, type, y > 0, inner, sub, inter, hevt);
                 wave_sync();
                 /* ---- write back rows -4..15, columns -4..15 as dwords (the cells this macroblock did not
                  * change are rewritten with the value it read: their owners are finished) -- but nothing

@@ -116,22 +116,65 @@ __device__ __forceinline__ void wave_sync()
 /* The row kernel filters the 16 luma lines and the 2 x 8 chroma lines of a macroblock with ONE instruction stream: lanes
  * 0-15 hold a luma line (edges at 0, 4, 8, 12), lanes 16-31 a chroma line (edges at 0 and 4; the normal filter only).
  * As two branches of an if / else the chroma lines ran behind the luma lines: half as much again per phase. */
+/* The same edge filters without control flow, for the row kernel.  Written as returns and if / else (edge_normal above),
+ * every edge became a nest of exec-mask regions around an array of twenty samples, and the compiler merged the arms with
+ * register copies: 1 090 of the kernel's 2 080 vector instructions were v_mov.  Here the decision is arithmetic:
+ * a filter that must not act gets a = 0, for which every one of its corrections is 0 (sclip2((0 + 4) >> 3) = 0,
+ * (27 * 0 + 63) >> 7 = 0, ...), and the two filters an edge chooses between never act together, so their corrections add.
+ * filt2 and filt4 are ONE computation: filt4 is filt2 without the p1 - q1 term plus the a3 correction of p1 / q1.
+ * Samples are 0..255, so |a - b| is one v_sad_u8. */
+__device__ __forceinline__ int absdiff(int a, int b) { return (int)__builtin_amdgcn_sad_u8((unsigned)a, (unsigned)b, 0u); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return __builtin_elementwise_max(__builtin_elementwise_max(a, b), c); }
+__device__ __forceinline__ void edge_simple_bf(int *s, int thresh)
+{
+    const bool apply = 4 * absdiff(s[3], s[4]) + absdiff(s[2], s[5]) <= 2 * thresh + 1;
+    const int a = apply ? 3 * (s[4] - s[3]) + sclip1(s[2] - s[5]) : 0;
+    const int a1 = sclip2((a + 4) >> 3), a2 = sclip2((a + 3) >> 3);
+    s[3] = clip255(s[3] + a2);
+    s[4] = clip255(s[4] - a1);
+}
+template <bool MB_EDGE>
+__device__ __forceinline__ void edge_normal_bf(int *s, int thresh, int ithresh, int hevt)
+{
+    const int d2 = absdiff(s[2], s[3]), d3 = absdiff(s[5], s[4]);
+    const int dmax = __builtin_elementwise_max(max3i(absdiff(s[0], s[1]), absdiff(s[1], s[2]), d2), max3i(absdiff(s[7], s[6]), absdiff(s[6], s[5]), d3));
+    const bool apply = 4 * absdiff(s[3], s[4]) + absdiff(s[2], s[5]) <= 2 * thresh + 1 && dmax <= ithresh;
+    const bool hev = __builtin_elementwise_max(d2, d3) > hevt;
+    const int w = sclip1(s[2] - s[5]), base = 3 * (s[4] - s[3]);
+    if (MB_EDGE) { /* filt2 where the edge has high variance, filt6 elsewhere */
+        const int a = (apply && hev) ? base + w : 0;
+        const int a1 = sclip2((a + 4) >> 3), a2 = sclip2((a + 3) >> 3);
+        const int b = (apply && !hev) ? sclip1(base + w) : 0;
+        const int b1 = (27 * b + 63) >> 7, b2 = (18 * b + 63) >> 7, b3 = (9 * b + 63) >> 7;
+        s[1] = clip255(s[1] + b3);
+        s[2] = clip255(s[2] + b2);
+        s[3] = clip255(s[3] + a2 + b1);
+        s[4] = clip255(s[4] - a1 - b1);
+        s[5] = clip255(s[5] - b2);
+        s[6] = clip255(s[6] - b3);
+    } else {       /* filt2 where the edge has high variance, filt4 elsewhere */
+        const int a = apply ? base + (hev ? w : 0) : 0;
+        const int a1 = sclip2((a + 4) >> 3), a2 = sclip2((a + 3) >> 3), a3 = hev ? 0 : (a1 + 1) >> 1;
+        s[2] = clip255(s[2] + a3);
+        s[3] = clip255(s[3] + a2);
+        s[4] = clip255(s[4] - a1);
+        s[5] = clip255(s[5] - a3);
+    }
+}
 __device__ __forceinline__ void filter_line_mixed(int *line, int type, bool outer, bool inner, bool lum, int sub, int inter, int hevt)
 {
     const int mb = sub + 4;
-    if (outer) {
-        if (type == 1) edge_simple(line, mb);
-        else edge_normal(line, mb, inter, hevt, true);
-    }
-    if (inner) {
-        if (type == 1) edge_simple(line + 4, sub);
-        else edge_normal(line + 4, sub, inter, hevt, false);
-        if (lum) {
-#pragma unroll
-            for (int k = 8; k < 16; k += 4) {
-                if (type == 1) edge_simple(line + k, sub);
-                else edge_normal(line + k, sub, inter, hevt, false);
-            }
+    if (type == 1) { /* wave-uniform */
+        if (outer) edge_simple_bf(line, mb);
+        if (inner) {
+            edge_simple_bf(line + 4, sub);
+            if (lum) { edge_simple_bf(line + 8, sub); edge_simple_bf(line + 12, sub); }
+        }
+    } else {
+        if (outer) edge_normal_bf<true>(line, mb, inter, hevt);
+        if (inner) {
+            edge_normal_bf<false>(line + 4, sub, inter, hevt);
+            if (lum) { edge_normal_bf<false>(line + 8, sub, inter, hevt); edge_normal_bf<false>(line + 12, sub, inter, hevt); }
         }
     }
 }

@@ -125,20 +125,20 @@ __device__ __forceinline__ void wave_sync()
  * Samples are 0..255, so |a - b| is one v_sad_u8. */
 __device__ __forceinline__ int absdiff(int a, int b) { return (int)__builtin_amdgcn_sad_u8((unsigned)a, (unsigned)b, 0u); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return __builtin_elementwise_max(__builtin_elementwise_max(a, b), c); }
-__device__ __forceinline__ void edge_simple_bf(int *s, int thresh)
+__device__ __forceinline__ void edge_simple_bf(int *s, int thresh, bool on)
 {
-    const bool apply = 4 * absdiff(s[3], s[4]) + absdiff(s[2], s[5]) <= 2 * thresh + 1;
+    const bool apply = on && 4 * absdiff(s[3], s[4]) + absdiff(s[2], s[5]) <= 2 * thresh + 1;
     const int a = apply ? 3 * (s[4] - s[3]) + sclip1(s[2] - s[5]) : 0;
     const int a1 = sclip2((a + 4) >> 3), a2 = sclip2((a + 3) >> 3);
     s[3] = clip255(s[3] + a2);
     s[4] = clip255(s[4] - a1);
 }
 template <bool MB_EDGE>
-__device__ __forceinline__ void edge_normal_bf(int *s, int thresh, int ithresh, int hevt)
+__device__ __forceinline__ void edge_normal_bf(int *s, int thresh, int ithresh, int hevt, bool on)
 {
     const int d2 = absdiff(s[2], s[3]), d3 = absdiff(s[5], s[4]);
     const int dmax = __builtin_elementwise_max(max3i(absdiff(s[0], s[1]), absdiff(s[1], s[2]), d2), max3i(absdiff(s[7], s[6]), absdiff(s[6], s[5]), d3));
-    const bool apply = 4 * absdiff(s[3], s[4]) + absdiff(s[2], s[5]) <= 2 * thresh + 1 && dmax <= ithresh;
+    const bool apply = on && 4 * absdiff(s[3], s[4]) + absdiff(s[2], s[5]) <= 2 * thresh + 1 && dmax <= ithresh;
     const bool hev = __builtin_elementwise_max(d2, d3) > hevt;
     const int w = sclip1(s[2] - s[5]), base = 3 * (s[4] - s[3]);
     if (MB_EDGE) { /* filt2 where the edge has high variance, filt6 elsewhere */
@@ -161,32 +161,39 @@ __device__ __forceinline__ void edge_normal_bf(int *s, int thresh, int ithresh, 
         s[5] = clip255(s[5] - a3);
     }
 }
-__device__ __forceinline__ void filter_line_mixed(int *line, int type, bool outer, bool inner, bool lum, int sub, int inter, int hevt)
+/* `outer` (the macroblock has a neighbour on that side) and `lum` (the lane holds a luma line: edges at 8 and 12) are
+ * predicates of the edges, not branches around them: a branch around code that rewrites part of a twenty-register array
+ * made the compiler keep two copies of the array and move one onto the other where the arms meet (two blocks of sixteen
+ * v_mov_b64 per branch).  `inner` stays a branch: it is wave-uniform and skips three edges. */
+template <int TYPE>
+__device__ __forceinline__ void filter_line_mixed(int *line, bool outer, bool inner, bool lum, int sub, int inter, int hevt)
 {
     const int mb = sub + 4;
-    if (type == 1) { /* wave-uniform */
-        if (outer) edge_simple_bf(line, mb);
+    if (TYPE == 1) {
+        edge_simple_bf(line, mb, outer);
         if (inner) {
-            edge_simple_bf(line + 4, sub);
-            if (lum) { edge_simple_bf(line + 8, sub); edge_simple_bf(line + 12, sub); }
+            edge_simple_bf(line + 4, sub, true);
+            edge_simple_bf(line + 8, sub, lum);
+            edge_simple_bf(line + 12, sub, lum);
         }
     } else {
-        if (outer) edge_normal_bf<true>(line, mb, inter, hevt);
+        edge_normal_bf<true>(line, mb, inter, hevt, outer);
         if (inner) {
-            edge_normal_bf<false>(line + 4, sub, inter, hevt);
-            if (lum) { edge_normal_bf<false>(line + 8, sub, inter, hevt); edge_normal_bf<false>(line + 12, sub, inter, hevt); }
+            edge_normal_bf<false>(line + 4, sub, inter, hevt, true);
+            edge_normal_bf<false>(line + 8, sub, inter, hevt, lum);
+            edge_normal_bf<false>(line + 12, sub, inter, hevt, lum);
         }
     }
 }
 /* STRIDE 1: the line is a pixel row (vertical edges); STRIDE LS (== CS): a pixel column (horizontal edges) */
-template <int STRIDE>
-__device__ __forceinline__ void filter_phase(uint8_t *base, const bool active, const bool lum, int type, bool outer, bool inner, int sub, int inter, int hevt)
+template <int STRIDE, int TYPE>
+__device__ __forceinline__ void filter_phase(uint8_t *base, const bool active, const bool lum, bool outer, bool inner, int sub, int inter, int hevt)
 {
     if (active) {
         int line[20];
 #pragma unroll
         for (int k = 0; k < 20; k++) line[k] = base[k * STRIDE]; /* a chroma lane's k >= 12 reads cells of its own tile array or the bytes behind it: never used */
-        filter_line_mixed(line, type, outer, inner, lum, sub, inter, hevt);
+        filter_line_mixed<TYPE>(line, outer, inner, lum, sub, inter, hevt);
 #pragma unroll
         for (int k = 1; k < 11; k++) base[k * STRIDE] = (uint8_t)line[k];
         if (lum) {
@@ -294,6 +301,7 @@ struct LfFetch {
     u32 m0, m4; /* mode bytes 0..3 and 16..19 of the macroblock */
 };
 
+template <int TYPE> /* the filter type of the launch (1 simple, 2 normal): a kernel each, no run-time switch in the edges */
 __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t TL[20 * LS];
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
     const int lane = threadIdx.x;
     const int n_mb = a.mbcols * a.mbrows;
     const int ys = 16 * a.mbcols, us = 8 * a.mbcols;
-    const int type = a.filter_type;
+    constexpr int type = TYPE;
     uint32_t *progress = a.ctrl + 4;
     if (lane < 24) FT[lane] = a.filters[lane]; /* a read from memory per macroblock would drain the fetches in flight */
     wave_sync();
@@ -398,9 +406,9 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
                 const bool lum = lane < 16, active = lane < 16 || (lane < 32 && type != 1);
                 uint8_t *const mine = lum ? TL : TC[(lane >> 3) & 1];
                 const int li = lum ? lane : (lane & 7);
-                filter_phase<1>(mine + (li + 4) * LS, active, lum, type, x > 0, inner, sub, inter, hevt);
+                filter_phase<1, TYPE>(mine + (li + 4) * LS, active, lum, x > 0, inner, sub, inter, hevt);
                 wave_sync();
-                filter_phase<LS>(mine + li + 4, active, lum, type, y > 0, inner, sub, inter, hevt);
+                filter_phase<LS, TYPE>(mine + li + 4, active, lum, y > 0, inner, sub, inter, hevt);
                 wave_sync();
                 /* ---- write back rows -4..15, columns -4..15 as dwords (the cells this macroblock did not
                  * change are rewritten with the value it read: their owners are finished) -- but nothing
@@ -467,7 +475,9 @@ extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int fi
         /* sixteen rows in flight per image cover its wavefront; a wave beyond that holds a ticket far from its turn and only polls
          * (16 x 1080p: 2048 waves 5.62 / 2.10 ms, 256 waves 5.48 / 1.96 -- tests/tools/bench_stages.py) */
         const long long cap = wv ? std::max(1, atoi(wv)) : std::min<long long>(2048, std::max<long long>(256, 16LL * n_images));
-        hipLaunchKernelGGL(k_vp8_loopfilter_rows, dim3((unsigned)std::min<long long>((long long)n_images * mbrows, cap)), dim3(64), 0, st, a);
+        const dim3 grid((unsigned)std::min<long long>((long long)n_images * mbrows, cap));
+        if (filter_type == 1) hipLaunchKernelGGL(k_vp8_loopfilter_rows<1>, grid, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(k_vp8_loopfilter_rows<2>, grid, dim3(64), 0, st, a);
         FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
         return FFHIP_OK;
     }

@@ -296,10 +296,21 @@ __global__ __launch_bounds__(256) void k_vp8_loopfilter(Vp8LfArgs a)
  * when the in-order completion of the wave's memory operations proves those stores done. */
 #define LF_SPIN_LIMIT (1 << 21)
 
+/* per lane: bit `lane` of a 64-bit mask picks b over a -- one v_cndmask with the mask in an SGPR pair */
+__device__ __forceinline__ int lane_select(unsigned long long mask, int a, int b)
+{
+    int d;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(mask));
+    return d;
+}
 struct LfFetch {
-    u32 d[2];  /* items lane and lane + 64 of: 80 luma dwords (20 rows x 4), then 48 chroma dwords (2 planes x 12 rows x 2) */
-    u32 m0, m4; /* mode bytes 0..3 and 16..19 of the macroblock */
+    u32 y0, y1, cu, cv; /* luma items lane and lane + 64 (of 80: 20 rows x 4 dwords), one chroma dword of U and of V (of 24 each: 12 rows x 2) */
+    u32 m0, m4;         /* mode bytes 0..3 and 16..19 of the macroblock */
 };
+
+/* per lane, by its number alone: everything the macroblock loop would otherwise work out per macroblock (divisions by 5
+ * and 3, row / column tests, a choice of plane per lane that the compiler turns into a loop over the planes) */
+#define LF_OUT ((int)0x80000000u) /* an offset outside every plane: loads return 0, stores are dropped (buffer range check) */
 
 template <int TYPE> /* the filter type of the launch (1 simple, 2 normal): a kernel each, no run-time switch in the edges */
 __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
@@ -307,6 +318,7 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
     __shared__ __attribute__((aligned(16))) uint8_t TL[20 * LS];
     __shared__ __attribute__((aligned(16))) uint8_t TC[2][20 * CS]; /* 12 rows in use; 20 so that filter_phase's unused reads of a chroma column stay inside */
     __shared__ uint8_t FT[24];
+    __shared__ u32 DUMP[64]; /* where lanes without a role read and write */
     static_assert(LS == CS, "filter_phase walks luma and chroma tiles with one stride");
     const int lane = threadIdx.x;
     const int n_mb = a.mbcols * a.mbrows;
@@ -315,6 +327,29 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
     uint32_t *progress = a.ctrl + 4;
     if (lane < 24) FT[lane] = a.filters[lane]; /* a read from memory per macroblock would drain the fetches in flight */
     wave_sync();
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    const unsigned tl = (unsigned)(unsigned long long)(lds_u8 *)TL, tc0 = (unsigned)(unsigned long long)(lds_u8 *)TC[0], tc1 = (unsigned)(unsigned long long)(lds_u8 *)TC[1],
+                   dump = (unsigned)(unsigned long long)(lds_u8 *)(uint8_t *)DUMP + 4u * (unsigned)lane;
+#define LDS32(addr) (*(__attribute__((address_space(3))) u32 *)(unsigned long long)(addr)) /* a dword of LDS at a byte address kept in a register */
+    /* fetch: plane offsets of the lane's items relative to the macroblock's first pixel, and where they go in the tiles */
+    const int fy0 = ((lane >> 2) - 4) * ys + 4 * (lane & 3);                       /* item lane: tile row lane >> 2 (picture row - 4) */
+    const int fy1 = lane < 16 ? ((lane >> 2) + 12) * ys + 4 * (lane & 3) : LF_OUT; /* item lane + 64                                  */
+    const int fc = lane < 24 ? ((lane >> 1) - 4) * us + 4 * (lane & 1) : LF_OUT;   /* chroma item lane of either plane                */
+    const unsigned dy0 = tl + (unsigned)((lane >> 2) * LS + 4 + 4 * (lane & 3));
+    const unsigned dy1 = lane < 16 ? tl + (unsigned)(((lane >> 2) + 16) * LS + 4 + 4 * (lane & 3)) : dump;
+    const unsigned dcu = lane < 24 ? tc0 + (unsigned)((lane >> 1) * CS + 4 + 4 * (lane & 1)) : dump;
+    const unsigned dcv = lane < 24 ? tc1 + (unsigned)((lane >> 1) * CS + 4 + 4 * (lane & 1)) : dump;
+    /* the tile's right end becomes the next macroblock's left border: lanes 0-19 a luma row, 32-43 / 44-55 a chroma row */
+    const unsigned keep_src = lane < 20 ? tl + (unsigned)(lane * LS + 16) : (lane >= 32 && lane < 56 && type != 1 ? (lane < 44 ? tc0 : tc1) + (unsigned)(((lane - 32) % 12) * CS + 8) : dump);
+    const unsigned keep_dst = lane < 20 ? tl + (unsigned)(lane * LS) : (lane >= 32 && lane < 56 && type != 1 ? (lane < 44 ? tc0 : tc1) + (unsigned)(((lane - 32) % 12) * CS) : dump);
+    /* write-back: luma items lane and lane + 64 of 100 (20 rows x 5 dwords, the first one the 4 columns left of the
+     * macroblock), chroma item lane of 36 (12 rows x 3) of either plane.  An item in tile rows 0-3 exists only below the
+     * first macroblock row, one in dword column 0 only right of the first macroblock: as lane masks, picked per macroblock */
+    const int wr0 = lane / 5, wd0 = lane % 5, wr1 = (lane + 64) / 5, wd1 = (lane + 64) % 5, wrc = lane / 3, wdc = lane % 3;
+    const int wy0 = (wr0 - 4) * ys + 4 * wd0 - 4, wy1 = lane < 36 ? (wr1 - 4) * ys + 4 * wd1 - 4 : LF_OUT, wc = lane < 36 ? (wrc - 4) * us + 4 * wdc - 4 : LF_OUT;
+    const unsigned sy0 = tl + (unsigned)(wr0 * LS + 4 * wd0), sy1 = lane < 36 ? tl + (unsigned)(wr1 * LS + 4 * wd1) : dump;
+    const unsigned scu = lane < 36 ? tc0 + (unsigned)(wrc * CS + 4 * wdc) : dump, scv = lane < 36 ? tc1 + (unsigned)(wrc * CS + 4 * wdc) : dump;
+
     for (;;) {
         unsigned ticket = 0;
         if (lane == 0) ticket = __hip_atomic_fetch_add(&a.ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -329,6 +364,13 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
         unsigned seen = y == 0 ? 0x7fffffffu : 0u;
         const __amdgpu_buffer_rsrc_t rY = ffhip_rsrc(Y, 256u * (unsigned)n_mb), rU = ffhip_rsrc(P[0], 64u * (unsigned)n_mb),
                                      rV = ffhip_rsrc(P[1], 64u * (unsigned)n_mb);
+        const int row_org = y * 16 * ys, row_corg = y * 8 * us;
+        /* lanes whose write-back items exist at all in this row (tile rows 0-3 need a row above), and those of them that also
+         * exist in the first macroblock (dword column 0 needs a macroblock to the left) */
+        const unsigned long long ok0 = __builtin_amdgcn_ballot_w64(wr0 >= 4 || y > 0), ok1 = __builtin_amdgcn_ballot_w64(wr1 >= 4 || y > 0),
+                                 okc = __builtin_amdgcn_ballot_w64(wrc >= 4 || y > 0);
+        const unsigned long long first0 = ok0 & __builtin_amdgcn_ballot_w64(wd0 > 0), first1 = ok1 & __builtin_amdgcn_ballot_w64(wd1 > 0),
+                                 firstc = okc & __builtin_amdgcn_ballot_w64(wdc > 0);
 
         auto fetch = [&](int x1, LfFetch &f) -> bool {
             const unsigned need = y == 0 ? 0u : (unsigned)(x1 + 2 < a.mbcols ? x1 + 2 : a.mbcols);
@@ -350,18 +392,14 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
             const u32 *mp = (const u32 *)(mrow + (long long)x1 * 20);
             f.m0 = mp[0];
             f.m4 = mp[4];
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int i = lane + 64 * j;
-                u32 v = 0;
-                if (i < 80) { /* rows -4..15 of the 16 new luma columns; offsets before the plane read as 0 and are never used */
-                    v = (u32)__builtin_amdgcn_raw_buffer_load_b32(rY, (y * 16 + (i >> 2) - 4) * ys + x1 * 16 + 4 * (i & 3), 0, FFHIP_AUX_SC1);
-                } else if (type != 1) {
-                    const int k = i - 80, pl = k >= 24, kk = pl ? k - 24 : k;
-                    const int off = (y * 8 + (kk >> 1) - 4) * us + x1 * 8 + 4 * (kk & 1);
-                    v = (u32)__builtin_amdgcn_raw_buffer_load_b32(pl ? rV : rU, off, 0, FFHIP_AUX_SC1);
-                }
-                f.d[j] = v;
+            /* unconditional loads, device-coherent (the four rows above belong to another wave): a lane without an item, and
+             * an item above the picture, read as 0 by the buffer range check and are never used */
+            const int org = row_org + x1 * 16, corg = row_corg + x1 * 8;
+            f.y0 = (u32)__builtin_amdgcn_raw_buffer_load_b32(rY, fy0 + org, 0, FFHIP_AUX_SC1);
+            f.y1 = (u32)__builtin_amdgcn_raw_buffer_load_b32(rY, fy1 + org, 0, FFHIP_AUX_SC1);
+            if (type != 1) {
+                f.cu = (u32)__builtin_amdgcn_raw_buffer_load_b32(rU, fc + corg, 0, FFHIP_AUX_SC1);
+                f.cv = (u32)__builtin_amdgcn_raw_buffer_load_b32(rV, fc + corg, 0, FFHIP_AUX_SC1);
             }
             return true;
         };
@@ -370,23 +408,18 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
          * sets rotated by copies, as in the first form, made every macroblock wait for the loads it had just issued: a copy of
          * a register with a load in flight waits for the load) */
         LfFetch f;
+        f.cu = f.cv = 0;
         if (!fetch(0, f)) return;
         for (int x = 0; x < a.mbcols; x++) {
             /* ---- consume: the tile's right end becomes the left border, the fetch the new columns ---- */
-            u32 keepl = 0, keepc = 0;
-            if (lane < 20) keepl = *(const u32 *)(TL + lane * LS + 16);
-            if (lane >= 32 && lane < 56) keepc = *(const u32 *)(TC[(lane - 32) / 12] + ((lane - 32) % 12) * CS + 8);
+            const u32 keep = LDS32(keep_src);
             wave_sync();
-            if (lane < 20) *(u32 *)(TL + lane * LS) = keepl;
-            if (lane >= 32 && lane < 56) *(u32 *)(TC[(lane - 32) / 12] + ((lane - 32) % 12) * CS) = keepc;
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int i = lane + 64 * j;
-                if (i < 80) *(u32 *)(TL + (i >> 2) * LS + 4 + 4 * (i & 3)) = f.d[j];
-                else if (type != 1) {
-                    const int k = i - 80, pl = k >= 24, kk = pl ? k - 24 : k;
-                    *(u32 *)(TC[pl] + (kk >> 1) * CS + 4 + 4 * (kk & 1)) = f.d[j];
-                }
+            LDS32(keep_dst) = keep;
+            LDS32(dy0) = f.y0;
+            LDS32(dy1) = f.y1;
+            if (type != 1) {
+                LDS32(dcu) = f.cu;
+                LDS32(dcv) = f.cv;
             }
             const u32 m0 = (u32)__builtin_amdgcn_readfirstlane((int)f.m0), m4 = (u32)__builtin_amdgcn_readfirstlane((int)f.m4);
             wave_sync();
@@ -410,30 +443,15 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
                 wave_sync();
                 filter_phase<LS, TYPE>(mine + li + 4, active, lum, y > 0, inner, sub, inter, hevt);
                 wave_sync();
-                /* ---- write back rows -4..15, columns -4..15 as dwords (the cells this macroblock did not
-                 * change are rewritten with the value it read: their owners are finished) -- but nothing
-                 * outside the picture ---- */
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const int i = lane + 64 * j;
-                    if (i < 100) {
-                        const int row = i / 5, d = i % 5;
-                        if ((row >= 4 || y > 0) && (d > 0 || x > 0))
-                            __hip_atomic_store((u32 *)(Y + (long long)(y * 16 + row - 4) * ys + x * 16 + 4 * d - 4), *(const u32 *)(TL + row * LS + 4 * d),
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
+                /* ---- write back rows -4..15, columns -4..15 as dwords (the cells this macroblock did not change are
+                 * rewritten with the value it read: their owners are finished) -- but nothing outside the picture ---- */
+                const int org = row_org + x * 16, corg = row_corg + x * 8;
+                __builtin_amdgcn_raw_buffer_store_b32(LDS32(sy0), rY, lane_select(x > 0 ? ok0 : first0, LF_OUT, wy0) + org, 0, FFHIP_AUX_SC1);
+                __builtin_amdgcn_raw_buffer_store_b32(LDS32(sy1), rY, lane_select(x > 0 ? ok1 : first1, LF_OUT, wy1) + org, 0, FFHIP_AUX_SC1);
                 if (type != 1) {
-#pragma unroll
-                    for (int j = 0; j < 2; j++) {
-                        const int i = lane + 64 * j;
-                        if (i < 72) {
-                            const int pl = i >= 36, k = pl ? i - 36 : i, row = k / 3, d = k % 3;
-                            if ((row >= 4 || y > 0) && (d > 0 || x > 0))
-                                __hip_atomic_store((u32 *)(P[pl] + (long long)(y * 8 + row - 4) * us + x * 8 + 4 * d - 4), *(const u32 *)(TC[pl] + row * CS + 4 * d),
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
+                    const int oc = lane_select(x > 0 ? okc : firstc, LF_OUT, wc) + corg; /* added here, not as the scalar offset: the range check looks at this operand alone, and a lane's offset may be negative */
+                    __builtin_amdgcn_raw_buffer_store_b32(LDS32(scu), rU, oc, 0, FFHIP_AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(LDS32(scv), rV, oc, 0, FFHIP_AUX_SC1);
                 }
             }
             wave_sync();

@@ -97,6 +97,13 @@ __device__ __forceinline__ int row_sum16(int v) /* every lane: the sum over its 
     v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false); /* row_mirror         */
     return v;
 }
+/* v < 0 ? alt : v, as compare + select whatever the compiler thinks of the cost of computing alt */
+__device__ __forceinline__ int neg_select(int v, int alt)
+{
+    int r;
+    asm("v_cmp_gt_i32 vcc, 0, %1\n\tv_cndmask_b32 %0, %1, %2, vcc" : "=v"(r) : "v"(v), "v"(alt) : "vcc");
+    return r;
+}
 __device__ __forceinline__ int clip3i(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 
@@ -467,8 +474,8 @@ __device__ __forceinline__ void fetch_residual_g(const HotArgs &a, const IntraSl
 }
 
 template <int LG, class MID>
-__device__ __forceinline__ void intra_tu_g(const HotArgs &a, const GroupCtx &g, const IntraSlot &t, const int lane, int *s, int *s2, short *R,
-                                           const ResPrefetch &rp, const JPrefetch &jp, short *tile, const short *zero_block, MID &&mid)
+__device__ __forceinline__ void intra_tu_g(const HotArgs &a, const GroupCtx &g, const IntraSlot &t, const int lane, int *__restrict__ s, int *__restrict__ s2, short *__restrict__ R,
+                                           const ResPrefetch &rp, const JPrefetch &jp, short *__restrict__ tile, const short *__restrict__ zero_block, MID &&mid)
 {
     constexpr int n = 1 << LG, lg = LG, cnt = 4 * n + 1;
     const int x0 = (int)t.x, y0 = (int)t.y;
@@ -669,8 +676,10 @@ __device__ __forceinline__ void intra_tu_g(const HotArgs &a, const GroupCtx &g, 
                     for (int pass = 0; pass < passes; pass++) {
                         const int prod = __mul24(al + 1, angle), fact = prod & 31, k0 = ac + (prod >> 5) + 1;
                         /* 8.4.4.2.6: negative indices come from the other side through the inverse angle */
-                        const int q0 = k0 >= 0 ? k0 : -((__mul24(k0, inv) + 128) >> 8);
-                        const int q1 = k0 + 1 >= 0 ? k0 + 1 : -((__mul24(k0 + 1, inv) + 128) >> 8);
+                        /* both forms computed, one v_cndmask: as a conditional the compiler wrapped the multiply in an exec-mask
+                         * region, which ends the basic block -- and with it any overlap of this pass's LDS reads with the next one's */
+                        const int q0 = neg_select(k0, -((__mul24(k0, inv) + 128) >> 8));
+                        const int q1 = neg_select(k0 + 1, -((__mul24(k0 + 1, inv) + 128) >> 8));
                         const int v = ((32 - fact) * TAP(q0) + fact * TAP(q1) + 16) >> 5;
                         EMIT(v, pass);
                         al += dal;

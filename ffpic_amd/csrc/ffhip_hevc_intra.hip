@@ -782,7 +782,7 @@ __device__ __forceinline__ void intra_program(const HotArgs &a, const GroupCtx &
         const int pr = (int)(short)(v & 0xffff);
         const short rec = (short)clip3i(0, g.maxv, pr + (int)pp.res);
         *(short *)((char *)tile + (t.packed >> 16) + cell_lane) = rec;
-        __builtin_amdgcn_raw_buffer_store_b16(rec, g.plane_rs, g.plane_lane[LG - 2], (int)t.plane_off, FFHIP_AUX_SC1);
+        __builtin_amdgcn_raw_buffer_store_b16(rec, g.plane_rs, g.plane_lane[LG - 2], __builtin_amdgcn_readfirstlane((int)t.plane_off), FFHIP_AUX_SC1); /* a scalar: left to itself the compiler loops over its 'distinct values' */
     }
 }
 /* halo: every scan position of a program TU whose (substituted) source lies outside the window comes from memory --
@@ -1342,6 +1342,9 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
                     JPrefetch jpn;
                     ResPrefetch rpn;
                     uint32_t widxn = 0;
+                    /* zeroed on purpose (twenty v_mov per generic TU): left undefined, the compiler lets the fetch below load straight
+                     * into the registers the NEXT TU reads, and the copies at the tail then wait for the loads on the spot (measured:
+                     * config-5 mix 5.56 -> 6.10 ms) */
                     jpn.j[0] = jpn.j[1] = jpn.j[2] = 0; rpn.wide = false; rpn.v[0] = rpn.v[1] = nq0;
                     auto fetch_next_extras = [&]() {
                         if (nx_have) {

@@ -24,7 +24,7 @@ EXPORTS = [
     "ffhip_jpeg_probe", "ffhip_jpeg_entropy_decode", "ffhip_jpeg_entropy_decode_mt", "ffhip_jpeg_entropy_batch", "ffhip_bmp_write",
     "ffhip_heif_grid_parse", "ffhip_heif_grid_compose", "ffhip_hevc_picture_layout", "ffhip_jpeg_decode_files", "ffhip_jpeg_decode_files_device", "ffhip_jpeg_entropy_batch_gpu", "ffhip_jpeg_stage_scan_test", "ffhip_host_malloc", "ffhip_host_free",
     "ffhip_shard_range", "ffhip_comm_unique_id", "ffhip_comm_init_rank", "ffhip_comm_destroy", "ffhip_batch_close", "ffhip_batch_complete",
-    "ffhip_bgra_checksum", "ffhip_vp8_filter_params",
+    "ffhip_bgra_checksum", "ffhip_vp8_filter_params", "ffhip_vp8_predict_loopfilter",
 ]
 
 
@@ -190,6 +190,7 @@ def lib():
     L.ffhip_hevc_intra_recon.argtypes = [vp, vp, C.c_longlong, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.ffhip_vp8_loopfilter.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, i64, i64, vp]
     L.ffhip_vp8_predict_recon.argtypes = [ci, ci, ci, vp, vp, vp, i64, vp, vp, vp, vp, i64, i64, vp]
+    L.ffhip_vp8_predict_loopfilter.argtypes = [ci, ci, ci, vp, vp, vp, i64, vp, ci, vp, vp, vp, vp, i64, i64, vp]
     ll = C.c_longlong
     L.ffhip_shard_range.argtypes = [ll, ci, ci, C.POINTER(ll), C.POINTER(ll)]
     L.ffhip_comm_unique_id.argtypes = [vp]

@@ -55,4 +55,16 @@ __device__ __forceinline__ int ffhip_load_s16_sc1(__amdgpu_buffer_rsrc_t r, int 
 }
 #endif
 
+
+/* ffhip_vp8_predict_loopfilter: the two row kernels of one call side by side (ffhip_vp8_lf.hip).  While `active`, the
+ * prediction entry records `fork` behind its counter reset and publishes where its per-row counters live, and the loop-filter
+ * entry launches on `side` behind `fork`, polling those counters. */
+struct FfhipVp8Fusion {
+    int active;
+    const uint32_t *pred_progress;
+    void *side;  /* hipStream_t */
+    void *fork;  /* hipEvent_t  */
+};
+extern thread_local FfhipVp8Fusion g_ffhip_vp8_fusion;
+
 #endif

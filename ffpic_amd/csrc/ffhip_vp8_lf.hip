@@ -34,6 +34,7 @@ struct Vp8LfArgs {
     uint32_t *ctrl; /* [0] next row ticket, [1] abort; from ctrl + 4: macroblocks finished per (image, row) */
     int *async_err;
     int n_images;
+    const uint32_t *pred_progress; /* fused with the prediction (ffhip_vp8_predict_loopfilter): its per-(image, row) counters, else null */
 };
 
 __device__ __forceinline__ int sclip1(int v) { return v < -128 ? -128 : (v > 127 ? 127 : v); }
@@ -362,6 +363,12 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
         const uint32_t *prog_up = progress + (long long)img * a.mbrows + y - 1;
         uint32_t *prog_me = progress + (long long)img * a.mbrows + y;
         unsigned seen = y == 0 ? 0x7fffffffu : 0u;
+        /* Running NEXT TO the prediction kernel (another stream of the same call): macroblock (x, y) may be filtered once the
+         * prediction has finished (x + 1, y + 1) -- the filter rewrites row 15 and columns 13-15 of what the prediction of the
+         * row below and of the right neighbour still reads unfiltered (predict.c reads reconstructed, not filtered, samples),
+         * and rows 13-15 of the row above, which the prediction of this row read.  The last row has no row below. */
+        const uint32_t *pred_row = a.pred_progress ? a.pred_progress + (long long)img * a.mbrows + (y + 1 < a.mbrows ? y + 1 : y) : nullptr;
+        unsigned seen_pred = a.pred_progress ? 0u : 0x7fffffffu;
         const __amdgpu_buffer_rsrc_t rY = ffhip_rsrc(Y, 256u * (unsigned)n_mb), rU = ffhip_rsrc(P[0], 64u * (unsigned)n_mb),
                                      rV = ffhip_rsrc(P[1], 64u * (unsigned)n_mb);
         const int row_org = y * 16 * ys, row_corg = y * 8 * us;
@@ -378,6 +385,20 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
             while (seen < need) {
                 seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(prog_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 if (seen >= need) break;
+                if (++spins > LF_SPIN_LIMIT || __hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    if (lane == 0) {
+                        __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(a.async_err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    return false;
+                }
+                if (spins < 16) __builtin_amdgcn_s_sleep(1);
+                else __builtin_amdgcn_s_sleep(16);
+            }
+            const unsigned need_pred = (unsigned)(x1 + 2 < a.mbcols ? x1 + 2 : a.mbcols);
+            while (seen_pred < need_pred) {
+                seen_pred = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(pred_row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (seen_pred >= need_pred) break;
                 if (++spins > LF_SPIN_LIMIT || __hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     if (lane == 0) {
                         __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -464,6 +485,8 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
 
 #define SCRATCH_VP8_LF 2
 
+thread_local FfhipVp8Fusion g_ffhip_vp8_fusion = {0, nullptr, nullptr, nullptr};
+
 extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int filter_type, const uint8_t *d_modes,
                                     const uint8_t *d_filters, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
                                     int64_t plane_stride_y, int64_t plane_stride_uv, void *stream)
@@ -483,8 +506,15 @@ extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int fi
         const size_t words = 4 + (size_t)n_images * (size_t)mbrows;
         uint32_t *g_work = ffhip_scratch(SCRATCH_VP8_LF, stream, words);
         if (!g_work) return FFHIP_ENOMEM;
+        const uint32_t *pred_progress = nullptr;
+        if (g_ffhip_vp8_fusion.active && g_ffhip_vp8_fusion.pred_progress) { /* next to the prediction kernel, behind its counter reset */
+            pred_progress = g_ffhip_vp8_fusion.pred_progress;
+            st = (hipStream_t)g_ffhip_vp8_fusion.side;
+            FFHIP_CHECK(hipStreamWaitEvent(st, (hipEvent_t)g_ffhip_vp8_fusion.fork, 0), FFHIP_EIO);
+        }
         FFHIP_CHECK(hipMemsetAsync(g_work, 0, words * sizeof(uint32_t), st), FFHIP_EIO);
         Vp8LfArgs a = {};
+        a.pred_progress = pred_progress;
         a.modes = d_modes; a.filters = d_filters; a.y = d_y; a.u = d_u; a.v = d_v;
         a.plane_y = plane_stride_y; a.plane_uv = plane_stride_uv;
         a.mbcols = mbcols; a.mbrows = mbrows; a.filter_type = filter_type;
@@ -517,7 +547,7 @@ extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int fi
     for (auto &l : lists) flat.insert(flat.end(), l.begin(), l.end());
     FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO);
     FFHIP_CHECK(hipMemcpy(g_work, flat.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice), FFHIP_EIO);
-    Vp8LfArgs a;
+    Vp8LfArgs a = {};
     a.modes = d_modes; a.filters = d_filters; a.y = d_y; a.u = d_u; a.v = d_v;
     a.plane_y = plane_stride_y; a.plane_uv = plane_stride_uv;
     a.mbcols = mbcols; a.mbrows = mbrows; a.filter_type = filter_type;
@@ -565,4 +595,44 @@ extern "C" int ffhip_vp8_filter_params(const ffhip_vp8_filter_header *h, uint8_t
             }
         }
     return FFHIP_OK;
+}
+
+/* Prediction + reconstruction and the loop filter of a batch of key frames as ONE call: both row kernels are enqueued
+ * side by side (the filter on a stream of the library's own, forked behind the prediction's counter reset and joined back
+ * into `stream`), the filter's rows following the prediction's through its per-row counters.  Same arguments and the same
+ * bytes as ffhip_vp8_predict_recon followed by ffhip_vp8_loopfilter; the two chains overlap instead of adding up. */
+extern "C" int ffhip_vp8_predict_recon(int mbcols, int mbrows, int n_images, const uint8_t *h_modes, const uint8_t *d_modes,
+                                       const int16_t *d_residual, int64_t residual_stride, const int32_t *d_resmap, uint8_t *d_y,
+                                       uint8_t *d_u, uint8_t *d_v, int64_t plane_stride_y, int64_t plane_stride_uv, void *stream);
+extern "C" int ffhip_vp8_predict_loopfilter(int mbcols, int mbrows, int n_images, const uint8_t *h_modes, const uint8_t *d_modes,
+                                            const int16_t *d_residual, int64_t residual_stride, const int32_t *d_resmap,
+                                            int filter_type, const uint8_t *d_filters, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
+                                            int64_t plane_stride_y, int64_t plane_stride_uv, void *stream)
+{
+    if (filter_type < 0 || filter_type > 2) return FFHIP_EINVAL;
+    if (filter_type != 0 && !d_filters) return FFHIP_EINVAL;
+    static thread_local hipStream_t side = nullptr;
+    static thread_local hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    const char *off = getenv("FFHIP_VP8_FUSE"); /* =0: one after the other on `stream` (A/B knob) */
+    const bool fuse = filter_type != 0 && n_images > 0 && !(off && off[0] == '0') && ffhip_have_device();
+    if (fuse && !side) {
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&join_ev, hipEventDisableTiming) != hipSuccess)
+            return FFHIP_EIO;
+    }
+    g_ffhip_vp8_fusion.active = fuse ? 1 : 0;
+    g_ffhip_vp8_fusion.pred_progress = nullptr;
+    g_ffhip_vp8_fusion.side = side;
+    g_ffhip_vp8_fusion.fork = fork_ev;
+    int rc = ffhip_vp8_predict_recon(mbcols, mbrows, n_images, h_modes, d_modes, d_residual, residual_stride, d_resmap, d_y, d_u, d_v,
+                                     plane_stride_y, plane_stride_uv, stream);
+    const bool forked = fuse && g_ffhip_vp8_fusion.pred_progress != nullptr;
+    if (rc == FFHIP_OK && filter_type != 0)
+        rc = ffhip_vp8_loopfilter(mbcols, mbrows, n_images, filter_type, d_modes, d_filters, d_y, d_u, d_v, plane_stride_y, plane_stride_uv, stream);
+    g_ffhip_vp8_fusion.active = 0;
+    g_ffhip_vp8_fusion.pred_progress = nullptr;
+    if (forked) { /* whatever happened to the filter's launch: `stream` continues behind the side stream */
+        if (hipEventRecord(join_ev, side) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, join_ev, 0) != hipSuccess) return FFHIP_EIO;
+    }
+    return rc;
 }

@@ -198,6 +198,28 @@ def vp8_predict_recon(mbcols, mbrows, modes, residual, resmap=None):
             dv.to_host((n, 8 * mbrows, 8 * mbcols), np.uint8))
 
 
+def vp8_predict_loopfilter(mbcols, mbrows, modes, residual, filter_type, filters, resmap=None):
+    """ffhip_vp8_predict_loopfilter: prediction + reconstruction and the loop filter of whole key frames as one call
+    (format/webp.c:1833-1866), the two row kernels side by side.  Arguments as vp8_predict_recon / vp8_loopfilter;
+    returns the filtered planes (Y [n][16r][16c], U, V)."""
+    L = capi.require_device()
+    n, n_mb = modes.shape[0], mbcols * mbrows
+    assert modes.shape == (n, n_mb, 20) and residual.shape[0] == n and residual.shape[2] == 384
+    modes = np.ascontiguousarray(modes)
+    dm, dr, df = DeviceBuffer(modes), DeviceBuffer(np.ascontiguousarray(residual)), DeviceBuffer(np.ascontiguousarray(filters))
+    dmap = DeviceBuffer(np.ascontiguousarray(resmap, dtype=np.int32)) if resmap is not None else None
+    ysz, csz = 256 * n_mb, 64 * n_mb
+    dy, du, dv = DeviceBuffer(nbytes=n * ysz), DeviceBuffer(nbytes=n * csz), DeviceBuffer(nbytes=n * csz)
+    for d in (dy, du, dv):
+        capi.check(L.ffhip_memset(d.ptr, 0, d.nbytes, None))
+    capi.check(L.ffhip_vp8_predict_loopfilter(mbcols, mbrows, n, modes.ctypes.data, dm.ptr, dr.ptr, residual.shape[1] * 384,
+                                              dmap.ptr if dmap else None, filter_type, df.ptr, dy.ptr, du.ptr, dv.ptr, ysz, csz, None),
+               "ffhip_vp8_predict_loopfilter")
+    capi.check(L.ffhip_stream_sync(None))
+    return (dy.to_host((n, 16 * mbrows, 16 * mbcols), np.uint8), du.to_host((n, 8 * mbrows, 8 * mbcols), np.uint8),
+            dv.to_host((n, 8 * mbrows, 8 * mbcols), np.uint8))
+
+
 def hevc_intra_recon(tus, residual, width, height, chroma=True, bd_y=8, bd_c=8, csub=2):
     """decode_intra_block steps 5-10 (coding/hevc.c:4730-4790) for a TU list in decode order
     (structured array of dtype synth.HEVC_TU_DTYPE == struct ffhip_hevc_tu); planes start at 0;

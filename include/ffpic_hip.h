@@ -267,6 +267,16 @@ int ffhip_vp8_filter_params(const ffhip_vp8_filter_header *hdr, uint8_t *filters
 int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int filter_type, const uint8_t *d_modes,
                          const uint8_t *d_filters, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
                          int64_t plane_stride_y, int64_t plane_stride_uv, void *stream);
+/* ffhip_vp8_predict_recon followed by ffhip_vp8_loopfilter as ONE call (the frame loop of format/webp.c:1833-1866: predict
+ * every macroblock, then filter the frame): same arguments, same bytes.  The two row kernels run side by side -- the filter
+ * on a stream of the library's own, forked from and joined back into `stream` -- with the filter's rows following the
+ * prediction's through its per-row progress counters (a macroblock is filtered once the prediction has finished its right
+ * neighbour in the row below: the prediction reads reconstructed, not filtered, samples), so the two dependency chains
+ * overlap instead of adding up.  filter_type 0 = prediction only.  FFHIP_VP8_FUSE=0: one after the other. */
+int ffhip_vp8_predict_loopfilter(int mbcols, int mbrows, int n_images, const uint8_t *h_modes, const uint8_t *d_modes,
+                                 const int16_t *d_residual, int64_t residual_stride, const int32_t *d_resmap,
+                                 int filter_type, const uint8_t *d_filters, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
+                                 int64_t plane_stride_y, int64_t plane_stride_uv, void *stream);
 
 /* ---- HEVC residual stage, batched over transform units of one size ----
  * For n_tu TUs of size nTbS x nTbS (4, 8, 16 or 32): scale_transform_coefficients

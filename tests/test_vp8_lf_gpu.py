@@ -132,6 +132,62 @@ def test_webp_file_1080p_real_encoder(golden):
     assert bad.size == 0, f"{bad.size} rows differ, first {bad[:5]}"
 
 
+@pytest.mark.parametrize("ft", [1, 2])
+def test_predict_and_loopfilter_side_by_side(ft):
+    """ffhip_vp8_predict_loopfilter (both row kernels enqueued next to each other, the filter following the prediction through
+    its progress counters) against the two calls one after the other and against the oracle: several 1080p frames, every byte"""
+    c, r, n = 120, 68, 3
+    modes = np.stack([synth.vp8_modes(c, r, seed=700 + i) for i in range(n)])
+    modes[..., 18] = np.random.default_rng(11).integers(0, 4, size=modes[..., 18].shape)
+    resid = np.stack([synth.vp8_residual(c * r, seed=710 + i) for i in range(n)])
+    flt = synth.vp8_filters(seed=13)
+    y0, u0, v0 = ops.vp8_predict_recon(c, r, modes, resid)
+    seq = ops.vp8_loopfilter(c, r, ft, modes, flt, y0, u0, v0)
+    fused = ops.vp8_predict_loopfilter(c, r, modes, resid, ft, flt)
+    for a, b, name in zip(seq, fused, "YUV"):
+        assert np.array_equal(a, b), (ft, name)
+    exp = oracle_lf(c, r, ft, modes[0], flt, (y0[0], u0[0], v0[0]))
+    for gp, e, name in zip(fused, exp, "YUV"):
+        assert np.array_equal(gp[0], e), (ft, name)
+
+
+def test_predict_and_loopfilter_side_by_side_small_and_odd():
+    """the side-by-side call on geometries with one row, one column, and a mode mix full of the wrapped H_PRED"""
+    for (c, r, n, seed) in ((1, 1, 2, 1), (7, 1, 1, 2), (1, 9, 1, 3), (21, 13, 4, 4)):
+        modes = np.stack([synth.vp8_modes(c, r, seed=720 + seed + i) for i in range(n)])
+        modes[:, ::c, 0] = 3                                 # H_PRED in column 0 of every row: the row-to-row chain
+        resid = np.stack([synth.vp8_residual(c * r, seed=730 + seed + i) for i in range(n)])
+        flt = synth.vp8_filters(seed=15)
+        for ft in (1, 2):
+            y0, u0, v0 = ops.vp8_predict_recon(c, r, modes, resid)
+            seq = ops.vp8_loopfilter(c, r, ft, modes, flt, y0, u0, v0)
+            fused = ops.vp8_predict_loopfilter(c, r, modes, resid, ft, flt)
+            for a, b, name in zip(seq, fused, "YUV"):
+                assert np.array_equal(a, b), (c, r, n, ft, name)
+
+
+def test_webp_file_1080p_side_by_side(golden):
+    """the real encoder's 1080p frame through ffhip_vp8_predict_loopfilter: the reference's whole-file decode, every row"""
+    import ctypes as C
+    from ffpic_amd import capi
+    from test_oracle_golden import vp8_filter_header
+    g = golden("webp_file_1080p.npz")
+    w, h, pitch = [int(x) for x in g["dims"]]
+    c, r = (w + 15) // 16, (h + 15) // 16
+    filt = np.zeros((4, 2, 3), np.uint8)
+    ft = C.c_int(-1)
+    capi.check(capi.lib().ffhip_vp8_filter_params(C.byref(vp8_filter_header(g["lf"], g["lf_header"])), filt.ctypes.data, C.byref(ft)))
+    modes = np.stack([g["modes"]] * 4)
+    resid = np.stack([g["residual"]] * 4)
+    y, u, v = ops.vp8_predict_loopfilter(c, r, modes, resid, ft.value, filt)
+    for i in (0, 3):
+        bgra = ops.yuv420_to_bgra(y[i:i + 1], u[i:i + 1], v[i:i + 1], r, c, pitch=pitch)[0][:h]
+        assert np.array_equal(bgra[:32], g["bgra_head"])
+        rows = np.ascontiguousarray(bgra).reshape(h, -1).view(np.uint32).astype(np.uint64)
+        sums = (rows * (np.arange(rows.shape[1], dtype=np.uint64) + np.uint64(1))).sum(axis=1, dtype=np.uint64)
+        assert np.array_equal(sums, g["bgra_row_sums"]), i
+
+
 @pytest.mark.parametrize("env", [{"FFHIP_VP8_LF_MODE": "levels"}, {"FFHIP_VP8_LF_WAVES": "3"}, {}])
 @pytest.mark.parametrize("ft", [1, 2])
 def test_lf_schedulers_agree(env, ft, monkeypatch):

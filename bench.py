@@ -226,8 +226,12 @@ def extra_c4(L, dev, stream, T, cpu=True):
     def s_col():
         capi.check(L.ffhip_yuv420_to_bgra(bgra.data_ptr(), Wp * 4, Y.data_ptr(), U.data_ptr(), V.data_ptr(), Wp, Wp // 2, r, c, nf, Hp * Wp, Hp * Wp // 4, Hp * Wp * 4, stream))
 
+    def s_pred_lf():                          # prediction and loop filter as ONE call: the two row kernels side by side
+        capi.check(L.ffhip_vp8_predict_loopfilter(c, r, nf, h_modes.ctypes.data, d_modes.data_ptr(), d_res.data_ptr(), n_mb * 384, None, 2, d_filt.data_ptr(),
+                                                  Y.data_ptr(), U.data_ptr(), V.data_ptr(), 256 * n_mb, 64 * n_mb, stream))
+
     def chain():
-        s_res(); s_pred(); s_lf(); s_col()
+        s_res(); s_pred_lf(); s_col()
     px = nf * Hp * Wp
     chain_ms = T.ms(chain, reps=5, warm=2)
     stages = {}
@@ -237,6 +241,8 @@ def extra_c4(L, dev, stream, T, cpu=True):
         stages[name] = {"ms": round(ms, 4), "GB/s": round(nbytes / ms / 1e6, 1), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
                         "algorithmic_bytes": int(nbytes)}
     stages["predict_recon"]["bound"] = stages["loopfilter"]["bound"] = "dependency chain (a wave per macroblock row), not HBM"
+    stages["predict_recon+loopfilter_side_by_side"] = {"ms": round(T.ms(s_pred_lf, reps=5, warm=1), 4),
+                                                       "note": "ffhip_vp8_predict_loopfilter, what the chain calls: the two stages above as one call, their row kernels overlapping"}
     for p in (Y, U, V):                           # the reference's wrapped 16x16 H_PRED / V_PRED at the frame edge read what the planes
         p.zero_()                                 # held before the frame (predict.c:338-353): zeros, as in its freshly allocated planes
     chain()                                       # leave the planes as ONE pass of the chain makes them
@@ -272,10 +278,15 @@ def extra_c4(L, dev, stream, T, cpu=True):
         def e_lf():
             capi.check(L.ffhip_vp8_loopfilter(c, r, nf, ft.value, de_modes.data_ptr(), de_filt.data_ptr(), Y.data_ptr(), U.data_ptr(), V.data_ptr(), 256 * n_mb, 64 * n_mb, stream))
 
+        def e_pred_lf():
+            capi.check(L.ffhip_vp8_predict_loopfilter(c, r, nf, e_modes.ctypes.data, de_modes.data_ptr(), de_res.data_ptr(), n_mb * 384, None, ft.value, de_filt.data_ptr(),
+                                                      Y.data_ptr(), U.data_ptr(), V.data_ptr(), 256 * n_mb, 64 * n_mb, stream))
+
         def e_chain():
-            s_res(); e_pred(); e_lf(); s_col()
+            s_res(); e_pred_lf(); s_col()
         e_ms = T.ms(e_chain, reps=5, warm=2)
-        e_stage = {"predict_recon_ms": round(T.ms(e_pred, reps=5, warm=1), 4), "loopfilter_ms": round(T.ms(e_lf, reps=5, warm=1), 4)}
+        e_stage = {"predict_recon_ms": round(T.ms(e_pred, reps=5, warm=1), 4), "loopfilter_ms": round(T.ms(e_lf, reps=5, warm=1), 4),
+                   "predict_recon+loopfilter_side_by_side_ms": round(T.ms(e_pred_lf, reps=5, warm=1), 4)}
         for pl in (Y, U, V):
             pl.zero_()
         e_chain()

@@ -77,6 +77,9 @@ def test_no_silent_cpu_fallback(L):
     modes = np.zeros(20, np.uint8)
     assert L.ffhip_vp8_predict_recon(1, 1, 1, modes.ctypes.data, p, p, 384, None, p, p, p, 256, 64, None) == -19
     assert L.ffhip_vp8_loopfilter(1, 1, 1, 2, p, p, p, p, p, 256, 64, None) == -19
+    assert L.ffhip_vp8_predict_loopfilter(1, 1, 1, modes.ctypes.data, p, p, 384, None, 2, p, p, p, p, 256, 64, None) == -19
+    assert L.ffhip_vp8_predict_loopfilter(1, 1, 1, modes.ctypes.data, p, p, 384, None, 3, p, p, p, p, 256, 64, None) == -22   # no such filter type
+    assert L.ffhip_vp8_predict_loopfilter(1, 1, 1, modes.ctypes.data, p, p, 384, None, 2, None, p, p, p, 256, 64, None) == -22  # a filter without parameters
     tu = np.zeros(32, np.uint8)
     tu[4] = 2                                   # log2_size
     assert L.ffhip_hevc_intra_recon(tu.ctypes.data, p, 1, p, p, None, None, 16, 16, 16, 0, 0, 0, 8, 8, None) == -19

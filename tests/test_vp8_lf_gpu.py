@@ -188,6 +188,25 @@ def test_webp_file_1080p_side_by_side(golden):
         assert np.array_equal(sums, g["bgra_row_sums"]), i
 
 
+@pytest.mark.parametrize("env", [{"FFHIP_VP8_PRED_MODE": "levels"}, {"FFHIP_VP8_LF_MODE": "levels"}, {"FFHIP_VP8_FUSE": "0"},
+                                 {"FFHIP_VP8_PRED_WAVES": "5", "FFHIP_VP8_LF_WAVES": "3"}])
+def test_side_by_side_call_under_every_scheduler(env, monkeypatch):
+    """ffhip_vp8_predict_loopfilter when one of its stages cannot take the row form (then they run one after the other), when
+    told not to overlap, and with far fewer waves than rows (tickets, not residency, order the rows of both kernels)"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    c, r, n = 21, 13, 3
+    modes = np.stack([synth.vp8_modes(c, r, seed=760 + i) for i in range(n)])
+    resid = np.stack([synth.vp8_residual(c * r, seed=770 + i) for i in range(n)])
+    flt = synth.vp8_filters(seed=17)
+    got = ops.vp8_predict_loopfilter(c, r, modes, resid, 2, flt)
+    for i in range(n):
+        y0, u0, v0 = O.oracle_vp8_frame(c, r, modes[i], resid[i])
+        exp = oracle_lf(c, r, 2, modes[i], flt, (y0, u0, v0))
+        for gp, e, name in zip(got, exp, "YUV"):
+            assert np.array_equal(gp[i], e), (env, i, name)
+
+
 @pytest.mark.parametrize("env", [{"FFHIP_VP8_LF_MODE": "levels"}, {"FFHIP_VP8_LF_WAVES": "3"}, {}])
 @pytest.mark.parametrize("ft", [1, 2])
 def test_lf_schedulers_agree(env, ft, monkeypatch):

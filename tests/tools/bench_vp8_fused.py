@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from ffpic_amd import capi, synth
+if os.environ.get("FFHIP_LIB"): capi.LIB_PATH = os.path.join(ROOT, "ffpic_amd", os.environ["FFHIP_LIB"])
 dev = torch.device("cuda", 0)
 L = capi.require_device(0)
 st = torch.cuda.current_stream().cuda_stream

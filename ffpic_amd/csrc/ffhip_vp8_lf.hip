@@ -379,9 +379,17 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
         const unsigned long long first0 = ok0 & __builtin_amdgcn_ballot_w64(wd0 > 0), first1 = ok1 & __builtin_amdgcn_ballot_w64(wd1 > 0),
                                  firstc = okc & __builtin_amdgcn_ballot_w64(wdc > 0);
 
+        /* one poll of the row above always in flight: issued behind a fetch, read in front of the next (k_vp8_predict_rows) */
+        u32 poll_v = 0;
+        bool poll_out = false;
         auto fetch = [&](int x1, LfFetch &f) -> bool {
             const unsigned need = y == 0 ? 0u : (unsigned)(x1 + 2 < a.mbcols ? x1 + 2 : a.mbcols);
             int spins = 0;
+            if (poll_out && seen < need) {
+                const unsigned got = (unsigned)__builtin_amdgcn_readfirstlane((int)poll_v);
+                seen = got > seen ? got : seen;
+            }
+            poll_out = false;
             while (seen < need) {
                 seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(prog_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 if (seen >= need) break;
@@ -421,6 +429,10 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
             if (type != 1) {
                 f.cu = (u32)__builtin_amdgcn_raw_buffer_load_b32(rU, fc + corg, 0, FFHIP_AUX_SC1);
                 f.cv = (u32)__builtin_amdgcn_raw_buffer_load_b32(rV, fc + corg, 0, FFHIP_AUX_SC1);
+            }
+            if (seen < (unsigned)a.mbcols) {
+                poll_v = __hip_atomic_load(prog_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                poll_out = true;
             }
             return true;
         };

@@ -186,6 +186,38 @@ def extra_c2(L, dev, stream, T):
     return res
 
 
+def extra_layouts(L, dev, stream, T):
+    """The other baseline sampling layouts (k_jpeg_fused_strip) at the headline's batch size: 256 x 3840x2160 (coded 3840x2176),
+    one launch each; algorithmic bytes per pixel 2 B per coefficient sample + 4 B BGRA.  Image 0 against the oracle."""
+    n, W, H = 256, 3840, 2176
+    q = synth.quant_tables()
+    t_q = torch.from_numpy(q.astype(np.int16)).to(dev)
+    O = oracle_lib()
+    res = {}
+    for name, (nc, h, v) in {"444": (3, 1, 1), "422": (3, 2, 1), "440": (3, 1, 2), "grey": (1, 1, 1)}.items():
+        cols, rows = W // (8 * h), H // (8 * v)
+        g = capi.jpeg_geom(cols, rows, nc, h, v, (0, 1, 1))
+        by, bc = cols * rows * h * v, cols * rows
+        ty = torch.randint(-30, 31, (n * by, 64), device=dev, dtype=torch.int16)
+        tu = torch.randint(-30, 31, (n * bc, 64), device=dev, dtype=torch.int16) if nc == 3 else None
+        tv = torch.randint(-30, 31, (n * bc, 64), device=dev, dtype=torch.int16) if nc == 3 else None
+        out = torch.empty(n * W * H * 4, dtype=torch.uint8, device=dev)
+
+        def step():
+            ops.jpeg_recon_batch(g, n, ty.data_ptr(), tu.data_ptr() if nc == 3 else None, tv.data_ptr() if nc == 3 else None, t_q.data_ptr(), 0,
+                                 out.data_ptr(), W * 4, W * 4 * H, None, 0, stream)
+        ms = T.ms(step, reps=10, warm=3)
+        exp = O.oracle_jpeg_recon(O.make_geom(cols, rows, nc, h, v, (0, 1, 1)), ty[:by].cpu().numpy(), tu[:bc].cpu().numpy() if nc == 3 else None,
+                                  tv[:bc].cpu().numpy() if nc == 3 else None, q)[0]
+        parity = bool(np.array_equal(out[:W * H * 4].cpu().numpy().reshape(H, W, 4), exp))
+        bpp = 4 + 2 * (1 + (2.0 / (h * v) if nc == 3 else 0))
+        res[name] = {"ms_per_step": round(ms, 4), "value": round(n * W * H / ms / 1e3, 1), "unit": "Mpixels/s", "parity_vs_oracle_first_image": parity,
+                     "roofline": dict(roof(bpp * n * W * H, ms), kernel="k_jpeg_fused_strip")}
+        del ty, tu, tv, out
+        torch.cuda.empty_cache()
+    return {"workload": "256 x 3840x2160 grids of the other baseline layouts (4:4:4, 4:2:2, 4:4:0, grey), one launch each", **res}
+
+
 def extra_c4(L, dev, stream, T, cpu=True):
     """configs[3]: WebP lossy post-entropy chain on 16 x 1080p key frames: residual (dequant + WHT + 4x4 IDCT) ->
     intra prediction + residual add -> loop filter (normal) -> YUV420 -> BGRA"""
@@ -586,8 +618,8 @@ def main():
             torch.cuda.empty_cache()
             T = Timer(L, stream)
             extra = {}
-            for key, fn in (("c2", lambda: extra_c2(L, dev, stream, T)), ("c4", lambda: extra_c4(L, dev, stream, T, not a.no_cpu)),
-                            ("c5", lambda: extra_c5(L, dev, stream, T, not a.no_cpu))):
+            for key, fn in (("c2", lambda: extra_c2(L, dev, stream, T)), ("jpeg_layouts", lambda: extra_layouts(L, dev, stream, T)),
+                            ("c4", lambda: extra_c4(L, dev, stream, T, not a.no_cpu)), ("c5", lambda: extra_c5(L, dev, stream, T, not a.no_cpu))):
                 try:
                     extra[key] = fn()
                 except Exception as e:   # an extra must never take the headline line with it

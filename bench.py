@@ -218,6 +218,42 @@ def extra_layouts(L, dev, stream, T):
     return {"workload": "256 x 3840x2160 grids of the other baseline layouts (4:4:4, 4:2:2, 4:4:0, grey), one launch each", **res}
 
 
+def extra_stage_kernels(L, dev, stream, T):
+    """The HBM-bound stage kernels of configs 4 and 5 alone, at batch sizes that fill the chip (inside the chains above they run
+    on one picture's worth of data, i.e. launch-bound): VP8 residual on 256 x 8160 macroblocks, the HEVC residual kernels on
+    sixteen 8K luma planes per TU size, planar colour on 256 x 1080p (8 bit) and sixteen 8K pictures (16 bit).  HIP events over ten
+    back-to-back launches (the gaps between launches are in: profiles/ has the rocprofv3 averages of the kernels alone)."""
+    out = {}
+    n_mb = 8160 * 256
+    lv, info = synth.vp8_macroblocks(8160, seed=1)
+    tl = torch.from_numpy(lv).to(dev).repeat(256, 1, 1); ti = torch.from_numpy(info).to(dev).repeat(256, 1)
+    tq = torch.from_numpy(synth.vp8_quant().astype(np.int16)).to(dev)
+    tr = torch.empty((n_mb, 384), dtype=torch.int16, device=dev)
+    ms = T.ms(lambda: capi.check(L.ffhip_vp8_residual_batch(n_mb, tl.data_ptr(), ti.data_ptr(), tq.data_ptr(), tr.data_ptr(), stream)), reps=10, warm=3)
+    out["vp8_residual_256x1080p"] = dict(roof(n_mb * (800 + 32 + 768), ms), kernel="k_vp8_residual")
+    del tl, ti, tr
+    for n, cnt in ((32, 16 * 240 * 135), (16, 16 * 480 * 270), (8, 16 * 960 * 540), (4, 16 * 1920 * 1080)):
+        lvl = torch.randint(-20, 21, (cnt, n * n), device=dev, dtype=torch.int16)
+        inf = torch.zeros((cnt, 4), dtype=torch.uint8, device=dev); inf[:, 0] = 27
+        res = torch.empty_like(lvl)
+        ms = T.ms(lambda: capi.check(L.ffhip_hevc_residual_batch(n, cnt, lvl.data_ptr(), inf.data_ptr(), None, 8, 0, res.data_ptr(), stream)), reps=10, warm=3)
+        out[f"hevc_residual_{n}x{n}_16x8K_luma"] = dict(roof(4 * cnt * n * n, ms), kernel="k_hevc_residual" + (f"{n}_mfma" if n > 4 else "4"))
+        del lvl, inf, res
+    for tag, (H, W, n, sixteen) in {"yuv420_8bit_256x1080p": (1088, 1920, 256, False), "yuv420_16bit_16x8K": (4352, 7680, 16, True)}.items():
+        dt = torch.int16 if sixteen else torch.uint8
+        y = torch.randint(0, 256, (n, H, W), device=dev, dtype=dt); u = torch.randint(0, 256, (n, H // 2, W // 2), device=dev, dtype=dt); v = u.clone()
+        o = torch.empty((n, H, W * 4), dtype=torch.uint8, device=dev)
+        if sixteen:
+            f = lambda: capi.check(L.ffhip_yuv420_to_bgra_16(o.data_ptr(), W * 4, y.data_ptr(), u.data_ptr(), v.data_ptr(), W, W // 2, H // 64, W // 64, 64, n, H * W, H * W // 4, H * W * 4, stream))
+        else:
+            f = lambda: capi.check(L.ffhip_yuv420_to_bgra(o.data_ptr(), W * 4, y.data_ptr(), u.data_ptr(), v.data_ptr(), W, W // 2, H // 16, W // 16, n, H * W, H * W // 4, H * W * 4, stream))
+        ms = T.ms(f, reps=10, warm=3)
+        out[tag] = dict(roof((3 + 4 if sixteen else 1.5 + 4) * n * H * W, ms), kernel="k_yuv420_to_bgra")
+        del y, u, v, o
+    torch.cuda.empty_cache()
+    return {"workload": "the HBM-bound stage kernels alone at chip-filling batch sizes", **out}
+
+
 def extra_c4(L, dev, stream, T, cpu=True):
     """configs[3]: WebP lossy post-entropy chain on 16 x 1080p key frames: residual (dequant + WHT + 4x4 IDCT) ->
     intra prediction + residual add -> loop filter (normal) -> YUV420 -> BGRA"""
@@ -619,7 +655,8 @@ def main():
             T = Timer(L, stream)
             extra = {}
             for key, fn in (("c2", lambda: extra_c2(L, dev, stream, T)), ("jpeg_layouts", lambda: extra_layouts(L, dev, stream, T)),
-                            ("c4", lambda: extra_c4(L, dev, stream, T, not a.no_cpu)), ("c5", lambda: extra_c5(L, dev, stream, T, not a.no_cpu))):
+                            ("c4", lambda: extra_c4(L, dev, stream, T, not a.no_cpu)), ("c5", lambda: extra_c5(L, dev, stream, T, not a.no_cpu)),
+                            ("stage_kernels", lambda: extra_stage_kernels(L, dev, stream, T))):
                 try:
                     extra[key] = fn()
                 except Exception as e:   # an extra must never take the headline line with it

@@ -6,6 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from ffpic_amd import capi, synth
+if os.environ.get("FFHIP_LIB"): capi.LIB_PATH = os.path.join(ROOT, "ffpic_amd", os.environ["FFHIP_LIB"])
+FRAMES = int(os.environ.get("FRAMES", "64"))
 
 dev = torch.device("cuda", 0)
 L = capi.require_device(0)
@@ -21,9 +23,9 @@ def timeit(fn, reps=20):
 
 best = None
 for _ in range(2):
-    n_mb = 8160 * 64
+    n_mb = 8160 * FRAMES
     lv, info = synth.vp8_macroblocks(8160, seed=1)
-    tl = torch.from_numpy(lv).to(dev).repeat(64, 1, 1); ti = torch.from_numpy(info).to(dev).repeat(64, 1)
+    tl = torch.from_numpy(lv).to(dev).repeat(FRAMES, 1, 1); ti = torch.from_numpy(info).to(dev).repeat(FRAMES, 1)
     tq = torch.from_numpy(synth.vp8_quant().astype(np.int16)).to(dev)
     tr = torch.empty((n_mb, 384), dtype=torch.int16, device=dev)
     ms = timeit(lambda: capi.check(L.ffhip_vp8_residual_batch(n_mb, tl.data_ptr(), ti.data_ptr(), tq.data_ptr(), tr.data_ptr(), st)))

@@ -2,7 +2,7 @@
 """bench.py -- Mpixels/s of the fused JPEG reconstruction (dequant + IDCT + YUV->BGRA)
 on MI355X, the metric BASELINE.json names.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W       (N > 1 without a launcher: spawns its own N ranks as a child torch.distributed.run)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one batch: 256 synthetic 3840x2160 4:2:0 coefficient grids
@@ -28,6 +28,38 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def _self_launch():
+    """`python3 bench.py --gpus N` with N > 1 and no launcher environment: this process -- which has imported neither torch
+    nor the HIP library, i.e. has made no GPU call -- starts `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    as a CHILD (never an exec), relays the one JSON line rank 0 prints and exits with the child's status."""
+    if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    gpus = ap.parse_known_args()[0].gpus
+    if gpus <= 1:
+        return
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL between processes needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    for line in child.stdout:
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    sys.exit(child.wait())
+
+
+if __name__ == "__main__":
+    _self_launch()
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -194,7 +226,7 @@ def extra_layouts(L, dev, stream, T):
     t_q = torch.from_numpy(q.astype(np.int16)).to(dev)
     O = oracle_lib()
     res = {}
-    for name, (nc, h, v) in {"444": (3, 1, 1), "422": (3, 2, 1), "440": (3, 1, 2), "grey": (1, 1, 1)}.items():
+    for name, (nc, h, v) in {"444": (3, 1, 1), "422": (3, 2, 1), "440": (3, 1, 2), "grey": (1, 1, 1), "411": (3, 4, 1), "114": (3, 1, 4)}.items():
         cols, rows = W // (8 * h), H // (8 * v)
         g = capi.jpeg_geom(cols, rows, nc, h, v, (0, 1, 1))
         by, bc = cols * rows * h * v, cols * rows
@@ -215,7 +247,7 @@ def extra_layouts(L, dev, stream, T):
                      "roofline": dict(roof(bpp * n * W * H, ms), kernel="k_jpeg_fused_strip")}
         del ty, tu, tv, out
         torch.cuda.empty_cache()
-    return {"workload": "256 x 3840x2160 grids of the other baseline layouts (4:4:4, 4:2:2, 4:4:0, grey), one launch each", **res}
+    return {"workload": "256 x 3840x2160 grids of the other baseline layouts (4:4:4, 4:2:2, 4:4:0, grey, 4:1:1 = h4v1 and its transpose h1v4), one launch each", **res}
 
 
 def extra_stage_kernels(L, dev, stream, T):
@@ -520,8 +552,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        sys.exit(f"--gpus {a.gpus} under a launcher with WORLD_SIZE={world}: start it as `python3 bench.py --gpus N` (it spawns its own ranks) "
+                 "or as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     # Rehearsal of the N > 1 path on a one-GPU box (FFHIP_BENCH_REHEARSE=1): every rank on cuda:0, gloo instead of
     # RCCL (which refuses two ranks on one device).  Exercises sharding, barriers, the batch close and the
     # rank-0-only legs; its numbers mean nothing and the JSON line says so.

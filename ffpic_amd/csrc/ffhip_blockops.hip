@@ -191,7 +191,9 @@ extern "C" void ffhip_idct_4x4_hevc(const int16_t *in, int16_t *out, int bitdept
 
 static void hip_yuv_to_bgra32(uint8_t *dst, int pitch, void *Y, void *U, void *V, int v, int h)
 {
-    if (v < 1 || v > 2 || h < 1 || h > 2) { fail("sampling factor"); return; }
+    /* any pair the reference's caller can pass: its MCU scratch holds h*v <= 4 luma blocks (jpg.c:501); a pair beyond
+     * that would make the reference itself read past Y[], so there is no behaviour to match */
+    if (v < 1 || h < 1 || h * v > 4) { fail("sampling factor (h*v > 4)"); return; }
     if (!stage_ready()) { fail("device init"); return; }
     /* staging layout: Y (h*v*128 B) | U 128 | V 128 | out (8v*8h*4 B <= 1024) */
     char *d = (char *)g_stage;

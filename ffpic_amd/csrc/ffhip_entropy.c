@@ -206,7 +206,7 @@ static int parse_headers(const uint8_t *f, size_t len, struct jpeg_hdr *j)
     }
     if (!j->scan) return FFHIP_EINVAL;
     if (j->ncomp == 1) { j->h[0] = j->v[0] = 1; } /* single-component scans are never interleaved */
-    if (j->h[0] < 1 || j->h[0] > 2 || j->v[0] < 1 || j->v[0] > 2) return FFHIP_EINVAL;
+    if (j->h[0] < 1 || j->v[0] < 1 || j->h[0] * j->v[0] > 4) return FFHIP_EINVAL; /* jpg.c:501: Y[3][64*4] */
     for (int c = 1; c < j->ncomp; c++)
         if (j->h[c] != 1 || j->v[c] != 1) return FFHIP_EINVAL; /* colorspace.c:149-150: chroma is one block per MCU */
     return FFHIP_OK;

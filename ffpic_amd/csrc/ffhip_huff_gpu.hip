@@ -336,7 +336,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     if (geom->ncomp == 3 && (!d_coef_u || !d_coef_v)) return FFHIP_EINVAL;
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 64) n_threads = 64;
-    if (geom->mcu_cols <= 0 || geom->mcu_rows <= 0 || geom->h < 1 || geom->h > 2 || geom->v < 1 || geom->v > 2 ||
+    if (geom->mcu_cols <= 0 || geom->mcu_rows <= 0 || geom->h < 1 || geom->v < 1 || geom->h * geom->v > 4 ||
         (geom->ncomp != 1 && geom->ncomp != 3)) return FFHIP_EINVAL;
     const size_t mcus = (size_t)geom->mcu_cols * geom->mcu_rows;
     const bool times = getenv("FFHIP_HUFF_TIMES") != nullptr; /* host phases on stderr */

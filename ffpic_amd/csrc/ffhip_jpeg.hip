@@ -38,6 +38,7 @@
 
 #include <errno.h>
 #include <stdlib.h>
+#include <mutex>
 
 #ifndef WAVES_PER_WG
 #define WAVES_PER_WG 4
@@ -508,8 +509,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg420_fused(JpegBatch p)
 
 /* ------------------------------------------------------------------------
  * Fused kernel for the other baseline layouts: 4:4:4 (h = v = 1), 4:2:2 (h = 2), 4:4:0 (v = 2),
- * grey.  One wave reconstructs a strip of 512 pixels -- 8 MCUs of 4:4:4 / grey (64x8), 4 MCUs of
- * 4:2:2 (64x8) or 4:4:0 (32x16) -- in 1-3 IDCT rounds of 8 blocks, parks the samples as small
+ * 4:1:1 (h = 4) and its transpose (v = 4), grey.  One wave reconstructs a strip of 512 pixels -- 8 MCUs
+ * of 4:4:4 / grey (64x8), 4 MCUs of 4:2:2 (64x8) or 4:4:0 (32x16), 2 MCUs of 4:1:1 (64x8) or of its
+ * transpose (16x32) -- in 1-3 IDCT rounds of 8 blocks (at h*v = 4 the chroma round carries 2 U + 2 V blocks
+ * and four idle ones), parks the samples as small
  * int16 planes in LDS and converts 4 pixels per lane and pass with the same exact integer forms
  * as the 4:2:0 kernel (fp64 only where the G sum is an exact multiple of 1000).  Same launch shape:
  * short-lived waves, all loads up front, 16-byte non-temporal stores, XCD-contiguous workgroups.
@@ -523,11 +526,11 @@ template <int H, int V, int NC, int NT>
 __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
 {
     constexpr int BPM = H * V;                            /* luma blocks per MCU          */
-    constexpr int MPS = (NC == 1 || BPM == 1) ? 8 : 4;   /* MCUs per strip               */
+    constexpr int MPS = (NC == 1 || BPM == 1) ? 8 : (BPM == 4 ? 2 : 4); /* MCUs per strip */
     constexpr int SW = MPS * 8 * H, SH = 8 * V;          /* strip size in pixels (512)   */
     constexpr int CW = MPS * 8;                          /* chroma samples per strip row */
     constexpr int GPR = SW / 4;                          /* 4-pixel groups per pixel row */
-    static_assert(SW * SH == 512 && BPM <= 2, "strip geometry");
+    static_assert(SW * SH == 512 && BPM <= 4 && BPM != 3 && (H == 1 || V == 1), "strip geometry");
     __shared__ __attribute__((aligned(16))) char lds_all[WAVES_PER_WG * SM_WAVE_BYTES];
     const u32 lane = threadIdx.x & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -591,7 +594,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
     {
         const u32x4 pk = idct8x8_round(c, ly, q_y);
         const u32 m = c.blk / BPM, sub = c.blk % BPM;
-        const u32 pcol = (m * H + (H == 2 ? sub : 0)) * 8, prow = (V == 2 ? sub : 0) * 8 + c.idx;
+        const u32 pcol = (m * H + (H > 1 ? sub : 0)) * 8, prow = (V > 1 ? sub : 0) * 8 + c.idx;
         *(u32x4 *)(c.lds + SM_YP + sw_off(V == 2 ? yrow_pos(prow) : prow, pcol, SW)) = pk;
     }
     if (NC == 3) {
@@ -602,7 +605,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
             *(u32x4 *)(c.lds + SM_VP + sw_off(c.idx, c.blk * 8, CW)) = pv;
         } else {
             const u32x4 pc = idct8x8_round(c, lc0, q_c0);
-            *(u32x4 *)(c.lds + (c.blk < 4 ? SM_UP : SM_VP) + sw_off(c.idx, (c.blk & 3) * 8, CW)) = pc;
+            if (MPS == 4 || (c.blk & 3) < MPS) /* h*v = 4: blocks 2, 3, 6, 7 of the round are repeats of the strip's last MCU */
+                *(u32x4 *)(c.lds + (c.blk < 4 ? SM_UP : SM_VP) + sw_off(c.idx, (c.blk & 3) * 8, CW)) = pc;
         }
     }
 
@@ -614,17 +618,19 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
     u32 tr2[2], tg2[2], tb2[2], ua[4] = {0, 0, 0, 0}, va[4] = {0, 0, 0, 0}, sens = 0;
     /* per-lane LDS offsets of the two passes, computed once: pass 1 reads 64 / GPR rows (v = 2: 8 row positions) further
      * on, which flips one bit of the swizzle key -- an XOR and an add instead of a second address computation */
-    const u32 row0 = V == 2 ? 2 * (lane / GPR) : lane / GPR, pc0 = (lane % GPR) * 4;
+    const u32 row0 = V >= 2 ? 2 * (lane / GPR) : lane / GPR, pc0 = (lane % GPR) * 4;
     const u32 y_off0 = sw_off(V == 2 ? yrow_pos(row0) : row0, pc0, SW);
-    const u32 y_off1 = SW == 64 ? (y_off0 ^ 0x40u) + 4 * 128 : (y_off0 ^ 0x20u) + 8 * 64;
-    static_assert((SW == 64 && 64 / GPR == 4 && V == 1) || (SW == 32 && V == 2), "pass-1 offset identities");
+    /* v = 4: rows 2j and 2j + 1 share (row >> 2), i.e. the swizzle key: the next plane row, 32 bytes on */
+    const u32 y_off1 = SW == 64 ? (y_off0 ^ 0x40u) + 4 * 128 : (SW == 32 ? (y_off0 ^ 0x20u) + 8 * 64 : y_off0 + 32);
+    static_assert((SW == 64 && 64 / GPR == 4 && V == 1) || (SW == 32 && V == 2) || (SW == 16 && V == 4), "pass-1 offset identities");
     const u32 c_off0 = NC == 3 ? sw_off(row0 / V, pc0 / H, CW) : 0;
-    const u32 c_off1 = V == 2 ? c_off0 : (CW == 64 ? (c_off0 ^ 0x40u) + 4 * 128 : (c_off0 ^ 0x10u) + 4 * 64);
+    /* v = 1: pass 1 is four rows down -- one bit of the key flips and four chroma rows (CW samples each) are skipped */
+    const u32 c_off1 = V >= 2 ? c_off0 : (CW == 64 ? (c_off0 ^ 0x40u) + 4 * 128 : (c_off0 ^ 0x10u) + 4 * CW * 2);
 #pragma unroll
     for (int it = 0; it < 2; it++) {
-        const u32 prow = row0 + (V == 2 ? it : it * (64 / GPR));
+        const u32 prow = row0 + (V >= 2 ? it : it * (64 / GPR));
         const u32x2 yy = *(const u32x2 *)(c.lds + SM_YP + (it ? y_off1 : y_off0));
-        if (V == 2 && it == 1) {
+        if (V >= 2 && it == 1) {
             /* the terms of pass 0 serve this row too */
         } else if (NC == 1) {
             tr2[0] = tr2[1] = __builtin_amdgcn_perm(grey_t.r, grey_t.r, 0x01000100u);
@@ -636,9 +642,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
             if (H == 1) {
                 const u32x2 a = *(const u32x2 *)(c.lds + SM_UP + c_off), b = *(const u32x2 *)(c.lds + SM_VP + c_off);
                 us[0] = a[0]; us[1] = a[1]; vs[0] = b[0]; vs[1] = b[1];
-            } else {
+            } else if (H == 2) {
                 us[0] = *(const u32 *)(c.lds + SM_UP + c_off);
                 vs[0] = *(const u32 *)(c.lds + SM_VP + c_off);
+                us[1] = vs[1] = 0;
+            } else { /* h = 4: the lane's four pixels share one chroma sample */
+                us[0] = *(const uint16_t *)(c.lds + SM_UP + c_off);
+                vs[0] = *(const uint16_t *)(c.lds + SM_VP + c_off);
                 us[1] = vs[1] = 0;
             }
             TermBits t[4 / H];
@@ -778,7 +788,9 @@ static int geom_ok(const ffhip_jpeg_geom *g)
 {
     if (!g || g->mcu_cols <= 0 || g->mcu_rows <= 0) return 0;
     if (g->ncomp != 1 && g->ncomp != 3) return 0;
-    if (g->h < 1 || g->h > 2 || g->v < 1 || g->v > 2) return 0;
+    /* what the reference's MCU loop admits: its scratch is Y[3][64*4] (jpg.c:501) and YUV_to_BGRA32_16bit takes any
+     * (v, h) (colorspace.c:143-150) -- every luma sampling pair with h*v <= 4 data units, 4:1:1 and its transpose included */
+    if (g->h < 1 || g->v < 1 || g->h * g->v > 4) return 0;
     for (int c = 0; c < g->ncomp; c++)
         if (g->qt_id[c] < 0 || g->qt_id[c] > 3) return 0;
     return 1;
@@ -828,10 +840,12 @@ static void launch_fused(const JpegBatch &q_in, int n_images, hipStream_t st)
 }
 
 static int is_fused420(const ffhip_jpeg_geom *g) { return g->ncomp == 3 && g->h == 2 && g->v == 2; }
-/* 4:4:4, 4:2:2, 4:4:0, grey: k_jpeg_fused_strip */
+/* 4:4:4, 4:2:2, 4:4:0, 4:1:1 (h = 4) and its transpose (v = 4), grey: k_jpeg_fused_strip.  The three-block pairs
+ * (h or v = 3) and grey with several blocks per MCU -- layouts the reference's loop admits and no encoder writes --
+ * take the two-pass path */
 static int is_fused_strip(const ffhip_jpeg_geom *g)
 {
-    return (g->ncomp == 3 && g->h * g->v <= 2) || (g->ncomp == 1 && g->h == 1 && g->v == 1);
+    return (g->ncomp == 3 && (g->h * g->v <= 2 || g->h == 4 || g->v == 4)) || (g->ncomp == 1 && g->h == 1 && g->v == 1);
 }
 
 static void launch_strip(const ffhip_jpeg_geom *g, const JpegBatch &q_in, int n_images, hipStream_t st)
@@ -846,7 +860,9 @@ static void launch_strip(const ffhip_jpeg_geom *g, const JpegBatch &q_in, int n_
     if (g->ncomp == 1) hipLaunchKernelGGL((k_jpeg_fused_strip<1, 1, 1, 3>), grid, dim3(WG_THREADS), 0, st, q);
     else if (g->h == 1 && g->v == 1) hipLaunchKernelGGL((k_jpeg_fused_strip<1, 1, 3, 3>), grid, dim3(WG_THREADS), 0, st, q);
     else if (g->h == 2) hipLaunchKernelGGL((k_jpeg_fused_strip<2, 1, 3, 3>), grid, dim3(WG_THREADS), 0, st, q);
-    else hipLaunchKernelGGL((k_jpeg_fused_strip<1, 2, 3, 3>), grid, dim3(WG_THREADS), 0, st, q);
+    else if (g->v == 2) hipLaunchKernelGGL((k_jpeg_fused_strip<1, 2, 3, 3>), grid, dim3(WG_THREADS), 0, st, q);
+    else if (g->h == 4) hipLaunchKernelGGL((k_jpeg_fused_strip<4, 1, 3, 3>), grid, dim3(WG_THREADS), 0, st, q);
+    else hipLaunchKernelGGL((k_jpeg_fused_strip<1, 4, 3, 3>), grid, dim3(WG_THREADS), 0, st, q);
 }
 
 static int grid_for(long long work_items_per_wg_unit)
@@ -923,7 +939,7 @@ extern "C" int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *g, int n_images, co
     }
 
     if (is_fused_strip(g)) {
-        const int mps = (g->ncomp == 1 || g->h * g->v == 1) ? 8 : 4, bpm = g->ncomp == 1 ? 1 : g->h * g->v;
+        const int mps = (g->ncomp == 1 || g->h * g->v == 1) ? 8 : (g->h * g->v == 4 ? 2 : 4), bpm = g->ncomp == 1 ? 1 : g->h * g->v;
         JpegBatch p = {};
         p.coef_y = d_coef_y; p.coef_u = d_coef_u; p.coef_v = d_coef_v;
         p.quant = d_quant; p.quant_stride = quant_stride;
@@ -952,7 +968,7 @@ extern "C" int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *g, int n_images, co
         return FFHIP_OK;
     }
 
-    /* remaining geometries (grey with h*v > 1): IDCT to sample planes, then colour */
+    /* remaining geometries (grey with h*v > 1, h or v = 3): IDCT to sample planes, then colour */
     const size_t need = ffhip_jpeg_workspace_bytes(g, n_images);
     if (!d_workspace || workspace_bytes < need || ((uintptr_t)d_workspace & 15)) return FFHIP_EINVAL;
     const long long mcus = (long long)g->mcu_cols * g->mcu_rows;
@@ -992,6 +1008,9 @@ extern "C" int ffhip_jpeg_recon_batch_host(const ffhip_jpeg_geom *g, int n_image
     if (!geom_ok(g) || n_images < 0) return FFHIP_EINVAL;
     if (n_images == 0) return FFHIP_OK;
     if (!ffhip_have_device()) return FFHIP_ENODEV;
+    /* one shared staging allocation: concurrent callers take turns for the whole call (copy in, launch, copy out) */
+    static std::mutex host_call_mu;
+    std::lock_guard<std::mutex> host_call_lock(host_call_mu);
     const size_t mcus = (size_t)g->mcu_cols * g->mcu_rows;
     const size_t ybytes = mcus * g->h * g->v * 128 * n_images, cbytes = mcus * 128 * n_images;
     const size_t qbytes = (quant_stride ? (size_t)quant_stride * (n_images - 1) + 256 : 256) * 2;
@@ -1001,7 +1020,7 @@ extern "C" int ffhip_jpeg_recon_batch_host(const ffhip_jpeg_geom *g, int n_image
     /* the device buffers are library scratch kept between calls (one allocation, grown on demand, released by
      * ffhip_shutdown): this is the per-picture entry a patched format/jpg.c calls, and allocating and freeing ~60 MB of
      * device memory around every picture cost more than the reconstruction itself.  Calls are serialised by the
-     * synchronous copies on the null stream, like the reference's single-threaded decode loop. */
+     * mutex above, like the reference's single-threaded decode loop. */
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_u = up(ybytes), o_v = o_u + up(g->ncomp == 3 ? cbytes : 0), o_q = o_v + up(g->ncomp == 3 ? cbytes : 0);
     const size_t o_out = o_q + up(qbytes), o_ws = o_out + up(obytes), total = o_ws + up(wbytes);

@@ -16,7 +16,24 @@
 #include "ffhip_internal.h"
 
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+/* a build host without the RCCL headers: the five entry points this file binds with dlsym, as rccl.h declares them (the
+ * library is optional at run time, so its header is optional at build time; without librccl the comm functions return
+ * FFHIP_ENODEV / NULL) */
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId *);
+ncclResult_t ncclCommInitRank(ncclComm_t *, int, ncclUniqueId, int);
+ncclResult_t ncclCommDestroy(ncclComm_t);
+ncclResult_t ncclAllGather(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+const char *ncclGetErrorString(ncclResult_t);
+}
+#endif
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -71,7 +88,7 @@ struct Comm {
     ncclComm_t comm;
     int rank, world;
     ffhip_batch_record *d_send, *d_recv; /* device: one record, world records */
-    ffhip_batch_record *h_recv;          /* pinned: world records */
+    ffhip_batch_record *h_recv;          /* pinned: world records, then this rank's outgoing record */
 };
 
 /* per image: sum over its 32-bit pixel words w[i] of w[i] * ((i & 0xffff) + 1), modulo 2^64 -- position-sensitive within
@@ -170,7 +187,7 @@ extern "C" void *ffhip_comm_init_rank(const void *id128, int rank, int world)
     if (r != ncclSuccess) { note_rccl(r, "ncclCommInitRank"); free(c); return nullptr; }
     if (hipMalloc((void **)&c->d_send, sizeof(ffhip_batch_record)) != hipSuccess ||
         hipMalloc((void **)&c->d_recv, sizeof(ffhip_batch_record) * (size_t)world) != hipSuccess ||
-        hipHostMalloc((void **)&c->h_recv, sizeof(ffhip_batch_record) * (size_t)world, hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void **)&c->h_recv, sizeof(ffhip_batch_record) * ((size_t)world + 1), hipHostMallocDefault) != hipSuccess) {
         ffhip_comm_destroy(c);
         return nullptr;
     }
@@ -213,8 +230,12 @@ extern "C" int ffhip_batch_close(void *comm, int rank, int world, long long firs
         h_records[0] = mine;
         return FFHIP_OK;
     }
+    /* every check that can fail on ONE rank sits in front of the collective: a rank that left early would leave the
+     * others in the gather.  From here on a failure is the device's (or RCCL's), which every rank sees. */
     if (c->world != world || c->rank != rank) return FFHIP_EINVAL;
-    FFHIP_CHECK(hipMemcpyAsync(c->d_send, &mine, sizeof mine, hipMemcpyHostToDevice, st), FFHIP_EIO);
+    ffhip_batch_record *h_send = c->h_recv + world; /* pinned, lives as long as the communicator: the async copy may read it late */
+    *h_send = mine;
+    FFHIP_CHECK(hipMemcpyAsync(c->d_send, h_send, sizeof mine, hipMemcpyHostToDevice, st), FFHIP_EIO);
     const ncclResult_t r = g_rccl.all_gather(c->d_send, c->d_recv, sizeof mine, ncclChar, c->comm, st);
     if (r != ncclSuccess) { note_rccl(r, "ncclAllGather"); return FFHIP_EIO; }
     FFHIP_CHECK(hipMemcpyAsync(c->h_recv, c->d_recv, sizeof mine * (size_t)world, hipMemcpyDeviceToHost, st), FFHIP_EIO);

@@ -47,17 +47,18 @@ class Batch:
         self.transport = "torch"
         if want == "rccl":
             L = capi.lib()
-            ident = torch.zeros(128, dtype=torch.uint8)
-            ok = 1
+            # 128 bytes of id + one byte "rank 0 got an id": ncclCommInitRank is collective, so a rank must only enter it
+            # when every rank will -- an id rank 0 failed to make would leave the others blocked in the bootstrap
+            ident = torch.zeros(129, dtype=torch.uint8)
             if rank == 0:
                 buf = (C.c_uint8 * 128)()
                 ok = int(L.ffhip_comm_unique_id(buf) == 0)
-                ident = torch.from_numpy(np.frombuffer(buf, dtype=np.uint8).copy())
+                ident = torch.from_numpy(np.concatenate([np.frombuffer(buf, dtype=np.uint8), np.array([ok], np.uint8)]))
             ident = ident.to(device) if device is not None else ident
             dist.broadcast(ident, 0)
-            host = ident.cpu().numpy().tobytes()
-            if ok or rank != 0:
-                self.comm = L.ffhip_comm_init_rank(host, rank, world)
+            host = ident.cpu().numpy()
+            if int(host[128]) == 1:
+                self.comm = L.ffhip_comm_init_rank(host[:128].tobytes(), rank, world)
             # every rank must take the same road: RCCL from C only if every rank got its communicator
             flag = torch.tensor([1 if self.comm else 0], dtype=torch.int32, device=device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)

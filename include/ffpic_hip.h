@@ -132,7 +132,9 @@ void ffhip_idct_4x4_hevc(const int16_t *in, int16_t *out, int bitdepth, bool epp
 typedef struct ffhip_jpeg_geom {
     int32_t mcu_cols, mcu_rows; /* MCUs per row / column                     */
     int32_t ncomp;              /* 1 (grey: U = V = zeros, jpg.c:501,552) or 3 */
-    int32_t h, v;               /* luma sampling factors, each 1 or 2         */
+    int32_t h, v;               /* luma sampling factors, h*v <= 4 data units per MCU: what the reference's MCU
+                                   scratch Y[3][64*4] holds (jpg.c:501) and YUV_to_BGRA32_16bit (colorspace.c:143-150)
+                                   converts -- 1x1, 2x1, 1x2, 2x2, 4x1 (4:1:1), 1x4, 3x1, 1x3 */
     int32_t qt_id[3];           /* DQT slot per component, 0..3               */
 } ffhip_jpeg_geom;
 
@@ -144,8 +146,9 @@ typedef struct ffhip_jpeg_geom {
  *                 d_bgra + i*image_stride + y*pitch + 4*x ; coded size is
  *                 (8*h*mcu_cols) x (8*v*mcu_rows); pitch >= 4*width, multiple of 16
  *   d_workspace   scratch of ffhip_jpeg_workspace_bytes(geom, n) bytes: 0 (pass NULL) for every
- *                 layout an encoder writes -- 4:2:0, 4:4:4, 4:2:2, 4:4:0 and grey run fully
- *                 fused -- and non-zero only for one component with h*v > 1 blocks per MCU
+ *                 layout an encoder writes -- 4:2:0, 4:4:4, 4:2:2, 4:4:0, 4:1:1 (h = 4), its
+ *                 transpose (v = 4) and grey run fully fused -- and non-zero only for one component
+ *                 with h*v > 1 blocks per MCU and for the three-block pairs (h or v = 3)
  *   stream        hipStream_t (NULL = default stream); the call only enqueues. */
 int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *geom, int n_images, const int16_t *d_coef_y,
                            const int16_t *d_coef_u, const int16_t *d_coef_v,
@@ -154,8 +157,11 @@ int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *geom, int n_images, const int1
                            size_t workspace_bytes, void *stream);
 size_t ffhip_jpeg_workspace_bytes(const ffhip_jpeg_geom *geom, int n_images);
 
-/* Same computation from HOST buffers (allocates, copies in, runs, copies out,
- * synchronises): what a patched format/jpg.c would call per picture. */
+/* Same computation from HOST buffers (copies in, runs, copies out, synchronises): what a patched
+ * format/jpg.c would call per picture.  The device staging is library scratch kept between calls
+ * (grown on demand, released by ffhip_shutdown); calls from several host threads are serialised
+ * inside the library (one picture at a time, like the reference's decode loop) -- a host that wants
+ * pictures in flight side by side uses the device-pointer entry above with its own buffers and streams. */
 int ffhip_jpeg_recon_batch_host(const ffhip_jpeg_geom *geom, int n_images, const int16_t *coef_y,
                                 const int16_t *coef_u, const int16_t *coef_v,
                                 const uint16_t *quant, int64_t quant_stride, uint8_t *bgra,

@@ -125,7 +125,10 @@ static int geom_ok(const ffo_jpeg_geom *g)
 {
     if (!g || g->mcu_cols <= 0 || g->mcu_rows <= 0) return 0;
     if (g->ncomp != 1 && g->ncomp != 3) return 0;
-    if (g->h < 1 || g->h > 2 || g->v < 1 || g->v > 2) return 0;
+    /* the MCU scratch is Y[3][64*4] (jpg.c:501): any sampling pair with h*v <= 4 data units, i.e. also
+     * 4:1:1 (h = 4) and its transpose (v = 4) and the three-block pairs; YUV_to_BGRA32_16bit itself takes
+     * any (v, h) (colorspace.c:143-150) */
+    if (g->h < 1 || g->v < 1 || g->h * g->v > 4) return 0;
     for (int c = 0; c < g->ncomp; c++)
         if (g->qt_id[c] < 0 || g->qt_id[c] > 3) return 0;
     return 1;

@@ -329,7 +329,8 @@ def gen_color(R):
     U = rng.integers(0, 256, size=64).astype(np.int16)
     V = rng.integers(0, 256, size=64).astype(np.int16)
     res = {}
-    for (v, h) in ((1, 1), (1, 2), (2, 1), (2, 2)):
+    # every sampling pair the MCU scratch of jpg.c:501 admits (h*v <= 4), 4:1:1 and its transpose included
+    for (v, h) in ((1, 1), (1, 2), (2, 1), (2, 2), (1, 4), (4, 1), (1, 3), (3, 1)):
         o = np.zeros((8 * v, 8 * h * 4), dtype=np.uint8)
         R.ref_yuv_to_bgra32_mcu16(o.reshape(-1), 8 * h * 4, Y, U, V, v, h)
         res[f"mcu_v{v}h{h}"] = o
@@ -361,7 +362,10 @@ def gen_grids(R):
     res = {"quant": q}
     for tag, (cols, rows, nc, h, v) in {"420": (6, 4, 3, 2, 2), "420tail": (7, 3, 3, 2, 2), "444": (5, 3, 3, 1, 1),
                                         "422": (5, 3, 3, 2, 1), "440": (5, 3, 3, 1, 2),
-                                        "grey": (5, 3, 1, 1, 1)}.items():
+                                        "grey": (5, 3, 1, 1, 1),
+                                        # h*v = 4 and 3 layouts (round 3): 4:1:1, its transpose, the three-block pairs
+                                        "411": (5, 3, 3, 4, 1), "114": (5, 3, 3, 1, 4), "311": (4, 3, 3, 3, 1),
+                                        "113": (4, 3, 3, 1, 3), "grey22": (3, 2, 1, 2, 2)}.items():
         g = O.make_geom(cols, rows, nc, h, v)
         cy, cu, cv = synth.coef_batch(1, cols, rows, nc, h, v)
         bgra = O.ref_jpeg_recon(g, cy, cu, cv, q)
@@ -377,6 +381,11 @@ def gen_grids(R):
     qa = rng.integers(1, 65536, size=(4, 64)).astype(np.uint16)
     res.update(adv_geom=g.as_array(), adv_cy=cy, adv_cu=cu, adv_cv=cv, adv_quant=qa,
                adv_bgra=O.ref_jpeg_recon(g, cy, cu, cv, qa))
+    # the same adversarial blocks and tables laid out as 4:1:1 (h = 4) and as its transpose (v = 4)
+    for tag, (h, v) in {"adv411": (4, 1), "adv114": (1, 4)}.items():
+        g = O.make_geom(8, 4, 3, h, v)
+        res[f"{tag}_geom"] = g.as_array()
+        res[f"{tag}_bgra"] = O.ref_jpeg_recon(g, cy, cu, cv, qa)
     save("jpeg_grids.npz", **res)
 
 

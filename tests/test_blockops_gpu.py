@@ -41,7 +41,7 @@ def test_idct_4x4_hevc(golden):
 
 def test_cs_ops_mcu(golden):
     g = golden("color_planar.npz")
-    for (v, h) in ((1, 1), (1, 2), (2, 1), (2, 2)):
+    for (v, h) in ((1, 1), (1, 2), (2, 1), (2, 2), (1, 4), (4, 1), (1, 3), (3, 1)):
         out = ops.yuv_to_bgra32(g["mcu_Y"], g["mcu_U"], g["mcu_V"], v, h)
         assert np.array_equal(out, g[f"mcu_v{v}h{h}"]), (v, h)
     tri = golden("color_triples.npz")

@@ -44,6 +44,10 @@ def test_golden_adversarial(golden):
     geom = O.make_geom(*[int(x) for x in g["adv_geom"][:5]])
     out = gpu_recon(geom, 1, g["adv_cy"], g["adv_cu"], g["adv_cv"], g["adv_quant"])[0]
     assert np.array_equal(out, g["adv_bgra"])
+    for tag in ("adv411", "adv114"):          # the same blocks as 4:1:1 (h = 4) and as its transpose (v = 4)
+        geom = O.make_geom(*[int(x) for x in g[f"{tag}_geom"][:5]])
+        out = gpu_recon(geom, 1, g["adv_cy"], g["adv_cu"], g["adv_cv"], g["adv_quant"])[0]
+        assert np.array_equal(out, g[f"{tag}_bgra"]), tag
 
 
 @pytest.mark.parametrize("tag", list(FILES))
@@ -78,7 +82,8 @@ def test_420_vs_oracle(cols, rows, n):
     assert np.array_equal(out, exp)
 
 
-@pytest.mark.parametrize("nc,h,v", [(3, 1, 1), (3, 2, 1), (3, 1, 2), (1, 1, 1)])
+@pytest.mark.parametrize("nc,h,v", [(3, 1, 1), (3, 2, 1), (3, 1, 2), (1, 1, 1), (3, 4, 1), (3, 1, 4), (3, 3, 1), (3, 1, 3),
+                                    (1, 4, 1), (1, 1, 4)])
 def test_other_geometries_vs_oracle(nc, h, v):
     geom = O.make_geom(11, 6, nc, h, v)
     q = synth.quant_tables(70)
@@ -254,10 +259,10 @@ def test_c_host_program_transbmp(golden, tmp_path):
     assert hashlib.sha256(bmp[54:]).digest() == g["q85_420_sha256"].tobytes()   # == the reference's decode of the file
 
 
-STRIP_LAYOUTS = [(3, 1, 1), (3, 2, 1), (3, 1, 2), (1, 1, 1)]
+STRIP_LAYOUTS = [(3, 1, 1), (3, 2, 1), (3, 1, 2), (1, 1, 1), (3, 4, 1), (3, 1, 4)]
 
 
-@pytest.mark.parametrize("nc,h,v", STRIP_LAYOUTS + [(1, 2, 2)])
+@pytest.mark.parametrize("nc,h,v", STRIP_LAYOUTS + [(1, 2, 2), (3, 3, 1), (3, 1, 3)])
 @pytest.mark.parametrize("cols,rows,n", [(1, 1, 1), (7, 1, 2), (8, 2, 1), (9, 3, 2), (17, 2, 1), (33, 1, 3)])
 def test_strip_kernel_sizes(nc, h, v, cols, rows, n):
     """k_jpeg_fused_strip (and, for grey with 2x2 blocks per MCU, the two-pass path): full and ragged strips"""
@@ -285,7 +290,7 @@ def test_strip_kernel_adversarial(nc, h, v):
     assert np.array_equal(gpu_recon(geom, 1, cy, cu, cv, q), exp)
 
 
-@pytest.mark.parametrize("h,v", [(1, 1), (2, 1), (1, 2)])
+@pytest.mark.parametrize("h,v", [(1, 1), (2, 1), (1, 2), (4, 1), (1, 4)])
 def test_strip_kernel_exact_integer_green(golden, h, v):
     """flat blocks carrying chroma pairs with 215 uu + 381 vv == 0 (mod 1000): the fp64 branch of the strip kernel"""
     tri = golden("color_triples.npz")["yuv"]

@@ -334,7 +334,7 @@ def test_color_triples(golden, ffo):
 
 def test_color_mcu_layouts_and_planar(golden, ffo):
     g = golden("color_planar.npz")
-    for (v, h) in ((1, 1), (1, 2), (2, 1), (2, 2)):
+    for (v, h) in ((1, 1), (1, 2), (2, 1), (2, 2), (1, 4), (4, 1), (1, 3), (3, 1)):       # every pair jpg.c:501's scratch admits (h*v <= 4)
         o = np.zeros((8 * v, 8 * h * 4), np.uint8)
         ffo.ffo_yuv_to_bgra32_mcu16(o.reshape(-1), 8 * h * 4, g["mcu_Y"], g["mcu_U"], g["mcu_V"], v, h)
         assert np.array_equal(o, g[f"mcu_v{v}h{h}"]), (v, h)
@@ -354,7 +354,10 @@ def test_color_mcu_layouts_and_planar(golden, ffo):
 
 
 GRID_TAGS = {"420": (6, 4, 3, 2, 2), "420tail": (7, 3, 3, 2, 2), "444": (5, 3, 3, 1, 1), "422": (5, 3, 3, 2, 1),
-             "440": (5, 3, 3, 1, 2), "grey": (5, 3, 1, 1, 1)}
+             "440": (5, 3, 3, 1, 2), "grey": (5, 3, 1, 1, 1),
+             # h*v = 4 / 3 MCUs (colorspace.c:143-150 takes any (v, h); jpg.c:501 sizes its scratch for h*v <= 4)
+             "411": (5, 3, 3, 4, 1), "114": (5, 3, 3, 1, 4), "311": (4, 3, 3, 3, 1), "113": (4, 3, 3, 1, 3),
+             "grey22": (3, 2, 1, 2, 2)}
 
 
 @pytest.mark.parametrize("tag", list(GRID_TAGS))
@@ -374,6 +377,10 @@ def test_jpeg_grid_adversarial(golden):
     geom = O.make_geom(*[int(x) for x in g["adv_geom"][:5]])
     out = O.oracle_jpeg_recon(geom, g["adv_cy"], g["adv_cu"], g["adv_cv"], g["adv_quant"])[0]
     assert np.array_equal(out, g["adv_bgra"])
+    for tag in ("adv411", "adv114"):          # the same blocks as 4:1:1 (h = 4) and as its transpose (v = 4)
+        geom = O.make_geom(*[int(x) for x in g[f"{tag}_geom"][:5]])
+        out = O.oracle_jpeg_recon(geom, g["adv_cy"], g["adv_cu"], g["adv_cv"], g["adv_quant"])[0]
+        assert np.array_equal(out, g[f"{tag}_bgra"]), tag
 
 
 def test_oracle_batch_threads_and_errors():

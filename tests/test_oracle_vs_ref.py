@@ -113,7 +113,8 @@ def test_hevc_scale_and_transform_every_branch(libs):
     assert len(seen) == 12          # rotation exists at 4x4 only, the dropped scaling list above 4x4 only
 
 
-@pytest.mark.parametrize("nc,h,v", [(3, 2, 2), (3, 1, 1), (3, 2, 1), (3, 1, 2), (1, 1, 1)])
+@pytest.mark.parametrize("nc,h,v", [(3, 2, 2), (3, 1, 1), (3, 2, 1), (3, 1, 2), (1, 1, 1), (3, 4, 1), (3, 1, 4), (3, 3, 1),
+                                    (3, 1, 3), (1, 2, 2), (1, 4, 1)])
 def test_jpeg_grid_random(libs, nc, h, v):
     q = synth.quant_tables(60)
     g = O.make_geom(9, 5, nc, h, v)

@@ -286,152 +286,220 @@ def extra_stage_kernels(L, dev, stream, T):
     return {"workload": "the HBM-bound stage kernels alone at chip-filling batch sizes", **out}
 
 
-def extra_c4(L, dev, stream, T, cpu=True):
-    """configs[3]: WebP lossy post-entropy chain on 16 x 1080p key frames: residual (dequant + WHT + 4x4 IDCT) ->
-    intra prediction + residual add -> loop filter (normal) -> YUV420 -> BGRA"""
-    c, r, nf = 120, 68, 16
-    n_mb = c * r
-    q = synth.vp8_quant(seed=2)
-    filt = synth.vp8_filters(seed=2)
-    lv, info, modes = [], [], []
-    for i in range(nf):
-        a, b = synth.vp8_macroblocks(n_mb, seed=100 + i)
-        m = synth.vp8_modes(c, r, seed=100 + i)
-        m[:, 18] = b[:, 26]
-        b[:, 25] = m[:, 0] != 4                 # a Y2 block exactly when the macroblock is not B_PRED
-        lv.append(a); info.append(b); modes.append(m)
-    h_modes = np.ascontiguousarray(np.stack(modes))
-    d_lv = torch.from_numpy(np.concatenate(lv)).to(dev)
-    d_info = torch.from_numpy(np.concatenate(info)).to(dev)
-    d_q = torch.from_numpy(q.astype(np.int16)).to(dev)
-    d_modes = torch.from_numpy(h_modes).to(dev)
-    d_filt = torch.from_numpy(filt).to(dev)
-    d_res = torch.empty((nf * n_mb, 384), dtype=torch.int16, device=dev)
-    Y = torch.zeros((nf, 16 * r, 16 * c), dtype=torch.uint8, device=dev)
-    U = torch.zeros((nf, 8 * r, 8 * c), dtype=torch.uint8, device=dev)
-    V = torch.zeros_like(U)
-    Wp, Hp = 16 * c, 16 * r
-    bgra = torch.empty((nf, Hp, Wp * 4), dtype=torch.uint8, device=dev)
+def _guarded(shape_rows, stride):
+    """A plane with one zeroed, readable row in front (what the reference's 16x16 V_PRED / H_PRED read at the top row)."""
+    buf = np.zeros((shape_rows + 1) * stride, np.uint8)
+    return buf, buf[stride:]
 
-    def s_res():
-        capi.check(L.ffhip_vp8_residual_batch(nf * n_mb, d_lv.data_ptr(), d_info.data_ptr(), d_q.data_ptr(), d_res.data_ptr(), stream))
 
-    def s_pred():
-        capi.check(L.ffhip_vp8_predict_recon(c, r, nf, h_modes.ctypes.data, d_modes.data_ptr(), d_res.data_ptr(), n_mb * 384, None, Y.data_ptr(), U.data_ptr(),
-                                             V.data_ptr(), 256 * n_mb, 64 * n_mb, stream))
+def c4_cpu_chain_frame(c, r, lv, info, q, modes, ft, filt):
+    """ONE key frame through residual -> predict -> loop filter -> BGRA in C, one call (oracle/_ref's ref_vp8_chain_frame: the
+    reference's own functions; oracle/ffo_chain.c when the compiled reference did not travel).  Returns (bgra, seconds, kind)."""
+    O = oracle_lib()
+    use_ref = os.path.exists(O.REF_SO)
+    lib = O.ref() if use_ref else O.ffo()
+    fn = lib.ref_vp8_chain_frame if use_ref else lib.ffo_vp8_chain_frame
+    vp = C.c_void_p
+    fn.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int]
+    fn.restype = None
+    n_mb, Wp, Hp = c * r, 16 * c, 16 * r
+    lv, info, q, modes, filt = (np.ascontiguousarray(a) for a in (lv, info, q.astype(np.uint16), modes, filt))
+    res = np.zeros((n_mb, 384), np.int16)
+    (yb, y), (ub, u), (vb, v) = _guarded(Hp, Wp), _guarded(Hp // 2, Wp // 2), _guarded(Hp // 2, Wp // 2)
+    o = np.zeros((Hp, Wp * 4), np.uint8)
+    t0 = time.perf_counter()
+    fn(c, r, lv.ctypes.data, info.ctypes.data, q.ctypes.data, modes.ctypes.data, ft, filt.ctypes.data, res.ctypes.data, y.ctypes.data, u.ctypes.data,
+       v.ctypes.data, o.ctypes.data, Wp * 4)
+    return o, time.perf_counter() - t0, ("reference" if use_ref else "port")
 
-    def s_lf():
-        capi.check(L.ffhip_vp8_loopfilter(c, r, nf, 2, d_modes.data_ptr(), d_filt.data_ptr(), Y.data_ptr(), U.data_ptr(), V.data_ptr(), 256 * n_mb, 64 * n_mb, stream))
 
-    def s_col():
-        capi.check(L.ffhip_yuv420_to_bgra(bgra.data_ptr(), Wp * 4, Y.data_ptr(), U.data_ptr(), V.data_ptr(), Wp, Wp // 2, r, c, nf, Hp * Wp, Hp * Wp // 4, Hp * Wp * 4, stream))
+class C4:
+    """configs[3]: the WebP lossy post-entropy chain -- residual (dequant + WHT + 4x4 IDCT) -> intra prediction + residual add ->
+    loop filter -> YUV420 -> BGRA -- on batches of 1080p key frames made of 16 distinct synthetic frames (uniformly random modes)
+    or of copies of a real encoder's frame (tests/golden/webp_file_1080p.npz), tiled to the batch size on the device."""
+    c, r, U = 120, 68, 16
 
-    def s_pred_lf():                          # prediction and loop filter as ONE call: the two row kernels side by side
-        capi.check(L.ffhip_vp8_predict_loopfilter(c, r, nf, h_modes.ctypes.data, d_modes.data_ptr(), d_res.data_ptr(), n_mb * 384, None, 2, d_filt.data_ptr(),
-                                                  Y.data_ptr(), U.data_ptr(), V.data_ptr(), 256 * n_mb, 64 * n_mb, stream))
+    def __init__(self, L, dev, stream, T):
+        self.L, self.dev, self.stream, self.T = L, dev, stream, T
+        c, r, U = self.c, self.r, self.U
+        self.n_mb = n_mb = c * r
+        self.q = synth.vp8_quant(seed=2)
+        self.filt = synth.vp8_filters(seed=2)
+        lv, info, modes = [], [], []
+        for i in range(U):
+            a, b = synth.vp8_macroblocks(n_mb, seed=100 + i)
+            m = synth.vp8_modes(c, r, seed=100 + i)
+            m[:, 18] = b[:, 26]
+            b[:, 25] = m[:, 0] != 4                 # a Y2 block exactly when the macroblock is not B_PRED
+            lv.append(a); info.append(b); modes.append(m)
+        self.lv, self.info, self.modes = np.stack(lv), np.stack(info), np.ascontiguousarray(np.stack(modes))
+        self.d_q = torch.from_numpy(self.q.astype(np.int16)).to(dev)
+        self.d_filt = torch.from_numpy(self.filt).to(dev)
+        self.u_lv = torch.from_numpy(self.lv.reshape(U * n_mb, 400)).to(dev)
+        self.u_info = torch.from_numpy(self.info.reshape(U * n_mb, 32)).to(dev)
+        self.u_modes = torch.from_numpy(self.modes.reshape(U * n_mb, 20)).to(dev)
+        self.enc = None
+        fx = os.path.join(ROOT, "tests", "golden", "webp_file_1080p.npz")
+        if os.path.exists(fx):
+            g = np.load(fx)
+            e_filt = np.zeros((4, 2, 3), np.uint8)
+            ft = C.c_int(-1)
+            lfv, lh = g["lf"], g["lf_header"]
+            # lf = [level, filter-type bit, segmentation_enabled, triples...], lf_header = [sharpness, segment_feature_mode, lf_update_value[4],
+            # adj_enable, mode_ref delta 0, mb_mode delta 0, partitions] as the recorder wrote them (tests/golden/make_golden.py)
+            hdr = capi.Vp8FilterHeader(int(lfv[1]), int(lfv[0]), int(lh[0]), int(lfv[2]), int(lh[1]), (C.c_int8 * 4)(*[int(x) for x in lh[2:6]]),
+                                       int(lh[6]), int(lh[7]), int(lh[8]), int(lh[9]))
+            capi.check(L.ffhip_vp8_filter_params(C.byref(hdr), e_filt.ctypes.data, C.byref(ft)))
+            self.enc = {"modes": np.ascontiguousarray(g["modes"]), "u_modes": torch.from_numpy(np.ascontiguousarray(g["modes"])).to(dev),
+                        "u_res": torch.from_numpy(np.ascontiguousarray(g["residual"])).to(dev), "d_filt": torch.from_numpy(e_filt).to(dev), "ft": ft.value,
+                        "row_sums": g["bgra_row_sums"], "level": int(lfv[0]), "bpred": round(float((g["modes"][:, 0] == 4).mean()) * 100)}
 
-    def chain():
-        s_res(); s_pred_lf(); s_col()
-    px = nf * Hp * Wp
-    chain_ms = T.ms(chain, reps=5, warm=2)
+    def batch(self, nf, source):
+        """Device buffers and stage closures for `nf` frames of `source` ("random" | "encoder")."""
+        L, dev, stream, c, r, n_mb, U = self.L, self.dev, self.stream, self.c, self.r, self.n_mb, self.U
+        reps = (nf + U - 1) // U
+        B = type("Batch", (), {})()
+        B.nf, B.Wp, B.Hp = nf, 16 * c, 16 * r
+        d_lv = self.u_lv.repeat(reps, 1)[:nf * n_mb]
+        d_info = self.u_info.repeat(reps, 1)[:nf * n_mb]
+        d_res = torch.empty((nf * n_mb, 384), dtype=torch.int16, device=dev)
+        if source == "encoder":
+            h_modes = np.ascontiguousarray(np.broadcast_to(self.enc["modes"], (nf,) + self.enc["modes"].shape))
+            d_modes = self.enc["u_modes"].repeat(nf, 1)
+            p_res = self.enc["u_res"].repeat(nf, 1)        # the residual the reference's decoder recorded; s_res still runs, on the synthetic levels
+            d_filt, ft = self.enc["d_filt"], self.enc["ft"]
+        else:
+            h_modes = np.ascontiguousarray(np.tile(self.modes, (reps, 1, 1))[:nf])
+            d_modes = self.u_modes.repeat(reps, 1)[:nf * n_mb]
+            p_res, d_filt, ft = d_res, self.d_filt, 2
+        Y = torch.zeros((nf, B.Hp, B.Wp), dtype=torch.uint8, device=dev)
+        U_ = torch.zeros((nf, B.Hp // 2, B.Wp // 2), dtype=torch.uint8, device=dev)
+        V = torch.zeros_like(U_)
+        B.bgra = torch.empty((nf, B.Hp, B.Wp * 4), dtype=torch.uint8, device=dev)
+        B.planes = (Y, U_, V)
+        B.keep = (d_lv, d_info, d_res, d_modes, p_res, h_modes)
+        B.s_res = lambda: capi.check(L.ffhip_vp8_residual_batch(nf * n_mb, d_lv.data_ptr(), d_info.data_ptr(), self.d_q.data_ptr(), d_res.data_ptr(), stream))
+        B.s_pred = lambda: capi.check(L.ffhip_vp8_predict_recon(c, r, nf, h_modes.ctypes.data, d_modes.data_ptr(), p_res.data_ptr(), n_mb * 384, None, Y.data_ptr(),
+                                                                 U_.data_ptr(), V.data_ptr(), 256 * n_mb, 64 * n_mb, stream))
+        B.s_lf = lambda: capi.check(L.ffhip_vp8_loopfilter(c, r, nf, ft, d_modes.data_ptr(), d_filt.data_ptr(), Y.data_ptr(), U_.data_ptr(), V.data_ptr(), 256 * n_mb, 64 * n_mb, stream))
+        # prediction and loop filter as ONE call: the two row kernels side by side
+        B.s_pred_lf = lambda: capi.check(L.ffhip_vp8_predict_loopfilter(c, r, nf, h_modes.ctypes.data, d_modes.data_ptr(), p_res.data_ptr(), n_mb * 384, None, ft, d_filt.data_ptr(),
+                                                                         Y.data_ptr(), U_.data_ptr(), V.data_ptr(), 256 * n_mb, 64 * n_mb, stream))
+        B.s_col = lambda: capi.check(L.ffhip_yuv420_to_bgra(B.bgra.data_ptr(), B.Wp * 4, Y.data_ptr(), U_.data_ptr(), V.data_ptr(), B.Wp, B.Wp // 2, r, c, nf, B.Hp * B.Wp,
+                                                            B.Hp * B.Wp // 4, B.Hp * B.Wp * 4, stream))
+
+        def chain():
+            B.s_res(); B.s_pred_lf(); B.s_col()
+        B.chain = chain
+
+        def one_clean_pass():
+            for p in B.planes:                        # the reference's wrapped 16x16 H_PRED / V_PRED at the frame edge read what the planes
+                p.zero_()                             # held before the frame (predict.c:338-353): zeros, as in its freshly allocated planes
+            chain()
+            capi.check(L.ffhip_stream_sync(stream))
+        B.one_clean_pass = one_clean_pass
+        return B
+
+    def parity(self, B, source, frames):
+        """Frames `frames` of the batch's BGRA against the reference: its whole-file decode (encoder) or its C chain (random)."""
+        ok = True
+        for i in frames:
+            got = B.bgra[i].cpu().numpy()
+            if source == "encoder":
+                rows = got.reshape(B.Hp, -1).view(np.uint32).astype(np.uint64)
+                sums = (rows * (np.arange(rows.shape[1], dtype=np.uint64) + np.uint64(1))).sum(axis=1, dtype=np.uint64)
+                ok = ok and bool(np.array_equal(sums, self.enc["row_sums"]))
+            else:
+                k = i % self.U
+                exp, _, _ = c4_cpu_chain_frame(self.c, self.r, self.lv[k], self.info[k], self.q, self.modes[k], 2, self.filt)
+                ok = ok and bool(np.array_equal(got, exp))
+        return ok
+
+    def sweep(self, sizes, parity_at_largest=True):
+        """Chain throughput against the number of frames in the call (the frame loop this replaces is webp.c:1833-1866, one frame
+        at a time): a frame's chain is a dependency chain of ~400 macroblock steps, so one frame keeps a handful of the chip's
+        1024 SIMDs busy and a batch's frames run side by side."""
+        out = {}
+        for source in ("encoder", "random") if self.enc else ("random",):
+            rows = []
+            for nf in sizes:
+                B = self.batch(nf, source)
+                reps = 5 if nf <= 64 else 3
+                ms = self.T.ms(B.chain, reps=reps, warm=1)
+                pl = self.T.ms(B.s_pred_lf, reps=reps, warm=0)
+                t0 = time.perf_counter()
+                B.s_pred_lf()
+                host_ms = (time.perf_counter() - t0) * 1e3          # what the enqueue call itself costs the host
+                row = {"frames": nf, "chain_ms": round(ms, 4), "value": round(nf * B.Hp * B.Wp / ms / 1e3, 1), "unit": "Mpixels/s",
+                       "predict+loopfilter_ms": round(pl, 4), "host_enqueue_ms": round(host_ms, 3)}
+                if parity_at_largest and nf == max(sizes):
+                    B.one_clean_pass()
+                    row["parity_first_and_last_frame"] = self.parity(B, source, sorted({0, nf - 1}))
+                rows.append(row)
+                del B
+                torch.cuda.empty_cache()
+            out[source] = rows
+        return out
+
+
+def extra_c4(L, dev, stream, T, cpu=True, sweep_sizes=(1, 16, 64, 256, 1024)):
+    X = C4(L, dev, stream, T)
+    c, r, n_mb, nf = X.c, X.r, X.n_mb, 16
+    B = X.batch(nf, "random")
+    px = nf * B.Hp * B.Wp
+    chain_ms = T.ms(B.chain, reps=5, warm=2)
     stages = {}
-    for name, fn, nbytes in (("residual", s_res, nf * n_mb * (800 + 32 + 768)), ("predict_recon", s_pred, nf * n_mb * (768 + 20 + 384)),
-                             ("loopfilter", s_lf, nf * n_mb * (2 * 384 + 20)), ("yuv420_to_bgra", s_col, px * 5.5)):
+    for name, fn, nbytes in (("residual", B.s_res, nf * n_mb * (800 + 32 + 768)), ("predict_recon", B.s_pred, nf * n_mb * (768 + 20 + 384)),
+                             ("loopfilter", B.s_lf, nf * n_mb * (2 * 384 + 20)), ("yuv420_to_bgra", B.s_col, px * 5.5)):
         ms = T.ms(fn, reps=5, warm=1)
         stages[name] = {"ms": round(ms, 4), "GB/s": round(nbytes / ms / 1e6, 1), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
                         "algorithmic_bytes": int(nbytes)}
     stages["predict_recon"]["bound"] = stages["loopfilter"]["bound"] = "dependency chain (a wave per macroblock row), not HBM"
-    stages["predict_recon+loopfilter_side_by_side"] = {"ms": round(T.ms(s_pred_lf, reps=5, warm=1), 4),
+    stages["predict_recon+loopfilter_side_by_side"] = {"ms": round(T.ms(B.s_pred_lf, reps=5, warm=1), 4),
                                                        "note": "ffhip_vp8_predict_loopfilter, what the chain calls: the two stages above as one call, their row kernels overlapping"}
-    for p in (Y, U, V):                           # the reference's wrapped 16x16 H_PRED / V_PRED at the frame edge read what the planes
-        p.zero_()                                 # held before the frame (predict.c:338-353): zeros, as in its freshly allocated planes
-    chain()                                       # leave the planes as ONE pass of the chain makes them
-    capi.check(L.ffhip_stream_sync(stream))
+    B.one_clean_pass()                                # leave the planes as ONE pass of the chain makes them
     res = {"workload": "C4: 16 x 1920x1088 VP8 key frames, residual -> predict -> loop filter (normal) -> BGRA", "chain_ms": round(chain_ms, 4),
            "value": round(px / chain_ms / 1e3, 1), "unit": "Mpixels/s", "stages": stages,
-           "roofline": dict(roof(nf * n_mb * 1600, stages["residual"]["ms"]), kernel="k_vp8_residual")}
-    # The same chain on a REAL encoder's syntax elements (tests/golden/webp_file_1080p.npz: libwebp on a photograph mosaic,
-    # decoded by the reference; 16 copies of the frame): the uniformly random modes above put H_PRED into column 0 of one
-    # row in five, where the reference's wrapped read chains the row to the END of the row above -- libwebp never
-    # chooses it there.  Checked against the reference's own whole-file decode (per-row checksums of its BGRA).
-    fx = os.path.join(ROOT, "tests", "golden", "webp_file_1080p.npz")
-    if os.path.exists(fx):
-        import ctypes as C
-        g = np.load(fx)
-        e_modes = np.ascontiguousarray(np.broadcast_to(g["modes"], (nf,) + g["modes"].shape))
-        de_modes = torch.from_numpy(e_modes).to(dev)
-        de_res = torch.from_numpy(np.ascontiguousarray(g["residual"])).to(dev).repeat(nf, 1)
-        e_filt = np.zeros((4, 2, 3), np.uint8)
-        ft = C.c_int(-1)
-        lfv, lh = g["lf"], g["lf_header"]
-        # lf = [level, filter-type bit, segmentation_enabled, triples...], lf_header = [sharpness, segment_feature_mode, lf_update_value[4],
-        # adj_enable, mode_ref delta 0, mb_mode delta 0, partitions] as the recorder wrote them (tests/golden/make_golden.py)
-        hdr = capi.Vp8FilterHeader(int(lfv[1]), int(lfv[0]), int(lh[0]), int(lfv[2]), int(lh[1]), (C.c_int8 * 4)(*[int(x) for x in lh[2:6]]),
-                                   int(lh[6]), int(lh[7]), int(lh[8]), int(lh[9]))
-        capi.check(L.ffhip_vp8_filter_params(C.byref(hdr), e_filt.ctypes.data, C.byref(ft)))
-        de_filt = torch.from_numpy(e_filt).to(dev)
-
-        def e_pred():
-            capi.check(L.ffhip_vp8_predict_recon(c, r, nf, e_modes.ctypes.data, de_modes.data_ptr(), de_res.data_ptr(), n_mb * 384, None, Y.data_ptr(), U.data_ptr(),
-                                                 V.data_ptr(), 256 * n_mb, 64 * n_mb, stream))
-
-        def e_lf():
-            capi.check(L.ffhip_vp8_loopfilter(c, r, nf, ft.value, de_modes.data_ptr(), de_filt.data_ptr(), Y.data_ptr(), U.data_ptr(), V.data_ptr(), 256 * n_mb, 64 * n_mb, stream))
-
-        def e_pred_lf():
-            capi.check(L.ffhip_vp8_predict_loopfilter(c, r, nf, e_modes.ctypes.data, de_modes.data_ptr(), de_res.data_ptr(), n_mb * 384, None, ft.value, de_filt.data_ptr(),
-                                                      Y.data_ptr(), U.data_ptr(), V.data_ptr(), 256 * n_mb, 64 * n_mb, stream))
-
-        def e_chain():
-            s_res(); e_pred_lf(); s_col()
-        e_ms = T.ms(e_chain, reps=5, warm=2)
-        e_stage = {"predict_recon_ms": round(T.ms(e_pred, reps=5, warm=1), 4), "loopfilter_ms": round(T.ms(e_lf, reps=5, warm=1), 4),
-                   "predict_recon+loopfilter_side_by_side_ms": round(T.ms(e_pred_lf, reps=5, warm=1), 4)}
-        for pl in (Y, U, V):
-            pl.zero_()
-        e_chain()
-        capi.check(L.ffhip_stream_sync(stream))
-        ok = True
-        for i in (0, nf - 1):
-            rows = bgra[i].cpu().numpy().reshape(Hp, -1).view(np.uint32).astype(np.uint64)
-            sums = (rows * (np.arange(rows.shape[1], dtype=np.uint64) + np.uint64(1))).sum(axis=1, dtype=np.uint64)
-            ok = ok and bool(np.array_equal(sums, g["bgra_row_sums"]))
-        res["encoder_stream"] = {"workload": "the same chain on 16 copies of a libwebp-encoded 1920x1088 photograph mosaic (quality 75: loop filter level "
-                                             f"{int(lfv[0])}, {round(float((g['modes'][:, 0] == 4).mean()) * 100)} % B_PRED macroblocks), syntax elements as the reference's decoder recorded them",
-                                 "chain_ms": round(e_ms, 4), "value": round(px / e_ms / 1e3, 1), "unit": "Mpixels/s", **e_stage,
-                                 "parity_vs_reference_whole_file_decode": ok}
-        for pl in (Y, U, V):
-            pl.zero_()
-        chain()                                   # back to the synthetic batch for the check below
-        capi.check(L.ffhip_stream_sync(stream))
+           # the chain's dominant kernel is the prediction; it is bound by its dependency chain, the HBM figure only shows how far from the roofline that leaves it
+           "roofline": dict(roof(nf * n_mb * (768 + 20 + 384), stages["predict_recon"]["ms"]), kernel="k_vp8_predict_rows",
+                            note="dominant kernel of the chain at 16 frames; dependency-bound (one wave per macroblock row): see batch_sweep for what the chip does with more frames in flight")}
     if cpu:
-        O = oracle_lib()
-        use_ref = os.path.exists(O.REF_SO)
-        lib = O.ref() if use_ref else O.ffo()
-        pre = "ref_" if use_ref else "ffo_"
-        t0 = time.perf_counter()
-        res0 = np.zeros((n_mb, 384), np.int16)
-        fn = getattr(lib, pre + "vp8_residual_mb")
-        for i in range(n_mb):
-            fn(np.ascontiguousarray(lv[0][i]).reshape(-1), info[0][i], int(info[0][i, 25]), np.ascontiguousarray(q[info[0][i, 26], :6]), res0[i])
-        y, u, v = (O.ref_vp8_frame if use_ref else O.oracle_vp8_frame)(c, r, modes[0], res0)
-        y, u, v = [np.ascontiguousarray(p).copy() for p in (y, u, v)]
-        getattr(lib, pre + "vp8_loopfilter_frame")(c, r, 2, np.ascontiguousarray(modes[0]).reshape(-1), np.ascontiguousarray(filt).reshape(-1),
-                                                   y.reshape(-1), u.reshape(-1), v.reshape(-1))
-        o = np.zeros((Hp, Wp * 4), np.uint8)
-        (lib.YUV420_to_BGRA32 if use_ref else lib.ffo_yuv420_to_bgra32)(o.reshape(-1), Wp * 4, y.reshape(-1), u.reshape(-1), v.reshape(-1), Wp, Wp // 2, r, c)
-        dt = time.perf_counter() - t0
-        res["parity_vs_reference_frame0"] = bool(np.array_equal(bgra[0].cpu().numpy(), o))
-        res["cpu_baseline"] = {"value": round(Hp * Wp / dt / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "reference" if use_ref else "port",
-                               "sample": "frame 0 of the batch (1920x1088) through the same four stages; the residual stage is called per "
-                                         "macroblock through ctypes, which adds ~0.1 s of call overhead"}
+        exp, dt, kind = c4_cpu_chain_frame(c, r, X.lv[0], X.info[0], X.q, X.modes[0], 2, X.filt)
+        exp2, dt2, _ = c4_cpu_chain_frame(c, r, X.lv[nf - 1], X.info[nf - 1], X.q, X.modes[nf - 1], 2, X.filt)
+        res["parity_vs_reference_first_and_last_frame"] = bool(np.array_equal(B.bgra[0].cpu().numpy(), exp) and np.array_equal(B.bgra[nf - 1].cpu().numpy(), exp2))
+        res["cpu_baseline"] = {"value": round(2 * B.Hp * B.Wp / (dt + dt2) / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": kind,
+                               "sample": "frames 0 and 15 of the batch (1920x1088 each) through the same four stages in C, one call per frame "
+                                         "(ref_vp8_chain_frame: the reference's own functions looped like vp8_decode)"}
+    del B
+    torch.cuda.empty_cache()
+    if X.enc:
+        # The same chain on a REAL encoder's syntax elements (tests/golden/webp_file_1080p.npz: libwebp on a photograph mosaic,
+        # decoded by the reference; 16 copies of the frame): the uniformly random modes above put H_PRED into column 0 of one
+        # row in five, where the reference's wrapped read chains the row to the END of the row above -- libwebp never
+        # chooses it there.  Checked against the reference's own whole-file decode (per-row checksums of its BGRA).
+        E = X.batch(nf, "encoder")
+        e_ms = T.ms(E.chain, reps=5, warm=2)
+        e_stage = {"predict_recon_ms": round(T.ms(E.s_pred, reps=5, warm=1), 4), "loopfilter_ms": round(T.ms(E.s_lf, reps=5, warm=1), 4),
+                   "predict_recon+loopfilter_side_by_side_ms": round(T.ms(E.s_pred_lf, reps=5, warm=1), 4)}
+        E.one_clean_pass()
+        res["encoder_stream"] = {"workload": "the same chain on 16 copies of a libwebp-encoded 1920x1088 photograph mosaic (quality 75: loop filter level "
+                                             f"{X.enc['level']}, {X.enc['bpred']} % B_PRED macroblocks), syntax elements as the reference's decoder recorded them",
+                                 "chain_ms": round(e_ms, 4), "value": round(px / e_ms / 1e3, 1), "unit": "Mpixels/s", **e_stage,
+                                 "parity_vs_reference_whole_file_decode": X.parity(E, "encoder", (0, nf - 1))}
+        del E
+        torch.cuda.empty_cache()
+    if sweep_sizes:
+        res["batch_sweep"] = {"workload": "the chain (ffhip_vp8_residual_batch -> ffhip_vp8_predict_loopfilter -> ffhip_yuv420_to_bgra) against the number of 1920x1088 frames "
+                                          "in ONE call each; `encoder`: copies of the libwebp frame, `random`: 16 distinct frames of uniformly random modes, tiled",
+                              **X.sweep(sweep_sizes)}
     return res
 
 
-def hevc_chain_inputs(W, H, seed):
+def hevc_chain_inputs(W, H, seed, tus=None):
     """One intra picture with SURVEY 8d's config-5 TU mix: the TU list, quantised levels grouped by TU size (as a decoder
     would hand them to ffhip_hevc_residual_batch) and residual offsets into one buffer laid out [32x32 | 16x16 | 8x8 | 4x4]."""
-    tus, _ = synth.hevc_intra_tus(W, H, seed=seed, tu_mix="c5")
+    if tus is None:
+        tus, _ = synth.hevc_intra_tus(W, H, seed=seed, tu_mix="c5")
     tus = tus.copy()
     tus["flags"] &= ~np.uint8(synth.TU_RDPCM)      # rdpcm belongs to transform-skip / bypass TUs: keep the chain plain
     rng = np.random.default_rng(seed)
@@ -478,6 +546,9 @@ def run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T=None):
     if T is not None:
         times = {"chain": T.ms(chain, reps=5, warm=2), "residual": T.ms(s_res, reps=5, warm=1), "intra_recon": T.ms(s_intra, reps=5, warm=1),
                  "yuv420_to_bgra_16": T.ms(s_col, reps=5, warm=1)}
+        t0 = time.perf_counter()
+        s_intra()
+        times["intra_host_enqueue"] = (time.perf_counter() - t0) * 1e3
     for p in (py, pu, pv):
         p.zero_()
     chain()
@@ -485,7 +556,83 @@ def run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T=None):
     return bgra, (py, pu, pv), d_res, times
 
 
-def extra_c5(L, dev, stream, T, cpu=True):
+def c5_cpu_chain_picture(W, H, tus, groups, total):
+    """ONE picture through scaling + inverse transforms -> intra prediction + reconstruction -> BGRA in C, one call
+    (oracle/_ref's ref_hevc_chain_picture: the reference's own functions; oracle/ffo_chain.c when it did not travel)."""
+    O = oracle_lib()
+    use_ref = os.path.exists(O.REF_SO)
+    lib = O.ref() if use_ref else O.ffo()
+    fn = lib.ref_hevc_chain_picture if use_ref else lib.ffo_hevc_chain_picture
+    vp = C.c_void_p
+    fn.argtypes = [vp, C.c_long, vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    fn.restype = None
+    levels = np.zeros(total + 64, np.int16)
+    for n, (idx, lv, info, off) in groups.items():
+        levels[off:off + lv.size] = lv.reshape(-1)
+    resid = np.zeros(total + 64, np.int16)
+    py, pu, pv = np.zeros((H, W), np.int16), np.zeros((H // 2, W // 2), np.int16), np.zeros((H // 2, W // 2), np.int16)
+    o = np.zeros((H, W * 4), np.uint8)
+    t = np.ascontiguousarray(tus)
+    t0 = time.perf_counter()
+    fn(t.ctypes.data, len(t), levels.ctypes.data, resid.ctypes.data, 27, 8, py.ctypes.data, pu.ctypes.data, pv.ctypes.data, W, H, 64, o.ctypes.data, W * 4)
+    return o, resid, time.perf_counter() - t0, ("reference" if use_ref else "port")
+
+
+def c5_grid_sweep(L, dev, stream, T, cpu=True, pictures=(1, 4, 8), tile=512, tiles_xy=(15, 9)):
+    """configs[4] says "single 8K tile grid": an 8K picture as a HEIF grid of 15 x 9 = 135 independent 512x512 tiles (7680x4608), every
+    tile a complete intra picture of the config-5 TU mix with its own neighbour availability, all tiles of all pictures in ONE plane set and
+    ONE ffhip_hevc_residual_batch / ffhip_hevc_intra_recon / ffhip_yuv420_to_bgra_16 call each (the tile loop this replaces decodes them
+    one after the other: heif.c:297-309).  Pictures side by side: 1, 4 (2 x 2), 8 (4 x 2)."""
+    t0, _ = synth.hevc_intra_tus(tile, tile, seed=3, tu_mix="c5")
+    out = {"workload": f"8K pictures as grids of {tiles_xy[0]} x {tiles_xy[1]} independent {tile}x{tile} HEVC tiles ({len(t0)} TUs per tile, config-5 mix), "
+                       "residual -> intra -> BGRA, one call per stage for all tiles", "rows": []}
+    for npic in pictures:
+        px_, py_ = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}[npic]
+        gx, gy = tiles_xy[0] * px_, tiles_xy[1] * py_
+        W, H = gx * tile, gy * tile
+        tus = np.tile(t0, gx * gy)
+        k = np.repeat(np.arange(gx * gy), len(t0))
+        sc = np.where(tus["cidx"] == 0, tile, tile // 2)
+        tus["x"] = (tus["x"].astype(np.int64) + (k % gx) * sc).astype(np.uint16)
+        tus["y"] = (tus["y"].astype(np.int64) + (k // gx) * sc).astype(np.uint16)
+        tus, groups, total = hevc_chain_inputs(W, H, seed=40 + npic, tus=tus)
+        bgra, planes, d_res, t = run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T)
+        row = {"pictures": npic, "tiles": gx * gy, "tus": int(len(tus)), "chain_ms": round(t["chain"], 4), "intra_recon_ms": round(t["intra_recon"], 4),
+               "intra_host_enqueue_ms": round(t["intra_host_enqueue"], 3), "value": round(W * H / t["chain"] / 1e3, 1), "unit": "Mpixels/s"}
+        if cpu and npic == max(pictures):
+            # parity of the first and the last tile of the largest grid: each tile is a picture of its own for the reference's C chain
+            ok = True
+            for ti in (0, gx * gy - 1):
+                sl = slice(ti * len(t0), (ti + 1) * len(t0))
+                tt = tus[sl].copy()
+                ox, oy = (ti % gx) * tile, (ti // gx) * tile
+                tt["x"] = (tt["x"].astype(np.int64) - np.where(tt["cidx"] == 0, ox, ox // 2)).astype(np.uint16)
+                tt["y"] = (tt["y"].astype(np.int64) - np.where(tt["cidx"] == 0, oy, oy // 2)).astype(np.uint16)
+                # the tile's levels, re-packed as a picture of its own
+                lv_all = {n: (g[1], g[3], {int(i): j for j, i in enumerate(g[0])}) for n, g in groups.items()}
+                tg, toff = {}, 0
+                for n in (32, 16, 8, 4):
+                    if n not in lv_all:
+                        continue
+                    lv, off, pos = lv_all[n]
+                    idx = np.nonzero(((tt["flags"] & synth.TU_RESIDUAL) != 0) & (tt["log2_size"] == int(np.log2(n))))[0]
+                    if idx.size == 0:
+                        continue
+                    rows_ = np.array([pos[int(sl.start + i)] for i in idx])
+                    tt["res_offset"][idx] = toff + np.arange(idx.size, dtype=np.uint32) * (n * n)
+                    tg[n] = (idx, lv[rows_], None, toff)
+                    toff += idx.size * n * n
+                o, _, _, _ = c5_cpu_chain_picture(tile, tile, tt, tg, toff)
+                got = bgra[oy:oy + tile].cpu().numpy().reshape(tile, W, 4)[:, ox:ox + tile].reshape(tile, tile * 4)
+                ok = ok and bool(np.array_equal(got, o))
+            row["parity_first_and_last_tile_vs_reference"] = ok
+        out["rows"].append(row)
+        del bgra, planes, d_res
+        torch.cuda.empty_cache()
+    return out
+
+
+def extra_c5(L, dev, stream, T, cpu=True, grid=True):
     """configs[4]: HEIF/HEVC still, one 8K picture (7680x4352 coded): scaling + inverse transforms per TU size -> intra
     prediction + reconstruction -> YUV420 16-bit -> BGRA"""
     W, H = 7680, 4352
@@ -506,32 +653,17 @@ def extra_c5(L, dev, stream, T, cpu=True):
            "roofline": dict(roof(9 * px, t["intra_recon"]), kernel="k_hevc_intra_groups",
                             note="algorithmic bytes 9 B/pixel (3 + 3 in, 3 out); the stage is bound by its dependency chain")}
     if cpu:
-        # bounded sample: a 1024x512 picture of the same mix through the reference, and the same picture through the GPU chain
-        O = oracle_lib()
-        use_ref = os.path.exists(O.REF_SO)
+        # bounded sample: a 1024x512 picture of the same mix through the reference's C (one call), and the same picture through the GPU chain
         sw, sh = 1024, 512
         stus, sgroups, stotal = hevc_chain_inputs(sw, sh, seed=6)
         g_bgra, g_planes, g_res, _ = run_hevc_chain_gpu(L, dev, stream, sw, sh, stus, sgroups, stotal)
-        t0 = time.perf_counter()
-        resid = np.zeros(stotal + 64, np.int16)
-        lib = O.ref() if use_ref else O.ffo()
-        for n, (idx, lv, info, off) in sgroups.items():
-            d = np.zeros(n * n, np.int16)
-            for k in range(len(idx)):
-                r = resid[off + k * n * n: off + (k + 1) * n * n]
-                if use_ref:
-                    lib.ref_hevc_scale(lv[k], d, n, 27, 8, 0, None, int(stus["cidx"][idx[k]]))
-                    lib.ref_hevc_transform(d, r, n, int(info[k, 1]), 8, 0)
-                else:
-                    lib.ffo_hevc_residual_tu(lv[k], r, n, 27, int(info[k, 1]), 8, 0, None)
-        planes = (O.ref_hevc_intra if use_ref else O.oracle_hevc_intra)(stus, resid, sw, sh, True, 8, 8)
-        o = np.zeros((sh, sw * 4), np.uint8)
-        (lib.YUV420_to_BGRA32_16bit if use_ref else lib.ffo_yuv420_to_bgra32_16bit)(o.reshape(-1), sw * 4, planes[0].reshape(-1), planes[1].reshape(-1),
-                                                                                  planes[2].reshape(-1), sw, sw // 2, sh // 64, sw // 64, 64)
-        dt = time.perf_counter() - t0
+        o, resid, dt, kind = c5_cpu_chain_picture(sw, sh, stus, sgroups, stotal)
         res["parity_vs_reference_sample"] = bool(np.array_equal(g_bgra.cpu().numpy(), o) and np.array_equal(g_res[:stotal].cpu().numpy(), resid[:stotal]))
-        res["cpu_baseline"] = {"value": round(sw * sh / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "reference" if use_ref else "port",
-                               "sample": f"one {sw}x{sh} picture of the same TU mix ({len(stus)} TUs) through the same three stages; one ctypes call per TU"}
+        res["cpu_baseline"] = {"value": round(sw * sh / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": kind,
+                               "sample": f"one {sw}x{sh} picture of the same TU mix ({len(stus)} TUs) through the same three stages in C, one call per picture "
+                                         "(ref_hevc_chain_picture: the reference's own functions per TU in decode order)"}
+    if grid:
+        res["grid"] = c5_grid_sweep(L, dev, stream, T, cpu=cpu)
     return res
 
 

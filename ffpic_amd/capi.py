@@ -24,7 +24,7 @@ EXPORTS = [
     "ffhip_jpeg_probe", "ffhip_jpeg_entropy_decode", "ffhip_jpeg_entropy_decode_mt", "ffhip_jpeg_entropy_batch", "ffhip_bmp_write",
     "ffhip_heif_grid_parse", "ffhip_heif_grid_compose", "ffhip_hevc_picture_layout", "ffhip_jpeg_decode_files", "ffhip_jpeg_decode_files_device", "ffhip_jpeg_entropy_batch_gpu", "ffhip_jpeg_stage_scan_test", "ffhip_host_malloc", "ffhip_host_free",
     "ffhip_shard_range", "ffhip_comm_unique_id", "ffhip_comm_init_rank", "ffhip_comm_destroy", "ffhip_batch_close", "ffhip_batch_complete",
-    "ffhip_bgra_checksum", "ffhip_vp8_filter_params", "ffhip_vp8_predict_loopfilter",
+    "ffhip_bgra_checksum", "ffhip_vp8_filter_params", "ffhip_vp8_predict_loopfilter", "ffhip_reload_env",
 ]
 
 
@@ -204,6 +204,21 @@ def lib():
     L.ffhip_bgra_checksum.argtypes = [vp, i64, i64, ci, ci, ci, vp, vp]
     _lib = L
     return L
+
+
+def reload_env():
+    """The library reads its FFHIP_* switches once per process; after changing one in a live process, call this."""
+    if _lib is not None:
+        _lib.ffhip_reload_env()
+
+
+def setenv(name, value):
+    """Set (or, with None, remove) an FFHIP_* switch in this process and make the library read it again."""
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
+    reload_env()
 
 
 def check(rc, what="ffhip call"):

@@ -160,7 +160,7 @@ static void fail(const char *what)
 {
     /* the reference's op tables return void: nothing to report through; say it once */
     static int said = 0;
-    if (!said || getenv("FFHIP_VERBOSE")) fprintf(stderr, "ffpic_hip: %s failed; block left untouched\n", what);
+    if (!said || FFHIP_ENV("FFHIP_VERBOSE")) fprintf(stderr, "ffpic_hip: %s failed; block left untouched\n", what);
     said = 1;
 }
 

@@ -1003,8 +1003,8 @@ extern "C" int ffhip_hevc_residual_batch(int nTbS, long long n_tu, const int16_t
     if (!ffhip_have_device()) return FFHIP_ENODEV;
     HevcResArgs a = {d_level, d_tuinfo, d_scaling, d_residual, n_tu, bitdepth, epp ? 1 : 0, 1};
     /* the 32x32 TUs take the matrix-core kernel (two TUs per wave); FFHIP_HEVC_RES32=dot keeps them on the butterflies */
-    const char *e32 = getenv("FFHIP_HEVC_RES32"), *e16 = getenv("FFHIP_HEVC_RES16"), *e8 = getenv("FFHIP_HEVC_RES8"),
-               *e4 = getenv("FFHIP_HEVC_RES4"), *eit = getenv("FFHIP_HEVC_RES_ITERS");
+    const char *e32 = FFHIP_ENV("FFHIP_HEVC_RES32"), *e16 = FFHIP_ENV("FFHIP_HEVC_RES16"), *e8 = FFHIP_ENV("FFHIP_HEVC_RES8"),
+               *e4 = FFHIP_ENV("FFHIP_HEVC_RES4"), *eit = FFHIP_ENV("FFHIP_HEVC_RES_ITERS");
     const bool mfma8 = !(e8 && !strcmp(e8, "dot"));
     const bool mfma16 = !(e16 && !strcmp(e16, "dot"));
     const bool mfma32 = !(e32 && !strcmp(e32, "dot"));

@@ -57,7 +57,7 @@ struct HevcIntraArgs {
     int n_groups;
     int debug_withhold;       /* test hook (FFHIP_DEBUG_WITHHOLD_TU): this TU's done flag is never published; -1 = off */
     /* device-planned launches: the planner's verdict is read by the kernel, not by the host */
-    const uint32_t *plan_result; /* {refused, number of groups, wait entries}; NULL: n_groups above is the truth */
+    const uint32_t *plan_result; /* {refused, number of groups, wait entries, -, widest wavefront}; NULL: n_groups above is the truth */
     uint32_t wait_cap;           /* wait entries the planner had room for                                        */
     long long n_tus;             /* for the serial path a refused plan takes                                     */
     /* substitution table (k_hevc_intra_jtable): per TU and scan position the scan position its sample comes from */
@@ -1121,6 +1121,13 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
         const uint32_t refused = a.plan_result[0] | (a.plan_result[2] > a.wait_cap ? 1u : 0u);
         n_groups = (int)a.plan_result[1];
         if (__builtin_amdgcn_readfirstlane((int)refused)) return;
+        /* The launch holds as many waves as the device can keep resident; how many of them can be AT WORK at once is the
+         * width of the list's dependency wavefront, which only the planner knows (a single 8K picture: ~200 groups; a grid
+         * of 135 independent tiles: more than the chip holds).  The waves beyond 5/4 of that leave now: a wave that holds
+         * a ticket far from its turn only polls, through the same memory path the working waves use (one 8K picture on
+         * 1024 waves: 6.5 ms, on 256: 5.9). */
+        const uint32_t width = a.plan_result[4];
+        if (width && blockIdx.x >= (width + (width >> 2) + 16 > 256u ? width + (width >> 2) + 16 : 256u)) return;
     }
     const __amdgpu_buffer_rsrc_t desc_rs = ffhip_rsrc(a.desc, 0xffffffffu), res_rs = ffhip_rsrc((const void *)hot.residual, PROG_NO_RESIDUAL);
     const int cell_lane4 = 2 * ((lane >> 2) * TILE_STRIDE + (lane & 3)), cell_lane8 = 2 * ((lane >> 3) * TILE_STRIDE + (lane & 7));
@@ -1472,7 +1479,7 @@ static bool plan_groups(const ffhip_hevc_tu *tus, long long n_tus, const int pw[
     /* the scratch vectors are thread_local: worker threads must go through pointers taken here */
     Meta *const mp = meta.data();
     const int32_t *const ownp[3] = {owner[0].data(), owner[1].data(), owner[2].data()};
-    const char *pt = getenv("FFHIP_PLAN_THREADS");
+    const char *pt = FFHIP_ENV("FFHIP_PLAN_THREADS");
     /* one thread unless asked: on the 16-core share of an MI355X box 2-8 threads were no faster
      * (2.5-5.0 ms against 2.7 ms for this pass on 172k TUs: thread start-up and the shared maps eat the gain) */
     const int n_threads = pt ? std::max(1, std::min(16, atoi(pt))) : 1;
@@ -1559,7 +1566,7 @@ static bool plan_groups(const ffhip_hevc_tu *tus, long long n_tus, const int pw[
     const size_t ng = gcount.size();
     order.resize(ng);
     for (size_t g = 0; g < ng; g++) order[g] = (uint32_t)g;
-    if (contiguous && !getenv("FFHIP_HEVC_INTRA_DECODE_ORDER"))
+    if (contiguous && !FFHIP_ENV("FFHIP_HEVC_INTRA_DECODE_ORDER"))
         std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return gdepth[x] < gdepth[y]; });
     gbase.resize(ng);
     out.groups.resize(ng);
@@ -1597,7 +1604,7 @@ static bool plan_groups(const ffhip_hevc_tu *tus, long long n_tus, const int pw[
         emit(0);
         for (auto &th : pool) th.join();
     }
-    if (getenv("FFHIP_PLAN_TIMES")) {
+    if (FFHIP_ENV("FFHIP_PLAN_TIMES")) {
         const auto T4 = std::chrono::steady_clock::now();
         auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
         fprintf(stderr, "plan: setup+pass1 %ld us, pass2 %ld us, pass3 %ld us, order+emit %ld us (threads %d)\n", us(T0, T1), us(T1, T2), us(T2, T3), us(T3, T4), n_threads);
@@ -1734,12 +1741,12 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
     a.stride[0] = y_stride; a.stride[1] = uv_stride; a.stride[2] = uv_stride;
     a.bitdepth_y = bitdepth_y; a.bitdepth_c = bitdepth_c;
     {   /* drives the bounded-spin give-up path in tests: the waiters of that TU run into SPIN_LIMIT and report FFHIP_EIO */
-        const char *dw = getenv("FFHIP_DEBUG_WITHHOLD_TU");
+        const char *dw = FFHIP_ENV("FFHIP_DEBUG_WITHHOLD_TU");
         a.debug_withhold = dw ? atoi(dw) : -1;
     }
 
     /* grouped single-launch form unless FFHIP_HEVC_INTRA_MODE=levels (diagnostics) or no window works */
-    const char *mode_env = getenv("FFHIP_HEVC_INTRA_MODE");
+    const char *mode_env = FFHIP_ENV("FFHIP_HEVC_INTRA_MODE");
     const bool want_groups = !(mode_env && !strcmp(mode_env, "levels"));
     int *async_err = want_groups ? ffhip_async_err_word() : nullptr;
     const bool offsets_fit = (long long)y_stride * height_y < (1LL << 30) && (long long)uv_stride * (height_c > 0 ? height_c : 1) < (1LL << 30);
@@ -1780,13 +1787,30 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
         hipLaunchKernelGGL(k_hevc_intra_jtable, dim3((unsigned)((n_tus + 3) / 4)), dim3(256), 0, st, ja);
     };
     if (want_groups && async_err && offsets_fit && jt_blocks * JT_STRIDE < (1ull << 32) && desc_px < (1ull << 29) /* 32-bit byte offsets into a plane, the table and the pixel words */) {
-        const char *we = getenv("FFHIP_HEVC_INTRA_WINDOW");
-        const char *wv = getenv("FFHIP_HEVC_INTRA_WAVES");
+        const char *we = FFHIP_ENV("FFHIP_HEVC_INTRA_WINDOW");
+        const char *wv = FFHIP_ENV("FFHIP_HEVC_INTRA_WAVES");
+        /* device-planned launches start as many waves as can be resident and trim themselves to the planner's wavefront width
+         * (k_hevc_intra_groups); host-planned ones keep the flat cap */
         const size_t max_waves = wv ? (size_t)std::max(1, atoi(wv)) : FFHIP_HEVC_INTRA_WAVES;
+        const size_t resident_waves = wv ? max_waves : (size_t)std::max(FFHIP_HEVC_INTRA_WAVES, ffhip_resident_waves((const void *)k_hevc_intra_groups, 0));
         /* the schedule: built on the device (ffhip_hevc_plan_gpu.hip) unless FFHIP_HEVC_PLAN=host; lists whose groups are
          * not contiguous runs of the decode order come back from there and take the host planner with its window search */
-        const char *pe = getenv("FFHIP_HEVC_PLAN");
-        if (!(pe && !strcmp(pe, "host"))) {
+        const char *pe = FFHIP_ENV("FFHIP_HEVC_PLAN");
+        /* a list whose groups are not contiguous runs of the decode order even at the smallest window would be refused by the device
+         * planner and decoded by ONE wave (k_hevc_intra_serial: exact, seconds for an 8K list): such a list takes the host planner
+         * with its window search -- or the levels form -- right away; the serial kernel stays for what only the device can find
+         * (more than 64 TUs to wait for, an order its ticket rule cannot serve) */
+        int dev_wl = we ? atoi(we) : 6;
+        dev_wl = dev_wl < 3 ? 3 : (dev_wl > 6 ? 6 : dev_wl);
+        const int dev_cs = (pw[1] > 0 && pw[1] * 2 <= pw[0] + 1) ? 1 : 0;
+        bool dev_ok = false;
+        for (; dev_wl >= 3 && !dev_ok; dev_wl--) {
+            const int win[3] = {dev_wl, dev_wl - dev_cs, dev_wl - dev_cs};
+            dev_ok = groups_contiguous(h_tus, n_tus, pw, ph, win);
+        }
+        dev_wl++;
+        if (pe && !strcmp(pe, "device")) dev_ok = true; /* tests: force the device planner (and with it the serial path of a list it refuses) */
+        if (!(pe && !strcmp(pe, "host")) && dev_ok) {
             /* NOTHING below waits for the device: the schedule is enqueued, the grouped kernel is enqueued behind it and
              * reads the planner's verdict itself (a refused list takes its serial path).  The window is chosen here, on
              * the host, from the list alone: the largest one (up to the requested) whose groups are contiguous runs of
@@ -1797,13 +1821,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
              * TUs running as per-pixel programs the longer serial walk through a 64x64 block costs less than that
              * (8K random quadtree: 14.8 ms against 17.3 with 32x32; the config-5 mix 8.1 against 12.0; 1080p and smaller
              * pictures are indifferent -- tests/tools/bench_intra_c5.py, bench_intra_sizes.py) */
-            int wl = we ? atoi(we) : 6;
-            wl = wl < 3 ? 3 : (wl > 6 ? 6 : wl);
-            const int cs = (pw[1] > 0 && pw[1] * 2 <= pw[0] + 1) ? 1 : 0;
-            for (; wl > 3; wl--) {
-                const int win[3] = {wl, wl - cs, wl - cs};
-                if (groups_contiguous(h_tus, n_tus, pw, ph, win)) break;
-            }
+            const int wl = dev_wl, cs = dev_cs;
             const int win[3] = {wl, wl - cs, wl - cs};
             const size_t w_plan = ffhip_hevc_plan_gpu_words(n_tus, pwc, ph, win), w_ctrl = 4 + (size_t)n_tus;
             uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, w_plan + w_ctrl + 16 + w_jt + w_desc);
@@ -1822,7 +1840,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
 #ifdef FFHIP_INTRA_TRACE
             a.trace = g_intra_trace;
 #endif
-            hipLaunchKernelGGL(k_hevc_intra_groups, dim3((unsigned)std::min<size_t>((size_t)n_tus, max_waves)), dim3(64), 0, st, a);
+            hipLaunchKernelGGL(k_hevc_intra_groups, dim3((unsigned)std::min<size_t>((size_t)n_tus, resident_waves)), dim3(64), 0, st, a);
             hipLaunchKernelGGL(k_hevc_intra_serial, dim3(1), dim3(64), 0, st, a); /* does something only for a list the planner refused */
             FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
             return FFHIP_OK;

@@ -38,7 +38,9 @@ struct PlanArgs {
     uint32_t *gstart;      /* TU index where run r starts; [n_runs] = n             */
     uint32_t *wait_idx;
     u32x4 *sched, *groups;
-    uint32_t *result;      /* [0] fail, [1] number of runs, [2] wait entries        */
+    uint32_t *result;      /* [0] fail, [1] number of runs, [2] wait entries, [3] no wavefront keys, [4] the widest wavefront:
+                              the largest number of runs that share a dependency depth */
+    uint32_t *depth_hist;  /* runs per wavefront index (cells of depth d: at most one run each and plane) */
     uint32_t wait_cap;     /* words reserved for wait_idx                           */
     uint32_t *cell_claim;  /* per 64x64-luma cell and plane: TU that opened it, ~0 = none (is the CTB 64?) */
     uint32_t *cell_edges;  /* bit 0 left, 1 above, 2 above-left, 3 above-right: cells this cell's TUs read */
@@ -132,7 +134,11 @@ __global__ __launch_bounds__(256) void k_plan_keys(PlanArgs a)
     if (r < a.result[1]) {
         const ffhip_hevc_tu t = a.tus[a.gstart[r]];
         const uint32_t cx = (uint32_t)(t.x >> a.cshift[t.cidx]), cy = (uint32_t)(t.y >> a.cshift[t.cidx]);
-        key = ((unsigned long long)(a.result[3] ? 0u : a.cell_depth[a.cell_off[t.cidx] + cy * a.cgw[t.cidx] + cx]) << 32) | r;
+        const uint32_t depth = a.result[3] ? 0u : a.cell_depth[a.cell_off[t.cidx] + cy * a.cgw[t.cidx] + cx];
+        key = ((unsigned long long)depth << 32) | r;
+        /* how many runs can be at work at once: the grouped kernel keeps only about that many of its waves (the others would
+         * hold tickets far from their turn and poll).  Without wavefront keys (decode order) nothing is known: result[4] stays 0 */
+        if (!a.result[3]) atomicMax(a.result + 4, atomicAdd(a.depth_hist + (depth < a.n_cells ? depth : a.n_cells), 1u) + 1u);
     }
     a.keys_in[r] = key;
     a.vals_in[r] = r;
@@ -282,7 +288,7 @@ extern "C" size_t ffhip_hevc_plan_gpu_words(long long n_tus, const int pw[3], co
         if (pw[c] > 0) cells += (size_t)(((pw[c] - 1) >> 4) + 1) * (size_t)(((ph[c] - 1) >> 4) + 1); /* generous: cells of >= 16 samples */
     /* sched 12n | groups 4(n+1) | wait 66... bounded by 33n in theory: sized by 8n + the fallback check | owner | win | start | startx | runid |
      * wcount | wbegin | flags | gstart | result | scan temp */
-    return 12 * n + 4 * (n + 1) + 8 * n + blocks + wins + 6 * n + (n + 3) / 4 + 4 + (n + 2) + 16 + (scan_tmp + 3) / 4 + 128 + 3 * cells + 3 * n + 4 * n + 8;
+    return 12 * n + 4 * (n + 1) + 8 * n + blocks + wins + 6 * n + (n + 3) / 4 + 4 + (n + 2) + 16 + (scan_tmp + 3) / 4 + 128 + 4 * cells + 1 + 3 * n + 4 * n + 8;
 }
 
 /* Returns 0 when the plan is in place (n_groups, n_wait filled), 1 when the list needs the host planner.
@@ -340,6 +346,7 @@ extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, 
     a.cell_claim = p; p += cells;
     a.cell_edges = p; p += cells;
     a.cell_depth = p; p += cells;
+    a.depth_hist = p; p += cells + 1;
     a.n_cells = (uint32_t)cells;
     for (int c = 0; c < 3; c++) a.cgh[c] = pw[c] > 0 ? (uint32_t)(((ph[c] - 1) >> a.cshift[c]) + 1) : 0;
     a.vals_in = p; p += n;
@@ -353,7 +360,7 @@ extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, 
     FFHIP_CHECK(hipMemsetAsync(a.owner, 0xff, (blocks + wins) * 4, st), FFHIP_EIO);
     FFHIP_CHECK(hipMemsetAsync(a.flags, 0, ((n + 3) / 4 + 4 + 16) * 4, st), FFHIP_EIO);
     FFHIP_CHECK(hipMemsetAsync(a.cell_claim, 0xff, cells * 4, st), FFHIP_EIO);
-    FFHIP_CHECK(hipMemsetAsync(a.cell_edges, 0, 2 * cells * 4, st), FFHIP_EIO);
+    FFHIP_CHECK(hipMemsetAsync(a.cell_edges, 0, (3 * cells + 1) * 4, st), FFHIP_EIO); /* edges, depths, histogram */
     const unsigned grid = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_plan_owner, dim3(grid), dim3(256), 0, st, a);
     if (hipcub::DeviceScan::ExclusiveSum(tmp, scan_tmp, a.start, start_excl, (int)n, st) != hipSuccess) return FFHIP_EIO;

@@ -339,7 +339,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     if (geom->mcu_cols <= 0 || geom->mcu_rows <= 0 || geom->h < 1 || geom->v < 1 || geom->h * geom->v > 4 ||
         (geom->ncomp != 1 && geom->ncomp != 3)) return FFHIP_EINVAL;
     const size_t mcus = (size_t)geom->mcu_cols * geom->mcu_rows;
-    const bool times = getenv("FFHIP_HUFF_TIMES") != nullptr; /* host phases on stderr */
+    const bool times = FFHIP_ENV("FFHIP_HUFF_TIMES") != nullptr; /* host phases on stderr */
     const auto T0 = std::chrono::steady_clock::now();
     /* ---- host, pictures over threads: headers, tables, restart-interval starts ---- */
     std::vector<struct jpeg_hdr> hdr((size_t)n);

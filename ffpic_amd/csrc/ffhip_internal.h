@@ -24,8 +24,21 @@ int ffhip_have_device(void); /* 1 once ffhip_init succeeded on a gfx950 device *
 uint32_t *ffhip_scratch(int kind, void *stream, size_t words);
 uint8_t *ffhip_pinned_scratch(int kind, void *stream, size_t bytes); /* per (kind, stream) pinned host staging, NULL on failure */ /* per (kind, stream) device scratch, NULL on failure */
 int *ffhip_async_err_word(void); /* pinned word kernels report an in-launch abort through; see ffhip_stream_sync */
+/* The FFHIP_* switches (A/B knobs of the tools, diagnostics) are read from the environment ONCE per process, at a call
+ * site's first use, and kept; ffhip_reload_env() (public, include/ffpic_hip.h) makes every site read its switch again. */
+struct ffhip_env_site { const char *name; int gen; int set; char val[56]; };
+const char *ffhip_env_lookup(struct ffhip_env_site *site); /* NULL when unset */
+int ffhip_resident_waves(const void *kernel, int lds_bytes); /* single-wave workgroups of `kernel` the device holds at once (occupancy x CUs), cached */
 #ifdef __cplusplus
 }
+#endif
+
+/* codes a dependency-scheduled kernel leaves in the async error word: 1-3 a bounded wait ran out (FFHIP_EIO), 4 the kernel
+ * met input it refuses, e.g. a mode byte no VP8 stream can hold (FFHIP_EINVAL) */
+#define FFHIP_ASYNC_BAD_INPUT 4
+
+#ifdef __cplusplus
+#define FFHIP_ENV(NAME) ([]() -> const char * { static struct ffhip_env_site site = {NAME, -1, 0, {0}}; return ffhip_env_lookup(&site); }())
 #endif
 
 typedef unsigned int u32;

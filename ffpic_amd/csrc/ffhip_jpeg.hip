@@ -801,26 +801,18 @@ static int geom_ok(const ffhip_jpeg_geom *g)
 /* A/B knobs; identical bytes either way.  FFHIP_JPEG_XCD_CHUNK_LOG2=k (2..20): the XCDs take chunks of 2^k workgroups in turn */
 static int jpeg_remap_mode(void)
 {
-    if (getenv("FFHIP_JPEG_NO_XCD_REMAP")) return 0;
-    const char *e = getenv("FFHIP_JPEG_XCD_CHUNK_LOG2");
+    if (FFHIP_ENV("FFHIP_JPEG_NO_XCD_REMAP")) return 0;
+    const char *e = FFHIP_ENV("FFHIP_JPEG_XCD_CHUNK_LOG2");
     if (e) { const int k = atoi(e); if (k >= 2 && k <= 20) return k; }
     return 1;
 }
-static int g_variant = -1;
 static void launch_fused(const JpegBatch &q_in, int n_images, hipStream_t st)
 {
-    static int dynamic = -1; /* FFHIP_JPEG_VARIANT_DYNAMIC: re-read the knob at every launch (diagnostics switch variants inside one process) */
-    if (dynamic < 0) dynamic = getenv("FFHIP_JPEG_VARIANT_DYNAMIC") ? 1 : 0;
-    if (g_variant < 0 || dynamic) {
-        const char *e = getenv("FFHIP_JPEG_VARIANT");
-        g_variant = (e && e[0] >= '1' && e[0] <= '2' && e[1] >= '0' && e[1] <= '3') ? (e[0] - '0') * 10 + (e[1] - '0')
-                                                                                 : FFHIP_JPEG_DEFAULT_VARIANT;
-    }
+    const char *e = FFHIP_ENV("FFHIP_JPEG_VARIANT");
+    const int g_variant = (e && e[0] >= '1' && e[0] <= '2' && e[1] >= '0' && e[1] <= '3') ? (e[0] - '0') * 10 + (e[1] - '0') : FFHIP_JPEG_DEFAULT_VARIANT;
     const int qpw = g_variant / 10;
     JpegBatch q = q_in;
-    static int remap = -1;
-    if (remap < 0) remap = jpeg_remap_mode();
-    q.xcd_remap = remap;
+    q.xcd_remap = jpeg_remap_mode();
     const int slots = (q.quads_per_image + qpw - 1) / qpw;
     q.wgs_per_image = (slots + WAVES_PER_WG - 1) / WAVES_PER_WG;
     q.wpi_magic = q.wgs_per_image == 1 ? 0xffffffffu : (u32)(0x100000000ULL / (unsigned)q.wgs_per_image) + 1u;
@@ -851,9 +843,7 @@ static int is_fused_strip(const ffhip_jpeg_geom *g)
 static void launch_strip(const ffhip_jpeg_geom *g, const JpegBatch &q_in, int n_images, hipStream_t st)
 {
     JpegBatch q = q_in;
-    static int remap = -1;
-    if (remap < 0) remap = jpeg_remap_mode();
-    q.xcd_remap = remap;
+    q.xcd_remap = jpeg_remap_mode();
     q.wgs_per_image = (q.quads_per_image + WAVES_PER_WG - 1) / WAVES_PER_WG;
     q.wpi_magic = q.wgs_per_image == 1 ? 0xffffffffu : (u32)(0x100000000ULL / (unsigned)q.wgs_per_image) + 1u;
     const dim3 grid((unsigned)((long long)q.wgs_per_image * n_images), 1, 1);

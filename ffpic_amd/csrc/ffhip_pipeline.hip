@@ -134,7 +134,7 @@ extern "C" int ffhip_jpeg_decode_files(const uint8_t *const *files, const size_t
     if (!ffhip_have_device()) return FFHIP_ENODEV;
     /* restart markers in the first file: try the device-side entropy decoder (FFHIP_JPEG_GPU_ENTROPY=0 keeps it off).
      * Its latency per batch is that of ONE restart interval, so it wants large chunks */
-    const char *ge = getenv("FFHIP_JPEG_GPU_ENTROPY");
+    const char *ge = FFHIP_ENV("FFHIP_JPEG_GPU_ENTROPY");
     bool gpu_entropy = !(ge && ge[0] == '0');
     if (gpu_entropy && !(ge && ge[0] == '1')) /* "1" forces it; default: restart markers, or enough files to give every lane one */
         gpu_entropy = ffhip_jpeg_probe_restart(files[0], lens[0]) > 0 || n >= 1024;
@@ -237,7 +237,7 @@ extern "C" int ffhip_jpeg_decode_files_device(const uint8_t *const *files, const
     int16_t *dy = (int16_t *)base, *du = cb ? dy + (size_t)n * yb : nullptr, *dv = cb ? du + (size_t)n * cb : nullptr;
     uint16_t *dq = (uint16_t *)(base + (((size_t)n * (yb + 2 * cb) * 2 + 15) & ~(size_t)15));
     hipStream_t st = (hipStream_t)stream;
-    const char *ge = getenv("FFHIP_JPEG_GPU_ENTROPY");
+    const char *ge = FFHIP_ENV("FFHIP_JPEG_GPU_ENTROPY");
     bool on_device = false;
     if (!(ge && ge[0] == '0') && ((ge && ge[0] == '1') || ffhip_jpeg_probe_restart(files[0], lens[0]) > 0 || n >= 1024)) {
         rc = ffhip_jpeg_entropy_batch_gpu(files, lens, n, n_threads, &g, dy, du, dv, dq, status, stream);

@@ -13,10 +13,50 @@ static int g_ready = 0;
 static char g_arch[64] = "";
 static char g_last_error[256] = "";
 
+/* FFHIP_* switches: read once per call site and process, re-read after ffhip_reload_env() */
+#include <atomic>
+#include <map>
+#include <mutex>
+static std::atomic<int> g_env_gen{0};
+static std::mutex g_env_mu;
+extern "C" const char *ffhip_env_lookup(struct ffhip_env_site *site)
+{
+    const int gen = g_env_gen.load(std::memory_order_acquire);
+    if (site->gen != gen) {
+        std::lock_guard<std::mutex> lock(g_env_mu);
+        const char *v = getenv(site->name);
+        site->set = v != nullptr;
+        if (v) { strncpy(site->val, v, sizeof site->val - 1); site->val[sizeof site->val - 1] = 0; }
+        site->gen = gen;
+    }
+    return site->set ? site->val : nullptr;
+}
+extern "C" void ffhip_reload_env(void) { g_env_gen.fetch_add(1, std::memory_order_acq_rel); }
+
 extern "C" void ffhip_note_hip_error(int hip_error, const char *what)
 {
     snprintf(g_last_error, sizeof g_last_error, "%s: %s", what, hipGetErrorString((hipError_t)hip_error));
-    if (getenv("FFHIP_VERBOSE")) fprintf(stderr, "ffpic_hip: %s\n", g_last_error);
+    if (FFHIP_ENV("FFHIP_VERBOSE")) fprintf(stderr, "ffpic_hip: %s\n", g_last_error);
+}
+
+/* How many single-wave workgroups of `kernel` the device holds at once: what a kernel whose waves WAIT for each other
+ * (tickets + progress counters) may launch without a wave holding a ticket it cannot run yet -- and, for two such
+ * kernels side by side, what lets both be resident whatever the hardware starts first. */
+static std::map<std::pair<const void *, int>, int> g_resident;
+extern "C" int ffhip_resident_waves(const void *kernel, int lds_bytes)
+{
+    std::lock_guard<std::mutex> lock(g_env_mu);
+    auto it = g_resident.find(std::make_pair(kernel, lds_bytes));
+    if (it != g_resident.end()) return it->second;
+    int per_cu = 0, cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, (size_t)lds_bytes) != hipSuccess || per_cu < 1 || cus < 1) {
+        (void)hipGetLastError();
+        return 256; /* one wave per CU of the smallest part: always resident */
+    }
+    const int n = per_cu * cus;
+    g_resident[std::make_pair(kernel, lds_bytes)] = n;
+    return n;
 }
 
 extern "C" int ffhip_have_device(void)
@@ -54,6 +94,7 @@ extern "C" int ffhip_init(int device)
 
 extern "C" void ffhip_release_caches(void); /* below: scratch kept per (stage, stream) */
 extern "C" void ffhip_pipeline_release(void); /* ffhip_pipeline.hip: its two slots of pinned + device buffers */
+extern "C" void ffhip_vp8_release_side_streams(void); /* ffhip_vp8_lf.hip: the side stream + events of ffhip_vp8_predict_loopfilter */
 /* Nothing of the library's may be in flight.  Frees what the library keeps between calls (device scratch, pinned
  * staging, the pipeline's buffers); the next compute call binds the device again. */
 extern "C" void ffhip_shutdown(void)
@@ -61,6 +102,7 @@ extern "C" void ffhip_shutdown(void)
     if (g_ready) {
         (void)hipDeviceSynchronize();
         ffhip_pipeline_release();
+        ffhip_vp8_release_side_streams();
         ffhip_release_caches();
     }
     g_ready = 0;
@@ -85,8 +127,6 @@ extern "C" const char *ffhip_arch_name(void) { return g_arch; }
  * the same stream may reuse its buffer call after call without waiting, and calls on different
  * streams (or threads) never share one.  Growing waits for the stream first: the old buffer may
  * still be read by what that stream has queued. */
-#include <map>
-#include <mutex>
 #include <utility>
 struct ScratchEntry { uint32_t *dev; size_t words; };
 static std::map<std::pair<int, void *>, ScratchEntry> g_scratch;
@@ -190,9 +230,11 @@ extern "C" int ffhip_stream_sync(void *s)
 {
     FFHIP_CHECK(hipStreamSynchronize((hipStream_t)s), FFHIP_EIO);
     if (g_async_err && *(volatile int *)g_async_err) {
-        snprintf(g_last_error, sizeof g_last_error, "a dependency-scheduled kernel aborted (code %d)", *(volatile int *)g_async_err);
+        const int code = *(volatile int *)g_async_err;
+        snprintf(g_last_error, sizeof g_last_error, code == FFHIP_ASYNC_BAD_INPUT ? "a dependency-scheduled kernel refused its input (code %d)"
+                                                                                   : "a dependency-scheduled kernel aborted (code %d)", code);
         *(volatile int *)g_async_err = 0;
-        return FFHIP_EIO;
+        return code == FFHIP_ASYNC_BAD_INPUT ? FFHIP_EINVAL : FFHIP_EIO;
     }
     return FFHIP_OK;
 }

@@ -59,7 +59,7 @@ void load_rccl()
     /* a copy that is already mapped (matched by its soname) first: two RCCLs in one process would each open the devices */
     for (const char *n : names)
         if (!g_rccl.lib) g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-    if (const char *forced = getenv("FFHIP_RCCL_LIB")) {
+    if (const char *forced = FFHIP_ENV("FFHIP_RCCL_LIB")) {
         if (!g_rccl.lib) g_rccl.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
     }
     for (const char *n : names)

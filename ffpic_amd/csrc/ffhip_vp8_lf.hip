@@ -19,6 +19,7 @@
 #include "ffhip_internal.h"
 
 #include <algorithm>
+#include <mutex>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -511,7 +512,7 @@ extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int fi
     if (!ffhip_have_device()) return FFHIP_ENODEV;
     hipStream_t st = (hipStream_t)stream;
     /* row form (default): one launch, no host-side scheduling */
-    const char *mode_env = getenv("FFHIP_VP8_LF_MODE");
+    const char *mode_env = FFHIP_ENV("FFHIP_VP8_LF_MODE");
     int *async_err = (mode_env && !strcmp(mode_env, "levels")) ? nullptr : ffhip_async_err_word();
     if (async_err && !((uintptr_t)d_modes & 3) && !(((uintptr_t)d_y | (uintptr_t)d_u | (uintptr_t)d_v | (uintptr_t)plane_stride_y | (uintptr_t)plane_stride_uv) & 3) &&
         n_mb < (1LL << 23)) {
@@ -531,10 +532,14 @@ extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int fi
         a.plane_y = plane_stride_y; a.plane_uv = plane_stride_uv;
         a.mbcols = mbcols; a.mbrows = mbrows; a.filter_type = filter_type;
         a.ctrl = g_work; a.async_err = async_err; a.n_images = n_images;
-        const char *wv = getenv("FFHIP_VP8_LF_WAVES");
-        /* sixteen rows in flight per image cover its wavefront; a wave beyond that holds a ticket far from its turn and only polls
-         * (16 x 1080p: 2048 waves 5.62 / 2.10 ms, 256 waves 5.48 / 1.96 -- tests/tools/bench_stages.py) */
-        const long long cap = wv ? std::max(1, atoi(wv)) : std::min<long long>(2048, std::max<long long>(256, 16LL * n_images));
+        /* as many waves as can be resident, at most a wavefront's width of rows per image (ffhip_vp8_predict_recon has the
+         * reasoning); next to the prediction kernel of the same call each of the two takes half of its own residency, so
+         * filter waves -- which wait for the prediction's counters -- can never keep the prediction from becoming resident */
+        const char *wv = FFHIP_ENV("FFHIP_VP8_LF_WAVES");
+        long long resident = ffhip_resident_waves(filter_type == 1 ? (const void *)k_vp8_loopfilter_rows<1> : (const void *)k_vp8_loopfilter_rows<2>, 0);
+        if (pred_progress) resident = std::max<long long>(1, resident / 2);
+        const long long wide = std::max<long long>(256, (long long)n_images * (mbcols / 4 + 2));
+        const long long cap = wv ? std::max(1, atoi(wv)) : std::min(resident, wide);
         const dim3 grid((unsigned)std::min<long long>((long long)n_images * mbrows, cap));
         if (filter_type == 1) hipLaunchKernelGGL(k_vp8_loopfilter_rows<1>, grid, dim3(64), 0, st, a);
         else hipLaunchKernelGGL(k_vp8_loopfilter_rows<2>, grid, dim3(64), 0, st, a);
@@ -609,6 +614,54 @@ extern "C" int ffhip_vp8_filter_params(const ffhip_vp8_filter_header *h, uint8_t
     return FFHIP_OK;
 }
 
+/* The side stream and the two events of ffhip_vp8_predict_loopfilter: one set per calling thread and device, made on first
+ * use, recreated when the thread's current device has changed, released by ffhip_shutdown (ffhip_vp8_release_side_streams)
+ * or when the thread ends. */
+namespace {
+struct SideStream { int device = -1; hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+std::mutex g_side_mu;
+std::vector<SideStream *> g_sides;
+void side_release(SideStream *s)
+{
+    if (s->side) (void)hipStreamDestroy(s->side);
+    if (s->fork) (void)hipEventDestroy(s->fork);
+    if (s->join) (void)hipEventDestroy(s->join);
+    s->side = nullptr; s->fork = s->join = nullptr; s->device = -1;
+}
+struct SideHolder {
+    SideStream s;
+    SideHolder() { std::lock_guard<std::mutex> l(g_side_mu); g_sides.push_back(&s); }
+    ~SideHolder()
+    {
+        std::lock_guard<std::mutex> l(g_side_mu);
+        g_sides.erase(std::remove(g_sides.begin(), g_sides.end(), &s), g_sides.end());
+        side_release(&s);
+    }
+};
+SideStream *side_stream_for_this_thread()
+{
+    static thread_local SideHolder h;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> l(g_side_mu);
+    if (h.s.side && h.s.device != dev) side_release(&h.s);
+    if (!h.s.side) {
+        if (hipStreamCreateWithFlags(&h.s.side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h.s.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h.s.join, hipEventDisableTiming) != hipSuccess) {
+            side_release(&h.s);
+            return nullptr;
+        }
+        h.s.device = dev;
+    }
+    return &h.s;
+}
+} // namespace
+extern "C" void ffhip_vp8_release_side_streams(void) /* ffhip_shutdown: nothing of the library's is in flight */
+{
+    std::lock_guard<std::mutex> l(g_side_mu);
+    for (SideStream *s : g_sides) side_release(s);
+}
+
 /* Prediction + reconstruction and the loop filter of a batch of key frames as ONE call: both row kernels are enqueued
  * side by side (the filter on a stream of the library's own, forked behind the prediction's counter reset and joined back
  * into `stream`), the filter's rows following the prediction's through its per-row counters.  Same arguments and the same
@@ -623,14 +676,14 @@ extern "C" int ffhip_vp8_predict_loopfilter(int mbcols, int mbrows, int n_images
 {
     if (filter_type < 0 || filter_type > 2) return FFHIP_EINVAL;
     if (filter_type != 0 && !d_filters) return FFHIP_EINVAL;
-    static thread_local hipStream_t side = nullptr;
-    static thread_local hipEvent_t fork_ev = nullptr, join_ev = nullptr;
-    const char *off = getenv("FFHIP_VP8_FUSE"); /* =0: one after the other on `stream` (A/B knob) */
+    const char *off = FFHIP_ENV("FFHIP_VP8_FUSE"); /* =0: one after the other on `stream` (A/B knob) */
     const bool fuse = filter_type != 0 && n_images > 0 && !(off && off[0] == '0') && ffhip_have_device();
-    if (fuse && !side) {
-        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&join_ev, hipEventDisableTiming) != hipSuccess)
-            return FFHIP_EIO;
+    hipStream_t side = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    if (fuse) {
+        SideStream *ss = side_stream_for_this_thread();
+        if (!ss) return FFHIP_EIO;
+        side = ss->side; fork_ev = ss->fork; join_ev = ss->join;
     }
     g_ffhip_vp8_fusion.active = fuse ? 1 : 0;
     g_ffhip_vp8_fusion.pred_progress = nullptr;

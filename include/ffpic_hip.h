@@ -46,6 +46,9 @@ int ffhip_init(int device);
 void ffhip_shutdown(void); /* with nothing in flight: frees the scratch, staging and pipeline buffers the library keeps
                               between calls; a later compute call binds the device again */
 const char *ffhip_strerror(int code);
+/* The FFHIP_* environment switches (A/B knobs of tests/tools, diagnostics; none is needed in production) are read ONCE per
+ * process, at first use.  A host that changes one in a live process calls this to have them read again. */
+void ffhip_reload_env(void);
 /* "gfx950" etc. of the bound device, "" if none. */
 const char *ffhip_arch_name(void);
 
@@ -311,7 +314,10 @@ int ffhip_hevc_residual_batch(int nTbS, long long n_tu, const int16_t *d_level, 
  *   h_modes / d_modes  the SAME uint8 [n_images][mbrows*mbcols][20] records on the host (used
  *                      to schedule the dependency wavefronts) and on the device:
  *                      [0] intra_y_mode (0 DC, 1 TM, 2 V, 3 H, 4 B_PRED), [1] intra_uv_mode,
- *                      [2..17] imodes[16] (4x4 modes 0..9), [18..19] 0  (format/webp.h:243-256)
+ *                      [2..17] imodes[16] (4x4 modes 0..9), [18..19] 0  (format/webp.h:243-256).
+ *                      A y / uv mode out of range is FFHIP_EINVAL: from this call for batches of up
+ *                      to 2^17 macroblocks (checked on the host copy), for larger ones from the next
+ *                      ffhip_stream_sync (checked by the kernel; the planes are then unspecified)
  *   d_residual         int16 [n_images][.][384], image i at + i*residual_stride (elements)
  *   d_resmap           int32 [n_images][n_mb] residual row used by each macroblock, or NULL for
  *                      the identity; the reference keeps the PREVIOUS macroblock's coefficients
@@ -321,7 +327,8 @@ int ffhip_hevc_residual_batch(int nTbS, long long n_tu, const int16_t *d_level, 
  *                      H_PRED read raw memory at the top row / left column (predict.c:338-353):
  *                      bytes before a plane read as 0.
  * Enqueues ONE launch on `stream`: a wave per macroblock row, rows chained through progress
- * counters inside the launch; should a wave's bounded wait ever run out, the next
+ * counters inside the launch, as many waves as the device can hold at once -- the
+ * frames of a batch run side by side, so throughput grows with the batch up to a few hundred frames; should a wave's bounded wait ever run out, the next
  * ffhip_stream_sync on any stream returns FFHIP_EIO.  FFHIP_VP8_PRED_MODE=levels selects the older
  * one-launch-per-wavefront-level form.  Scratch is kept per stream: calls on different streams (or
  * host threads with their own streams) may be in flight together; calls on one stream are ordered. */

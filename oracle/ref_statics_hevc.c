@@ -392,3 +392,29 @@ void ref_hevc_sps_info(void *hps_, int *out)
     out[4] = sps->ChromaArrayType; out[5] = sps->CtbLog2SizeY;
 }
 void *ref_hevc_param_set_new(void) { return calloc(1, sizeof(struct hevc_param_set)); }
+
+/* ---- config 5's CPU baseline (bench.py `extra.c5.cpu_baseline`): ONE picture through the three post-entropy stages in C,
+ * one call per picture, every arithmetic step the reference's own code: per TU in decode order
+ * scale_transform_coefficients + transform_scaled_coeffients (ref_hevc_scale / ref_hevc_transform above), then the
+ * neighbour processing, prediction and construct_pic_pior_to_filtering of ref_hevc_intra_tu; at the end
+ * YUV420_to_BGRA32_16bit over the planes, as parse_slice_segment_layer does (hevc.c:7260-7277).
+ * tus: ffhip_hevc_tu records (32 bytes each); levels and residual share ONE layout (element offset res_offset). */
+struct ref_chain_tu { uint16_t x, y; uint8_t log2_size, cidx, pred_mode, flags; uint32_t res_offset; int32_t res_scale; uint64_t avail_top, avail_left; };
+void ref_hevc_chain_picture(const struct ref_chain_tu *tus, long n_tus, const int16_t *levels, int16_t *residual, int qP,
+                            int bitdepth, int16_t *py, int16_t *pu, int16_t *pv, int width, int height, int ctbsize,
+                            uint8_t *bgra, int pitch)
+{
+    int16_t d[32 * 32];
+    for (long i = 0; i < n_tus; i++) {
+        const struct ref_chain_tu *t = tus + i;
+        const int n = 1 << t->log2_size;
+        if (t->flags & 2) {
+            ref_hevc_scale(levels + t->res_offset, d, n, qP, bitdepth, 0, NULL, t->cidx);
+            ref_hevc_transform(d, residual + t->res_offset, n, t->cidx == 0 && n == 4, bitdepth, 0);
+        }
+        ref_hevc_intra_tu(t->x, t->y, t->log2_size, t->cidx, t->pred_mode, t->flags, t->avail_top, t->avail_left,
+                          residual + t->res_offset, t->cidx == 0 ? py : (t->cidx == 1 ? pu : pv), t->cidx == 0 ? width : width / 2,
+                          bitdepth, bitdepth, t->res_scale);
+    }
+    YUV420_to_BGRA32_16bit(bgra, pitch, py, pu, pv, width, width / 2, height / ctbsize, width / ctbsize, ctbsize);
+}

@@ -282,3 +282,21 @@ void ref_webp_filter_params(const int *hdr, int *out)
         }
     free(w);
 }
+
+/* ---- config 4's CPU baseline (bench.py `extra.c4.cpu_baseline`): ONE key frame through the four post-entropy stages in C,
+ * one call per frame, every arithmetic step the reference's own code -- per macroblock the dequantising stores, IWHT_long /
+ * IWHT_fast and get_dct_ops(16)->idct_4x4 under the control flow of vp8_decode_residual_block (ref_vp8_residual_mb above),
+ * pred_luma / pred_chrome, then the frame's loopfilter() pass and YUV420_to_BGRA32, looped like vp8_decode
+ * (webp.c:1833-1868).  levels [n_mb][25][16], info [n_mb][32] (token counts 0..24, [25] has_y2, [26] segment), quant [4][8];
+ * residual [n_mb][384] is scratch that also comes back; the planes are preceded by one readable row (predict.c:338-353). */
+void ref_vp8_chain_frame(int mbcols, int mbrows, const int16_t *levels, const uint8_t *info, const uint16_t *quant,
+                         const uint8_t *modes, int filter_type, const uint8_t *filters, int16_t *residual, uint8_t *yp,
+                         uint8_t *up, uint8_t *vp, uint8_t *bgra, int pitch)
+{
+    const long n_mb = (long)mbcols * mbrows;
+    for (long i = 0; i < n_mb; i++)
+        ref_vp8_residual_mb(levels + i * 400, info + i * 32, info[i * 32 + 25], quant + 8 * (info[i * 32 + 26] & 3), residual + i * 384);
+    ref_vp8_recon_frame(mbcols, mbrows, modes, residual, NULL, yp, up, vp);
+    if (filter_type) ref_vp8_loopfilter_frame(mbcols, mbrows, filter_type, modes, filters, yp, up, vp);
+    YUV420_to_BGRA32(bgra, pitch, yp, up, vp, 16 * mbcols, 8 * mbcols, mbrows, mbcols);
+}

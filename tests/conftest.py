@@ -35,3 +35,12 @@ def golden():
 def ffo():
     import oracle_lib
     return oracle_lib.ffo()
+
+
+@pytest.fixture(autouse=True)
+def _ffhip_switches_reread():
+    """The library reads its FFHIP_* switches once per process (ffhip_reload_env makes it read them again): a test that flips
+    one with monkeypatch.setenv calls capi.reload_env() itself; this puts the library back after monkeypatch has undone it."""
+    yield
+    from ffpic_amd import capi
+    capi.reload_env()

@@ -90,7 +90,7 @@ def test_give_up_path_reports_eio_and_the_library_recovers(monkeypatch):
     # a TU of the first coding tree block that later groups read: the last luma TU of the first 64x64 window (the default scheduling window)
     first = [i for i, t in enumerate(tus) if t["cidx"] == 0 and t["x"] < 64 and t["y"] < 64]
     victim = first[-1]
-    monkeypatch.setenv("FFHIP_DEBUG_WITHHOLD_TU", str(victim))
+    monkeypatch.setenv("FFHIP_DEBUG_WITHHOLD_TU", str(victim)); capi.reload_env()
     with pytest.raises(capi.FfhipError) as ei:
         ops.hevc_intra_recon(tus, res, w, h, True, 8, 8)           # the wrapper's stream sync sees the abort
     assert "-5" in str(ei.value)

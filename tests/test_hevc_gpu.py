@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from ffpic_amd import ops
+from ffpic_amd import capi, ops
 
 pytestmark = pytest.mark.gpu
 
@@ -105,7 +105,7 @@ def test_kernel_variants_agree(env, n, n_tu, monkeypatch):
     """Several batches per wave (with the ragged tail inside a wave's run), and the butterfly / rows kernels the
     32x32 and 4x4 sizes no longer use by default."""
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        monkeypatch.setenv(k, v); capi.reload_env()
     rng = np.random.default_rng(n + n_tu)
     lv = rng.integers(-32768, 32768, size=(n_tu, n * n)).astype(np.int16)
     lv[1::2] = np.rint(rng.laplace(0, 6, size=lv[1::2].shape)).astype(np.int16)

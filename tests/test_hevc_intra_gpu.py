@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from ffpic_amd import ops, synth
+from ffpic_amd import capi, ops, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -76,7 +76,7 @@ def test_every_mode_and_size_isolated():
 def test_schedulers_agree(env, monkeypatch):
     """the level-synchronous launches and the grouped single launch (any window) give the oracle's picture"""
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        monkeypatch.setenv(k, v); capi.reload_env()
     for (w, h, seed, adv, c444) in ((256, 192, 41, False, False), (192, 128, 42, True, False), (128, 128, 43, True, True)):
         tus, res = synth.hevc_intra_tus(w, h, seed, adversarial_masks=adv, ccp=c444, chroma_444=c444)
         csub = 1 if c444 else 2
@@ -192,10 +192,14 @@ def test_residual_blocks_at_odd_offsets(shift):
         assert np.array_equal(a, b)
 
 
-def test_list_the_device_planner_refuses_takes_the_serial_path():
+@pytest.mark.parametrize("plan", [None, "device"])
+def test_list_the_device_planner_refuses_takes_the_serial_path(monkeypatch, plan):
     """4x4 TUs of a whole picture in RASTER order (not coding-tree order): every scheduling window is entered many times,
-    so no window gives contiguous groups, the device planner refuses the list and the grouped kernel decodes it with one
-    wave in list order -- inside the same launch, nobody on the host having looked at the verdict."""
+    so no window gives contiguous groups.  By default the host sees that from the list alone and takes its own planner (or
+    the levels form); with FFHIP_HEVC_PLAN=device the list goes to the device planner all the same, which refuses it, and
+    k_hevc_intra_serial decodes it with one wave in list order -- nobody on the host having looked at the verdict."""
+    if plan:
+        monkeypatch.setenv("FFHIP_HEVC_PLAN", plan); capi.reload_env()
     rng = np.random.default_rng(12)
     w, h = 96, 48
     recs, parts, off = [], [], 0

@@ -358,9 +358,9 @@ def test_pipeline_with_device_entropy_forced_on_plain_files(monkeypatch):
     """FFHIP_JPEG_GPU_ENTROPY=1: files without restart markers through the device decoder (one lane per file), same bytes"""
     data = open(os.path.join(os.path.dirname(__file__), "golden", FILES["q85_420"]), "rb").read()
     files = [data] * 6
-    monkeypatch.setenv("FFHIP_JPEG_GPU_ENTROPY", "0")
+    monkeypatch.setenv("FFHIP_JPEG_GPU_ENTROPY", "0"); capi.reload_env()
     _, ref = ops.jpeg_decode_files(files, n_threads=2, chunk=4)
-    monkeypatch.setenv("FFHIP_JPEG_GPU_ENTROPY", "1")
+    monkeypatch.setenv("FFHIP_JPEG_GPU_ENTROPY", "1"); capi.reload_env()
     _, out = ops.jpeg_decode_files(files, n_threads=2, chunk=4)
     _, dev, _ = ops.jpeg_decode_files_device(files, n_threads=2)
     assert np.array_equal(out, ref) and np.array_equal(dev, ref)

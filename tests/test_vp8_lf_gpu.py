@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from ffpic_amd import ops, synth
+from ffpic_amd import capi, ops, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -194,7 +194,7 @@ def test_side_by_side_call_under_every_scheduler(env, monkeypatch):
     """ffhip_vp8_predict_loopfilter when one of its stages cannot take the row form (then they run one after the other), when
     told not to overlap, and with far fewer waves than rows (tickets, not residency, order the rows of both kernels)"""
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        monkeypatch.setenv(k, v); capi.reload_env()
     c, r, n = 21, 13, 3
     modes = np.stack([synth.vp8_modes(c, r, seed=760 + i) for i in range(n)])
     resid = np.stack([synth.vp8_residual(c * r, seed=770 + i) for i in range(n)])
@@ -212,7 +212,7 @@ def test_side_by_side_call_under_every_scheduler(env, monkeypatch):
 def test_lf_schedulers_agree(env, ft, monkeypatch):
     """level-synchronous launches vs the single row-form launch (few / many waves), both filter types"""
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        monkeypatch.setenv(k, v); capi.reload_env()
     c, r, n = 21, 13, 3
     modes = np.stack([synth.vp8_modes(c, r, seed=500 + i) for i in range(n)])
     modes[..., 18] = np.random.default_rng(5).integers(0, 4, size=modes[..., 18].shape)

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from ffpic_amd import ops, synth
+from ffpic_amd import capi, ops, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -61,7 +61,7 @@ def test_1080p_frame():
 def test_schedulers_agree(env, monkeypatch):
     """level-synchronous launches, and the single row-form launch with few and with many waves"""
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        monkeypatch.setenv(k, v); capi.reload_env()
     c, r, n = 23, 11, 4
     modes = np.stack([synth.vp8_modes(c, r, seed=170 + i) for i in range(n)])
     modes[1, np.arange(r) * c, 0] = 3        # H_PRED down the whole left column: every row waits for the full row above

@@ -23,7 +23,7 @@ pageable = np.zeros((n, 2160, 3840, 4), np.uint8)     # touched once: no first-t
 pinned = ops.PinnedArray((n, 2160, 3840, 4))
 ops.jpeg_decode_files(files, n_threads=8, chunk=4, out=pageable)
 for dst_name, dst, gpu in (("pageable", pageable, "0"), ("pinned", pinned.array, "0"), ("pinned_gpu_entropy", pinned.array, "1"), ("pageable_gpu_entropy", pageable, "1")):
-    os.environ["FFHIP_JPEG_GPU_ENTROPY"] = gpu
+    capi.setenv("FFHIP_JPEG_GPU_ENTROPY", gpu)
     for th in ((1, 8, 16) if gpu == "0" else (4, 16)):
         for chunk in ((4, 8) if gpu == "0" else (16, 32, 64)):
             best = 1e9
@@ -31,7 +31,7 @@ for dst_name, dst, gpu in (("pageable", pageable, "0"), ("pinned", pinned.array,
                 t0 = time.perf_counter(); g, px = ops.jpeg_decode_files(files, n_threads=th, chunk=chunk, out=dst); best = min(best, time.perf_counter() - t0)
             out[f"{dst_name}_threads_{th}_chunk_{chunk}"] = {"ms": round(best * 1e3, 1), "Gpx/s": round(n * g.width * g.height / best / 1e9, 2), "files/s": round(n / best, 1)}
 assert np.array_equal(pageable, pinned.array)
-os.environ["FFHIP_JPEG_GPU_ENTROPY"] = "0"
+capi.setenv("FFHIP_JPEG_GPU_ENTROPY", "0")
 # the unpipelined two-step path for comparison
 best = 1e9
 for _ in range(2):

@@ -87,7 +87,7 @@ bufs = [np.frombuffer(f, dtype=np.uint8) for f in files]
 ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs]); lens = (C.c_size_t * n)(*[b.size for b in bufs])
 dout = ops.DeviceBuffer(nbytes=n * gs.width * gs.height * 4); status = (C.c_int * n)(); g2 = capi.JpegGeom()
 for mode in ("0", "1"):
-    os.environ["FFHIP_JPEG_GPU_ENTROPY"] = mode
+    capi.setenv("FFHIP_JPEG_GPU_ENTROPY", mode)
     def run3():
         capi.check(L.ffhip_jpeg_decode_files_device(ptrs, lens, n, 16, C.byref(g2), dout.ptr, gs.width * 4, gs.width * 4 * gs.height, status, None))
         capi.check(L.ffhip_stream_sync(None))
@@ -96,5 +96,5 @@ for mode in ("0", "1"):
     for _ in range(3):
         t0 = time.perf_counter(); run3(); best = min(best, time.perf_counter() - t0)
     out[f"thumbnails_256x256_no_dri_n{n}_{'device' if mode == '1' else 'host16'}_entropy"] = {"file_bytes": len(data), "ms": round(best * 1e3, 2), "Gpx/s": round(n * gs.width * gs.height / best / 1e9, 2), "files/s": round(n / best)}
-os.environ.pop("FFHIP_JPEG_GPU_ENTROPY", None)
+capi.setenv("FFHIP_JPEG_GPU_ENTROPY", None)
 print(json.dumps(out, indent=1))

@@ -20,7 +20,7 @@ for tag, mix, seed in (("c5mix", "c5", 5), ("quadtree", None, 2)):
     def run():
         capi.check(L.ffhip_hevc_intra_recon(tus.ctypes.data, dt.data_ptr(), len(tus), dr.data_ptr(), py.data_ptr(), pu.data_ptr(), pv.data_ptr(), W, H, W, W // 2, H // 2, W // 2, 8, 8, st))
     for wl in sys.argv[1:] or ["6", "5", "4"]:
-        os.environ["FFHIP_HEVC_INTRA_WINDOW"] = wl
+        capi.setenv("FFHIP_HEVC_INTRA_WINDOW", wl)
         run(); capi.check(L.ffhip_stream_sync(st))
         L.ffhip_event_record(e0, st)
         for _ in range(5): run()

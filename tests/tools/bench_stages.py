@@ -59,27 +59,27 @@ import time
 def pred():
     capi.check(L.ffhip_vp8_predict_recon(c, r, nf, modes.ctypes.data, dm.data_ptr(), resid.data_ptr(), c * r * 384, None, Y.data_ptr(), U.data_ptr(), V.data_ptr(), 256 * c * r, 64 * c * r, st))
 for name, env in (("levels", {"FFHIP_VP8_PRED_MODE": "levels"}), ("rows", {})):
-    os.environ.pop("FFHIP_VP8_PRED_MODE", None)
-    os.environ.update(env)
+    capi.setenv("FFHIP_VP8_PRED_MODE", None)
+    [capi.setenv(k_, v_) for k_, v_ in env.items()]
     pred(); capi.check(L.ffhip_stream_sync(st))
     best = 1e9
     for _ in range(3):
         t0 = time.perf_counter(); pred(); capi.check(L.ffhip_stream_sync(st)); best = min(best, (time.perf_counter() - t0) * 1e3)
     out[f"vp8_predict_recon_16x1080p_{name}"] = {"wall_ms": round(best, 3), "Mpx/s": round(nf * 256 * c * r / best / 1e3, 1)}
-os.environ.pop("FFHIP_VP8_PRED_MODE", None)
+capi.setenv("FFHIP_VP8_PRED_MODE", None)
 # --- VP8 loop filter, same 16 frames
 flt = torch.from_numpy(synth.vp8_filters(seed=3)).to(dev)
 def lf():
     capi.check(L.ffhip_vp8_loopfilter(c, r, nf, 2, dm.data_ptr(), flt.data_ptr(), Y.data_ptr(), U.data_ptr(), V.data_ptr(), 256 * c * r, 64 * c * r, st))
 for name, env in (("levels", {"FFHIP_VP8_LF_MODE": "levels"}), ("rows", {})):
-    os.environ.pop("FFHIP_VP8_LF_MODE", None)
-    os.environ.update(env)
+    capi.setenv("FFHIP_VP8_LF_MODE", None)
+    [capi.setenv(k_, v_) for k_, v_ in env.items()]
     lf(); capi.check(L.ffhip_stream_sync(st))
     best = 1e9
     for _ in range(3):
         t0 = time.perf_counter(); lf(); capi.check(L.ffhip_stream_sync(st)); best = min(best, (time.perf_counter() - t0) * 1e3)
     out[f"vp8_loopfilter_normal_16x1080p_{name}"] = {"wall_ms": round(best, 3), "Mpx/s": round(nf * 256 * c * r / best / 1e3, 1)}
-os.environ.pop("FFHIP_VP8_LF_MODE", None)
+capi.setenv("FFHIP_VP8_LF_MODE", None)
 # --- HEVC intra recon: one 1920x1088 picture, then the 8K picture of config 5, level launches vs grouped single launch
 def intra_case(tag, W, H, seed, envs):
     tus, res = synth.hevc_intra_tus(W, H, seed=seed)
@@ -89,8 +89,8 @@ def intra_case(tag, W, H, seed, envs):
         capi.check(L.ffhip_hevc_intra_recon(tus.ctypes.data, dtus.data_ptr(), len(tus), dres.data_ptr(), py.data_ptr(), pu.data_ptr(), pv.data_ptr(), W, H, W, W // 2, H // 2, W // 2, 8, 8, st))
     for name, env in envs:
         for k in ("FFHIP_HEVC_INTRA_MODE", "FFHIP_HEVC_INTRA_WINDOW", "FFHIP_HEVC_INTRA_WAVES", "FFHIP_HEVC_INTRA_DECODE_ORDER"):
-            os.environ.pop(k, None)
-        os.environ.update(env)
+            capi.setenv(k, None)
+        [capi.setenv(k_, v_) for k_, v_ in env.items()]
         intra(); capi.check(L.ffhip_stream_sync(st))
         best_wall, best_dev = 1e9, 1e9
         for _ in range(3):
@@ -100,7 +100,7 @@ def intra_case(tag, W, H, seed, envs):
             best_wall = min(best_wall, (time.perf_counter() - t0) * 1e3)
         out[f"hevc_intra_recon_{tag}_{name}"] = {"wall_ms": round(best_wall, 3), "tus": int(len(tus)), "Mpx/s": round(W * H / best_wall / 1e3, 1)}
     for k in ("FFHIP_HEVC_INTRA_MODE", "FFHIP_HEVC_INTRA_WINDOW"):
-        os.environ.pop(k, None)
+        capi.setenv(k, None)
 envs = [("levels", {"FFHIP_HEVC_INTRA_MODE": "levels"})] + [(f"groups_w{1 << w}", {"FFHIP_HEVC_INTRA_WINDOW": str(w)}) for w in (6, 5, 4, 3)]
 if "--sweep" in sys.argv:
     envs += [(f"w32_waves{n}", {"FFHIP_HEVC_INTRA_WAVES": str(n)}) for n in (128, 256, 512, 2048, 4096)]

@@ -24,7 +24,7 @@ L.ffhip_debug_intra_trace.restype = None
 st = torch.cuda.current_stream().cuda_stream
 which = sys.argv[1] if len(sys.argv) > 1 else "quadtree"
 if len(sys.argv) > 2:
-    os.environ["FFHIP_HEVC_INTRA_WINDOW"] = sys.argv[2]
+    capi.setenv("FFHIP_HEVC_INTRA_WINDOW", sys.argv[2])
 W, H = (7680, 4352) if not os.environ.get("TRACE_SMALL") else (1920, 1088)
 tus, res = synth.hevc_intra_tus(W, H, seed=2 if which == "quadtree" else 5, tu_mix=None if which == "quadtree" else "c5")
 n = len(tus)

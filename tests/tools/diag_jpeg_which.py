@@ -25,7 +25,7 @@ def measure():
     if os.environ.get("VARIANTS"):
         r = []
         for v in os.environ["VARIANTS"].split(","):
-            os.environ["FFHIP_JPEG_VARIANT"] = v
+            capi.setenv("FFHIP_JPEG_VARIANT", v)
             r.append(measure1())
         return r
     return measure1()

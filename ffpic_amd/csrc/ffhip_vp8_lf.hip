@@ -35,6 +35,7 @@ struct Vp8LfArgs {
     uint32_t *ctrl; /* [0] next row ticket, [1] abort; from ctrl + 4: macroblocks finished per (image, row) */
     int *async_err;
     int n_images;
+    int slack; /* as in Vp8PredArgs */
     const uint32_t *pred_progress; /* fused with the prediction (ffhip_vp8_predict_loopfilter): its per-(image, row) counters, else null */
 };
 
@@ -391,9 +392,10 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
                 seen = got > seen ? got : seen;
             }
             poll_out = false;
-            while (seen < need) {
+            const unsigned want = seen < need ? ((need + (unsigned)a.slack) < (unsigned)a.mbcols ? need + (unsigned)a.slack : (unsigned)a.mbcols) : need;
+            while (seen < want) {
                 seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(prog_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                if (seen >= need) break;
+                if (seen >= want) break;
                 if (++spins > LF_SPIN_LIMIT || __hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     if (lane == 0) {
                         __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -405,9 +407,10 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
                 else __builtin_amdgcn_s_sleep(16);
             }
             const unsigned need_pred = (unsigned)(x1 + 2 < a.mbcols ? x1 + 2 : a.mbcols);
-            while (seen_pred < need_pred) {
+            const unsigned want_pred = seen_pred < need_pred ? ((need_pred + (unsigned)a.slack) < (unsigned)a.mbcols ? need_pred + (unsigned)a.slack : (unsigned)a.mbcols) : need_pred;
+            while (seen_pred < want_pred) {
                 seen_pred = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(pred_row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                if (seen_pred >= need_pred) break;
+                if (seen_pred >= want_pred) break;
                 if (++spins > LF_SPIN_LIMIT || __hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     if (lane == 0) {
                         __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -532,6 +535,7 @@ extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int fi
         a.plane_y = plane_stride_y; a.plane_uv = plane_stride_uv;
         a.mbcols = mbcols; a.mbrows = mbrows; a.filter_type = filter_type;
         a.ctrl = g_work; a.async_err = async_err; a.n_images = n_images;
+        { const char *sl = FFHIP_ENV("FFHIP_VP8_SLACK"); a.slack = sl ? std::max(0, atoi(sl)) : 0; }
         /* as many waves as can be resident, at most a wavefront's width of rows per image (ffhip_vp8_predict_recon has the
          * reasoning); next to the prediction kernel of the same call each of the two takes half of its own residency, so
          * filter waves -- which wait for the prediction's counters -- can never keep the prediction from becoming resident */

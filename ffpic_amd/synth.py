@@ -165,11 +165,17 @@ HEVC_TU_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2_size", "u1"), ("cid
 TU_CORNER, TU_RESIDUAL, TU_FILTER, TU_STRONG, TU_NO_BF, TU_NO_DC_BF, TU_RDPCM, TU_CCP = 1, 2, 4, 8, 16, 32, 64, 128
 
 
-def _quadtree(rng, x0, y0, size, min_size, max_tu, out):
-    if size > max_tu or (size > min_size and rng.random() < 0.55):
+def _quadtree(rng, x0, y0, size, min_size, max_tu, out, pw=1 << 30, ph=1 << 30):
+    """pw, ph: the plane's size -- a block that crosses the picture edge is split (the implicit split of 7.3.8.4), one
+    that lies outside it does not exist"""
+    if x0 >= pw or y0 >= ph:
+        return
+    crosses = x0 + size > pw or y0 + size > ph
+    if size > max_tu or crosses or (size > min_size and rng.random() < 0.55):
+        assert size > min_size or not crosses, "picture size must be a multiple of the smallest TU"
         h = size // 2
         for (dx, dy) in ((0, 0), (h, 0), (0, h), (h, h)):          # z-order
-            _quadtree(rng, x0 + dx, y0 + dy, h, min_size, max_tu, out)
+            _quadtree(rng, x0 + dx, y0 + dy, h, min_size, max_tu, out, pw, ph)
     else:
         out.append((x0, y0, size))
 
@@ -198,7 +204,7 @@ def hevc_intra_tus(width, height, seed=0, ctb=64, chroma=True, min_tu=4, adversa
     60/40, chroma 16/8 at 60/40.
     Returns (tus structured array, residual int16 flat)."""
     rng = np.random.default_rng(SEED_BASE + 15000 + seed)
-    assert width % ctb == 0 and height % ctb == 0
+    assert (width % ctb == 0 and height % ctb == 0) or (tu_mix is None and width % 8 == 0 and height % 8 == 0)
     csub = 1 if chroma_444 else 2
     planes = [(width, height)] + ([(width // csub, height // csub)] * 2 if chroma else [])
     done = [np.zeros((h, w), bool) for (w, h) in planes]
@@ -211,7 +217,7 @@ def hevc_intra_tus(width, height, seed=0, ctb=64, chroma=True, min_tu=4, adversa
                 if tu_mix == "c5":
                     _c5_mix(rng, cx // sc, cy // sc, ctb // sc, 32 // sc, parts)
                 else:
-                    _quadtree(rng, cx // sc, cy // sc, ctb // sc, max(min_tu, 4), 32, parts)
+                    _quadtree(rng, cx // sc, cy // sc, ctb // sc, max(min_tu, 4), 32, parts, pw, ph)
                 for (x0, y0, n) in parts:
                     d = done[c]
                     at = al = 0

@@ -280,6 +280,13 @@ static void rec_intra_sample_prediction(struct slice_segment_header *slice, stru
     intra_sample_prediction(slice, hps, cu, xTbCmp, yTbCmp, predModeIntra, nTbS, cIdx, predSamples, p);
 }
 
+/* the reference's function as it is, for drivers that keep their own record open (ref_hevc_isp_picture) */
+static void rec_intra_sample_prediction_bare(struct slice_segment_header *slice, struct hevc_param_set *hps, struct cu *cu, int xTbCmp,
+                                             int yTbCmp, int predModeIntra, int nTbS, int cIdx, int16_t *predSamples, struct picture *p)
+{
+    intra_sample_prediction(slice, hps, cu, xTbCmp, yTbCmp, predModeIntra, nTbS, cIdx, predSamples, p);
+}
+
 static void rec_reference_sample_substitution(struct sps *sps, int16_t *left, int16_t *top, int nTbS, int cIdx, int unavaible,
                                               int8_t *unavaibleL, int8_t *unavaibleT)
 {
@@ -417,4 +424,74 @@ void ref_hevc_chain_picture(const struct ref_chain_tu *tus, long n_tus, const in
                           bitdepth, bitdepth, t->res_scale);
     }
     YUV420_to_BGRA32_16bit(bgra, pitch, py, pu, pv, width, width / 2, height / ctbsize, width / ctbsize, ctbsize);
+}
+
+/* ---- the reference's static intra_sample_prediction ITSELF (hevc.c:4542-4662) over a caller-prepared TU list -------------
+ * hps: a parameter set the reference's own parse_nalu filled from VPS / SPS / PPS NAL units (so MinTbAddrZs, CtbAddrRsToTs,
+ * TileId and the picture geometry are the reference's); the picture is allocated as parse_slice_segment_layer does
+ * (hevc.c:7221-7240).  Per TU in list order: CuPredMode of the TU's coding block is set (what parse_coding_unit has done by
+ * the time decode_intra_block runs; it decides availability under constrained_intra_pred_flag), intra_sample_prediction
+ * gathers the neighbours with ITS OWN process_zscan_order_block_availablity, substitutes, filters and predicts; the
+ * availability it derived is read back through the call-site tap on reference_sample_substitution; the residual is added by
+ * construct_pic_pior_to_filtering.  Nothing of the neighbour gathering is restated here.
+ * masks_out[2 i], [2 i + 1] = avail_top, avail_left of TU i, corner_out[i] = its corner availability.
+ * Returns the number of int16 elements of the picture (Y | U | V as at hevc.c:7225-7230) copied to pixel_out, or -1. */
+long ref_hevc_isp_picture(void *hps_, const struct ref_chain_tu *tus, long n_tus, const int16_t *residual, int16_t *pixel_out,
+                          long pixel_cap, uint64_t *masks_out, uint8_t *corner_out, int *geom_out)
+{
+    struct hevc_param_set *hps = hps_;
+    struct slice_segment_header *slice = calloc(1, sizeof *slice);
+    slice->slice_pic_parameter_set_id = 0;
+    struct pps *pps = hps->pps[0];
+    struct sps *sps = hps->sps[pps->pps_seq_parameter_set_id];
+    /* what the slice header parser does once it knows the parameter sets (hevc.c:2701-2702): the derived picture geometry
+     * and the z-scan / tile tables process_zscan_order_block_availablity reads */
+    calc_sps_params(sps);
+    calc_pps_params(sps, pps);
+    const int width = sps->pic_width_in_luma_samples, height = ((sps->pic_height_in_luma_samples + 3) >> 2) << 2;
+    const int y_stride = ((width + 3) >> 2) << 2, uv_stride = y_stride >> 1;
+    struct picture p;
+    memset(&p, 0, sizeof p);
+    p.size = height * y_stride;
+    p.pixel = calloc((size_t)height * y_stride * 2, sizeof(int16_t));
+    p.y_stride = y_stride;
+    p.uv_stride = uv_stride;
+    p.info = calloc((size_t)sps->PicWidthInMinCbsY * sps->PicHeightInMinCbsY, sizeof(struct cu_info));
+    struct cu *cu = calloc(1, sizeof *cu);
+    long rc = -1;
+    if (!p.pixel || !p.info || !cu || (long)p.size * 2 > pixel_cap) goto out;
+    for (long i = 0; i < n_tus; i++) {
+        const struct ref_chain_tu *t = tus + i;
+        const int nTbS = 1 << t->log2_size, cIdx = t->cidx;
+        if (cIdx == 0) {
+            const int lg = t->log2_size > sps->MinCbLog2SizeY ? t->log2_size : sps->MinCbLog2SizeY;
+            set_CuPredMode(sps, &p, (t->x >> lg) << lg, (t->y >> lg) << lg, lg, MODE_INTRA);
+        }
+        int16_t predSamples[64 * 64];
+        int16_t resSamples[32 * 32] = {0};
+        memset(&g_rec.cur, 0, sizeof g_rec.cur);
+        g_rec.cur.avail_top = nTbS == 32 ? ~0ull : (1ull << (2 * nTbS)) - 1; /* everything available unless the substitution is invoked */
+        g_rec.cur.avail_left = g_rec.cur.avail_top;
+        g_rec.cur.flags = 1;
+        g_rec.on = 1; g_rec.open = 1;
+        rec_intra_sample_prediction_bare(slice, hps, cu, t->x, t->y, t->pred_mode, nTbS, cIdx, predSamples, &p);
+        g_rec.on = 0; g_rec.open = 0;
+        masks_out[2 * i] = g_rec.cur.avail_top;
+        masks_out[2 * i + 1] = g_rec.cur.avail_left;
+        corner_out[i] = (uint8_t)(g_rec.cur.flags & 1);
+        if (t->flags & 2) {
+            memcpy(resSamples, residual + t->res_offset, (size_t)nTbS * nTbS * sizeof(int16_t));
+            if (t->flags & 64) residual_modification_transform_bypass(t->pred_mode / 26, nTbS, resSamples);
+        }
+        int16_t *dst = cIdx == 0 ? p.pixel : (cIdx == 1 ? p.pixel + p.size : p.pixel + p.size * 3 / 2);
+        construct_pic_pior_to_filtering(sps, t->x, t->y, nTbS, nTbS, cIdx, predSamples, resSamples, dst, cIdx == 0 ? y_stride : uv_stride);
+    }
+    memcpy(pixel_out, p.pixel, (size_t)p.size * 2 * sizeof(int16_t));
+    geom_out[0] = width; geom_out[1] = height; geom_out[2] = y_stride; geom_out[3] = uv_stride; geom_out[4] = p.size;
+    geom_out[5] = pps->constrained_intra_pred_flag; geom_out[6] = sps->strong_intra_smoothing_enabled_flag;
+    geom_out[7] = sps->sps_range_ext.intra_smoothing_disabled_flag;
+    rc = (long)p.size * 2;
+out:
+    free(p.pixel); free(p.info); free(cu); free(slice);
+    return rc;
 }

@@ -773,6 +773,60 @@ def gen_hevc_file(R):
     save("hevc_file.npz", **res)
 
 
+ISP_SPECS = {"p1080": (1920, 1080, 7, 0), "p1080_constrained": (1920, 1080, 8, 1), "odd": (1000, 520, 9, 1)}
+
+
+def isp_inputs(w, h, seed):
+    """The TU list of the intra_sample_prediction fixtures: a random quadtree over the (edge-aware) picture with the flags a plain
+    Main-profile decoder has at that point -- neighbour smoothing for luma only (intra_smoothing_disabled_flag 0, 4:2:0), strong
+    smoothing on, no boundary-filter switches, no rdpcm -- and the availability masks of ffpic_amd.synth's z-scan model."""
+    tus, res = synth.hevc_intra_tus(w, h, seed=seed)
+    keep = tus["flags"] & (synth.TU_RESIDUAL | synth.TU_CORNER)
+    tus["flags"] = keep | np.where(tus["cidx"] == 0, synth.TU_FILTER, 0).astype(np.uint8) | synth.TU_STRONG
+    return tus, res
+
+
+def gen_hevc_isp(R):
+    """Pins the neighbour GATHERING of intra_sample_prediction (coding/hevc.c:4570-4608) at picture scale: the reference's static
+    function itself, with its own process_zscan_order_block_availablity over parameter sets its own parser read, run over
+    1080p-class TU lists (oracle/ref_statics_hevc.c::ref_hevc_isp_picture).  Stored: what the list is made from (size, seed), the
+    availability the reference derived IF it differs from the generator's (it does not), and the sha256 of its planes."""
+    import hevc_bitstream as HB
+    R.ref_hevc_param_set_new.restype = C.c_void_p
+    R.parse_nalu.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]
+    R.ref_hevc_isp_picture.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p]
+    R.ref_hevc_isp_picture.restype = C.c_long
+    res = {}
+    for tag, (w, h, seed, ci) in ISP_SPECS.items():
+        hps = R.ref_hevc_param_set_new()
+        for n in (HB.vps(), HB.sps(w, h), HB.pps(constrained_intra=ci)):
+            buf = np.frombuffer(n, np.uint8).copy()
+            dummy = C.c_void_p(0)
+            R.parse_nalu(buf.ctypes.data, buf.size, C.byref(dummy), hps)
+        tus, resid = isp_inputs(w, h, seed)
+        tus = np.ascontiguousarray(tus)
+        hh = (h + 3) // 4 * 4
+        pix = np.zeros(hh * w * 2, np.int16)
+        masks = np.zeros((len(tus), 2), np.uint64)
+        corner = np.zeros(len(tus), np.uint8)
+        geom = np.zeros(8, np.int32)
+        rc = R.ref_hevc_isp_picture(hps, tus.ctypes.data, len(tus), resid.ctypes.data, pix.ctypes.data, pix.size, masks.ctypes.data, corner.ctypes.data, geom.ctypes.data)
+        assert rc == pix.size and list(geom[:4]) == [w, hh, w, w // 2] and int(geom[5]) == ci and int(geom[6]) == 1 and int(geom[7]) == 0, (rc, geom)
+        same = bool(np.array_equal(masks[:, 0], tus["avail_top"]) and np.array_equal(masks[:, 1], tus["avail_left"]) and
+                    np.array_equal(corner, tus["flags"] & synth.TU_CORNER))
+        assert same, f"{tag}: the generator's availability differs from process_zscan_order_block_availablity"
+        size = hh * w
+        y, u, v = pix[:size].reshape(hh, w)[:h], pix[size:size + size // 4].reshape(hh // 2, w // 2)[:h // 2], pix[size * 3 // 2:size * 3 // 2 + size // 4].reshape(hh // 2, w // 2)[:h // 2]
+        oy, ou, ov = O.oracle_hevc_intra(tus, resid, w, h, True, 8, 8)
+        assert np.array_equal(oy, y) and np.array_equal(ou, u) and np.array_equal(ov, v), f"{tag}: restatement != reference"
+        sha = hashlib.sha256(np.ascontiguousarray(y).tobytes() + np.ascontiguousarray(u).tobytes() + np.ascontiguousarray(v).tobytes()).digest()
+        edge = int(((tus["avail_top"] != np.where(tus["log2_size"] == 5, np.uint64(0xFFFFFFFFFFFFFFFF), (np.uint64(1) << (np.uint64(2) << tus["log2_size"].astype(np.uint64))) - np.uint64(1)))).sum())
+        print(f"  {tag}: {w}x{h} seed {seed} constrained_intra_pred {ci}: {len(tus)} TUs, {edge} with unavailable top neighbours, generator masks == reference: {same}")
+        res.update({f"{tag}_spec": np.array([w, h, seed, ci, len(tus)], np.int32), f"{tag}_sha256": np.frombuffer(sha, np.uint8),
+                    f"{tag}_row0": y[0].copy(), f"{tag}_lastrow": y[h - 1].copy()})
+    save("hevc_isp.npz", **res)
+
+
 def ref_decode_file(R, path):
     """Run the reference's whole-file decode in a child process (its Huffman reader overruns its
     input at the end of some scans -- utils/bitstream.c:117 -- and can take the process down)."""
@@ -859,7 +913,7 @@ def main():
     R = O.ref()
     steps = [("blocks", gen_blocks), ("vp8 macroblocks", gen_vp8_mbs), ("vp8 driven", gen_vp8_driven), ("vp8 frames", gen_vp8_frames),
              ("hevc intra", gen_hevc_intra), ("hevc glue", gen_hevc_glue), ("vp8 loop filter", gen_vp8_loopfilter), ("colour", gen_color),
-             ("grids", gen_grids), ("files", gen_files), ("files 422", gen_files_422), ("webp file", gen_webp_file), ("webp file lf", gen_webp_file_lf), ("webp file 1080p", gen_webp_file_1080p), ("vp8 filter params", gen_vp8_filter_params), ("hevc file", gen_hevc_file), ("heic file", gen_heic_file)]
+             ("grids", gen_grids), ("files", gen_files), ("files 422", gen_files_422), ("webp file", gen_webp_file), ("webp file lf", gen_webp_file_lf), ("webp file 1080p", gen_webp_file_1080p), ("vp8 filter params", gen_vp8_filter_params), ("hevc file", gen_hevc_file), ("heic file", gen_heic_file), ("hevc isp", gen_hevc_isp)]
     only = sys.argv[2] if len(sys.argv) == 3 and sys.argv[1] == "--only" else None   # e.g. --only "hevc intra"
     for name, fn in steps:
         if only is None or only == name:

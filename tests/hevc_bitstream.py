@@ -83,10 +83,10 @@ def sps(width, height, bitdepth=8, ctb_log2=6, min_cb_log2=3, min_tb_log2=2, max
     return nal(33, w.bytes())
 
 
-def pps(init_qp=30, transform_skip=1, transquant_bypass=1, sign_data_hiding=0):
+def pps(init_qp=30, transform_skip=1, transquant_bypass=1, sign_data_hiding=0, constrained_intra=0):
     w = BitWriter()
     w.ue(0); w.ue(0); w.u(1, 0); w.u(1, 0); w.u(3, 0); w.u(1, sign_data_hiding); w.u(1, 0); w.ue(0); w.ue(0); w.se(init_qp - 26)
-    w.u(1, 0); w.u(1, transform_skip); w.u(1, 0)
+    w.u(1, constrained_intra); w.u(1, transform_skip); w.u(1, 0)
     w.se(0); w.se(0); w.u(1, 0); w.u(1, 0); w.u(1, 0); w.u(1, transquant_bypass); w.u(1, 0); w.u(1, 0)
     w.u(1, 0); w.u(1, 0); w.u(1, 0); w.u(1, 0); w.ue(0); w.u(1, 0); w.u(1, 0)
     w.trailing()

@@ -222,3 +222,16 @@ def test_list_the_device_planner_refuses_takes_the_serial_path(monkeypatch, plan
     got = ops.hevc_intra_recon(tus, res, w, h, False)[0]
     exp = O.oracle_hevc_intra(tus, res, w, h, False)[0]
     assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("tag", ["p1080", "p1080_constrained", "odd"])
+def test_isp_picture_vs_reference(golden, tag):
+    """tests/golden/hevc_isp.npz: 1080p-class pictures reconstructed by the reference's static intra_sample_prediction itself, with
+    its own z-scan availability, picture edges that cut coding tree blocks included (test_oracle_golden.py::test_hevc_isp_picture)"""
+    from test_oracle_golden import isp_digest, isp_inputs
+    g = golden("hevc_isp.npz")
+    w, h, seed, _, n = [int(x) for x in g[f"{tag}_spec"]]
+    tus, res = isp_inputs(w, h, seed)
+    got = ops.hevc_intra_recon(tus, res, w, h, True, 8, 8)
+    assert np.array_equal(got[0][0], g[f"{tag}_row0"]) and np.array_equal(got[0][h - 1], g[f"{tag}_lastrow"])
+    assert isp_digest(got) == g[f"{tag}_sha256"].tobytes()

@@ -458,3 +458,37 @@ def test_heic_grid_fixture(golden):
     assert b"grid" in data and b"dimg" in data and b"iref" in data
     i = data.index(b"mdat") + 4
     assert data[i:i + 8] == grid
+
+
+# ---- intra_sample_prediction at picture scale (tests/golden/hevc_isp.npz) ----
+ISP_TAGS = ("p1080", "p1080_constrained", "odd")
+
+
+def isp_inputs(w, h, seed):
+    """the TU list of the fixture (tests/golden/make_golden.py::isp_inputs): a random quadtree over the edge-aware picture with a plain
+    Main-profile decoder's flags; its availability masks are what the reference's own process_zscan_order_block_availablity gave
+    when the fixture was made (asserted there)"""
+    from ffpic_amd import synth
+    tus, res = synth.hevc_intra_tus(w, h, seed=seed)
+    keep = tus["flags"] & (synth.TU_RESIDUAL | synth.TU_CORNER)
+    tus["flags"] = keep | np.where(tus["cidx"] == 0, synth.TU_FILTER, 0).astype(np.uint8) | synth.TU_STRONG
+    return tus, res
+
+
+def isp_digest(planes):
+    import hashlib
+    return hashlib.sha256(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).digest()
+
+
+@pytest.mark.parametrize("tag", ISP_TAGS)
+def test_hevc_isp_picture(golden, tag):
+    """1080p-class pictures (1920x1080: a partial last row of coding tree blocks; 1000x520: partial last row AND column; constrained
+    intra prediction on and off) whose planes came from the reference's static intra_sample_prediction itself
+    (coding/hevc.c:4542-4662, neighbour gathering :4570-4608 with its own z-scan availability)"""
+    g = golden("hevc_isp.npz")
+    w, h, seed, _, n = [int(x) for x in g[f"{tag}_spec"]]
+    tus, res = isp_inputs(w, h, seed)
+    assert len(tus) == n
+    planes = O.oracle_hevc_intra(tus, res, w, h, True, 8, 8)
+    assert np.array_equal(planes[0][0], g[f"{tag}_row0"]) and np.array_equal(planes[0][h - 1], g[f"{tag}_lastrow"])
+    assert isp_digest(planes) == g[f"{tag}_sha256"].tobytes()

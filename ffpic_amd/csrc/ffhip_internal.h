@@ -28,7 +28,7 @@ int *ffhip_async_err_word(void); /* pinned word kernels report an in-launch abor
  * site's first use, and kept; ffhip_reload_env() (public, include/ffpic_hip.h) makes every site read its switch again. */
 struct ffhip_env_site { const char *name; int gen; int set; char val[56]; };
 const char *ffhip_env_lookup(struct ffhip_env_site *site); /* NULL when unset */
-int ffhip_resident_waves(const void *kernel, int lds_bytes); /* single-wave workgroups of `kernel` the device holds at once (occupancy x CUs), cached */
+int ffhip_resident_waves(const void *kernel, int block_threads); /* workgroups of `block_threads` threads of `kernel` the device holds at once (occupancy x CUs), cached */
 #ifdef __cplusplus
 }
 #endif

@@ -43,19 +43,19 @@ extern "C" void ffhip_note_hip_error(int hip_error, const char *what)
  * (tickets + progress counters) may launch without a wave holding a ticket it cannot run yet -- and, for two such
  * kernels side by side, what lets both be resident whatever the hardware starts first. */
 static std::map<std::pair<const void *, int>, int> g_resident;
-extern "C" int ffhip_resident_waves(const void *kernel, int lds_bytes)
+extern "C" int ffhip_resident_waves(const void *kernel, int block_threads)
 {
     std::lock_guard<std::mutex> lock(g_env_mu);
-    auto it = g_resident.find(std::make_pair(kernel, lds_bytes));
+    auto it = g_resident.find(std::make_pair(kernel, block_threads));
     if (it != g_resident.end()) return it->second;
     int per_cu = 0, cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, (size_t)lds_bytes) != hipSuccess || per_cu < 1 || cus < 1) {
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, 0) != hipSuccess || per_cu < 1 || cus < 1) {
         (void)hipGetLastError();
         return 256; /* one wave per CU of the smallest part: always resident */
     }
     const int n = per_cu * cus;
-    g_resident[std::make_pair(kernel, lds_bytes)] = n;
+    g_resident[std::make_pair(kernel, block_threads)] = n;
     return n;
 }
 

@@ -25,6 +25,7 @@ def golden():
             cache[name] = dict(np.load(os.path.join(GOLDEN, name)))
             if name == "jpeg_files.npz":      # the 4:2:2 file fixture of round 2 lives in its own archive
                 cache[name].update(dict(np.load(os.path.join(GOLDEN, "jpeg_file_422.npz"))))
+                cache[name].update(dict(np.load(os.path.join(GOLDEN, "jpeg_file_411.npz"))))   # round 3: h4v1 (4:1:1, with DRI) and h1v4 files
             if name == "hevc_file.npz":       # tag "e": the same kind of picture, decoded by the reference from a .heic container
                 cache[name].update(dict(np.load(os.path.join(GOLDEN, "heic_file.npz"))))
         return cache[name]

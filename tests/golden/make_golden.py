@@ -856,6 +856,61 @@ def gen_files_422(R):
     gen_files(R, FILE_SPECS_422, "jpeg_file_422.npz")
 
 
+def gen_files_411(R):
+    """Whole-file fixtures for the h*v = 4 layouts PIL cannot write (its "4:1:1" is h2v2): a photograph-like test card, its luma at full size
+    and its chroma planes box-filtered 4:1 (horizontally: 4:1:1, h4v1; vertically: h1v4), every plane coded by libjpeg as a grey baseline
+    JPEG; the entropy-decoded blocks of the three are re-interleaved in MCU order and written as ONE baseline file by tests/jpeg_writer.py
+    (Annex K Huffman tables; the h4v1 file with a restart interval per MCU row).  Expected pixels: the reference's OWN loader on that file."""
+    from PIL import Image
+    import jpeg_writer
+    rng = np.random.default_rng(11)
+    Hh, Ww = 96, 160
+    yy, xx = np.mgrid[0:Hh, 0:Ww]
+    img = np.stack([127 + 120 * np.sin(xx / 17.0) * np.cos(yy / 13.0), 127 + 100 * np.cos(xx / 7.0 + yy / 23.0), (xx * 255 / (Ww - 1) + yy * 255 / (Hh - 1)) / 2], axis=2)
+    ycc = np.asarray(Image.fromarray(np.clip(img + rng.normal(0, 5, img.shape), 0, 255).astype(np.uint8)).convert("YCbCr"))
+
+    def blocks_of(plane, quality):
+        bio = io.BytesIO()
+        Image.fromarray(plane, "L").save(bio, "JPEG", quality=quality, optimize=False, progressive=False)
+        d = jpeg_entropy.decode(bio.getvalue())
+        assert d["ncomp"] == 1 and d["mcu_cols"] * 8 == plane.shape[1] and d["mcu_rows"] * 8 == plane.shape[0]
+        return np.asarray(d["coef"][0]).reshape(d["mcu_rows"], d["mcu_cols"], 64), np.asarray(d["quant"][d["qt_id"][0]])
+
+    res = {}
+    for tag, (h, v, restart_rows) in {"q85_411": (4, 1, 1), "q85_114": (1, 4, 0)}.items():
+        cb = ycc[..., 1].reshape(Hh // v, v, Ww // h, h).mean(axis=(1, 3)).round().astype(np.uint8)
+        cr = ycc[..., 2].reshape(Hh // v, v, Ww // h, h).mean(axis=(1, 3)).round().astype(np.uint8)
+        by, qy = blocks_of(np.ascontiguousarray(ycc[..., 0]), 85)
+        bu, qc = blocks_of(cb, 70)
+        bv, qc2 = blocks_of(cr, 70)
+        assert np.array_equal(qc, qc2)
+        mcu_rows, mcu_cols = Hh // (8 * v), Ww // (8 * h)
+        ymcu = by.reshape(mcu_rows, v, mcu_cols, h, 64).transpose(0, 2, 1, 3, 4).reshape(-1, 64)      # mcu * (h*v) + vi * h + hi
+        quant = np.zeros((4, 64), np.uint16)
+        quant[0], quant[1] = qy, qc
+        W_, H_ = Ww - 5, Hh - 3                                                                        # not a whole number of MCUs
+        data = jpeg_writer.encode(W_, H_, h, v, [ymcu, bu.reshape(-1, 64), bv.reshape(-1, 64)], quant, restart=mcu_cols * restart_rows)
+        name = f"file_{tag}.jpg"
+        open(os.path.join(HERE, name), "wb").write(data)
+        assert Image.open(io.BytesIO(data)).size == (W_, H_)                                           # libjpeg reads it
+        bgra = ref_decode_file(R, os.path.join(HERE, name))
+        dec = jpeg_entropy.decode(data)
+        assert (dec["h"], dec["v"]) == (h, v) and np.array_equal(np.asarray(dec["coef"][0]).reshape(-1, 64), ymcu)
+        g = O.make_geom(dec["mcu_cols"], dec["mcu_rows"], dec["ncomp"], dec["h"], dec["v"], dec["qt_id"])
+        mine = O.ref_jpeg_recon(g, dec["coef"][0], dec["coef"][1], dec["coef"][2], dec["quant"])
+        Hc, Wc = bgra.shape[:2]
+        same = (mine[:Hc, :Wc] == bgra).all(axis=2)
+        last = np.zeros_like(same)
+        last[(g.mcu_rows - 1) * 8 * g.v:, (g.mcu_cols - 1) * 8 * g.h:] = True
+        assert same[~last].all(), f"{tag}: coefficient dump does not reproduce the file decode ({int((~same).sum())} pixels differ)"
+        res[f"{tag}_last_mcu_exact"] = np.array(int(same.all()), dtype=np.int32)
+        res[f"{tag}_sha256"] = np.frombuffer(hashlib.sha256(bgra.tobytes()).digest(), dtype=np.uint8)
+        res[f"{tag}_shape"] = np.array(bgra.shape, dtype=np.int32)
+        res[f"{tag}_bgra"] = bgra
+        print(f"  {name}: {len(data)} B, {bgra.shape}, h{h}v{v}, reference decode == recon from entropy-decoded planes (last MCU exact: {bool(same.all())})")
+    save("jpeg_file_411.npz", **res)
+
+
 def gen_files(R, specs=FILE_SPECS, out_name="jpeg_files.npz"):
     """BASELINE config 1: PIL-made baseline JPEGs decoded by the reference from the file."""
     from PIL import Image
@@ -913,7 +968,7 @@ def main():
     R = O.ref()
     steps = [("blocks", gen_blocks), ("vp8 macroblocks", gen_vp8_mbs), ("vp8 driven", gen_vp8_driven), ("vp8 frames", gen_vp8_frames),
              ("hevc intra", gen_hevc_intra), ("hevc glue", gen_hevc_glue), ("vp8 loop filter", gen_vp8_loopfilter), ("colour", gen_color),
-             ("grids", gen_grids), ("files", gen_files), ("files 422", gen_files_422), ("webp file", gen_webp_file), ("webp file lf", gen_webp_file_lf), ("webp file 1080p", gen_webp_file_1080p), ("vp8 filter params", gen_vp8_filter_params), ("hevc file", gen_hevc_file), ("heic file", gen_heic_file), ("hevc isp", gen_hevc_isp)]
+             ("grids", gen_grids), ("files", gen_files), ("files 422", gen_files_422), ("files 411", gen_files_411), ("webp file", gen_webp_file), ("webp file lf", gen_webp_file_lf), ("webp file 1080p", gen_webp_file_1080p), ("vp8 filter params", gen_vp8_filter_params), ("hevc file", gen_hevc_file), ("heic file", gen_heic_file), ("hevc isp", gen_hevc_isp)]
     only = sys.argv[2] if len(sys.argv) == 3 and sys.argv[1] == "--only" else None   # e.g. --only "hevc intra"
     for name, fn in steps:
         if only is None or only == name:

@@ -398,7 +398,9 @@ def test_oracle_batch_threads_and_errors():
 
 
 FILES = {"q85_420": "file_q85_420.jpg", "q92_444": "file_q92_444.jpg", "q80_grey": "file_q80_grey.jpg",
-         "q85_420_dri": "file_q85_420_dri.jpg", "q88_422": "file_q88_422.jpg"}
+         "q85_420_dri": "file_q85_420_dri.jpg", "q88_422": "file_q88_422.jpg",
+         # h*v = 4 MCUs: files PIL cannot write, made by tests/jpeg_writer.py from libjpeg-coded planes (make_golden.py::gen_files_411)
+         "q85_411": "file_q85_411.jpg", "q85_114": "file_q85_114.jpg"}
 
 
 def decode_fixture(tag):

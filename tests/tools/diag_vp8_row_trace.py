@@ -17,13 +17,13 @@ n_mb = c * r
 modes = np.ascontiguousarray(g["modes"])[None]
 res = torch.from_numpy(np.ascontiguousarray(g["residual"])).to(dev); dm = torch.from_numpy(modes).to(dev)
 Y = torch.zeros((1, 16 * r, 16 * c), dtype=torch.uint8, device=dev); U = torch.zeros((1, 8 * r, 8 * c), dtype=torch.uint8, device=dev); V = torch.zeros_like(U)
-tr = torch.zeros((r, 4), dtype=torch.int64, device=dev)
+tr = torch.zeros((r, 8), dtype=torch.int64, device=dev)
 fn = lambda: capi.check(L.ffhip_vp8_predict_recon(c, r, 1, modes.ctypes.data, dm.data_ptr(), res.data_ptr(), n_mb * 384, None, Y.data_ptr(), U.data_ptr(), V.data_ptr(), 256 * n_mb, 64 * n_mb, st))
 for _ in range(3): fn()
 L.ffhip_debug_vp8_trace(tr.data_ptr())
 fn(); capi.check(L.ffhip_stream_sync(st))
 L.ffhip_debug_vp8_trace(None)
-t = tr.cpu().numpy().astype(np.float64) / 100.0          # us
+t = tr.cpu().numpy().astype(np.float64)[:, :4] / 100.0          # us (words 4-7: per-phase sums, see ffhip_vp8_pred.hip)
 t -= t[:, 0].min()
 dur = t[:, 3] - t[:, 1]; first_half = t[:, 2] - t[:, 1]; second_half = t[:, 3] - t[:, 2]
 lag_end = np.diff(t[:, 3]); lag_start = np.diff(t[:, 1]); lag_mid = np.diff(t[:, 2])

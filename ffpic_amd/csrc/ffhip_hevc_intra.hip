@@ -488,7 +488,7 @@ __device__ __forceinline__ void wg_barrier()
  * a pass.  Here a pass of the angular loop is ~30 instructions: what changes from pass to pass moves by additions (rows per pass
  * are fixed), 24-bit multiplies, tile and plane offsets by immediate / one add.
  * NW waves share the passes: wave `wv` takes passes wv, wv + NW, ... (NW = 1: all of them). */
-template <int LG, int NW>
+template <int LG, int NW, bool STORE = true> /* STORE false: the samples go to the LDS tile only (somebody else writes them to the plane: intra_store_passes) */
 __device__ __forceinline__ void intra_passes(const HotArgs &a, const GroupCtx &g, const IntraSlot &t, const int lane, const int wv,
                                              const int *__restrict__ s, const short *__restrict__ R, short *__restrict__ tile,
                                              const short *__restrict__ zero_block)
@@ -522,8 +522,7 @@ __device__ __forceinline__ void intra_passes(const HotArgs &a, const GroupCtx &g
 #define EMIT(v_, j_) do { \
             const int pr_ = (int)(short)((v_) & 0xffff); \
             const short rec_ = (short)clip3i(0, maxv, pr_ + (int)Rr[64 * NW * (j_)]); \
-            __builtin_amdgcn_raw_buffer_store_b16(rec_, prs, goff, 0, FFHIP_AUX_SC1); \
-            goff += gstep; \
+            if (STORE) { __builtin_amdgcn_raw_buffer_store_b16(rec_, prs, goff, 0, FFHIP_AUX_SC1); goff += gstep; } \
             cellp[(j_) * NW * rows * TILE_STRIDE] = rec_; \
         } while (0)
         if (n >= 8 || lane < 16) {
@@ -611,6 +610,22 @@ __device__ __forceinline__ void intra_passes(const HotArgs &a, const GroupCtx &g
 #undef LEFT
 #undef TOP
 #undef U16
+}
+
+/* the plane stores of the passes wave `wv` of NW computed with STORE = false, from the tile, by whoever has the time */
+template <int LG, int NW>
+__device__ __forceinline__ void intra_store_passes(const GroupCtx &g, const IntraSlot &t, const int lane, const int wv, const short *__restrict__ tile)
+{
+    constexpr int n = 1 << LG, passes = n * n / 64, rows = 64 / n, mine = passes / NW;
+    const int x = lane & (n - 1), yl = (lane >> LG) + wv * rows;
+    int goff = (((int)t.y + yl) * g.stride + (int)t.x + x) * 2;
+    const int gstep = NW * rows * g.stride * 2;
+    const short *const cellp = tile + TILE_ORIGIN + ((int)t.y - g.wy0 + yl) * TILE_STRIDE + ((int)t.x - g.wx0 + x);
+#pragma unroll
+    for (int j = 0; j < mine; j++) {
+        __builtin_amdgcn_raw_buffer_store_b16(cellp[j * NW * rows * TILE_STRIDE], g.plane_rs, goff, 0, FFHIP_AUX_SC1);
+        goff += gstep;
+    }
 }
 
 template <int LG, int NW, class MID>
@@ -725,8 +740,10 @@ __device__ __forceinline__ void intra_tu_g(const HotArgs &a, const GroupCtx &g, 
     /* ---- 4 + 5. prediction and reconstruction: with helper waves (NW > 1) the passes of a 16x16 / 32x32 block are shared out
      * over the workgroup's waves -- they have no dependency on each other -- between two workgroup barriers ---- */
     if (NW > 1 && LG >= 4) wg_barrier(); /* A: the neighbours (s), the residual (R) and the tile are in LDS for everybody */
-    intra_passes<LG, (LG >= 4 ? NW : 1)>(a, g, t, lane, 0, s, R, tile, zero_block);
-    if (NW > 1 && LG >= 4) wg_barrier(); /* B: every wave's samples are in the tile, its stores have completed (the helpers drain theirs in front of it) */
+    /* with helpers the leader's passes go to the tile only: a helper writes them to the plane behind barrier B, and the helpers --
+     * not the leader -- drain their stores and publish the TU (see the helper loop), while the leader is at the next TU's gather */
+    intra_passes<LG, (LG >= 4 ? NW : 1), !(NW > 1 && LG >= 4)>(a, g, t, lane, 0, s, R, tile, zero_block);
+    if (NW > 1 && LG >= 4) wg_barrier(); /* B: every wave's samples are in the tile */
     STAMP(3);
 #undef LEFT
 #undef TOP
@@ -1136,6 +1153,7 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_hevc_intra_groups(HevcIntraArgs a)
 {
     __shared__ short tile[TILE_CELLS];
+    __shared__ u32 pub_cnt[2]; /* NW > 1: helpers that have yet to drain their stores of the big TU at hand (even / odd slot) */
     __shared__ u32 gstate[8]; /* NW > 1: wave 0 -> helpers: [0] 1 = a group follows / 0 = no more, [1..3] the group record, [4] abort */
     __shared__ int nbA[NB_MAX], nbB[NB_MAX];
     __shared__ __attribute__((aligned(16))) short resl[2][32 * 32];
@@ -1217,8 +1235,18 @@ __global__ __launch_bounds__(64 * NW) void k_hevc_intra_groups(HevcIntraArgs a)
                     if (SGPR(gstate[4])) return;
                     if (cur.lg == 4) intra_passes<4, NW>(hot, gc, cur, lane, wave, nbA, resl[k & 1], tile, resz);
                     else intra_passes<5, NW>(hot, gc, cur, lane, wave, nbA, resl[k & 1], tile, resz);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the leader publishes the TU behind barrier B: these stores are part of it */
-                    wg_barrier(); /* B */
+                    wg_barrier(); /* B: the leader goes on to the next TU; what follows is off its path */
+                    if (wave == 1) { /* the leader's passes, from the tile to the plane */
+                        if (cur.lg == 4) intra_store_passes<4, NW>(gc, cur, lane, 0, tile);
+                        else intra_store_passes<5, NW>(gc, cur, lane, 0, tile);
+                    }
+                    if (cur.signal) { /* somebody outside the group reads this TU: the helper whose stores complete last publishes it */
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        unsigned left = 0;
+                        if (lane == 0) left = __hip_atomic_fetch_sub(&pub_cnt[k & 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (lane == 0 && left == 1u && (int)cur.tu_index != a.debug_withhold)
+                            __hip_atomic_store(flags + cur.tu_index, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
                 wg_barrier(); /* C2: the leader is done with this chunk's slots */
                 if (SGPR(gstate[4])) return;
@@ -1475,9 +1503,11 @@ __global__ __launch_bounds__(64 * NW) void k_hevc_intra_groups(HevcIntraArgs a)
                         STAMP(3);
                         fetch_next_extras(); /* a program is short: behind it */
                     } else {
+                        if (NW > 1 && cur.lg >= 4 && cur.signal && lane == 0) pub_cnt[k & 1] = NW - 1; /* in LDS before barrier A; the helpers count it down */
                         intra_tu_g_any<NW>(hot, gc, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, resz, fetch_next_extras);
                     }
-                    if (cur.signal) { /* somebody outside the group reads this TU: publish it once its stores have completed */
+                    if (cur.signal && !(NW > 1 && !is_prog && cur.lg >= 4)) { /* somebody outside the group reads this TU: publish it once its stores have completed
+                                                                                  (the big TUs of the four-wave form are published by the helpers) */
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* compiler ordering; no L2-wide write-back */
                         /* the fence alone lowers to s_waitcnt lgkmcnt(0): the flag must not overtake the sample stores
                          * (MI355X_MICROARCH.md: every storing wave drains its vector-memory counter before it signals).

@@ -540,8 +540,10 @@ extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int fi
          * reasoning); next to the prediction kernel of the same call each of the two takes half of its own residency, so
          * filter waves -- which wait for the prediction's counters -- can never keep the prediction from becoming resident */
         const char *wv = FFHIP_ENV("FFHIP_VP8_LF_WAVES");
+        /* measured (256 x 1080p): the filter is at its best with two waves per SIMD and loses a factor of two with four (1024 / 2048 /
+         * 3584 waves: 1.95 / 1.86 / 3.4 ms -- its waves mostly wait, and waiting waves poll); next to the prediction one per SIMD does */
         long long resident = ffhip_resident_waves(filter_type == 1 ? (const void *)k_vp8_loopfilter_rows<1> : (const void *)k_vp8_loopfilter_rows<2>, 64);
-        if (pred_progress) resident = std::max<long long>(1, resident / 2);
+        resident = std::max<long long>(1, pred_progress ? resident / 4 : resident / 3);
         const long long wide = std::max<long long>(256, (long long)n_images * (mbcols / 4 + 2));
         const long long cap = wv ? std::max(1, atoi(wv)) : std::min(resident, wide);
         const dim3 grid((unsigned)std::min<long long>((long long)n_images * mbrows, cap));

@@ -95,7 +95,7 @@ def test_give_up_path_reports_eio_and_the_library_recovers(monkeypatch):
         ops.hevc_intra_recon(tus, res, w, h, True, 8, 8)           # the wrapper's stream sync sees the abort
     assert "-5" in str(ei.value)
     assert L.ffhip_stream_sync(None) == 0                           # reported once, then clear
-    monkeypatch.delenv("FFHIP_DEBUG_WITHHOLD_TU")
+    monkeypatch.delenv("FFHIP_DEBUG_WITHHOLD_TU"); capi.reload_env()
     L.ffhip_shutdown()
     capi.require_device()
     got = ops.hevc_intra_recon(tus, res, w, h, True, 8, 8)

@@ -56,7 +56,6 @@ struct HevcIntraArgs {
     int *async_err;           /* pinned host word (ffhip_async_err_word)                          */
     int n_groups;
     int debug_withhold;       /* test hook (FFHIP_DEBUG_WITHHOLD_TU): this TU's done flag is never published; -1 = off */
-    uint32_t form4_max_width; /* device-planned launches: lists whose wavefront is at most this wide take the four-wave form (0: never) */
     /* device-planned launches: the planner's verdict is read by the kernel, not by the host */
     const uint32_t *plan_result; /* {refused, number of groups, wait entries, -, widest wavefront}; NULL: n_groups above is the truth */
     uint32_t wait_cap;           /* wait entries the planner had room for                                        */
@@ -474,161 +473,7 @@ __device__ __forceinline__ void fetch_residual_g(const HotArgs &a, const IntraSl
         if (8 * lane + 512 * j < nn) rp.v[j] = *(const __attribute__((address_space(1))) u32x4 *)(src + 8 * lane + 512 * j);
 }
 
-__device__ __forceinline__ void wg_barrier()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-/* Prediction + reconstruction of one TU from the scan-order neighbours s (smoothed where 8.4.4.2.3 says so) and the residual R,
- * 64 samples a pass (the reference reads the neighbours as uint16_t and stores the prediction as int16 before the add).  One loop
- * per KIND of mode, chosen once: the first form decided planar / DC / angular, the direction and the sign of the angle again for
- * every pass, with 32-bit multiplies by +-1 and 64-bit address arithmetic in between -- ~75 instructions and several taken branches
- * a pass.  Here a pass of the angular loop is ~30 instructions: what changes from pass to pass moves by additions (rows per pass
- * are fixed), 24-bit multiplies, tile and plane offsets by immediate / one add.
- * NW waves share the passes: wave `wv` takes passes wv, wv + NW, ... (NW = 1: all of them). */
-template <int LG, int NW, bool STORE = true> /* STORE false: the samples go to the LDS tile only (somebody else writes them to the plane: intra_store_passes) */
-__device__ __forceinline__ void intra_passes(const HotArgs &a, const GroupCtx &g, const IntraSlot &t, const int lane, const int wv,
-                                             const int *__restrict__ s, const short *__restrict__ R, short *__restrict__ tile,
-                                             const short *__restrict__ zero_block)
-{
-    constexpr int n = 1 << LG, lg = LG;
-    const int x0 = (int)t.x, y0 = (int)t.y;
-    const int wx0 = g.wx0, wy0 = g.wy0;
-    const int cidx = g.cidx, mode = (int)t.mode, flags = (int)t.flags;
-    const int bd = cidx == 0 ? a.bitdepth_y : a.bitdepth_c;
-    const int stride = g.stride;
-    const __amdgpu_buffer_rsrc_t prs = g.plane_rs;
-    const bool has_res = (flags & 2) != 0;
-#define LEFT(y) s[2 * n - 1 - (y)]
-#define TOP(x) s[2 * n + 1 + (x)] /* TOP(-1) is the corner */
-#define U16(v) ((int)((unsigned)(v) & 0xffffu))
-    {
-        constexpr int passes = n * n >= 64 ? n * n / 64 : 1, rows = n >= 8 ? 64 / n : 4; /* rows of the block per pass */
-        static_assert(passes % NW == 0, "the waves share the passes evenly");
-        constexpr int mine = passes / NW; /* passes of this wave */
-        constexpr int unroll = mine > 4 ? 4 : mine; /* 32x32 on one wave: sixteen passes, four to a loop body (the kernel's code must stay inside the instruction cache) */
-        const bool edge_ok = cidx == 0 && n < 32;
-        const int maxv = (1 << bd) - 1;
-        const int x = lane & (n - 1), yl = (lane >> lg) + wv * rows; /* the lane's sample in this wave's first pass; later passes: y += NW * rows */
-        int goff = ((y0 + yl) * stride + x0 + x) * 2;  /* plane byte offset, stepped by gstep per pass */
-        const int gstep = NW * rows * stride * 2;
-        /* the window copy is written without asking whether the sample lies in the window: a TU larger than its window
-         * (it then starts at the window's origin) spills into cells right of and below the window that nobody reads --
-         * halo cells are row 0 and column 0 only -- and the layout has room for a 32x32 block from any window origin */
-        short *const cellp = tile + TILE_ORIGIN + (y0 - wy0 + yl) * TILE_STRIDE + (x0 - wx0 + x);
-        const short *const Rr = (has_res ? R : zero_block) + lane + 64 * wv; /* no residual: a block of zeros, no branch per pass */
-#define EMIT(v_, j_) do { \
-            const int pr_ = (int)(short)((v_) & 0xffff); \
-            const short rec_ = (short)clip3i(0, maxv, pr_ + (int)Rr[64 * NW * (j_)]); \
-            if (STORE) { __builtin_amdgcn_raw_buffer_store_b16(rec_, prs, goff, 0, FFHIP_AUX_SC1); goff += gstep; } \
-            cellp[(j_) * NW * rows * TILE_STRIDE] = rec_; \
-        } while (0)
-        if (n >= 8 || lane < 16) {
-            if (mode == 0) {
-                const int tn = U16(TOP(n)), ln = U16(LEFT(n)), tx = U16(TOP(x));
-                const int fixed = (x + 1) * tn + n; /* the part of the sum that does not change from pass to pass */
-#pragma unroll unroll
-                for (int j = 0; j < mine; j++) {
-                    const int y = yl + j * NW * rows;
-                    const int v = ((n - 1 - x) * U16(LEFT(y)) + fixed + (n - 1 - y) * tx + (y + 1) * ln) >> (lg + 1);
-                    EMIT(v, j);
-                }
-            } else if (mode == 1) {
-                /* the 2n-sample sum: one element per lane, added across the wave */
-                const int e = lane < n ? U16(LEFT(lane)) : (lane < 2 * n ? U16(TOP(lane - n)) : 0);
-                const int rsum = row_sum16(e); /* n = 4: lanes 8 .. 15 hold 0 */
-                int sum = __builtin_amdgcn_readlane(rsum, 0);
-                if (n >= 16) sum += __builtin_amdgcn_readlane(rsum, 16);
-                if (n == 32) sum += __builtin_amdgcn_readlane(rsum, 32) + __builtin_amdgcn_readlane(rsum, 48);
-                const int dc = (sum + n) >> (lg + 1);
-                if (edge_ok && !(flags & 0x20)) {
-                    const int tx = U16(TOP(x));
-#pragma unroll unroll
-                    for (int j = 0; j < mine; j++) {
-                        const int y = yl + j * NW * rows;
-                        int v = dc;
-                        if (x == 0) v = y == 0 ? (U16(LEFT(0)) + 2 * dc + tx + 2) >> 2 : (U16(LEFT(y)) + 3 * dc + 2) >> 2;
-                        else if (y == 0) v = (tx + 3 * dc + 2) >> 2;
-                        EMIT(v, j);
-                    }
-                } else {
-#pragma unroll unroll
-                    for (int j = 0; j < mine; j++) EMIT(dc, j);
-                }
-            } else {
-                const int angle = intra_angle(mode);
-                const bool vert = mode >= 18; /* the top row is the main reference: scan positions grow with the ref index */
-                const int sg4 = vert ? 4 : -4; /* bytes per step of the ref index in the scan-order array */
-                int al = vert ? yl : x, ac = vert ? x : yl; /* along / across the direction */
-                const int dal = vert ? NW * rows : 0, dac = vert ? 0 : NW * rows;
-                const char *const sc = (const char *)(s + 2 * n); /* the corner: ref[k] is at sc + sg4 * k for k >= 0 */
-#define TAP(q_) U16(*(const int *)(sc + __mul24((q_), sg4)))
-                const bool e26 = edge_ok && !(flags & 0x10) && mode == 26, e10 = edge_ok && !(flags & 0x10) && mode == 10;
-                if (e26 || e10) { /* pure vertical / horizontal with the boundary filter (angle 0: one tap) */
-                    const int corner = U16(TOP(-1)), first = e26 ? U16(TOP(0)) : U16(LEFT(0));
-#pragma unroll unroll
-                    for (int j = 0; j < mine; j++) {
-                        const int y = yl + j * NW * rows;
-                        int v = e26 ? U16(TOP(x)) : U16(LEFT(y));
-                        if (e26 && x == 0) v = clip3i(0, (1 << a.bitdepth_y) - 1, first + ((U16(LEFT(y)) - corner) >> 1));
-                        if (e10 && y == 0) v = clip3i(0, (1 << a.bitdepth_y) - 1, first + ((U16(TOP(x)) - corner) >> 1));
-                        EMIT(v, j);
-                    }
-                } else if (angle >= 0) {
-#pragma unroll unroll
-                    for (int j = 0; j < mine; j++) {
-                        const int prod = __mul24(al + 1, angle), fact = prod & 31, k0 = ac + (prod >> 5) + 1;
-                        /* fact == 0: the second tap has weight 0 (it may lie one past the array: any finite value does) */
-                        const int v = ((32 - fact) * TAP(k0) + fact * TAP(k0 + 1) + 16) >> 5;
-                        EMIT(v, j);
-                        al += dal;
-                        ac += dac;
-                    }
-                } else {
-                    const int inv = intra_inv_angle(mode);
-#pragma unroll unroll
-                    for (int j = 0; j < mine; j++) {
-                        const int prod = __mul24(al + 1, angle), fact = prod & 31, k0 = ac + (prod >> 5) + 1;
-                        /* 8.4.4.2.6: negative indices come from the other side through the inverse angle */
-                        /* both forms computed, one v_cndmask: as a conditional the compiler wrapped the multiply in an exec-mask
-                         * region, which ends the basic block -- and with it any overlap of this pass's LDS reads with the next one's */
-                        const int q0 = neg_select(k0, -((__mul24(k0, inv) + 128) >> 8));
-                        const int q1 = neg_select(k0 + 1, -((__mul24(k0 + 1, inv) + 128) >> 8));
-                        const int v = ((32 - fact) * TAP(q0) + fact * TAP(q1) + 16) >> 5;
-                        EMIT(v, j);
-                        al += dal;
-                        ac += dac;
-                    }
-                }
-#undef TAP
-            }
-        }
-#undef EMIT
-    }
-#undef LEFT
-#undef TOP
-#undef U16
-}
-
-/* the plane stores of the passes wave `wv` of NW computed with STORE = false, from the tile, by whoever has the time */
-template <int LG, int NW>
-__device__ __forceinline__ void intra_store_passes(const GroupCtx &g, const IntraSlot &t, const int lane, const int wv, const short *__restrict__ tile)
-{
-    constexpr int n = 1 << LG, passes = n * n / 64, rows = 64 / n, mine = passes / NW;
-    const int x = lane & (n - 1), yl = (lane >> LG) + wv * rows;
-    int goff = (((int)t.y + yl) * g.stride + (int)t.x + x) * 2;
-    const int gstep = NW * rows * g.stride * 2;
-    const short *const cellp = tile + TILE_ORIGIN + ((int)t.y - g.wy0 + yl) * TILE_STRIDE + ((int)t.x - g.wx0 + x);
-#pragma unroll
-    for (int j = 0; j < mine; j++) {
-        __builtin_amdgcn_raw_buffer_store_b16(cellp[j * NW * rows * TILE_STRIDE], g.plane_rs, goff, 0, FFHIP_AUX_SC1);
-        goff += gstep;
-    }
-}
-
-template <int LG, int NW, class MID>
+template <int LG, class MID>
 __device__ __forceinline__ void intra_tu_g(const HotArgs &a, const GroupCtx &g, const IntraSlot &t, const int lane, int *__restrict__ s, int *__restrict__ s2, short *__restrict__ R,
                                            const ResPrefetch &rp, const JPrefetch &jp, short *__restrict__ tile, const short *__restrict__ zero_block, MID &&mid)
 {
@@ -737,13 +582,115 @@ __device__ __forceinline__ void intra_tu_g(const HotArgs &a, const GroupCtx &g, 
     }
 
     STAMP(2);
-    /* ---- 4 + 5. prediction and reconstruction: with helper waves (NW > 1) the passes of a 16x16 / 32x32 block are shared out
-     * over the workgroup's waves -- they have no dependency on each other -- between two workgroup barriers ---- */
-    if (NW > 1 && LG >= 4) wg_barrier(); /* A: the neighbours (s), the residual (R) and the tile are in LDS for everybody */
-    /* with helpers the leader's passes go to the tile only: a helper writes them to the plane behind barrier B, and the helpers --
-     * not the leader -- drain their stores and publish the TU (see the helper loop), while the leader is at the next TU's gather */
-    intra_passes<LG, (LG >= 4 ? NW : 1), !(NW > 1 && LG >= 4)>(a, g, t, lane, 0, s, R, tile, zero_block);
-    if (NW > 1 && LG >= 4) wg_barrier(); /* B: every wave's samples are in the tile */
+    /* ---- 4 + 5. prediction and reconstruction, 64 samples a pass (the reference reads the neighbours as uint16_t and
+     * stores the prediction as int16 before the add).  One loop per KIND of mode, chosen once: the first form decided
+     * planar / DC / angular, the direction and the sign of the angle again for every pass, with 32-bit multiplies by
+     * +-1 and 64-bit address arithmetic in between -- ~75 instructions and several taken branches a pass.  Here a pass
+     * of the angular loop is ~30 instructions: what changes from pass to pass moves by additions (rows per pass are
+     * fixed), 24-bit multiplies, tile and plane offsets by immediate / one add. ---- */
+#define U16(v) ((int)((unsigned)(v) & 0xffffu))
+    {
+        constexpr int passes = n * n >= 64 ? n * n / 64 : 1, rows = n >= 8 ? 64 / n : 4; /* rows of the block per pass */
+        constexpr int unroll = passes > 4 ? 4 : passes; /* 32x32: sixteen passes, four to a loop body (the kernel's code must stay inside the instruction cache) */
+        const bool edge_ok = cidx == 0 && n < 32;
+        const int maxv = (1 << bd) - 1;
+        const int x = lane & (n - 1), yl = lane >> lg; /* the lane's sample in pass 0; later passes: y = yl + pass * rows */
+        int goff = ((y0 + yl) * stride + x0 + x) * 2;  /* plane byte offset, stepped by gstep per pass */
+        const int gstep = rows * stride * 2;
+        /* the window copy is written without asking whether the sample lies in the window: a TU larger than its window
+         * (it then starts at the window's origin) spills into cells right of and below the window that nobody reads --
+         * halo cells are row 0 and column 0 only -- and the layout has room for a 32x32 block from any window origin */
+        short *const cellp = tile + TILE_ORIGIN + (y0 - wy0 + yl) * TILE_STRIDE + (x0 - wx0 + x);
+        const short *const Rr = has_res ? R + lane : zero_block + lane; /* no residual: a block of zeros, no branch per pass */
+#define EMIT(v_, pass_) do { \
+            const int pr_ = (int)(short)((v_) & 0xffff); \
+            const short rec_ = (short)clip3i(0, maxv, pr_ + (int)Rr[64 * (pass_)]); \
+            __builtin_amdgcn_raw_buffer_store_b16(rec_, prs, goff, 0, FFHIP_AUX_SC1); \
+            goff += gstep; \
+            cellp[(pass_) * rows * TILE_STRIDE] = rec_; \
+        } while (0)
+        if (n >= 8 || lane < 16) {
+            if (mode == 0) {
+                const int tn = U16(TOP(n)), ln = U16(LEFT(n)), tx = U16(TOP(x));
+                const int fixed = (x + 1) * tn + n; /* the part of the sum that does not change from pass to pass */
+#pragma unroll unroll
+                for (int pass = 0; pass < passes; pass++) {
+                    const int y = yl + pass * rows;
+                    const int v = ((n - 1 - x) * U16(LEFT(y)) + fixed + (n - 1 - y) * tx + (y + 1) * ln) >> (lg + 1);
+                    EMIT(v, pass);
+                }
+            } else if (mode == 1) {
+                /* the 2n-sample sum: one element per lane, added across the wave */
+                const int e = lane < n ? U16(LEFT(lane)) : (lane < 2 * n ? U16(TOP(lane - n)) : 0);
+                const int rsum = row_sum16(e); /* n = 4: lanes 8 .. 15 hold 0 */
+                int sum = __builtin_amdgcn_readlane(rsum, 0);
+                if (n >= 16) sum += __builtin_amdgcn_readlane(rsum, 16);
+                if (n == 32) sum += __builtin_amdgcn_readlane(rsum, 32) + __builtin_amdgcn_readlane(rsum, 48);
+                const int dc = (sum + n) >> (lg + 1);
+                if (edge_ok && !(flags & 0x20)) {
+                    const int tx = U16(TOP(x));
+#pragma unroll unroll
+                    for (int pass = 0; pass < passes; pass++) {
+                        const int y = yl + pass * rows;
+                        int v = dc;
+                        if (x == 0) v = y == 0 ? (U16(LEFT(0)) + 2 * dc + tx + 2) >> 2 : (U16(LEFT(y)) + 3 * dc + 2) >> 2;
+                        else if (pass == 0 && y == 0) v = (tx + 3 * dc + 2) >> 2;
+                        EMIT(v, pass);
+                    }
+                } else {
+#pragma unroll unroll
+                    for (int pass = 0; pass < passes; pass++) EMIT(dc, pass);
+                }
+            } else {
+                const int angle = intra_angle(mode);
+                const bool vert = mode >= 18; /* the top row is the main reference: scan positions grow with the ref index */
+                const int sg4 = vert ? 4 : -4; /* bytes per step of the ref index in the scan-order array */
+                int al = vert ? yl : x, ac = vert ? x : yl; /* along / across the direction */
+                const int dal = vert ? rows : 0, dac = vert ? 0 : rows;
+                const char *const sc = (const char *)(s + 2 * n); /* the corner: ref[k] is at sc + sg4 * k for k >= 0 */
+#define TAP(q_) U16(*(const int *)(sc + __mul24((q_), sg4)))
+                const bool e26 = edge_ok && !(flags & 0x10) && mode == 26, e10 = edge_ok && !(flags & 0x10) && mode == 10;
+                if (e26 || e10) { /* pure vertical / horizontal with the boundary filter (angle 0: one tap) */
+                    const int corner = U16(TOP(-1)), first = e26 ? U16(TOP(0)) : U16(LEFT(0));
+#pragma unroll unroll
+                    for (int pass = 0; pass < passes; pass++) {
+                        const int y = yl + pass * rows;
+                        int v = e26 ? U16(TOP(x)) : U16(LEFT(y));
+                        if (e26 && x == 0) v = clip3i(0, (1 << a.bitdepth_y) - 1, first + ((U16(LEFT(y)) - corner) >> 1));
+                        if (e10 && pass == 0 && y == 0) v = clip3i(0, (1 << a.bitdepth_y) - 1, first + ((U16(TOP(x)) - corner) >> 1));
+                        EMIT(v, pass);
+                    }
+                } else if (angle >= 0) {
+#pragma unroll unroll
+                    for (int pass = 0; pass < passes; pass++) {
+                        const int prod = __mul24(al + 1, angle), fact = prod & 31, k0 = ac + (prod >> 5) + 1;
+                        /* fact == 0: the second tap has weight 0 (it may lie one past the array: any finite value does) */
+                        const int v = ((32 - fact) * TAP(k0) + fact * TAP(k0 + 1) + 16) >> 5;
+                        EMIT(v, pass);
+                        al += dal;
+                        ac += dac;
+                    }
+                } else {
+                    const int inv = intra_inv_angle(mode);
+#pragma unroll unroll
+                    for (int pass = 0; pass < passes; pass++) {
+                        const int prod = __mul24(al + 1, angle), fact = prod & 31, k0 = ac + (prod >> 5) + 1;
+                        /* 8.4.4.2.6: negative indices come from the other side through the inverse angle */
+                        /* both forms computed, one v_cndmask: as a conditional the compiler wrapped the multiply in an exec-mask
+                         * region, which ends the basic block -- and with it any overlap of this pass's LDS reads with the next one's */
+                        const int q0 = neg_select(k0, -((__mul24(k0, inv) + 128) >> 8));
+                        const int q1 = neg_select(k0 + 1, -((__mul24(k0 + 1, inv) + 128) >> 8));
+                        const int v = ((32 - fact) * TAP(q0) + fact * TAP(q1) + 16) >> 5;
+                        EMIT(v, pass);
+                        al += dal;
+                        ac += dac;
+                    }
+                }
+#undef TAP
+            }
+        }
+#undef EMIT
+    }
     STAMP(3);
 #undef LEFT
 #undef TOP
@@ -965,15 +912,15 @@ __global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
     }
 }
 
-template <int NW, class MID>
+template <class MID>
 __device__ __forceinline__ void intra_tu_g_any(const HotArgs &a, const GroupCtx &g, const IntraSlot &t, const int lane, int *s, int *s2, short *R,
                                                const ResPrefetch &rp, const JPrefetch &jp, short *tile, const short *zero_block, MID &&mid)
 {
     switch (t.lg) {
-    case 2: intra_tu_g<2, NW>(a, g, t, lane, s, s2, R, rp, jp, tile, zero_block, mid); break;
-    case 3: intra_tu_g<3, NW>(a, g, t, lane, s, s2, R, rp, jp, tile, zero_block, mid); break;
-    case 4: intra_tu_g<4, NW>(a, g, t, lane, s, s2, R, rp, jp, tile, zero_block, mid); break;
-    default: intra_tu_g<5, NW>(a, g, t, lane, s, s2, R, rp, jp, tile, zero_block, mid); break;
+    case 2: intra_tu_g<2>(a, g, t, lane, s, s2, R, rp, jp, tile, zero_block, mid); break;
+    case 3: intra_tu_g<3>(a, g, t, lane, s, s2, R, rp, jp, tile, zero_block, mid); break;
+    case 4: intra_tu_g<4>(a, g, t, lane, s, s2, R, rp, jp, tile, zero_block, mid); break;
+    default: intra_tu_g<5>(a, g, t, lane, s, s2, R, rp, jp, tile, zero_block, mid); break;
     }
 }
 
@@ -1133,7 +1080,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_serial(HevcIntraArgs a)
             sg.cidx = (int)cur.cidx; sg.wl = 6; sg.wx0 = (int)(cur.x >> 6) << 6; sg.wy0 = (int)(cur.y >> 6) << 6;
             sg.stride = sg.cidx == 0 ? a.stride[0] : (sg.cidx == 1 ? a.stride[1] : a.stride[2]);
             sg.plane_rs = ffhip_rsrc(sg.cidx == 0 ? a.plane[0] : (sg.cidx == 1 ? a.plane[1] : a.plane[2]), 0xffffffffu);
-            intra_tu_g_any<1>(hot, sg, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, resz, [] {});
+            intra_tu_g_any(hot, sg, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, resz, [] {});
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the next TU may read these samples back from memory */
             wave_sync();
         }
@@ -1141,37 +1088,23 @@ __global__ __launch_bounds__(64) void k_hevc_intra_serial(HevcIntraArgs a)
     }
 }
 
-/* NW = 1: a workgroup is one wave (the throughput form: as many groups in flight as the chip holds waves of this size).
- * NW = 4: a workgroup is four waves on the four SIMDs of a CU, ONE group at a time (the latency form).  Wave 0 is the wave of the
- * NW = 1 form; waves 1-3 follow it through the schedule by the slot words in LDS -- scalar bookkeeping on SIMDs of their own, no
- * memory traffic -- and join it for the passes of every generic 16x16 / 32x32 TU: the 4 / 16 passes of such a block have no
- * dependency on each other, and a 32x32 TU was sixteen passes on one wave while three SIMDs of the CU idled.  Two workgroup
- * barriers per such TU (neighbours + residual ready; samples written), one per chunk of slots and per group.  Which form runs is
- * decided ON THE DEVICE from the planner's wavefront width (both kernels are enqueued; the one that is not wanted returns at once):
- * a picture whose wavefront fits the chip four times over takes NW = 4, a grid of many independent tiles NW = 1. */
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_hevc_intra_groups(HevcIntraArgs a)
+__global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
 {
     __shared__ short tile[TILE_CELLS];
-    __shared__ u32 pub_cnt[2]; /* NW > 1: helpers that have yet to drain their stores of the big TU at hand (even / odd slot) */
-    __shared__ u32 gstate[8]; /* NW > 1: wave 0 -> helpers: [0] 1 = a group follows / 0 = no more, [1..3] the group record, [4] abort */
     __shared__ int nbA[NB_MAX], nbB[NB_MAX];
     __shared__ __attribute__((aligned(16))) short resl[2][32 * 32];
     __shared__ __attribute__((aligned(16))) short resz[32 * 32]; /* zeros: the residual of a TU without one */
     __shared__ u32x4 slots[(SLOT_CHUNK + 2) * 3];
-    const int lane = threadIdx.x & 63;
-    const int wave = NW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int lane = threadIdx.x;
     uint32_t *flags = a.ctrl + 4;
     int n_groups = a.n_groups;
-    if (threadIdx.x == 0) {
-        gstate[4] = 0;
+    if (lane == 0) {
         tile[TILE_CONST_Y] = (short)(1 << (a.bitdepth_y - 1));
         tile[TILE_CONST_C] = (short)(1 << (a.bitdepth_c - 1));
         tile[TILE_ZERO] = 0;
     }
-    for (int i = (int)threadIdx.x; i < 32 * 32 / 8; i += 64 * NW) ((u32x4 *)resz)[i] = u32x4{0u, 0u, 0u, 0u};
-    if (NW > 1) wg_barrier();
-    else wave_sync();
+    for (int i = lane; i < 32 * 32 / 8; i += 64) ((u32x4 *)resz)[i] = u32x4{0u, 0u, 0u, 0u};
+    wave_sync();
     HotArgs hot;
     {
         unsigned long long p_res = (unsigned long long)a.residual, p_jt = (unsigned long long)a.jt, p_wait = (unsigned long long)a.wait_idx;
@@ -1195,9 +1128,6 @@ __global__ __launch_bounds__(64 * NW) void k_hevc_intra_groups(HevcIntraArgs a)
          * 1024 waves: 6.5 ms, on 256: 5.9). */
         const uint32_t width = a.plan_result[4];
         if (width && blockIdx.x >= (width + (width >> 2) + 16 > 256u ? width + (width >> 2) + 16 : 256u)) return;
-        /* latency form or throughput form (see the kernel's head): both are in the stream, one of them works */
-        const bool want4 = a.form4_max_width != 0 && width != 0 && width <= a.form4_max_width;
-        if (want4 != (NW > 1)) return;
     }
     const __amdgpu_buffer_rsrc_t desc_rs = ffhip_rsrc(a.desc, 0xffffffffu), res_rs = ffhip_rsrc((const void *)hot.residual, PROG_NO_RESIDUAL);
     const int cell_lane4 = 2 * ((lane >> 2) * TILE_STRIDE + (lane & 3)), cell_lane8 = 2 * ((lane >> 3) * TILE_STRIDE + (lane & 7));
@@ -1206,70 +1136,13 @@ __global__ __launch_bounds__(64 * NW) void k_hevc_intra_groups(HevcIntraArgs a)
      * same words, same residual, same value to the same addresses */
     const int lane4 = lane < 16 ? lane : 0;
     const int cell_alias4 = 2 * ((lane4 >> 2) * TILE_STRIDE + (lane4 & 3));
-    if (NW > 1 && wave != 0) {
-        /* ---- helper waves: the leader's schedule, read from LDS; work only in the passes of the big generic TUs ---- */
-        for (;;) {
-            wg_barrier(); /* G: the leader has a group (or none) */
-            if (SGPR(gstate[4]) || !SGPR(gstate[0])) return;
-            const unsigned gy = SGPR(gstate[2]);
-            GroupCtx gc = {};
-            gc.wl = (int)SGPR(gstate[3]);
-            for (unsigned base = 0; base < gy; base += SLOT_CHUNK) {
-                const int m = (int)(gy - base < SLOT_CHUNK ? gy - base : SLOT_CHUNK);
-                wg_barrier(); /* C1: this chunk's slots are in LDS */
-                if (SGPR(gstate[4])) return;
-                if (base == 0) {
-                    const unsigned d0 = SGPR(slots[0].x), d1 = SGPR(slots[0].y);
-                    gc.cidx = (int)((d1 >> 8) & 0xff);
-                    gc.wx0 = (int)(((d0 & 0xffff) >> gc.wl) << gc.wl);
-                    gc.wy0 = (int)(((d0 >> 16) >> gc.wl) << gc.wl);
-                    gc.stride = gc.cidx == 0 ? a.stride[0] : (gc.cidx == 1 ? a.stride[1] : a.stride[2]);
-                    gc.maxv = (1 << (gc.cidx == 0 ? hot.bitdepth_y : hot.bitdepth_c)) - 1;
-                    gc.plane_rs = ffhip_rsrc(gc.cidx == 0 ? a.plane[0] : (gc.cidx == 1 ? a.plane[1] : a.plane[2]), 0xffffffffu);
-                }
-                for (int k = 0; k < m; k++) {
-                    const unsigned q1x = SGPR(slots[3 * k + 1].x), q0y = SGPR(slots[3 * k].y);
-                    if (PK_KIND(q1x) != PROG_GENERIC || (q0y & 0xff) < 4) continue; /* the leader's alone */
-                    const IntraSlot cur = decode_slot(slots[3 * k], slots[3 * k + 2]);
-                    wg_barrier(); /* A */
-                    if (SGPR(gstate[4])) return;
-                    if (cur.lg == 4) intra_passes<4, NW>(hot, gc, cur, lane, wave, nbA, resl[k & 1], tile, resz);
-                    else intra_passes<5, NW>(hot, gc, cur, lane, wave, nbA, resl[k & 1], tile, resz);
-                    wg_barrier(); /* B: the leader goes on to the next TU; what follows is off its path */
-                    if (wave == 1) { /* the leader's passes, from the tile to the plane */
-                        if (cur.lg == 4) intra_store_passes<4, NW>(gc, cur, lane, 0, tile);
-                        else intra_store_passes<5, NW>(gc, cur, lane, 0, tile);
-                    }
-                    if (cur.signal) { /* somebody outside the group reads this TU: the helper whose stores complete last publishes it */
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        unsigned left = 0;
-                        if (lane == 0) left = __hip_atomic_fetch_sub(&pub_cnt[k & 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (lane == 0 && left == 1u && (int)cur.tu_index != a.debug_withhold)
-                            __hip_atomic_store(flags + cur.tu_index, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                wg_barrier(); /* C2: the leader is done with this chunk's slots */
-                if (SGPR(gstate[4])) return;
-            }
-        }
-    }
     bool dead = false; /* a wave that gave up waiting (bounded spin): leaves through the loop heads, not from inside them */
     while (!dead) {
         unsigned ticket = 0;
         if (lane == 0) ticket = __hip_atomic_fetch_add(&a.ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
-        if (ticket >= (unsigned)n_groups) {
-            if (NW > 1) { /* the helpers leave with the leader */
-                if (lane == 0) gstate[0] = 0u;
-                wg_barrier();
-            }
-            break;
-        }
+        if (ticket >= (unsigned)n_groups) break;
         const u32x4 g = a.groups[ticket];
-        if (NW > 1) {
-            if (lane == 0) { gstate[0] = 1u; gstate[1] = g.x; gstate[2] = g.y; gstate[3] = g.z; }
-            wg_barrier(); /* G */
-        }
         GroupCtx gc;
         int plane_alias4 = 0, desc_alias4 = 0;
         gc.wl = (int)g.z;
@@ -1285,7 +1158,6 @@ __global__ __launch_bounds__(64 * NW) void k_hevc_intra_groups(HevcIntraArgs a)
                 slots[3 * m + 4] = end;
             }
             wave_sync();
-            if (NW > 1) wg_barrier(); /* C1 */
             if (base == 0) { /* the group's plane and window, from its first TU */
                 const unsigned d0 = SGPR(slots[0].x), d1 = SGPR(slots[0].y);
                 gc.cidx = (int)((d1 >> 8) & 0xff);
@@ -1503,11 +1375,9 @@ __global__ __launch_bounds__(64 * NW) void k_hevc_intra_groups(HevcIntraArgs a)
                         STAMP(3);
                         fetch_next_extras(); /* a program is short: behind it */
                     } else {
-                        if (NW > 1 && cur.lg >= 4 && cur.signal && lane == 0) pub_cnt[k & 1] = NW - 1; /* in LDS before barrier A; the helpers count it down */
-                        intra_tu_g_any<NW>(hot, gc, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, resz, fetch_next_extras);
+                        intra_tu_g_any(hot, gc, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, resz, fetch_next_extras);
                     }
-                    if (cur.signal && !(NW > 1 && !is_prog && cur.lg >= 4)) { /* somebody outside the group reads this TU: publish it once its stores have completed
-                                                                                  (the big TUs of the four-wave form are published by the helpers) */
+                    if (cur.signal) { /* somebody outside the group reads this TU: publish it once its stores have completed */
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* compiler ordering; no L2-wide write-back */
                         /* the fence alone lowers to s_waitcnt lgkmcnt(0): the flag must not overtake the sample stores
                          * (MI355X_MICROARCH.md: every storing wave drains its vector-memory counter before it signals).
@@ -1533,12 +1403,7 @@ __global__ __launch_bounds__(64 * NW) void k_hevc_intra_groups(HevcIntraArgs a)
                 if (dead) break;
             }
             wave_sync(); /* slots[] is about to be overwritten */
-            if (NW > 1 && !dead) wg_barrier(); /* C2 */
         }
-    }
-    if (NW > 1 && dead) { /* the helpers wait at one of their barriers: they see the abort word behind it and leave */
-        if (lane == 0) gstate[4] = 1u;
-        wg_barrier();
     }
 }
 #undef SGPR
@@ -1927,7 +1792,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
         /* device-planned launches start as many waves as can be resident and trim themselves to the planner's wavefront width
          * (k_hevc_intra_groups); host-planned ones keep the flat cap */
         const size_t max_waves = wv ? (size_t)std::max(1, atoi(wv)) : FFHIP_HEVC_INTRA_WAVES;
-        const size_t resident_waves = wv ? max_waves : (size_t)std::max(FFHIP_HEVC_INTRA_WAVES, ffhip_resident_waves((const void *)k_hevc_intra_groups<1>, 64));
+        const size_t resident_waves = wv ? max_waves : (size_t)std::max(FFHIP_HEVC_INTRA_WAVES, ffhip_resident_waves((const void *)k_hevc_intra_groups, 64));
         /* the schedule: built on the device (ffhip_hevc_plan_gpu.hip) unless FFHIP_HEVC_PLAN=host; lists whose groups are
          * not contiguous runs of the decode order come back from there and take the host planner with its window search */
         const char *pe = FFHIP_ENV("FFHIP_HEVC_PLAN");
@@ -1975,14 +1840,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
 #ifdef FFHIP_INTRA_TRACE
             a.trace = g_intra_trace;
 #endif
-            /* both forms are enqueued; each looks at the planner's wavefront width and one of them returns at once (see the kernel's head).
-             * The four-wave form is for lists whose wavefront fits the workgroups of that size the chip holds at once */
-            const char *f4 = FFHIP_ENV("FFHIP_HEVC_INTRA_FORM4"); /* "0": never, "1": always (A/B), default: by the width */
-            const size_t resident4 = (size_t)std::max(64, ffhip_resident_waves((const void *)k_hevc_intra_groups<4>, 256));
-            a.form4_max_width = f4 ? (f4[0] == '0' ? 0u : 0x7fffffffu) : (uint32_t)(resident4 - resident4 / 4);
-            if (wv) a.form4_max_width = f4 && f4[0] == '1' ? 0x7fffffffu : 0u; /* an explicit wave count (tests) means the one-wave form */
-            hipLaunchKernelGGL(k_hevc_intra_groups<1>, dim3((unsigned)std::min<size_t>((size_t)n_tus, resident_waves)), dim3(64), 0, st, a);
-            if (a.form4_max_width) hipLaunchKernelGGL(k_hevc_intra_groups<4>, dim3((unsigned)std::min<size_t>((size_t)n_tus, wv ? max_waves : resident4)), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(k_hevc_intra_groups, dim3((unsigned)std::min<size_t>((size_t)n_tus, resident_waves)), dim3(64), 0, st, a);
             hipLaunchKernelGGL(k_hevc_intra_serial, dim3(1), dim3(64), 0, st, a); /* does something only for a list the planner refused */
             FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
             return FFHIP_OK;
@@ -2015,7 +1873,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
                 enqueue_programs(jt_words + w_jt, win, (size_t)n_tus);
             }
             const unsigned wgs = (unsigned)std::min<size_t>(plan.groups.size(), max_waves); /* one wave each; waves loop over tickets */
-            hipLaunchKernelGGL(k_hevc_intra_groups<1>, dim3(wgs), dim3(64), 0, st, a);
+            hipLaunchKernelGGL(k_hevc_intra_groups, dim3(wgs), dim3(64), 0, st, a);
             FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
             return FFHIP_OK;
         }

@@ -104,14 +104,11 @@ def _intra_full_picture(W, H, tus, res):
     return exp
 
 
-@pytest.mark.parametrize("form4", [None, "0"])
 @pytest.mark.parametrize("mix,seed", [(None, 2), ("c5", 5)])
-def test_c5_8k_intra_picture(mix, seed, form4, monkeypatch):
+def test_c5_8k_intra_picture(mix, seed):
     """BASELINE configs[4]: ffhip_hevc_intra_recon on one 7680x4352 picture against ffo_hevc_intra_recon over the whole
     planes.  mix=None is the random quadtree down to 4x4 (~700 k TUs: the device planner's radix sort and scans and the
     32-bit offset guard at full size); "c5" is SURVEY 8d's mix (luma 32/16 at 60/40, chroma 16/8)."""
-    if form4 is not None:            # default: the device picks the form from the wavefront width (an 8K picture: four waves per group); "0": one wave per group
-        monkeypatch.setenv("FFHIP_HEVC_INTRA_FORM4", form4); capi.reload_env()
     W, H = 7680, 4352
     tus, res = synth.hevc_intra_tus(W, H, seed=seed, tu_mix=mix)
     assert len(tus) > (600_000 if mix is None else 40_000)

@@ -72,10 +72,7 @@ def test_every_mode_and_size_isolated():
 @pytest.mark.parametrize("env", [{"FFHIP_HEVC_INTRA_MODE": "levels"}, {"FFHIP_HEVC_PLAN": "host"}, {"FFHIP_HEVC_PLAN": "host", "FFHIP_HEVC_INTRA_WINDOW": "4"},
                                  {"FFHIP_HEVC_INTRA_WINDOW": "3"},
                                  {"FFHIP_HEVC_INTRA_WINDOW": "4"}, {"FFHIP_HEVC_INTRA_WINDOW": "5"},
-                                 {"FFHIP_HEVC_INTRA_WINDOW": "6"},
-                                 # the two forms of the grouped kernel (four waves on a CU per group / one wave per group), forced either way
-                                 {"FFHIP_HEVC_INTRA_FORM4": "1"}, {"FFHIP_HEVC_INTRA_FORM4": "0"}, {"FFHIP_HEVC_INTRA_FORM4": "1", "FFHIP_HEVC_INTRA_WINDOW": "5"},
-                                 {"FFHIP_HEVC_INTRA_FORM4": "1", "FFHIP_HEVC_INTRA_WAVES": "3"}])
+                                 {"FFHIP_HEVC_INTRA_WINDOW": "6"}, {"FFHIP_HEVC_INTRA_WAVES": "3"}])
 def test_schedulers_agree(env, monkeypatch):
     """the level-synchronous launches and the grouped single launch (any window) give the oracle's picture"""
     for k, v in env.items():

@@ -20,7 +20,7 @@ for tag, mix, seed in (("c5mix", "c5", 5), ("quadtree", None, 2)):
     def run():
         capi.check(L.ffhip_hevc_intra_recon(tus.ctypes.data, dt.data_ptr(), len(tus), dr.data_ptr(), py.data_ptr(), pu.data_ptr(), pv.data_ptr(), W, H, W, W // 2, H // 2, W // 2, 8, 8, st))
     for wl in sys.argv[1:] or ["6", "5", "4"]:
-      for form in os.environ.get("FORMS", "default").split(","):     # FORMS=0,1: one wave per group / four waves per group (FFHIP_HEVC_INTRA_FORM4)
+      for form in os.environ.get("FORMS", "default").split(","):     # FORMS=0,1 with a build of tests/tools/experiments/r3_hevc_intra_*.patch: one wave per group / four waves per group
         capi.setenv("FFHIP_HEVC_INTRA_WINDOW", wl)
         capi.setenv("FFHIP_HEVC_INTRA_FORM4", None if form == "default" else form)
         run(); capi.check(L.ffhip_stream_sync(st))

@@ -137,13 +137,21 @@ __device__ __forceinline__ int intra_inv_angle(int mode) /* modes 11..25 */
 #define NB_MAX 132 /* 4*32 + 1, padded */
 
 /* The grouped form's LDS copy of its window, WITH a halo: cell (ty, tx) holds picture sample (wy0 - 1 + ty, wx0 - 1 + tx).
- * Rows 0 .. 64 (the row above the window, then the window; up to 64 more columns to the right for above-right
- * neighbours) sit at ty * TILE_STRIDE + tx; the left column continues below the window (below-left neighbours) in
- * TILE_LEFT_EXT; three constant cells follow.  The window itself is written by the wave as it reconstructs; halo cells
- * are filled from memory by the TUs that need them (see intra_program).  One layout for every window size. */
-#define TILE_STRIDE 130 /* shorts per row: 65 dwords, so a column walk hits 32 different banks */
-#define TILE_ORIGIN (TILE_STRIDE + 1) /* cell of the window's first sample */
-#define TILE_LEFT_EXT (65 * TILE_STRIDE) /* cells (65 + k, 0), k = 0 .. 63 */
+ * Row 0 -- the row above the window, with up to 64 more columns to the right for above-right neighbours -- has 130 cells of its
+ * own; rows 1 .. 64 (the window, its left neighbour column in front) are 66 cells each: a neighbour to the right of the window in
+ * one of THOSE rows belongs to a window that comes later in every coding-tree order, i.e. is never available (a list that claims
+ * otherwise gets no cell from the program kernel and takes the generic body, which reads it from the plane).  The left column
+ * continues below the window (below-left neighbours) in TILE_LEFT_EXT; three constant cells follow.  The window itself is written
+ * by the wave as it reconstructs; halo cells are filled from memory by the TUs that need them (see intra_program).  One layout for
+ * every window size.  (Round 2 kept 130 cells in every row: 17 KB of the kernel's 27 KB of LDS, which held the launch at five
+ * waves per CU; with 9 KB it is the registers that bound it, at eight.) */
+#define TILE_STRIDE 66 /* shorts per window row: 33 dwords, so a column walk hits 32 different banks */
+#define TILE_ROW0 0 /* cells (0, tx), tx = 0 .. 129 */
+#define TILE_BODY 132 /* cell (1, 0) */
+#define TILE_ORIGIN (TILE_BODY + 1) /* cell of the window's first sample */
+#define TILE_CELL(ty, tx) ((ty) == 0 ? TILE_ROW0 + (tx) : ((ty) <= 64 ? TILE_BODY + ((ty) - 1) * TILE_STRIDE + (tx) : TILE_LEFT_EXT + (ty) - 65)) /* any cell the layout has */
+#define TILE_HAS_CELL(ty, tx) ((ty) == 0 ? (tx) <= 129 : ((ty) <= 64 ? (tx) <= TILE_STRIDE - 1 : ((ty) <= 128 && (tx) == 0)))
+#define TILE_LEFT_EXT (TILE_BODY + 64 * TILE_STRIDE) /* cells (65 + k, 0), k = 0 .. 63 */
 #define TILE_CONST_Y (TILE_LEFT_EXT + 64) /* 1 << (bitdepth_y - 1): what a TU without any neighbour predicts from */
 #define TILE_CONST_C (TILE_LEFT_EXT + 65)
 #define TILE_ZERO (TILE_LEFT_EXT + 66)
@@ -796,9 +804,9 @@ __device__ __forceinline__ void intra_program_halo(const GroupCtx &g, const int 
         if ((int)j < 2 * n) py = y0 + (2 * n - 1 - (int)j);
         else if ((int)j > 2 * n) px = x0 + ((int)j - 2 * n - 1);
         const int tx = px - g.wx0 + 1, ty = py - g.wy0 + 1;
-        if (tx == 0 || ty == 0 || tx > wsz || ty > wsz) {
+        if ((tx == 0 || ty == 0 || tx > wsz || ty > wsz) && TILE_HAS_CELL(ty, tx)) { /* a source without a cell is one no pixel of this program reads (k_hevc_intra_program) */
             const int v = ffhip_load_s16_sc1(g.plane_rs, (py * g.stride + px) * 2);
-            tile[ty <= 64 ? ty * TILE_STRIDE + tx : TILE_LEFT_EXT + ty - 65] = (short)v;
+            tile[TILE_CELL(ty, tx)] = (short)v;
         }
     }
 }
@@ -849,8 +857,8 @@ __global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
         else if (j > 2 * n) px = x0 + (j - 2 * n - 1);
         const int tx = px - wx0 + 1, ty = py - wy0 + 1;
         if (tx == 0 || ty == 0 || tx > wsz || ty > wsz) outside = true;
-        if (tx > TILE_STRIDE - 1 || ty > 128 || (ty > 64 && tx != 0)) ok = false;
-        return 2u * (unsigned)(ty <= 64 ? ty * TILE_STRIDE + tx : TILE_LEFT_EXT + ty - 65);
+        if (!TILE_HAS_CELL(ty, tx)) { ok = false; return 0u; }
+        return 2u * (unsigned)TILE_CELL(ty, tx);
     };
     auto cell = [&](int pos) -> unsigned { return filt ? 2u * (unsigned)(TILE_F + pos) : src_cell(pos); }; /* what a tap reads */
 #define POS_LEFT(yy) (2 * n - 1 - (yy))
@@ -1121,13 +1129,15 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
         const uint32_t refused = a.plan_result[0] | (a.plan_result[2] > a.wait_cap ? 1u : 0u);
         n_groups = (int)a.plan_result[1];
         if (__builtin_amdgcn_readfirstlane((int)refused)) return;
-        /* The launch holds as many waves as the device can keep resident; how many of them can be AT WORK at once is the
-         * width of the list's dependency wavefront, which only the planner knows (a single 8K picture: ~200 groups; a grid
-         * of 135 independent tiles: more than the chip holds).  The waves beyond 5/4 of that leave now: a wave that holds
-         * a ticket far from its turn only polls, through the same memory path the working waves use (one 8K picture on
-         * 1024 waves: 6.5 ms, on 256: 5.9). */
+        /* The launch holds as many waves as the device can keep resident (eight per CU: registers); how many of them can be AT
+         * WORK at once follows from the width of the list's dependency wavefront, which only the planner knows (a single 8K
+         * picture: ~200 groups of one depth; a grid of 135 independent tiles: ~1 600; eight such pictures: more than the chip
+         * holds).  A wave that holds a ticket far from its turn only polls, through the same memory path the working waves use
+         * (one 8K picture on 1024 waves: 6.5 ms, on 256: 5.9; the 135-tile grid on 2048 / 1280 / 1024 / 640 waves: 2.36 / 1.68 /
+         * 1.46 / 1.46 ms; eight of them: 8.7 / 9.4 / 10.0 / 11.9 ms -- tests/tools/bench_hevc_grid.py): half the width, at least
+         * 256, is what those runs ask for; the waves beyond that leave now. */
         const uint32_t width = a.plan_result[4];
-        if (width && blockIdx.x >= (width + (width >> 2) + 16 > 256u ? width + (width >> 2) + 16 : 256u)) return;
+        if (width && blockIdx.x >= ((width >> 1) + 16 > 256u ? (width >> 1) + 16 : 256u)) return;
     }
     const __amdgpu_buffer_rsrc_t desc_rs = ffhip_rsrc(a.desc, 0xffffffffu), res_rs = ffhip_rsrc((const void *)hot.residual, PROG_NO_RESIDUAL);
     const int cell_lane4 = 2 * ((lane >> 2) * TILE_STRIDE + (lane & 3)), cell_lane8 = 2 * ((lane >> 3) * TILE_STRIDE + (lane & 7));

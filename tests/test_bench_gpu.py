@@ -29,17 +29,22 @@ def test_one_gpu_line_small():
     assert rec["config"]["images_total"] == 5 and rec["roofline"]["bound"] == "hbm" and rec["roofline"]["frac"] > 0
 
 
-@pytest.mark.parametrize("scaling,total", [("strong", 7), ("weak", 6)])
-def test_two_rank_rehearsal(scaling, total):
+@pytest.mark.parametrize("scaling,total,launcher", [("strong", 7, "self"), ("weak", 6, "torchrun")])
+def test_two_rank_rehearsal(scaling, total, launcher):
+    """launcher "self": `python3 bench.py --gpus 2 ...` with no launcher environment -- the way the driver starts the one-GPU line -- must
+    spawn its own two ranks (a child torch.distributed.run; the parent never touches the GPU), relay rank 0's ONE JSON line and exit 0;
+    "torchrun": started under torch.distributed.run by the caller, as the contract's N > 1 command line does."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, FFHIP_BENCH_REHEARSE="1")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FFHIP_BENCH_REHEARSE"] = "1"
     images = 7 if scaling == "strong" else 3
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--images", str(images), "--scaling", scaling, "--no-cpu"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--images", str(images), "--scaling", scaling, "--no-cpu"]
+    head = [sys.executable] if launcher == "self" else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                                        "--master-port", str(port)]
+    out = subprocess.run(head + tail, capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
     rec = _line(out)
     assert rec["n_gpus"] == 2 and rec["scaling"] == scaling and "rehearsal" in rec["config"]
     assert rec["config"]["images_total"] == total and rec["config"]["batch_complete"] is True

@@ -268,6 +268,40 @@ __device__ __forceinline__ TermBits chroma_term_bits(u32 a_raw, u32 b_raw)
     return t;
 }
 
+/* The same terms for TWO chroma samples at once, in the packed fp32 forms (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: one issue
+ * for both samples): uw, vw hold two raw 16-bit samples each.  r, g, b come back as the two int16 terms side by side (sample 0
+ * low), ready for the packed 16-bit adds.  The "sensitive" test is left to the caller in two steps: rem (= tf mod 1000, exact)
+ * is zero where 215 uu + 381 vv is a multiple of 1000 -- a product over the samples of a pass says whether ANY is -- and only
+ * then is sf != 76288 (the multiple is not zero itself) looked at, per sample: 3 instructions per pass in the common case where
+ * the two compares, the and and the mask insertion per SAMPLE used to be. */
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct TermBits2 {
+    u32 r, g, b;
+    f32x2 rem, sf;
+};
+__device__ __forceinline__ TermBits2 chroma_term_bits2(u32 uw, u32 vw)
+{
+    f32x2 af, bf; /* the halfword select rides on the conversion (SDWA) */
+    asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(af.x) : "v"(uw));
+    asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(af.y) : "v"(uw));
+    asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(bf.x) : "v"(vw));
+    asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(bf.y) : "v"(vw));
+    const f32x2 r = __builtin_elementwise_fma(bf, (f32x2)(1.28f), (f32x2)(-0.32f)) + (f32x2)(8453980.0f);
+    const f32x2 b = __builtin_elementwise_fma(af, (f32x2)(2.128f), (f32x2)(0.12f)) + (f32x2)(8453871.0f);
+    TermBits2 t;
+    t.sf = __builtin_elementwise_fma(bf, (f32x2)(381.0f), af * (f32x2)(215.0f));
+    const f32x2 tf = (f32x2)(4882288.0f) - t.sf;
+    const f32x2 tg = __builtin_elementwise_fma(tf, (f32x2)(0.001f), (f32x2)(-0.4995f)) + (f32x2)(8449338.0f);
+    const f32x2 kf = tg - (f32x2)(8449338.0f);
+    t.rem = __builtin_elementwise_fma(kf, (f32x2)(-1000.0f), tf);
+    /* (whole-vector bit casts: __builtin_bit_cast of ONE element of an ext_vector reads element 0 whichever is named, clang 20) */
+    const u32x2 rb = __builtin_bit_cast(u32x2, r), gb = __builtin_bit_cast(u32x2, tg), bb = __builtin_bit_cast(u32x2, b);
+    t.r = __builtin_amdgcn_perm(rb[1], rb[0], 0x05040100u);
+    t.g = __builtin_amdgcn_perm(gb[1], gb[0], 0x05040100u);
+    t.b = __builtin_amdgcn_perm(bb[1], bb[0], 0x05040100u);
+    return t;
+}
+
 /* blockIdx.x -> position in the workgroup sequence.  mode 0: as dispatched (round-robin over the XCDs); 1: every XCD
  * gets one contiguous eighth of the sequence; k >= 2: the XCDs take chunks of 2^k workgroups in turn (the part of the grid
  * that is not a whole number of 8 * 2^k stays as dispatched).  Speed only: any placement computes the same bytes. */
@@ -615,7 +649,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
     uint8_t *const obase = p.bgra + (long long)img * p.image_stride + (long long)mrow * SH * p.pitch + (long long)mcu0 * (32 * H);
     TermBits grey_t = {};
     if (NC == 1) grey_t = chroma_term_bits(0u, 0u); /* U = V = 0 planes (jpg.c:501,552-554): uu = vv = -128, never "sensitive" */
-    u32 tr2[2], tg2[2], tb2[2], ua[4] = {0, 0, 0, 0}, va[4] = {0, 0, 0, 0}, sens = 0;
+    u32 tr2[2], tg2[2], tb2[2], us[2] = {0, 0}, vs[2] = {0, 0}, sens = 0;
     /* per-lane LDS offsets of the two passes, computed once: pass 1 reads 64 / GPR rows (v = 2: 8 row positions) further
      * on, which flips one bit of the swizzle key -- an XOR and an add instead of a second address computation */
     const u32 row0 = V >= 2 ? 2 * (lane / GPR) : lane / GPR, pc0 = (lane % GPR) * 4;
@@ -638,7 +672,6 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
             tb2[0] = tb2[1] = __builtin_amdgcn_perm(grey_t.b, grey_t.b, 0x01000100u);
         } else {
             const u32 c_off = it ? c_off1 : c_off0;
-            u32 us[2], vs[2];
             if (H == 1) {
                 const u32x2 a = *(const u32x2 *)(c.lds + SM_UP + c_off), b = *(const u32x2 *)(c.lds + SM_VP + c_off);
                 us[0] = a[0]; us[1] = a[1]; vs[0] = b[0]; vs[1] = b[1];
@@ -651,25 +684,43 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
                 vs[0] = *(const uint16_t *)(c.lds + SM_VP + c_off);
                 us[1] = vs[1] = 0;
             }
-            TermBits t[4 / H];
             sens = 0;
+            if (H == 4) {
+                const TermBits t = chroma_term_bits(us[0], vs[0]);
+                sens = t.sens ? 1u : 0u;
+                tr2[0] = tr2[1] = __builtin_amdgcn_perm(t.r, t.r, 0x01000100u);
+                tg2[0] = tg2[1] = __builtin_amdgcn_perm(t.g, t.g, 0x01000100u);
+                tb2[0] = tb2[1] = __builtin_amdgcn_perm(t.b, t.b, 0x01000100u);
+            } else {
+                constexpr int NP = H == 1 ? 2 : 1; /* sample pairs: two at h = 1, one at h = 2 */
+                TermBits2 t[NP];
 #pragma unroll
-            for (int k = 0; k < 4 / H; k++) {
-                ua[k] = (k & 1) ? (us[k >> 1] >> 16) : (us[k >> 1] & 0xffffu); /* raw samples: uu = u - 128 (colorspace.c:149) */
-                va[k] = (k & 1) ? (vs[k >> 1] >> 16) : (vs[k >> 1] & 0xffffu);
-                t[k] = chroma_term_bits(ua[k], va[k]);
-                sens |= t[k].sens ? 1u << k : 0u;
-            }
+                for (int k = 0; k < NP; k++) t[k] = chroma_term_bits2(us[k], vs[k]);
+                float any;
+                if (H == 1) {
+                    const f32x2 m = t[0].rem * t[NP - 1].rem;
+                    any = m.x * m.y;
 #pragma unroll
-            for (int h2 = 0; h2 < 2; h2++) {
-                if (H == 1) { /* one chroma sample per pixel: low halves of two terms side by side */
-                    tr2[h2] = __builtin_amdgcn_perm(t[2 * h2 + 1].r, t[2 * h2].r, 0x05040100u);
-                    tg2[h2] = __builtin_amdgcn_perm(t[2 * h2 + 1].g, t[2 * h2].g, 0x05040100u);
-                    tb2[h2] = __builtin_amdgcn_perm(t[2 * h2 + 1].b, t[2 * h2].b, 0x05040100u);
-                } else {      /* the pair shares its chroma sample */
-                    tr2[h2] = __builtin_amdgcn_perm(t[h2 % (4 / H)].r, t[h2 % (4 / H)].r, 0x01000100u);
-                    tg2[h2] = __builtin_amdgcn_perm(t[h2 % (4 / H)].g, t[h2 % (4 / H)].g, 0x01000100u);
-                    tb2[h2] = __builtin_amdgcn_perm(t[h2 % (4 / H)].b, t[h2 % (4 / H)].b, 0x01000100u);
+                    for (int h2 = 0; h2 < 2; h2++) { /* one chroma sample per pixel */
+                        tr2[h2] = t[h2 % NP].r;
+                        tg2[h2] = t[h2 % NP].g;
+                        tb2[h2] = t[h2 % NP].b;
+                    }
+                } else {
+                    any = t[0].rem.x * t[0].rem.y;
+                    tr2[0] = __builtin_amdgcn_perm(t[0].r, t[0].r, 0x01000100u); /* a pixel pair shares its chroma sample */
+                    tr2[1] = __builtin_amdgcn_perm(t[0].r, t[0].r, 0x03020302u);
+                    tg2[0] = __builtin_amdgcn_perm(t[0].g, t[0].g, 0x01000100u);
+                    tg2[1] = __builtin_amdgcn_perm(t[0].g, t[0].g, 0x03020302u);
+                    tb2[0] = __builtin_amdgcn_perm(t[0].b, t[0].b, 0x01000100u);
+                    tb2[1] = __builtin_amdgcn_perm(t[0].b, t[0].b, 0x03020302u);
+                }
+                if (any == 0.0f) { /* rare: some sample's G sum is a multiple of 1000 (zero included) */
+#pragma unroll
+                    for (int k = 0; k < 2 * NP; k++) {
+                        const float rem = (k & 1) ? t[k >> 1].rem.y : t[k >> 1].rem.x, sf = (k & 1) ? t[k >> 1].sf.y : t[k >> 1].sf.x;
+                        sens |= (rem == 0.0f && sf != 76288.0f) ? 1u << k : 0u;
+                    }
                 }
             }
         }
@@ -690,7 +741,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
                 const int k = d / H;
                 if (sens & (1u << k)) {
                     const int y1 = (int)((d & 1) ? (yy[d >> 1] >> 16) : (yy[d >> 1] & 0xffffu));
-                    px[d] = (px[d] & 0xffff00ffu) | (green_fp64(y1, (int)ua[k] - 128, (int)va[k] - 128) << 8);
+                    const u32 ua = (k & 1) ? (us[k >> 1] >> 16) : (us[k >> 1] & 0xffffu); /* raw samples: uu = u - 128 (colorspace.c:149) */
+                    const u32 va = (k & 1) ? (vs[k >> 1] >> 16) : (vs[k >> 1] & 0xffffu);
+                    px[d] = (px[d] & 0xffff00ffu) | (green_fp64(y1, (int)ua - 128, (int)va - 128) << 8);
                 }
             }
         }

@@ -61,14 +61,34 @@ __device__ __forceinline__ void vp8_idct4x4(u32 p[8])
     }
 }
 
-/* 16 bytes of the even (EVEN_SRC) or odd lane of every lane pair, to both lanes of the pair: DPP quad_perm [0,0,2,2] / [1,1,3,3] */
-template <bool EVEN_SRC>
-__device__ __forceinline__ u32x4 pair_bcast(u32x4 v)
+/* Four dwords per lane, picked inside every lane pair in ONE instruction each (v_cndmask_b32 with a DPP source operand):
+ * lanes in `own` keep s1, the others take s0 of the pair's even (FROM_ODD = false: quad_perm [0,0,2,2]) or odd ([1,1,3,3])
+ * lane.  A v_mov_b32_dpp broadcast followed by a v_cndmask, as the compiler writes the same thing, is twice the VALU
+ * work: 32 of this kernel's 276 instructions.  (s_nop 1: the two wait states a DPP read needs after the VALU write of
+ * its source, which the hazard pass cannot insert inside an asm block.) */
+template <bool FROM_ODD>
+__device__ __forceinline__ u32x4 pair_pick(u32x4 s0, u32x4 s1, unsigned long long own)
 {
-    u32x4 r;
-#pragma unroll
-    for (int i = 0; i < 4; i++) r[i] = (u32)__builtin_amdgcn_update_dpp(0, (int)v[i], EVEN_SRC ? 0xA0 : 0xF5, 0xf, 0xf, true);
-    return r;
+    u32 d0, d1, d2, d3;
+    if (FROM_ODD)
+        asm("s_mov_b64 vcc, %12\n\ts_nop 1\n\t"
+            "v_cndmask_b32_dpp %0, %4, %8, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %1, %5, %9, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %2, %6, %10, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %3, %7, %11, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf"
+            : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+            : "v"(s0[0]), "v"(s0[1]), "v"(s0[2]), "v"(s0[3]), "v"(s1[0]), "v"(s1[1]), "v"(s1[2]), "v"(s1[3]), "s"(own)
+            : "vcc");
+    else
+        asm("s_mov_b64 vcc, %12\n\ts_nop 1\n\t"
+            "v_cndmask_b32_dpp %0, %4, %8, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %1, %5, %9, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %2, %6, %10, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_dpp %3, %7, %11, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf"
+            : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+            : "v"(s0[0]), "v"(s0[1]), "v"(s0[2]), "v"(s0[3]), "v"(s1[0]), "v"(s1[1]), "v"(s1[2]), "v"(s1[3]), "s"(own)
+            : "vcc");
+    return u32x4{d0, d1, d2, d3};
 }
 
 /* 32 lanes own one macroblock.  Memory moves LINEARLY: lane t loads 16-byte chunk t of the macroblock's 800 bytes of
@@ -78,7 +98,7 @@ __device__ __forceinline__ u32x4 pair_bcast(u32x4 v)
  * arithmetic over linear accesses measures 5.7-5.9.  Blocks are then assembled inside lane PAIRS with two DPP
  * broadcasts: even lane 2b computes luma block b from chunks 2b (its own) and 2b + 1 (its neighbour's); odd lane
  * 2j + 1 computes block 16 + j (U/V blocks 16-23, the Y2 block 24 on lane 17) from chunks 32 + 2j (its neighbour's
- * second load) and 32 + 2j + 1 (its own).  The results go back the same way. */
+ * second load) and 32 + 2j + 1 (its own).  The results go back the same way (pair_pick). */
 __global__ __launch_bounds__(256) void k_vp8_residual(Vp8ResArgs a)
 {
     __shared__ __attribute__((aligned(16))) short y2in[8][16];
@@ -103,13 +123,9 @@ __global__ __launch_bounds__(256) void k_vp8_residual(Vp8ResArgs a)
     u32x4 c2 = {0u, 0u, 0u, 0u};
     if (t < 18) c2 = __builtin_nontemporal_load(src + 32 + t);
     /* block assembly inside the lane pair */
-    const u32x4 nb_hi = pair_bcast<false>(c1), nb_lo = pair_bcast<true>(c2);
-    u32x4 l0, l1;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        l0[i] = even ? c1[i] : nb_lo[i];
-        l1[i] = even ? nb_hi[i] : c2[i];
-    }
+    const unsigned long long even_lanes = 0x5555555555555555ull;
+    const u32x4 l0 = pair_pick<false>(c2, c1, even_lanes);  /* even: my first chunk; odd: my even neighbour's second load */
+    const u32x4 l1 = pair_pick<true>(c1, c2, ~even_lanes);  /* even: my odd neighbour's first chunk; odd: my second load */
     const u32 lv[8] = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
     u32 pk[8]; /* pk[2r + h] = (c[4r + 2h], c[4r + 2h + 1]) */
 #pragma unroll
@@ -160,13 +176,7 @@ __global__ __launch_bounds__(256) void k_vp8_residual(Vp8ResArgs a)
     /* back to chunks: chunk t = even ? my lower half : my even neighbour's upper half; chunk 32 + t (t < 16) = even ? my odd
      * neighbour's lower half : my upper half */
     const u32x4 o0 = {pk[0], pk[1], pk[2], pk[3]}, o1 = {pk[4], pk[5], pk[6], pk[7]};
-    const u32x4 ev_hi = pair_bcast<true>(o1), od_lo = pair_bcast<false>(o0);
-    u32x4 s1, s2;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        s1[i] = even ? o0[i] : ev_hi[i];
-        s2[i] = even ? od_lo[i] : o1[i];
-    }
+    const u32x4 s1 = pair_pick<false>(o1, o0, even_lanes), s2 = pair_pick<true>(o0, o1, ~even_lanes);
     u32x4 *dst = (u32x4 *)(a.out + mb * 384);
     __builtin_nontemporal_store(s1, dst + t);
     if (t < 16) __builtin_nontemporal_store(s2, dst + 32 + t);

@@ -103,7 +103,7 @@ def idr_slice(slice_data):
 def random_slice_data(seed, n_bytes):
     """no zero bytes: nothing to escape, and the stream stays the same under the reference's 00 00 03 removal"""
     rng = np.random.default_rng(seed)
-    return bytes(int(x) for x in rng.integers(1, 256, size=200000)[:n_bytes])
+    return rng.integers(1, 256, size=max(200000, n_bytes))[:n_bytes].astype(np.uint8).tobytes()   # (the first 200 000 values do not depend on the size drawn)
 
 
 def stream(width, height, seed, n_bytes=8000, **pps_kw):

@@ -15,7 +15,7 @@ st = torch.cuda.current_stream().cuda_stream
 e0, e1 = L.ffhip_event_create(), L.ffhip_event_create()
 n = int(os.environ.get("FFHIP_BENCH_IMAGES", "64"))
 out = {}
-for name, (nc, h, v) in {"420": (3, 2, 2), "444": (3, 1, 1), "422": (3, 2, 1), "440": (3, 1, 2), "grey": (1, 1, 1)}.items():
+for name, (nc, h, v) in {"420": (3, 2, 2), "444": (3, 1, 1), "422": (3, 2, 1), "440": (3, 1, 2), "411": (3, 4, 1), "114": (3, 1, 4), "grey": (1, 1, 1)}.items():
     W, H = 3840, 2176
     cols, rows = W // (8 * h), H // (8 * v)
     g = capi.jpeg_geom(cols, rows, nc, h, v, (0, 1, 1))

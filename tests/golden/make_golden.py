@@ -589,7 +589,7 @@ HEVC_REC = np.dtype([("x", "<i4"), ("y", "<i4"), ("log2", "<i4"), ("cidx", "<i4"
                      ("level_off", "<i4"), ("pad", "<i4"), ("avail_top", "<u8"), ("avail_left", "<u8")])   # struct rec_tu of oracle/ref_statics_hevc.c
 
 
-def _ref_decode_hevc_inproc(width, height, seed, n_bytes, out_npz):
+def _ref_decode_hevc_inproc(width, height, seed, n_bytes, out_npz, constrained_intra=0):
     """the reference's parse_nalu (coding/hevc.c:7300) over a hand-assembled stream, with the recorder of
     oracle/ref_statics_hevc.c on: TU list, levels, residuals, planes, BGRA"""
     import hevc_bitstream as HB
@@ -598,8 +598,8 @@ def _ref_decode_hevc_inproc(width, height, seed, n_bytes, out_npz):
     R.parse_nalu.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]
     R.ref_hevc_record_fetch.argtypes = [C.c_void_p] * 4
     hps = R.ref_hevc_param_set_new()
-    nals = HB.stream(width, height, seed, n_bytes)
-    pix = np.zeros(width * (height + 64) * 4 + 4096, np.uint8)
+    nals = HB.stream(width, height, seed, n_bytes, constrained_intra=constrained_intra)
+    pix = np.zeros(width * (height + 64) * 4 + 4096, np.uint8)      # the conversion writes whole coding tree blocks (hevc.c:7261-7263): up to 63 rows past the picture
     for n in nals[:3]:
         buf = np.frombuffer(n, np.uint8).copy()
         dummy = C.c_void_p(0)
@@ -771,6 +771,42 @@ def gen_hevc_file(R):
                     f"{tag}_levels": d["levels"], f"{tag}_resid": d["resid"], f"{tag}_y": y, f"{tag}_u": u, f"{tag}_v": v, f"{tag}_bgra": bgra,
                     f"{tag}_stream": d["stream"]})
     save("hevc_file.npz", **res)
+
+
+def _sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+def gen_hevc_file_1080p(R):
+    """The same kind of stream at 1920x1080 (30 x 17 coding tree blocks, the bottom row cut at 56 of 64 lines): seed 14677 of
+    tests/tools/find_hevc_stream_seed.py's search -- one random byte string in a few thousand ends where a picture of 510 coding
+    tree blocks does (hevc.c:7007-7019).  93 000 TUs, 1.8 M levels.  The fixture holds the INPUTS the reference's parser handed
+    to reconstruction (TU list, qP / flags, levels) and SHA-256 of what the reference made of them (residuals, the three planes,
+    the 1080 BGRA rows): the planes and the picture themselves would be 16 MB of noise.  The stream is not stored either: it is
+    HB.stream(1920, 1080, 14677, 1326000), pinned by its own hash.  With constrained_intra_pred_flag = 1 the reference records the
+    same TUs and produces the same picture (every neighbour of an all-intra picture is intra): asserted here, the flag's real
+    cases are hevc_isp.npz's."""
+    import hevc_bitstream as HB
+    w, h, seed, n_bytes = 1920, 1080, 14677, 1326000
+    got = []
+    for ci in (0, 1):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "hevc.npz")
+            rc = subprocess.call([sys.executable, os.path.abspath(__file__), "--decode-hevc", f"{w},{h},{seed},{n_bytes},{ci}", out],
+                                 stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            assert rc == 0 and os.path.exists(out), f"the reference did not decode the {w}x{h} stream of seed {seed} to a clean end"
+            got.append(dict(np.load(out)))
+    d, d1 = got
+    for k in ("tus", "levels", "resid", "planes", "bgra"):
+        assert np.array_equal(d[k], d1[k]), "constrained_intra_pred_flag changed the decode of an all-intra picture: " + k
+    full = {}
+    _hevc_record_to_fixture("g", w, h, seed, d, full)           # checks the restatement against the record, stage by stage
+    res = {"g_dims": np.array([w, h, seed, n_bytes], np.int32), "g_tus": full["g_tus"], "g_tuinfo": full["g_tuinfo"], "g_levels": full["g_levels"],
+           "g_sha_stream": _sha(np.frombuffer(b"".join(len(n).to_bytes(4, "big") + n for n in HB.stream(w, h, seed, n_bytes)), np.uint8)),
+           "g_sha_resid": _sha(full["g_resid"]), "g_sha_y": _sha(full["g_y"]), "g_sha_u": _sha(full["g_u"]), "g_sha_v": _sha(full["g_v"]),
+           "g_sha_bgra": _sha(full["g_bgra"]), "g_rows": np.stack([full["g_bgra"][0], full["g_bgra"][h // 2], full["g_bgra"][h - 1]])}
+    assert np.array_equal(res["g_sha_stream"], _sha(d["stream"]))
+    save("hevc_file_1080p.npz", **res)
 
 
 ISP_SPECS = {"p1080": (1920, 1080, 7, 0), "p1080_constrained": (1920, 1080, 8, 1), "odd": (1000, 520, 9, 1)}
@@ -968,7 +1004,7 @@ def main():
     R = O.ref()
     steps = [("blocks", gen_blocks), ("vp8 macroblocks", gen_vp8_mbs), ("vp8 driven", gen_vp8_driven), ("vp8 frames", gen_vp8_frames),
              ("hevc intra", gen_hevc_intra), ("hevc glue", gen_hevc_glue), ("vp8 loop filter", gen_vp8_loopfilter), ("colour", gen_color),
-             ("grids", gen_grids), ("files", gen_files), ("files 422", gen_files_422), ("files 411", gen_files_411), ("webp file", gen_webp_file), ("webp file lf", gen_webp_file_lf), ("webp file 1080p", gen_webp_file_1080p), ("vp8 filter params", gen_vp8_filter_params), ("hevc file", gen_hevc_file), ("heic file", gen_heic_file), ("hevc isp", gen_hevc_isp)]
+             ("grids", gen_grids), ("files", gen_files), ("files 422", gen_files_422), ("files 411", gen_files_411), ("webp file", gen_webp_file), ("webp file lf", gen_webp_file_lf), ("webp file 1080p", gen_webp_file_1080p), ("vp8 filter params", gen_vp8_filter_params), ("hevc file", gen_hevc_file), ("heic file", gen_heic_file), ("hevc isp", gen_hevc_isp), ("hevc file 1080p", gen_hevc_file_1080p)]
     only = sys.argv[2] if len(sys.argv) == 3 and sys.argv[1] == "--only" else None   # e.g. --only "hevc intra"
     for name, fn in steps:
         if only is None or only == name:
@@ -981,7 +1017,8 @@ if __name__ == "__main__":
     if len(sys.argv) == 4 and sys.argv[1] == "--decode":
         _ref_decode_file_inproc(sys.argv[2], sys.argv[3])
     if len(sys.argv) == 4 and sys.argv[1] == "--decode-hevc":
-        _ref_decode_hevc_inproc(*[int(x) for x in sys.argv[2].split(",")], sys.argv[3])
+        spec = [int(x) for x in sys.argv[2].split(",")]
+        _ref_decode_hevc_inproc(*spec[:4], sys.argv[3], *spec[4:])
     if len(sys.argv) == 4 and sys.argv[1] == "--decode-heic":
         _ref_decode_heic_inproc(sys.argv[2], sys.argv[3])
     if len(sys.argv) == 4 and sys.argv[1] == "--decode-webp":

@@ -177,6 +177,43 @@ def test_hevc_file_config5(golden, tag):
     assert np.array_equal(bgra, g[f"{tag}_bgra"])
 
 
+def test_hevc_file_1080p(golden):
+    """The same chain on the 1920x1080 stream (93 330 TUs; the bottom row of coding tree blocks is cut at 56 of 64 lines): inputs as
+    the reference's parser recorded them, results against SHA-256 of the reference's own residuals, planes and BGRA rows
+    (tests/golden/make_golden.py::gen_hevc_file_1080p).  The colour step is called the way hevc.c:7261-7263 calls it: 17 rows of
+    coding tree blocks over ONE allocation holding Y, U at w*h and V at w*h*3/2, so that the rows past the picture read what the
+    reference reads; the picture's 1080 rows are compared."""
+    import hashlib
+
+    def sha(a):
+        return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+    g = golden("hevc_file_1080p.npz")
+    w, h = int(g["g_dims"][0]), int(g["g_dims"][1])
+    tus = np.ascontiguousarray(g["g_tus"]).view(synth.HEVC_TU_DTYPE).reshape(-1).copy()
+    info, lv = g["g_tuinfo"], g["g_levels"]
+    has = (tus["flags"] & synth.TU_RESIDUAL) != 0
+    resid = np.zeros(len(lv) + 16, np.int16)
+    for lg in (2, 3, 4, 5):
+        idx = np.nonzero(has & (tus["log2_size"] == lg))[0]
+        n = 1 << lg
+        offs = tus["res_offset"][idx].astype(np.int64)
+        levels = lv[(offs[:, None] + np.arange(n * n)[None, :]).reshape(-1)].reshape(len(idx), n * n)
+        got = ops.hevc_residual_batch(n, levels, np.ascontiguousarray(info[idx]), bitdepth=8)
+        resid[(offs[:, None] + np.arange(n * n)[None, :]).reshape(-1)] = got.reshape(-1)
+    assert np.array_equal(sha(resid[:len(lv)]), g["g_sha_resid"])
+    y, u, v = ops.hevc_intra_recon(tus, resid, w, h, True, 8, 8)
+    assert np.array_equal(sha(y), g["g_sha_y"]) and np.array_equal(sha(u), g["g_sha_u"]) and np.array_equal(sha(v), g["g_sha_v"])
+    size, rows = w * h, -(-h // 64) * 64
+    planes = np.zeros(2 * size, np.int16)
+    planes[:size], planes[size:size + size // 4], planes[size * 3 // 2:size * 3 // 2 + size // 4] = y.reshape(-1), u.reshape(-1), v.reshape(-1)
+    L = capi.require_device()
+    dp, do = ops.DeviceBuffer(planes), ops.DeviceBuffer(nbytes=rows * w * 4)
+    capi.check(L.ffhip_yuv420_to_bgra_16(do.ptr, w * 4, dp.ptr, dp.ptr + 2 * size, dp.ptr + 3 * size, w, w // 2, rows // 64, w // 64, 64, 1, 0, 0, 0, None))
+    bgra = do.to_host((rows, w * 4), np.uint8)
+    assert np.array_equal(bgra[[0, h // 2, h - 1]], g["g_rows"])
+    assert np.array_equal(sha(bgra[:h]), g["g_sha_bgra"])
+
+
 @pytest.mark.parametrize("shift", [1, 3, 8, 13])
 def test_residual_blocks_at_odd_offsets(shift):
     """Residual blocks need not be 16-byte aligned in d_residual: the kernel fetches aligned blocks ahead with 16-byte

@@ -248,6 +248,44 @@ def test_hevc_file_config5(golden, ffo, tag):
     assert np.array_equal(out, g[f"{tag}_bgra"])
 
 
+def _sha(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+def test_hevc_file_1080p(golden, ffo):
+    """The same at 1920x1080 (30 x 17 coding tree blocks, bottom row cut; 93 330 TUs): the inputs the reference's parser recorded
+    and SHA-256 of what the reference made of them -- residuals, planes, the 1080 BGRA rows (make_golden.py::gen_hevc_file_1080p).
+    The stream is tests/hevc_bitstream.py's, reproduced here from its seed and pinned by its hash."""
+    import hevc_bitstream as HB
+    from ffpic_amd import synth
+    g = golden("hevc_file_1080p.npz")
+    w, h, seed, n_bytes = [int(x) for x in g["g_dims"]]
+    nals = HB.stream(w, h, seed, n_bytes)
+    assert np.array_equal(_sha(np.frombuffer(b"".join(len(n).to_bytes(4, "big") + n for n in nals), np.uint8)), g["g_sha_stream"])
+    tus = np.ascontiguousarray(g["g_tus"]).view(synth.HEVC_TU_DTYPE).reshape(-1)
+    info, lv = g["g_tuinfo"], g["g_levels"]
+    assert (int(tus["y"].max()) + (1 << int(tus["log2_size"][tus["y"].argmax()]))) == h and len(tus) > 90000
+    resid = np.zeros_like(lv)
+    has = (tus["flags"] & synth.TU_RESIDUAL) != 0
+    for i in np.nonzero(has)[0]:
+        n, o = 1 << int(tus["log2_size"][i]), int(tus["res_offset"][i])
+        ffo.ffo_hevc_residual_tu(np.ascontiguousarray(lv[o:o + n * n]), resid[o:o + n * n], n, int(info[i, 0]), int(info[i, 1]), 8, 0, None)
+    assert np.array_equal(_sha(resid), g["g_sha_resid"])
+    y, u, v = O.oracle_hevc_intra(tus, resid, w, h, True, 8, 8)
+    assert np.array_equal(_sha(y), g["g_sha_y"]) and np.array_equal(_sha(u), g["g_sha_u"]) and np.array_equal(_sha(v), g["g_sha_v"])
+    # the conversion walks whole coding tree blocks (hevc.c:7261-7263): 17 rows of them over planes laid out as the decoder holds them
+    # (Y, then U at w*h, V at w*h*3/2 of one allocation), 1088 output rows of which the picture's 1080 count
+    size = w * h
+    planes = np.zeros(2 * size, np.int16)
+    planes[:size], planes[size:size + size // 4], planes[size * 3 // 2:size * 3 // 2 + size // 4] = y.reshape(-1), u.reshape(-1), v.reshape(-1)
+    rows = -(-h // 64) * 64
+    out = np.zeros((rows, w * 4), np.uint8)
+    ffo.ffo_yuv420_to_bgra32_16bit(out.reshape(-1), w * 4, planes, planes[size:], planes[size * 3 // 2:], w, w // 2, rows // 64, w // 64, 64)
+    assert np.array_equal(out[[0, h // 2, h - 1]], g["g_rows"])
+    assert np.array_equal(_sha(out[:h]), g["g_sha_bgra"])
+
+
 def test_hevc_dst4(golden, ffo):
     g = golden("hevc_dst4.npz")
     for bd in (8, 10):

@@ -129,3 +129,22 @@ def test_c5_48_tile_grid():
     exp = _intra_full_picture(T * K, T, tus, res)
     for i in range(1, K):                                  # and every tile is the same picture
         assert np.array_equal(exp[0][:, i * T:(i + 1) * T], exp[0][:, :T])
+
+
+def test_c5_135_tile_8k_grid():
+    """BASELINE configs[4] reads "single 8K tile grid": an 8K picture as a HEIF grid of 15 x 9 = 135 independent 512x512 tiles
+    (7680x4608; the tile loop this replaces is heif.c:297-309), all tiles in ONE plane set and ONE ffhip_hevc_intra_recon call, against
+    the oracle over the whole plane set; every tile is the same picture."""
+    T, gx, gy = 512, 15, 9
+    t0, res0 = synth.hevc_intra_tus(T, T, seed=6)
+    K = gx * gy
+    tus = np.tile(t0, K)
+    k = np.repeat(np.arange(K), len(t0))
+    sc = np.where(tus["cidx"] == 0, T, T // 2)
+    tus["x"] = (tus["x"].astype(np.int64) + (k % gx) * sc).astype(np.uint16)
+    tus["y"] = (tus["y"].astype(np.int64) + (k // gx) * sc).astype(np.uint16)
+    tus["res_offset"] += (k * len(res0)).astype(np.uint32)
+    exp = _intra_full_picture(T * gx, T * gy, tus, np.tile(res0, K))
+    for i in range(1, K):
+        ox, oy = (i % gx) * T, (i // gx) * T
+        assert np.array_equal(exp[0][oy:oy + T, ox:ox + T], exp[0][:T, :T]), i

@@ -188,6 +188,33 @@ def test_webp_file_1080p_side_by_side(golden):
         assert np.array_equal(sums, g["bgra_row_sums"]), i
 
 
+def test_webp_file_1080p_256_frames(golden):
+    """A chip-filling batch: 256 copies of the real encoder's 1080p frame in ONE ffhip_vp8_predict_loopfilter call (the frame loop
+    of webp.c:1833-1866; the wave caps follow residency at this size, not 16 waves per image).  Every frame's planes equal the
+    first frame's, and the first, the middle and the last frame are the reference's whole-file decode, every row."""
+    import ctypes as C
+    from ffpic_amd import capi
+    from test_oracle_golden import vp8_filter_header
+    g = golden("webp_file_1080p.npz")
+    w, h, pitch = [int(x) for x in g["dims"]]
+    c, r = (w + 15) // 16, (h + 15) // 16
+    filt = np.zeros((4, 2, 3), np.uint8)
+    ft = C.c_int(-1)
+    capi.check(capi.lib().ffhip_vp8_filter_params(C.byref(vp8_filter_header(g["lf"], g["lf_header"])), filt.ctypes.data, C.byref(ft)))
+    n = 256
+    modes = np.broadcast_to(g["modes"], (n,) + g["modes"].shape)
+    resid = np.broadcast_to(g["residual"], (n,) + g["residual"].shape)
+    y, u, v = ops.vp8_predict_loopfilter(c, r, np.ascontiguousarray(modes), np.ascontiguousarray(resid), ft.value, filt)
+    for i in range(1, n):
+        assert np.array_equal(y[i], y[0]) and np.array_equal(u[i], u[0]) and np.array_equal(v[i], v[0]), i
+    for i in (0, n // 2, n - 1):
+        bgra = ops.yuv420_to_bgra(y[i:i + 1], u[i:i + 1], v[i:i + 1], r, c, pitch=pitch)[0][:h]
+        assert np.array_equal(bgra[:32], g["bgra_head"])
+        rows = np.ascontiguousarray(bgra).reshape(h, -1).view(np.uint32).astype(np.uint64)
+        sums = (rows * (np.arange(rows.shape[1], dtype=np.uint64) + np.uint64(1))).sum(axis=1, dtype=np.uint64)
+        assert np.array_equal(sums, g["bgra_row_sums"]), i
+
+
 @pytest.mark.parametrize("env", [{"FFHIP_VP8_PRED_MODE": "levels"}, {"FFHIP_VP8_LF_MODE": "levels"}, {"FFHIP_VP8_FUSE": "0"},
                                  {"FFHIP_VP8_PRED_WAVES": "5", "FFHIP_VP8_LF_WAVES": "3"}])
 def test_side_by_side_call_under_every_scheduler(env, monkeypatch):

@@ -48,7 +48,7 @@ struct PlanArgs {
     uint32_t n_cells, cgh[3];
     uint32_t cell_off[3], cgw[3];
     int cshift[3];         /* log2 of the cell size in samples of the plane          */
-    unsigned long long *keys_in, *keys_out; /* (wavefront key << 32 | run) per run    */
+    uint32_t *keys32_in, *keys32_out;      /* wavefront key (the depth of its cell) per run */
     uint32_t *vals_in, *rank_of;           /* sort payload (run); ticket of a run    */
 };
 
@@ -79,75 +79,110 @@ __global__ __launch_bounds__(256) void k_plan_owner(PlanArgs a)
 
 /* longest dependency chain per cell (the wavefront index of the cell), inside ONE workgroup per plane.  Every edge a
  * cell can have points to a cell with a smaller x + 2y (left: -1, above: -2, above-left: -3, above-right: -1), so the
- * cells of one anti-diagonal x + 2y = K depend on finished diagonals only: ONE sweep over K, a barrier per diagonal, at
- * most one cell per row and step.  (The first form relaxed ALL cells until nothing changed -- as many rounds, each over
- * the whole plane: 0.95 ms for an 8K picture, more than a tenth of the config-5 chain.)  A grid of tiles still gets
- * depth 0 at every tile's first cell, which is the point of computing depths instead of using x + 2y itself. */
-#define CELLS_LDS 16384 /* cells of one plane the LDS form holds: 8K at 64x64 is 8 160 */
+ * cells of one anti-diagonal x + 2y = K depend on the three diagonals before it only: ONE sweep over K, at most one cell
+ * per row and step, and all a step reads of earlier results is a ring of four diagonals in LDS (ring[K & 3][row]) --
+ * results go to memory and are never read back.  (The first form relaxed ALL cells until nothing changed: 0.95 ms for an
+ * 8K picture.  The second kept the whole plane's depths in LDS when they fitted, 16 384 cells, and swept memory with a
+ * device-scope fence per diagonal when they did not: 0.12 ms for one 8K picture, but 3.0 ms for eight pictures' worth of
+ * tiles in one plane set, a third of that call.)  Planes of up to 256 rows of cells are swept by ONE wave, up to four rows
+ * per lane and no barrier (LDS serves a wave in program order); taller ones by 1024 threads and a barrier per diagonal.
+ * The cells' edge bits are packed two to a byte in LDS up front (114 688 cells: 7 300 x 4 000 coding tree blocks' worth
+ * would be a 450-megapixel plane); beyond that they are read from memory where they are needed.  A grid of tiles still
+ * gets depth 0 at every tile's first cell, which is the point of computing depths instead of using x + 2y itself. */
+#define CELLS_LDS 114688
+#define DEPTH_ROWS 1024 /* rows of cells one lane set covers per pass */
 __global__ __launch_bounds__(1024) void k_plan_cell_depth(PlanArgs a)
 {
-    __shared__ unsigned short dl[CELLS_LDS];
-    __shared__ unsigned char el[CELLS_LDS]; /* the cells' edge bits: read once, not once per diagonal step (a trip to memory each) */
+    __shared__ unsigned char el[CELLS_LDS / 2];
+    __shared__ unsigned short ring[4][DEPTH_ROWS];
     const int c = blockIdx.x;
     const uint32_t gw = a.cgw[c], gh = a.cgh[c], cnt = gw * gh;
     if (cnt == 0) return;
     const bool lds = cnt <= CELLS_LDS;
     uint32_t *dg = a.cell_depth + a.cell_off[c];
     const uint32_t *eg = a.cell_edges + a.cell_off[c];
+    const bool one_wave = blockDim.x == 64;
     if (lds) {
-#pragma unroll 8
-        for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) el[k] = (unsigned char)eg[k]; /* eight loads in flight per lane */
-        __syncthreads();
+#pragma unroll 4
+        for (uint32_t k = threadIdx.x; 2 * k < cnt; k += blockDim.x)
+            el[k] = (unsigned char)((eg[2 * k] & 15u) | (2 * k + 1 < cnt ? (eg[2 * k + 1] & 15u) << 4 : 0u));
     }
-    for (uint32_t K = 0; K <= (gw - 1) + 2 * (gh - 1); K++) {
-        for (uint32_t y = threadIdx.x; y < gh && 2 * y <= K; y += blockDim.x) {
-            const uint32_t x = K - 2 * y;
-            if (x >= gw) continue;
-            const uint32_t k = y * gw + x, e = lds ? (uint32_t)el[k] : eg[k];
-#define DEPTH(i) (lds ? (uint32_t)dl[i] : dg[i])
-            /* the four neighbours at once (a cell without that neighbour reads itself and ignores it): one LDS latency per
-             * step instead of four dependent ones */
-            const bool hl = x > 0, hu = y > 0, hr = y > 0 && x + 1 < gw;
-            const uint32_t dl_ = DEPTH(hl ? k - 1 : k), du_ = DEPTH(hu ? k - gw : k), dul_ = DEPTH(hl && hu ? k - gw - 1 : k), dur_ = DEPTH(hr ? k - gw + 1 : k);
-#undef DEPTH
-            uint32_t v = 0;
-            if ((e & 1u) && hl) v = max(v, dl_ + 1);
-            if ((e & 2u) && hu) v = max(v, du_ + 1);
-            if ((e & 4u) && hl && hu) v = max(v, dul_ + 1);
-            if ((e & 8u) && hr) v = max(v, dur_ + 1);
-            if (lds) dl[k] = (unsigned short)v;
-            else dg[k] = v;
+    for (uint32_t y = threadIdx.x; y < 4 * DEPTH_ROWS; y += blockDim.x) (&ring[0][0])[y] = 0;
+    __syncthreads();
+    for (uint32_t y0 = 0; y0 < gh; y0 += DEPTH_ROWS) { /* bands of DEPTH_ROWS rows of cells (one, short of a 65 536-line plane): a band reads the band above through memory */
+        const uint32_t rows = gh - y0 < DEPTH_ROWS ? gh - y0 : DEPTH_ROWS;
+        for (uint32_t K = 0; K <= (gw - 1) + 2 * (rows - 1); K++) {
+            for (uint32_t yl = threadIdx.x; yl < rows && 2 * yl <= K; yl += blockDim.x) {
+                const uint32_t x = K - 2 * yl, y = y0 + yl;
+                if (x >= gw) continue;
+                const uint32_t k = y * gw + x;
+                const uint32_t e = lds ? ((uint32_t)el[k >> 1] >> (4 * (k & 1))) & 15u : eg[k];
+                const bool hl = x > 0, hu = y > 0, hr = y > 0 && x + 1 < gw;
+                uint32_t v = 0;
+                if (yl > 0) { /* the row above is in the ring: diagonals K - 2 (above), K - 3 (above-left), K - 1 (above-right) */
+                    const uint32_t du_ = ring[(K - 2) & 3][yl - 1], dul_ = ring[(K - 3) & 3][yl - 1], dur_ = ring[(K - 1) & 3][yl - 1];
+                    if ((e & 2u) && hu) v = max(v, du_ + 1);
+                    if ((e & 4u) && hl && hu) v = max(v, dul_ + 1);
+                    if ((e & 8u) && hr) v = max(v, dur_ + 1);
+                } else if (hu) { /* first row of a later band: the band above finished before this one began */
+                    if (e & 2u) v = max(v, dg[k - gw] + 1);
+                    if ((e & 4u) && hl) v = max(v, dg[k - gw - 1] + 1);
+                    if ((e & 8u) && hr) v = max(v, dg[k - gw + 1] + 1);
+                }
+                if ((e & 1u) && hl) v = max(v, (uint32_t)ring[(K - 1) & 3][yl] + 1);
+                ring[K & 3][yl] = (unsigned short)v;
+                dg[k] = v;
+            }
+            if (one_wave) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            } else {
+                __syncthreads();
+            }
         }
-        if (!lds) __threadfence();
-        __syncthreads();
+        if (y0 + DEPTH_ROWS < gh) { /* the next band reads this band's last row from memory */
+            __threadfence();
+            __syncthreads();
+        }
     }
-    if (lds)
-        for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) dg[k] = dl[k];
 }
 
-/* per run: its wavefront key.  Runs of one cell share a key and keep their decode order (the run id in the low bits) */
-__global__ __launch_bounds__(256) void k_plan_keys(PlanArgs a)
+/* per run: its wavefront key, the depth of its cell.  The sort behind it is stable, so runs of one cell (equal keys) keep
+ * their decode order.  Only the first `m` entries exist: a plan is refused unless every window has ONE run, so there are
+ * never more runs than windows -- the sort's size, known on the host (an 8K picture: 24 480 against 215 472 TUs). */
+__global__ __launch_bounds__(256) void k_plan_keys(PlanArgs a, uint32_t m, uint32_t no_run)
 {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= a.n) return;
-    unsigned long long key = ~0ull; /* beyond the last run: sorts to the end */
+    if (r >= m) return;
+    uint32_t key = no_run; /* beyond the last run: above every depth, sorts to the end */
     if (r < a.result[1]) {
         const ffhip_hevc_tu t = a.tus[a.gstart[r]];
         const uint32_t cx = (uint32_t)(t.x >> a.cshift[t.cidx]), cy = (uint32_t)(t.y >> a.cshift[t.cidx]);
         const uint32_t depth = a.result[3] ? 0u : a.cell_depth[a.cell_off[t.cidx] + cy * a.cgw[t.cidx] + cx];
-        key = ((unsigned long long)depth << 32) | r;
-        /* how many runs can be at work at once: the grouped kernel keeps only about that many of its waves (the others would
-         * hold tickets far from their turn and poll).  Without wavefront keys (decode order) nothing is known: result[4] stays 0 */
-        if (!a.result[3]) atomicMax(a.result + 4, atomicAdd(a.depth_hist + (depth < a.n_cells ? depth : a.n_cells), 1u) + 1u);
+        key = depth;
+        /* how many runs can be at work at once (k_plan_rank takes the maximum): the grouped kernel keeps only about that many of
+         * its waves.  No value comes back from the add: returning atomics on a few hundred hot words, and an atomicMax of what
+         * they returned on ONE word, were 1.1 ms of a 1.8-million-TU plan */
+        if (!a.result[3]) atomicAdd(a.depth_hist + (depth < a.n_cells ? depth : a.n_cells), 1u);
     }
-    a.keys_in[r] = key;
+    a.keys32_in[r] = key;
     a.vals_in[r] = r;
 }
 
-__global__ __launch_bounds__(256) void k_plan_rank(PlanArgs a, const uint32_t *sorted_runs)
+__global__ __launch_bounds__(256) void k_plan_rank(PlanArgs a, const uint32_t *sorted_runs, uint32_t m)
 {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (a.result[1] > m) { /* more runs than windows: some window has two (k_plan_count has refused the list already); nothing was sorted for them */
+        if (k == 0) a.result[0] = 1;
+        return;
+    }
     if (k < a.result[1]) a.rank_of[sorted_runs[k]] = k;
+    /* the widest wavefront: without wavefront keys (decode order) nothing is known and result[4] stays 0 */
+    if (!a.result[3] && k <= a.n_cells) {
+        const uint32_t h = a.depth_hist[k];
+        if (h) atomicMax(a.result + 4, h);
+    }
 }
 
 /* the TUs of other runs TU i reads; returns their number (<= 66), fills deps when not NULL */
@@ -222,10 +257,11 @@ __global__ __launch_bounds__(256) void k_plan_count(PlanArgs a)
     }
 }
 
-__global__ __launch_bounds__(256) void k_plan_emit(PlanArgs a)
+__global__ __launch_bounds__(256) void k_plan_emit(PlanArgs a, uint32_t m)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n) return;
+    if (a.result[1] > m) return; /* refused (k_plan_rank): the runs have no tickets, and nobody will read a schedule */
     const ffhip_hevc_tu t = a.tus[i];
     const uint32_t wb = a.wbegin[i], wc = a.wcount[i];
     if (wc) {
@@ -281,7 +317,7 @@ extern "C" size_t ffhip_hevc_plan_gpu_words(long long n_tus, const int pw[3], co
     const size_t n = (size_t)n_tus;
     size_t scan_tmp = 0, sort_tmp = 0, cells = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (const uint32_t *)nullptr,
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
                                              (uint32_t *)nullptr, (int)n);
     if (sort_tmp > scan_tmp) scan_tmp = sort_tmp;
     for (int c = 0; c < 3; c++)
@@ -317,7 +353,7 @@ extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, 
     }
     size_t scan_tmp = 0, sort_tmp = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (const uint32_t *)nullptr,
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
                                              (uint32_t *)nullptr, (int)n);
     if (sort_tmp > scan_tmp) scan_tmp = sort_tmp;
     uint32_t *p = scratch;
@@ -353,8 +389,8 @@ extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, 
     uint32_t *vals_out = p; p += n;
     a.rank_of = p; p += n;
     p = (uint32_t *)(((uintptr_t)p + 7) & ~(uintptr_t)7);
-    a.keys_in = (unsigned long long *)p; p += 2 * n;
-    a.keys_out = (unsigned long long *)p; p += 2 * n;
+    a.keys32_in = p; p += 2 * n;      /* (sized as in round 2, when the keys were 64-bit: the layout formula is shared with the host) */
+    a.keys32_out = p; p += 2 * n;
     void *tmp = (void *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
     /* owner = -1, win_run = ~0: one memset over both; flags, result = 0 */
     FFHIP_CHECK(hipMemsetAsync(a.owner, 0xff, (blocks + wins) * 4, st), FFHIP_EIO);
@@ -372,12 +408,18 @@ extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, 
          * plane (a wave-local barrier per step), larger ones by 1024 threads so that a step stays one pass */
         uint32_t max_gh = 0;
         for (int c = 0; c < 3; c++) max_gh = a.cgh[c] > max_gh ? a.cgh[c] : max_gh;
-        hipLaunchKernelGGL(k_plan_cell_depth, dim3(3), dim3(max_gh <= 64 ? 64 : 1024), 0, st, a);
+        hipLaunchKernelGGL(k_plan_cell_depth, dim3(3), dim3(max_gh <= 256 ? 64 : 1024), 0, st, a);
     }
-    hipLaunchKernelGGL(k_plan_keys, dim3(grid), dim3(256), 0, st, a);
-    if (hipcub::DeviceRadixSort::SortPairs(tmp, scan_tmp, a.keys_in, a.keys_out, a.vals_in, vals_out, (int)n, 0, 64, st) != hipSuccess) return FFHIP_EIO;
-    hipLaunchKernelGGL(k_plan_rank, dim3(grid), dim3(256), 0, st, a, (const uint32_t *)vals_out);
-    hipLaunchKernelGGL(k_plan_emit, dim3(grid), dim3(256), 0, st, a);
+    const size_t m = n < wins ? n : wins; /* runs <= windows, or the plan is refused (k_plan_count: a window with two runs) */
+    int key_bits = 1;
+    while (key_bits < 32 && (1ull << key_bits) <= cells + 1) key_bits++; /* depths are < cells; 2^key_bits - 1 stands for "no run" and sorts last */
+    hipLaunchKernelGGL(k_plan_keys, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a, (uint32_t)m, (uint32_t)((1ull << key_bits) - 1));
+    if (hipcub::DeviceRadixSort::SortPairs(tmp, scan_tmp, a.keys32_in, a.keys32_out, a.vals_in, vals_out, (int)m, 0, key_bits, st) != hipSuccess) return FFHIP_EIO;
+    {
+        const size_t rk = (m > cells + 1 ? m : cells + 1);
+        hipLaunchKernelGGL(k_plan_rank, dim3((unsigned)((rk + 255) / 256)), dim3(256), 0, st, a, (const uint32_t *)vals_out, (uint32_t)m);
+    }
+    hipLaunchKernelGGL(k_plan_emit, dim3(grid), dim3(256), 0, st, a, (uint32_t)m);
     FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
     if (d_result) {
         *sched = a.sched;

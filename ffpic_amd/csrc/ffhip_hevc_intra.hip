@@ -1622,6 +1622,26 @@ static bool plan_groups(const ffhip_hevc_tu *tus, long long n_tus, const int pw[
     return true;
 }
 
+/* Host-side passes over a TU list (validation, the contiguity test) are ~2-4 ns per TU and thread: 7 ms for the 1.8 million TUs of
+ * eight 8K grids, more than the device needs for them.  Lists of 2^17 TUs and more are cut into pieces for up to 16 threads
+ * (started per call: ~20 us each, they work while the others start). */
+template <class F>
+static void host_parallel_for(long long n, F &&fn)
+{
+    const long long min_piece = 1 << 16;
+    unsigned hw = std::thread::hardware_concurrency();
+    long long nt = n / min_piece;
+    nt = nt > 16 ? 16 : nt;
+    nt = hw && nt > (long long)hw ? (long long)hw : nt;
+    if (nt < 2) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    th.reserve((size_t)nt - 1);
+    const long long piece = (n + nt - 1) / nt;
+    for (long long k = 1; k < nt; k++) th.emplace_back([&fn, k, piece, n]() { fn(k * piece, std::min(n, (k + 1) * piece)); });
+    fn(0, std::min(n, piece));
+    for (auto &t : th) t.join();
+}
+
 /* Are the groups of this window -- the TUs whose top-left corner falls into one window tile of one plane -- contiguous
  * runs of the list?  (Then a group is complete before a later one starts, the condition of the grouped kernel.)  One
  * byte map per plane, one pass; scratch kept per thread. */
@@ -1633,19 +1653,23 @@ static bool groups_contiguous(const ffhip_hevc_tu *tus, long long n_tus, const i
         gw[c] = pw[c] > 0 ? ((pw[c] - 1) >> win_log2[c]) + 1 : 0;
         seen[c].assign((size_t)gw[c] * (size_t)(ph[c] > 0 ? ((ph[c] - 1) >> win_log2[c]) + 1 : 0), 0);
     }
-    long long last = -1;
-    int last_c = -1;
-    for (long long i = 0; i < n_tus; i++) {
-        const ffhip_hevc_tu &t = tus[i];
-        const int c = t.cidx;
-        const long long w = (long long)(t.y >> win_log2[c]) * gw[c] + (t.x >> win_log2[c]);
-        if (w == last && c == last_c) continue;
-        if (seen[c][(size_t)w]) return false;
-        seen[c][(size_t)w] = 1;
-        last = w;
-        last_c = c;
-    }
-    return true;
+    uint8_t *const map[3] = {seen[0].data(), seen[1].data(), seen[2].data()};
+    std::atomic<bool> twice{false};
+    /* a TU opens a run where its window differs from its predecessor's: stateless per TU, so the list is cut into pieces for as
+     * many threads as pay (a window entered by two pieces is entered twice all the same: the mark is an atomic exchange) */
+    host_parallel_for(n_tus, [&](long long b, long long e) {
+        for (long long i = b; i < e && !twice.load(std::memory_order_relaxed); i++) {
+            const ffhip_hevc_tu &t = tus[i];
+            const int c = t.cidx;
+            const long long w = (long long)(t.y >> win_log2[c]) * gw[c] + (t.x >> win_log2[c]);
+            if (i > 0) {
+                const ffhip_hevc_tu &p = tus[i - 1];
+                if (p.cidx == c && (long long)(p.y >> win_log2[c]) * gw[c] + (p.x >> win_log2[c]) == w) continue;
+            }
+            if (__atomic_exchange_n(map[c] + w, (uint8_t)1, __ATOMIC_RELAXED)) twice.store(true, std::memory_order_relaxed);
+        }
+    });
+    return !twice.load();
 }
 
 /* the window search both entry points share: the requested (or default) luma window, halved until a
@@ -1702,22 +1726,29 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
     if (!ffhip_have_device()) return FFHIP_ENODEV;
     const int pw[3] = {width_y, width_c, width_c}, ph[3] = {height_y, height_c, height_c};
     /* validation: field ranges, the block inside its plane, and no availability bit pointing outside the plane */
-    bool has_res = false;
-    for (long long i = 0; i < n_tus; i++) {
-        const ffhip_hevc_tu &t = h_tus[i];
-        const int c = t.cidx, n = 1 << t.log2_size;
-        if (c > 2 || t.log2_size < 2 || t.log2_size > 5 || t.pred_mode > 34) return FFHIP_EINVAL;
-        if (c > 0 && (!d_cb || !d_cr || uv_stride < width_c)) return FFHIP_EINVAL;
-        if (t.x + n > pw[c] || t.y + n > ph[c]) return FFHIP_EINVAL;
-        const unsigned long long span = n == 32 ? ~0ull : (1ull << (2 * n)) - 1;
-        const unsigned long long top = t.avail_top & span, left = t.avail_left & span;
-        const int room_x = pw[c] - t.x, room_y = ph[c] - t.y; /* samples that exist right of x0 / below y0 */
-        if ((top || (t.flags & 1)) && t.y == 0) return FFHIP_EINVAL;
-        if ((left || (t.flags & 1)) && t.x == 0) return FFHIP_EINVAL;
-        if (room_x < 64 && (top >> room_x)) return FFHIP_EINVAL;
-        if (room_y < 64 && (left >> room_y)) return FFHIP_EINVAL;
-        has_res |= (t.flags & 2) != 0;
-    }
+    std::atomic<bool> bad{false}, any_res{false};
+    host_parallel_for(n_tus, [&](long long b, long long e) {
+        bool res = false, ok = true;
+        for (long long i = b; i < e && ok; i++) {
+            const ffhip_hevc_tu &t = h_tus[i];
+            const int c = t.cidx, n = 1 << t.log2_size;
+            if (c > 2 || t.log2_size < 2 || t.log2_size > 5 || t.pred_mode > 34) { ok = false; break; }
+            if (c > 0 && (!d_cb || !d_cr || uv_stride < width_c)) { ok = false; break; }
+            if (t.x + n > pw[c] || t.y + n > ph[c]) { ok = false; break; }
+            const unsigned long long span = n == 32 ? ~0ull : (1ull << (2 * n)) - 1;
+            const unsigned long long top = t.avail_top & span, left = t.avail_left & span;
+            const int room_x = pw[c] - t.x, room_y = ph[c] - t.y; /* samples that exist right of x0 / below y0 */
+            if ((top || (t.flags & 1)) && t.y == 0) ok = false;
+            if ((left || (t.flags & 1)) && t.x == 0) ok = false;
+            if (room_x < 64 && (top >> room_x)) ok = false;
+            if (room_y < 64 && (left >> room_y)) ok = false;
+            res |= (t.flags & 2) != 0;
+        }
+        if (!ok) bad.store(true, std::memory_order_relaxed);
+        if (res) any_res.store(true, std::memory_order_relaxed);
+    });
+    if (bad.load()) return FFHIP_EINVAL;
+    const bool has_res = any_res.load();
     /* wavefront levels at 4x4-block granularity, per plane: only the level-synchronous form needs them */
     std::vector<std::vector<uint32_t>> lists;
     auto build_levels = [&]() {

@@ -40,7 +40,6 @@ struct PlanArgs {
     u32x4 *sched, *groups;
     uint32_t *result;      /* [0] fail, [1] number of runs, [2] wait entries, [3] no wavefront keys, [4] the widest wavefront:
                               the largest number of runs that share a dependency depth */
-    uint32_t *depth_hist;  /* runs per wavefront index (cells of depth d: at most one run each and plane) */
     uint32_t wait_cap;     /* words reserved for wait_idx                           */
     uint32_t *cell_claim;  /* per 64x64-luma cell and plane: TU that opened it, ~0 = none (is the CTB 64?) */
     uint32_t *cell_edges;  /* bit 0 left, 1 above, 2 above-left, 3 above-right: cells this cell's TUs read */
@@ -51,6 +50,28 @@ struct PlanArgs {
     uint32_t *keys32_in, *keys32_out;      /* wavefront key (the depth of its cell) per run */
     uint32_t *vals_in, *rank_of;           /* sort payload (run); ticket of a run    */
 };
+
+struct PlanInit {
+    uint32_t *p[4];
+    size_t words[4];
+    uint32_t value[4];
+};
+__global__ __launch_bounds__(256) void k_plan_init(PlanInit in) /* blockIdx.y: the region */
+{
+    uint32_t *p = in.p[blockIdx.y];
+    const size_t words = in.words[blockIdx.y];
+    const uint32_t v = in.value[blockIdx.y];
+    const size_t head = (size_t)((4 - (((uintptr_t)p >> 2) & 3)) & 3); /* words in front of the first 16-byte boundary */
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
+    if (tid < head && tid < words) p[tid] = v;
+    if (words <= head) return;
+    u32x4 *q = (u32x4 *)(p + head);
+    const size_t quads = (words - head) / 4;
+    const u32x4 v4 = {v, v, v, v};
+    for (size_t i = tid; i < quads; i += nth) q[i] = v4;
+    const size_t tail = head + quads * 4;
+    if (tid < words - tail) p[tail + tid] = v;
+}
 
 __device__ __forceinline__ uint32_t win_of(const PlanArgs &a, const ffhip_hevc_tu &t)
 {
@@ -84,8 +105,8 @@ __global__ __launch_bounds__(256) void k_plan_owner(PlanArgs a)
  * results go to memory and are never read back.  (The first form relaxed ALL cells until nothing changed: 0.95 ms for an
  * 8K picture.  The second kept the whole plane's depths in LDS when they fitted, 16 384 cells, and swept memory with a
  * device-scope fence per diagonal when they did not: 0.12 ms for one 8K picture, but 3.0 ms for eight pictures' worth of
- * tiles in one plane set, a third of that call.)  Planes of up to 256 rows of cells are swept by ONE wave, up to four rows
- * per lane and no barrier (LDS serves a wave in program order); taller ones by 1024 threads and a barrier per diagonal.
+ * tiles in one plane set, a third of that call.)  A lane per row of cells: planes of up to 64 rows are swept by ONE wave
+ * and no barrier (LDS serves a wave in program order); taller ones by more waves and a barrier per diagonal.
  * The cells' edge bits are packed two to a byte in LDS up front (114 688 cells: 7 300 x 4 000 coding tree blocks' worth
  * would be a 450-megapixel plane); beyond that they are read from memory where they are needed.  A grid of tiles still
  * gets depth 0 at every tile's first cell, which is the point of computing depths instead of using x + 2y itself. */
@@ -161,10 +182,6 @@ __global__ __launch_bounds__(256) void k_plan_keys(PlanArgs a, uint32_t m, uint3
         const uint32_t cx = (uint32_t)(t.x >> a.cshift[t.cidx]), cy = (uint32_t)(t.y >> a.cshift[t.cidx]);
         const uint32_t depth = a.result[3] ? 0u : a.cell_depth[a.cell_off[t.cidx] + cy * a.cgw[t.cidx] + cx];
         key = depth;
-        /* how many runs can be at work at once (k_plan_rank takes the maximum): the grouped kernel keeps only about that many of
-         * its waves.  No value comes back from the add: returning atomics on a few hundred hot words, and an atomicMax of what
-         * they returned on ONE word, were 1.1 ms of a 1.8-million-TU plan */
-        if (!a.result[3]) atomicAdd(a.depth_hist + (depth < a.n_cells ? depth : a.n_cells), 1u);
     }
     a.keys32_in[r] = key;
     a.vals_in[r] = r;
@@ -177,12 +194,24 @@ __global__ __launch_bounds__(256) void k_plan_rank(PlanArgs a, const uint32_t *s
         if (k == 0) a.result[0] = 1;
         return;
     }
-    if (k < a.result[1]) a.rank_of[sorted_runs[k]] = k;
-    /* the widest wavefront: without wavefront keys (decode order) nothing is known and result[4] stays 0 */
-    if (!a.result[3] && k <= a.n_cells) {
-        const uint32_t h = a.depth_hist[k];
-        if (h) atomicMax(a.result + 4, h);
+    const uint32_t runs = a.result[1];
+    if (k >= runs) return;
+    a.rank_of[sorted_runs[k]] = k;
+    /* How many runs can be at work at once -- the widest wavefront, i.e. the longest stretch of equal keys in the sorted order:
+     * the grouped kernel keeps only about that many of its waves (the others would hold tickets far from their turn and poll).
+     * The first run of a stretch finds the stretch's end by bisection; without wavefront keys (decode order) nothing is known
+     * and result[4] stays 0.  (Counted by atomics while the keys were made -- 196 k adds on the two dozen words a grid of
+     * tiles has depths for -- this was 1.1 ms of an 1.8-million-TU plan, returning or not.) */
+    if (a.result[3]) return;
+    const uint32_t key = a.keys32_out[k];
+    if (k > 0 && a.keys32_out[k - 1] == key) return;
+    uint32_t lo = k, hi = runs; /* keys[lo] == key, keys[hi] != key (or hi == runs) */
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (a.keys32_out[mid] == key) lo = mid;
+        else hi = mid;
     }
+    atomicMax(a.result + 4, hi - k);
 }
 
 /* the TUs of other runs TU i reads; returns their number (<= 66), fills deps when not NULL */
@@ -382,7 +411,7 @@ extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, 
     a.cell_claim = p; p += cells;
     a.cell_edges = p; p += cells;
     a.cell_depth = p; p += cells;
-    a.depth_hist = p; p += cells + 1;
+    p += cells + 1; /* (a histogram of runs per depth until round 3; the layout formula is shared with the host) */
     a.n_cells = (uint32_t)cells;
     for (int c = 0; c < 3; c++) a.cgh[c] = pw[c] > 0 ? (uint32_t)(((ph[c] - 1) >> a.cshift[c]) + 1) : 0;
     a.vals_in = p; p += n;
@@ -392,11 +421,20 @@ extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, 
     a.keys32_in = p; p += 2 * n;      /* (sized as in round 2, when the keys were 64-bit: the layout formula is shared with the host) */
     a.keys32_out = p; p += 2 * n;
     void *tmp = (void *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
-    /* owner = -1, win_run = ~0: one memset over both; flags, result = 0 */
-    FFHIP_CHECK(hipMemsetAsync(a.owner, 0xff, (blocks + wins) * 4, st), FFHIP_EIO);
-    FFHIP_CHECK(hipMemsetAsync(a.flags, 0, ((n + 3) / 4 + 4 + 16) * 4, st), FFHIP_EIO);
-    FFHIP_CHECK(hipMemsetAsync(a.cell_claim, 0xff, cells * 4, st), FFHIP_EIO);
-    FFHIP_CHECK(hipMemsetAsync(a.cell_edges, 0, (3 * cells + 1) * 4, st), FFHIP_EIO); /* edges, depths, histogram */
+    /* owner = -1, win_run = ~0 (adjacent); flags, result = 0 (adjacent); cell_claim = ~0; cell_edges = 0 (the edge bits are OR-ed
+     * in; every cell's depth is written by the sweep): ONE launch for the four regions -- as four memsets they were four more
+     * kernel boundaries in front of a chain of a dozen small kernels */
+    {
+        PlanInit in;
+        in.p[0] = (uint32_t *)a.owner; in.words[0] = blocks + wins; in.value[0] = ~0u;
+        in.p[1] = (uint32_t *)a.flags; in.words[1] = (n + 3) / 4 + 4 + 16; in.value[1] = 0u;
+        in.p[2] = a.cell_claim; in.words[2] = cells; in.value[2] = ~0u;
+        in.p[3] = a.cell_edges; in.words[3] = cells; in.value[3] = 0u;
+        size_t most = 0;
+        for (int r = 0; r < 4; r++) most = in.words[r] > most ? in.words[r] : most;
+        const size_t wg = (most / 4 + 255) / 256 + 1;
+        hipLaunchKernelGGL(k_plan_init, dim3((unsigned)(wg > 4096 ? 4096 : wg), 4), dim3(256), 0, st, in);
+    }
     const unsigned grid = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_plan_owner, dim3(grid), dim3(256), 0, st, a);
     if (hipcub::DeviceScan::ExclusiveSum(tmp, scan_tmp, a.start, start_excl, (int)n, st) != hipSuccess) return FFHIP_EIO;
@@ -404,21 +442,20 @@ extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, 
     hipLaunchKernelGGL(k_plan_count, dim3(grid), dim3(256), 0, st, a);
     if (hipcub::DeviceScan::ExclusiveSum(tmp, scan_tmp, a.wcount, a.wbegin, (int)n, st) != hipSuccess) return FFHIP_EIO;
     /* tickets: runs sorted by (wavefront key of their cell, decode order) */
-    {   /* one diagonal per step, at most one cell per row of cells: a picture of up to 64 rows of cells is swept by ONE wave per
-         * plane (a wave-local barrier per step), larger ones by 1024 threads so that a step stays one pass */
+    {   /* one diagonal per step, at most one cell per row of cells, a lane per row: a picture of up to 64 rows of cells is swept by ONE
+         * wave per plane (a wave-local barrier per step), taller ones by as many waves as they have rows (up to 1024 threads) and a
+         * workgroup barrier per step.  (One wave with three rows per lane: 1.15 us a step on the 144-row plane of an eight-picture grid.) */
         uint32_t max_gh = 0;
         for (int c = 0; c < 3; c++) max_gh = a.cgh[c] > max_gh ? a.cgh[c] : max_gh;
-        hipLaunchKernelGGL(k_plan_cell_depth, dim3(3), dim3(max_gh <= 256 ? 64 : 1024), 0, st, a);
+        const unsigned threads = max_gh >= 1024 ? 1024u : (unsigned)((max_gh + 63) / 64 * 64);
+        hipLaunchKernelGGL(k_plan_cell_depth, dim3(3), dim3(threads ? threads : 64u), 0, st, a);
     }
     const size_t m = n < wins ? n : wins; /* runs <= windows, or the plan is refused (k_plan_count: a window with two runs) */
     int key_bits = 1;
     while (key_bits < 32 && (1ull << key_bits) <= cells + 1) key_bits++; /* depths are < cells; 2^key_bits - 1 stands for "no run" and sorts last */
     hipLaunchKernelGGL(k_plan_keys, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a, (uint32_t)m, (uint32_t)((1ull << key_bits) - 1));
     if (hipcub::DeviceRadixSort::SortPairs(tmp, scan_tmp, a.keys32_in, a.keys32_out, a.vals_in, vals_out, (int)m, 0, key_bits, st) != hipSuccess) return FFHIP_EIO;
-    {
-        const size_t rk = (m > cells + 1 ? m : cells + 1);
-        hipLaunchKernelGGL(k_plan_rank, dim3((unsigned)((rk + 255) / 256)), dim3(256), 0, st, a, (const uint32_t *)vals_out, (uint32_t)m);
-    }
+    hipLaunchKernelGGL(k_plan_rank, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a, (const uint32_t *)vals_out, (uint32_t)m);
     hipLaunchKernelGGL(k_plan_emit, dim3(grid), dim3(256), 0, st, a, (uint32_t)m);
     FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
     if (d_result) {

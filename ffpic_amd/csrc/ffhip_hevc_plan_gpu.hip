@@ -112,6 +112,9 @@ __global__ __launch_bounds__(256) void k_plan_owner(PlanArgs a)
  * gets depth 0 at every tile's first cell, which is the point of computing depths instead of using x + 2y itself. */
 #define CELLS_LDS 114688
 #define DEPTH_ROWS 1024 /* rows of cells one lane set covers per pass */
+template <bool FAST> /* FAST: every plane's edge bits fit the LDS form and no plane is taller than one band -- then the sweep has no LOAD from
+                        memory in it, and nothing makes a step wait for the result store of the step before (one counter serves loads and
+                        stores: with the slow paths' loads in the same loop every diagonal waited ~0.5 us for its own store) */
 __global__ __launch_bounds__(1024) void k_plan_cell_depth(PlanArgs a)
 {
     __shared__ unsigned char el[CELLS_LDS / 2];
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(1024) void k_plan_cell_depth(PlanArgs a)
     const int c = blockIdx.x;
     const uint32_t gw = a.cgw[c], gh = a.cgh[c], cnt = gw * gh;
     if (cnt == 0) return;
-    const bool lds = cnt <= CELLS_LDS;
+    const bool lds = FAST || cnt <= CELLS_LDS;
     uint32_t *dg = a.cell_depth + a.cell_off[c];
     const uint32_t *eg = a.cell_edges + a.cell_off[c];
     const bool one_wave = blockDim.x == 64;
@@ -130,6 +133,35 @@ __global__ __launch_bounds__(1024) void k_plan_cell_depth(PlanArgs a)
     }
     for (uint32_t y = threadIdx.x; y < 4 * DEPTH_ROWS; y += blockDim.x) (&ring[0][0])[y] = 0;
     __syncthreads();
+    if (FAST) { /* a lane per row, a step without a branch: ~40 instructions (what a lone wave pays per instruction and taken branch made the
+                   general loop below 0.47 us a step: 0.36 ms for the 768 diagonals of an eight-picture grid) */
+        const uint32_t yl = threadIdx.x, ym = yl ? yl - 1 : 0, rowbase = yl * gw;
+        const bool row = yl < gh, hu = yl > 0;
+        for (uint32_t K = 0; K <= (gw - 1) + 2 * (gh - 1); K++) {
+            const uint32_t x = K - 2 * yl;          /* wraps far beyond gw where the row has not started */
+            const bool valid = row && x < gw;
+            const uint32_t xc = valid ? x : 0, k = rowbase + xc;
+            const uint32_t e = ((uint32_t)el[k >> 1] >> (4 * (k & 1))) & 15u;
+            const bool hl = xc > 0, hr = hu && xc + 1 < gw;
+            const uint32_t dl_ = ring[(K - 1) & 3][yl], du_ = ring[(K - 2) & 3][ym], dul_ = ring[(K - 3) & 3][ym], dur_ = ring[(K - 1) & 3][ym];
+            uint32_t v = (((e & 1u) != 0) & hl) ? dl_ + 1 : 0u;
+            v = max(v, (((e & 2u) != 0) & hu) ? du_ + 1 : 0u);
+            v = max(v, (((e & 4u) != 0) & hl & hu) ? dul_ + 1 : 0u);
+            v = max(v, (((e & 8u) != 0) & hr) ? dur_ + 1 : 0u);
+            if (valid) {
+                ring[K & 3][yl] = (unsigned short)v;
+                dg[k] = v;
+            }
+            if (one_wave) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+        }
+        return;
+    }
     for (uint32_t y0 = 0; y0 < gh; y0 += DEPTH_ROWS) { /* bands of DEPTH_ROWS rows of cells (one, short of a 65 536-line plane): a band reads the band above through memory */
         const uint32_t rows = gh - y0 < DEPTH_ROWS ? gh - y0 : DEPTH_ROWS;
         for (uint32_t K = 0; K <= (gw - 1) + 2 * (rows - 1); K++) {
@@ -145,7 +177,7 @@ __global__ __launch_bounds__(1024) void k_plan_cell_depth(PlanArgs a)
                     if ((e & 2u) && hu) v = max(v, du_ + 1);
                     if ((e & 4u) && hl && hu) v = max(v, dul_ + 1);
                     if ((e & 8u) && hr) v = max(v, dur_ + 1);
-                } else if (hu) { /* first row of a later band: the band above finished before this one began */
+                } else if (!FAST && hu) { /* first row of a later band: the band above finished before this one began */
                     if (e & 2u) v = max(v, dg[k - gw] + 1);
                     if ((e & 4u) && hl) v = max(v, dg[k - gw - 1] + 1);
                     if ((e & 8u) && hr) v = max(v, dg[k - gw + 1] + 1);
@@ -159,7 +191,9 @@ __global__ __launch_bounds__(1024) void k_plan_cell_depth(PlanArgs a)
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             } else {
-                __syncthreads();
+                /* the ring lives in LDS: wait for LDS only.  __syncthreads() also drains the vector-memory counter, i.e. every diagonal
+                 * waited for its own result store to reach memory (0.5 us a step where the step's work is 0.15) */
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
         }
         if (y0 + DEPTH_ROWS < gh) { /* the next band reads this band's last row from memory */
@@ -448,7 +482,10 @@ extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, 
         uint32_t max_gh = 0;
         for (int c = 0; c < 3; c++) max_gh = a.cgh[c] > max_gh ? a.cgh[c] : max_gh;
         const unsigned threads = max_gh >= 1024 ? 1024u : (unsigned)((max_gh + 63) / 64 * 64);
-        hipLaunchKernelGGL(k_plan_cell_depth, dim3(3), dim3(threads ? threads : 64u), 0, st, a);
+        bool fast = max_gh <= DEPTH_ROWS;
+        for (int c = 0; c < 3; c++) fast = fast && (size_t)a.cgw[c] * a.cgh[c] <= CELLS_LDS;
+        if (fast) hipLaunchKernelGGL(k_plan_cell_depth<true>, dim3(3), dim3(threads ? threads : 64u), 0, st, a);
+        else hipLaunchKernelGGL(k_plan_cell_depth<false>, dim3(3), dim3(threads ? threads : 64u), 0, st, a);
     }
     const size_t m = n < wins ? n : wins; /* runs <= windows, or the plan is refused (k_plan_count: a window with two runs) */
     int key_bits = 1;

@@ -396,7 +396,8 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
             while (seen < want) {
                 seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(prog_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 if (seen >= want) break;
-                if (++spins > LF_SPIN_LIMIT || __hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                if (__hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false; /* given up elsewhere: whoever did has said why */
+                if (++spins > LF_SPIN_LIMIT) {
                     if (lane == 0) {
                         __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(a.async_err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -411,7 +412,14 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
             while (seen_pred < want_pred) {
                 seen_pred = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(pred_row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 if (seen_pred >= want_pred) break;
-                if (++spins > LF_SPIN_LIMIT || __hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                /* the prediction was refused (bad mode bytes) or gave up: it has reported why; this kernel just stops (the prediction's
+                 * abort word sits three words in front of its counters) */
+                if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.pred_progress - 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    if (lane == 0) __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return false;
+                }
+                if (__hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false; /* given up elsewhere: whoever did has said why */
+                if (++spins > LF_SPIN_LIMIT) {
                     if (lane == 0) {
                         __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(a.async_err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -188,6 +188,43 @@ def test_webp_file_1080p_side_by_side(golden):
         assert np.array_equal(sums, g["bgra_row_sums"]), i
 
 
+@pytest.mark.parametrize("entry", ["predict", "predict_loopfilter"])
+def test_bad_mode_bytes_in_a_large_batch_are_refused_through_the_stream(entry):
+    """Up to 2^17 macroblocks the mode bytes are checked on the host and the call returns FFHIP_EINVAL; beyond that a kernel in front of
+    the row kernel checks them, the call itself returns 0, nothing is written and ffhip_stream_sync reports FFHIP_EINVAL -- once: the
+    next sync is clean, and a valid call afterwards works (the side-by-side filter must neither hang nor report its own time-out)."""
+    from ffpic_amd import capi
+    L = capi.require_device()
+    c, r, n = 120, 68, 17                                     # 138 720 macroblocks
+    n_mb = c * r
+    m0, r0 = synth.vp8_modes(c, r, seed=31), synth.vp8_residual(n_mb, seed=32)
+    modes = np.ascontiguousarray(np.broadcast_to(m0, (n,) + m0.shape)).copy()
+    resid = np.ascontiguousarray(np.broadcast_to(r0, (n,) + r0.shape))
+    flt = synth.vp8_filters(seed=15)
+    dm_good = ops.DeviceBuffer(modes)
+    modes_bad = modes.copy()
+    modes_bad[n - 1, n_mb - 3, 0] = 9                         # one record of the last frame: not a VP8 16x16 mode
+    dm, dr, df = ops.DeviceBuffer(modes_bad), ops.DeviceBuffer(resid), ops.DeviceBuffer(np.ascontiguousarray(flt))
+    ysz, csz = 256 * n_mb, 64 * n_mb
+    dy, du, dv = ops.DeviceBuffer(nbytes=n * ysz), ops.DeviceBuffer(nbytes=n * csz), ops.DeviceBuffer(nbytes=n * csz)
+
+    def call(host_modes, dev_modes):
+        if entry == "predict":
+            return L.ffhip_vp8_predict_recon(c, r, n, host_modes.ctypes.data, dev_modes.ptr, dr.ptr, n_mb * 384, None, dy.ptr, du.ptr, dv.ptr, ysz, csz, None)
+        return L.ffhip_vp8_predict_loopfilter(c, r, n, host_modes.ctypes.data, dev_modes.ptr, dr.ptr, n_mb * 384, None, 2, df.ptr, dy.ptr, du.ptr, dv.ptr, ysz, csz, None)
+    for d in (dy, du, dv):
+        capi.check(L.ffhip_memset(d.ptr, 0x5a, d.nbytes, None))
+    capi.check(L.ffhip_stream_sync(None))
+    assert call(modes_bad, dm) == 0
+    assert L.ffhip_stream_sync(None) == capi.FFHIP_EINVAL
+    assert L.ffhip_stream_sync(None) == 0
+    assert (dy.to_host((n * ysz,), np.uint8) == 0x5a).all() and (du.to_host((n * csz,), np.uint8) == 0x5a).all()
+    assert call(modes, dm_good) == 0
+    assert L.ffhip_stream_sync(None) == 0
+    y = dy.to_host((n, 16 * r, 16 * c), np.uint8)
+    assert np.array_equal(y[0], y[n - 1]) and not (y[0] == 0x5a).all()
+
+
 def test_webp_file_1080p_256_frames(golden):
     """A chip-filling batch: 256 copies of the real encoder's 1080p frame in ONE ffhip_vp8_predict_loopfilter call (the frame loop
     of webp.c:1833-1866; the wave caps follow residency at this size, not 16 waves per image).  Every frame's planes equal the

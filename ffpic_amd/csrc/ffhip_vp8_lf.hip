@@ -414,7 +414,9 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
                 if (seen_pred >= want_pred) break;
                 /* the prediction was refused (bad mode bytes) or gave up: it has reported why; this kernel just stops (the prediction's
                  * abort word sits three words in front of its counters) */
-                if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.pred_progress - 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                /* looked at every 64th poll only: the word shares its cache line with the prediction's ticket counter, and a load per
+                 * poll from every waiting filter wave slowed a 1024-frame call by a third */
+                if ((spins & 63) == 63 && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.pred_progress - 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                     if (lane == 0) __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     return false;
                 }

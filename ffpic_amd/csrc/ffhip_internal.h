@@ -77,6 +77,7 @@ struct FfhipVp8Fusion {
     const uint32_t *pred_progress;
     void *side;  /* hipStream_t */
     void *fork;  /* hipEvent_t  */
+    int pred_split; /* the prediction runs luma and chroma rows apart: its chroma counters (behind the luma ones) count too */
 };
 extern thread_local FfhipVp8Fusion g_ffhip_vp8_fusion;
 

@@ -37,6 +37,7 @@ struct Vp8LfArgs {
     int n_images;
     int slack; /* as in Vp8PredArgs */
     const uint32_t *pred_progress; /* fused with the prediction (ffhip_vp8_predict_loopfilter): its per-(image, row) counters, else null */
+    int pred_split;                /* that prediction runs its chroma as rows of their own: their counters follow the luma rows' */
 };
 
 __device__ __forceinline__ int sclip1(int v) { return v < -128 ? -128 : (v > 127 ? 127 : v); }
@@ -370,7 +371,8 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
          * row below and of the right neighbour still reads unfiltered (predict.c reads reconstructed, not filtered, samples),
          * and rows 13-15 of the row above, which the prediction of this row read.  The last row has no row below. */
         const uint32_t *pred_row = a.pred_progress ? a.pred_progress + (long long)img * a.mbrows + (y + 1 < a.mbrows ? y + 1 : y) : nullptr;
-        unsigned seen_pred = a.pred_progress ? 0u : 0x7fffffffu;
+        unsigned seen_pred = a.pred_progress ? 0u : 0x7fffffffu, seen_pred_c = seen_pred;
+        const uint32_t *pred_row_c = pred_row ? pred_row + (long long)a.n_images * a.mbrows : nullptr; /* the chroma rows' counters follow the luma rows' */
         const __amdgpu_buffer_rsrc_t rY = ffhip_rsrc(Y, 256u * (unsigned)n_mb), rU = ffhip_rsrc(P[0], 64u * (unsigned)n_mb),
                                      rV = ffhip_rsrc(P[1], 64u * (unsigned)n_mb);
         const int row_org = y * 16 * ys, row_corg = y * 8 * us;
@@ -408,29 +410,36 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
                 else __builtin_amdgcn_s_sleep(16);
             }
             const unsigned need_pred = (unsigned)(x1 + 2 < a.mbcols ? x1 + 2 : a.mbcols);
-            const unsigned want_pred = seen_pred < need_pred ? ((need_pred + (unsigned)a.slack) < (unsigned)a.mbcols ? need_pred + (unsigned)a.slack : (unsigned)a.mbcols) : need_pred;
-            while (seen_pred < want_pred) {
-                seen_pred = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(pred_row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                if (seen_pred >= want_pred) break;
-                /* the prediction was refused (bad mode bytes) or gave up: it has reported why; this kernel just stops (the prediction's
-                 * abort word sits three words in front of its counters) */
-                /* looked at every 64th poll only: the word shares its cache line with the prediction's ticket counter, and a load per
-                 * poll from every waiting filter wave slowed a 1024-frame call by a third */
-                if ((spins & 63) == 63 && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.pred_progress - 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                    if (lane == 0) __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return false;
-                }
-                if (__hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false; /* given up elsewhere: whoever did has said why */
-                if (++spins > LF_SPIN_LIMIT) {
-                    if (lane == 0) {
-                        __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(a.async_err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            /* the prediction's luma rows and (normal filter: it rewrites chroma too) its chroma rows, which are rows of their own
+             * with counters of their own since round 3 and run ahead of the luma: their counter is polled only while it is short */
+            auto wait_pred = [&](const uint32_t *row, unsigned &seen_p) -> bool {
+                const unsigned want_pred = seen_p < need_pred ? ((need_pred + (unsigned)a.slack) < (unsigned)a.mbcols ? need_pred + (unsigned)a.slack : (unsigned)a.mbcols) : need_pred;
+                while (seen_p < want_pred) {
+                    seen_p = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (seen_p >= want_pred) break;
+                    /* the prediction was refused (bad mode bytes) or gave up: it has reported why; this kernel just stops (the prediction's
+                     * abort word sits three words in front of its counters) */
+                    /* looked at every 64th poll only: the word shares its cache line with the prediction's ticket counter, and a load per
+                     * poll from every waiting filter wave slowed a 1024-frame call by a third */
+                    if ((spins & 63) == 63 && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.pred_progress - 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                        if (lane == 0) __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        return false;
                     }
-                    return false;
+                    if (__hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false; /* given up elsewhere: whoever did has said why */
+                    if (++spins > LF_SPIN_LIMIT) {
+                        if (lane == 0) {
+                            __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(a.async_err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                        return false;
+                    }
+                    if (spins < 16) __builtin_amdgcn_s_sleep(1);
+                    else __builtin_amdgcn_s_sleep(16);
                 }
-                if (spins < 16) __builtin_amdgcn_s_sleep(1);
-                else __builtin_amdgcn_s_sleep(16);
-            }
+                return true;
+            };
+            if (!wait_pred(pred_row, seen_pred)) return false;
+            if (type != 1 && a.pred_split && !wait_pred(pred_row_c, seen_pred_c)) return false;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* ordering only */
             const u32 *mp = (const u32 *)(mrow + (long long)x1 * 20);
             f.m0 = mp[0];
@@ -457,8 +466,12 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
         LfFetch f;
         f.cu = f.cv = 0;
         if (!fetch(0, f)) return;
-        for (int x = 0; x < a.mbcols; x++) {
-            /* ---- consume: the tile's right end becomes the left border, the fetch the new columns ---- */
+        /* The fetch of macroblock x + 1 is consumed at the END of macroblock x, in front of x's stores (k_vp8_predict_rows has the
+         * reasoning: consumed at the loop's top, the wait for the fetched registers was a wait for the stores just issued to
+         * complete).  The tile shifts when the fetch goes in, so the four dwords a lane writes back are read from the tile first. */
+        u32 m0 = 0, m4 = 0; /* mode bytes 0..3 and 16..19 of the macroblock at hand */
+        auto consume = [&]() {
+            /* the tile's right end becomes the left border, the fetch the new columns */
             const u32 keep = LDS32(keep_src);
             wave_sync();
             LDS32(keep_dst) = keep;
@@ -468,9 +481,13 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
                 LDS32(dcu) = f.cu;
                 LDS32(dcv) = f.cv;
             }
-            const u32 m0 = (u32)__builtin_amdgcn_readfirstlane((int)f.m0), m4 = (u32)__builtin_amdgcn_readfirstlane((int)f.m4);
+            m0 = (u32)__builtin_amdgcn_readfirstlane((int)f.m0);
+            m4 = (u32)__builtin_amdgcn_readfirstlane((int)f.m4);
             wave_sync();
-            /* the fetch just consumed was issued behind the stores of macroblock x - 2: those are done */
+        };
+        consume();
+        for (int x = 0; x < a.mbcols; x++) {
+            /* the fetch consumed at the end of the previous iteration was issued behind the stores of macroblock x - 2: those are done */
             if (lane == 0 && x >= 2) __hip_atomic_store(prog_me, (unsigned)(x - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (x + 1 < a.mbcols && !fetch(x + 1, f)) return;
 
@@ -478,6 +495,7 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
             const uint8_t *fp = FT + ((((m4 >> 16) & 3) * 2) + (bpred ? 1 : 0)) * 3;
             const int sub = __builtin_amdgcn_readfirstlane((int)fp[0]), inter = __builtin_amdgcn_readfirstlane((int)fp[1]),
                       hevt = __builtin_amdgcn_readfirstlane((int)fp[2]);
+            u32 wb0 = 0, wb1 = 0, wbu = 0, wbv = 0;
             if (sub) { /* wave-uniform */
                 /* webp.c:1710-1745: inner edges for B_PRED MBs in the simple filter, for the others in the normal one */
                 const bool inner = type == 1 ? bpred : !bpred;
@@ -490,18 +508,23 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
                 wave_sync();
                 filter_phase<LS, TYPE>(mine + li + 4, active, lum, y > 0, inner, sub, inter, hevt);
                 wave_sync();
+                wb0 = LDS32(sy0); wb1 = LDS32(sy1);
+                if (type != 1) { wbu = LDS32(scu); wbv = LDS32(scv); }
+            }
+            wave_sync();
+            if (x + 1 < a.mbcols) consume();
+            if (sub) {
                 /* ---- write back rows -4..15, columns -4..15 as dwords (the cells this macroblock did not change are
                  * rewritten with the value it read: their owners are finished) -- but nothing outside the picture ---- */
                 const int org = row_org + x * 16, corg = row_corg + x * 8;
-                __builtin_amdgcn_raw_buffer_store_b32(LDS32(sy0), rY, lane_select(x > 0 ? ok0 : first0, LF_OUT, wy0) + org, 0, FFHIP_AUX_SC1);
-                __builtin_amdgcn_raw_buffer_store_b32(LDS32(sy1), rY, lane_select(x > 0 ? ok1 : first1, LF_OUT, wy1) + org, 0, FFHIP_AUX_SC1);
+                __builtin_amdgcn_raw_buffer_store_b32(wb0, rY, lane_select(x > 0 ? ok0 : first0, LF_OUT, wy0) + org, 0, FFHIP_AUX_SC1);
+                __builtin_amdgcn_raw_buffer_store_b32(wb1, rY, lane_select(x > 0 ? ok1 : first1, LF_OUT, wy1) + org, 0, FFHIP_AUX_SC1);
                 if (type != 1) {
                     const int oc = lane_select(x > 0 ? okc : firstc, LF_OUT, wc) + corg; /* added here, not as the scalar offset: the range check looks at this operand alone, and a lane's offset may be negative */
-                    __builtin_amdgcn_raw_buffer_store_b32(LDS32(scu), rU, oc, 0, FFHIP_AUX_SC1);
-                    __builtin_amdgcn_raw_buffer_store_b32(LDS32(scv), rV, oc, 0, FFHIP_AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(wbu, rU, oc, 0, FFHIP_AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(wbv, rV, oc, 0, FFHIP_AUX_SC1);
                 }
             }
-            wave_sync();
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -511,7 +534,7 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
 
 #define SCRATCH_VP8_LF 2
 
-thread_local FfhipVp8Fusion g_ffhip_vp8_fusion = {0, nullptr, nullptr, nullptr};
+thread_local FfhipVp8Fusion g_ffhip_vp8_fusion = {0, nullptr, nullptr, nullptr, 0};
 
 extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int filter_type, const uint8_t *d_modes,
                                     const uint8_t *d_filters, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
@@ -541,6 +564,7 @@ extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int fi
         FFHIP_CHECK(hipMemsetAsync(g_work, 0, words * sizeof(uint32_t), st), FFHIP_EIO);
         Vp8LfArgs a = {};
         a.pred_progress = pred_progress;
+        a.pred_split = pred_progress ? g_ffhip_vp8_fusion.pred_split : 0;
         a.modes = d_modes; a.filters = d_filters; a.y = d_y; a.u = d_u; a.v = d_v;
         a.plane_y = plane_stride_y; a.plane_uv = plane_stride_uv;
         a.mbcols = mbcols; a.mbrows = mbrows; a.filter_type = filter_type;

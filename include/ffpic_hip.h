@@ -317,7 +317,8 @@ int ffhip_hevc_residual_batch(int nTbS, long long n_tu, const int16_t *d_level, 
  *                      [2..17] imodes[16] (4x4 modes 0..9), [18..19] 0  (format/webp.h:243-256).
  *                      A y / uv mode out of range is FFHIP_EINVAL: from this call for batches of up
  *                      to 2^17 macroblocks (checked on the host copy), for larger ones from the next
- *                      ffhip_stream_sync (checked by the kernel; the planes are then unspecified)
+ *                      ffhip_stream_sync (checked by a kernel in front of the prediction: the planes
+ *                      are then left untouched)
  *   d_residual         int16 [n_images][.][384], image i at + i*residual_stride (elements)
  *   d_resmap           int32 [n_images][n_mb] residual row used by each macroblock, or NULL for
  *                      the identity; the reference keeps the PREVIOUS macroblock's coefficients

@@ -825,12 +825,9 @@ struct ProgArgs {
     const uint32_t *plan_result;
     uint32_t wait_cap;
 };
-__global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
+/* the program of ONE slot, by one wave (k is wave-uniform) */
+__device__ __forceinline__ void intra_program_slot(const ProgArgs &a, const uint32_t k, const int lane)
 {
-    const uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (k >= a.n_slots) return;
-    if (a.plan_result && (a.plan_result[0] | (a.plan_result[2] > a.wait_cap ? 1u : 0u))) return; /* refused plan: the slots mean nothing */
     const u32x4 q0 = a.sched[(size_t)k * 3], q2 = a.sched[(size_t)k * 3 + 2];
     const u32x4 generic = {PK_SLOW, PROG_NO_RESIDUAL, 0u, 0u};
     const int x0 = (int)(q0.x & 0xffff), y0 = (int)(q0.x >> 16);
@@ -920,6 +917,36 @@ __global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
     }
 }
 
+/* A wave takes 64 consecutive slots: every lane decides for ITS slot whether it can be a program at all -- the answer is no for
+ * the TUs above 8x8, rdpcm / cross-component TUs and TUs whose in-window neighbours another group wrote, i.e. for most of a
+ * config-5 list -- and marks the others generic; then the wave builds the programs of the slots that remain, one after the other.
+ * (One wave per slot, as before round 3, was bound by the rate waves can be started at: 0.75 ms for the 1.84 M slots of an
+ * eight-picture grid, most of which left after reading two dwords.) */
+__global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64u;
+    if (base >= a.n_slots) return;
+    if (a.plan_result && (a.plan_result[0] | (a.plan_result[2] > a.wait_cap ? 1u : 0u))) return; /* refused plan: the slots mean nothing */
+    const uint32_t k = base + (uint32_t)lane;
+    bool prog = false;
+    if (k < a.n_slots) {
+        const u32x4 q0 = a.sched[(size_t)k * 3], q2 = a.sched[(size_t)k * 3 + 2];
+        const int lg = (int)(q0.y & 0xff), cidx = (int)((q0.y >> 8) & 0xff), flags = (int)(q0.y >> 24);
+        prog = lg <= 3 && (1 << lg) <= (1 << a.wl[cidx]) && ((q2.y >> 9) & 1) && !(flags & 0xC0) && q0.z < 0x7fff0000u;
+        if (!prog) {
+            const u32x4 generic = {PK_SLOW, PROG_NO_RESIDUAL, 0u, 0u};
+            a.sched[(size_t)k * 3 + 1] = generic;
+        }
+    }
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(prog);
+    while (todo) {
+        const int b = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        intra_program_slot(a, base + (uint32_t)b, lane);
+    }
+}
+
 template <class MID>
 __device__ __forceinline__ void intra_tu_g_any(const HotArgs &a, const GroupCtx &g, const IntraSlot &t, const int lane, int *s, int *s2, short *R,
                                                const ResPrefetch &rp, const JPrefetch &jp, short *tile, const short *zero_block, MID &&mid)
@@ -943,10 +970,14 @@ struct JTabArgs {
     int bw[3];
     uint32_t boff[3];
 };
+#define JT_TUS_PER_WAVE 4 /* consecutive TUs a wave takes, one after the other: a wave per TU was bound by the rate waves start at */
 __global__ __launch_bounds__(256) void k_hevc_intra_jtable(JTabArgs a)
 {
-    const uint32_t i_tu = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    const uint32_t first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * JT_TUS_PER_WAVE;
+#pragma unroll
+    for (uint32_t q = 0; q < JT_TUS_PER_WAVE; q++) {
+    const uint32_t i_tu = first + q;
     if (i_tu >= a.n) return;
     const ffhip_hevc_tu t = a.tus[i_tu];
     const int n = 1 << t.log2_size, cnt = 4 * n + 1;
@@ -980,6 +1011,7 @@ __global__ __launch_bounds__(256) void k_hevc_intra_jtable(JTabArgs a)
             if (j < 0) j = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : 128);
         }
         out[i] = (uint8_t)j;
+    }
     }
 }
 
@@ -1820,12 +1852,12 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
         for (int c = 0; c < 3; c++) { pa.wl[c] = win[c]; pa.stride[c] = a.stride[c]; }
         pa.plan_result = a.plan_result; pa.wait_cap = a.wait_cap;
         a.desc = pa.desc;
-        hipLaunchKernelGGL(k_hevc_intra_program, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, st, pa);
+        hipLaunchKernelGGL(k_hevc_intra_program, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, pa);
     };
     auto enqueue_jtable = [&](uint32_t *words) {
         ja.tus = d_tus; ja.n = (uint32_t)n_tus; ja.jt = (uint8_t *)words;
         a.jt = ja.jt;
-        hipLaunchKernelGGL(k_hevc_intra_jtable, dim3((unsigned)((n_tus + 3) / 4)), dim3(256), 0, st, ja);
+        hipLaunchKernelGGL(k_hevc_intra_jtable, dim3((unsigned)((n_tus + 4 * JT_TUS_PER_WAVE - 1) / (4 * JT_TUS_PER_WAVE))), dim3(256), 0, st, ja);
     };
     if (want_groups && async_err && offsets_fit && jt_blocks * JT_STRIDE < (1ull << 32) && desc_px < (1ull << 29) /* 32-bit byte offsets into a plane, the table and the pixel words */) {
         const char *we = FFHIP_ENV("FFHIP_HEVC_INTRA_WINDOW");

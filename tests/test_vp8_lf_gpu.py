@@ -253,10 +253,15 @@ def test_webp_file_1080p_256_frames(golden):
 
 
 @pytest.mark.parametrize("env", [{"FFHIP_VP8_PRED_MODE": "levels"}, {"FFHIP_VP8_LF_MODE": "levels"}, {"FFHIP_VP8_FUSE": "0"},
-                                 {"FFHIP_VP8_PRED_WAVES": "5", "FFHIP_VP8_LF_WAVES": "3"}])
+                                 {"FFHIP_VP8_PRED_WAVES": "5", "FFHIP_VP8_LF_WAVES": "3"},
+                                 {"FFHIP_VP8_PRED_SPLIT": "0"}, {"FFHIP_VP8_PRED_SPLIT": "1"},
+                                 {"FFHIP_VP8_PRED_SPLIT": "1", "FFHIP_VP8_PRED_WAVES": "2", "FFHIP_VP8_LF_WAVES": "3"},
+                                 {"FFHIP_VP8_PRED_SPLIT": "1", "FFHIP_VP8_PRED_WAVES": "1", "FFHIP_VP8_FUSE": "0"}])
 def test_side_by_side_call_under_every_scheduler(env, monkeypatch):
     """ffhip_vp8_predict_loopfilter when one of its stages cannot take the row form (then they run one after the other), when
-    told not to overlap, and with far fewer waves than rows (tickets, not residency, order the rows of both kernels)"""
+    told not to overlap, with far fewer waves than rows (tickets, not residency, order the rows of both kernels), and in both
+    forms of the prediction's rows -- one wave per macroblock row, or luma rows and chroma rows on different waves with counters
+    of their own that the filter waits for too (with two waves: one of each kind; with one, not overlapped: it does both)"""
     for k, v in env.items():
         monkeypatch.setenv(k, v); capi.reload_env()
     c, r, n = 21, 13, 3

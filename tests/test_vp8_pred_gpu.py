@@ -57,7 +57,8 @@ def test_1080p_frame():
     check(c, r, synth.vp8_modes(c, r, seed=4), synth.vp8_residual(c * r, seed=4))
 
 
-@pytest.mark.parametrize("env", [{"FFHIP_VP8_PRED_MODE": "levels"}, {"FFHIP_VP8_PRED_WAVES": "3"}, {}])
+@pytest.mark.parametrize("env", [{"FFHIP_VP8_PRED_MODE": "levels"}, {"FFHIP_VP8_PRED_WAVES": "3"}, {}, {"FFHIP_VP8_PRED_SPLIT": "0"},
+                                 {"FFHIP_VP8_PRED_SPLIT": "1", "FFHIP_VP8_PRED_WAVES": "1"}, {"FFHIP_VP8_PRED_SPLIT": "1", "FFHIP_VP8_PRED_WAVES": "7"}])
 def test_schedulers_agree(env, monkeypatch):
     """level-synchronous launches, and the single row-form launch with few and with many waves"""
     for k, v in env.items():

@@ -22,16 +22,16 @@ from ffpic_amd import capi, ops, synth
 pytestmark = pytest.mark.gpu
 
 
-def _jpeg_full_batch(cols, rows, n, n_unique, seed, must_cross=()):
+def _jpeg_full_batch(cols, rows, n, n_unique, seed, must_cross=(), h=2, v=2):
     torch = pytest.importorskip("torch")
     capi.require_device()
     dev = torch.device("cuda:0")
-    geom = O.make_geom(cols, rows)
-    cg = capi.jpeg_geom(cols, rows)
+    geom = O.make_geom(cols, rows, 3, h, v)
+    cg = capi.jpeg_geom(cols, rows, 3, h, v)
     H, W = geom.height, geom.width
     mcus = cols * rows
     q = synth.quant_tables()
-    cy, cu, cv = synth.coef_batch(n_unique, cols, rows, first=seed)
+    cy, cu, cv = synth.coef_batch(n_unique, cols, rows, h=h, v=v, first=seed)
     exp = O.oracle_jpeg_recon(geom, cy, cu, cv, q, n_images=n_unique, n_threads=4)
     rng = np.random.default_rng(seed)
     order = rng.integers(0, n_unique, size=n)
@@ -77,6 +77,15 @@ def test_c3_4k_batch_crossing_4gib():
     assert (out_straddle, coef_straddle) == (129, 258)
     for i in (0, out_straddle, coef_straddle, n - 1):
         assert np.array_equal(o[i].cpu().numpy().reshape(H, W, 4), exp[int(order[i])]), i
+
+
+@pytest.mark.parametrize("h,v", [(4, 1), (1, 4), (1, 1)])
+def test_4k_batches_of_the_other_layouts(h, v):
+    """The MCU layouts round 3 added (4:1:1 = h4v1 and its transpose) and 4:4:4 at the headline's picture size, 64 images in one
+    launch of the fused strip kernel: every image against the oracle's bytes (3840 is 120 MCUs of 32 pixels; 2160 is not a whole
+    number of 32-line MCUs, so the h1v4 pictures are 2176 lines)"""
+    cols, rows = 3840 // (8 * h), -(-2160 // (8 * v))
+    _jpeg_full_batch(cols, rows, 64, 3, seed=4100 + 10 * h + v, h=h, v=v)
 
 
 def _intra_full_picture(W, H, tus, res):

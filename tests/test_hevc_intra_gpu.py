@@ -272,3 +272,31 @@ def test_isp_picture_vs_reference(golden, tag):
     got = ops.hevc_intra_recon(tus, res, w, h, True, 8, 8)
     assert np.array_equal(got[0][0], g[f"{tag}_row0"]) and np.array_equal(got[0][h - 1], g[f"{tag}_lastrow"])
     assert isp_digest(got) == g[f"{tag}_sha256"].tobytes()
+
+
+def test_one_bad_tu_in_a_list_validated_by_several_threads():
+    """Lists of 2^17 TUs and more are validated (and tested for contiguity) in pieces by several host threads: a TU that lies outside
+    its plane, an availability bit that points outside, a bad size -- one of them in the LAST piece -- still make the call
+    FFHIP_EINVAL before anything is enqueued; the untouched list decodes bit for bit."""
+    L = capi.require_device()
+    w, h = 3840, 2176
+    tus, res = synth.hevc_intra_tus(w, h, seed=91)
+    assert len(tus) >= (1 << 17) + 1000
+    want = ops.hevc_intra_recon(tus, res, w, h, True, 8, 8)
+    exp = O.oracle_hevc_intra(tus, res, w, h, True, 8, 8)
+    for a, b in zip(want, exp):
+        assert np.array_equal(a, b)
+    dt, dr = ops.DeviceBuffer(tus.view(np.uint8)), ops.DeviceBuffer(res)
+    dy, du, dv = ops.DeviceBuffer(nbytes=w * h * 2), ops.DeviceBuffer(nbytes=w * h // 2), ops.DeviceBuffer(nbytes=w * h // 2)
+
+    def call(t):
+        return L.ffhip_hevc_intra_recon(t.ctypes.data, dt.ptr, len(t), dr.ptr, dy.ptr, du.ptr, dv.ptr, w, h, w, w // 2, h // 2, w // 2, 8, 8, None)
+    for field, value in (("x", w), ("log2_size", 6), ("pred_mode", 35), ("cidx", 3)):
+        bad = tus.copy()
+        bad[field][len(bad) - 7] = value
+        assert call(bad) == capi.FFHIP_EINVAL, field
+    bad = tus.copy()
+    i = int(np.nonzero((bad["y"] == 0) & (bad["cidx"] == 0))[0][-1])      # a TU of the top row claims a row above
+    bad["avail_top"][i] = 1
+    assert call(bad) == capi.FFHIP_EINVAL
+    capi.check(L.ffhip_stream_sync(None))

@@ -26,7 +26,10 @@ uint8_t *ffhip_pinned_scratch(int kind, void *stream, size_t bytes); /* per (kin
 int *ffhip_async_err_word(void); /* pinned word kernels report an in-launch abort through; see ffhip_stream_sync */
 /* The FFHIP_* switches (A/B knobs of the tools, diagnostics) are read from the environment ONCE per process, at a call
  * site's first use, and kept; ffhip_reload_env() (public, include/ffpic_hip.h) makes every site read its switch again. */
-struct ffhip_env_site { const char *name; int gen; int set; char val[56]; };
+/* `val` points into storage the library keeps for the life of the process (values are interned, whatever their length:
+ * FFHIP_RCCL_LIB is a path), so a pointer a caller got stays valid and unchanged across ffhip_reload_env(); `gen` and `val`
+ * are only touched with atomic loads / stores (val first, then gen with release), so lookups may race with a reload. */
+struct ffhip_env_site { const char *name; int gen; const char *val; };
 const char *ffhip_env_lookup(struct ffhip_env_site *site); /* NULL when unset */
 int ffhip_resident_waves(const void *kernel, int block_threads); /* workgroups of `block_threads` threads of `kernel` the device holds at once (occupancy x CUs), cached */
 #ifdef __cplusplus
@@ -38,7 +41,7 @@ int ffhip_resident_waves(const void *kernel, int block_threads); /* workgroups o
 #define FFHIP_ASYNC_BAD_INPUT 4
 
 #ifdef __cplusplus
-#define FFHIP_ENV(NAME) ([]() -> const char * { static struct ffhip_env_site site = {NAME, -1, 0, {0}}; return ffhip_env_lookup(&site); }())
+#define FFHIP_ENV(NAME) ([]() -> const char * { static struct ffhip_env_site site = {NAME, -1, nullptr}; return ffhip_env_lookup(&site); }())
 #endif
 
 typedef unsigned int u32;

@@ -17,21 +17,49 @@ static char g_last_error[256] = "";
 #include <atomic>
 #include <map>
 #include <mutex>
+#include <set>
+#include <string>
+#include <tuple>
 static std::atomic<int> g_env_gen{0};
 static std::mutex g_env_mu;
+static std::set<std::string> g_env_values; /* interned: element addresses of a std::set never move, nothing is ever erased */
 extern "C" const char *ffhip_env_lookup(struct ffhip_env_site *site)
 {
     const int gen = g_env_gen.load(std::memory_order_acquire);
-    if (site->gen != gen) {
+    if (__atomic_load_n(&site->gen, __ATOMIC_ACQUIRE) != gen) {
         std::lock_guard<std::mutex> lock(g_env_mu);
         const char *v = getenv(site->name);
-        site->set = v != nullptr;
-        if (v) { strncpy(site->val, v, sizeof site->val - 1); site->val[sizeof site->val - 1] = 0; }
-        site->gen = gen;
+        const char *kept = v ? g_env_values.insert(std::string(v)).first->c_str() : nullptr;
+        __atomic_store_n(&site->val, kept, __ATOMIC_RELAXED);
+        __atomic_store_n(&site->gen, gen, __ATOMIC_RELEASE);
     }
-    return site->set ? site->val : nullptr;
+    return __atomic_load_n(&site->val, __ATOMIC_RELAXED);
 }
 extern "C" void ffhip_reload_env(void) { g_env_gen.fetch_add(1, std::memory_order_acq_rel); }
+/* test hook (tests/test_capi.py; needs no device): the value the library holds for switch `name`, by the same lookup a call
+ * site makes (a site per name, kept for the process); copies it into dst[0..cap) and returns its full length, or -1 when unset */
+extern "C" long ffhip_env_value_test(const char *name, char *dst, size_t cap)
+{
+    static std::mutex mu;
+    static std::map<std::string, ffhip_env_site *> sites;
+    if (!name) return -1;
+    ffhip_env_site *site;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = sites.find(name);
+        if (it == sites.end()) {
+            auto ins = sites.emplace(std::string(name), nullptr);
+            ins.first->second = new ffhip_env_site{ins.first->first.c_str(), -1, nullptr};
+            it = ins.first;
+        }
+        site = it->second;
+    }
+    const char *v = ffhip_env_lookup(site);
+    if (!v) return -1;
+    const size_t n = strlen(v);
+    if (dst && cap) { strncpy(dst, v, cap - 1); dst[cap - 1] = 0; }
+    return (long)n;
+}
 
 extern "C" void ffhip_note_hip_error(int hip_error, const char *what)
 {
@@ -42,20 +70,22 @@ extern "C" void ffhip_note_hip_error(int hip_error, const char *what)
 /* How many single-wave workgroups of `kernel` the device holds at once: what a kernel whose waves WAIT for each other
  * (tickets + progress counters) may launch without a wave holding a ticket it cannot run yet -- and, for two such
  * kernels side by side, what lets both be resident whatever the hardware starts first. */
-static std::map<std::pair<const void *, int>, int> g_resident;
+static std::map<std::tuple<int, const void *, int>, int> g_resident; /* keyed by device too: CU counts differ between parts */
 extern "C" int ffhip_resident_waves(const void *kernel, int block_threads)
 {
     std::lock_guard<std::mutex> lock(g_env_mu);
-    auto it = g_resident.find(std::make_pair(kernel, block_threads));
-    if (it != g_resident.end()) return it->second;
     int per_cu = 0, cus = 0, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+    const auto key = std::make_tuple(dev, kernel, block_threads);
+    auto it = g_resident.find(key);
+    if (it != g_resident.end()) return it->second;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, 0) != hipSuccess || per_cu < 1 || cus < 1) {
         (void)hipGetLastError();
         return 256; /* one wave per CU of the smallest part: always resident */
     }
     const int n = per_cu * cus;
-    g_resident[std::make_pair(kernel, block_threads)] = n;
+    g_resident[key] = n;
     return n;
 }
 

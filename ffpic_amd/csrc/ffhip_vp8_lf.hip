@@ -398,7 +398,7 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
             while (seen < want) {
                 seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(prog_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 if (seen >= want) break;
-                if (__hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false; /* given up elsewhere: whoever did has said why */
+                if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return false; /* given up elsewhere: whoever did has said why */
                 if (++spins > LF_SPIN_LIMIT) {
                     if (lane == 0) {
                         __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
                         if (lane == 0) __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         return false;
                     }
-                    if (__hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false; /* given up elsewhere: whoever did has said why */
+                    if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return false; /* given up elsewhere: whoever did has said why */
                     if (++spins > LF_SPIN_LIMIT) {
                         if (lane == 0) {
                             __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

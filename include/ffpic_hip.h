@@ -49,6 +49,9 @@ const char *ffhip_strerror(int code);
 /* The FFHIP_* environment switches (A/B knobs of tests/tools, diagnostics; none is needed in production) are read ONCE per
  * process, at first use.  A host that changes one in a live process calls this to have them read again. */
 void ffhip_reload_env(void);
+/* Test hook (no device needed): what the library holds for the switch `name` -- copied into dst[0..cap), full length returned,
+ * -1 when unset.  Values are kept whole whatever their length (FFHIP_RCCL_LIB is a path). */
+long ffhip_env_value_test(const char *name, char *dst, size_t cap);
 /* "gfx950" etc. of the bound device, "" if none. */
 const char *ffhip_arch_name(void);
 
@@ -315,7 +318,8 @@ int ffhip_hevc_residual_batch(int nTbS, long long n_tu, const int16_t *d_level, 
  *                      to schedule the dependency wavefronts) and on the device:
  *                      [0] intra_y_mode (0 DC, 1 TM, 2 V, 3 H, 4 B_PRED), [1] intra_uv_mode,
  *                      [2..17] imodes[16] (4x4 modes 0..9), [18..19] 0  (format/webp.h:243-256).
- *                      A y / uv mode out of range is FFHIP_EINVAL: from this call for batches of up
+ *                      A y / uv mode out of range -- or, in a B_PRED record, a 4x4 mode above 9 (the
+ *                      reference indexes a table of ten predictors with it) -- is FFHIP_EINVAL: from this call for batches of up
  *                      to 2^17 macroblocks (checked on the host copy), for larger ones from the next
  *                      ffhip_stream_sync (checked by a kernel in front of the prediction: the planes
  *                      are then left untouched)

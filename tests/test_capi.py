@@ -110,3 +110,43 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".c", ".cpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text and "libffo" not in text and "ffo_" not in text, os.path.join(dirpath, f)
+
+
+def test_switch_values_are_kept_whole_and_survive_reloads(L, monkeypatch):
+    """FFHIP_* values are interned, not cut at a fixed width (FFHIP_RCCL_LIB is a path: a torch wheel's librccl.so is 60
+    characters away), a pointer handed out stays valid across ffhip_reload_env, and lookups may race with reloads."""
+    import threading
+    path = "/usr/local/lib/python3.10/dist-packages/torch/lib/" + "x" * 150 + "/librccl.so"
+    buf = C.create_string_buffer(512)
+    monkeypatch.setenv("FFHIP_TEST_SWITCH", path)
+    capi.reload_env()
+    assert L.ffhip_env_value_test(b"FFHIP_TEST_SWITCH", buf, 512) == len(path) and buf.value.decode() == path
+    monkeypatch.setenv("FFHIP_TEST_SWITCH", "1")
+    assert L.ffhip_env_value_test(b"FFHIP_TEST_SWITCH", buf, 512) == len(path)          # read once per process ...
+    capi.reload_env()
+    assert L.ffhip_env_value_test(b"FFHIP_TEST_SWITCH", buf, 512) == 1 and buf.value == b"1"   # ... until told otherwise
+    monkeypatch.delenv("FFHIP_TEST_SWITCH")
+    capi.reload_env()
+    assert L.ffhip_env_value_test(b"FFHIP_TEST_SWITCH", buf, 512) == -1
+    # lookups from four threads while the main thread flips the value and reloads: every answer is one of the values set
+    values = [b"a" * 10, b"b" * 100, b"c" * 300]
+    bad, stop = [], threading.Event()
+
+    def reader():
+        b = C.create_string_buffer(512)
+        while not stop.is_set():
+            n = L.ffhip_env_value_test(b"FFHIP_TEST_SWITCH2", b, 512)
+            if n >= 0 and b.value not in values:
+                bad.append(b.value)
+    threads = [threading.Thread(target=reader) for _ in range(4)]
+    for t in threads:
+        t.start()
+    for i in range(300):
+        os.environ["FFHIP_TEST_SWITCH2"] = values[i % 3].decode()
+        capi.reload_env()
+    stop.set()
+    for t in threads:
+        t.join()
+    os.environ.pop("FFHIP_TEST_SWITCH2", None)
+    capi.reload_env()
+    assert not bad

@@ -1,5 +1,6 @@
 """GPU: the JPEG entropy front end on the device (one lane per restart interval) against the host decoder,
-whose planes the CPU tests pin to the reference's whole-file decode."""
+whose planes the CPU tests pin to the reference's whole-file decode -- and (round 4, bottom of the file) against the
+reference's whole-file decode directly."""
 import io
 import os
 
@@ -174,3 +175,75 @@ def test_hostile_tables_cannot_read_past_the_staged_bytes():
     with pytest.raises(capi.FfhipError):
         ops.jpeg_entropy_batch([hostile])                       # the host decoder refuses it as well
     same_planes([_good_dri_file()])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: the device front end against the REFERENCE, not against the host decoder.  tests/golden/jpeg_files.npz,
+# jpeg_file_422.npz and jpeg_file_411.npz hold what the reference's own loader (format/jpg.c:255-415 decode_data_unit,
+# :588-637 read_compressed_scan, coding/huffman.c:92-222) made of each fixture file: BGRA or its SHA-256.  Two files
+# (the small ones whose last data unit the reference's bit reader runs dry in, utils/bitstream.c:117) compare
+# everything except the last MCU, exactly as test_jpeg_gpu.py::test_golden_files does for the reconstruction alone.
+# ---------------------------------------------------------------------------------------------------------------------
+import ctypes as C
+import hashlib
+
+from test_oracle_golden import FILES
+
+
+def _equals_reference_decode(g, tag, geom, img):
+    H, W = [int(x) for x in g[f"{tag}_shape"][:2]]
+    img = np.ascontiguousarray(img[:H, :W])
+    if int(g[f"{tag}_last_mcu_exact"]):
+        assert hashlib.sha256(img.tobytes()).digest() == g[f"{tag}_sha256"].tobytes(), tag
+    else:
+        keep = np.ones((H, W), bool)
+        keep[(geom.mcu_rows - 1) * 8 * geom.v:, (geom.mcu_cols - 1) * 8 * geom.h:] = False
+        assert np.array_equal(img[keep], g[f"{tag}_bgra"][keep]), tag
+
+
+@pytest.mark.parametrize("tag", list(FILES))
+@pytest.mark.parametrize("device_entropy", ["auto", "1", "0"])
+def test_files_to_device_pixels_equal_the_reference_decode(golden, monkeypatch, tag, device_entropy):
+    """ffhip_jpeg_decode_files_device on every fixture file -> BGRA in device memory -> the reference's whole-file decode.
+    "1" sends files WITHOUT restart markers through the device Huffman kernel too (one lane per file); "0" keeps every
+    file on the host threads; "auto" is the shipped choice (device for DRI files)."""
+    if device_entropy != "auto":
+        monkeypatch.setenv("FFHIP_JPEG_GPU_ENTROPY", device_entropy)
+    else:
+        monkeypatch.delenv("FFHIP_JPEG_GPU_ENTROPY", raising=False)
+    capi.reload_env()
+    g = golden("jpeg_files.npz")
+    data = open(os.path.join(GOLDEN, FILES[tag]), "rb").read()
+    geom, out, _ = ops.jpeg_decode_files_device([data] * 3, n_threads=2)
+    for i in range(3):
+        _equals_reference_decode(g, tag, geom, out[i])
+
+
+@pytest.mark.parametrize("tag", list(FILES))
+def test_device_entropy_planes_reconstruct_to_the_reference_decode(golden, tag):
+    """ffhip_jpeg_entropy_batch_gpu leaves coefficient planes and quantisers in device memory; ffhip_jpeg_recon_batch takes
+    them from there (nothing visits the host in between) -> the reference's whole-file decode."""
+    L = capi.require_device()
+    g = golden("jpeg_files.npz")
+    data = open(os.path.join(GOLDEN, FILES[tag]), "rb").read()
+    n = 2
+    geom, _, _ = ops.jpeg_probe(data)
+    bufs = [np.frombuffer(data, dtype=np.uint8) for _ in range(n)]
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    lens = (C.c_size_t * n)(*[b.size for b in bufs])
+    dy = ops.DeviceBuffer(nbytes=n * geom.y_blocks * 128)
+    du = ops.DeviceBuffer(nbytes=max(n * geom.c_blocks * 128, 16))
+    dv = ops.DeviceBuffer(nbytes=max(n * geom.c_blocks * 128, 16))
+    dq = ops.DeviceBuffer(nbytes=n * 512)
+    status = (C.c_int * n)()
+    three = geom.ncomp == 3
+    capi.check(L.ffhip_jpeg_entropy_batch_gpu(ptrs, lens, n, 2, C.byref(geom), dy.ptr, du.ptr if three else None,
+                                              dv.ptr if three else None, dq.ptr, status, None), "ffhip_jpeg_entropy_batch_gpu")
+    assert list(status) == [0] * n
+    H, W = geom.height, geom.width
+    dout = ops.DeviceBuffer(nbytes=n * H * W * 4)
+    ops.jpeg_recon_batch(geom, n, dy.ptr, du.ptr if three else None, dv.ptr if three else None, dq.ptr, 256, dout.ptr, W * 4, H * W * 4)
+    capi.check(L.ffhip_stream_sync(None))
+    out = dout.to_host((n, H, W, 4), np.uint8)
+    for i in range(n):
+        _equals_reference_decode(g, tag, geom, out[i])

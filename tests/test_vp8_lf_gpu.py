@@ -225,6 +225,42 @@ def test_bad_mode_bytes_in_a_large_batch_are_refused_through_the_stream(entry):
     assert np.array_equal(y[0], y[n - 1]) and not (y[0] == 0x5a).all()
 
 
+@pytest.mark.parametrize("large", [False, True])
+def test_sub_block_mode_above_9_is_refused(large):
+    """A B_PRED record whose 4x4 mode byte is above 9 indexes past the reference's table of ten predictors (predict.c: PredLuma4):
+    refused like a bad 16x16 mode -- by the call itself for small batches, through the stream for large ones; the same byte in a record
+    that is NOT B_PRED is never looked at (the reference does not look at it either)."""
+    from ffpic_amd import capi
+    L = capi.require_device()
+    c, r = 120, 68
+    n = 17 if large else 1
+    n_mb = c * r
+    m0, r0 = synth.vp8_modes(c, r, seed=41), synth.vp8_residual(n_mb, seed=42)
+    modes = np.ascontiguousarray(np.broadcast_to(m0, (n,) + m0.shape)).copy()
+    resid = np.ascontiguousarray(np.broadcast_to(r0, (n,) + r0.shape))
+    bp = np.flatnonzero(modes[n - 1, :, 0] == 4)
+    nb = np.flatnonzero(modes[n - 1, :, 0] != 4)
+    assert len(bp) and len(nb)
+    harmless = modes.copy()
+    harmless[n - 1, nb[-1], 2 + 7] = 200                     # not a B_PRED record: its imodes are not read
+    bad = modes.copy()
+    bad[n - 1, bp[-1], 2 + 15] = 10                          # the last sub-block of a B_PRED record
+    dr = ops.DeviceBuffer(resid)
+    ysz, csz = 256 * n_mb, 64 * n_mb
+    dy, du, dv = ops.DeviceBuffer(nbytes=n * ysz), ops.DeviceBuffer(nbytes=n * csz), ops.DeviceBuffer(nbytes=n * csz)
+
+    def call(m):
+        dm = ops.DeviceBuffer(m)
+        rc = L.ffhip_vp8_predict_recon(c, r, n, m.ctypes.data, dm.ptr, dr.ptr, n_mb * 384, None, dy.ptr, du.ptr, dv.ptr, ysz, csz, None)
+        rs = L.ffhip_stream_sync(None)
+        return rc, rs
+    assert call(bad) == ((0, capi.FFHIP_EINVAL) if large else (capi.FFHIP_EINVAL, 0))
+    assert call(harmless) == (0, 0)
+    y_h = dy.to_host((n, 16 * r, 16 * c), np.uint8)
+    assert call(modes) == (0, 0)
+    assert np.array_equal(dy.to_host((n, 16 * r, 16 * c), np.uint8), y_h)
+
+
 def test_webp_file_1080p_256_frames(golden):
     """A chip-filling batch: 256 copies of the real encoder's 1080p frame in ONE ffhip_vp8_predict_loopfilter call (the frame loop
     of webp.c:1833-1866; the wave caps follow residency at this size, not 16 waves per image).  Every frame's planes equal the

@@ -220,6 +220,37 @@ def vp8_predict_loopfilter(mbcols, mbrows, modes, residual, filter_type, filters
             dv.to_host((n, 8 * mbrows, 8 * mbcols), np.uint8))
 
 
+def vp8_decode_frames(mbcols, mbrows, modes, residual, filter_type, filters, resmap=None, planes=False, pitch=None, host_modes=True):
+    """ffhip_vp8_decode_frames: the frame loop of vp8_decode (format/webp.c:1833-1868) for a batch -- prediction, loop filter and
+    colour conversion as one call.  Returns BGRA uint8 [n][16r][pitch] and, with planes=True, the filtered (Y, U, V) too."""
+    L = capi.require_device()
+    n, n_mb = modes.shape[0], mbcols * mbrows
+    assert modes.shape == (n, n_mb, 20) and residual.shape[0] == n and residual.shape[2] == 384
+    modes = np.ascontiguousarray(modes)
+    dm, dr = DeviceBuffer(modes), DeviceBuffer(np.ascontiguousarray(residual))
+    df = DeviceBuffer(np.ascontiguousarray(filters)) if filters is not None else None
+    dmap = DeviceBuffer(np.ascontiguousarray(resmap, dtype=np.int32)) if resmap is not None else None
+    H, W = 16 * mbrows, 16 * mbcols
+    pitch = pitch or W * 4
+    do = DeviceBuffer(nbytes=n * H * pitch)
+    capi.check(L.ffhip_memset(do.ptr, 0, do.nbytes, None))
+    ysz, csz = 256 * n_mb, 64 * n_mb
+    dy = du = dv = None
+    if planes:
+        dy, du, dv = DeviceBuffer(nbytes=n * ysz), DeviceBuffer(nbytes=n * csz), DeviceBuffer(nbytes=n * csz)
+        for d in (dy, du, dv):
+            capi.check(L.ffhip_memset(d.ptr, 0, d.nbytes, None))
+    capi.check(L.ffhip_vp8_decode_frames(mbcols, mbrows, n, modes.ctypes.data if host_modes else None, dm.ptr, dr.ptr, residual.shape[1] * 384,
+                                         dmap.ptr if dmap else None, filter_type, df.ptr if df else None, do.ptr, pitch, H * pitch,
+                                         dy.ptr if planes else None, du.ptr if planes else None, dv.ptr if planes else None, ysz, csz, None),
+               "ffhip_vp8_decode_frames")
+    capi.check(L.ffhip_stream_sync(None), "ffhip_stream_sync")
+    bgra = do.to_host((n, H, pitch), np.uint8)
+    if not planes:
+        return bgra
+    return bgra, (dy.to_host((n, H, W), np.uint8), du.to_host((n, H // 2, W // 2), np.uint8), dv.to_host((n, H // 2, W // 2), np.uint8))
+
+
 def hevc_intra_recon(tus, residual, width, height, chroma=True, bd_y=8, bd_c=8, csub=2):
     """decode_intra_block steps 5-10 (coding/hevc.c:4730-4790) for a TU list in decode order
     (structured array of dtype synth.HEVC_TU_DTYPE == struct ffhip_hevc_tu); planes start at 0;

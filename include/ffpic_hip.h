@@ -342,6 +342,27 @@ int ffhip_vp8_predict_recon(int mbcols, int mbrows, int n_images, const uint8_t 
                             const int32_t *d_resmap, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
                             int64_t plane_stride_y, int64_t plane_stride_uv, void *stream);
 
+/* ---- the VP8 key-frame chain of a batch as ONE call: prediction + loop filter + colour conversion ----
+ * The frame loop of vp8_decode (format/webp.c:1833-1868: vp8_prerdict_mb for every macroblock, loopfilter for every
+ * macroblock, YUV420_to_BGRA32) with the residual of ffhip_vp8_residual_batch; the same bytes as
+ * ffhip_vp8_predict_loopfilter on zero-initialised planes followed by ffhip_yuv420_to_bgra.  Arguments as there:
+ *   h_modes / d_modes, d_residual, residual_stride, d_resmap   as ffhip_vp8_predict_recon (h_modes may be NULL for
+ *                      batches of more than 2^17 macroblocks: those are checked on the device)
+ *   filter_type, d_filters                                      as ffhip_vp8_loopfilter
+ *   d_bgra, pitch, image_stride                                 as ffhip_yuv420_to_bgra: 16*mbrows rows of 16*mbcols pixels
+ *   d_y / d_u / d_v    NULL, or planes (stride 16*mbcols / 8*mbcols, image i at + i*plane_stride_*) that receive the
+ *                      filtered samples as well.  The planes are OUTPUTS only here: where the reference's 16x16 H_PRED reads
+ *                      raw memory left of a row's first pixel (predict.c:346-353) it finds the last pixel of the row above
+ *                      and, below it, samples not reconstructed yet -- 0, as in the freshly allocated planes of vp8_decode.
+ * Batches of at least half as many frames as the device has CUs run as ONE kernel in which a workgroup owns a frame, its
+ * waves the frame's macroblock rows, and a wave predicts, filters and converts its macroblock before anything is stored
+ * (every pixel is written once, as BGRA); smaller batches run the three stages (row kernels, then the colour
+ * kernel: a single frame's critical path is shorter there).  FFHIP_VP8_FRAMES=fused|rows forces either. */
+int ffhip_vp8_decode_frames(int mbcols, int mbrows, int n_images, const uint8_t *h_modes, const uint8_t *d_modes,
+                            const int16_t *d_residual, int64_t residual_stride, const int32_t *d_resmap, int filter_type,
+                            const uint8_t *d_filters, uint8_t *d_bgra, int pitch, int64_t image_stride, uint8_t *d_y,
+                            uint8_t *d_u, uint8_t *d_v, int64_t plane_stride_y, int64_t plane_stride_uv, void *stream);
+
 /* ---- HEVC intra prediction + reconstruction for a list of transform units ----
  * decode_intra_block steps 5-10 (coding/hevc.c:4730-4790) for every TU of a picture:
  * intra_sample_prediction (hevc.c:4542-4662: neighbour gathering, reference_sample_substitution

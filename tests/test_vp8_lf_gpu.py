@@ -251,6 +251,8 @@ def test_sub_block_mode_above_9_is_refused(large):
 
     def call(m):
         dm = ops.DeviceBuffer(m)
+        for d in (dy, du, dv):                                # the planes' initial contents matter (raw H_PRED reads at x = 0)
+            capi.check(L.ffhip_memset(d.ptr, 0, d.nbytes, None))
         rc = L.ffhip_vp8_predict_recon(c, r, n, m.ctypes.data, dm.ptr, dr.ptr, n_mb * 384, None, dy.ptr, du.ptr, dv.ptr, ysz, csz, None)
         rs = L.ffhip_stream_sync(None)
         return rc, rs

@@ -388,8 +388,17 @@ class C4:
         B.s_col = lambda: capi.check(L.ffhip_yuv420_to_bgra(B.bgra.data_ptr(), B.Wp * 4, Y.data_ptr(), U_.data_ptr(), V.data_ptr(), B.Wp, B.Wp // 2, r, c, nf, B.Hp * B.Wp,
                                                             B.Hp * B.Wp // 4, B.Hp * B.Wp * 4, stream))
 
-        def chain():
+        # ... and prediction, loop filter and colour conversion as ONE call (round 4): ffhip_vp8_decode_frames -- one fused kernel (a workgroup per
+        # frame, every pixel stored once) for chip-filling batches, the row kernels + the colour kernel (on library scratch planes) for small ones
+        B.s_frames = lambda: capi.check(L.ffhip_vp8_decode_frames(c, r, nf, h_modes.ctypes.data, d_modes.data_ptr(), p_res.data_ptr(), n_mb * 384, None, ft, d_filt.data_ptr(),
+                                                                  B.bgra.data_ptr(), B.Wp * 4, B.Hp * B.Wp * 4, None, None, None, 0, 0, stream))
+
+        def chain_stages():
             B.s_res(); B.s_pred_lf(); B.s_col()
+        B.chain_stages = chain_stages
+
+        def chain():
+            B.s_res(); B.s_frames()
         B.chain = chain
 
         def one_clean_pass():
@@ -427,11 +436,13 @@ class C4:
                 reps = 5 if nf <= 64 else 3
                 ms = self.T.ms(B.chain, reps=reps, warm=1)
                 pl = self.T.ms(B.s_pred_lf, reps=reps, warm=0)
+                fr = self.T.ms(B.s_frames, reps=reps, warm=0)
                 t0 = time.perf_counter()
-                B.s_pred_lf()
+                B.s_frames()
                 host_ms = (time.perf_counter() - t0) * 1e3          # what the enqueue call itself costs the host
                 row = {"frames": nf, "chain_ms": round(ms, 4), "value": round(nf * B.Hp * B.Wp / ms / 1e3, 1), "unit": "Mpixels/s",
-                       "predict+loopfilter_ms": round(pl, 4), "host_enqueue_ms": round(host_ms, 3)}
+                       "decode_frames_ms": round(fr, 4), "form": "fused" if nf >= 128 else "rows",
+                       "row_kernels_predict+loopfilter_ms": round(pl, 4), "host_enqueue_ms": round(host_ms, 3)}
                 if parity_at_largest and nf == max(sizes):
                     B.one_clean_pass()
                     row["parity_first_and_last_frame"] = self.parity(B, source, sorted({0, nf - 1}))

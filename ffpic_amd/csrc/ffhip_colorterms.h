@@ -56,4 +56,61 @@ __device__ __forceinline__ u32 ff_bgra_int(int yy, const ChromaTerms &t)
 {
     return (u32)ff_clamp255(yy + t.fb) | ((u32)ff_clamp255(yy + t.fg) << 8) | ((u32)ff_clamp255(yy + t.fr) << 16) | 0xff000000u;
 }
+
+/* ---- the packed forms of the fused kernels (ffhip_jpeg.hip, ffhip_vp8_frame.hip): two pixels per dword ---- */
+__device__ __forceinline__ u32 sat_pk_u8_i16(u32 v)
+{
+    u32 d;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(v));
+    return d;
+}
+
+__device__ __forceinline__ u32 pk_add16(u32 a, u32 b)
+{
+    return __builtin_bit_cast(u32, (s16x2)(__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b)));
+}
+
+/* literal fp64 G of colorspace.c:163 (contraction is off for this file) */
+__device__ __forceinline__ u32 green_fp64(int yy, int uu, int vv)
+{
+    double g = (double)yy - 0.215 * (double)uu;
+    g = g - 0.381 * (double)vv;
+    int gi = (int)g;
+    return (u32)(gi < 0 ? 0 : (gi > 255 ? 255 : gi));
+}
+
+/* The same terms for TWO chroma samples at once, in the packed fp32 forms (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: one issue
+ * for both samples): uw, vw hold two raw 16-bit samples each.  r, g, b come back as the two int16 terms side by side (sample 0
+ * low), ready for the packed 16-bit adds.  The "sensitive" test is left to the caller in two steps: rem (= tf mod 1000, exact)
+ * is zero where 215 uu + 381 vv is a multiple of 1000 -- a product over the samples of a pass says whether ANY is -- and only
+ * then is sf != 76288 (the multiple is not zero itself) looked at, per sample: 3 instructions per pass in the common case where
+ * the two compares, the and and the mask insertion per SAMPLE used to be. */
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct TermBits2 {
+    u32 r, g, b;
+    f32x2 rem, sf;
+};
+__device__ __forceinline__ TermBits2 chroma_term_bits2(u32 uw, u32 vw)
+{
+    f32x2 af, bf; /* the halfword select rides on the conversion (SDWA) */
+    asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(af.x) : "v"(uw));
+    asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(af.y) : "v"(uw));
+    asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(bf.x) : "v"(vw));
+    asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(bf.y) : "v"(vw));
+    const f32x2 r = __builtin_elementwise_fma(bf, (f32x2)(1.28f), (f32x2)(-0.32f)) + (f32x2)(8453980.0f);
+    const f32x2 b = __builtin_elementwise_fma(af, (f32x2)(2.128f), (f32x2)(0.12f)) + (f32x2)(8453871.0f);
+    TermBits2 t;
+    t.sf = __builtin_elementwise_fma(bf, (f32x2)(381.0f), af * (f32x2)(215.0f));
+    const f32x2 tf = (f32x2)(4882288.0f) - t.sf;
+    const f32x2 tg = __builtin_elementwise_fma(tf, (f32x2)(0.001f), (f32x2)(-0.4995f)) + (f32x2)(8449338.0f);
+    const f32x2 kf = tg - (f32x2)(8449338.0f);
+    t.rem = __builtin_elementwise_fma(kf, (f32x2)(-1000.0f), tf);
+    /* (whole-vector bit casts: __builtin_bit_cast of ONE element of an ext_vector reads element 0 whichever is named, clang 20) */
+    const u32x2 rb = __builtin_bit_cast(u32x2, r), gb = __builtin_bit_cast(u32x2, tg), bb = __builtin_bit_cast(u32x2, b);
+    t.r = __builtin_amdgcn_perm(rb[1], rb[0], 0x05040100u);
+    t.g = __builtin_amdgcn_perm(gb[1], gb[0], 0x05040100u);
+    t.b = __builtin_amdgcn_perm(bb[1], bb[0], 0x05040100u);
+    return t;
+}
+
 #endif

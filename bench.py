@@ -481,6 +481,15 @@ def extra_c4(L, dev, stream, T, cpu=True, sweep_sizes=(1, 16, 64, 256, 1024)):
         res["cpu_baseline"] = {"value": round(2 * B.Hp * B.Wp / (dt + dt2) / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": kind,
                                "sample": "frames 0 and 15 of the batch (1920x1088 each) through the same four stages in C, one call per frame "
                                          "(ref_vp8_chain_frame: the reference's own functions looped like vp8_decode)"}
+        # all host cores: frames over threads (ctypes releases the GIL), two frames per thread
+        from concurrent.futures import ThreadPoolExecutor
+        cores = max(1, min(os.cpu_count() or 1, 16))
+        with ThreadPoolExecutor(cores) as ex:
+            t0 = time.perf_counter()
+            list(ex.map(lambda k: [c4_cpu_chain_frame(c, r, X.lv[(k + j) % nf], X.info[(k + j) % nf], X.q, X.modes[(k + j) % nf], 2, X.filt) for j in range(2)], range(cores)))
+            dta = time.perf_counter() - t0
+        res["cpu_baseline_all_cores"] = {"value": round(2 * cores * B.Hp * B.Wp / dta / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": kind,
+                                         "sample": f"{2 * cores} frames, two per thread"}
     del B
     torch.cuda.empty_cache()
     if X.enc:
@@ -500,9 +509,16 @@ def extra_c4(L, dev, stream, T, cpu=True, sweep_sizes=(1, 16, 64, 256, 1024)):
         del E
         torch.cuda.empty_cache()
     if sweep_sizes:
-        res["batch_sweep"] = {"workload": "the chain (ffhip_vp8_residual_batch -> ffhip_vp8_predict_loopfilter -> ffhip_yuv420_to_bgra) against the number of 1920x1088 frames "
-                                          "in ONE call each; `encoder`: copies of the libwebp frame, `random`: 16 distinct frames of uniformly random modes, tiled",
+        res["batch_sweep"] = {"workload": "the chain (ffhip_vp8_residual_batch -> ffhip_vp8_decode_frames: the fused frame kernel from 128 frames on, the row kernels + colour "
+                                          "kernel below) against the number of 1920x1088 frames in ONE call each; `encoder`: copies of the libwebp frame, `random`: 16 distinct "
+                                          "frames of uniformly random modes, tiled",
                               **X.sweep(sweep_sizes)}
+        # the fused frame kernel's own roofline at its largest encoder-stream batch: residual + modes in, BGRA out, every byte once
+        rows = [r for r in res["batch_sweep"].get("encoder", res["batch_sweep"].get("random", [])) if r["form"] == "fused"]
+        if rows:
+            r = rows[-1]
+            res["fused_roofline"] = dict(roof(r["frames"] * n_mb * (768 + 20 + 1024), r["decode_frames_ms"]), kernel="k_vp8_frames", frames=r["frames"],
+                                         note="algorithmic bytes per macroblock: 768 residual + 20 mode bytes in, 1024 BGRA out; bound by instruction issue (VALU ~65 % busy), not HBM")
     return res
 
 
@@ -673,9 +689,59 @@ def extra_c5(L, dev, stream, T, cpu=True, grid=True):
         res["cpu_baseline"] = {"value": round(sw * sh / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": kind,
                                "sample": f"one {sw}x{sh} picture of the same TU mix ({len(stus)} TUs) through the same three stages in C, one call per picture "
                                          "(ref_hevc_chain_picture: the reference's own functions per TU in decode order)"}
+        from concurrent.futures import ThreadPoolExecutor
+        cores = max(1, min(os.cpu_count() or 1, 16))
+        with ThreadPoolExecutor(cores) as ex:      # all host cores: the same picture once per thread (pictures are independent)
+            t0 = time.perf_counter()
+            list(ex.map(lambda k: c5_cpu_chain_picture(sw, sh, stus, sgroups, stotal), range(cores)))
+            dta = time.perf_counter() - t0
+        res["cpu_baseline_all_cores"] = {"value": round(cores * sw * sh / dta / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": kind,
+                                         "sample": f"{cores} pictures of {sw}x{sh}, one per thread"}
     if grid:
         res["grid"] = c5_grid_sweep(L, dev, stream, T, cpu=cpu)
     return res
+
+
+def compact_configs(extra):
+    """Every BASELINE config and layout in a few hundred bytes each: what the result line carries (the verbose `extra` goes to stderr /
+    --extra-file).  Values in Mpixels/s, `frac` = fraction of the 8 TB/s HBM peak of the kernel named in the verbose record."""
+    def g(d, *ks):
+        for k in ks:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+    out = {}
+    c2 = extra.get("c2", {})
+    out["c2"] = {"value": g(c2, "value"), "frac": g(c2, "roofline", "frac"), "parity": g(c2, "parity_vs_oracle_first_and_last_image")} if "error" not in c2 else c2
+    lay = extra.get("jpeg_layouts", {})
+    out["layouts"] = {k: {"frac": g(v, "roofline", "frac"), "parity": g(v, "parity_vs_oracle_first_image")} for k, v in lay.items() if isinstance(v, dict)} if "error" not in lay else lay
+    c4 = extra.get("c4", {})
+    if "error" in c4:
+        out["c4"] = c4
+    else:
+        sw = g(c4, "batch_sweep") or {}
+        out["c4"] = {"frames16_random": {"value": g(c4, "value"), "ms": g(c4, "chain_ms"), "parity": g(c4, "parity_vs_reference_first_and_last_frame")},
+                     "frames16_encoder": {"value": g(c4, "encoder_stream", "value"), "ms": g(c4, "encoder_stream", "chain_ms"),
+                                          "parity": g(c4, "encoder_stream", "parity_vs_reference_whole_file_decode")},
+                     "sweep_encoder": {str(r["frames"]): r["value"] for r in sw.get("encoder", [])},
+                     "sweep_random": {str(r["frames"]): r["value"] for r in sw.get("random", [])},
+                     "sweep_parity": [r.get("parity_first_and_last_frame") for src in ("encoder", "random") for r in sw.get(src, []) if "parity_first_and_last_frame" in r],
+                     "fused_kernel": g(c4, "fused_roofline"),
+                     "cpu_1_core": g(c4, "cpu_baseline", "value"), "cpu_all_cores": g(c4, "cpu_baseline_all_cores", "value"), "cpu_cores": g(c4, "cpu_baseline_all_cores", "cores")}
+    c5 = extra.get("c5", {})
+    if "error" in c5:
+        out["c5"] = c5
+    else:
+        rows = g(c5, "grid", "rows") or []
+        out["c5"] = {"one_8k_picture": {"value": g(c5, "value"), "ms": g(c5, "chain_ms"), "intra_ms": g(c5, "stages", "intra_recon", "ms"), "parity": g(c5, "parity_vs_reference_sample")},
+                     "grid_135_tiles": {str(r["pictures"]): r["value"] for r in rows},
+                     "grid_host_enqueue_ms": {str(r["pictures"]): r["intra_host_enqueue_ms"] for r in rows},
+                     "grid_parity": [r.get("parity_first_and_last_tile_vs_reference") for r in rows if "parity_first_and_last_tile_vs_reference" in r],
+                     "cpu_1_core": g(c5, "cpu_baseline", "value"), "cpu_all_cores": g(c5, "cpu_baseline_all_cores", "value"), "cpu_cores": g(c5, "cpu_baseline_all_cores", "cores")}
+    sk = extra.get("stage_kernels", {})
+    out["stage_kernels"] = {k: g(v, "frac") for k, v in sk.items() if isinstance(v, dict)} if "error" not in sk else sk
+    return out
 
 
 def main():
@@ -689,6 +755,7 @@ def main():
                     help="strong: the configuration's batch is shared out over the GPUs (BASELINE config 3: 256 images in total); weak: that many per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-extra", action="store_true", help="skip the C2 / C4 / C5 measurements of `extra`")
+    ap.add_argument("--extra-file", default="", help="also write the result line WITH the verbose `extra` object (every stage, roofline and sample description) to this file")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -805,17 +872,17 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / max(a.steps, 1) * 1e3, 4),
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
-            "dtype": "int16 coefficients -> int32 accumulate -> u8 BGRA (fp64 only for exact-integer G cases)",
-            "data": "synthetic (device RNG; Annex-K q85 tables, Laplace AC / normal DC, SURVEY 8d)",
+            "dtype": "int16 -> int32 -> u8",
+            "data": "synthetic (SURVEY 8d)",
             "config": {"workload": desc + (" in total" if a.scaling == "strong" else " per GPU"), "images_total": total_images,
                        "images_this_rank": n, "coded_size": f"{W}x{H}",
-                       "subsampling": "4:2:0", "parallelism": f"contiguous image ranges over {world} GPU(s) (ffhip_shard_range), no data-path collective",
-                       "batch_close": {"none": "one GPU: stream sync + own record (ffhip_batch_close)", "rccl": "ncclAllGather of 32-byte records from C (ffhip_batch_close)",
-                                       "torch": "records through torch.distributed (RCCL from C unavailable here)"}[batch.transport],
+                       "subsampling": "4:2:0", "parallelism": f"image ranges over {world} GPU(s), no data-path collective",
+                       "batch_close": {"none": "one GPU: stream sync + own record", "rccl": "ncclAllGather of 32-byte records from C",
+                                       "torch": "records through torch.distributed"}[batch.transport],
                        "batch_complete": complete, "parity_vs_oracle_first_and_last_image": parity},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": None if traffic is None else "profiles/latest_pmc.json (rocprofv3 --pmc passes of this workload, not collected in this run)",
+                         "traffic_source": None if traffic is None else "profiles/latest_pmc.json",
                          "kernel": "k_jpeg420_fused", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": int(BYTES_PER_PIXEL * px_per_launch),
                          "copy_kernel_GBps": None if copy_gbs is None else round(copy_gbs, 1)},
@@ -836,7 +903,15 @@ def main():
                     extra[key] = fn()
                 except Exception as e:   # an extra must never take the headline line with it
                     extra[key] = {"error": f"{type(e).__name__}: {e}"}
-            line["extra"] = extra
+            line["configs"] = compact_configs(extra)
+            # the verbose record goes to stderr (one line, in FRONT of the result line) and, with --extra-file, to a file: the driver keeps the
+            # last 8 KB of the output, and the one line it must find there whole is the result line below
+            blob = json.dumps({"extra": extra})
+            sys.stderr.write(blob + "\n")
+            sys.stderr.flush()
+            if a.extra_file:
+                with open(a.extra_file, "w") as fh:
+                    json.dump({**line, "extra": extra}, fh)
         print(json.dumps(line), flush=True)
     batch.destroy()
     if world > 1:

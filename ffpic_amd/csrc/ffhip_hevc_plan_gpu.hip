@@ -5,23 +5,30 @@
  * feeds once a picture has a few hundred thousand TUs (an 8K picture, a HEIF grid).  Everything it derives is a pure
  * function of the TU list, one TU at a time, given the map "which TU owns this 4x4 block":
  *   k_plan_owner   every TU stamps its index on its blocks, and says whether it starts a new RUN (a maximal stretch
- *                  of consecutive TUs whose top-left corners fall into the same window of the same plane)
- *   (scan)         run id per TU
- *   k_plan_count   per TU: the TUs of OTHER runs among its available neighbours (only earlier ones count: a block
- *                  stamped by a later TU held older content when the sequential decoder looked), whether all its
- *                  in-window neighbours are its own run's (LDS tile allowed), who must publish a done flag; per run
- *                  start: its position, and the claim on its window -- a window claimed by two runs means the list
- *                  is not "groups contiguous in decode order", and the caller falls back to the host planner
- *   (scan)         first wait entry per TU
- *   k_plan_emit    wait lists, schedule slots (position = TU index: runs in decode order ARE the ticket order, and a
- *                  TU an earlier-listed TU of another run precedes lies in a run that started earlier, i.e. has a
- *                  smaller ticket -- the deadlock-freedom condition of the grouped kernel), group records
- * Same output layout as the host planner; tickets in decode order (the host's dependency-depth order is a polling
- * optimisation worth ~3 %).
+ *                  of consecutive TUs whose top-left corners fall into the same window of the same plane); per block of
+ *                  256 TUs the number of run starts
+ *   k_plan_scan    exclusive scan of those block totals (one workgroup)
+ *   k_plan_runid   run id per TU: the block's prefix + the starts in front of it inside the block (ballots)
+ *   k_plan_count   per TU, ONCE: the TUs of OTHER runs among its available neighbours (only earlier ones count: a block
+ *                  stamped by a later TU held older content when the sequential decoder looked) -- written straight into
+ *                  the wait list, whose room a block reserves with one atomic add (where a TU's entries sit does not
+ *                  matter, only that they are together); whether all its in-window neighbours are its own run's (LDS tile
+ *                  allowed), who must publish a done flag; per run start: its position, the claim on its window -- a window
+ *                  claimed by two runs means the list is not "groups contiguous in decode order" -- and the count of runs
+ *                  per 64x64 cell
+ *   k_plan_cell_depth   the wavefront index of every cell (longest chain of dependency edges ending there)
+ *   tickets        runs in (depth of their cell, decode order) order WITHOUT a sort: a cell is entered once, so its runs are
+ *                  consecutive run ids and stay in decode order inside a contiguous range of tickets; the cells of one depth
+ *                  never depend on each other, so their ranges may follow each other in any order -- a histogram of runs per
+ *                  depth (k_plan_cell_hist), its exclusive scan (k_plan_scan, which also finds the widest wavefront), one
+ *                  atomic add per cell for the cell's range (k_plan_cell_base), and ticket = range start + run - first run of
+ *                  the cell (k_plan_rank).  Until round 4 this was hipcub's radix sort over (depth, run) pairs and two hipcub
+ *                  scans over all TUs: a dozen rocprim launches per picture.
+ *   k_plan_emit    schedule slots (position = TU index), group records, and the check that every TU a TU waits for has a
+ *                  smaller ticket -- the deadlock-freedom condition of the grouped kernel -- from the wait list as written
+ * Same output layout as the host planner.  Nothing here is a library primitive: the scans are a wave shuffle scan + LDS.
  */
 #include "ffhip_internal.h"
-
-#include <hipcub/hipcub.hpp>
 
 struct PlanArgs {
     const ffhip_hevc_tu *tus;
@@ -47,9 +54,90 @@ struct PlanArgs {
     uint32_t n_cells, cgh[3];
     uint32_t cell_off[3], cgw[3];
     int cshift[3];         /* log2 of the cell size in samples of the plane          */
-    uint32_t *keys32_in, *keys32_out;      /* wavefront key (the depth of its cell) per run */
-    uint32_t *vals_in, *rank_of;           /* sort payload (run); ticket of a run    */
+    uint32_t *rank_of;     /* ticket of a run                                          */
+    uint32_t *blk_tot;     /* per block of 256 TUs: run starts; after the scan: starts in the blocks before */
+    uint32_t *cell_nruns;  /* runs per cell                                            */
+    uint32_t *cell_base;   /* first ticket of the cell's runs                          */
+    uint32_t *hist;        /* [depths][shards] runs per (depth, shard); after the scan: first ticket of the pair */
+    uint32_t *fill;        /* [depths][shards] tickets of the pair handed out so far   */
+    uint32_t depths;       /* a bound on the depths: a chain ending at cell (x, y) has at most x + 2y edges */
+    uint32_t shard_log2;   /* the counters of one depth are spread over 2^shard_log2 words, picked by the cell's block: a grid of tiles has
+                              two dozen distinct depths for its 200 000 cells, and that many atomic adds on two dozen words took 0.4 ms */
 };
+
+/* ---- scans: a shuffle scan inside the wave, the waves' totals through LDS ---- */
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, const int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+/* exclusive scan of one value per thread over the workgroup (blockDim.x a multiple of 64, at most 1024); *total = the workgroup's sum.
+ * `wsum` is LDS of 17 words; two barriers */
+__device__ __forceinline__ uint32_t block_excl_scan(const uint32_t v, uint32_t *wsum, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint32_t inc = wave_incl_scan(v, lane);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    if (w == 0) {
+        const uint32_t x = lane < nw ? wsum[lane] : 0u;
+        const uint32_t xi = wave_incl_scan(x, lane);
+        if (lane < nw) wsum[lane] = xi - x;
+        if (lane == nw - 1) wsum[16] = xi;
+    }
+    __syncthreads();
+    const uint32_t r = wsum[w] + inc - v;
+    *total = wsum[16];
+    return r;
+}
+/* in-place exclusive scan of v[0..n) by ONE workgroup of 1024 threads, four entries per thread and pass (block totals: n / 256 entries;
+ * the (depth, shard) histogram: a few ten thousand).  With vmax: v is [groups][1 << group_log2] and *vmax receives the largest GROUP total
+ * (the widest wavefront: the most runs of one depth). */
+__global__ __launch_bounds__(1024) void k_plan_scan(uint32_t *v, uint32_t n, uint32_t *vmax, uint32_t group_log2, const uint32_t *skip)
+{
+    __shared__ uint32_t wsum[17];
+    __shared__ uint32_t wmax[16];
+    if (skip && *skip) return; /* no wavefront keys: nobody reads the histogram */
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 4096) {
+        const uint32_t i = base + 4 * threadIdx.x;
+        uint32_t x[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[k] = i + k < n ? v[i + k] : 0u;
+        uint32_t total;
+        const uint32_t e = block_excl_scan(x[0] + x[1] + x[2] + x[3], wsum, &total);
+        uint32_t run = carry + e;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i + k < n) v[i + k] = run;
+            run += x[k];
+        }
+        carry += total;
+        __syncthreads(); /* wsum is reused */
+    }
+    if (vmax) {
+        __threadfence_block();
+        __syncthreads();
+        const uint32_t groups = n >> group_log2;
+        uint32_t mx = 0;
+        for (uint32_t g = threadIdx.x; g < groups; g += 1024) {
+            const uint32_t lo = v[g << group_log2], hi = g + 1 < groups ? v[(g + 1) << group_log2] : carry;
+            mx = hi - lo > mx ? hi - lo : mx;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)mx, o, 64); mx = t > mx ? t : mx; }
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 16; w++) mx = wmax[w] > mx ? wmax[w] : mx;
+            *vmax = mx;
+        }
+    }
+}
 
 struct PlanInit {
     uint32_t *p[4];
@@ -79,23 +167,36 @@ __device__ __forceinline__ uint32_t win_of(const PlanArgs &a, const ffhip_hevc_t
     return a.win_off[c] + (uint32_t)(t.y >> a.wl[c]) * (uint32_t)a.gw[c] + (uint32_t)(t.x >> a.wl[c]);
 }
 
-__global__ __launch_bounds__(256) void k_plan_owner(PlanArgs a)
+__device__ __forceinline__ bool plan_owner_tu(const PlanArgs &a, const uint32_t i)
 {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n) return;
     const ffhip_hevc_tu t = a.tus[i];
     const int c = t.cidx, nb = (1 << t.log2_size) >> 2;
     int32_t *o = a.owner + a.owner_off[c] + (size_t)(t.y >> 2) * a.bw[c] + (t.x >> 2);
     for (int by = 0; by < nb; by++)
         for (int bx = 0; bx < nb; bx++) o[(size_t)by * a.bw[c] + bx] = (int32_t)i;
     const ffhip_hevc_tu tp = a.tus[i ? i - 1 : 0];
-    a.start[i] = (i == 0 || win_of(a, t) != win_of(a, tp)) ? 1u : 0u;
+    const bool starts = i == 0 || win_of(a, t) != win_of(a, tp);
+    a.start[i] = starts ? 1u : 0u;
     /* does the list visit every 64x64 (luma) cell in ONE stretch per plane?  Then the coding tree block is 64 and the
      * classic wavefront order over cells -- x + 2y -- is a valid ticket order (checked edge by edge in k_plan_emit) */
     const uint32_t cell = a.cell_off[c] + (uint32_t)(t.y >> a.cshift[c]) * a.cgw[c] + (uint32_t)(t.x >> a.cshift[c]);
     const uint32_t cellp = a.cell_off[tp.cidx] + (uint32_t)(tp.y >> a.cshift[tp.cidx]) * a.cgw[tp.cidx] + (uint32_t)(tp.x >> a.cshift[tp.cidx]);
     if (i == 0 || cell != cellp)
         if (atomicCAS(a.cell_claim + cell, ~0u, i) != ~0u) a.result[3] = 1; /* a cell entered twice: no wavefront keys */
+    return starts;
+}
+
+__global__ __launch_bounds__(256) void k_plan_owner(PlanArgs a)
+{
+    __shared__ uint32_t wtot[4];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    bool starts = false;
+    if (i < a.n) starts = plan_owner_tu(a, i);
+    /* run starts of this block of 256 TUs, for the scan behind */
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(starts);
+    if ((threadIdx.x & 63) == 0) wtot[threadIdx.x >> 6] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) a.blk_tot[blockIdx.x] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
 }
 
 /* longest dependency chain per cell (the wavefront index of the cell), inside ONE workgroup per plane.  Every edge a
@@ -203,49 +304,83 @@ __global__ __launch_bounds__(1024) void k_plan_cell_depth(PlanArgs a)
     }
 }
 
-/* per run: its wavefront key, the depth of its cell.  The sort behind it is stable, so runs of one cell (equal keys) keep
- * their decode order.  Only the first `m` entries exist: a plan is refused unless every window has ONE run, so there are
- * never more runs than windows -- the sort's size, known on the host (an 8K picture: 24 480 against 215 472 TUs). */
-__global__ __launch_bounds__(256) void k_plan_keys(PlanArgs a, uint32_t m, uint32_t no_run)
+/* Tickets without a sort.  A cell is entered ONCE (or result[3] says otherwise and tickets stay in decode order), so the runs of a cell are
+ * consecutive run ids, and all of them have the cell's depth.  What the grouped kernel needs of the ticket order is (1) every run a TU waits
+ * for has a smaller ticket and (2) tickets roughly follow the ready front.  Dependencies point to cells of smaller depth or to earlier runs
+ * of the same cell, never to another cell of the same depth: so the depths take their tickets in order (an exclusive scan of "runs per
+ * depth"), the cells of one depth take contiguous ranges in WHATEVER order their atomic adds arrive, and the runs of a cell keep their decode
+ * order inside the cell's range.  m bounds the runs: a plan is refused unless every window has ONE run, so there are never more runs than
+ * windows -- known on the host (an 8K picture: 24 480 against 215 472 TUs). */
+/* the counter a cell's runs are counted in: (depth, stripe) -- the stripe is the cell's position in its plane in 2^shard_log2 steps, so inside
+ * a depth the tickets still run from the top of the picture to its bottom, luma and chroma of one area side by side: a group and the groups
+ * it waits for (one depth up, a neighbouring cell) then sit at about the same place of their depths' ranges, a whole range of tickets apart.
+ * (With the counters picked round-robin instead, dependent groups could get neighbouring tickets and the grouped kernel's waves waited: the
+ * eight-picture grid took 3.2 ms where the sorted order of round 3 took 2.5.) */
+__device__ __forceinline__ uint32_t plan_cell_key(const PlanArgs &a, const uint32_t c)
+{
+    const int pc = c >= a.cell_off[2] && a.cgw[2] ? 2 : (c >= a.cell_off[1] && a.cgw[1] ? 1 : 0);
+    const uint32_t local = c - a.cell_off[pc], count = a.cgw[pc] * a.cgh[pc];
+    const uint32_t stripe = (uint32_t)(((unsigned long long)local << a.shard_log2) / count);
+    return (a.cell_depth[c] << a.shard_log2) | stripe;
+}
+/* One atomic add per DISTINCT counter and wave, not per cell: the lanes that share a counter add their runs up first (a row of a tile grid has
+ * eight distinct depths in a wave's 64 cells; 200 000 adds on the few hundred hot words of such a grid took 0.13 ms per kernel, on two dozen
+ * words 0.4 ms).  Returns, for a lane with runs, the sum of the runs of the lower lanes that share its counter; *grant (BASE only) = what the
+ * counter held before the wave's add. */
+template <bool BASE>
+__device__ __forceinline__ uint32_t plan_wave_add(uint32_t *counters, const uint32_t key, const uint32_t nr, uint32_t *grant)
+{
+    const int lane = threadIdx.x & 63;
+    bool todo = nr != 0;
+    uint32_t before = 0, got = 0;
+    for (;;) {
+        const unsigned long long left = __builtin_amdgcn_ballot_w64(todo);
+        if (!left) break;
+        const int first = __builtin_ctzll(left);
+        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, first);
+        const bool mine = todo && key == k0;
+        const uint32_t incl = wave_incl_scan(mine ? nr : 0u, lane);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint32_t old = 0;
+        if (lane == first) old = atomicAdd(counters + k0, total);
+        if (BASE) old = (uint32_t)__builtin_amdgcn_readlane((int)old, first);
+        if (mine) { before = incl - nr; got = old; todo = false; }
+    }
+    if (BASE) *grant = got;
+    return before;
+}
+__global__ __launch_bounds__(256) void k_plan_cell_hist(PlanArgs a)
+{
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (a.result[3]) return;
+    const uint32_t nr = c < a.n_cells ? a.cell_nruns[c] : 0u;
+    plan_wave_add<false>(a.hist, nr ? plan_cell_key(a, c) : 0u, nr, nullptr);
+}
+__global__ __launch_bounds__(256) void k_plan_cell_base(PlanArgs a)
+{
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (a.result[3]) return;
+    const uint32_t nr = c < a.n_cells ? a.cell_nruns[c] : 0u;
+    const uint32_t key = nr ? plan_cell_key(a, c) : 0u;
+    uint32_t grant = 0;
+    const uint32_t before = plan_wave_add<true>(a.fill, key, nr, &grant);
+    if (nr) a.cell_base[c] = a.hist[key] + grant + before;
+}
+__global__ __launch_bounds__(256) void k_plan_rank(PlanArgs a, uint32_t m)
 {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= m) return;
-    uint32_t key = no_run; /* beyond the last run: above every depth, sorts to the end */
-    if (r < a.result[1]) {
-        const ffhip_hevc_tu t = a.tus[a.gstart[r]];
-        const uint32_t cx = (uint32_t)(t.x >> a.cshift[t.cidx]), cy = (uint32_t)(t.y >> a.cshift[t.cidx]);
-        const uint32_t depth = a.result[3] ? 0u : a.cell_depth[a.cell_off[t.cidx] + cy * a.cgw[t.cidx] + cx];
-        key = depth;
-    }
-    a.keys32_in[r] = key;
-    a.vals_in[r] = r;
-}
-
-__global__ __launch_bounds__(256) void k_plan_rank(PlanArgs a, const uint32_t *sorted_runs, uint32_t m)
-{
-    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    if (a.result[1] > m) { /* more runs than windows: some window has two (k_plan_count has refused the list already); nothing was sorted for them */
-        if (k == 0) a.result[0] = 1;
+    if (a.result[1] > m) { /* more runs than windows: some window has two (k_plan_count has refused the list already) */
+        if (r == 0) a.result[0] = 1;
         return;
     }
-    const uint32_t runs = a.result[1];
-    if (k >= runs) return;
-    a.rank_of[sorted_runs[k]] = k;
-    /* How many runs can be at work at once -- the widest wavefront, i.e. the longest stretch of equal keys in the sorted order:
-     * the grouped kernel keeps only about that many of its waves (the others would hold tickets far from their turn and poll).
-     * The first run of a stretch finds the stretch's end by bisection; without wavefront keys (decode order) nothing is known
-     * and result[4] stays 0.  (Counted by atomics while the keys were made -- 196 k adds on the two dozen words a grid of
-     * tiles has depths for -- this was 1.1 ms of an 1.8-million-TU plan, returning or not.) */
-    if (a.result[3]) return;
-    const uint32_t key = a.keys32_out[k];
-    if (k > 0 && a.keys32_out[k - 1] == key) return;
-    uint32_t lo = k, hi = runs; /* keys[lo] == key, keys[hi] != key (or hi == runs) */
-    while (hi - lo > 1) {
-        const uint32_t mid = lo + (hi - lo) / 2;
-        if (a.keys32_out[mid] == key) lo = mid;
-        else hi = mid;
+    if (r >= a.result[1]) return;
+    uint32_t rank = r; /* no wavefront keys: decode order */
+    if (!a.result[3]) {
+        const ffhip_hevc_tu t = a.tus[a.gstart[r]];
+        const uint32_t cell = a.cell_off[t.cidx] + (uint32_t)(t.y >> a.cshift[t.cidx]) * a.cgw[t.cidx] + (uint32_t)(t.x >> a.cshift[t.cidx]);
+        rank = a.cell_base[cell] + (r - a.runid[a.cell_claim[cell]]); /* the cell's first run is the run of the TU that opened it */
     }
-    atomicMax(a.result + 4, hi - k);
+    a.rank_of[r] = rank;
 }
 
 /* the TUs of other runs TU i reads; returns their number (<= 66), fills deps when not NULL */
@@ -285,14 +420,30 @@ __device__ __forceinline__ int gather_deps(const PlanArgs &a, uint32_t i, const 
 
 __global__ __launch_bounds__(256) void k_plan_count(PlanArgs a)
 {
+    __shared__ uint32_t wsum[17];
+    __shared__ uint32_t blk_base;
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n) return;
-    const ffhip_hevc_tu t = a.tus[i];
+    const bool live = i < a.n;
     uint32_t deps[66];
-    bool ok;
-    const int nd = gather_deps(a, i, t, deps, &ok); /* exact count needs the de-duplication, hence the array */
+    int nd = 0;
+    bool ok = true;
+    ffhip_hevc_tu t = {};
+    if (live) {
+        t = a.tus[i];
+        nd = gather_deps(a, i, t, deps, &ok); /* exact count needs the de-duplication, hence the array */
+        if (nd > 64) a.result[0] = 1; /* more than the kernel's 64 pollers: leave it to the host planner */
+    }
+    /* room in the wait list: this block's entries together, reserved by ONE atomic add (result[2] ends up as the total) */
+    uint32_t total;
+    const uint32_t off = block_excl_scan((uint32_t)nd, wsum, &total);
+    if (threadIdx.x == 0) blk_base = total ? atomicAdd(a.result + 2, total) : 0u;
+    __syncthreads();
+    if (!live) return;
+    const uint32_t wb = blk_base + off;
+    a.wbegin[i] = wb;
     a.wcount[i] = (uint32_t)nd;
-    if (nd > 64) a.result[0] = 1; /* more than the kernel's 64 pollers: leave it to the host planner */
+    for (int q = 0; q < nd && q < 66; q++)
+        if (wb + q < a.wait_cap) a.wait_idx[wb + q] = deps[q]; /* beyond the reservation: the caller sees result[2] and falls back */
     atomicOr((unsigned *)(a.flags + (i & ~3u)), (ok ? 2u : 0u) << (8 * (i & 3)));
     const int c = t.cidx;
     const int cx = t.x >> a.cshift[c], cy = t.y >> a.cshift[c];
@@ -308,10 +459,12 @@ __global__ __launch_bounds__(256) void k_plan_count(PlanArgs a)
         else if (dx == 1 && dy == -1) edges |= 8u;
         else a.result[3] = 1; /* a dependency no coding-tree wavefront has: keep decode order */
     }
-    if (edges) atomicOr(a.cell_edges + a.cell_off[c] + (uint32_t)cy * a.cgw[c] + (uint32_t)cx, edges);
+    const uint32_t cell = a.cell_off[c] + (uint32_t)cy * a.cgw[c] + (uint32_t)cx;
+    if (edges) atomicOr(a.cell_edges + cell, edges);
     const bool starts = i == 0 || a.runid[i] != a.runid[i - 1];
     if (starts) {
         a.gstart[a.runid[i]] = i;
+        atomicAdd(a.cell_nruns + cell, 1u);
         if (atomicCAS(a.win_run + win_of(a, t), ~0u, a.runid[i]) != ~0u) a.result[0] = 1; /* a window with two runs */
     }
     if (i == a.n - 1) {
@@ -328,13 +481,9 @@ __global__ __launch_bounds__(256) void k_plan_emit(PlanArgs a, uint32_t m)
     const ffhip_hevc_tu t = a.tus[i];
     const uint32_t wb = a.wbegin[i], wc = a.wcount[i];
     if (wc) {
-        uint32_t deps[66];
-        gather_deps(a, i, t, deps, nullptr);
         const uint32_t my_ticket = a.rank_of[a.runid[i]];
-        for (uint32_t q = 0; q < wc && q < 66; q++) {
-            if (wb + q < a.wait_cap) a.wait_idx[wb + q] = deps[q]; /* beyond the reservation: the caller sees result[2] and falls back */
-            if (a.rank_of[a.runid[deps[q]]] >= my_ticket) a.result[0] = 1; /* would wait for a later ticket: not with this order */
-        }
+        for (uint32_t q = 0; q < wc && q < 66 && wb + q < a.wait_cap; q++)
+            if (a.rank_of[a.runid[a.wait_idx[wb + q]]] >= my_ticket) a.result[0] = 1; /* would wait for a later ticket: not with this order */
     }
     const u32x4 *src = (const u32x4 *)(a.tus + i);
     const uint32_t f = a.flags[i];
@@ -347,7 +496,6 @@ __global__ __launch_bounds__(256) void k_plan_emit(PlanArgs a, uint32_t m)
     a.sched[(size_t)i * 3] = src[0];
     a.sched[(size_t)i * 3 + 1] = src[1];
     a.sched[(size_t)i * 3 + 2] = q2;
-    if (i == a.n - 1) a.result[2] = wb + wc;
     const bool starts = i == 0 || a.runid[i] != a.runid[i - 1];
     if (starts) {
         const uint32_t r = a.runid[i];
@@ -360,34 +508,95 @@ __global__ __launch_bounds__(256) void k_plan_emit(PlanArgs a, uint32_t m)
     }
 }
 
-__global__ __launch_bounds__(256) void k_plan_runid(uint32_t *runid, const uint32_t *start_excl, const uint32_t *start_flag_src, uint32_t n)
+__global__ __launch_bounds__(256) void k_plan_runid(PlanArgs a)
 {
-    /* inclusive - 1 = exclusive + flag - 1 */
+    /* run id = starts in the blocks before (scanned totals) + starts up to and including me in this block - 1 */
+    __shared__ uint32_t wtot[4];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) runid[i] = start_excl[i] + start_flag_src[i] - 1u;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool st = i < a.n && a.start[i] != 0;
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(st);
+    if (lane == 0) wtot[w] = (uint32_t)__popcll(b);
+    __syncthreads();
+    uint32_t before = a.blk_tot[blockIdx.x];
+    for (int k = 0; k < w; k++) before += wtot[k];
+    const uint32_t incl = (uint32_t)__popcll(b & ((2ull << lane) - 1ull));
+    if (i < a.n) a.runid[i] = before + incl - 1u;
 }
 
 /* Layout of the device scratch the caller provides (32-bit words).  sched / groups / wait_idx sit where the grouped
- * kernel expects to be told they are; everything else is planner-private. */
+ * kernel expects to be told they are; everything else is planner-private.  ONE function lays the scratch out, for the size
+ * query (base = NULL: only the word count matters) and for the launch. */
+struct PlanLayout {
+    size_t words, blocks, wins, cells, n_blocks, wait_cap;
+    uint32_t *zero_cells; /* cell_edges | cell_nruns | hist | fill, adjacent: cleared together */
+    size_t zero_cells_words;
+};
+static PlanLayout plan_layout(PlanArgs &a, uint32_t *base, const ffhip_hevc_tu *d_tus, long long n_tus, const int pw[3], const int ph[3], const int wl[3])
+{
+    PlanLayout L = {};
+    const size_t n = (size_t)n_tus;
+    a.tus = d_tus;
+    a.n = (uint32_t)n;
+    size_t blocks = 0, wins = 0, cells = 0;
+    for (int c = 0; c < 3; c++) {
+        a.pw[c] = pw[c]; a.ph[c] = ph[c]; a.wl[c] = wl[c];
+        a.bw[c] = (pw[c] + 3) / 4;
+        a.gw[c] = pw[c] > 0 ? ((pw[c] - 1) >> wl[c]) + 1 : 0;
+        a.owner_off[c] = (uint32_t)blocks;
+        a.win_off[c] = (uint32_t)wins;
+        if (pw[c] > 0) {
+            blocks += (size_t)a.bw[c] * (size_t)((ph[c] + 3) / 4);
+            wins += (size_t)a.gw[c] * (size_t)(((ph[c] - 1) >> wl[c]) + 1);
+        }
+        a.cshift[c] = c == 0 ? 6 : 6 - ((pw[c] > 0 && pw[c] * 2 <= pw[0] + 1) ? 1 : 0); /* the cell is 64x64 LUMA samples */
+        a.cgw[c] = pw[c] > 0 ? (uint32_t)(((pw[c] - 1) >> a.cshift[c]) + 1) : 0;
+        a.cgh[c] = pw[c] > 0 ? (uint32_t)(((ph[c] - 1) >> a.cshift[c]) + 1) : 0;
+        a.cell_off[c] = (uint32_t)cells;
+        if (pw[c] > 0) cells += (size_t)a.cgw[c] * (size_t)a.cgh[c];
+    }
+    a.n_cells = (uint32_t)cells;
+    L.blocks = blocks; L.wins = wins; L.cells = cells;
+    L.n_blocks = (n + 255) / 256;
+    L.wait_cap = 8 * n; /* 66 entries per TU bounds the list in theory; 8n is reserved, and a list that needs more is refused (result[2]) */
+    a.wait_cap = (uint32_t)L.wait_cap;
+    uint32_t *p = base;
+    a.sched = (u32x4 *)p; p += 12 * n;
+    a.groups = (u32x4 *)p; p += 4 * (n + 1);
+    a.wait_idx = p; p += L.wait_cap;
+    a.owner = (int32_t *)p; p += blocks;          /* owner | win_run: adjacent, set to ~0 together */
+    a.win_run = p; p += wins;
+    a.start = p; p += n;
+    a.runid = p; p += n;
+    a.wcount = p; p += n;
+    a.wbegin = p; p += n;
+    a.gstart = p; p += n + 2;
+    a.flags = (uint8_t *)p; p += (n + 3) / 4 + 4;   /* flags | result: adjacent, cleared together */
+    a.result = p; p += 16;
+    a.cell_claim = p; p += cells;
+    L.zero_cells = p;
+    a.cell_edges = p; p += cells;
+    a.cell_nruns = p; p += cells;
+    uint32_t depths = 1;
+    for (int c = 0; c < 3; c++) depths = a.cgw[c] + 2 * a.cgh[c] + 1 > depths ? a.cgw[c] + 2 * a.cgh[c] + 1 : depths;
+    a.depths = depths;
+    a.shard_log2 = 0; /* as many shards as keep the table at 32 K words or below, at most 64 */
+    while (a.shard_log2 < 6 && ((size_t)depths << (a.shard_log2 + 1)) <= 32768) a.shard_log2++;
+    const size_t hwords = (size_t)depths << a.shard_log2;
+    a.hist = p; p += hwords;
+    a.fill = p; p += hwords;
+    L.zero_cells_words = 2 * cells + 2 * hwords;
+    a.cell_depth = p; p += cells;
+    a.cell_base = p; p += cells;
+    a.rank_of = p; p += n;
+    a.blk_tot = p; p += L.n_blocks + 1;
+    L.words = (size_t)(p - base) + 8;
+    return L;
+}
 extern "C" size_t ffhip_hevc_plan_gpu_words(long long n_tus, const int pw[3], const int ph[3], const int wl[3])
 {
-    size_t blocks = 0, wins = 0;
-    for (int c = 0; c < 3; c++) {
-        if (pw[c] <= 0) continue;
-        blocks += (size_t)((pw[c] + 3) / 4) * (size_t)((ph[c] + 3) / 4);
-        wins += (size_t)(((pw[c] - 1) >> wl[c]) + 1) * (size_t)(((ph[c] - 1) >> wl[c]) + 1);
-    }
-    const size_t n = (size_t)n_tus;
-    size_t scan_tmp = 0, sort_tmp = 0, cells = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
-                                             (uint32_t *)nullptr, (int)n);
-    if (sort_tmp > scan_tmp) scan_tmp = sort_tmp;
-    for (int c = 0; c < 3; c++)
-        if (pw[c] > 0) cells += (size_t)(((pw[c] - 1) >> 4) + 1) * (size_t)(((ph[c] - 1) >> 4) + 1); /* generous: cells of >= 16 samples */
-    /* sched 12n | groups 4(n+1) | wait 66... bounded by 33n in theory: sized by 8n + the fallback check | owner | win | start | startx | runid |
-     * wcount | wbegin | flags | gstart | result | scan temp */
-    return 12 * n + 4 * (n + 1) + 8 * n + blocks + wins + 6 * n + (n + 3) / 4 + 4 + (n + 2) + 16 + (scan_tmp + 3) / 4 + 128 + 4 * cells + 1 + 3 * n + 4 * n + 8;
+    PlanArgs a;
+    return plan_layout(a, nullptr, nullptr, n_tus, pw, ph, wl).words;
 }
 
 /* Returns 0 when the plan is in place (n_groups, n_wait filled), 1 when the list needs the host planner.
@@ -399,83 +608,28 @@ extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, 
                                    int *n_groups, const uint32_t **d_result, uint32_t *wait_cap_out)
 {
     PlanArgs a;
-    const size_t n = (size_t)n_tus;
-    a.tus = d_tus;
-    a.n = (uint32_t)n;
-    size_t blocks = 0, wins = 0;
-    for (int c = 0; c < 3; c++) {
-        a.pw[c] = pw[c]; a.ph[c] = ph[c]; a.wl[c] = wl[c];
-        a.bw[c] = (pw[c] + 3) / 4;
-        a.gw[c] = pw[c] > 0 ? ((pw[c] - 1) >> wl[c]) + 1 : 0;
-        a.owner_off[c] = (uint32_t)blocks;
-        a.win_off[c] = (uint32_t)wins;
-        if (pw[c] > 0) {
-            blocks += (size_t)a.bw[c] * (size_t)((ph[c] + 3) / 4);
-            wins += (size_t)a.gw[c] * (size_t)(((ph[c] - 1) >> wl[c]) + 1);
-        }
-    }
-    size_t scan_tmp = 0, sort_tmp = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
-                                             (uint32_t *)nullptr, (int)n);
-    if (sort_tmp > scan_tmp) scan_tmp = sort_tmp;
-    uint32_t *p = scratch;
-    a.sched = (u32x4 *)p; p += 12 * n;
-    a.groups = (u32x4 *)p; p += 4 * (n + 1);
-    const size_t wait_cap = 8 * n;
-    a.wait_cap = (uint32_t)wait_cap;
-    a.wait_idx = p; p += wait_cap;
-    a.owner = (int32_t *)p; p += blocks;
-    a.win_run = p; p += wins;
-    a.start = p; p += n;
-    uint32_t *start_excl = p; p += n;
-    a.runid = p; p += n;
-    a.wcount = p; p += n;
-    a.wbegin = p; p += n;
-    a.gstart = p; p += n + 2;
-    a.flags = (uint8_t *)p; p += (n + 3) / 4 + 4;
-    a.result = p; p += 16;
-    size_t cells = 0;
-    for (int c = 0; c < 3; c++) {
-        a.cshift[c] = c == 0 ? 6 : 6 - ((pw[c] > 0 && pw[c] * 2 <= pw[0] + 1) ? 1 : 0); /* the cell is 64x64 LUMA samples */
-        a.cgw[c] = pw[c] > 0 ? (uint32_t)(((pw[c] - 1) >> a.cshift[c]) + 1) : 0;
-        a.cell_off[c] = (uint32_t)cells;
-        if (pw[c] > 0) cells += (size_t)a.cgw[c] * (size_t)(((ph[c] - 1) >> a.cshift[c]) + 1);
-    }
-    a.cell_claim = p; p += cells;
-    a.cell_edges = p; p += cells;
-    a.cell_depth = p; p += cells;
-    p += cells + 1; /* (a histogram of runs per depth until round 3; the layout formula is shared with the host) */
-    a.n_cells = (uint32_t)cells;
-    for (int c = 0; c < 3; c++) a.cgh[c] = pw[c] > 0 ? (uint32_t)(((ph[c] - 1) >> a.cshift[c]) + 1) : 0;
-    a.vals_in = p; p += n;
-    uint32_t *vals_out = p; p += n;
-    a.rank_of = p; p += n;
-    p = (uint32_t *)(((uintptr_t)p + 7) & ~(uintptr_t)7);
-    a.keys32_in = p; p += 2 * n;      /* (sized as in round 2, when the keys were 64-bit: the layout formula is shared with the host) */
-    a.keys32_out = p; p += 2 * n;
-    void *tmp = (void *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
-    /* owner = -1, win_run = ~0 (adjacent); flags, result = 0 (adjacent); cell_claim = ~0; cell_edges = 0 (the edge bits are OR-ed
-     * in; every cell's depth is written by the sweep): ONE launch for the four regions -- as four memsets they were four more
-     * kernel boundaries in front of a chain of a dozen small kernels */
+    const PlanLayout Lo = plan_layout(a, scratch, d_tus, n_tus, pw, ph, wl);
+    const size_t n = (size_t)n_tus, blocks = Lo.blocks, wins = Lo.wins, cells = Lo.cells, wait_cap = Lo.wait_cap;
+    /* owner = -1, win_run = ~0 (adjacent); flags, result = 0 (adjacent); cell_claim = ~0; cell_edges, cell_nruns, hist, fill = 0 (adjacent:
+     * OR-ed and added into; every cell's depth is written by the sweep): ONE launch for the four regions -- as four memsets they were four
+     * more kernel boundaries in front of a chain of small kernels */
     {
         PlanInit in;
         in.p[0] = (uint32_t *)a.owner; in.words[0] = blocks + wins; in.value[0] = ~0u;
         in.p[1] = (uint32_t *)a.flags; in.words[1] = (n + 3) / 4 + 4 + 16; in.value[1] = 0u;
         in.p[2] = a.cell_claim; in.words[2] = cells; in.value[2] = ~0u;
-        in.p[3] = a.cell_edges; in.words[3] = cells; in.value[3] = 0u;
+        in.p[3] = Lo.zero_cells; in.words[3] = Lo.zero_cells_words; in.value[3] = 0u;
         size_t most = 0;
         for (int r = 0; r < 4; r++) most = in.words[r] > most ? in.words[r] : most;
         const size_t wg = (most / 4 + 255) / 256 + 1;
         hipLaunchKernelGGL(k_plan_init, dim3((unsigned)(wg > 4096 ? 4096 : wg), 4), dim3(256), 0, st, in);
     }
-    const unsigned grid = (unsigned)((n + 255) / 256);
+    const unsigned grid = (unsigned)Lo.n_blocks;
     hipLaunchKernelGGL(k_plan_owner, dim3(grid), dim3(256), 0, st, a);
-    if (hipcub::DeviceScan::ExclusiveSum(tmp, scan_tmp, a.start, start_excl, (int)n, st) != hipSuccess) return FFHIP_EIO;
-    hipLaunchKernelGGL(k_plan_runid, dim3(grid), dim3(256), 0, st, a.runid, start_excl, a.start, (uint32_t)n);
+    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, a.blk_tot, (uint32_t)Lo.n_blocks, (uint32_t *)nullptr, 0u, (const uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_plan_runid, dim3(grid), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_plan_count, dim3(grid), dim3(256), 0, st, a);
-    if (hipcub::DeviceScan::ExclusiveSum(tmp, scan_tmp, a.wcount, a.wbegin, (int)n, st) != hipSuccess) return FFHIP_EIO;
-    /* tickets: runs sorted by (wavefront key of their cell, decode order) */
+    /* tickets: runs by (wavefront index of their cell, decode order) */
     {   /* one diagonal per step, at most one cell per row of cells, a lane per row: a picture of up to 64 rows of cells is swept by ONE
          * wave per plane (a wave-local barrier per step), taller ones by as many waves as they have rows (up to 1024 threads) and a
          * workgroup barrier per step.  (One wave with three rows per lane: 1.15 us a step on the 144-row plane of an eight-picture grid.) */
@@ -488,11 +642,11 @@ extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, 
         else hipLaunchKernelGGL(k_plan_cell_depth<false>, dim3(3), dim3(threads ? threads : 64u), 0, st, a);
     }
     const size_t m = n < wins ? n : wins; /* runs <= windows, or the plan is refused (k_plan_count: a window with two runs) */
-    int key_bits = 1;
-    while (key_bits < 32 && (1ull << key_bits) <= cells + 1) key_bits++; /* depths are < cells; 2^key_bits - 1 stands for "no run" and sorts last */
-    hipLaunchKernelGGL(k_plan_keys, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a, (uint32_t)m, (uint32_t)((1ull << key_bits) - 1));
-    if (hipcub::DeviceRadixSort::SortPairs(tmp, scan_tmp, a.keys32_in, a.keys32_out, a.vals_in, vals_out, (int)m, 0, key_bits, st) != hipSuccess) return FFHIP_EIO;
-    hipLaunchKernelGGL(k_plan_rank, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a, (const uint32_t *)vals_out, (uint32_t)m);
+    const unsigned cgrid = (unsigned)((cells + 255) / 256);
+    hipLaunchKernelGGL(k_plan_cell_hist, dim3(cgrid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, a.hist, (uint32_t)(a.depths << a.shard_log2), a.result + 4, a.shard_log2, (const uint32_t *)(a.result + 3));
+    hipLaunchKernelGGL(k_plan_cell_base, dim3(cgrid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_plan_rank, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a, (uint32_t)m);
     hipLaunchKernelGGL(k_plan_emit, dim3(grid), dim3(256), 0, st, a, (uint32_t)m);
     FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
     if (d_result) {

@@ -826,9 +826,8 @@ struct ProgArgs {
     uint32_t wait_cap;
 };
 /* the program of ONE slot, by one wave (k is wave-uniform) */
-__device__ __forceinline__ void intra_program_slot(const ProgArgs &a, const uint32_t k, const int lane)
+__device__ __forceinline__ void intra_program_slot(const ProgArgs &a, const uint32_t k, const int lane, const u32x4 q0, const u32x4 q2)
 {
-    const u32x4 q0 = a.sched[(size_t)k * 3], q2 = a.sched[(size_t)k * 3 + 2];
     const u32x4 generic = {PK_SLOW, PROG_NO_RESIDUAL, 0u, 0u};
     const int x0 = (int)(q0.x & 0xffff), y0 = (int)(q0.x >> 16);
     const int lg = (int)(q0.y & 0xff), cidx = (int)((q0.y >> 8) & 0xff), mode = (int)((q0.y >> 16) & 0xff), flags = (int)(q0.y >> 24);
@@ -930,8 +929,9 @@ __global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
     if (a.plan_result && (a.plan_result[0] | (a.plan_result[2] > a.wait_cap ? 1u : 0u))) return; /* refused plan: the slots mean nothing */
     const uint32_t k = base + (uint32_t)lane;
     bool prog = false;
+    u32x4 q0 = {0, 0, 0, 0}, q2 = {0, 0, 0, 0};
     if (k < a.n_slots) {
-        const u32x4 q0 = a.sched[(size_t)k * 3], q2 = a.sched[(size_t)k * 3 + 2];
+        q0 = a.sched[(size_t)k * 3]; q2 = a.sched[(size_t)k * 3 + 2];
         const int lg = (int)(q0.y & 0xff), cidx = (int)((q0.y >> 8) & 0xff), flags = (int)(q0.y >> 24);
         prog = lg <= 3 && (1 << lg) <= (1 << a.wl[cidx]) && ((q2.y >> 9) & 1) && !(flags & 0xC0) && q0.z < 0x7fff0000u;
         if (!prog) {
@@ -943,7 +943,15 @@ __global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
     while (todo) {
         const int b = __builtin_ctzll(todo);
         todo &= todo - 1;
-        intra_program_slot(a, base + (uint32_t)b, lane);
+        /* the slot's two quarters come from the lane that loaded them: read again by the whole wave they were a trip to memory per program,
+         * in front of the trip for the substitution table's bytes */
+        u32x4 b0, b2;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            b0[e] = (uint32_t)__builtin_amdgcn_readlane((int)q0[e], b);
+            b2[e] = (uint32_t)__builtin_amdgcn_readlane((int)q2[e], b);
+        }
+        intra_program_slot(a, base + (uint32_t)b, lane, b0, b2);
     }
 }
 
@@ -970,22 +978,32 @@ struct JTabArgs {
     int bw[3];
     uint32_t boff[3];
 };
-#define JT_TUS_PER_WAVE 4 /* consecutive TUs a wave takes, one after the other: a wave per TU was bound by the rate waves start at */
+#define JT_TUS_PER_WAVE 64 /* a wave takes 64 consecutive TUs: every lane LOADS one record (one trip to memory for the wave), then the wave builds the
+                              tables one after the other from records passed round by readlane.  (A wave per TU was bound by the rate waves start at; four
+                              TUs per wave, each loaded when its turn came, by four trips to memory in a row: 0.29 ms for the 1.84 M TUs of an eight-picture
+                              grid, whose tables are 60 us worth of bytes.) */
 __global__ __launch_bounds__(256) void k_hevc_intra_jtable(JTabArgs a)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * JT_TUS_PER_WAVE;
-#pragma unroll
-    for (uint32_t q = 0; q < JT_TUS_PER_WAVE; q++) {
-    const uint32_t i_tu = first + q;
-    if (i_tu >= a.n) return;
-    const ffhip_hevc_tu t = a.tus[i_tu];
-    const int n = 1 << t.log2_size, cnt = 4 * n + 1;
-    const unsigned long long rl = __brevll(t.avail_left) >> (64 - 2 * n); /* bit i = left[2n-1-i] */
+    if (first >= a.n) return;
+    const uint32_t mine = first + (uint32_t)lane < a.n ? first + (uint32_t)lane : a.n - 1;
+    const u32x4 *rec = (const u32x4 *)(a.tus + mine);
+    const u32x4 r0 = rec[0], r1 = rec[1]; /* x | y << 16, log2_size | cidx << 8 | mode << 16 | flags << 24, res_offset, res_scale; avail_top, avail_left */
+    const uint32_t count = a.n - first < JT_TUS_PER_WAVE ? a.n - first : JT_TUS_PER_WAVE;
+    for (uint32_t q = 0; q < count; q++) {
+    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)r0.x, (int)q), w1 = (uint32_t)__builtin_amdgcn_readlane((int)r0.y, (int)q);
+    const unsigned long long avail_top = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)r1.x, (int)q) |
+                                         ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)r1.y, (int)q) << 32);
+    const unsigned long long avail_left = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)r1.z, (int)q) |
+                                          ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)r1.w, (int)q) << 32);
+    const int tx = (int)(w0 & 0xffff), ty = (int)(w0 >> 16), lg = (int)(w1 & 0xff), cidx = (int)((w1 >> 8) & 0xff), flags = (int)(w1 >> 24);
+    const int n = 1 << lg, cnt = 4 * n + 1;
+    const unsigned long long rl = __brevll(avail_left) >> (64 - 2 * n); /* bit i = left[2n-1-i] */
     unsigned long long m0, m1;
     unsigned m2 = 0;
-    const unsigned long long c = (t.flags & 1) ? 1ull : 0ull;
-    const unsigned long long tp = n == 32 ? t.avail_top : (t.avail_top & ((1ull << (2 * n)) - 1));
+    const unsigned long long c = (flags & 1) ? 1ull : 0ull;
+    const unsigned long long tp = n == 32 ? avail_top : (avail_top & ((1ull << (2 * n)) - 1));
     if (n == 32) { /* left 0..63, corner 64, top 65..128 */
         m0 = rl; m1 = c | (tp << 1); m2 = (unsigned)(tp >> 63);
     } else {
@@ -993,7 +1011,7 @@ __global__ __launch_bounds__(256) void k_hevc_intra_jtable(JTabArgs a)
         m1 = tp >> (63 - 2 * n); /* bits that spill past 64 (n = 16: 4n + 1 = 65) */
     }
     const int n_avail = __popcll(m0) + __popcll(m1) + (int)m2;
-    uint8_t *out = a.jt + (size_t)(a.boff[t.cidx] + (uint32_t)(t.y >> 2) * (uint32_t)a.bw[t.cidx] + (uint32_t)(t.x >> 2)) * JT_STRIDE;
+    uint8_t *out = a.jt + (size_t)(a.boff[cidx] + (uint32_t)(ty >> 2) * (uint32_t)a.bw[cidx] + (uint32_t)(tx >> 2)) * JT_STRIDE;
     for (int i = lane; i < cnt; i += 64) {
         int j = i;
         if (n_avail == 0) j = 255;
@@ -1854,10 +1872,28 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
         a.desc = pa.desc;
         hipLaunchKernelGGL(k_hevc_intra_program, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, pa);
     };
-    auto enqueue_jtable = [&](uint32_t *words) {
+    /* The substitution table depends on the TU list alone: for large lists it is built on the calling thread's side stream, NEXT TO the planner's
+     * kernels (which are chains of dependent loads with the chip mostly idle), and joined in front of the first kernel that reads it. */
+    bool jt_forked = false;
+    FfhipSide side = {nullptr, nullptr, nullptr};
+    auto enqueue_jtable = [&](uint32_t *words, bool may_fork) -> int {
         ja.tus = d_tus; ja.n = (uint32_t)n_tus; ja.jt = (uint8_t *)words;
         a.jt = ja.jt;
-        hipLaunchKernelGGL(k_hevc_intra_jtable, dim3((unsigned)((n_tus + 4 * JT_TUS_PER_WAVE - 1) / (4 * JT_TUS_PER_WAVE))), dim3(256), 0, st, ja);
+        hipStream_t js = st;
+        if (may_fork && n_tus >= (1 << 15) && !FFHIP_ENV("FFHIP_HEVC_JT_INLINE") && ffhip_side_stream_get(&side) == FFHIP_OK) {
+            FFHIP_CHECK(hipEventRecord((hipEvent_t)side.fork, st), FFHIP_EIO); /* behind whatever of an earlier call still reads the table's memory */
+            FFHIP_CHECK(hipStreamWaitEvent((hipStream_t)side.stream, (hipEvent_t)side.fork, 0), FFHIP_EIO);
+            js = (hipStream_t)side.stream;
+            jt_forked = true;
+        }
+        hipLaunchKernelGGL(k_hevc_intra_jtable, dim3((unsigned)((n_tus + 4 * JT_TUS_PER_WAVE - 1) / (4 * JT_TUS_PER_WAVE))), dim3(256), 0, js, ja);
+        if (jt_forked) FFHIP_CHECK(hipEventRecord((hipEvent_t)side.join, js), FFHIP_EIO);
+        return FFHIP_OK;
+    };
+    auto join_jtable = [&]() -> int { /* in front of the first kernel on `st` that reads the table */
+        if (jt_forked) FFHIP_CHECK(hipStreamWaitEvent(st, (hipEvent_t)side.join, 0), FFHIP_EIO);
+        jt_forked = false;
+        return FFHIP_OK;
     };
     if (want_groups && async_err && offsets_fit && jt_blocks * JT_STRIDE < (1ull << 32) && desc_px < (1ull << 29) /* 32-bit byte offsets into a plane, the table and the pixel words */) {
         const char *we = FFHIP_ENV("FFHIP_HEVC_INTRA_WINDOW");
@@ -1900,15 +1936,16 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, w_plan + w_ctrl + 16 + w_jt + w_desc);
             if (!g_work) return FFHIP_ENOMEM;
             uint32_t *const jt_words = g_work + ((w_plan + 3) & ~(size_t)3) + ((w_ctrl + 3) & ~(size_t)3);
-            enqueue_jtable(jt_words);
+            { const int jrc = enqueue_jtable(jt_words, true); if (jrc) return jrc; }
             int n_groups = 0;
             const int prc = ffhip_hevc_plan_gpu(d_tus, n_tus, pwc, ph, win, g_work, st, &a.sched, &a.groups, &a.wait_idx, &n_groups, &a.plan_result, &a.wait_cap);
-            if (prc < 0) return prc;
+            if (prc < 0) { (void)join_jtable(); return prc; } /* (`stream` must not run ahead of the side stream's read of the caller's list) */
             a.ctrl = g_work + ((w_plan + 3) & ~(size_t)3);
-            FFHIP_CHECK(hipMemsetAsync(a.ctrl, 0, w_ctrl * 4, st), FFHIP_EIO);
+            if (hipMemsetAsync(a.ctrl, 0, w_ctrl * 4, st) != hipSuccess) { (void)join_jtable(); return FFHIP_EIO; }
             a.async_err = async_err;
             a.n_groups = 0;
             a.n_tus = n_tus;
+            { const int jrc = join_jtable(); if (jrc) return jrc; }
             enqueue_programs(jt_words + w_jt, win, (size_t)n_tus);
 #ifdef FFHIP_INTRA_TRACE
             a.trace = g_intra_trace;
@@ -1929,7 +1966,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, o_ctrl + w_ctrl + 4 + w_jt + w_desc);
             if (!g_work) return FFHIP_ENOMEM;
             uint32_t *const jt_words = g_work + ((o_ctrl + w_ctrl + 3) & ~(size_t)3);
-            enqueue_jtable(jt_words);
+            { const int jrc = enqueue_jtable(jt_words, false); if (jrc) return jrc; }
             FFHIP_CHECK(hipMemcpy(g_work, plan.sched.data(), w_sched * 4, hipMemcpyHostToDevice), FFHIP_EIO);
             FFHIP_CHECK(hipMemcpy(g_work + o_groups, plan.groups.data(), w_groups * 4, hipMemcpyHostToDevice), FFHIP_EIO);
             FFHIP_CHECK(hipMemcpy(g_work + o_wait, plan.wait.data(), w_wait * 4, hipMemcpyHostToDevice), FFHIP_EIO);

@@ -383,54 +383,70 @@ __global__ __launch_bounds__(256) void k_plan_rank(PlanArgs a, uint32_t m)
     a.rank_of[r] = rank;
 }
 
-/* the TUs of other runs TU i reads; returns their number (<= 66), fills deps when not NULL */
-__device__ __forceinline__ int gather_deps(const PlanArgs &a, uint32_t i, const ffhip_hevc_tu &t, uint32_t *deps, bool *tile_ok)
+/* The TUs of OTHER runs TU i reads, each handed to f ONCE, in the order corner, row above (left to right), column left (top to bottom);
+ * returns whether every neighbour inside the TU's window belongs to its own run (then the grouped kernel may take them from its LDS tile).
+ * A neighbouring TU covers a contiguous stretch of the row above or of the column to the left, so its blocks follow each other there: "same as
+ * the one before" removes every repeat, the corner TU reaching into the row or the column included (it would be their first entry).  No TU can
+ * be above AND left of another.  (Until round 4 the two edges were walked in step and repeats were found by searching an array of up to 66
+ * entries -- 272 bytes of scratch memory per lane, written and re-read through memory.) */
+template <class F>
+__device__ __forceinline__ bool for_each_dep(const PlanArgs &a, const uint32_t i, const ffhip_hevc_tu &t, F &&f)
 {
     const int c = t.cidx, n = 1 << t.log2_size, wl = a.wl[c];
     const uint32_t run = a.runid[i];
     const int wx0 = (t.x >> wl) << wl, wy0 = (t.y >> wl) << wl, wsz = 1 << wl;
     const int32_t *own = a.owner + a.owner_off[c];
-    int nd = 0;
     bool ok = true;
-    uint32_t last = ~0u;
+    int32_t corner = -1, last;
     auto dep = [&](int px, int py) {
         int32_t j = own[(size_t)(py >> 2) * a.bw[c] + (px >> 2)];
-        if (j >= (int32_t)i) j = -1;
+        if (j >= (int32_t)i) j = -1; /* stamped by a later TU: held older content when the sequential decoder looked */
         const bool mine = j >= 0 && a.runid[j] == run;
-        if (j >= 0 && !mine && (uint32_t)j != last) {
-            bool dup = false;
-            if (deps)
-                for (int q = 0; q < nd && !dup; q++) dup = deps[q] == (uint32_t)j;
-            if (!dup) {
-                if (deps && nd < 66) deps[nd] = (uint32_t)j;
-                nd++;
-                last = (uint32_t)j;
-            }
-        }
+        if (j >= 0 && !mine && j != last && j != corner) f((uint32_t)j);
+        if (j >= 0 && !mine) last = j;
         if (!mine && px >= wx0 && px < wx0 + wsz && py >= wy0 && py < wy0 + wsz) ok = false;
+        return (j >= 0 && !mine) ? j : -1;
     };
-    if (t.flags & 1) dep(t.x - 1, t.y - 1);
-    for (int k = 0; k < 2 * n; k += 4) {
+    last = -1;
+    if (t.flags & 1) corner = dep(t.x - 1, t.y - 1);
+    last = -1;
+    for (int k = 0; k < 2 * n; k += 4)
         if ((t.avail_top >> k) & 0xf) dep(t.x + k, t.y - 1);
+    last = -1;
+    for (int k = 0; k < 2 * n; k += 4)
         if ((t.avail_left >> k) & 0xf) dep(t.x - 1, t.y + k);
-    }
-    if (tile_ok) *tile_ok = ok;
-    return nd;
+    return ok;
 }
 
+#define PLAN_STASH 6 /* waited-for TUs a lane keeps in LDS between counting them and knowing where its wait entries go; a TU with more walks its edges again */
 __global__ __launch_bounds__(256) void k_plan_count(PlanArgs a)
 {
     __shared__ uint32_t wsum[17];
     __shared__ uint32_t blk_base;
+    __shared__ uint32_t stash[PLAN_STASH][256];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const bool live = i < a.n;
-    uint32_t deps[66];
     int nd = 0;
     bool ok = true;
+    unsigned edges = 0;
     ffhip_hevc_tu t = {};
+    int c = 0, cx = 0, cy = 0;
     if (live) {
         t = a.tus[i];
-        nd = gather_deps(a, i, t, deps, &ok); /* exact count needs the de-duplication, hence the array */
+        c = t.cidx; cx = t.x >> a.cshift[c]; cy = t.y >> a.cshift[c];
+        ok = for_each_dep(a, i, t, [&](uint32_t j) {
+            if (nd < PLAN_STASH) stash[nd][threadIdx.x] = j;
+            nd++;
+            atomicOr((unsigned *)(a.flags + (j & ~3u)), 1u << (8 * (j & 3))); /* that TU must publish a done flag */
+            const ffhip_hevc_tu tj = a.tus[j];
+            const int dx = (tj.x >> a.cshift[c]) - cx, dy = (tj.y >> a.cshift[c]) - cy;
+            if (dx == 0 && dy == 0) return;
+            if (dx == -1 && dy == 0) edges |= 1u;
+            else if (dx == 0 && dy == -1) edges |= 2u;
+            else if (dx == -1 && dy == -1) edges |= 4u;
+            else if (dx == 1 && dy == -1) edges |= 8u;
+            else a.result[3] = 1; /* a dependency no coding-tree wavefront has: keep decode order */
+        });
         if (nd > 64) a.result[0] = 1; /* more than the kernel's 64 pollers: leave it to the host planner */
     }
     /* room in the wait list: this block's entries together, reserved by ONE atomic add (result[2] ends up as the total) */
@@ -442,23 +458,17 @@ __global__ __launch_bounds__(256) void k_plan_count(PlanArgs a)
     const uint32_t wb = blk_base + off;
     a.wbegin[i] = wb;
     a.wcount[i] = (uint32_t)nd;
-    for (int q = 0; q < nd && q < 66; q++)
-        if (wb + q < a.wait_cap) a.wait_idx[wb + q] = deps[q]; /* beyond the reservation: the caller sees result[2] and falls back */
-    atomicOr((unsigned *)(a.flags + (i & ~3u)), (ok ? 2u : 0u) << (8 * (i & 3)));
-    const int c = t.cidx;
-    const int cx = t.x >> a.cshift[c], cy = t.y >> a.cshift[c];
-    unsigned edges = 0;
-    for (int q = 0; q < nd && q < 66; q++) {
-        atomicOr((unsigned *)(a.flags + (deps[q] & ~3u)), 1u << (8 * (deps[q] & 3)));
-        const ffhip_hevc_tu tj = a.tus[deps[q]];
-        const int dx = (tj.x >> a.cshift[c]) - cx, dy = (tj.y >> a.cshift[c]) - cy;
-        if (dx == 0 && dy == 0) continue;
-        if (dx == -1 && dy == 0) edges |= 1u;
-        else if (dx == 0 && dy == -1) edges |= 2u;
-        else if (dx == -1 && dy == -1) edges |= 4u;
-        else if (dx == 1 && dy == -1) edges |= 8u;
-        else a.result[3] = 1; /* a dependency no coding-tree wavefront has: keep decode order */
+    if (nd <= PLAN_STASH) {
+        for (int q = 0; q < nd; q++)
+            if (wb + q < a.wait_cap) a.wait_idx[wb + q] = stash[q][threadIdx.x]; /* beyond the reservation: the caller sees result[2] and falls back */
+    } else {
+        uint32_t q = 0;
+        for_each_dep(a, i, t, [&](uint32_t j) {
+            if (wb + q < a.wait_cap) a.wait_idx[wb + q] = j;
+            q++;
+        });
     }
+    atomicOr((unsigned *)(a.flags + (i & ~3u)), (ok ? 2u : 0u) << (8 * (i & 3)));
     const uint32_t cell = a.cell_off[c] + (uint32_t)cy * a.cgw[c] + (uint32_t)cx;
     if (edges) atomicOr(a.cell_edges + cell, edges);
     const bool starts = i == 0 || a.runid[i] != a.runid[i - 1];
@@ -482,7 +492,7 @@ __global__ __launch_bounds__(256) void k_plan_emit(PlanArgs a, uint32_t m)
     const uint32_t wb = a.wbegin[i], wc = a.wcount[i];
     if (wc) {
         const uint32_t my_ticket = a.rank_of[a.runid[i]];
-        for (uint32_t q = 0; q < wc && q < 66 && wb + q < a.wait_cap; q++)
+        for (uint32_t q = 0; q < wc && wb + q < a.wait_cap; q++)
             if (a.rank_of[a.runid[a.wait_idx[wb + q]]] >= my_ticket) a.result[0] = 1; /* would wait for a later ticket: not with this order */
     }
     const u32x4 *src = (const u32x4 *)(a.tus + i);

@@ -84,4 +84,8 @@ struct FfhipVp8Fusion {
 };
 extern thread_local FfhipVp8Fusion g_ffhip_vp8_fusion;
 
+/* the calling thread's side stream with its fork / join events (ffhip_vp8_lf.hip: one set per thread and device, released by ffhip_shutdown) */
+struct FfhipSide { void *stream, *fork, *join; };
+extern "C" int ffhip_side_stream_get(FfhipSide *out);
+
 #endif

@@ -535,6 +535,15 @@ SideStream *side_stream_for_this_thread()
     return &h.s;
 }
 } // namespace
+/* the same side stream for other stages of the library that have two independent chains in one call (ffhip_hevc_intra_recon: the
+ * substitution table next to the planner's kernels); 0 on success */
+extern "C" int ffhip_side_stream_get(FfhipSide *out)
+{
+    SideStream *ss = side_stream_for_this_thread();
+    if (!ss) return FFHIP_EIO;
+    out->stream = ss->side; out->fork = ss->fork; out->join = ss->join;
+    return FFHIP_OK;
+}
 extern "C" void ffhip_vp8_release_side_streams(void) /* ffhip_shutdown: nothing of the library's is in flight */
 {
     std::lock_guard<std::mutex> l(g_side_mu);

@@ -977,6 +977,7 @@ struct JTabArgs {
     uint8_t *jt;
     int bw[3];
     uint32_t boff[3];
+    const uint32_t *refused; /* NULL, or the word k_hevc_check_tus sets for a list with a bad record (then the records' positions mean nothing) */
 };
 #define JT_TUS_PER_WAVE 64 /* a wave takes 64 consecutive TUs: every lane LOADS one record (one trip to memory for the wave), then the wave builds the
                               tables one after the other from records passed round by readlane.  (A wave per TU was bound by the rate waves start at; four
@@ -987,6 +988,7 @@ __global__ __launch_bounds__(256) void k_hevc_intra_jtable(JTabArgs a)
     const int lane = threadIdx.x & 63;
     const uint32_t first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * JT_TUS_PER_WAVE;
     if (first >= a.n) return;
+    if (a.refused && *a.refused) return;
     const uint32_t mine = first + (uint32_t)lane < a.n ? first + (uint32_t)lane : a.n - 1;
     const u32x4 *rec = (const u32x4 *)(a.tus + mine);
     const u32x4 r0 = rec[0], r1 = rec[1]; /* x | y << 16, log2_size | cidx << 8 | mode << 16 | flags << 24, res_offset, res_scale; avail_top, avail_left */
@@ -1108,6 +1110,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_serial(HevcIntraArgs a)
     if (!a.plan_result) return;
     const uint32_t refused = a.plan_result[0] | (a.plan_result[2] > a.wait_cap ? 1u : 0u);
     if (!__builtin_amdgcn_readfirstlane((int)refused)) return;
+    if (__builtin_amdgcn_readfirstlane((int)a.plan_result[6])) return; /* refused as INVALID (k_hevc_check_tus): nothing is written */
     for (int i = lane; i < 32 * 32 / 8; i += 64) ((u32x4 *)resz)[i] = u32x4{0u, 0u, 0u, 0u};
     wave_sync();
     HotArgs hot;
@@ -1477,6 +1480,11 @@ extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, 
                                    uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
                                    int *n_groups, const uint32_t **d_result, uint32_t *wait_cap_out);
 
+extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long n_tus, const int pw[3], const int ph[3], const int wl[3],
+                                           uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
+                                           int *n_groups, const uint32_t **d_result, uint32_t *wait_cap_out, const int *check, int *async_err,
+                                           int (*after_check)(void *, const uint32_t *), void *hook_ctx);
+
 struct GroupPlan {
     std::vector<u32x4> sched;  /* 3 per slot */
     std::vector<u32x4> groups;
@@ -1695,7 +1703,11 @@ static void host_parallel_for(long long n, F &&fn)
 /* Are the groups of this window -- the TUs whose top-left corner falls into one window tile of one plane -- contiguous
  * runs of the list?  (Then a group is complete before a later one starts, the condition of the grouped kernel.)  One
  * byte map per plane, one pass; scratch kept per thread. */
-static bool groups_contiguous(const ffhip_hevc_tu *tus, long long n_tus, const int pw[3], const int ph[3], const int win_log2[3])
+/* sampled: only the records of every 64th stretch of 4096 are looked at (large lists, whose full test runs on the device: a window that
+ * is not contiguous there is refused by the planner and the list decoded by the serial kernel -- exact, slow, and only for a list whose
+ * coding-tree-block size changes between the sampled stretches) */
+#define SAMPLED_OUT(i) ((((i) >> 12) & 63) != 0)
+static bool groups_contiguous(const ffhip_hevc_tu *tus, long long n_tus, const int pw[3], const int ph[3], const int win_log2[3], const bool sampled = false)
 {
     static thread_local std::vector<uint8_t> seen[3];
     int gw[3];
@@ -1707,14 +1719,17 @@ static bool groups_contiguous(const ffhip_hevc_tu *tus, long long n_tus, const i
     std::atomic<bool> twice{false};
     /* a TU opens a run where its window differs from its predecessor's: stateless per TU, so the list is cut into pieces for as
      * many threads as pay (a window entered by two pieces is entered twice all the same: the mark is an atomic exchange) */
-    host_parallel_for(n_tus, [&](long long b, long long e) {
+    host_parallel_for(sampled ? 1 : n_tus, [&](long long b, long long e) { /* (a sample is one thread's work: starting sixteen costs more than the pass) */
+        if (sampled) e = n_tus;
         for (long long i = b; i < e && !twice.load(std::memory_order_relaxed); i++) {
+            if (sampled && SAMPLED_OUT(i)) { i |= 4095; continue; }
             const ffhip_hevc_tu &t = tus[i];
             const int c = t.cidx;
+            if (c > 2 || t.x >= pw[c] || t.y >= ph[c]) continue; /* (an unvalidated record of a sampled list: the device pass refuses it) */
             const long long w = (long long)(t.y >> win_log2[c]) * gw[c] + (t.x >> win_log2[c]);
             if (i > 0) {
                 const ffhip_hevc_tu &p = tus[i - 1];
-                if (p.cidx == c && (long long)(p.y >> win_log2[c]) * gw[c] + (p.x >> win_log2[c]) == w) continue;
+                if (p.cidx == c && p.x < pw[c] && p.y < ph[c] && (long long)(p.y >> win_log2[c]) * gw[c] + (p.x >> win_log2[c]) == w) continue;
             }
             if (__atomic_exchange_n(map[c] + w, (uint8_t)1, __ATOMIC_RELAXED)) twice.store(true, std::memory_order_relaxed);
         }
@@ -1776,10 +1791,17 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
     if (!ffhip_have_device()) return FFHIP_ENODEV;
     const int pw[3] = {width_y, width_c, width_c}, ph[3] = {height_y, height_c, height_c};
     /* validation: field ranges, the block inside its plane, and no availability bit pointing outside the plane */
+    /* lists of 2^17 TUs and more: the host looks at a sample (a bad record there is refused here, at once), every record is checked by a
+     * kernel in front of the planner (k_hevc_check_tus), which refuses the call through the stream -- or by a full host pass below, should the
+     * call not take the device planner */
+    const bool big_list = n_tus >= (1LL << 17) && !FFHIP_ENV("FFHIP_HEVC_HOST_CHECK");
     std::atomic<bool> bad{false}, any_res{false};
-    host_parallel_for(n_tus, [&](long long b, long long e) {
+    auto validate = [&](const bool sampled) {
+    host_parallel_for(sampled ? 1 : n_tus, [&](long long b, long long e) {
+        if (sampled) e = n_tus;
         bool res = false, ok = true;
         for (long long i = b; i < e && ok; i++) {
+            if (sampled && SAMPLED_OUT(i)) { i |= 4095; continue; }
             const ffhip_hevc_tu &t = h_tus[i];
             const int c = t.cidx, n = 1 << t.log2_size;
             if (c > 2 || t.log2_size < 2 || t.log2_size > 5 || t.pred_mode > 34) { ok = false; break; }
@@ -1797,8 +1819,18 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
         if (!ok) bad.store(true, std::memory_order_relaxed);
         if (res) any_res.store(true, std::memory_order_relaxed);
     });
+    };
+    const bool host_times = FFHIP_ENV("FFHIP_PLAN_TIMES") != nullptr;
+    const auto TH0 = std::chrono::steady_clock::now();
+    validate(big_list);
+    const auto TH1 = std::chrono::steady_clock::now();
     if (bad.load()) return FFHIP_EINVAL;
-    const bool has_res = any_res.load();
+    bool has_res = any_res.load();
+    bool fully_validated = !big_list;
+    auto validate_fully = [&]() -> bool { /* before anything on the host walks the whole list */
+        if (!fully_validated) { validate(false); fully_validated = true; has_res = any_res.load(); }
+        return !bad.load() && !(has_res && !d_residual);
+    };
     /* wavefront levels at 4x4-block granularity, per plane: only the level-synchronous form needs them */
     std::vector<std::vector<uint32_t>> lists;
     auto build_levels = [&]() {
@@ -1915,9 +1947,10 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
         bool dev_ok = false;
         for (; dev_wl >= 3 && !dev_ok; dev_wl--) {
             const int win[3] = {dev_wl, dev_wl - dev_cs, dev_wl - dev_cs};
-            dev_ok = groups_contiguous(h_tus, n_tus, pw, ph, win);
+            dev_ok = groups_contiguous(h_tus, n_tus, pw, ph, win, big_list);
         }
         dev_wl++;
+        const auto TH2 = std::chrono::steady_clock::now();
         if (pe && !strcmp(pe, "device")) dev_ok = true; /* tests: force the device planner (and with it the serial path of a list it refuses) */
         if (!(pe && !strcmp(pe, "host")) && dev_ok) {
             /* NOTHING below waits for the device: the schedule is enqueued, the grouped kernel is enqueued behind it and
@@ -1936,9 +1969,17 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, w_plan + w_ctrl + 16 + w_jt + w_desc);
             if (!g_work) return FFHIP_ENOMEM;
             uint32_t *const jt_words = g_work + ((w_plan + 3) & ~(size_t)3) + ((w_ctrl + 3) & ~(size_t)3);
-            { const int jrc = enqueue_jtable(jt_words, true); if (jrc) return jrc; }
             int n_groups = 0;
-            const int prc = ffhip_hevc_plan_gpu(d_tus, n_tus, pwc, ph, win, g_work, st, &a.sched, &a.groups, &a.wait_idx, &n_groups, &a.plan_result, &a.wait_cap);
+            /* the substitution table starts (on the side stream) behind the list's validation: a bad record's position would send its stores anywhere */
+            struct Hook { decltype(enqueue_jtable) *fn; uint32_t *words; JTabArgs *ja; } hook = {&enqueue_jtable, jt_words, &ja};
+            auto after_check = [](void *ctx, const uint32_t *refused) -> int {
+                Hook *h = (Hook *)ctx;
+                h->ja->refused = refused;
+                return (*h->fn)(h->words, true);
+            };
+            const int check[2] = {(d_cb && d_cr && uv_stride >= width_c) ? 1 : 0, d_residual ? 1 : 0};
+            const int prc = ffhip_hevc_plan_gpu_checked(d_tus, n_tus, pwc, ph, win, g_work, st, &a.sched, &a.groups, &a.wait_idx, &n_groups, &a.plan_result, &a.wait_cap,
+                                                        big_list ? check : nullptr, async_err, after_check, &hook);
             if (prc < 0) { (void)join_jtable(); return prc; } /* (`stream` must not run ahead of the side stream's read of the caller's list) */
             a.ctrl = g_work + ((w_plan + 3) & ~(size_t)3);
             if (hipMemsetAsync(a.ctrl, 0, w_ctrl * 4, st) != hipSuccess) { (void)join_jtable(); return FFHIP_EIO; }
@@ -1952,9 +1993,15 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
 #endif
             hipLaunchKernelGGL(k_hevc_intra_groups, dim3((unsigned)std::min<size_t>((size_t)n_tus, resident_waves)), dim3(64), 0, st, a);
             hipLaunchKernelGGL(k_hevc_intra_serial, dim3(1), dim3(64), 0, st, a); /* does something only for a list the planner refused */
+            if (host_times) {
+                const auto TH3 = std::chrono::steady_clock::now();
+                auto us = [](auto x, auto y) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(y - x).count(); };
+                fprintf(stderr, "intra_recon host: validate %ld us, window %ld us, enqueue %ld us (%lld TUs)\n", us(TH0, TH1), us(TH1, TH2), us(TH2, TH3), n_tus);
+            }
             FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
             return FFHIP_OK;
         }
+        if (!validate_fully()) return FFHIP_EINVAL; /* the host planner walks every record */
         GroupPlan plan;
         int host_wl = 0;
         if (plan_with_window_search(h_tus, n_tus, pw, ph, we ? atoi(we) : FFHIP_HEVC_INTRA_WINDOW_LOG2, plan, &host_wl, ja.boff)) {
@@ -1989,6 +2036,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
         }
     }
 
+    if (!validate_fully()) return FFHIP_EINVAL;
     build_levels();
     std::vector<uint32_t> flat;
     flat.reserve((size_t)n_tus);

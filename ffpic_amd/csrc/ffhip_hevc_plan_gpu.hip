@@ -188,6 +188,7 @@ __device__ __forceinline__ bool plan_owner_tu(const PlanArgs &a, const uint32_t 
 
 __global__ __launch_bounds__(256) void k_plan_owner(PlanArgs a)
 {
+    if (a.result[6]) return; /* the list was refused by k_hevc_check_tus */
     __shared__ uint32_t wtot[4];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     bool starts = false;
@@ -218,6 +219,7 @@ template <bool FAST> /* FAST: every plane's edge bits fit the LDS form and no pl
                         stores: with the slow paths' loads in the same loop every diagonal waited ~0.5 us for its own store) */
 __global__ __launch_bounds__(1024) void k_plan_cell_depth(PlanArgs a)
 {
+    if (a.result[6]) return; /* the list was refused by k_hevc_check_tus */
     __shared__ unsigned char el[CELLS_LDS / 2];
     __shared__ unsigned short ring[4][DEPTH_ROWS];
     const int c = blockIdx.x;
@@ -368,6 +370,7 @@ __global__ __launch_bounds__(256) void k_plan_cell_base(PlanArgs a)
 }
 __global__ __launch_bounds__(256) void k_plan_rank(PlanArgs a, uint32_t m)
 {
+    if (a.result[6]) return; /* the list was refused by k_hevc_check_tus */
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
     if (a.result[1] > m) { /* more runs than windows: some window has two (k_plan_count has refused the list already) */
         if (r == 0) a.result[0] = 1;
@@ -421,6 +424,7 @@ __device__ __forceinline__ bool for_each_dep(const PlanArgs &a, const uint32_t i
 #define PLAN_STASH 6 /* waited-for TUs a lane keeps in LDS between counting them and knowing where its wait entries go; a TU with more walks its edges again */
 __global__ __launch_bounds__(256) void k_plan_count(PlanArgs a)
 {
+    if (a.result[6]) return; /* the list was refused by k_hevc_check_tus */
     __shared__ uint32_t wsum[17];
     __shared__ uint32_t blk_base;
     __shared__ uint32_t stash[PLAN_STASH][256];
@@ -485,6 +489,7 @@ __global__ __launch_bounds__(256) void k_plan_count(PlanArgs a)
 
 __global__ __launch_bounds__(256) void k_plan_emit(PlanArgs a, uint32_t m)
 {
+    if (a.result[6]) return; /* the list was refused by k_hevc_check_tus */
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n) return;
     if (a.result[1] > m) return; /* refused (k_plan_rank): the runs have no tickets, and nobody will read a schedule */
@@ -520,6 +525,7 @@ __global__ __launch_bounds__(256) void k_plan_emit(PlanArgs a, uint32_t m)
 
 __global__ __launch_bounds__(256) void k_plan_runid(PlanArgs a)
 {
+    if (a.result[6]) return; /* the list was refused by k_hevc_check_tus */
     /* run id = starts in the blocks before (scanned totals) + starts up to and including me in this block - 1 */
     __shared__ uint32_t wtot[4];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -532,6 +538,42 @@ __global__ __launch_bounds__(256) void k_plan_runid(PlanArgs a)
     for (int k = 0; k < w; k++) before += wtot[k];
     const uint32_t incl = (uint32_t)__popcll(b & ((2ull << lane) - 1ull));
     if (i < a.n) a.runid[i] = before + incl - 1u;
+}
+
+/* Validation of a large TU list ON the device (what ffhip_hevc_intra_recon's host pass checks record by record: field ranges, the block
+ * inside its plane, no availability bit pointing outside the plane, a residual buffer where a TU asks for one).  For lists of 2^17 TUs and
+ * more the host only looks at a sample (a pass over 1.8 M records was 0.7 ms of an enqueue call next to 4 ms of device work); a bad record
+ * found here refuses the call through the stream: result[6] sends every kernel behind this one home, result[0] the grouped kernel, and
+ * ffhip_stream_sync reports FFHIP_EINVAL -- nothing is written. */
+struct PlanCheck {
+    int pw[3], ph[3];
+    int chroma_ok;    /* chroma planes present and wide enough */
+    int have_residual;
+    int *async_err;
+};
+__global__ __launch_bounds__(256) void k_hevc_check_tus(const ffhip_hevc_tu *tus, uint32_t n, PlanCheck k, uint32_t *result)
+{
+    bool bad = false;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const ffhip_hevc_tu t = tus[i];
+        const int c = t.cidx;
+        if (c > 2 || t.log2_size < 2 || t.log2_size > 5 || t.pred_mode > 34) { bad = true; continue; }
+        const int sz = 1 << t.log2_size;
+        if (c > 0 && !k.chroma_ok) bad = true;
+        if (t.x + sz > k.pw[c] || t.y + sz > k.ph[c]) { bad = true; continue; }
+        const unsigned long long span = sz == 32 ? ~0ull : (1ull << (2 * sz)) - 1;
+        const unsigned long long top = t.avail_top & span, left = t.avail_left & span;
+        const int room_x = k.pw[c] - t.x, room_y = k.ph[c] - t.y;
+        if ((top || (t.flags & 1)) && t.y == 0) bad = true;
+        if ((left || (t.flags & 1)) && t.x == 0) bad = true;
+        if (room_x < 64 && (top >> room_x)) bad = true;
+        if (room_y < 64 && (left >> room_y)) bad = true;
+        if ((t.flags & 2) && !k.have_residual) bad = true;
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) && (threadIdx.x & 63) == 0) {
+        result[6] = 1u; result[0] = 1u; result[3] = 1u;
+        __hip_atomic_store(k.async_err, FFHIP_ASYNC_BAD_INPUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 /* Layout of the device scratch the caller provides (32-bit words).  sched / groups / wait_idx sit where the grouped
@@ -613,9 +655,23 @@ extern "C" size_t ffhip_hevc_plan_gpu_words(long long n_tus, const int pw[3], co
  * With d_result != NULL nothing is waited for: the plan is only ENQUEUED, *d_result points at the device words
  * {refused, number of groups, wait entries} the grouped kernel reads for itself (with *wait_cap, the reservation the
  * wait entries must fit), *n_groups is left alone and the return value is 0. */
+extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long n_tus, const int pw[3], const int ph[3], const int wl[3],
+                                           uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
+                                           int *n_groups, const uint32_t **d_result, uint32_t *wait_cap_out, const int *check /* NULL, or {chroma_ok,
+                                           have_residual} */, int *async_err, int (*after_check)(void *, const uint32_t *), void *hook_ctx);
 extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, const int pw[3], const int ph[3], const int wl[3],
                                    uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
                                    int *n_groups, const uint32_t **d_result, uint32_t *wait_cap_out)
+{
+    return ffhip_hevc_plan_gpu_checked(d_tus, n_tus, pw, ph, wl, scratch, st, sched, groups, wait_idx, n_groups, d_result, wait_cap_out, nullptr, nullptr,
+                                       nullptr, nullptr);
+}
+/* ... with the list's validation as the first kernel behind the scratch's reset (check != NULL), and a hook that runs once that kernel is
+ * enqueued: what the caller starts from there (the substitution table on a side stream) may rely on result[6], handed to the hook */
+extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long n_tus, const int pw[3], const int ph[3], const int wl[3],
+                                           uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
+                                           int *n_groups, const uint32_t **d_result, uint32_t *wait_cap_out, const int *check, int *async_err,
+                                           int (*after_check)(void *, const uint32_t *), void *hook_ctx)
 {
     PlanArgs a;
     const PlanLayout Lo = plan_layout(a, scratch, d_tus, n_tus, pw, ph, wl);
@@ -635,8 +691,18 @@ extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, 
         hipLaunchKernelGGL(k_plan_init, dim3((unsigned)(wg > 4096 ? 4096 : wg), 4), dim3(256), 0, st, in);
     }
     const unsigned grid = (unsigned)Lo.n_blocks;
+    if (check && async_err) {
+        PlanCheck k;
+        for (int c = 0; c < 3; c++) { k.pw[c] = pw[c]; k.ph[c] = ph[c]; }
+        k.chroma_ok = check[0]; k.have_residual = check[1]; k.async_err = async_err;
+        hipLaunchKernelGGL(k_hevc_check_tus, dim3(grid > 2048 ? 2048u : grid), dim3(256), 0, st, d_tus, (uint32_t)n, k, a.result);
+    }
+    if (after_check) {
+        const int hrc = after_check(hook_ctx, a.result + 6);
+        if (hrc) return hrc;
+    }
     hipLaunchKernelGGL(k_plan_owner, dim3(grid), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, a.blk_tot, (uint32_t)Lo.n_blocks, (uint32_t *)nullptr, 0u, (const uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, a.blk_tot, (uint32_t)Lo.n_blocks, (uint32_t *)nullptr, 0u, (const uint32_t *)(a.result + 6));
     hipLaunchKernelGGL(k_plan_runid, dim3(grid), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_plan_count, dim3(grid), dim3(256), 0, st, a);
     /* tickets: runs by (wavefront index of their cell, decode order) */

@@ -274,29 +274,54 @@ def test_isp_picture_vs_reference(golden, tag):
     assert isp_digest(got) == g[f"{tag}_sha256"].tobytes()
 
 
-def test_one_bad_tu_in_a_list_validated_by_several_threads():
-    """Lists of 2^17 TUs and more are validated (and tested for contiguity) in pieces by several host threads: a TU that lies outside
-    its plane, an availability bit that points outside, a bad size -- one of them in the LAST piece -- still make the call
-    FFHIP_EINVAL before anything is enqueued; the untouched list decodes bit for bit."""
+@pytest.mark.parametrize("host_check", [False, True])
+def test_one_bad_tu_in_a_large_list(host_check, monkeypatch):
+    """Lists of 2^17 TUs and more: the host looks at a sample of the records (a bad one there is FFHIP_EINVAL at once), EVERY record is checked by
+    a kernel in front of the planner, which refuses the call through the stream -- the call returns 0, nothing is written, ffhip_stream_sync says
+    FFHIP_EINVAL once.  A TU that lies outside its plane, an availability bit that points outside, a bad size, in the last stretch of the list
+    and in a stretch the host does not sample.  FFHIP_HEVC_HOST_CHECK=1: the whole list on host threads, as before round 4.  The untouched list
+    decodes bit for bit afterwards."""
+    if host_check:
+        monkeypatch.setenv("FFHIP_HEVC_HOST_CHECK", "1"); capi.reload_env()
     L = capi.require_device()
     w, h = 3840, 2176
     tus, res = synth.hevc_intra_tus(w, h, seed=91)
-    assert len(tus) >= (1 << 17) + 1000
-    want = ops.hevc_intra_recon(tus, res, w, h, True, 8, 8)
+    n = len(tus)
+    assert n >= (1 << 17) + 1000
     exp = O.oracle_hevc_intra(tus, res, w, h, True, 8, 8)
-    for a, b in zip(want, exp):
-        assert np.array_equal(a, b)
-    dt, dr = ops.DeviceBuffer(tus.view(np.uint8)), ops.DeviceBuffer(res)
+    dr = ops.DeviceBuffer(res)
     dy, du, dv = ops.DeviceBuffer(nbytes=w * h * 2), ops.DeviceBuffer(nbytes=w * h // 2), ops.DeviceBuffer(nbytes=w * h // 2)
 
     def call(t):
-        return L.ffhip_hevc_intra_recon(t.ctypes.data, dt.ptr, len(t), dr.ptr, dy.ptr, du.ptr, dv.ptr, w, h, w, w // 2, h // 2, w // 2, 8, 8, None)
+        dt = ops.DeviceBuffer(np.ascontiguousarray(t).view(np.uint8))     # the same records on both sides, as the entry point asks
+        for d in (dy, du, dv):
+            capi.check(L.ffhip_memset(d.ptr, 0x11, d.nbytes, None))
+        rc = L.ffhip_hevc_intra_recon(t.ctypes.data, dt.ptr, len(t), dr.ptr, dy.ptr, du.ptr, dv.ptr, w, h, w, w // 2, h // 2, w // 2, 8, 8, None)
+        rs = L.ffhip_stream_sync(None)
+        return rc, rs
+    unsampled = 5 * 4096 + 77                                             # stretch 5 of 4096 records: the host's sample (every 64th) skips it
+    assert unsampled < n
     for field, value in (("x", w), ("log2_size", 6), ("pred_mode", 35), ("cidx", 3)):
-        bad = tus.copy()
-        bad[field][len(bad) - 7] = value
-        assert call(bad) == capi.FFHIP_EINVAL, field
+        for at in (n - 7, unsampled):
+            bad = tus.copy()
+            bad[field][at] = value
+            rc, rs = call(bad)
+            assert (rc, rs) in ((capi.FFHIP_EINVAL, 0), (0, capi.FFHIP_EINVAL)), (field, at, rc, rs)
+            if host_check:
+                assert rc == capi.FFHIP_EINVAL
+            assert L.ffhip_stream_sync(None) == 0
+            assert (dy.to_host((w * h * 2,), np.uint8) == 0x11).all() and (du.to_host((w * h // 2,), np.uint8) == 0x11).all(), (field, at)
     bad = tus.copy()
     i = int(np.nonzero((bad["y"] == 0) & (bad["cidx"] == 0))[0][-1])      # a TU of the top row claims a row above
     bad["avail_top"][i] = 1
-    assert call(bad) == capi.FFHIP_EINVAL
-    capi.check(L.ffhip_stream_sync(None))
+    rc, rs = call(bad)
+    assert (rc, rs) in ((capi.FFHIP_EINVAL, 0), (0, capi.FFHIP_EINVAL))
+    assert L.ffhip_stream_sync(None) == 0
+    for d in (dy, du, dv):
+        capi.check(L.ffhip_memset(d.ptr, 0, d.nbytes, None))
+    dt = ops.DeviceBuffer(tus.view(np.uint8))
+    assert L.ffhip_hevc_intra_recon(tus.ctypes.data, dt.ptr, n, dr.ptr, dy.ptr, du.ptr, dv.ptr, w, h, w, w // 2, h // 2, w // 2, 8, 8, None) == 0
+    assert L.ffhip_stream_sync(None) == 0
+    got = (dy.to_host((h, w), np.int16), du.to_host((h // 2, w // 2), np.int16), dv.to_host((h // 2, w // 2), np.int16))
+    for a, b in zip(got, exp):
+        assert np.array_equal(a, b)

@@ -824,6 +824,13 @@ struct ProgArgs {
     int wl[3], stride[3];
     const uint32_t *plan_result;
     uint32_t wait_cap;
+    /* "early" form (device-planned lists, slot = TU index): the slot's first and third quarter are not written yet -- the ticket kernels and
+     * k_plan_emit run NEXT TO this kernel -- and are put together from what k_plan_count left: the TU record, its flag byte, its wait count */
+    const ffhip_hevc_tu *tus;
+    const uint8_t *flags;
+    const uint32_t *wcount;
+    int jt_bw[3];
+    uint32_t jt_boff[3];
 };
 /* the program of ONE slot, by one wave (k is wave-uniform) */
 __device__ __forceinline__ void intra_program_slot(const ProgArgs &a, const uint32_t k, const int lane, const u32x4 q0, const u32x4 q2)
@@ -926,12 +933,21 @@ __global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
     const int lane = threadIdx.x & 63;
     const uint32_t base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64u;
     if (base >= a.n_slots) return;
-    if (a.plan_result && (a.plan_result[0] | (a.plan_result[2] > a.wait_cap ? 1u : 0u))) return; /* refused plan: the slots mean nothing */
+    if (a.plan_result && (a.plan_result[0] | (a.plan_result[2] > a.wait_cap ? 1u : 0u))) return; /* refused plan: the slots mean nothing (early form: refused
+                                                                                                       SO FAR -- a list refused later has its programs built for nothing) */
     const uint32_t k = base + (uint32_t)lane;
     bool prog = false;
     u32x4 q0 = {0, 0, 0, 0}, q2 = {0, 0, 0, 0};
     if (k < a.n_slots) {
-        q0 = a.sched[(size_t)k * 3]; q2 = a.sched[(size_t)k * 3 + 2];
+        if (a.tus) {
+            q0 = ((const u32x4 *)(a.tus + k))[0];
+            const uint32_t f = a.flags[k], cidx = (q0.y >> 8) & 0xff;
+            q2.y = a.wcount[k] | ((f & 1u) << 8) | (((f >> 1) & 1u) << 9);
+            q2.z = k;
+            q2.w = (a.jt_boff[cidx] + (q0.x >> 18) * (uint32_t)a.jt_bw[cidx] + ((q0.x & 0xffffu) >> 2)) * JT_STRIDE;
+        } else {
+            q0 = a.sched[(size_t)k * 3]; q2 = a.sched[(size_t)k * 3 + 2];
+        }
         const int lg = (int)(q0.y & 0xff), cidx = (int)((q0.y >> 8) & 0xff), flags = (int)(q0.y >> 24);
         prog = lg <= 3 && (1 << lg) <= (1 << a.wl[cidx]) && ((q2.y >> 9) & 1) && !(flags & 0xC0) && q0.z < 0x7fff0000u;
         if (!prog) {
@@ -1483,7 +1499,8 @@ extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, 
 extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long n_tus, const int pw[3], const int ph[3], const int wl[3],
                                            uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
                                            int *n_groups, const uint32_t **d_result, uint32_t *wait_cap_out, const int *check, int *async_err,
-                                           int (*after_check)(void *, const uint32_t *), void *hook_ctx);
+                                           int (*after_check)(void *, const uint32_t *),
+                                           int (*after_count)(void *, const uint8_t *, const uint32_t *, const uint32_t *), void *hook_ctx);
 
 struct GroupPlan {
     std::vector<u32x4> sched;  /* 3 per slot */
@@ -1896,18 +1913,18 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
         a.desc_off[c] = pa.desc_off[c];
     }
     const size_t w_desc = desc_px * 2 + 2;
-    auto enqueue_programs = [&](uint32_t *words, const int win[3], size_t n_slots) {
+    auto enqueue_programs = [&](uint32_t *words, const int win[3], size_t n_slots, hipStream_t ps) {
         pa.sched = (u32x4 *)a.sched; pa.n_slots = (uint32_t)n_slots; pa.jt = a.jt;
         pa.desc = (uint2 *)(((uintptr_t)words + 7) & ~(uintptr_t)7);
-        for (int c = 0; c < 3; c++) { pa.wl[c] = win[c]; pa.stride[c] = a.stride[c]; }
+        for (int c = 0; c < 3; c++) { pa.wl[c] = win[c]; pa.stride[c] = a.stride[c]; pa.jt_bw[c] = ja.bw[c]; pa.jt_boff[c] = ja.boff[c]; }
         pa.plan_result = a.plan_result; pa.wait_cap = a.wait_cap;
         a.desc = pa.desc;
-        hipLaunchKernelGGL(k_hevc_intra_program, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, pa);
+        hipLaunchKernelGGL(k_hevc_intra_program, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, ps, pa);
     };
     /* The substitution table depends on the TU list alone: for large lists it is built on the calling thread's side stream, NEXT TO the planner's
      * kernels (which are chains of dependent loads with the chip mostly idle), and joined in front of the first kernel that reads it. */
     bool jt_forked = false;
-    FfhipSide side = {nullptr, nullptr, nullptr};
+    FfhipSide side = {nullptr, nullptr, nullptr, nullptr};
     auto enqueue_jtable = [&](uint32_t *words, bool may_fork) -> int {
         ja.tus = d_tus; ja.n = (uint32_t)n_tus; ja.jt = (uint8_t *)words;
         a.jt = ja.jt;
@@ -1971,23 +1988,42 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             uint32_t *const jt_words = g_work + ((w_plan + 3) & ~(size_t)3) + ((w_ctrl + 3) & ~(size_t)3);
             int n_groups = 0;
             /* the substitution table starts (on the side stream) behind the list's validation: a bad record's position would send its stores anywhere */
-            struct Hook { decltype(enqueue_jtable) *fn; uint32_t *words; JTabArgs *ja; } hook = {&enqueue_jtable, jt_words, &ja};
+            /* ... and the per-pixel programs follow it there, behind k_plan_count (whose flags and wait counts are all they need of the schedule),
+             * next to the ticket kernels and k_plan_emit on `stream`; the grouped kernel waits for both */
+            bool programs_forked = false;
+            auto programs_early = [&](const uint8_t *flags, const uint32_t *wcount, const uint32_t *result) -> int {
+                if (!jt_forked) return FFHIP_OK; /* a small list: everything on `stream`, in order */
+                FFHIP_CHECK(hipEventRecord((hipEvent_t)side.mid, st), FFHIP_EIO);
+                FFHIP_CHECK(hipStreamWaitEvent((hipStream_t)side.stream, (hipEvent_t)side.mid, 0), FFHIP_EIO);
+                pa.tus = d_tus; pa.flags = flags; pa.wcount = wcount;
+                a.sched = (const u32x4 *)g_work; /* where the planner puts the slots (ffhip_hevc_plan_gpu's layout starts with them) */
+                a.plan_result = result; a.wait_cap = (uint32_t)(8 * (size_t)n_tus);
+                enqueue_programs(jt_words + w_jt, win, (size_t)n_tus, (hipStream_t)side.stream);
+                FFHIP_CHECK(hipEventRecord((hipEvent_t)side.join, (hipStream_t)side.stream), FFHIP_EIO);
+                programs_forked = true;
+                return FFHIP_OK;
+            };
+            struct Hook { decltype(enqueue_jtable) *fn; decltype(programs_early) *pe; uint32_t *words; JTabArgs *ja; } hook = {&enqueue_jtable, &programs_early, jt_words, &ja};
             auto after_check = [](void *ctx, const uint32_t *refused) -> int {
                 Hook *h = (Hook *)ctx;
                 h->ja->refused = refused;
                 return (*h->fn)(h->words, true);
             };
+            auto after_count = [](void *ctx, const uint8_t *flags, const uint32_t *wcount, const uint32_t *result) -> int {
+                Hook *h = (Hook *)ctx;
+                return (*h->pe)(flags, wcount, result);
+            };
             const int check[2] = {(d_cb && d_cr && uv_stride >= width_c) ? 1 : 0, d_residual ? 1 : 0};
             const int prc = ffhip_hevc_plan_gpu_checked(d_tus, n_tus, pwc, ph, win, g_work, st, &a.sched, &a.groups, &a.wait_idx, &n_groups, &a.plan_result, &a.wait_cap,
-                                                        big_list ? check : nullptr, async_err, after_check, &hook);
+                                                        big_list ? check : nullptr, async_err, after_check, FFHIP_ENV("FFHIP_HEVC_PROGRAMS_INLINE") ? nullptr : after_count, &hook);
             if (prc < 0) { (void)join_jtable(); return prc; } /* (`stream` must not run ahead of the side stream's read of the caller's list) */
             a.ctrl = g_work + ((w_plan + 3) & ~(size_t)3);
             if (hipMemsetAsync(a.ctrl, 0, w_ctrl * 4, st) != hipSuccess) { (void)join_jtable(); return FFHIP_EIO; }
             a.async_err = async_err;
             a.n_groups = 0;
             a.n_tus = n_tus;
-            { const int jrc = join_jtable(); if (jrc) return jrc; }
-            enqueue_programs(jt_words + w_jt, win, (size_t)n_tus);
+            { const int jrc = join_jtable(); if (jrc) return jrc; } /* (the side stream's last record: behind the programs when they went there) */
+            if (!programs_forked) enqueue_programs(jt_words + w_jt, win, (size_t)n_tus, st);
 #ifdef FFHIP_INTRA_TRACE
             a.trace = g_intra_trace;
 #endif
@@ -2027,7 +2063,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             {
                 const int cs = (pw[1] > 0 && pw[1] * 2 <= pw[0] + 1) ? 1 : 0;
                 const int win[3] = {host_wl, host_wl - cs, host_wl - cs};
-                enqueue_programs(jt_words + w_jt, win, (size_t)n_tus);
+                enqueue_programs(jt_words + w_jt, win, (size_t)n_tus, st);
             }
             const unsigned wgs = (unsigned)std::min<size_t>(plan.groups.size(), max_waves); /* one wave each; waves loop over tickets */
             hipLaunchKernelGGL(k_hevc_intra_groups, dim3(wgs), dim3(64), 0, st, a);

@@ -509,7 +509,8 @@ __global__ __launch_bounds__(256) void k_plan_emit(PlanArgs a, uint32_t m)
     q2.w = (a.owner_off[t.cidx] + (uint32_t)(t.y >> 2) * (uint32_t)a.bw[t.cidx] + (uint32_t)(t.x >> 2)) * 20u; /* the TU's stripe of the substitution
                                                                                                                  table (JT_STRIDE bytes per 4x4 block) */
     a.sched[(size_t)i * 3] = src[0];
-    a.sched[(size_t)i * 3 + 1] = src[1];
+    /* (the second quarter belongs to k_hevc_intra_program, which writes it for EVERY slot and may be running next to this kernel: the
+     * availability masks that once sat there are in the substitution table) */
     a.sched[(size_t)i * 3 + 2] = q2;
     const bool starts = i == 0 || a.runid[i] != a.runid[i - 1];
     if (starts) {
@@ -658,20 +659,24 @@ extern "C" size_t ffhip_hevc_plan_gpu_words(long long n_tus, const int pw[3], co
 extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long n_tus, const int pw[3], const int ph[3], const int wl[3],
                                            uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
                                            int *n_groups, const uint32_t **d_result, uint32_t *wait_cap_out, const int *check /* NULL, or {chroma_ok,
-                                           have_residual} */, int *async_err, int (*after_check)(void *, const uint32_t *), void *hook_ctx);
+                                           have_residual} */, int *async_err, int (*after_check)(void *, const uint32_t *),
+                                           int (*after_count)(void *, const uint8_t *, const uint32_t *, const uint32_t *), void *hook_ctx);
 extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, const int pw[3], const int ph[3], const int wl[3],
                                    uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
                                    int *n_groups, const uint32_t **d_result, uint32_t *wait_cap_out)
 {
     return ffhip_hevc_plan_gpu_checked(d_tus, n_tus, pw, ph, wl, scratch, st, sched, groups, wait_idx, n_groups, d_result, wait_cap_out, nullptr, nullptr,
-                                       nullptr, nullptr);
+                                       nullptr, nullptr, nullptr);
 }
-/* ... with the list's validation as the first kernel behind the scratch's reset (check != NULL), and a hook that runs once that kernel is
- * enqueued: what the caller starts from there (the substitution table on a side stream) may rely on result[6], handed to the hook */
+/* ... with the list's validation as the first kernel behind the scratch's reset (check != NULL), a hook that runs once that kernel is
+ * enqueued: what the caller starts from there (the substitution table on a side stream) may rely on result[6], handed to the hook; and a
+ * second hook behind k_plan_count, when the per-TU flags (who publishes, who may use the LDS tile) and wait counts are final: the per-pixel
+ * programs need nothing else of the schedule and can be built next to the ticket kernels (flags, wait counts, result words) */
 extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long n_tus, const int pw[3], const int ph[3], const int wl[3],
                                            uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
                                            int *n_groups, const uint32_t **d_result, uint32_t *wait_cap_out, const int *check, int *async_err,
-                                           int (*after_check)(void *, const uint32_t *), void *hook_ctx)
+                                           int (*after_check)(void *, const uint32_t *),
+                                           int (*after_count)(void *, const uint8_t *, const uint32_t *, const uint32_t *), void *hook_ctx)
 {
     PlanArgs a;
     const PlanLayout Lo = plan_layout(a, scratch, d_tus, n_tus, pw, ph, wl);
@@ -705,6 +710,10 @@ extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long
     hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, a.blk_tot, (uint32_t)Lo.n_blocks, (uint32_t *)nullptr, 0u, (const uint32_t *)(a.result + 6));
     hipLaunchKernelGGL(k_plan_runid, dim3(grid), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_plan_count, dim3(grid), dim3(256), 0, st, a);
+    if (after_count) {
+        const int hrc = after_count(hook_ctx, a.flags, a.wcount, a.result);
+        if (hrc) return hrc;
+    }
     /* tickets: runs by (wavefront index of their cell, decode order) */
     {   /* one diagonal per step, at most one cell per row of cells, a lane per row: a picture of up to 64 rows of cells is swept by ONE
          * wave per plane (a wave-local barrier per step), taller ones by as many waves as they have rows (up to 1024 threads) and a

@@ -85,7 +85,7 @@ struct FfhipVp8Fusion {
 extern thread_local FfhipVp8Fusion g_ffhip_vp8_fusion;
 
 /* the calling thread's side stream with its fork / join events (ffhip_vp8_lf.hip: one set per thread and device, released by ffhip_shutdown) */
-struct FfhipSide { void *stream, *fork, *join; };
+struct FfhipSide { void *stream, *fork, *join, *mid; }; /* mid: a second point of the main stream the side stream may wait for */
 extern "C" int ffhip_side_stream_get(FfhipSide *out);
 
 #endif

@@ -497,7 +497,7 @@ extern "C" int ffhip_vp8_filter_params(const ffhip_vp8_filter_header *h, uint8_t
  * use, recreated when the thread's current device has changed, released by ffhip_shutdown (ffhip_vp8_release_side_streams)
  * or when the thread ends. */
 namespace {
-struct SideStream { int device = -1; hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+struct SideStream { int device = -1; hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr, mid = nullptr; };
 std::mutex g_side_mu;
 std::vector<SideStream *> g_sides;
 void side_release(SideStream *s)
@@ -505,7 +505,8 @@ void side_release(SideStream *s)
     if (s->side) (void)hipStreamDestroy(s->side);
     if (s->fork) (void)hipEventDestroy(s->fork);
     if (s->join) (void)hipEventDestroy(s->join);
-    s->side = nullptr; s->fork = s->join = nullptr; s->device = -1;
+    if (s->mid) (void)hipEventDestroy(s->mid);
+    s->side = nullptr; s->fork = s->join = s->mid = nullptr; s->device = -1;
 }
 struct SideHolder {
     SideStream s;
@@ -526,7 +527,7 @@ SideStream *side_stream_for_this_thread()
     if (h.s.side && h.s.device != dev) side_release(&h.s);
     if (!h.s.side) {
         if (hipStreamCreateWithFlags(&h.s.side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h.s.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h.s.join, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&h.s.join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h.s.mid, hipEventDisableTiming) != hipSuccess) {
             side_release(&h.s);
             return nullptr;
         }
@@ -541,7 +542,7 @@ extern "C" int ffhip_side_stream_get(FfhipSide *out)
 {
     SideStream *ss = side_stream_for_this_thread();
     if (!ss) return FFHIP_EIO;
-    out->stream = ss->side; out->fork = ss->fork; out->join = ss->join;
+    out->stream = ss->side; out->fork = ss->fork; out->join = ss->join; out->mid = ss->mid;
     return FFHIP_OK;
 }
 extern "C" void ffhip_vp8_release_side_streams(void) /* ffhip_shutdown: nothing of the library's is in flight */

@@ -24,7 +24,7 @@ EXPORTS = [
     "ffhip_jpeg_probe", "ffhip_jpeg_entropy_decode", "ffhip_jpeg_entropy_decode_mt", "ffhip_jpeg_entropy_batch", "ffhip_bmp_write",
     "ffhip_heif_grid_parse", "ffhip_heif_grid_compose", "ffhip_hevc_picture_layout", "ffhip_jpeg_decode_files", "ffhip_jpeg_decode_files_device", "ffhip_jpeg_entropy_batch_gpu", "ffhip_jpeg_stage_scan_test", "ffhip_host_malloc", "ffhip_host_free",
     "ffhip_shard_range", "ffhip_comm_unique_id", "ffhip_comm_init_rank", "ffhip_comm_destroy", "ffhip_batch_close", "ffhip_batch_complete",
-    "ffhip_bgra_checksum", "ffhip_vp8_filter_params", "ffhip_vp8_predict_loopfilter", "ffhip_reload_env", "ffhip_env_value_test", "ffhip_vp8_decode_frames",
+    "ffhip_bgra_checksum", "ffhip_vp8_filter_params", "ffhip_vp8_predict_loopfilter", "ffhip_reload_env", "ffhip_env_value_test", "ffhip_vp8_decode_frames", "ffhip_bgra_layout",
 ]
 
 
@@ -203,6 +203,7 @@ def lib():
     L.ffhip_vp8_filter_params.argtypes = [C.POINTER(Vp8FilterHeader), vp, C.POINTER(ci)]
     L.ffhip_bgra_checksum.argtypes = [vp, i64, i64, ci, ci, ci, vp, vp]
     L.ffhip_vp8_decode_frames.argtypes = [ci, ci, ci, vp, vp, vp, i64, vp, ci, vp, vp, ci, i64, vp, vp, vp, i64, i64, vp]
+    L.ffhip_bgra_layout.argtypes = [C.POINTER(JpegGeom), C.POINTER(i64), C.POINTER(i64)]
     L.ffhip_env_value_test.argtypes = [C.c_char_p, vp, sz]
     L.ffhip_env_value_test.restype = C.c_long
     _lib = L

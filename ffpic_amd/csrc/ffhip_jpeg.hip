@@ -132,12 +132,14 @@ struct WaveCtx {
     u32 tr_odd;     /*   reads (even rows 0,4,2,6 / odd rows 1,3,5,7)         */
     u32 blk, idx;   /* after a transposing read: block and column/row index   */
     int rnd1, rnd2; /* the two passes' rounding constants, held in VGPRs               */
+    int kflip, kwait; /* store-pattern experiments (JpegBatch::store_exp), 0 in the shipped configuration */
 };
 
 __device__ __forceinline__ void wave_ctx_init(WaveCtx &c, char *lds, u32 lane)
 {
     c.lds = lds;
     c.lane = lane;
+    c.kflip = 0; c.kwait = 0;
     c.wr_off = tile_off(lane >> 3, lane & 7);
     const u32 g = lane >> 4, t = lane & 15, q = t >> 2, p = t & 3;
     const u32 b = 2 * g + (p >> 1);
@@ -210,6 +212,8 @@ struct JpegBatch {
     int wgs_per_image;     /* workgroups that cover one image                            */
     u32 wpi_magic;         /* same trick for image = workgroup / wgs_per_image          */
     int xcd_remap;         /* 1: give each XCD a contiguous chunk of the workgroup sequence */
+    int store_exp;         /* experiments on the store pattern (FFHIP_JPEG_STORE_EXP): bit 0 odd waves write rows 8-15 of a quad first,
+                              bit 1 a wave waits for each half's stores before it issues the next (8 rows of a quad in flight, not 16) */
 };
 
 /* exact floor((x)/d) for the small non-negative ranges of the chroma terms:
@@ -387,7 +391,8 @@ __device__ __forceinline__ void quad_recon(const JpegBatch &p, const WaveCtx &c,
             *(u32x4 *)(c.lds + LDS_W + r.yc_wr) = pk;
         }
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
+        for (int k0 = 0; k0 < 2; k0++) {
+            const int k = k0 ^ c.kflip; /* (0 unless the store-order experiment is on: a wave-uniform value) */
             /* output role: 8 lanes cover one 32-px row segment (128 B); all LDS addresses are a
              * per-lane base (LaneRoles) plus a compile-time constant */
             const u32x2 yy = *(const u32x2 *)(c.lds + LDS_W + k * 512 + r.yc_rd);
@@ -426,6 +431,7 @@ __device__ __forceinline__ void quad_recon(const JpegBatch &p, const WaveCtx &c,
                 if (NT & 2) __builtin_nontemporal_store(px, dst);
                 else *dst = px;
             }
+            if (c.kwait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
 }
@@ -462,6 +468,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg420_fused(JpegBatch p)
 
     WaveCtx c;
     wave_ctx_init(c, lds_all + wave * LDS_WAVE_BYTES, lane);
+    c.kflip = (p.store_exp & 1) ? (int)((wave + blockIdx.x) & 1u) : 0;
+    c.kwait = (p.store_exp >> 1) & 1;
     LaneRoles r;
     lane_roles_init(r, c, lane, (u32)p.pitch);
 
@@ -811,6 +819,7 @@ static void launch_fused(const JpegBatch &q_in, int n_images, hipStream_t st)
     const int qpw = g_variant / 10;
     JpegBatch q = q_in;
     q.xcd_remap = jpeg_remap_mode();
+    { const char *se = FFHIP_ENV("FFHIP_JPEG_STORE_EXP"); q.store_exp = se ? atoi(se) : 0; }
     const int slots = (q.quads_per_image + qpw - 1) / qpw;
     q.wgs_per_image = (slots + WAVES_PER_WG - 1) / WAVES_PER_WG;
     q.wpi_magic = q.wgs_per_image == 1 ? 0xffffffffu : (u32)(0x100000000ULL / (unsigned)q.wgs_per_image) + 1u;
@@ -860,6 +869,15 @@ static int grid_for(long long work_items_per_wg_unit)
     long long want = 256LL * 7;
     if (work_items_per_wg_unit < want) want = work_items_per_wg_unit;
     return (int)(want < 1 ? 1 : want);
+}
+
+extern "C" int ffhip_bgra_layout(const ffhip_jpeg_geom *g, int64_t *pitch, int64_t *image_stride)
+{
+    if (!g || !pitch || !image_stride || !geom_ok(g)) return FFHIP_EINVAL;
+    const int64_t w = 8LL * g->h * g->mcu_cols, h = 8LL * g->v * g->mcu_rows;
+    *pitch = 4 * w + 1024;
+    *image_stride = *pitch * h;
+    return FFHIP_OK;
 }
 
 extern "C" size_t ffhip_jpeg_workspace_bytes(const ffhip_jpeg_geom *g, int n_images)

@@ -162,6 +162,13 @@ int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *geom, int n_images, const int1
                            int64_t pitch, int64_t image_stride, void *d_workspace,
                            size_t workspace_bytes, void *stream);
 size_t ffhip_jpeg_workspace_bytes(const ffhip_jpeg_geom *geom, int n_images);
+/* The BGRA layout this library recommends to a caller that owns its output buffer: *pitch = the reference's row pitch
+ * (4 bytes x the coded width, format/jpg.c:484-486) + 1024 bytes, *image_stride = pitch x coded height.  The fused kernels
+ * write 16 rows of a macroblock row at once, and with rows exactly 15 360 bytes apart (a 3840-pixel row) the rate depends on
+ * where the buffer landed in physical memory (5.7-5.9 or 6.2-6.6 TB/s: DESIGN.md 5); a kibibyte more per row is the one
+ * pitch that never measured slower and recovers 0.15-0.26 TB/s on the slow placements.  The drop-in path keeps the
+ * reference's pitch, and every entry point takes whatever pitch the caller passes. */
+int ffhip_bgra_layout(const ffhip_jpeg_geom *geom, int64_t *pitch, int64_t *image_stride);
 
 /* Same computation from HOST buffers (copies in, runs, copies out, synchronises): what a patched
  * format/jpg.c would call per picture.  The device staging is library scratch kept between calls

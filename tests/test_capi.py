@@ -150,3 +150,14 @@ def test_switch_values_are_kept_whole_and_survive_reloads(L, monkeypatch):
     os.environ.pop("FFHIP_TEST_SWITCH2", None)
     capi.reload_env()
     assert not bad
+
+
+def test_bgra_layout_recommendation(L):
+    """ffhip_bgra_layout: the reference's pitch plus one KiB, stride = pitch x coded height; needs no device"""
+    g = capi.jpeg_geom(240, 135)
+    p, s = C.c_int64(), C.c_int64()
+    assert L.ffhip_bgra_layout(C.byref(g), C.byref(p), C.byref(s)) == 0
+    assert (p.value, s.value) == (3840 * 4 + 1024, (3840 * 4 + 1024) * 2160)
+    g = capi.jpeg_geom(10, 7, 3, 4, 1, (0, 1, 1))
+    assert L.ffhip_bgra_layout(C.byref(g), C.byref(p), C.byref(s)) == 0 and p.value == 320 * 4 + 1024 and s.value == p.value * 56
+    assert L.ffhip_bgra_layout(C.byref(g), None, C.byref(s)) == capi.FFHIP_EINVAL

@@ -58,6 +58,7 @@ struct HevcIntraArgs {
     int debug_withhold;       /* test hook (FFHIP_DEBUG_WITHHOLD_TU): this TU's done flag is never published; -1 = off */
     /* device-planned launches: the planner's verdict is read by the kernel, not by the host */
     const uint32_t *plan_result; /* {refused, number of groups, wait entries, -, widest wavefront}; NULL: n_groups above is the truth */
+    uint32_t tp_width;           /* device-built plans: from this wavefront width on the throughput instance of the grouped kernel runs (0: never) */
     uint32_t wait_cap;           /* wait entries the planner had room for                                        */
     long long n_tus;             /* for the serial path a refused plan takes                                     */
     /* substitution table (k_hevc_intra_jtable): per TU and scan position the scan position its sample comes from */
@@ -609,10 +610,12 @@ __device__ __forceinline__ void intra_tu_g(const HotArgs &a, const GroupCtx &g, 
          * (it then starts at the window's origin) spills into cells right of and below the window that nobody reads --
          * halo cells are row 0 and column 0 only -- and the layout has room for a 32x32 block from any window origin */
         short *const cellp = tile + TILE_ORIGIN + (y0 - wy0 + yl) * TILE_STRIDE + (x0 - wx0 + x);
-        const short *const Rr = has_res ? R + lane : zero_block + lane; /* no residual: a block of zeros, no branch per pass */
+        const short *Rr = has_res ? R + lane : zero_block + lane; /* no residual: 64 zeros every pass reads again, no branch per pass */
+        const int rstep = has_res ? 64 : 0;
 #define EMIT(v_, pass_) do { \
             const int pr_ = (int)(short)((v_) & 0xffff); \
-            const short rec_ = (short)clip3i(0, maxv, pr_ + (int)Rr[64 * (pass_)]); \
+            const short rec_ = (short)clip3i(0, maxv, pr_ + (int)*Rr); \
+            Rr += rstep; \
             __builtin_amdgcn_raw_buffer_store_b16(rec_, prs, goff, 0, FFHIP_AUX_SC1); \
             goff += gstep; \
             cellp[(pass_) * rows * TILE_STRIDE] = rec_; \
@@ -1120,14 +1123,14 @@ __global__ __launch_bounds__(64) void k_hevc_intra_serial(HevcIntraArgs a)
     __shared__ short tile[TILE_CELLS];
     __shared__ int nbA[NB_MAX], nbB[NB_MAX];
     __shared__ __attribute__((aligned(16))) short resl[2][32 * 32];
-    __shared__ __attribute__((aligned(16))) short resz[32 * 32];
+    __shared__ __attribute__((aligned(16))) short resz[64];
     __shared__ u32x4 slots[SLOT_CHUNK * 3];
     const int lane = threadIdx.x;
     if (!a.plan_result) return;
     const uint32_t refused = a.plan_result[0] | (a.plan_result[2] > a.wait_cap ? 1u : 0u);
     if (!__builtin_amdgcn_readfirstlane((int)refused)) return;
     if (__builtin_amdgcn_readfirstlane((int)a.plan_result[6])) return; /* refused as INVALID (k_hevc_check_tus): nothing is written */
-    for (int i = lane; i < 32 * 32 / 8; i += 64) ((u32x4 *)resz)[i] = u32x4{0u, 0u, 0u, 0u};
+    resz[lane] = 0;
     wave_sync();
     HotArgs hot;
     hot.residual = (const __attribute__((address_space(1))) int16_t *)(unsigned long long)a.residual;
@@ -1165,13 +1168,17 @@ __global__ __launch_bounds__(64) void k_hevc_intra_serial(HevcIntraArgs a)
     }
 }
 
-__global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
+/* MINW: waves per SIMD the register allocation is asked to fit (2: the latency instance, 186 VGPRs; 3: the throughput instance for lists of many
+ * groups, 168 VGPRs and a dozen spilled); CHUNK: slots of a group staged in LDS at a time (64 / 16: with the 128-byte zero block the throughput
+ * instance's LDS comes to 14.4 KB, eleven one-wave workgroups per CU instead of eight) */
+template <int MINW, int CHUNK>
+__global__ __launch_bounds__(64, MINW) void k_hevc_intra_groups(HevcIntraArgs a)
 {
     __shared__ short tile[TILE_CELLS];
     __shared__ int nbA[NB_MAX], nbB[NB_MAX];
     __shared__ __attribute__((aligned(16))) short resl[2][32 * 32];
-    __shared__ __attribute__((aligned(16))) short resz[32 * 32]; /* zeros: the residual of a TU without one */
-    __shared__ u32x4 slots[(SLOT_CHUNK + 2) * 3];
+    __shared__ __attribute__((aligned(16))) short resz[64]; /* zeros: the residual of a TU without one (every pass reads the same 64) */
+    __shared__ u32x4 slots[(CHUNK + 2) * 3];
     const int lane = threadIdx.x;
     uint32_t *flags = a.ctrl + 4;
     int n_groups = a.n_groups;
@@ -1180,7 +1187,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
         tile[TILE_CONST_C] = (short)(1 << (a.bitdepth_c - 1));
         tile[TILE_ZERO] = 0;
     }
-    for (int i = lane; i < 32 * 32 / 8; i += 64) ((u32x4 *)resz)[i] = u32x4{0u, 0u, 0u, 0u};
+    resz[lane] = 0;
     wave_sync();
     HotArgs hot;
     {
@@ -1206,6 +1213,11 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
          * 1.46 / 1.46 ms; eight of them: 8.7 / 9.4 / 10.0 / 11.9 ms -- tests/tools/bench_hevc_grid.py): half the width, at least
          * 256, is what those runs ask for; the waves beyond that leave now. */
         const uint32_t width = a.plan_result[4];
+        /* two instances of this kernel are launched behind a device-built plan, and the plan's wavefront width says which one works: lists
+         * with a thousand groups and more ready at once (grids of tiles) are bound by how many waves the chip holds -- the instance that fits
+         * three waves per SIMD; a single picture's few hundred by one wave's latency -- the instance with all its registers */
+        const bool wide = a.tp_width && width >= a.tp_width;
+        if (wide != (MINW >= 3)) return;
         if (width && blockIdx.x >= ((width >> 1) + 16 > 256u ? (width >> 1) + 16 : 256u)) return;
     }
     const __amdgpu_buffer_rsrc_t desc_rs = ffhip_rsrc(a.desc, 0xffffffffu), res_rs = ffhip_rsrc((const void *)hot.residual, PROG_NO_RESIDUAL);
@@ -1228,8 +1240,8 @@ __global__ __launch_bounds__(64) void k_hevc_intra_groups(HevcIntraArgs a)
 #ifdef FFHIP_INTRA_TRACE
         if (a.trace && lane == 0) a.trace[12 * a.n_tus + ticket] = TRACE_NOW();
 #endif
-        for (unsigned base = 0; base < g.y && !dead; base += SLOT_CHUNK) {
-            const int m = (int)(g.y - base < SLOT_CHUNK ? g.y - base : SLOT_CHUNK);
+        for (unsigned base = 0; base < g.y && !dead; base += CHUNK) {
+            const int m = (int)(g.y - base < CHUNK ? g.y - base : CHUNK);
             for (int i = lane; i < 3 * m; i += 64) slots[i] = a.sched[(size_t)(g.x + base) * 3 + i];
             if (lane == 0) { /* behind the last slot: sentinels (the fetch runs two TUs ahead) the run of plain programs below stops at */
                 const u32x4 end = {PK_SLOW | PK_END, PROG_NO_RESIDUAL, 0u, 0u};
@@ -1950,7 +1962,13 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
         /* device-planned launches start as many waves as can be resident and trim themselves to the planner's wavefront width
          * (k_hevc_intra_groups); host-planned ones keep the flat cap */
         const size_t max_waves = wv ? (size_t)std::max(1, atoi(wv)) : FFHIP_HEVC_INTRA_WAVES;
-        const size_t resident_waves = wv ? max_waves : (size_t)std::max(FFHIP_HEVC_INTRA_WAVES, ffhip_resident_waves((const void *)k_hevc_intra_groups, 64));
+        const size_t resident_waves = wv ? max_waves : (size_t)std::max(FFHIP_HEVC_INTRA_WAVES, ffhip_resident_waves((const void *)k_hevc_intra_groups<2, 64>, 64));
+        const size_t resident_waves_tp = wv ? max_waves : (size_t)std::max(FFHIP_HEVC_INTRA_WAVES, ffhip_resident_waves((const void *)k_hevc_intra_groups<3, 16>, 64));
+        /* the throughput instance is OFF by default: measured on the tile grids it changes nothing (eight pictures 4.28 against 4.29 ms, four 2.55
+         * against 2.42) -- eleven waves per CU instead of nine do not make the groups of a depth finish sooner, they wait 76 % of their cycles
+         * (SQ_WAIT_ANY, profiles/r4_hevc_grid8_pmc.txt) for loads whose latency grows with the load.  FFHIP_HEVC_INTRA_TP_WIDTH=<width> turns it on
+         * for plans whose widest wavefront is at least that. */
+        { const char *tw = FFHIP_ENV("FFHIP_HEVC_INTRA_TP_WIDTH"); a.tp_width = tw ? (uint32_t)std::max(0, atoi(tw)) : 0u; }
         /* the schedule: built on the device (ffhip_hevc_plan_gpu.hip) unless FFHIP_HEVC_PLAN=host; lists whose groups are
          * not contiguous runs of the decode order come back from there and take the host planner with its window search */
         const char *pe = FFHIP_ENV("FFHIP_HEVC_PLAN");
@@ -2027,7 +2045,8 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
 #ifdef FFHIP_INTRA_TRACE
             a.trace = g_intra_trace;
 #endif
-            hipLaunchKernelGGL(k_hevc_intra_groups, dim3((unsigned)std::min<size_t>((size_t)n_tus, resident_waves)), dim3(64), 0, st, a);
+            hipLaunchKernelGGL((k_hevc_intra_groups<2, 64>), dim3((unsigned)std::min<size_t>((size_t)n_tus, resident_waves)), dim3(64), 0, st, a);
+            if (a.tp_width) hipLaunchKernelGGL((k_hevc_intra_groups<3, 16>), dim3((unsigned)std::min<size_t>((size_t)n_tus, resident_waves_tp)), dim3(64), 0, st, a);
             hipLaunchKernelGGL(k_hevc_intra_serial, dim3(1), dim3(64), 0, st, a); /* does something only for a list the planner refused */
             if (host_times) {
                 const auto TH3 = std::chrono::steady_clock::now();
@@ -2066,7 +2085,8 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
                 enqueue_programs(jt_words + w_jt, win, (size_t)n_tus, st);
             }
             const unsigned wgs = (unsigned)std::min<size_t>(plan.groups.size(), max_waves); /* one wave each; waves loop over tickets */
-            hipLaunchKernelGGL(k_hevc_intra_groups, dim3(wgs), dim3(64), 0, st, a);
+            a.tp_width = 0;
+            hipLaunchKernelGGL((k_hevc_intra_groups<2, 64>), dim3(wgs), dim3(64), 0, st, a);
             FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
             return FFHIP_OK;
         }

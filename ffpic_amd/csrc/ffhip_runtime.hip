@@ -256,16 +256,35 @@ extern "C" void *ffhip_stream_create(void)
     return (void *)s;
 }
 extern "C" void ffhip_stream_destroy(void *s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
+extern "C" int ffhip_vp8_side_by_side_retry(void *stream, int code); /* ffhip_vp8_lf.hip: > 0 nothing to retry on this stream, 0 healed, < 0 failed */
+extern "C" void ffhip_vp8_retry_forget(void *stream);
 extern "C" int ffhip_stream_sync(void *s)
 {
     FFHIP_CHECK(hipStreamSynchronize((hipStream_t)s), FFHIP_EIO);
     if (g_async_err && *(volatile int *)g_async_err) {
-        const int code = *(volatile int *)g_async_err;
+        int code = *(volatile int *)g_async_err;
+        /* A bounded wait of the side-by-side VP8 call ran out (codes 2 / 3: possible on a device shared with other work, where one of its two
+         * kernels may not become resident next to the other).  Its inputs are intact and the one thing of the planes' former contents it reads is
+         * kept (the last luma column), so the library repeats the two stages ONE AFTER THE OTHER here and reports what that run did. */
+        if (code == 2 || code == 3) {
+            *(volatile int *)g_async_err = 0;
+            const int rc = ffhip_vp8_side_by_side_retry(s, code);
+            if (rc == 0) {
+                if (hipStreamSynchronize((hipStream_t)s) != hipSuccess) return FFHIP_EIO;
+                code = *(volatile int *)g_async_err;
+                if (!code) return FFHIP_OK;
+            } else if (rc > 0 || !*(volatile int *)g_async_err) {
+                *(volatile int *)g_async_err = code; /* not this stream's call, or the retry could not be enqueued: as before */
+            } else {
+                code = *(volatile int *)g_async_err;
+            }
+        }
         snprintf(g_last_error, sizeof g_last_error, code == FFHIP_ASYNC_BAD_INPUT ? "a dependency-scheduled kernel refused its input (code %d)"
                                                                                    : "a dependency-scheduled kernel aborted (code %d)", code);
         *(volatile int *)g_async_err = 0;
         return code == FFHIP_ASYNC_BAD_INPUT ? FFHIP_EINVAL : FFHIP_EIO;
     }
+    ffhip_vp8_retry_forget(s);
     return FFHIP_OK;
 }
 extern "C" void *ffhip_event_create(void)

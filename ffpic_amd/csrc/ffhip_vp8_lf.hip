@@ -19,6 +19,7 @@
 #include "ffhip_internal.h"
 
 #include <algorithm>
+#include <map>
 #include <mutex>
 #include <stdlib.h>
 #include <string.h>
@@ -36,6 +37,7 @@ struct Vp8LfArgs {
     int *async_err;
     int n_images;
     int slack; /* as in Vp8PredArgs */
+    int debug_giveup;              /* test hook: a fused launch gives up by itself (the self-healing path of ffhip_stream_sync) */
     const uint32_t *pred_progress; /* fused with the prediction (ffhip_vp8_predict_loopfilter): its per-(image, row) counters, else null */
     int pred_split;                /* that prediction runs its chroma as rows of their own: their counters follow the luma rows' */
 };
@@ -199,6 +201,13 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
         ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
         if (ticket >= (unsigned)(a.n_images * a.mbrows)) return;
         const int y = (int)(ticket / (unsigned)a.n_images), img = (int)(ticket % (unsigned)a.n_images);
+        if (a.debug_giveup && a.pred_progress && y == a.mbrows / 2) { /* test hook (FFHIP_DEBUG_VP8_LF_GIVEUP): as if a wait for the prediction had run out half-way down */
+            if (lane == 0) {
+                __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.async_err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
         uint8_t *Y = a.y + (long long)img * a.plane_y;
         uint8_t *P[2] = {a.u + (long long)img * a.plane_uv, a.v + (long long)img * a.plane_uv};
         const uint8_t *mrow = a.modes + ((long long)img * n_mb + (long long)y * a.mbcols) * 20;
@@ -374,6 +383,7 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
 #define SCRATCH_VP8_LF 2
 
 thread_local FfhipVp8Fusion g_ffhip_vp8_fusion = {0, nullptr, nullptr, nullptr, 0};
+extern "C" void ffhip_vp8_note_enqueue(void *stream); /* below: the self-healing record of a side-by-side call is good while that call is the stream's last */
 
 extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int filter_type, const uint8_t *d_modes,
                                     const uint8_t *d_filters, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
@@ -382,6 +392,7 @@ extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int fi
     if (mbcols <= 0 || mbrows <= 0 || n_images < 0 || filter_type < 0 || filter_type > 2) return FFHIP_EINVAL;
     if (n_images == 0 || filter_type == 0) return FFHIP_OK; /* WEBP_FILTER_NONE (webp.c:1852-1856) */
     if (!d_modes || !d_filters || !d_y || !d_u || !d_v) return FFHIP_EINVAL;
+    ffhip_vp8_note_enqueue(stream);
     const long long n_mb = (long long)mbcols * mbrows;
     if (n_mb * n_images > 0x3fffffffLL) return FFHIP_EINVAL;
     if (!ffhip_have_device()) return FFHIP_ENODEV;
@@ -409,6 +420,7 @@ extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int fi
         a.mbcols = mbcols; a.mbrows = mbrows; a.filter_type = filter_type;
         a.ctrl = g_work; a.async_err = async_err; a.n_images = n_images;
         { const char *sl = FFHIP_ENV("FFHIP_VP8_SLACK"); a.slack = sl ? std::max(0, atoi(sl)) : 0; }
+        a.debug_giveup = FFHIP_ENV("FFHIP_DEBUG_VP8_LF_GIVEUP") ? 1 : 0;
         /* as many waves as can be resident, at most a wavefront's width of rows per image (ffhip_vp8_predict_recon has the
          * reasoning); next to the prediction kernel of the same call each of the two takes half of its own residency, so
          * filter waves -- which wait for the prediction's counters -- can never keep the prediction from becoming resident */
@@ -551,6 +563,69 @@ extern "C" void ffhip_vp8_release_side_streams(void) /* ffhip_shutdown: nothing 
     for (SideStream *s : g_sides) side_release(s);
 }
 
+/* ---- the side-by-side call heals itself ----
+ * What the prediction reads of the planes' FORMER contents is one column: the reference's wrapped 16x16 H_PRED at x = 0 reads the sample left
+ * of a row's first pixel, i.e. the plane's last column a line further up (predict.c:346-353).  The one-call form keeps a copy of that column
+ * (one byte per picture line) and a record of its arguments per stream; when a bounded wait of either kernel has run out, ffhip_stream_sync
+ * puts the column back and runs prediction, then filter, one after the other -- everything else the two stages read is their inputs, which are
+ * intact -- so the caller sees FFHIP_OK and the bytes of an undisturbed call. */
+#define SCRATCH_VP8_RETRY 8
+__global__ __launch_bounds__(256) void k_vp8_last_column(uint8_t *y, long long plane_y, int ys, int rows, int n_images, uint8_t *keep, int restore)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)rows * n_images) return;
+    const long long img = i / rows, r = i - img * rows;
+    uint8_t *p = y + img * plane_y + r * ys + (ys - 1);
+    if (restore) *p = keep[i];
+    else keep[i] = *p;
+}
+namespace {
+struct Vp8Retry {
+    int mbcols, mbrows, n_images, filter_type;
+    std::vector<uint8_t> h_modes;
+    const uint8_t *d_modes, *d_filters;
+    const int16_t *d_residual;
+    int64_t residual_stride, plane_y, plane_uv;
+    const int32_t *d_resmap;
+    uint8_t *y, *u, *v, *keep;
+    unsigned long long seq;
+};
+std::mutex g_retry_mu;
+std::map<void *, Vp8Retry> g_retry; /* by stream: the last side-by-side call enqueued there */
+std::map<void *, unsigned long long> g_vp8_seq; /* by stream: VP8 prediction / filter calls enqueued so far -- a record is only good while its call is the LAST of them */
+} // namespace
+extern "C" void ffhip_vp8_note_enqueue(void *stream)
+{
+    std::lock_guard<std::mutex> l(g_retry_mu);
+    g_vp8_seq[stream]++;
+}
+extern "C" void ffhip_vp8_retry_forget(void *stream) /* a clean ffhip_stream_sync: whatever was enqueued there has run */
+{
+    std::lock_guard<std::mutex> l(g_retry_mu);
+    g_retry.erase(stream);
+}
+extern "C" int ffhip_vp8_side_by_side_retry(void *stream, int code)
+{
+    (void)code;
+    Vp8Retry r;
+    {
+        std::lock_guard<std::mutex> l(g_retry_mu);
+        auto it = g_retry.find(stream);
+        if (it == g_retry.end()) return 1;
+        r = it->second;
+        g_retry.erase(it);
+        if (r.seq != g_vp8_seq[stream]) return 1; /* other VP8 calls went onto the stream behind it: their order cannot be restored */
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const long long lines = (long long)16 * r.mbrows * r.n_images;
+    hipLaunchKernelGGL(k_vp8_last_column, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, st, r.y, (long long)r.plane_y, 16 * r.mbcols, 16 * r.mbrows, r.n_images, r.keep, 1);
+    if (hipGetLastError() != hipSuccess) return FFHIP_EIO;
+    int rc = ffhip_vp8_predict_recon(r.mbcols, r.mbrows, r.n_images, r.h_modes.data(), r.d_modes, r.d_residual, r.residual_stride, r.d_resmap, r.y, r.u, r.v,
+                                     r.plane_y, r.plane_uv, stream);
+    if (rc == FFHIP_OK) rc = ffhip_vp8_loopfilter(r.mbcols, r.mbrows, r.n_images, r.filter_type, r.d_modes, r.d_filters, r.y, r.u, r.v, r.plane_y, r.plane_uv, stream);
+    return rc;
+}
+
 /* Prediction + reconstruction and the loop filter of a batch of key frames as ONE call: both row kernels are enqueued
  * side by side (the filter on a stream of the library's own, forked behind the prediction's counter reset and joined back
  * into `stream`), the filter's rows following the prediction's through its per-row counters.  Same arguments and the same
@@ -574,6 +649,28 @@ extern "C" int ffhip_vp8_predict_loopfilter(int mbcols, int mbrows, int n_images
         if (!ss) return FFHIP_EIO;
         side = ss->side; fork_ev = ss->fork; join_ev = ss->join;
     }
+    /* for the self-healing path: the last luma column as it is now, and who to call again (small batches only: the record holds a copy of the
+     * host's mode bytes, which the row form checks on the host; a chip-filling batch leaves no room for the second kernel to be kept out) */
+    uint8_t *keep = nullptr;
+    const bool heal = fuse && h_modes && d_y && (long long)mbcols * mbrows * n_images <= (1LL << 17) && !FFHIP_ENV("FFHIP_VP8_NO_RETRY");
+    if (heal) {
+        const long long lines = (long long)16 * mbrows * n_images;
+        keep = (uint8_t *)ffhip_scratch(SCRATCH_VP8_RETRY, stream, (size_t)(lines + 3) / 4);
+        if (keep) {
+            hipLaunchKernelGGL(k_vp8_last_column, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_y, (long long)plane_stride_y, 16 * mbcols,
+                               16 * mbrows, n_images, keep, 0);
+            Vp8Retry r;
+            r.mbcols = mbcols; r.mbrows = mbrows; r.n_images = n_images; r.filter_type = filter_type;
+            r.h_modes.assign(h_modes, h_modes + (size_t)mbcols * mbrows * n_images * 20);
+            r.d_modes = d_modes; r.d_filters = d_filters; r.d_residual = d_residual; r.residual_stride = residual_stride; r.d_resmap = d_resmap;
+            r.plane_y = plane_stride_y; r.plane_uv = plane_stride_uv; r.y = d_y; r.u = d_u; r.v = d_v; r.keep = keep;
+            std::lock_guard<std::mutex> l(g_retry_mu);
+            g_retry[stream] = std::move(r);
+        }
+    } else {
+        std::lock_guard<std::mutex> l(g_retry_mu);
+        g_retry.erase(stream);
+    }
     g_ffhip_vp8_fusion.active = fuse ? 1 : 0;
     g_ffhip_vp8_fusion.pred_progress = nullptr;
     g_ffhip_vp8_fusion.side = side;
@@ -585,6 +682,14 @@ extern "C" int ffhip_vp8_predict_loopfilter(int mbcols, int mbrows, int n_images
         rc = ffhip_vp8_loopfilter(mbcols, mbrows, n_images, filter_type, d_modes, d_filters, d_y, d_u, d_v, plane_stride_y, plane_stride_uv, stream);
     g_ffhip_vp8_fusion.active = 0;
     g_ffhip_vp8_fusion.pred_progress = nullptr;
+    {
+        std::lock_guard<std::mutex> l(g_retry_mu);
+        auto it = g_retry.find(stream);
+        if (it != g_retry.end()) {
+            if (rc == FFHIP_OK && forked) it->second.seq = g_vp8_seq[stream];
+            else g_retry.erase(it); /* nothing ran side by side: nothing to heal */
+        }
+    }
     if (forked) { /* whatever happened to the filter's launch: `stream` continues behind the side stream */
         if (hipEventRecord(join_ev, side) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, join_ev, 0) != hipSuccess) return FFHIP_EIO;
     }

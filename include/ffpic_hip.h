@@ -291,7 +291,14 @@ int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int filter_type, 
  * on a stream of the library's own, forked from and joined back into `stream` -- with the filter's rows following the
  * prediction's through its per-row progress counters (a macroblock is filtered once the prediction has finished its right
  * neighbour in the row below: the prediction reads reconstructed, not filtered, samples), so the two dependency chains
- * overlap instead of adding up.  filter_type 0 = prediction only.  FFHIP_VP8_FUSE=0: one after the other. */
+ * overlap instead of adding up.  filter_type 0 = prediction only.  FFHIP_VP8_FUSE=0: one after the other.
+ * The call HEALS ITSELF (batches of up to 2^17 macroblocks): on a device shared with other work one of the two kernels can be
+ * kept from becoming resident next to the other, and a bounded wait then runs out.  The library keeps a copy of the one thing of
+ * the planes' former contents the prediction reads (their last luma column, for the wrapped H_PRED read of predict.c:346-353) and
+ * of the call's arguments; ffhip_stream_sync on `stream` then restores that column, runs prediction and filter one after the
+ * other and returns what THAT run did -- FFHIP_OK and the bytes of an undisturbed call, as a rule -- provided the call is still
+ * the last VP8 prediction / filter call enqueued on `stream` and d_modes, d_residual, d_resmap and d_filters are still what
+ * they were (FFHIP_VP8_NO_RETRY=1: FFHIP_EIO, planes unspecified, as before round 4). */
 int ffhip_vp8_predict_loopfilter(int mbcols, int mbrows, int n_images, const uint8_t *h_modes, const uint8_t *d_modes,
                                  const int16_t *d_residual, int64_t residual_stride, const int32_t *d_resmap,
                                  int filter_type, const uint8_t *d_filters, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,

@@ -102,3 +102,40 @@ def test_give_up_path_reports_eio_and_the_library_recovers(monkeypatch):
     exp = O.oracle_hevc_intra(tus, res, w, h, True, 8, 8)
     for g, e in zip(got, exp):
         assert np.array_equal(g, e)
+
+
+def test_side_by_side_vp8_call_heals_itself(monkeypatch):
+    """ffhip_vp8_predict_loopfilter on a device where the filter's wait for the prediction runs out (test hook FFHIP_DEBUG_VP8_LF_GIVEUP: the fused
+    filter launch gives up half-way down every frame): ffhip_stream_sync puts the one column of the planes' former contents the prediction
+    reads back, runs prediction and filter one after the other and returns FFHIP_OK with the bytes of an undisturbed call -- H_PRED in the
+    first column included, whose wrapped read sees that column.  With FFHIP_VP8_NO_RETRY the sync says FFHIP_EIO, as before round 4."""
+    import oracle_lib as O
+    from ffpic_amd import capi, ops, synth
+    from test_vp8_lf_gpu import oracle_lf
+    L = capi.require_device()
+    c, r, n = 21, 13, 3
+    modes = np.stack([synth.vp8_modes(c, r, seed=1200 + i) for i in range(n)])
+    modes.reshape(n, r, c, 20)[:, 1::2, 0, 0] = 3              # every other row starts with the wrapped H_PRED
+    resid = np.stack([synth.vp8_residual(c * r, seed=1210 + i) for i in range(n)])
+    flt = synth.vp8_filters(seed=31)
+    exp = []
+    for i in range(n):
+        y0, u0, v0 = O.oracle_vp8_frame(c, r, modes[i], resid[i])
+        exp.append(oracle_lf(c, r, 2, modes[i], flt, (y0, u0, v0)))
+    want = ops.vp8_predict_loopfilter(c, r, modes, resid, 2, flt)          # undisturbed
+    monkeypatch.setenv("FFHIP_DEBUG_VP8_LF_GIVEUP", "1"); capi.reload_env()
+    got = ops.vp8_predict_loopfilter(c, r, modes, resid, 2, flt)           # gives up, heals inside the wrapper's ffhip_stream_sync
+    for i in range(n):
+        for gp, wp, e, name in zip(got, want, exp[i], "YUV"):
+            assert np.array_equal(gp[i], e) and np.array_equal(wp[i], e), (i, name)
+    assert L.ffhip_stream_sync(None) == 0
+    monkeypatch.setenv("FFHIP_VP8_NO_RETRY", "1"); capi.reload_env()
+    with pytest.raises(capi.FfhipError) as ei:
+        ops.vp8_predict_loopfilter(c, r, modes, resid, 2, flt)
+    assert "-5" in str(ei.value)
+    assert L.ffhip_stream_sync(None) == 0
+    monkeypatch.delenv("FFHIP_VP8_NO_RETRY"); monkeypatch.delenv("FFHIP_DEBUG_VP8_LF_GIVEUP"); capi.reload_env()
+    again = ops.vp8_predict_loopfilter(c, r, modes, resid, 2, flt)
+    for i in range(n):
+        for gp, e in zip(again, exp[i]):
+            assert np.array_equal(gp[i], e)

@@ -372,6 +372,8 @@ class C4:
             h_modes = np.ascontiguousarray(np.tile(self.modes, (reps, 1, 1))[:nf])
             d_modes = self.u_modes.repeat(reps, 1)[:nf * n_mb]
             p_res, d_filt, ft = d_res, self.d_filt, 2
+        if os.environ.get("BENCH_VP8_FT"):                 # diagnostics (tests/tools/bench_vp8_frames.py): what the loop filter costs the chain
+            ft = int(os.environ["BENCH_VP8_FT"])
         Y = torch.zeros((nf, B.Hp, B.Wp), dtype=torch.uint8, device=dev)
         U_ = torch.zeros((nf, B.Hp // 2, B.Wp // 2), dtype=torch.uint8, device=dev)
         V = torch.zeros_like(U_)

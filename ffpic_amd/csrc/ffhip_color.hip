@@ -35,6 +35,31 @@ __device__ __forceinline__ void convert_quad(const T *yp, int u_s, int v_s, bool
     }
 }
 
+/* 8-bit planes (WebP): the packed forms of the fused kernels -- the chroma terms of the lane's two chroma samples once for both rows (one fma
+ * and one add per term), per pixel pair three 16-bit adds, three saturating packs, three byte permutes: 93 vector instructions per lane
+ * where the per-pixel integer form below (kept for the 16-bit planes, whose samples may lie outside the exact domain) took 296.  Same lane
+ * layout and stores: 4 pixels x 2 rows per lane, one non-temporal dwordx4 per lane and row. */
+__global__ __launch_bounds__(256) void k_yuv420_to_bgra_u8(PlanarArgs a)
+{
+    const int w4 = a.width / 4, h2 = a.height / 2;
+    const int gx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int gy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int img = blockIdx.z;
+    if (gx >= w4 || gy >= h2) return;
+    const uint8_t *Y = (const uint8_t *)a.y + (long long)img * a.plane_y;
+    const uint8_t *U = (const uint8_t *)a.u + (long long)img * a.plane_uv;
+    const uint8_t *V = (const uint8_t *)a.v + (long long)img * a.plane_uv;
+    const long long co = (long long)gy * a.uv_stride + 2 * gx;
+    const uint8_t *y0 = Y + (long long)(2 * gy) * a.y_stride + 4 * gx;
+    /* (alignment: 4 * gx and 2 * gx bytes into rows whose stride the entry point checks to be a multiple of 4 / 2) */
+    const u32 l0 = *(const u32 *)y0, l1 = *(const u32 *)(y0 + a.y_stride);
+    const u32 eu = (u32)*(const unsigned short *)(U + co), ev = (u32)*(const unsigned short *)(V + co);
+    const Packed420 p = ff_packed420_terms(eu, ev);
+    uint8_t *o = a.bgra + (long long)img * a.image_stride + (long long)(2 * gy) * a.pitch + 16LL * gx;
+    __builtin_nontemporal_store(ff_packed420_row(p, l0), (u32x4 *)o);
+    __builtin_nontemporal_store(ff_packed420_row(p, l1), (u32x4 *)(o + a.pitch));
+}
+
 template <typename T, bool CHECK>
 __global__ __launch_bounds__(256) void k_yuv420_to_bgra(PlanarArgs a)
 {
@@ -102,7 +127,11 @@ extern "C" int ffhip_yuv420_to_bgra(uint8_t *d_bgra, int pitch, const uint8_t *d
     if (rc || n_images == 0) return rc;
     if (!ffhip_have_device()) return FFHIP_ENODEV;
     dim3 grid((a.width / 4 + 63) / 64, (a.height / 2 + 3) / 4, n_images);
-    hipLaunchKernelGGL((k_yuv420_to_bgra<uint8_t, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    /* the packed kernel loads a lane's samples as a dword of luma and a halfword of each chroma plane: strides and bases that keep those aligned
+     * (every picture of 16x16 macroblocks does); anything else takes the per-sample form */
+    const bool aligned = !((uintptr_t)d_y & 3) && !(y_stride & 3) && !(plane_stride_y & 3) && !((uintptr_t)d_u & 1) && !((uintptr_t)d_v & 1) && !(uv_stride & 1) && !(plane_stride_uv & 1);
+    if (aligned && !FFHIP_ENV("FFHIP_COLOR8_SCALAR")) hipLaunchKernelGGL(k_yuv420_to_bgra_u8, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_yuv420_to_bgra<uint8_t, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
     return FFHIP_OK;
 }
@@ -118,6 +147,8 @@ extern "C" int ffhip_yuv420_to_bgra_16(uint8_t *d_bgra, int pitch, const int16_t
     if (rc || n_images == 0) return rc;
     if (!ffhip_have_device()) return FFHIP_ENODEV;
     dim3 grid((a.width / 4 + 63) / 64, (a.height / 2 + 3) / 4, n_images);
+    /* (the packed form of the 8-bit kernel was tried here too, behind a per-lane test that every sample lies in [0, 8191]: 0.778 against 0.792 of the
+     * HBM peak on sixteen 8K pictures -- this kernel moves twice the input bytes per instruction and was not bound by its arithmetic) */
     hipLaunchKernelGGL((k_yuv420_to_bgra<short, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
     FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
     return FFHIP_OK;

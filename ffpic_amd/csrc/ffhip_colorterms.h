@@ -112,5 +112,51 @@ __device__ __forceinline__ TermBits2 chroma_term_bits2(u32 uw, u32 vw)
     t.b = __builtin_amdgcn_perm(bb[1], bb[0], 0x05040100u);
     return t;
 }
+/* Four pixels of one row at 4:2:0 in the packed forms: `el` four 8-bit luma samples, `eu` / `ev` the two 8-bit chroma samples they share
+ * (pixels 0, 1 the first, 2, 3 the second).  The chroma terms are made once (ff_packed420_terms) and serve every row that shares the
+ * samples; a row is three 16-bit adds, three saturating packs and three byte permutes per pixel PAIR, fp64 only where 215 uu + 381 vv is a
+ * non-zero multiple of 1000.  Exact for 8-bit samples (the forms hold on [0, 8191]: tests/tools/check_color_fma.c). */
+struct Packed420 {
+    u32 tr2[2], tg2[2], tb2[2];
+    f32x2 rem, sf;
+    u32 eu, ev;
+};
+__device__ __forceinline__ Packed420 ff_packed420_terms(const u32 eu, const u32 ev)
+{
+    const u32 uw = __builtin_amdgcn_perm(0u, eu, 0x0c010c00u), vw = __builtin_amdgcn_perm(0u, ev, 0x0c010c00u); /* two raw samples as halfwords */
+    const TermBits2 t = chroma_term_bits2(uw, vw);
+    Packed420 p;
+    p.tr2[0] = __builtin_amdgcn_perm(t.r, t.r, 0x01000100u); p.tr2[1] = __builtin_amdgcn_perm(t.r, t.r, 0x03020302u);
+    p.tg2[0] = __builtin_amdgcn_perm(t.g, t.g, 0x01000100u); p.tg2[1] = __builtin_amdgcn_perm(t.g, t.g, 0x03020302u);
+    p.tb2[0] = __builtin_amdgcn_perm(t.b, t.b, 0x01000100u); p.tb2[1] = __builtin_amdgcn_perm(t.b, t.b, 0x03020302u);
+    p.rem = t.rem; p.sf = t.sf; p.eu = eu; p.ev = ev;
+    return p;
+}
+__device__ __forceinline__ u32x4 ff_packed420_row(const Packed420 &p, const u32 el)
+{
+    const u32 yp[2] = {__builtin_amdgcn_perm(0u, el, 0x0c010c00u), __builtin_amdgcn_perm(0u, el, 0x0c030c02u)};
+    u32x4 px;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++) {
+        const u32 r2 = sat_pk_u8_i16(pk_add16(yp[h2], p.tr2[h2]));
+        const u32 g2 = sat_pk_u8_i16(pk_add16(yp[h2], p.tg2[h2]));
+        const u32 b2 = sat_pk_u8_i16(pk_add16(yp[h2], p.tb2[h2]));
+        const u32 bg = __builtin_amdgcn_perm(g2, b2, 0x05010400u); /* b0 g0 b1 g1 */
+        px[2 * h2] = __builtin_amdgcn_perm(r2, bg, 0x0d040100u);     /* b0 g0 r0 ff */
+        px[2 * h2 + 1] = __builtin_amdgcn_perm(r2, bg, 0x0d050302u); /* b1 g1 r1 ff */
+    }
+    if (p.rem.x * p.rem.y == 0.0f) { /* rare: some sample's G sum is a multiple of 1000 (zero included) */
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int k2 = d >> 1;
+            const float rem = k2 ? p.rem.y : p.rem.x, sf = k2 ? p.sf.y : p.sf.x;
+            if (rem == 0.0f && sf != 76288.0f) {
+                const int uu = (int)((p.eu >> (8 * k2)) & 0xff) - 128, vv = (int)((p.ev >> (8 * k2)) & 0xff) - 128;
+                px[d] = (px[d] & 0xffff00ffu) | (green_fp64((int)((el >> (8 * d)) & 0xff), uu, vv) << 8);
+            }
+        }
+    }
+    return px;
+}
 
 #endif

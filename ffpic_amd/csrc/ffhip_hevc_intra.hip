@@ -835,85 +835,99 @@ struct ProgArgs {
     int jt_bw[3];
     uint32_t jt_boff[3];
 };
-/* the program of ONE slot, by one wave (k is wave-uniform) */
+/* The program of ONE slot, by one wave (k is wave-uniform; the caller has found the slot eligible: 4x4 / 8x8, LDS tile allowed, no rdpcm /
+ * cross-component residual).  Everything that differs from lane to lane is a SELECT, never a branch: the kernel was bound by the scalar
+ * unit -- 286 scalar instructions per slot, most of them the exec-mask bookkeeping of per-lane ifs around the table reads (252 M of them
+ * for the 1.84 M slots of an eight-picture grid, at one per cycle and CU: 0.47 ms) -- so a table read that a lane does not need is made
+ * anyway, at position 0, and its answer dropped; on a 4x4 slot lanes 16 .. 63 do what lanes 0 .. 15 do (same words to the same addresses).
+ * What IS the same for all lanes (the mode's kind, the smoothing) stays a scalar branch. */
 __device__ __forceinline__ void intra_program_slot(const ProgArgs &a, const uint32_t k, const int lane, const u32x4 q0, const u32x4 q2)
 {
     const u32x4 generic = {PK_SLOW, PROG_NO_RESIDUAL, 0u, 0u};
     const int x0 = (int)(q0.x & 0xffff), y0 = (int)(q0.x >> 16);
     const int lg = (int)(q0.y & 0xff), cidx = (int)((q0.y >> 8) & 0xff), mode = (int)((q0.y >> 16) & 0xff), flags = (int)(q0.y >> 24);
     const int n = 1 << lg, wl = a.wl[cidx], wsz = 1 << wl;
-    bool prog = lg <= 3 && n <= wsz && ((q2.y >> 9) & 1) && !(flags & 0xC0) && q0.z < 0x7fff0000u;
     bool filt = false; /* neighbour smoothing applies (8.4.4.2.3; at 8x8: planar and modes 2, 18, 34): the taps read the smoothed copy */
-    if (prog && (flags & 4) && mode != 1 && n != 4) {
+    if ((flags & 4) && mode != 1 && n != 4) {
         const int d26 = iabs(mode - 26), d10 = iabs(mode - 10);
         filt = (d26 < d10 ? d26 : d10) > 7;
     }
-    if (!prog) {
-        if (lane == 0) a.sched[(size_t)k * 3 + 1] = generic;
-        return;
-    }
     const int wx0 = (x0 >> wl) << wl, wy0 = (y0 >> wl) << wl;
     const uint8_t *jt = a.jt + q2.w;
+    const unsigned cconst = 2u * (cidx == 0 ? TILE_CONST_Y : TILE_CONST_C);
     bool ok = true, outside = false;
-    auto src_cell = [&](int pos) -> unsigned { /* LDS byte address of the sample scan position pos takes */
-        const int j = (int)jt[pos];
-        if (j == 255) return 2u * (cidx == 0 ? TILE_CONST_Y : TILE_CONST_C);
-        int px = x0 - 1, py = y0 - 1;
-        if (j < 2 * n) py = y0 + (2 * n - 1 - j);
-        else if (j > 2 * n) px = x0 + (j - 2 * n - 1);
+    /* LDS byte address of the sample scan position pos takes; a lane that does not `use` the answer reads position 0 and leaves the slot's
+     * verdicts (ok, outside) alone */
+    auto src_cell = [&](const int pos, const bool use) -> unsigned {
+        const int j = (int)jt[use ? pos : 0];
+        const bool none = j == 255;
+        const int py = y0 - 1 + max(2 * n - j, 0), px = x0 - 1 + max(j - 2 * n, 0); /* j < 2n: the left column, bottom-up; j > 2n: the top row */
         const int tx = px - wx0 + 1, ty = py - wy0 + 1;
-        if (tx == 0 || ty == 0 || tx > wsz || ty > wsz) outside = true;
-        if (!TILE_HAS_CELL(ty, tx)) { ok = false; return 0u; }
-        return 2u * (unsigned)TILE_CELL(ty, tx);
+        const bool out = ((unsigned)(tx - 1) >= (unsigned)wsz) | ((unsigned)(ty - 1) >= (unsigned)wsz);
+        /* TILE_HAS_CELL / TILE_CELL with every arm worked out first: as nested conditional expressions they became nested branches */
+        const bool z = ty == 0, m = ty <= 64;
+        const bool has0 = tx <= 129, has1 = tx <= TILE_STRIDE - 1, has2 = (ty <= 128) & (tx == 0);
+        const int cell0 = TILE_ROW0 + tx, cell1 = TILE_BODY + (ty - 1) * TILE_STRIDE + tx, cell2 = TILE_LEFT_EXT + ty - 65;
+        const bool has12 = m ? has1 : has2, has = z ? has0 : has12;
+        const int cell12 = m ? cell1 : cell2, cellw = z ? cell0 : cell12;
+        outside = outside | (use & !none & out);
+        ok = ok & (!use | none | has);
+        const unsigned cw = has ? 2u * (unsigned)cellw : 0u;
+        return none ? cconst : cw;
     };
-    auto cell = [&](int pos) -> unsigned { return filt ? 2u * (unsigned)(TILE_F + pos) : src_cell(pos); }; /* what a tap reads */
+    auto cell = [&](const int pos, const bool use) -> unsigned { return filt ? 2u * (unsigned)(TILE_F + pos) : src_cell(pos, use); }; /* what a tap reads */
 #define POS_LEFT(yy) (2 * n - 1 - (yy))
 #define POS_TOP(xx) (2 * n + 1 + (xx))
-    const bool act = lane < n * n;
-    const int x = lane & (n - 1), y = lane >> lg;
+    const int le = lane & (n * n - 1); /* the pixel this lane works for */
+    const int x = le & (n - 1), y = le >> lg;
     unsigned w0 = 0, w1 = 0, w2 = 0, w3 = 0, kind;
     const bool edge_ok = cidx == 0; /* n < 32 here */
     if (mode == 0) {
         kind = PROG_PLANAR;
-        if (act && !filt) { w0 = cell(POS_LEFT(y)); w1 = cell(POS_TOP(x)); w2 = cell(POS_TOP(n)); w3 = cell(POS_LEFT(n)); }
+        if (!filt) { w0 = cell(POS_LEFT(y), true); w1 = cell(POS_TOP(x), true); w2 = cell(POS_TOP(n), true); w3 = cell(POS_LEFT(n), true); }
     } else if (mode == 1) {
         kind = PROG_DC;
-        if (act) {
-            w0 = cell(POS_LEFT(y)); w1 = cell(POS_TOP(x));
-            w2 = lane < n ? cell(POS_LEFT(lane)) : (lane < 2 * n ? cell(POS_TOP(lane - n)) : 2u * TILE_ZERO);
-            if (edge_ok && !(flags & 0x20)) w3 = (x == 0 && y == 0) ? 1u : (y == 0 ? 2u : (x == 0 ? 3u : 0u));
-        }
+        w0 = cell(POS_LEFT(y), true); w1 = cell(POS_TOP(x), true);
+        const bool sum_lane = le < 2 * n; /* lanes 0 .. 2n - 1 hold the 2n samples the sum runs over */
+        const unsigned ws = cell(le < n ? POS_LEFT(le) : POS_TOP(le - n), sum_lane);
+        w2 = sum_lane ? ws : 2u * TILE_ZERO;
+        if (edge_ok && !(flags & 0x20)) w3 = (x == 0 && y == 0) ? 1u : (y == 0 ? 2u : (x == 0 ? 3u : 0u));
     } else {
         const bool edge_tu = edge_ok && !(flags & 0x10) && (mode == 26 || mode == 10);
         kind = edge_tu ? PROG_ANGULAR_EDGE : PROG_ANGULAR;
-        if (act) {
-            const int angle = intra_angle(mode), inv = angle < 0 ? intra_inv_angle(mode) : 0, sg = mode >= 18 ? 1 : -1;
-            const int al = mode >= 18 ? y : x, ac = mode >= 18 ? x : y;
-            const int prod = (al + 1) * angle, idx = prod >> 5, fact = prod & 31;
-            const int k0 = ac + idx + 1, k1 = k0 + 1;
-            const int p0 = k0 >= 0 ? k0 : -((k0 * inv + 128) >> 8), p1 = k1 >= 0 ? k1 : -((k1 * inv + 128) >> 8);
-            if (edge_tu && ((mode == 26 && x == 0) || (mode == 10 && y == 0))) {
-                w0 = cell(mode == 26 ? POS_TOP(0) : POS_LEFT(0));
-                w1 = cell(mode == 26 ? POS_LEFT(y) : POS_TOP(x));
-                w2 = cell(2 * n);
-                w3 = 1;
-            } else {
-                w0 = cell(2 * n + sg * p0);
-                w1 = fact ? cell(2 * n + sg * p1) : w0; /* weight 0: any cell does (the true one may lie past the array) */
-                w2 = (unsigned)fact;
-            }
+        const int angle = intra_angle(mode), inv = angle < 0 ? intra_inv_angle(mode) : 0, sg = mode >= 18 ? 1 : -1;
+        const int al = mode >= 18 ? y : x, ac = mode >= 18 ? x : y;
+        const int prod = (al + 1) * angle, idx = prod >> 5, fact = prod & 31;
+        const int k0 = ac + idx + 1, k1 = k0 + 1;
+        const int p0 = k0 >= 0 ? k0 : -((k0 * inv + 128) >> 8), p1 = k1 >= 0 ? k1 : -((k1 * inv + 128) >> 8);
+        const bool e = edge_tu && (mode == 26 ? x == 0 : y == 0); /* this pixel takes the boundary filter of modes 10 / 26 */
+        const int posA = e ? (mode == 26 ? POS_TOP(0) : POS_LEFT(0)) : 2 * n + sg * p0;
+        const int posB = e ? (mode == 26 ? POS_LEFT(y) : POS_TOP(x)) : 2 * n + sg * p1;
+        w0 = cell(posA, true);
+        const unsigned wb = cell(posB, e | (fact != 0)); /* weight 0: any cell does (the true one may lie past the array) */
+        w1 = (e | (fact != 0)) ? wb : w0;
+        if (edge_tu) { /* (wave-uniform) */
+            const unsigned wc = cell(2 * n, e);
+            w2 = e ? wc : (unsigned)fact;
+            w3 = e ? 1u : 0u;
+        } else {
+            w2 = (unsigned)fact;
         }
     }
 #undef POS_LEFT
 #undef POS_TOP
-    if (filt && lane < 4 * n + 1) w3 = src_cell(lane); /* lane i fetches scan position i for the smoothing step */
+    if (filt) { /* lane i fetches scan position i for the smoothing step */
+        const bool fl = lane < 4 * n + 1;
+        const unsigned wf = src_cell(lane, fl);
+        w3 = fl ? wf : w3;
+    }
     const unsigned long long any_out = __builtin_amdgcn_ballot_w64(outside);
     if (__builtin_amdgcn_ballot_w64(!ok)) { /* a neighbour the tile layout has no cell for: the generic body */
         if (lane == 0) a.sched[(size_t)k * 3 + 1] = generic;
         return;
     }
     const uint32_t d_first = a.desc_off[cidx] + (uint32_t)y0 * (uint32_t)a.desc_w[cidx] + (uint32_t)x0;
-    if (act) a.desc[d_first + (uint32_t)y * (uint32_t)a.desc_w[cidx] + (uint32_t)x] = make_uint2(w0 | (w1 << 16), w2 | (w3 << 16));
+    a.desc[d_first + (uint32_t)y * (uint32_t)a.desc_w[cidx] + (uint32_t)x] = make_uint2(w0 | (w1 << 16), w2 | (w3 << 16));
     if (lane == 0) {
         u32x4 q1;
         q1.x = kind | (lg == 3 ? PK_LG3 : 0u) | (filt ? PK_FILTER : 0u) | ((flags & 2) ? PK_RES : 0u) | (any_out ? PK_OUTSIDE : 0u) | (((q2.y >> 8) & 1) ? PK_SIGNAL : 0u) |
@@ -1151,7 +1165,8 @@ __global__ __launch_bounds__(64) void k_hevc_intra_serial(HevcIntraArgs a)
         }
         wave_sync();
         for (int k = 0; k < m; k++) {
-            const IntraSlot cur = decode_slot(slots[3 * k], slots[3 * k + 2]);
+            IntraSlot cur = decode_slot(slots[3 * k], slots[3 * k + 2]);
+            cur.tile_ok = 0; /* every neighbour through memory: the planner's answer assumes ONE run per window (for_each_dep), which a refused list need not have */
             ResPrefetch rp;
             JPrefetch jp;
             fetch_residual_g(hot, cur, lane, rp);
@@ -1512,7 +1527,8 @@ extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long
                                            uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
                                            int *n_groups, const uint32_t **d_result, uint32_t *wait_cap_out, const int *check, int *async_err,
                                            int (*after_check)(void *, const uint32_t *),
-                                           int (*after_count)(void *, const uint8_t *, const uint32_t *, const uint32_t *), void *hook_ctx);
+                                           int (*after_count)(void *, const uint8_t *, const uint32_t *, const uint32_t *), void *hook_ctx, uint32_t *also_zero,
+                                           size_t also_zero_words);
 
 struct GroupPlan {
     std::vector<u32x4> sched;  /* 3 per slot */
@@ -2033,10 +2049,10 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             };
             const int check[2] = {(d_cb && d_cr && uv_stride >= width_c) ? 1 : 0, d_residual ? 1 : 0};
             const int prc = ffhip_hevc_plan_gpu_checked(d_tus, n_tus, pwc, ph, win, g_work, st, &a.sched, &a.groups, &a.wait_idx, &n_groups, &a.plan_result, &a.wait_cap,
-                                                        big_list ? check : nullptr, async_err, after_check, FFHIP_ENV("FFHIP_HEVC_PROGRAMS_INLINE") ? nullptr : after_count, &hook);
+                                                        big_list ? check : nullptr, async_err, after_check, FFHIP_ENV("FFHIP_HEVC_PROGRAMS_INLINE") ? nullptr : after_count, &hook,
+                                                        g_work + ((w_plan + 3) & ~(size_t)3), w_ctrl /* the ticket counter and the done flags: cleared by the planner's first launch */);
             if (prc < 0) { (void)join_jtable(); return prc; } /* (`stream` must not run ahead of the side stream's read of the caller's list) */
             a.ctrl = g_work + ((w_plan + 3) & ~(size_t)3);
-            if (hipMemsetAsync(a.ctrl, 0, w_ctrl * 4, st) != hipSuccess) { (void)join_jtable(); return FFHIP_EIO; }
             a.async_err = async_err;
             a.n_groups = 0;
             a.n_tus = n_tus;

@@ -55,10 +55,12 @@ struct PlanArgs {
     uint32_t cell_off[3], cgw[3];
     int cshift[3];         /* log2 of the cell size in samples of the plane          */
     uint32_t *rank_of;     /* ticket of a run                                          */
-    uint32_t *blk_tot;     /* per block of 256 TUs: run starts; after the scan: starts in the blocks before */
+    uint32_t *blk_tot;     /* per block of 256 TUs: run starts                                        */
+    uint32_t *blk_pre;     /* its exclusive scan: starts in the blocks before                         */
     uint32_t *cell_nruns;  /* runs per cell                                            */
     uint32_t *cell_base;   /* first ticket of the cell's runs                          */
-    uint32_t *hist;        /* [depths][shards] runs per (depth, shard); after the scan: first ticket of the pair */
+    uint32_t *hist;        /* [depths][shards] runs per (depth, shard)                 */
+    uint32_t *hist_pre;    /* its exclusive scan: first ticket of the pair             */
     uint32_t *fill;        /* [depths][shards] tickets of the pair handed out so far   */
     uint32_t depths;       /* a bound on the depths: a chain ending at cell (x, y) has at most x + 2y edges */
     uint32_t shard_log2;   /* the counters of one depth are spread over 2^shard_log2 words, picked by the cell's block: a grid of tiles has
@@ -94,55 +96,57 @@ __device__ __forceinline__ uint32_t block_excl_scan(const uint32_t v, uint32_t *
     *total = wsum[16];
     return r;
 }
-/* in-place exclusive scan of v[0..n) by ONE workgroup of 1024 threads, four entries per thread and pass (block totals: n / 256 entries;
- * the (depth, shard) histogram: a few ten thousand).  With vmax: v is [groups][1 << group_log2] and *vmax receives the largest GROUP total
- * (the widest wavefront: the most runs of one depth). */
-__global__ __launch_bounds__(1024) void k_plan_scan(uint32_t *v, uint32_t n, uint32_t *vmax, uint32_t group_log2, const uint32_t *skip)
+/* Exclusive scan of v[0..n) into out[0..n) (out != v), 4096 entries per workgroup.  A workgroup first adds up everything IN FRONT of its
+ * chunk by itself -- the tables scanned here are small (n / 256 block totals, at most 32 K histogram words), reading them again costs a
+ * few microseconds and no workgroup waits for another -- then scans its chunk.  (ONE workgroup walking the table pass by pass, until late in
+ * round 4: 58 us for the 7 176 block totals and 148 us for the histogram of an eight-picture grid, the side stream's kernels on the same
+ * CUs.)  With vmax: v is [groups][1 << group_log2] and *vmax (zero beforehand) receives the largest GROUP total (the widest wavefront:
+ * the most runs of one depth). */
+__global__ __launch_bounds__(1024) void k_plan_scan(const uint32_t *v, uint32_t *out, uint32_t n, uint32_t *vmax, uint32_t group_log2, const uint32_t *skip)
 {
     __shared__ uint32_t wsum[17];
-    __shared__ uint32_t wmax[16];
+    __shared__ uint32_t red[16];
     if (skip && *skip) return; /* no wavefront keys: nobody reads the histogram */
+    __builtin_amdgcn_s_setprio(3); /* a handful of waves next to the side stream's thousands: first in line at the issue arbiter */
+    const uint32_t base = blockIdx.x * 4096u;
+    uint32_t s = 0;
+    for (uint32_t i = threadIdx.x; i < base; i += 1024) s += v[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += (uint32_t)__shfl_xor((int)s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < n; base += 4096) {
-        const uint32_t i = base + 4 * threadIdx.x;
-        uint32_t x[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) x[k] = i + k < n ? v[i + k] : 0u;
-        uint32_t total;
-        const uint32_t e = block_excl_scan(x[0] + x[1] + x[2] + x[3], wsum, &total);
-        uint32_t run = carry + e;
+    for (int w = 0; w < 16; w++) carry += red[w];
+    const uint32_t i = base + 4 * threadIdx.x;
+    uint32_t x[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (i + k < n) v[i + k] = run;
-            run += x[k];
-        }
-        carry += total;
-        __syncthreads(); /* wsum is reused */
+    for (int k = 0; k < 4; k++) x[k] = i + k < n ? v[i + k] : 0u;
+    uint32_t total;
+    uint32_t run = carry + block_excl_scan(x[0] + x[1] + x[2] + x[3], wsum, &total);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (i + k < n) out[i + k] = run;
+        run += x[k];
     }
     if (vmax) {
-        __threadfence_block();
-        __syncthreads();
-        const uint32_t groups = n >> group_log2;
+        const uint32_t gend = ((base + 4096u < n ? base + 4096u : n) >> group_log2);
         uint32_t mx = 0;
-        for (uint32_t g = threadIdx.x; g < groups; g += 1024) {
-            const uint32_t lo = v[g << group_log2], hi = g + 1 < groups ? v[(g + 1) << group_log2] : carry;
-            mx = hi - lo > mx ? hi - lo : mx;
+        for (uint32_t g = (base >> group_log2) + threadIdx.x; g < gend; g += 1024) {
+            uint32_t t = 0;
+            for (uint32_t e = 0; e < (1u << group_log2); e++) t += v[(g << group_log2) + e];
+            mx = t > mx ? t : mx;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)mx, o, 64); mx = t > mx ? t : mx; }
-        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < 16; w++) mx = wmax[w] > mx ? wmax[w] : mx;
-            *vmax = mx;
-        }
+        if ((threadIdx.x & 63) == 0 && mx) atomicMax(vmax, mx);
     }
 }
 
 struct PlanInit {
-    uint32_t *p[4];
-    size_t words[4];
-    uint32_t value[4];
+    uint32_t *p[5];
+    size_t words[5];
+    uint32_t value[5];
 };
 __global__ __launch_bounds__(256) void k_plan_init(PlanInit in) /* blockIdx.y: the region */
 {
@@ -172,8 +176,21 @@ __device__ __forceinline__ bool plan_owner_tu(const PlanArgs &a, const uint32_t 
     const ffhip_hevc_tu t = a.tus[i];
     const int c = t.cidx, nb = (1 << t.log2_size) >> 2;
     int32_t *o = a.owner + a.owner_off[c] + (size_t)(t.y >> 2) * a.bw[c] + (t.x >> 2);
-    for (int by = 0; by < nb; by++)
-        for (int bx = 0; bx < nb; bx++) o[(size_t)by * a.bw[c] + bx] = (int32_t)i;
+    /* rows of a 16x16 / 32x32 TU are one / two 16-byte stores, of an 8x8 TU one 8-byte store, where the plane's block rows keep that alignment
+     * (a 32x32 TU was 64 stores from one lane; the 25 M blocks of an eight-picture grid took 0.17 ms) */
+    const uintptr_t al = (uintptr_t)o | ((uintptr_t)a.bw[c] << 2);
+    if (nb >= 4 && !(al & 15)) {
+        const u32x4 v4 = {i, i, i, i};
+        for (int by = 0; by < nb; by++)
+            for (int bx = 0; bx < nb; bx += 4) *(u32x4 *)(o + (size_t)by * a.bw[c] + bx) = v4;
+    } else if (nb == 2 && !(al & 7)) {
+        const u32x2 v2 = {i, i};
+        *(u32x2 *)o = v2;
+        *(u32x2 *)(o + a.bw[c]) = v2;
+    } else {
+        for (int by = 0; by < nb; by++)
+            for (int bx = 0; bx < nb; bx++) o[(size_t)by * a.bw[c] + bx] = (int32_t)i;
+    }
     const ffhip_hevc_tu tp = a.tus[i ? i - 1 : 0];
     const bool starts = i == 0 || win_of(a, t) != win_of(a, tp);
     a.start[i] = starts ? 1u : 0u;
@@ -214,14 +231,18 @@ __global__ __launch_bounds__(256) void k_plan_owner(PlanArgs a)
  * gets depth 0 at every tile's first cell, which is the point of computing depths instead of using x + 2y itself. */
 #define CELLS_LDS 114688
 #define DEPTH_ROWS 1024 /* rows of cells one lane set covers per pass */
+#define DEPTH_SKEW 16
+#define DEPTH_RING 64
 template <bool FAST> /* FAST: every plane's edge bits fit the LDS form and no plane is taller than one band -- then the sweep has no LOAD from
                         memory in it, and nothing makes a step wait for the result store of the step before (one counter serves loads and
                         stores: with the slow paths' loads in the same loop every diagonal waited ~0.5 us for its own store) */
 __global__ __launch_bounds__(1024) void k_plan_cell_depth(PlanArgs a)
 {
     if (a.result[6]) return; /* the list was refused by k_hevc_check_tus */
+    __builtin_amdgcn_s_setprio(3); /* three workgroups next to the side stream's thousands of waves: first in line at the issue arbiter */
     __shared__ unsigned char el[CELLS_LDS / 2];
     __shared__ unsigned short ring[4][DEPTH_ROWS];
+    unsigned short (*edge)[DEPTH_RING] = (unsigned short (*)[DEPTH_RING]) & ring[0][0]; /* the FAST sweep's use of the same LDS: [wave][diagonal mod DEPTH_RING] */
     const int c = blockIdx.x;
     const uint32_t gw = a.cgw[c], gh = a.cgh[c], cnt = gw * gh;
     if (cnt == 0) return;
@@ -230,38 +251,64 @@ __global__ __launch_bounds__(1024) void k_plan_cell_depth(PlanArgs a)
     const uint32_t *eg = a.cell_edges + a.cell_off[c];
     const bool one_wave = blockDim.x == 64;
     if (lds) {
+        /* (the FAST form is launched with 1024 threads whatever the plane's height: 192 threads fetching the 69 120 cells of an eight-picture
+         * grid two at a time WERE most of the kernel -- 0.2 ms; the waves the sweep has no rows for leave behind the barrier below) */
 #pragma unroll 4
-        for (uint32_t k = threadIdx.x; 2 * k < cnt; k += blockDim.x)
-            el[k] = (unsigned char)((eg[2 * k] & 15u) | (2 * k + 1 < cnt ? (eg[2 * k + 1] & 15u) << 4 : 0u));
+        for (uint32_t k = threadIdx.x; 2 * k < cnt; k += blockDim.x) {
+            uint32_t nib[2];
+#pragma unroll
+            for (uint32_t h = 0; h < 2; h++) { /* bit 0 left, 1 above, 2 above-left, 3 above-right: not where the plane has no such cell */
+                const uint32_t kk = 2 * k + h, cy = kk / gw, cx = kk - cy * gw;
+                const uint32_t keep = (cx > 0 ? 5u : 0u) | (cy > 0 ? 2u : 0u) | ((cy > 0 && cx + 1 < gw) ? 8u : 0u);
+                const uint32_t both = (cx > 0 && cy > 0) ? 4u : 0u;
+                nib[h] = kk < cnt ? eg[kk] & ((keep & ~4u) | both) : 0u;
+            }
+            el[k] = (unsigned char)(nib[0] | (nib[1] << 4));
+        }
     }
     for (uint32_t y = threadIdx.x; y < 4 * DEPTH_ROWS; y += blockDim.x) (&ring[0][0])[y] = 0;
     __syncthreads();
-    if (FAST) { /* a lane per row, a step without a branch: ~40 instructions (what a lone wave pays per instruction and taken branch made the
-                   general loop below 0.47 us a step: 0.36 ms for the 768 diagonals of an eight-picture grid) */
-        const uint32_t yl = threadIdx.x, ym = yl ? yl - 1 : 0, rowbase = yl * gw;
-        const bool row = yl < gh, hu = yl > 0;
-        for (uint32_t K = 0; K <= (gw - 1) + 2 * (gh - 1); K++) {
-            const uint32_t x = K - 2 * yl;          /* wraps far beyond gw where the row has not started */
-            const bool valid = row && x < gw;
-            const uint32_t xc = valid ? x : 0, k = rowbase + xc;
-            const uint32_t e = ((uint32_t)el[k >> 1] >> (4 * (k & 1))) & 15u;
-            const bool hl = xc > 0, hr = hu && xc + 1 < gw;
-            const uint32_t dl_ = ring[(K - 1) & 3][yl], du_ = ring[(K - 2) & 3][ym], dul_ = ring[(K - 3) & 3][ym], dur_ = ring[(K - 1) & 3][ym];
-            uint32_t v = (((e & 1u) != 0) & hl) ? dl_ + 1 : 0u;
-            v = max(v, (((e & 2u) != 0) & hu) ? du_ + 1 : 0u);
-            v = max(v, (((e & 4u) != 0) & hl & hu) ? dul_ + 1 : 0u);
-            v = max(v, (((e & 8u) != 0) & hr) ? dur_ + 1 : 0u);
-            if (valid) {
-                ring[K & 3][yl] = (unsigned short)v;
-                dg[k] = v;
-            }
-            if (one_wave) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            }
+    if (FAST) {
+        /* A lane per row, and NOTHING of the recurrence in memory: a cell's left neighbour is the lane's own value of the step before; the
+         * three above it (above-right, above, above-left: diagonals K - 1, K - 2, K - 3 of the row above) are the value the lane above
+         * computed in the step before -- one DPP move -- and what that move returned one and two steps ago.  Across waves the lane above is
+         * lane 63 of the previous wave: wave w runs DEPTH_SKEW steps behind wave w - 1, takes that lane's values from a ring in LDS, and a
+         * barrier every DEPTH_SKEW steps keeps the distance (a value is read DEPTH_SKEW steps after it was written and overwritten
+         * DEPTH_RING steps after, DEPTH_RING >= 2 DEPTH_SKEW + 2).  A lone wave pays for every instruction it issues, so the step is kept
+         * short: the edge bits a cell cannot have (left of column 0, above row 0, right of the last column) are cleared once, up front;
+         * the bits and the ring value of the NEXT step are fetched during this one; a term is one multiply-add by its bit; the result store
+         * of a lane without a cell is dropped by its buffer offset.  (A ring of four diagonals in LDS and a barrier per step, until late in
+         * round 4: 0.3 us a step, 247 us for the 766 diagonals of an eight-picture grid, 72 us for one picture's 253.) */
+        const uint32_t yl = threadIdx.x, w = yl >> 6, lane = yl & 63, nw = (gh + 63) >> 6;
+        if (w >= nw) return; /* (a wave that has ended is not waited for at a barrier) */
+        const bool row = yl < gh;
+        const uint32_t rowbase = row ? yl * gw : 0u, gwv = row ? gw : 0u; /* a lane beyond the last row never has a cell */
+        const uint32_t iters = (gw - 1) + 2 * (gh - 1) + 1 + (nw - 1) * DEPTH_SKEW;
+        const __amdgpu_buffer_rsrc_t drs = ffhip_rsrc(dg, cnt * 4u);
+        const unsigned short *up_edge = edge[w ? w - 1 : 0];
+        unsigned short *my_edge = edge[w];
+        const bool l0 = lane == 0 && w > 0, l63 = lane == 63 && nw > 1;
+        auto load_e = [&](const uint32_t xx) -> uint32_t {
+            const bool v = xx < gwv;
+            const uint32_t k = rowbase + (v ? xx : 0u);
+            const uint32_t b = (uint32_t)el[k >> 1] >> (4 * (k & 1));
+            return v ? b & 15u : 0u;
+        };
+        uint32_t K = 0u - w * DEPTH_SKEW; /* wraps far beyond every diagonal while the wave has not started */
+        uint32_t x = K - 2 * yl;          /* ... and where the row has not started */
+        uint32_t h1 = 0, n2 = 0, n3 = 0;
+        uint32_t e = load_e(x), ev = up_edge[(K - 1) & (DEPTH_RING - 1)];
+        for (uint32_t T = 0; T < iters; T++) {
+            const uint32_t en = load_e(x + 1), evn = up_edge[K & (DEPTH_RING - 1)];
+            uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h1, 0x138, 0xf, 0xf, false); /* wave_shr:1 -- lane i - 1 */
+            n1 = l0 ? ev : n1;
+            const uint32_t b0 = e & 1u, b1 = (e >> 1) & 1u, b2 = (e >> 2) & 1u, b3 = e >> 3;
+            const uint32_t v = max(max(__umul24(h1, b0) + b0, __umul24(n2, b1) + b1), max(__umul24(n3, b2) + b2, __umul24(n1, b3) + b3));
+            __builtin_amdgcn_raw_buffer_store_b32(v, drs, x < gwv ? 4u * (rowbase + x) : 0x80000000u, 0, 0);
+            if (l63) my_edge[K & (DEPTH_RING - 1)] = (unsigned short)v;
+            n3 = n2; n2 = n1; h1 = v; e = en; ev = evn;
+            x++; K++;
+            if (nw > 1 && ((T + 1) & (DEPTH_SKEW - 1)) == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         return;
     }
@@ -366,7 +413,7 @@ __global__ __launch_bounds__(256) void k_plan_cell_base(PlanArgs a)
     const uint32_t key = nr ? plan_cell_key(a, c) : 0u;
     uint32_t grant = 0;
     const uint32_t before = plan_wave_add<true>(a.fill, key, nr, &grant);
-    if (nr) a.cell_base[c] = a.hist[key] + grant + before;
+    if (nr) a.cell_base[c] = a.hist_pre[key] + grant + before;
 }
 __global__ __launch_bounds__(256) void k_plan_rank(PlanArgs a, uint32_t m)
 {
@@ -390,34 +437,50 @@ __global__ __launch_bounds__(256) void k_plan_rank(PlanArgs a, uint32_t m)
  * returns whether every neighbour inside the TU's window belongs to its own run (then the grouped kernel may take them from its LDS tile).
  * A neighbouring TU covers a contiguous stretch of the row above or of the column to the left, so its blocks follow each other there: "same as
  * the one before" removes every repeat, the corner TU reaching into the row or the column included (it would be their first entry).  No TU can
- * be above AND left of another.  (Until round 4 the two edges were walked in step and repeats were found by searching an array of up to 66
- * entries -- 272 bytes of scratch memory per lane, written and re-read through memory.) */
+ * be above AND left of another.
+ * "Of my own run" is decided WITHOUT the neighbour's run id: a plan is only accepted when every window has ONE run (k_plan_count refuses the
+ * list otherwise and the serial kernel, which takes every neighbour from memory, decodes it), TUs are aligned to their size and so lie inside
+ * one window or cover whole windows -- an earlier TU is of my run exactly when its block lies in my window.  And the owners of all edge blocks
+ * are loaded up front, into registers: with a conditional atomic and a record load between one block's owner and the next the loads went out one
+ * at a time -- up to 33 trips to the L2 per TU, and a second one each for the run id: 0.39 ms for the 1.84 M TUs of an eight-picture grid. */
 template <class F>
 __device__ __forceinline__ bool for_each_dep(const PlanArgs &a, const uint32_t i, const ffhip_hevc_tu &t, F &&f)
 {
     const int c = t.cidx, n = 1 << t.log2_size, wl = a.wl[c];
-    const uint32_t run = a.runid[i];
     const int wx0 = (t.x >> wl) << wl, wy0 = (t.y >> wl) << wl, wsz = 1 << wl;
+    const int bwc = a.bw[c];
     const int32_t *own = a.owner + a.owner_off[c];
+    const int32_t *up = own + (ptrdiff_t)((t.y >> 2) - 1) * bwc + (t.x >> 2);   /* the block row above, from my first column */
+    const int32_t *lf = own + (ptrdiff_t)(t.y >> 2) * bwc + (t.x >> 2) - 1;     /* the block column to the left, from my first row */
+    int32_t jc = -1, jt[16], jl[16];
+    if (t.flags & 1) jc = up[-1];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const bool in = 4 * k < 2 * n;
+        jt[k] = (in && ((t.avail_top >> (4 * k)) & 0xf)) ? up[k] : -2;
+        jl[k] = (in && ((t.avail_left >> (4 * k)) & 0xf)) ? lf[(ptrdiff_t)k * bwc] : -2;
+    }
     bool ok = true;
     int32_t corner = -1, last;
-    auto dep = [&](int px, int py) {
-        int32_t j = own[(size_t)(py >> 2) * a.bw[c] + (px >> 2)];
+    auto dep = [&](int32_t j, const int px, const int py) {
         if (j >= (int32_t)i) j = -1; /* stamped by a later TU: held older content when the sequential decoder looked */
-        const bool mine = j >= 0 && a.runid[j] == run;
-        if (j >= 0 && !mine && j != last && j != corner) f((uint32_t)j);
-        if (j >= 0 && !mine) last = j;
-        if (!mine && px >= wx0 && px < wx0 + wsz && py >= wy0 && py < wy0 + wsz) ok = false;
-        return (j >= 0 && !mine) ? j : -1;
+        const bool inwin = px >= wx0 && px < wx0 + wsz && py >= wy0 && py < wy0 + wsz;
+        const bool other = j >= 0 && !inwin;
+        if (other && j != last && j != corner) f((uint32_t)j);
+        if (other) last = j;
+        if (inwin && j < 0) ok = false;
+        return other ? j : -1;
     };
     last = -1;
-    if (t.flags & 1) corner = dep(t.x - 1, t.y - 1);
+    if (t.flags & 1) corner = dep(jc, t.x - 1, t.y - 1);
     last = -1;
-    for (int k = 0; k < 2 * n; k += 4)
-        if ((t.avail_top >> k) & 0xf) dep(t.x + k, t.y - 1);
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (jt[k] != -2) dep(jt[k], t.x + 4 * k, t.y - 1);
     last = -1;
-    for (int k = 0; k < 2 * n; k += 4)
-        if ((t.avail_left >> k) & 0xf) dep(t.x - 1, t.y + k);
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (jl[k] != -2) dep(jl[k], t.x - 1, t.y + 4 * k);
     return ok;
 }
 
@@ -535,7 +598,7 @@ __global__ __launch_bounds__(256) void k_plan_runid(PlanArgs a)
     const unsigned long long b = __builtin_amdgcn_ballot_w64(st);
     if (lane == 0) wtot[w] = (uint32_t)__popcll(b);
     __syncthreads();
-    uint32_t before = a.blk_tot[blockIdx.x];
+    uint32_t before = a.blk_pre[blockIdx.x];
     for (int k = 0; k < w; k++) before += wtot[k];
     const uint32_t incl = (uint32_t)__popcll(b & ((2ull << lane) - 1ull));
     if (i < a.n) a.runid[i] = before + incl - 1u;
@@ -643,6 +706,8 @@ static PlanLayout plan_layout(PlanArgs &a, uint32_t *base, const ffhip_hevc_tu *
     a.cell_base = p; p += cells;
     a.rank_of = p; p += n;
     a.blk_tot = p; p += L.n_blocks + 1;
+    a.blk_pre = p; p += L.n_blocks + 1;
+    a.hist_pre = p; p += hwords;
     L.words = (size_t)(p - base) + 8;
     return L;
 }
@@ -660,13 +725,14 @@ extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long
                                            uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
                                            int *n_groups, const uint32_t **d_result, uint32_t *wait_cap_out, const int *check /* NULL, or {chroma_ok,
                                            have_residual} */, int *async_err, int (*after_check)(void *, const uint32_t *),
-                                           int (*after_count)(void *, const uint8_t *, const uint32_t *, const uint32_t *), void *hook_ctx);
+                                           int (*after_count)(void *, const uint8_t *, const uint32_t *, const uint32_t *), void *hook_ctx, uint32_t *also_zero,
+                                           size_t also_zero_words);
 extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, const int pw[3], const int ph[3], const int wl[3],
                                    uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
                                    int *n_groups, const uint32_t **d_result, uint32_t *wait_cap_out)
 {
     return ffhip_hevc_plan_gpu_checked(d_tus, n_tus, pw, ph, wl, scratch, st, sched, groups, wait_idx, n_groups, d_result, wait_cap_out, nullptr, nullptr,
-                                       nullptr, nullptr, nullptr);
+                                       nullptr, nullptr, nullptr, nullptr, 0);
 }
 /* ... with the list's validation as the first kernel behind the scratch's reset (check != NULL), a hook that runs once that kernel is
  * enqueued: what the caller starts from there (the substitution table on a side stream) may rely on result[6], handed to the hook; and a
@@ -676,7 +742,8 @@ extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long
                                            uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
                                            int *n_groups, const uint32_t **d_result, uint32_t *wait_cap_out, const int *check, int *async_err,
                                            int (*after_check)(void *, const uint32_t *),
-                                           int (*after_count)(void *, const uint8_t *, const uint32_t *, const uint32_t *), void *hook_ctx)
+                                           int (*after_count)(void *, const uint8_t *, const uint32_t *, const uint32_t *), void *hook_ctx, uint32_t *also_zero /* a region of the
+                                           caller's (the grouped kernel's ticket counter and done flags), cleared by the same launch */, size_t also_zero_words)
 {
     PlanArgs a;
     const PlanLayout Lo = plan_layout(a, scratch, d_tus, n_tus, pw, ph, wl);
@@ -690,10 +757,11 @@ extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long
         in.p[1] = (uint32_t *)a.flags; in.words[1] = (n + 3) / 4 + 4 + 16; in.value[1] = 0u;
         in.p[2] = a.cell_claim; in.words[2] = cells; in.value[2] = ~0u;
         in.p[3] = Lo.zero_cells; in.words[3] = Lo.zero_cells_words; in.value[3] = 0u;
+        in.p[4] = also_zero; in.words[4] = also_zero ? also_zero_words : 0; in.value[4] = 0u;
         size_t most = 0;
-        for (int r = 0; r < 4; r++) most = in.words[r] > most ? in.words[r] : most;
+        for (int r = 0; r < 5; r++) most = in.words[r] > most ? in.words[r] : most;
         const size_t wg = (most / 4 + 255) / 256 + 1;
-        hipLaunchKernelGGL(k_plan_init, dim3((unsigned)(wg > 4096 ? 4096 : wg), 4), dim3(256), 0, st, in);
+        hipLaunchKernelGGL(k_plan_init, dim3((unsigned)(wg > 4096 ? 4096 : wg), also_zero ? 5 : 4), dim3(256), 0, st, in);
     }
     const unsigned grid = (unsigned)Lo.n_blocks;
     if (check && async_err) {
@@ -707,7 +775,8 @@ extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long
         if (hrc) return hrc;
     }
     hipLaunchKernelGGL(k_plan_owner, dim3(grid), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, a.blk_tot, (uint32_t)Lo.n_blocks, (uint32_t *)nullptr, 0u, (const uint32_t *)(a.result + 6));
+    hipLaunchKernelGGL(k_plan_scan, dim3((unsigned)((Lo.n_blocks + 4095) / 4096)), dim3(1024), 0, st, (const uint32_t *)a.blk_tot, a.blk_pre, (uint32_t)Lo.n_blocks, (uint32_t *)nullptr, 0u,
+                       (const uint32_t *)(a.result + 6));
     hipLaunchKernelGGL(k_plan_runid, dim3(grid), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_plan_count, dim3(grid), dim3(256), 0, st, a);
     if (after_count) {
@@ -723,13 +792,14 @@ extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long
         const unsigned threads = max_gh >= 1024 ? 1024u : (unsigned)((max_gh + 63) / 64 * 64);
         bool fast = max_gh <= DEPTH_ROWS;
         for (int c = 0; c < 3; c++) fast = fast && (size_t)a.cgw[c] * a.cgh[c] <= CELLS_LDS;
-        if (fast) hipLaunchKernelGGL(k_plan_cell_depth<true>, dim3(3), dim3(threads ? threads : 64u), 0, st, a);
+        if (fast) hipLaunchKernelGGL(k_plan_cell_depth<true>, dim3(3), dim3(1024), 0, st, a);
         else hipLaunchKernelGGL(k_plan_cell_depth<false>, dim3(3), dim3(threads ? threads : 64u), 0, st, a);
     }
     const size_t m = n < wins ? n : wins; /* runs <= windows, or the plan is refused (k_plan_count: a window with two runs) */
     const unsigned cgrid = (unsigned)((cells + 255) / 256);
     hipLaunchKernelGGL(k_plan_cell_hist, dim3(cgrid), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, a.hist, (uint32_t)(a.depths << a.shard_log2), a.result + 4, a.shard_log2, (const uint32_t *)(a.result + 3));
+    hipLaunchKernelGGL(k_plan_scan, dim3((unsigned)((((size_t)a.depths << a.shard_log2) + 4095) / 4096)), dim3(1024), 0, st, (const uint32_t *)a.hist, a.hist_pre,
+                       (uint32_t)(a.depths << a.shard_log2), a.result + 4, a.shard_log2, (const uint32_t *)(a.result + 3));
     hipLaunchKernelGGL(k_plan_cell_base, dim3(cgrid), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_plan_rank, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a, (uint32_t)m);
     hipLaunchKernelGGL(k_plan_emit, dim3(grid), dim3(256), 0, st, a, (uint32_t)m);

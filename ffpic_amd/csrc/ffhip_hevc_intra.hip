@@ -728,12 +728,12 @@ __device__ __forceinline__ void intra_tu_g(const HotArgs &a, const GroupCtx &g, 
 #define PK_LG3 8u
 #define PK_RES 16u
 #define PK_OUTSIDE 32u
-#define PK_SIGNAL 64u
-#define PK_WAIT 128u
+#define PK_SIGNAL FFHIP_PK_SIGNAL
+#define PK_WAIT FFHIP_PK_WAIT
 #define PK_FILTER 1024u /* 8x8 program with neighbour smoothing: the words' fourth field is the lane's scan position source */
 #define PK_END 512u /* the sentinel behind a chunk's last slot */
-#define PK_SLOW 256u /* anything but a plain program: generic TU, a wait, halo cells */
-#define PROG_NO_RESIDUAL 0xffffff00u /* res_off of a TU without residual = size of the residual buffer resource: reads 0 */
+#define PK_SLOW FFHIP_PK_SLOW /* anything but a plain program: generic TU, a wait, halo cells */
+#define PROG_NO_RESIDUAL FFHIP_PROG_NO_RESIDUAL /* res_off of a TU without residual = size of the residual buffer resource: reads 0 */
 struct ProgSlot {
     unsigned packed;    /* kind, flags above, bits 31:16 = LDS byte address of the TU's first sample in the tile */
     unsigned res_off;   /* byte offset of the residual block                                                     */
@@ -834,33 +834,48 @@ struct ProgArgs {
     const uint32_t *wcount;
     int jt_bw[3];
     uint32_t jt_boff[3];
+    const uint32_t *refused; /* NULL, or the word k_hevc_check_tus sets for a list with a bad record (then the records' positions mean nothing) */
+    const ffhip_hevc_tu *records; /* the TU list, always (a slot's third quarter names its TU): the availability masks are read from it */
 };
-/* The program of ONE slot, by one wave (k is wave-uniform; the caller has found the slot eligible: 4x4 / 8x8, LDS tile allowed, no rdpcm /
- * cross-component residual).  Everything that differs from lane to lane is a SELECT, never a branch: the kernel was bound by the scalar
- * unit -- 286 scalar instructions per slot, most of them the exec-mask bookkeeping of per-lane ifs around the table reads (252 M of them
- * for the 1.84 M slots of an eight-picture grid, at one per cycle and CU: 0.47 ms) -- so a table read that a lane does not need is made
- * anyway, at position 0, and its answer dropped; on a 4x4 slot lanes 16 .. 63 do what lanes 0 .. 15 do (same words to the same addresses).
- * What IS the same for all lanes (the mode's kind, the smoothing) stays a scalar branch. */
-__device__ __forceinline__ void intra_program_slot(const ProgArgs &a, const uint32_t k, const int lane, const u32x4 q0, const u32x4 q2)
+/* The program of ONE slot, by one wave.  Everything that differs from lane to lane is a SELECT, never a branch: the kernel was bound by
+ * the scalar unit -- 286 scalar instructions per slot, most of them the exec-mask bookkeeping of per-lane ifs around the table reads
+ * (252 M of them for the 1.84 M slots of an eight-picture grid, at one per cycle and CU: 0.47 ms) -- so a table read that a lane does not
+ * need is made anyway, at position 0, and its answer dropped; on a 4x4 slot lanes 16 .. 63 do what lanes 0 .. 15 do (same words to the
+ * same addresses).  What IS the same for all lanes (the mode's kind, the smoothing) stays a scalar branch, and what is the same for the
+ * whole SLOT -- decoding the record, the angle tables, the window, where the slot's words go -- is not worked out here at all: the lane
+ * that owns the slot has done that for its slot in the vector unit, 64 slots at a time (SlotPre), and the wave picks it up by readlane.
+ * Returns the slot's verdict: bit 0 = every source has a cell in the tile layout (else the generic body), bit 1 = a source lies outside
+ * the window (halo). */
+struct SlotPre {
+    uint32_t p0;      /* x0 | y0 << 16 */
+    uint32_t p1;      /* bit 0: 8x8; 1-2: plane; 3-8: mode; 9: smoothing; 10: DC boundary filter; 11: modes 10 / 26 with theirs; 12-14: log2 of the window; 15: scan position 32 is available */
+    uint32_t p2;      /* intraPredAngle + 32 | -invAngle << 8 */
+    uint32_t m_lo;    /* availability of scan positions 0 .. 31 (left column bottom-up, corner, top row), position 32 in bit 15 of p1 */
+    uint32_t d_first; /* index of the TU's first pixel words */
+};
+__device__ __forceinline__ unsigned intra_program_slot(const ProgArgs &a, const int lane, const uint32_t P0, const uint32_t P1, const uint32_t P2,
+                                                       const uint32_t M_LO, const uint32_t DF)
 {
-    const u32x4 generic = {PK_SLOW, PROG_NO_RESIDUAL, 0u, 0u};
-    const int x0 = (int)(q0.x & 0xffff), y0 = (int)(q0.x >> 16);
-    const int lg = (int)(q0.y & 0xff), cidx = (int)((q0.y >> 8) & 0xff), mode = (int)((q0.y >> 16) & 0xff), flags = (int)(q0.y >> 24);
-    const int n = 1 << lg, wl = a.wl[cidx], wsz = 1 << wl;
-    bool filt = false; /* neighbour smoothing applies (8.4.4.2.3; at 8x8: planar and modes 2, 18, 34): the taps read the smoothed copy */
-    if ((flags & 4) && mode != 1 && n != 4) {
-        const int d26 = iabs(mode - 26), d10 = iabs(mode - 10);
-        filt = (d26 < d10 ? d26 : d10) > 7;
-    }
+    const int x0 = (int)(P0 & 0xffff), y0 = (int)(P0 >> 16);
+    const int lg = 2 + (int)(P1 & 1u), cidx = (int)((P1 >> 1) & 3u), mode = (int)((P1 >> 3) & 63u);
+    const bool filt = (P1 >> 9) & 1u, edge_dc = (P1 >> 10) & 1u, edge_tu = (P1 >> 11) & 1u;
+    const int n = 1 << lg, wl = (int)((P1 >> 12) & 7u), wsz = 1 << wl;
     const int wx0 = (x0 >> wl) << wl, wy0 = (y0 >> wl) << wl;
-    const uint8_t *jt = a.jt + q2.w;
+    const uint32_t m_hi = (P1 >> 15) & 1u;
+    const bool none = (M_LO | m_hi) == 0;                       /* nothing around the TU is available (the whole slot: a scalar) */
+    const int first = M_LO ? __builtin_ctz(M_LO) : 32;           /* the first available scan position */
     const unsigned cconst = 2u * (cidx == 0 ? TILE_CONST_Y : TILE_CONST_C);
     bool ok = true, outside = false;
     /* LDS byte address of the sample scan position pos takes; a lane that does not `use` the answer reads position 0 and leaves the slot's
      * verdicts (ok, outside) alone */
+    /* ... the substitution of 8.4.4.2.2 worked out here, from the availability bits: "the nearest available position at or before mine, else
+     * the first available one" -- seven vector instructions where a byte of the substitution table was a trip to memory in front of every
+     * program (the kernel waited 68 % of its wave cycles for those bytes once the scalar work was gone) */
     auto src_cell = [&](const int pos, const bool use) -> unsigned {
-        const int j = (int)jt[use ? pos : 0];
-        const bool none = j == 255;
+        const uint32_t upto = pos >= 31 ? ~0u : (2u << pos) - 1u;
+        const uint32_t mm = M_LO & upto;
+        const int jn = mm ? 31 - __builtin_clz(mm) : first;
+        const int j = (pos >= 32 && m_hi) ? 32 : jn;
         const int py = y0 - 1 + max(2 * n - j, 0), px = x0 - 1 + max(j - 2 * n, 0); /* j < 2n: the left column, bottom-up; j > 2n: the top row */
         const int tx = px - wx0 + 1, ty = py - wy0 + 1;
         const bool out = ((unsigned)(tx - 1) >= (unsigned)wsz) | ((unsigned)(ty - 1) >= (unsigned)wsz);
@@ -880,22 +895,17 @@ __device__ __forceinline__ void intra_program_slot(const ProgArgs &a, const uint
 #define POS_TOP(xx) (2 * n + 1 + (xx))
     const int le = lane & (n * n - 1); /* the pixel this lane works for */
     const int x = le & (n - 1), y = le >> lg;
-    unsigned w0 = 0, w1 = 0, w2 = 0, w3 = 0, kind;
-    const bool edge_ok = cidx == 0; /* n < 32 here */
+    unsigned w0 = 0, w1 = 0, w2 = 0, w3 = 0;
     if (mode == 0) {
-        kind = PROG_PLANAR;
         if (!filt) { w0 = cell(POS_LEFT(y), true); w1 = cell(POS_TOP(x), true); w2 = cell(POS_TOP(n), true); w3 = cell(POS_LEFT(n), true); }
     } else if (mode == 1) {
-        kind = PROG_DC;
         w0 = cell(POS_LEFT(y), true); w1 = cell(POS_TOP(x), true);
         const bool sum_lane = le < 2 * n; /* lanes 0 .. 2n - 1 hold the 2n samples the sum runs over */
         const unsigned ws = cell(le < n ? POS_LEFT(le) : POS_TOP(le - n), sum_lane);
         w2 = sum_lane ? ws : 2u * TILE_ZERO;
-        if (edge_ok && !(flags & 0x20)) w3 = (x == 0 && y == 0) ? 1u : (y == 0 ? 2u : (x == 0 ? 3u : 0u));
+        if (edge_dc) w3 = (x == 0 && y == 0) ? 1u : (y == 0 ? 2u : (x == 0 ? 3u : 0u));
     } else {
-        const bool edge_tu = edge_ok && !(flags & 0x10) && (mode == 26 || mode == 10);
-        kind = edge_tu ? PROG_ANGULAR_EDGE : PROG_ANGULAR;
-        const int angle = intra_angle(mode), inv = angle < 0 ? intra_inv_angle(mode) : 0, sg = mode >= 18 ? 1 : -1;
+        const int angle = (int)(P2 & 0xffu) - 32, inv = -(int)(P2 >> 8), sg = mode >= 18 ? 1 : -1;
         const int al = mode >= 18 ? y : x, ac = mode >= 18 ? x : y;
         const int prod = (al + 1) * angle, idx = prod >> 5, fact = prod & 31;
         const int k0 = ac + idx + 1, k1 = k0 + 1;
@@ -921,28 +931,18 @@ __device__ __forceinline__ void intra_program_slot(const ProgArgs &a, const uint
         const unsigned wf = src_cell(lane, fl);
         w3 = fl ? wf : w3;
     }
-    const unsigned long long any_out = __builtin_amdgcn_ballot_w64(outside);
-    if (__builtin_amdgcn_ballot_w64(!ok)) { /* a neighbour the tile layout has no cell for: the generic body */
-        if (lane == 0) a.sched[(size_t)k * 3 + 1] = generic;
-        return;
+    const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0, any_out = __builtin_amdgcn_ballot_w64(outside) != 0;
+    if (all_ok) {
+        const int dw = cidx == 0 ? a.desc_w[0] : (cidx == 1 ? a.desc_w[1] : a.desc_w[2]);
+        a.desc[DF + (uint32_t)y * (uint32_t)dw + (uint32_t)x] = make_uint2(w0 | (w1 << 16), w2 | (w3 << 16));
     }
-    const uint32_t d_first = a.desc_off[cidx] + (uint32_t)y0 * (uint32_t)a.desc_w[cidx] + (uint32_t)x0;
-    a.desc[d_first + (uint32_t)y * (uint32_t)a.desc_w[cidx] + (uint32_t)x] = make_uint2(w0 | (w1 << 16), w2 | (w3 << 16));
-    if (lane == 0) {
-        u32x4 q1;
-        q1.x = kind | (lg == 3 ? PK_LG3 : 0u) | (filt ? PK_FILTER : 0u) | ((flags & 2) ? PK_RES : 0u) | (any_out ? PK_OUTSIDE : 0u) | (((q2.y >> 8) & 1) ? PK_SIGNAL : 0u) |
-               ((q2.y & 0xff) ? PK_WAIT : 0u) | ((uint32_t)(2 * (TILE_ORIGIN + (y0 - wy0) * TILE_STRIDE + (x0 - wx0))) << 16);
-        if (q1.x & (PK_OUTSIDE | PK_WAIT)) q1.x |= PK_SLOW;
-        q1.y = (flags & 2) ? q0.z * 2u : PROG_NO_RESIDUAL;
-        q1.z = d_first * 8u;
-        q1.w = (uint32_t)(y0 * a.stride[cidx] + x0) * 2u;
-        a.sched[(size_t)k * 3 + 1] = q1;
-    }
+    return (all_ok ? 1u : 0u) | (any_out ? 2u : 0u);
 }
 
 /* A wave takes 64 consecutive slots: every lane decides for ITS slot whether it can be a program at all -- the answer is no for
  * the TUs above 8x8, rdpcm / cross-component TUs and TUs whose in-window neighbours another group wrote, i.e. for most of a
- * config-5 list -- and marks the others generic; then the wave builds the programs of the slots that remain, one after the other.
+ * config-5 list -- and prepares what its slot's program needs (SlotPre, and the slot's program words but for the two bits the program
+ * itself decides); then the wave builds the programs of the slots that remain, one after the other, and every lane writes its slot's words.
  * (One wave per slot, as before round 3, was bound by the rate waves can be started at: 0.75 ms for the 1.84 M slots of an
  * eight-picture grid, most of which left after reading two dwords.) */
 __global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
@@ -950,41 +950,82 @@ __global__ __launch_bounds__(256) void k_hevc_intra_program(ProgArgs a)
     const int lane = threadIdx.x & 63;
     const uint32_t base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64u;
     if (base >= a.n_slots) return;
-    if (a.plan_result && (a.plan_result[0] | (a.plan_result[2] > a.wait_cap ? 1u : 0u))) return; /* refused plan: the slots mean nothing (early form: refused
-                                                                                                       SO FAR -- a list refused later has its programs built for nothing) */
+    if (a.plan_result && (a.plan_result[0] | (a.plan_result[2] > a.wait_cap ? 1u : 0u))) return; /* refused plan: the slots mean nothing */
+    if (a.refused && *a.refused) return;
     const uint32_t k = base + (uint32_t)lane;
     bool prog = false;
+    SlotPre sp = {0u, 0u, 0u, 0u, 0u};
+    u32x4 q1 = {PK_SLOW, PROG_NO_RESIDUAL, 0u, 0u}; /* the generic body */
     u32x4 q0 = {0, 0, 0, 0}, q2 = {0, 0, 0, 0};
     if (k < a.n_slots) {
         if (a.tus) {
             q0 = ((const u32x4 *)(a.tus + k))[0];
             const uint32_t f = a.flags[k], cidx = (q0.y >> 8) & 0xff;
+            const uint32_t jb = cidx == 0 ? a.jt_boff[0] : (cidx == 1 ? a.jt_boff[1] : a.jt_boff[2]);
+            const uint32_t jw = (uint32_t)(cidx == 0 ? a.jt_bw[0] : (cidx == 1 ? a.jt_bw[1] : a.jt_bw[2]));
             q2.y = a.wcount[k] | ((f & 1u) << 8) | (((f >> 1) & 1u) << 9);
             q2.z = k;
-            q2.w = (a.jt_boff[cidx] + (q0.x >> 18) * (uint32_t)a.jt_bw[cidx] + ((q0.x & 0xffffu) >> 2)) * JT_STRIDE;
+            q2.w = (jb + (q0.x >> 18) * jw + ((q0.x & 0xffffu) >> 2)) * JT_STRIDE;
         } else {
             q0 = a.sched[(size_t)k * 3]; q2 = a.sched[(size_t)k * 3 + 2];
         }
-        const int lg = (int)(q0.y & 0xff), cidx = (int)((q0.y >> 8) & 0xff), flags = (int)(q0.y >> 24);
-        prog = lg <= 3 && (1 << lg) <= (1 << a.wl[cidx]) && ((q2.y >> 9) & 1) && !(flags & 0xC0) && q0.z < 0x7fff0000u;
-        if (!prog) {
-            const u32x4 generic = {PK_SLOW, PROG_NO_RESIDUAL, 0u, 0u};
-            a.sched[(size_t)k * 3 + 1] = generic;
+    }
+    {
+        const int x0 = (int)(q0.x & 0xffff), y0 = (int)(q0.x >> 16);
+        const int lg = (int)(q0.y & 0xff), cidx = (int)((q0.y >> 8) & 0xff), mode = (int)((q0.y >> 16) & 0xff), flags = (int)(q0.y >> 24);
+        const int wl = cidx == 0 ? a.wl[0] : (cidx == 1 ? a.wl[1] : a.wl[2]);
+        const int n = 1 << lg;
+        prog = k < a.n_slots && lg <= 3 && lg >= 2 && n <= (1 << wl) && ((q2.y >> 9) & 1) && !(flags & 0xC0) && q0.z < 0x7fff0000u && cidx <= 2;
+        bool filt = false; /* neighbour smoothing applies (8.4.4.2.3; at 8x8: planar and modes 2, 18, 34): the taps read the smoothed copy */
+        {
+            const int d26 = iabs(mode - 26), d10 = iabs(mode - 10);
+            filt = (flags & 4) && mode != 1 && n != 4 && (d26 < d10 ? d26 : d10) > 7;
+        }
+        const bool edge_ok = cidx == 0; /* n < 32 here */
+        const bool edge_dc = edge_ok && !(flags & 0x20), edge_tu = edge_ok && !(flags & 0x10) && (mode == 26 || mode == 10);
+        const bool ang = mode >= 2 && mode <= 34;
+        const int angle = ang ? intra_angle(mode) : 0, inv = (ang && angle < 0) ? intra_inv_angle(mode) : 0;
+        const int wx0 = (x0 >> wl) << wl, wy0 = (y0 >> wl) << wl;
+        const uint32_t doff = cidx == 0 ? a.desc_off[0] : (cidx == 1 ? a.desc_off[1] : a.desc_off[2]);
+        const int dw = cidx == 0 ? a.desc_w[0] : (cidx == 1 ? a.desc_w[1] : a.desc_w[2]);
+        const int stride = cidx == 0 ? a.stride[0] : (cidx == 1 ? a.stride[1] : a.stride[2]);
+        sp.p0 = q0.x;
+        sp.p1 = (lg == 3 ? 1u : 0u) | ((uint32_t)cidx << 1) | ((uint32_t)(mode & 63) << 3) | (filt ? 1u << 9 : 0u) | (edge_dc ? 1u << 10 : 0u) | (edge_tu ? 1u << 11 : 0u) |
+                ((uint32_t)(wl & 7) << 12);
+        sp.p2 = (uint32_t)(angle + 32) | ((uint32_t)(-inv) << 8);
+        {   /* availability by scan position, as k_hevc_intra_jtable lays it out: left column bottom-up (bit i = left[2n - 1 - i]), corner, top row */
+            u32x4 av = {0u, 0u, 0u, 0u};
+            if (prog) av = ((const u32x4 *)(a.records + q2.z))[1];
+            const unsigned long long avail_top = (unsigned long long)av.x | ((unsigned long long)av.y << 32), avail_left = (unsigned long long)av.z | ((unsigned long long)av.w << 32);
+            const int n2 = prog ? 2 * n : 8;
+            const unsigned long long m0 = (__brevll(avail_left) >> (64 - n2)) | ((unsigned long long)(flags & 1) << n2) | ((avail_top & ((1ull << n2) - 1)) << (n2 + 1));
+            sp.m_lo = (uint32_t)m0;
+            sp.p1 |= (uint32_t)((m0 >> 32) & 1ull) << 15;
+        }
+        sp.d_first = doff + (uint32_t)y0 * (uint32_t)dw + (uint32_t)x0;
+        if (prog) {
+            const unsigned kind = mode == 0 ? PROG_PLANAR : (mode == 1 ? PROG_DC : (edge_tu ? PROG_ANGULAR_EDGE : PROG_ANGULAR));
+            q1.x = kind | (lg == 3 ? PK_LG3 : 0u) | (filt ? PK_FILTER : 0u) | ((flags & 2) ? PK_RES : 0u) | (((q2.y >> 8) & 1) ? PK_SIGNAL : 0u) |
+                   ((q2.y & 0xff) ? (PK_WAIT | PK_SLOW) : 0u) | ((uint32_t)(2 * (TILE_ORIGIN + (y0 - wy0) * TILE_STRIDE + (x0 - wx0))) << 16);
+            q1.y = (flags & 2) ? q0.z * 2u : PROG_NO_RESIDUAL;
+            q1.z = sp.d_first * 8u;
+            q1.w = (uint32_t)(y0 * stride + x0) * 2u;
         }
     }
     unsigned long long todo = __builtin_amdgcn_ballot_w64(prog);
+    unsigned verdict = 1u; /* of MY slot: bit 0 = stays a program, bit 1 = reads halo cells */
     while (todo) {
         const int b = __builtin_ctzll(todo);
         todo &= todo - 1;
-        /* the slot's two quarters come from the lane that loaded them: read again by the whole wave they were a trip to memory per program,
-         * in front of the trip for the substitution table's bytes */
-        u32x4 b0, b2;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            b0[e] = (uint32_t)__builtin_amdgcn_readlane((int)q0[e], b);
-            b2[e] = (uint32_t)__builtin_amdgcn_readlane((int)q2[e], b);
-        }
-        intra_program_slot(a, base + (uint32_t)b, lane, b0, b2);
+        const unsigned r = intra_program_slot(a, lane, (uint32_t)__builtin_amdgcn_readlane((int)sp.p0, b), (uint32_t)__builtin_amdgcn_readlane((int)sp.p1, b),
+                                              (uint32_t)__builtin_amdgcn_readlane((int)sp.p2, b), (uint32_t)__builtin_amdgcn_readlane((int)sp.m_lo, b),
+                                              (uint32_t)__builtin_amdgcn_readlane((int)sp.d_first, b));
+        verdict = lane == b ? r : verdict;
+    }
+    if (k < a.n_slots) {
+        const u32x4 generic = {PK_SLOW, PROG_NO_RESIDUAL, 0u, 0u};
+        if (prog && (verdict & 2u)) q1.x |= PK_OUTSIDE | PK_SLOW;
+        a.sched[(size_t)k * 3 + 1] = (prog && (verdict & 1u)) ? q1 : generic;
     }
 }
 
@@ -1012,59 +1053,45 @@ struct JTabArgs {
     uint32_t boff[3];
     const uint32_t *refused; /* NULL, or the word k_hevc_check_tus sets for a list with a bad record (then the records' positions mean nothing) */
 };
-#define JT_TUS_PER_WAVE 64 /* a wave takes 64 consecutive TUs: every lane LOADS one record (one trip to memory for the wave), then the wave builds the
-                              tables one after the other from records passed round by readlane.  (A wave per TU was bound by the rate waves start at; four
-                              TUs per wave, each loaded when its turn came, by four trips to memory in a row: 0.29 ms for the 1.84 M TUs of an eight-picture
-                              grid, whose tables are 60 us worth of bytes.) */
+/* A LANE per TU: the table of a TU is a running scan over its positions -- j(i) = i where position i is available, else j(i - 1), starting
+ * from the first available position -- two instructions a position, four positions to a stored dword (a TU's stripe has 5n >= 4n + 4 bytes),
+ * and the lanes of a wave walk 64 tables side by side.  (A wave per TU was bound by the rate waves start at; a wave walking 64 TUs one after
+ * the other, every lane a position, by its instruction count -- ~120 per TU, most of them scalar: 0.23 ms for the 1.84 M TUs of an
+ * eight-picture grid, whose tables are 60 us worth of bytes.) */
 __global__ __launch_bounds__(256) void k_hevc_intra_jtable(JTabArgs a)
 {
-    const int lane = threadIdx.x & 63;
-    const uint32_t first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * JT_TUS_PER_WAVE;
-    if (first >= a.n) return;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (a.refused && *a.refused) return;
-    const uint32_t mine = first + (uint32_t)lane < a.n ? first + (uint32_t)lane : a.n - 1;
-    const u32x4 *rec = (const u32x4 *)(a.tus + mine);
+    if (i >= a.n) return;
+    const u32x4 *rec = (const u32x4 *)(a.tus + i);
     const u32x4 r0 = rec[0], r1 = rec[1]; /* x | y << 16, log2_size | cidx << 8 | mode << 16 | flags << 24, res_offset, res_scale; avail_top, avail_left */
-    const uint32_t count = a.n - first < JT_TUS_PER_WAVE ? a.n - first : JT_TUS_PER_WAVE;
-    for (uint32_t q = 0; q < count; q++) {
-    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)r0.x, (int)q), w1 = (uint32_t)__builtin_amdgcn_readlane((int)r0.y, (int)q);
-    const unsigned long long avail_top = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)r1.x, (int)q) |
-                                         ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)r1.y, (int)q) << 32);
-    const unsigned long long avail_left = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)r1.z, (int)q) |
-                                          ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)r1.w, (int)q) << 32);
-    const int tx = (int)(w0 & 0xffff), ty = (int)(w0 >> 16), lg = (int)(w1 & 0xff), cidx = (int)((w1 >> 8) & 0xff), flags = (int)(w1 >> 24);
-    const int n = 1 << lg, cnt = 4 * n + 1;
-    const unsigned long long rl = __brevll(avail_left) >> (64 - 2 * n); /* bit i = left[2n-1-i] */
-    unsigned long long m0, m1;
-    unsigned m2 = 0;
+    const unsigned long long avail_top = (unsigned long long)r1.x | ((unsigned long long)r1.y << 32), avail_left = (unsigned long long)r1.z | ((unsigned long long)r1.w << 32);
+    const int tx = (int)(r0.x & 0xffff), ty = (int)(r0.x >> 16), lg = (int)(r0.y & 0xff), cidx = (int)((r0.y >> 8) & 0xff), flags = (int)(r0.y >> 24);
+    if (lg < 2 || lg > 5 || cidx > 2) return; /* (a list nobody has validated yet: k_hevc_check_tus refuses it) */
+    const int n = 1 << lg;
+    /* availability by scan position as a 129-bit number: left column bottom-up (bit i = left[2n - 1 - i]), corner (bit 2n), top row */
+    const unsigned long long rl = __brevll(avail_left) >> (64 - 2 * n);
     const unsigned long long c = (flags & 1) ? 1ull : 0ull;
     const unsigned long long tp = n == 32 ? avail_top : (avail_top & ((1ull << (2 * n)) - 1));
+    unsigned long long w0, w1;
+    unsigned w2 = 0;
     if (n == 32) { /* left 0..63, corner 64, top 65..128 */
-        m0 = rl; m1 = c | (tp << 1); m2 = (unsigned)(tp >> 63);
+        w0 = rl; w1 = c | (tp << 1); w2 = (unsigned)(tp >> 63);
     } else {
-        m0 = rl | (c << (2 * n)) | (tp << (2 * n + 1));
-        m1 = tp >> (63 - 2 * n); /* bits that spill past 64 (n = 16: 4n + 1 = 65) */
+        w0 = rl | (c << (2 * n)) | (tp << (2 * n + 1));
+        w1 = tp >> (63 - 2 * n); /* bits that spill past 64 (n = 16: 4n + 1 = 65) */
     }
-    const int n_avail = __popcll(m0) + __popcll(m1) + (int)m2;
-    uint8_t *out = a.jt + (size_t)(a.boff[cidx] + (uint32_t)(ty >> 2) * (uint32_t)a.bw[cidx] + (uint32_t)(tx >> 2)) * JT_STRIDE;
-    for (int i = lane; i < cnt; i += 64) {
-        int j = i;
-        if (n_avail == 0) j = 255;
-        else if (n_avail < cnt) {
-            j = -1;
-            if (i >= 128 && m2) j = 128;
-            if (j < 0 && i >= 64) {
-                const unsigned long long mm = i >= 127 ? m1 : (m1 & ((2ull << (i - 64)) - 1));
-                if (mm) j = 127 - __clzll(mm);
-            }
-            if (j < 0) {
-                const unsigned long long mm = i >= 63 ? m0 : (m0 & ((2ull << i) - 1));
-                if (mm) j = 63 - __clzll(mm);
-            }
-            if (j < 0) j = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : 128);
-        }
-        out[i] = (uint8_t)j;
-    }
+    const int first = w0 ? __builtin_ctzll(w0) : (w1 ? 64 + __builtin_ctzll(w1) : (w2 ? 128 : 255)); /* 255: nothing around the TU is available */
+    const int bw = cidx == 0 ? a.bw[0] : (cidx == 1 ? a.bw[1] : a.bw[2]);
+    const uint32_t boff = cidx == 0 ? a.boff[0] : (cidx == 1 ? a.boff[1] : a.boff[2]);
+    uint32_t *out = (uint32_t *)(a.jt + (size_t)(boff + (uint32_t)(ty >> 2) * (uint32_t)bw + (uint32_t)(tx >> 2)) * JT_STRIDE); /* JT_STRIDE is a multiple of 4 */
+    uint32_t j = (uint32_t)first;
+    for (int q = 0; q <= n; q++) { /* 4n + 1 positions: n + 1 dwords */
+        const unsigned long long word = q < 16 ? w0 : (q < 32 ? w1 : (unsigned long long)w2);
+        const uint32_t nib = (uint32_t)(word >> (4 * (q & 15))) & 15u, p = 4u * (uint32_t)q;
+        const uint32_t j0 = (nib & 1u) ? p : j, j1 = (nib & 2u) ? p + 1 : j0, j2 = (nib & 4u) ? p + 2 : j1, j3 = (nib & 8u) ? p + 3 : j2;
+        out[q] = j0 | (j1 << 8) | (j2 << 16) | (j3 << 24);
+        j = j3;
     }
 }
 
@@ -1243,6 +1270,11 @@ __global__ __launch_bounds__(64, MINW) void k_hevc_intra_groups(HevcIntraArgs a)
     const int lane4 = lane < 16 ? lane : 0;
     const int cell_alias4 = 2 * ((lane4 >> 2) * TILE_STRIDE + (lane4 & 3));
     bool dead = false; /* a wave that gave up waiting (bounded spin): leaves through the loop heads, not from inside them */
+    /* (Taking the NEXT ticket while the group at hand is still being worked on -- the ticket, the group record and the slots are three trips
+     * to memory in a row between two groups, 4.2 us a group on the eight-picture grid, 15 % of the kernel's wave time
+     * (tests/tools/diag_intra_trace_grid.py) -- was built and measured slower: grids of 1 / 4 / 8 pictures 1.19 / 2.40 / 4.07 ms against
+     * 1.08 / 2.22 / 4.03, one 8K picture 5.30 against 5.18.  A ticket held by a busy wave is a ready group that waits for it while idle waves
+     * hold later tickets.) */
     while (!dead) {
         unsigned ticket = 0;
         if (lane == 0) ticket = __hip_atomic_fetch_add(&a.ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1943,6 +1975,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
     const size_t w_desc = desc_px * 2 + 2;
     auto enqueue_programs = [&](uint32_t *words, const int win[3], size_t n_slots, hipStream_t ps) {
         pa.sched = (u32x4 *)a.sched; pa.n_slots = (uint32_t)n_slots; pa.jt = a.jt;
+        pa.records = d_tus;
         pa.desc = (uint2 *)(((uintptr_t)words + 7) & ~(uintptr_t)7);
         for (int c = 0; c < 3; c++) { pa.wl[c] = win[c]; pa.stride[c] = a.stride[c]; pa.jt_bw[c] = ja.bw[c]; pa.jt_boff[c] = ja.boff[c]; }
         pa.plan_result = a.plan_result; pa.wait_cap = a.wait_cap;
@@ -1963,7 +1996,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             js = (hipStream_t)side.stream;
             jt_forked = true;
         }
-        hipLaunchKernelGGL(k_hevc_intra_jtable, dim3((unsigned)((n_tus + 4 * JT_TUS_PER_WAVE - 1) / (4 * JT_TUS_PER_WAVE))), dim3(256), 0, js, ja);
+        hipLaunchKernelGGL(k_hevc_intra_jtable, dim3((unsigned)((n_tus + 255) / 256)), dim3(256), 0, js, ja);
         if (jt_forked) FFHIP_CHECK(hipEventRecord((hipEvent_t)side.join, js), FFHIP_EIO);
         return FFHIP_OK;
     };
@@ -2023,13 +2056,16 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             int n_groups = 0;
             /* the substitution table starts (on the side stream) behind the list's validation: a bad record's position would send its stores anywhere */
             /* ... and the per-pixel programs follow it there, behind k_plan_count (whose flags and wait counts are all they need of the schedule),
-             * next to the ticket kernels and k_plan_emit on `stream`; the grouped kernel waits for both */
+             * next to the ticket kernels and k_plan_emit on `stream`; the grouped kernel waits for both.  (Started right behind the validation
+             * instead, from the TU records alone, with k_plan_emit settling the slot words afterwards -- the programs read no table any more --
+             * they ran next to k_plan_owner and k_plan_count, which then took 341 and 383 us instead of 135 and 223: the eight-picture grid's
+             * pre-pass 1.14 ms instead of 1.00.) */
             bool programs_forked = false;
             auto programs_early = [&](const uint8_t *flags, const uint32_t *wcount, const uint32_t *result) -> int {
                 if (!jt_forked) return FFHIP_OK; /* a small list: everything on `stream`, in order */
                 FFHIP_CHECK(hipEventRecord((hipEvent_t)side.mid, st), FFHIP_EIO);
                 FFHIP_CHECK(hipStreamWaitEvent((hipStream_t)side.stream, (hipEvent_t)side.mid, 0), FFHIP_EIO);
-                pa.tus = d_tus; pa.flags = flags; pa.wcount = wcount;
+                pa.tus = d_tus; pa.flags = flags; pa.wcount = wcount; pa.refused = nullptr;
                 a.sched = (const u32x4 *)g_work; /* where the planner puts the slots (ffhip_hevc_plan_gpu's layout starts with them) */
                 a.plan_result = result; a.wait_cap = (uint32_t)(8 * (size_t)n_tus);
                 enqueue_programs(jt_words + w_jt, win, (size_t)n_tus, (hipStream_t)side.stream);
@@ -2057,7 +2093,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             a.n_groups = 0;
             a.n_tus = n_tus;
             { const int jrc = join_jtable(); if (jrc) return jrc; } /* (the side stream's last record: behind the programs when they went there) */
-            if (!programs_forked) enqueue_programs(jt_words + w_jt, win, (size_t)n_tus, st);
+            if (!programs_forked) { pa.tus = nullptr; pa.flags = nullptr; pa.wcount = nullptr; pa.refused = nullptr; enqueue_programs(jt_words + w_jt, win, (size_t)n_tus, st); }
 #ifdef FFHIP_INTRA_TRACE
             a.trace = g_intra_trace;
 #endif

@@ -102,37 +102,37 @@ __device__ __forceinline__ uint32_t block_excl_scan(const uint32_t v, uint32_t *
  * round 4: 58 us for the 7 176 block totals and 148 us for the histogram of an eight-picture grid, the side stream's kernels on the same
  * CUs.)  With vmax: v is [groups][1 << group_log2] and *vmax (zero beforehand) receives the largest GROUP total (the widest wavefront:
  * the most runs of one depth). */
-__global__ __launch_bounds__(1024) void k_plan_scan(const uint32_t *v, uint32_t *out, uint32_t n, uint32_t *vmax, uint32_t group_log2, const uint32_t *skip)
+__global__ __launch_bounds__(256) void k_plan_scan(const uint32_t *v, uint32_t *out, uint32_t n, uint32_t *vmax, uint32_t group_log2, const uint32_t *skip)
 {
+    /* 256 threads, sixteen entries each: a workgroup of 1024 needs sixteen free wave slots on ONE CU at once, and next to the side stream's
+     * thousands of four-wave workgroups it waited for them (the same scan: 5 us alone, 60 - 130 us there) */
     __shared__ uint32_t wsum[17];
-    __shared__ uint32_t red[16];
+    __shared__ uint32_t red[4];
     if (skip && *skip) return; /* no wavefront keys: nobody reads the histogram */
-    __builtin_amdgcn_s_setprio(3); /* a handful of waves next to the side stream's thousands: first in line at the issue arbiter */
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t base = blockIdx.x * 4096u;
     uint32_t s = 0;
-    for (uint32_t i = threadIdx.x; i < base; i += 1024) s += v[i];
+    for (uint32_t i = threadIdx.x; i < base; i += 256) s += v[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += (uint32_t)__shfl_xor((int)s, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    uint32_t carry = 0;
+    const uint32_t carry = red[0] + red[1] + red[2] + red[3];
+    const uint32_t i = base + 16 * threadIdx.x;
+    uint32_t x[16], mine = 0;
 #pragma unroll
-    for (int w = 0; w < 16; w++) carry += red[w];
-    const uint32_t i = base + 4 * threadIdx.x;
-    uint32_t x[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) x[k] = i + k < n ? v[i + k] : 0u;
+    for (int k = 0; k < 16; k++) { x[k] = i + k < n ? v[i + k] : 0u; mine += x[k]; }
     uint32_t total;
-    uint32_t run = carry + block_excl_scan(x[0] + x[1] + x[2] + x[3], wsum, &total);
+    uint32_t run = carry + block_excl_scan(mine, wsum, &total);
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < 16; k++) {
         if (i + k < n) out[i + k] = run;
         run += x[k];
     }
     if (vmax) {
         const uint32_t gend = ((base + 4096u < n ? base + 4096u : n) >> group_log2);
         uint32_t mx = 0;
-        for (uint32_t g = (base >> group_log2) + threadIdx.x; g < gend; g += 1024) {
+        for (uint32_t g = (base >> group_log2) + threadIdx.x; g < gend; g += 256) {
             uint32_t t = 0;
             for (uint32_t e = 0; e < (1u << group_log2); e++) t += v[(g << group_log2) + e];
             mx = t > mx ? t : mx;
@@ -775,7 +775,7 @@ extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long
         if (hrc) return hrc;
     }
     hipLaunchKernelGGL(k_plan_owner, dim3(grid), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_plan_scan, dim3((unsigned)((Lo.n_blocks + 4095) / 4096)), dim3(1024), 0, st, (const uint32_t *)a.blk_tot, a.blk_pre, (uint32_t)Lo.n_blocks, (uint32_t *)nullptr, 0u,
+    hipLaunchKernelGGL(k_plan_scan, dim3((unsigned)((Lo.n_blocks + 4095) / 4096)), dim3(256), 0, st, (const uint32_t *)a.blk_tot, a.blk_pre, (uint32_t)Lo.n_blocks, (uint32_t *)nullptr, 0u,
                        (const uint32_t *)(a.result + 6));
     hipLaunchKernelGGL(k_plan_runid, dim3(grid), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_plan_count, dim3(grid), dim3(256), 0, st, a);
@@ -798,7 +798,7 @@ extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long
     const size_t m = n < wins ? n : wins; /* runs <= windows, or the plan is refused (k_plan_count: a window with two runs) */
     const unsigned cgrid = (unsigned)((cells + 255) / 256);
     hipLaunchKernelGGL(k_plan_cell_hist, dim3(cgrid), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_plan_scan, dim3((unsigned)((((size_t)a.depths << a.shard_log2) + 4095) / 4096)), dim3(1024), 0, st, (const uint32_t *)a.hist, a.hist_pre,
+    hipLaunchKernelGGL(k_plan_scan, dim3((unsigned)((((size_t)a.depths << a.shard_log2) + 4095) / 4096)), dim3(256), 0, st, (const uint32_t *)a.hist, a.hist_pre,
                        (uint32_t)(a.depths << a.shard_log2), a.result + 4, a.shard_log2, (const uint32_t *)(a.result + 3));
     hipLaunchKernelGGL(k_plan_cell_base, dim3(cgrid), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_plan_rank, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a, (uint32_t)m);

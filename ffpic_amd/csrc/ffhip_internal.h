@@ -88,4 +88,12 @@ extern thread_local FfhipVp8Fusion g_ffhip_vp8_fusion;
 struct FfhipSide { void *stream, *fork, *join, *mid; }; /* mid: a second point of the main stream the side stream may wait for */
 extern "C" int ffhip_side_stream_get(FfhipSide *out);
 
+/* bits of a schedule slot's program word (second quarter, .x) that two files know: k_hevc_intra_program writes the word, k_plan_emit adds
+ * what only the planner knows when the programs were built NEXT TO it (ffhip_hevc_intra.hip has the rest of the layout) */
+#define FFHIP_PK_KIND_MASK 7u
+#define FFHIP_PK_SIGNAL 64u
+#define FFHIP_PK_WAIT 128u
+#define FFHIP_PK_SLOW 256u
+#define FFHIP_PROG_NO_RESIDUAL 0xffffff00u
+
 #endif

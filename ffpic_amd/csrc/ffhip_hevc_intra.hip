@@ -40,6 +40,7 @@
 #define FFHIP_HEVC_INTRA_WINDOW_LOG2 5 /* luma window of the grouped form: 32x32 (1080p sweep in profiles/r1_stages.json) */
 #endif
 
+#define CTRL_HDR 352 /* words in front of the done flags: room for ten 128-byte lines wherever the block starts (ticket counters, abort) */
 struct HevcIntraArgs {
     const ffhip_hevc_tu *tus;
     const uint32_t *work; /* TU indices of this level */
@@ -52,13 +53,21 @@ struct HevcIntraArgs {
                                  wait count | signal << 8 | tile_ok << 9, TU index, 0}               */
     const u32x4 *groups;      /* per group: {first slot, slot count, log2 window, 0}              */
     const uint32_t *wait_idx; /* TU indices a slot waits for (TUs of other groups)                */
-    uint32_t *ctrl;           /* [0] next group ticket, [1] abort; done flags per TU from ctrl + 4 */
+    uint32_t *ctrl;           /* CTRL_HDR words, then one done flag per TU.  The header holds the next group ticket and the abort word, each ALONE in
+                                 a 128-byte line (ctrl_ticket / ctrl_abort: their word indices): every wave takes its tickets from the one word with a
+                                 device-scope atomic, and anything else that lives in its line queues up with them -- 826 resident waves that did nothing
+                                 but read that line once in 30 us made a 135-tile grid take 1.58 ms instead of 1.08; the abort word, read by every
+                                 waiting wave between two polls, sat next to it until late in round 4 */
+    uint32_t ctrl_ticket, ctrl_abort;
+    uint32_t ticket_shards;
     int *async_err;           /* pinned host word (ffhip_async_err_word)                          */
     int n_groups;
     int debug_withhold;       /* test hook (FFHIP_DEBUG_WITHHOLD_TU): this TU's done flag is never published; -1 = off */
     /* device-planned launches: the planner's verdict is read by the kernel, not by the host */
     const uint32_t *plan_result; /* {refused, number of groups, wait entries, -, widest wavefront}; NULL: n_groups above is the truth */
     uint32_t tp_width;           /* device-built plans: from this wavefront width on the throughput instance of the grouped kernel runs (0: never) */
+    uint32_t poll_reps;          /* sleeps of ~0.5 us between two polls of a wave far from its turn (FFHIP_HEVC_INTRA_POLL_REPS) */
+    uint32_t width_pct;          /* device-built plans: waves kept = widest wavefront x this / 128 (+ 16, at least 256): FFHIP_HEVC_INTRA_WIDTH_PCT */
     uint32_t wait_cap;           /* wait entries the planner had room for                                        */
     long long n_tus;             /* for the serial path a refused plan takes                                     */
     /* substitution table (k_hevc_intra_jtable): per TU and scan position the scan position its sample comes from */
@@ -1222,7 +1231,7 @@ __global__ __launch_bounds__(64, MINW) void k_hevc_intra_groups(HevcIntraArgs a)
     __shared__ __attribute__((aligned(16))) short resz[64]; /* zeros: the residual of a TU without one (every pass reads the same 64) */
     __shared__ u32x4 slots[(CHUNK + 2) * 3];
     const int lane = threadIdx.x;
-    uint32_t *flags = a.ctrl + 4;
+    uint32_t *flags = a.ctrl + CTRL_HDR;
     int n_groups = a.n_groups;
     if (lane == 0) {
         tile[TILE_CONST_Y] = (short)(1 << (a.bitdepth_y - 1));
@@ -1260,7 +1269,8 @@ __global__ __launch_bounds__(64, MINW) void k_hevc_intra_groups(HevcIntraArgs a)
          * three waves per SIMD; a single picture's few hundred by one wave's latency -- the instance with all its registers */
         const bool wide = a.tp_width && width >= a.tp_width;
         if (wide != (MINW >= 3)) return;
-        if (width && blockIdx.x >= ((width >> 1) + 16 > 256u ? (width >> 1) + 16 : 256u)) return;
+        const uint32_t cap = ((width * a.width_pct) >> 7) + 16;
+        if (width && blockIdx.x >= (cap > 256u ? cap : 256u)) return;
     }
     const __amdgpu_buffer_rsrc_t desc_rs = ffhip_rsrc(a.desc, 0xffffffffu), res_rs = ffhip_rsrc((const void *)hot.residual, PROG_NO_RESIDUAL);
     const int cell_lane4 = 2 * ((lane >> 2) * TILE_STRIDE + (lane & 3)), cell_lane8 = 2 * ((lane >> 3) * TILE_STRIDE + (lane & 7));
@@ -1270,6 +1280,7 @@ __global__ __launch_bounds__(64, MINW) void k_hevc_intra_groups(HevcIntraArgs a)
     const int lane4 = lane < 16 ? lane : 0;
     const int cell_alias4 = 2 * ((lane4 >> 2) * TILE_STRIDE + (lane4 & 3));
     bool dead = false; /* a wave that gave up waiting (bounded spin): leaves through the loop heads, not from inside them */
+    unsigned my_shard = blockIdx.x % (a.ticket_shards ? a.ticket_shards : 1u);
     /* (Taking the NEXT ticket while the group at hand is still being worked on -- the ticket, the group record and the slots are three trips
      * to memory in a row between two groups, 4.2 us a group on the eight-picture grid, 15 % of the kernel's wave time
      * (tests/tools/diag_intra_trace_grid.py) -- was built and measured slower: grids of 1 / 4 / 8 pictures 1.19 / 2.40 / 4.07 ms against
@@ -1277,8 +1288,22 @@ __global__ __launch_bounds__(64, MINW) void k_hevc_intra_groups(HevcIntraArgs a)
      * hold later tickets.) */
     while (!dead) {
         unsigned ticket = 0;
-        if (lane == 0) ticket = __hip_atomic_fetch_add(&a.ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+        if (a.ticket_shards > 1) {
+            /* Ticket t belongs to counter t mod shards (each in a line of its own); a wave starts at "its" counter and moves on when one is used
+             * up.  With one counter the eight-picture grid's 207 000 tickets were 83 device-scope atomics a microsecond on one word: 4.00 ms
+             * against 3.80 with four counters (four pictures 2.05 / 1.93).  The order argument holds per counter and across them: the smallest
+             * unfinished ticket is either somebody's group at hand or not taken yet -- then a wave of its counter is at work on a smaller one,
+             * which cannot be (FFHIP_HEVC_TICKET_SHARDS=1: the single counter). */
+            for (unsigned tries = 0; tries < a.ticket_shards; tries++) {
+                const unsigned sh = (my_shard + tries) % a.ticket_shards;
+                if (lane == 0) ticket = __hip_atomic_fetch_add(&a.ctrl[a.ctrl_ticket + 32 * sh], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket) * a.ticket_shards + sh;
+                if (ticket < (unsigned)n_groups) { my_shard = sh; break; }
+            }
+        } else {
+            if (lane == 0) ticket = __hip_atomic_fetch_add(&a.ctrl[a.ctrl_ticket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+        }
         if (ticket >= (unsigned)n_groups) break;
         const u32x4 g = a.groups[ticket];
         GroupCtx gc;
@@ -1454,9 +1479,9 @@ __global__ __launch_bounds__(64, MINW) void k_hevc_intra_groups(HevcIntraArgs a)
                         for (;;) {
                             const unsigned done = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (__builtin_amdgcn_ballot_w64(done == 0) == 0) break;
-                            if (++spins > SPIN_LIMIT || SGPR(__hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                            if (++spins > SPIN_LIMIT || ((spins & 15) == 0 && SGPR(__hip_atomic_load(&a.ctrl[a.ctrl_abort], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))) {
                                 if (lane == 0) {
-                                    __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    __hip_atomic_store(&a.ctrl[a.ctrl_abort], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                     __hip_atomic_store(a.async_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                 }
                                 dead = true;
@@ -1470,7 +1495,7 @@ __global__ __launch_bounds__(64, MINW) void k_hevc_intra_groups(HevcIntraArgs a)
                                     reads per 8K picture through the L2 the working waves use and 64 was better; with 256 waves 8 .. 32 are alike */
 #endif
                             if (spins < FFHIP_POLL_FAST) __builtin_amdgcn_s_sleep(1);
-                            else __builtin_amdgcn_s_sleep(FFHIP_POLL_SLOW_SLEEP); /* far from ready */
+                            else for (uint32_t r_ = 0; r_ < a.poll_reps; r_++) __builtin_amdgcn_s_sleep(FFHIP_POLL_SLOW_SLEEP); /* far from ready */
                         }
                         if (dead) break;
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* ordering only: no cache-wide invalidate */
@@ -2018,6 +2043,9 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
          * (SQ_WAIT_ANY, profiles/r4_hevc_grid8_pmc.txt) for loads whose latency grows with the load.  FFHIP_HEVC_INTRA_TP_WIDTH=<width> turns it on
          * for plans whose widest wavefront is at least that. */
         { const char *tw = FFHIP_ENV("FFHIP_HEVC_INTRA_TP_WIDTH"); a.tp_width = tw ? (uint32_t)std::max(0, atoi(tw)) : 0u; }
+        { const char *pr = FFHIP_ENV("FFHIP_HEVC_INTRA_POLL_REPS"); a.poll_reps = pr ? (uint32_t)std::max(1, atoi(pr)) : 1u; }
+        { const char *tsx = FFHIP_ENV("FFHIP_HEVC_TICKET_SHARDS"); a.ticket_shards = tsx ? (uint32_t)std::min(8, std::max(1, atoi(tsx))) : 4u; }
+        { const char *wp = FFHIP_ENV("FFHIP_HEVC_INTRA_WIDTH_PCT"); a.width_pct = wp ? (uint32_t)std::max(1, atoi(wp)) : 128u; }
         /* the schedule: built on the device (ffhip_hevc_plan_gpu.hip) unless FFHIP_HEVC_PLAN=host; lists whose groups are
          * not contiguous runs of the decode order come back from there and take the host planner with its window search */
         const char *pe = FFHIP_ENV("FFHIP_HEVC_PLAN");
@@ -2049,7 +2077,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
              * pictures are indifferent -- tests/tools/bench_intra_c5.py, bench_intra_sizes.py) */
             const int wl = dev_wl, cs = dev_cs;
             const int win[3] = {wl, wl - cs, wl - cs};
-            const size_t w_plan = ffhip_hevc_plan_gpu_words(n_tus, pwc, ph, win), w_ctrl = 4 + (size_t)n_tus;
+            const size_t w_plan = ffhip_hevc_plan_gpu_words(n_tus, pwc, ph, win), w_ctrl = CTRL_HDR + (size_t)n_tus;
             uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, w_plan + w_ctrl + 16 + w_jt + w_desc);
             if (!g_work) return FFHIP_ENOMEM;
             uint32_t *const jt_words = g_work + ((w_plan + 3) & ~(size_t)3) + ((w_ctrl + 3) & ~(size_t)3);
@@ -2089,6 +2117,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
                                                         g_work + ((w_plan + 3) & ~(size_t)3), w_ctrl /* the ticket counter and the done flags: cleared by the planner's first launch */);
             if (prc < 0) { (void)join_jtable(); return prc; } /* (`stream` must not run ahead of the side stream's read of the caller's list) */
             a.ctrl = g_work + ((w_plan + 3) & ~(size_t)3);
+            a.ctrl_ticket = (uint32_t)((32 - (((uintptr_t)a.ctrl >> 2) & 31)) & 31); a.ctrl_abort = a.ctrl_ticket + 32 * 9;
             a.async_err = async_err;
             a.n_groups = 0;
             a.n_tus = n_tus;
@@ -2112,9 +2141,9 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
         GroupPlan plan;
         int host_wl = 0;
         if (plan_with_window_search(h_tus, n_tus, pw, ph, we ? atoi(we) : FFHIP_HEVC_INTRA_WINDOW_LOG2, plan, &host_wl, ja.boff)) {
-            /* device image: sched | groups | wait | ctrl[4] + one done flag per TU */
+            /* device image: sched | groups | wait | ctrl[CTRL_HDR] + one done flag per TU */
             const size_t w_sched = plan.sched.size() * 4, w_groups = plan.groups.size() * 4, w_wait = plan.wait.size();
-            const size_t w_ctrl = 4 + (size_t)n_tus;
+            const size_t w_ctrl = CTRL_HDR + (size_t)n_tus;
             const size_t o_groups = w_sched, o_wait = o_groups + w_groups, o_ctrl = (o_wait + w_wait + 3) & ~(size_t)3;
             FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO); /* the work buffer may still be in use by an earlier call */
             uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, o_ctrl + w_ctrl + 4 + w_jt + w_desc);
@@ -2129,6 +2158,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             a.groups = (const u32x4 *)(g_work + o_groups);
             a.wait_idx = g_work + o_wait;
             a.ctrl = g_work + o_ctrl;
+            a.ctrl_ticket = (uint32_t)((32 - (((uintptr_t)a.ctrl >> 2) & 31)) & 31); a.ctrl_abort = a.ctrl_ticket + 32 * 9;
             a.async_err = async_err;
             a.n_groups = (int)plan.groups.size();
             {

@@ -96,4 +96,14 @@ extern "C" int ffhip_side_stream_get(FfhipSide *out);
 #define FFHIP_PK_SLOW 256u
 #define FFHIP_PROG_NO_RESIDUAL 0xffffff00u
 
+/* Control words of the VP8 row kernels (ffhip_vp8_pred.hip, ffhip_vp8_lf.hip; the scratch they live in starts on a 256-byte boundary): the
+ * ticket counters -- one device-scope atomic per row from every wave -- and the abort word -- read by waiting waves between polls -- each
+ * ALONE in a 128-byte line, the per-row progress counters behind them.  (Until late in round 4 they were words 0, 2 and 1 of one line, with
+ * the first progress counters behind them in the same line: every poll of a waiting wave queued up with the ticket atomics.) */
+#define FFHIP_VP8_CTRL_TICKET_C 32
+#define FFHIP_VP8_CTRL_ABORT 64
+#define FFHIP_VP8_CTRL_HDR 128
+#define FFHIP_VP8_LF_CTRL_ABORT 32
+#define FFHIP_VP8_LF_CTRL_HDR 64
+
 #endif

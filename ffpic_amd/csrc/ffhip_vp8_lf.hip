@@ -33,7 +33,7 @@ struct Vp8LfArgs {
     long long plane_y, plane_uv;
     int mbcols, mbrows, count, filter_type;
     /* row form only */
-    uint32_t *ctrl; /* [0] next row ticket, [1] abort; from ctrl + 4: macroblocks finished per (image, row) */
+    uint32_t *ctrl; /* [0] next row ticket, [FFHIP_VP8_LF_CTRL_ABORT] abort; from ctrl + FFHIP_VP8_LF_CTRL_HDR: macroblocks finished per (image, row) */
     int *async_err;
     int n_images;
     int slack; /* as in Vp8PredArgs */
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
     const int n_mb = a.mbcols * a.mbrows;
     const int ys = 16 * a.mbcols, us = 8 * a.mbcols;
     constexpr int type = TYPE;
-    uint32_t *progress = a.ctrl + 4;
+    uint32_t *progress = a.ctrl + FFHIP_VP8_LF_CTRL_HDR;
     if (lane < 24) FT[lane] = a.filters[lane]; /* a read from memory per macroblock would drain the fetches in flight */
     wave_sync();
     typedef __attribute__((address_space(3))) uint8_t lds_u8;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
         const int y = (int)(ticket / (unsigned)a.n_images), img = (int)(ticket % (unsigned)a.n_images);
         if (a.debug_giveup && a.pred_progress && y == a.mbrows / 2) { /* test hook (FFHIP_DEBUG_VP8_LF_GIVEUP): as if a wait for the prediction had run out half-way down */
             if (lane == 0) {
-                __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a.ctrl[FFHIP_VP8_LF_CTRL_ABORT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(a.async_err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             return;
@@ -246,10 +246,10 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
             while (seen < want) {
                 seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(prog_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 if (seen >= want) break;
-                if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return false; /* given up elsewhere: whoever did has said why */
+                if ((spins & 15) == 15 && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&a.ctrl[FFHIP_VP8_LF_CTRL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return false; /* given up elsewhere: whoever did has said why */
                 if (++spins > LF_SPIN_LIMIT) {
                     if (lane == 0) {
-                        __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&a.ctrl[FFHIP_VP8_LF_CTRL_ABORT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(a.async_err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
                     return false;
@@ -269,14 +269,14 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
                      * abort word sits three words in front of its counters) */
                     /* looked at every 64th poll only: the word shares its cache line with the prediction's ticket counter, and a load per
                      * poll from every waiting filter wave slowed a 1024-frame call by a third */
-                    if ((spins & 63) == 63 && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.pred_progress - 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                        if (lane == 0) __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((spins & 63) == 63 && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.pred_progress - FFHIP_VP8_CTRL_HDR + FFHIP_VP8_CTRL_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                        if (lane == 0) __hip_atomic_store(&a.ctrl[FFHIP_VP8_LF_CTRL_ABORT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         return false;
                     }
-                    if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&a.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return false; /* given up elsewhere: whoever did has said why */
+                    if ((spins & 15) == 15 && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&a.ctrl[FFHIP_VP8_LF_CTRL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return false; /* given up elsewhere: whoever did has said why */
                     if (++spins > LF_SPIN_LIMIT) {
                         if (lane == 0) {
-                            __hip_atomic_store(&a.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(&a.ctrl[FFHIP_VP8_LF_CTRL_ABORT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             __hip_atomic_store(a.async_err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         }
                         return false;
@@ -402,7 +402,7 @@ extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int fi
     int *async_err = (mode_env && !strcmp(mode_env, "levels")) ? nullptr : ffhip_async_err_word();
     if (async_err && !((uintptr_t)d_modes & 3) && !(((uintptr_t)d_y | (uintptr_t)d_u | (uintptr_t)d_v | (uintptr_t)plane_stride_y | (uintptr_t)plane_stride_uv) & 3) &&
         n_mb < (1LL << 23)) {
-        const size_t words = 4 + (size_t)n_images * (size_t)mbrows;
+        const size_t words = FFHIP_VP8_LF_CTRL_HDR + (size_t)n_images * (size_t)mbrows;
         uint32_t *g_work = ffhip_scratch(SCRATCH_VP8_LF, stream, words);
         if (!g_work) return FFHIP_ENOMEM;
         const uint32_t *pred_progress = nullptr;

@@ -1280,7 +1280,9 @@ __global__ __launch_bounds__(64, MINW) void k_hevc_intra_groups(HevcIntraArgs a)
     const int lane4 = lane < 16 ? lane : 0;
     const int cell_alias4 = 2 * ((lane4 >> 2) * TILE_STRIDE + (lane4 & 3));
     bool dead = false; /* a wave that gave up waiting (bounded spin): leaves through the loop heads, not from inside them */
-    unsigned my_shard = blockIdx.x % (a.ticket_shards ? a.ticket_shards : 1u);
+    const unsigned shards = a.ticket_shards < gridDim.x ? (a.ticket_shards ? a.ticket_shards : 1u) : gridDim.x; /* every counter needs a wave of its own: one
+                                                                                                                    that stays with it until it is used up */
+    unsigned my_shard = blockIdx.x % shards;
     /* (Taking the NEXT ticket while the group at hand is still being worked on -- the ticket, the group record and the slots are three trips
      * to memory in a row between two groups, 4.2 us a group on the eight-picture grid, 15 % of the kernel's wave time
      * (tests/tools/diag_intra_trace_grid.py) -- was built and measured slower: grids of 1 / 4 / 8 pictures 1.19 / 2.40 / 4.07 ms against
@@ -1288,16 +1290,16 @@ __global__ __launch_bounds__(64, MINW) void k_hevc_intra_groups(HevcIntraArgs a)
      * hold later tickets.) */
     while (!dead) {
         unsigned ticket = 0;
-        if (a.ticket_shards > 1) {
+        if (shards > 1) {
             /* Ticket t belongs to counter t mod shards (each in a line of its own); a wave starts at "its" counter and moves on when one is used
              * up.  With one counter the eight-picture grid's 207 000 tickets were 83 device-scope atomics a microsecond on one word: 4.00 ms
              * against 3.80 with four counters (four pictures 2.05 / 1.93).  The order argument holds per counter and across them: the smallest
              * unfinished ticket is either somebody's group at hand or not taken yet -- then a wave of its counter is at work on a smaller one,
              * which cannot be (FFHIP_HEVC_TICKET_SHARDS=1: the single counter). */
-            for (unsigned tries = 0; tries < a.ticket_shards; tries++) {
-                const unsigned sh = (my_shard + tries) % a.ticket_shards;
+            for (unsigned tries = 0; tries < shards; tries++) {
+                const unsigned sh = (my_shard + tries) % shards;
                 if (lane == 0) ticket = __hip_atomic_fetch_add(&a.ctrl[a.ctrl_ticket + 32 * sh], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket) * a.ticket_shards + sh;
+                ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket) * shards + sh;
                 if (ticket < (unsigned)n_groups) { my_shard = sh; break; }
             }
         } else {

@@ -81,6 +81,7 @@ struct FfhipVp8Fusion {
     void *side;  /* hipStream_t */
     void *fork;  /* hipEvent_t  */
     int pred_split; /* the prediction runs luma and chroma rows apart: its chroma counters (behind the luma ones) count too */
+    int pshift; /* a row's progress counter is word (image * mbrows + row) << pshift */
 };
 extern thread_local FfhipVp8Fusion g_ffhip_vp8_fusion;
 

@@ -33,6 +33,7 @@ struct Vp8LfArgs {
     long long plane_y, plane_uv;
     int mbcols, mbrows, count, filter_type;
     /* row form only */
+    int pshift, pred_pshift; /* a row's progress counter is word (image * mbrows + row) << pshift; the prediction's likewise */
     uint32_t *ctrl; /* [0] next row ticket, [FFHIP_VP8_LF_CTRL_ABORT] abort; from ctrl + FFHIP_VP8_LF_CTRL_HDR: macroblocks finished per (image, row) */
     int *async_err;
     int n_images;
@@ -211,16 +212,16 @@ __global__ __launch_bounds__(64) void k_vp8_loopfilter_rows(Vp8LfArgs a)
         uint8_t *Y = a.y + (long long)img * a.plane_y;
         uint8_t *P[2] = {a.u + (long long)img * a.plane_uv, a.v + (long long)img * a.plane_uv};
         const uint8_t *mrow = a.modes + ((long long)img * n_mb + (long long)y * a.mbcols) * 20;
-        const uint32_t *prog_up = progress + (long long)img * a.mbrows + y - 1;
-        uint32_t *prog_me = progress + (long long)img * a.mbrows + y;
+        const uint32_t *prog_up = progress + (((long long)img * a.mbrows + y - 1) << a.pshift);
+        uint32_t *prog_me = progress + (((long long)img * a.mbrows + y) << a.pshift);
         unsigned seen = y == 0 ? 0x7fffffffu : 0u;
         /* Running NEXT TO the prediction kernel (another stream of the same call): macroblock (x, y) may be filtered once the
          * prediction has finished (x + 1, y + 1) -- the filter rewrites row 15 and columns 13-15 of what the prediction of the
          * row below and of the right neighbour still reads unfiltered (predict.c reads reconstructed, not filtered, samples),
          * and rows 13-15 of the row above, which the prediction of this row read.  The last row has no row below. */
-        const uint32_t *pred_row = a.pred_progress ? a.pred_progress + (long long)img * a.mbrows + (y + 1 < a.mbrows ? y + 1 : y) : nullptr;
+        const uint32_t *pred_row = a.pred_progress ? a.pred_progress + (((long long)img * a.mbrows + (y + 1 < a.mbrows ? y + 1 : y)) << a.pred_pshift) : nullptr;
         unsigned seen_pred = a.pred_progress ? 0u : 0x7fffffffu, seen_pred_c = seen_pred;
-        const uint32_t *pred_row_c = pred_row ? pred_row + (long long)a.n_images * a.mbrows : nullptr; /* the chroma rows' counters follow the luma rows' */
+        const uint32_t *pred_row_c = pred_row ? pred_row + (((long long)a.n_images * a.mbrows) << a.pred_pshift) : nullptr; /* the chroma rows' counters follow the luma rows' */
         const __amdgpu_buffer_rsrc_t rY = ffhip_rsrc(Y, 256u * (unsigned)n_mb), rU = ffhip_rsrc(P[0], 64u * (unsigned)n_mb),
                                      rV = ffhip_rsrc(P[1], 64u * (unsigned)n_mb);
         const int row_org = y * 16 * ys, row_corg = y * 8 * us;
@@ -402,7 +403,8 @@ extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int fi
     int *async_err = (mode_env && !strcmp(mode_env, "levels")) ? nullptr : ffhip_async_err_word();
     if (async_err && !((uintptr_t)d_modes & 3) && !(((uintptr_t)d_y | (uintptr_t)d_u | (uintptr_t)d_v | (uintptr_t)plane_stride_y | (uintptr_t)plane_stride_uv) & 3) &&
         n_mb < (1LL << 23)) {
-        const size_t words = FFHIP_VP8_LF_CTRL_HDR + (size_t)n_images * (size_t)mbrows;
+        const int pshift = []{ const char *e = FFHIP_ENV("FFHIP_VP8_PROGRESS_SHIFT"); return e ? std::min(5, std::max(0, atoi(e))) : 5; }();
+        const size_t words = FFHIP_VP8_LF_CTRL_HDR + (((size_t)n_images * (size_t)mbrows) << pshift);
         uint32_t *g_work = ffhip_scratch(SCRATCH_VP8_LF, stream, words);
         if (!g_work) return FFHIP_ENOMEM;
         const uint32_t *pred_progress = nullptr;
@@ -413,7 +415,7 @@ extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int fi
         }
         FFHIP_CHECK(hipMemsetAsync(g_work, 0, words * sizeof(uint32_t), st), FFHIP_EIO);
         Vp8LfArgs a = {};
-        a.pred_progress = pred_progress;
+        a.pred_progress = pred_progress; a.pshift = pshift; a.pred_pshift = g_ffhip_vp8_fusion.pshift;
         a.pred_split = pred_progress ? g_ffhip_vp8_fusion.pred_split : 0;
         a.modes = d_modes; a.filters = d_filters; a.y = d_y; a.u = d_u; a.v = d_v;
         a.plane_y = plane_stride_y; a.plane_uv = plane_stride_uv;

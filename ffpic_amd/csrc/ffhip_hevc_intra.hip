@@ -2040,11 +2040,11 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
         const size_t max_waves = wv ? (size_t)std::max(1, atoi(wv)) : FFHIP_HEVC_INTRA_WAVES;
         const size_t resident_waves = wv ? max_waves : (size_t)std::max(FFHIP_HEVC_INTRA_WAVES, ffhip_resident_waves((const void *)k_hevc_intra_groups<2, 64>, 64));
         const size_t resident_waves_tp = wv ? max_waves : (size_t)std::max(FFHIP_HEVC_INTRA_WAVES, ffhip_resident_waves((const void *)k_hevc_intra_groups<3, 16>, 64));
-        /* the throughput instance is OFF by default: measured on the tile grids it changes nothing (eight pictures 4.28 against 4.29 ms, four 2.55
-         * against 2.42) -- eleven waves per CU instead of nine do not make the groups of a depth finish sooner, they wait 76 % of their cycles
-         * (SQ_WAIT_ANY, profiles/r4_hevc_grid8_pmc.txt) for loads whose latency grows with the load.  FFHIP_HEVC_INTRA_TP_WIDTH=<width> turns it on
-         * for plans whose widest wavefront is at least that. */
-        { const char *tw = FFHIP_ENV("FFHIP_HEVC_INTRA_TP_WIDTH"); a.tp_width = tw ? (uint32_t)std::max(0, atoi(tw)) : 0u; }
+        /* The throughput instance (three waves per SIMD, 168 VGPRs) takes plans whose widest wavefront is 3 000 groups and more -- grids of several
+         * pictures: four / eight pictures 1.86 / 3.58 ms against 1.98 / 3.85 with the latency instance; one picture's 135 tiles (width 1 652) are
+         * indifferent (0.78 / 0.77).  While every ticket was an atomic on ONE word in a cache line that waiting waves polled, the extra waves bought
+         * nothing (4.28 against 4.29 ms at eight pictures) and the instance was off.  FFHIP_HEVC_INTRA_TP_WIDTH=<width> moves the threshold, 0 = never. */
+        { const char *tw = FFHIP_ENV("FFHIP_HEVC_INTRA_TP_WIDTH"); a.tp_width = tw ? (uint32_t)std::max(0, atoi(tw)) : 3000u; }
         { const char *pr = FFHIP_ENV("FFHIP_HEVC_INTRA_POLL_REPS"); a.poll_reps = pr ? (uint32_t)std::max(1, atoi(pr)) : 1u; }
         { const char *tsx = FFHIP_ENV("FFHIP_HEVC_TICKET_SHARDS"); a.ticket_shards = tsx ? (uint32_t)std::min(8, std::max(1, atoi(tsx))) : 4u; }
         { const char *wp = FFHIP_ENV("FFHIP_HEVC_INTRA_WIDTH_PCT"); a.width_pct = wp ? (uint32_t)std::max(1, atoi(wp)) : 128u; }

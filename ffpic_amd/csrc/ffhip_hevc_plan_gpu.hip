@@ -48,6 +48,8 @@ struct PlanArgs {
     uint32_t *result;      /* [0] fail, [1] number of runs, [2] wait entries, [3] no wavefront keys, [4] the widest wavefront:
                               the largest number of runs that share a dependency depth */
     uint32_t wait_cap;     /* words reserved for wait_idx                           */
+    uint32_t wsub_n;       /* slices in use: a power of two, at most PLAN_WSUB, never more than blocks of 256 TUs */
+    uint32_t *wsub;        /* PLAN_WSUB counters, one per 128-byte line: wait entries handed out of slice r of wait_idx */
     uint32_t *cell_claim;  /* per 64x64-luma cell and plane: TU that opened it, ~0 = none (is the CTB 64?) */
     uint32_t *cell_edges;  /* bit 0 left, 1 above, 2 above-left, 3 above-right: cells this cell's TUs read */
     uint32_t *cell_depth;  /* longest chain of such edges ending here: the wavefront index of the cell     */
@@ -484,6 +486,7 @@ __device__ __forceinline__ bool for_each_dep(const PlanArgs &a, const uint32_t i
     return ok;
 }
 
+#define PLAN_WSUB 32
 #define PLAN_STASH 6 /* waited-for TUs a lane keeps in LDS between counting them and knowing where its wait entries go; a TU with more walks its edges again */
 __global__ __launch_bounds__(256) void k_plan_count(PlanArgs a)
 {
@@ -519,7 +522,18 @@ __global__ __launch_bounds__(256) void k_plan_count(PlanArgs a)
     /* room in the wait list: this block's entries together, reserved by ONE atomic add (result[2] ends up as the total) */
     uint32_t total;
     const uint32_t off = block_excl_scan((uint32_t)nd, wsum, &total);
-    if (threadIdx.x == 0) blk_base = total ? atomicAdd(a.result + 2, total) : 0u;
+    if (threadIdx.x == 0) {
+        /* (one counter for the whole list was 7 000 returning atomics on one word, a block of 256 TUs waiting for each: the list is cut into
+         * PLAN_WSUB slices, blocks take their room from slice blockIdx mod PLAN_WSUB; a slice that runs over refuses the plan like the whole
+         * list running over did) */
+        const uint32_t r = blockIdx.x & (a.wsub_n - 1), slice = a.wait_cap / a.wsub_n;
+        uint32_t got = 0;
+        if (total) {
+            got = atomicAdd(a.wsub + 32 * r, total);
+            if (got + total > slice) { a.result[0] = 1; got = 0; }
+        }
+        blk_base = r * slice + got;
+    }
     __syncthreads();
     if (!live) return;
     const uint32_t wb = blk_base + off;
@@ -689,6 +703,8 @@ static PlanLayout plan_layout(PlanArgs &a, uint32_t *base, const ffhip_hevc_tu *
     a.gstart = p; p += n + 2;
     a.flags = (uint8_t *)p; p += (n + 3) / 4 + 4;   /* flags | result: adjacent, cleared together */
     a.result = p; p += 16;
+    a.wsub_n = 1; while (a.wsub_n < PLAN_WSUB && 2 * (size_t)a.wsub_n <= L.n_blocks) a.wsub_n *= 2;
+    a.wsub = p ? p + ((32 - (((uintptr_t)p >> 2) & 31)) & 31) : p; p += 32 * PLAN_WSUB + 32; /* (cleared with flags | result) */
     a.cell_claim = p; p += cells;
     L.zero_cells = p;
     a.cell_edges = p; p += cells;
@@ -754,7 +770,7 @@ extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long
     {
         PlanInit in;
         in.p[0] = (uint32_t *)a.owner; in.words[0] = blocks + wins; in.value[0] = ~0u;
-        in.p[1] = (uint32_t *)a.flags; in.words[1] = (n + 3) / 4 + 4 + 16; in.value[1] = 0u;
+        in.p[1] = (uint32_t *)a.flags; in.words[1] = (n + 3) / 4 + 4 + 16 + 32 * PLAN_WSUB + 32; in.value[1] = 0u;
         in.p[2] = a.cell_claim; in.words[2] = cells; in.value[2] = ~0u;
         in.p[3] = Lo.zero_cells; in.words[3] = Lo.zero_cells_words; in.value[3] = 0u;
         in.p[4] = also_zero; in.words[4] = also_zero ? also_zero_words : 0; in.value[4] = 0u;

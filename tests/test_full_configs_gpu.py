@@ -88,7 +88,8 @@ def test_4k_batches_of_the_other_layouts(h, v):
     _jpeg_full_batch(cols, rows, 64, 3, seed=4100 + 10 * h + v, h=h, v=v)
 
 
-def _intra_full_picture(W, H, tus, res):
+def _intra_full_picture(W, H, tus, res, envs=({},), monkeypatch=None):
+    """... once per entry of `envs` (library switches for the call: the oracle's picture is worked out once)"""
     torch = pytest.importorskip("torch")
     L = capi.require_device()
     dev = torch.device("cuda:0")
@@ -99,17 +100,24 @@ def _intra_full_picture(W, H, tus, res):
     pu = torch.zeros((H // 2, W // 2), dtype=torch.int16, device=dev)
     pv = torch.zeros_like(pu)
     st = torch.cuda.current_stream().cuda_stream
-    for rep in range(2):                                   # the second call reuses the per-stream scratch and schedule buffers
-        for p in (py, pu, pv):
-            p.zero_()
-        capi.check(L.ffhip_hevc_intra_recon(tus.ctypes.data, dt.data_ptr(), len(tus), dr.data_ptr(), py.data_ptr(), pu.data_ptr(),
-                                            pv.data_ptr(), W, H, W, W // 2, H // 2, W // 2, 8, 8, st), "ffhip_hevc_intra_recon")
-        capi.check(L.ffhip_stream_sync(st), "sync")
-        for got, e, name in zip((py, pu, pv), exp, "YUV"):
-            g = got.cpu().numpy()
-            if not np.array_equal(g, e):
-                ys, xs = np.nonzero(g != e)
-                raise AssertionError(f"{name} plane differs in {len(ys)} samples (pass {rep}), first at x={xs[0]} y={ys[0]}")
+    for env in envs:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        capi.reload_env()
+        for rep in range(2):                               # the second call reuses the per-stream scratch and schedule buffers
+            for p in (py, pu, pv):
+                p.zero_()
+            capi.check(L.ffhip_hevc_intra_recon(tus.ctypes.data, dt.data_ptr(), len(tus), dr.data_ptr(), py.data_ptr(), pu.data_ptr(),
+                                                pv.data_ptr(), W, H, W, W // 2, H // 2, W // 2, 8, 8, st), "ffhip_hevc_intra_recon")
+            capi.check(L.ffhip_stream_sync(st), "sync")
+            for got, e, name in zip((py, pu, pv), exp, "YUV"):
+                g = got.cpu().numpy()
+                if not np.array_equal(g, e):
+                    ys, xs = np.nonzero(g != e)
+                    raise AssertionError(f"{name} plane differs in {len(ys)} samples (pass {rep}, {env}), first at x={xs[0]} y={ys[0]}")
+        for k in env:
+            monkeypatch.delenv(k)
+        capi.reload_env()
     return exp
 
 
@@ -140,10 +148,11 @@ def test_c5_48_tile_grid():
         assert np.array_equal(exp[0][:, i * T:(i + 1) * T], exp[0][:, :T])
 
 
-def test_c5_135_tile_8k_grid():
+def test_c5_135_tile_8k_grid(monkeypatch):
     """BASELINE configs[4] reads "single 8K tile grid": an 8K picture as a HEIF grid of 15 x 9 = 135 independent 512x512 tiles
     (7680x4608; the tile loop this replaces is heif.c:297-309), all tiles in ONE plane set and ONE ffhip_hevc_intra_recon call, against
-    the oracle over the whole plane set; every tile is the same picture."""
+    the oracle over the whole plane set; every tile is the same picture.  As shipped, with the throughput instance of the grouped kernel
+    forced (larger grids take it by themselves), and with the single ticket counter."""
     T, gx, gy = 512, 15, 9
     t0, res0 = synth.hevc_intra_tus(T, T, seed=6)
     K = gx * gy
@@ -153,7 +162,8 @@ def test_c5_135_tile_8k_grid():
     tus["x"] = (tus["x"].astype(np.int64) + (k % gx) * sc).astype(np.uint16)
     tus["y"] = (tus["y"].astype(np.int64) + (k // gx) * sc).astype(np.uint16)
     tus["res_offset"] += (k * len(res0)).astype(np.uint32)
-    exp = _intra_full_picture(T * gx, T * gy, tus, np.tile(res0, K))
+    exp = _intra_full_picture(T * gx, T * gy, tus, np.tile(res0, K), envs=({}, {"FFHIP_HEVC_INTRA_TP_WIDTH": "1"}, {"FFHIP_HEVC_TICKET_SHARDS": "1"}, {"FFHIP_HEVC_TICKET_SHARDS": "8"}),
+                              monkeypatch=monkeypatch)
     for i in range(1, K):
         ox, oy = (i % gx) * T, (i // gx) * T
         assert np.array_equal(exp[0][oy:oy + T, ox:ox + T], exp[0][:T, :T]), i

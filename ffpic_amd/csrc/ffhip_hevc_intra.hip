@@ -1585,9 +1585,7 @@ extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, 
 extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long n_tus, const int pw[3], const int ph[3], const int wl[3],
                                            uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
                                            int *n_groups, const uint32_t **d_result, uint32_t *wait_cap_out, const int *check, int *async_err,
-                                           int (*after_check)(void *, const uint32_t *),
-                                           int (*after_count)(void *, const uint8_t *, const uint32_t *, const uint32_t *), void *hook_ctx, uint32_t *also_zero,
-                                           size_t also_zero_words);
+                                           const FfhipPlanHooks *hooks, uint32_t *also_zero, size_t also_zero_words);
 
 struct GroupPlan {
     std::vector<u32x4> sched;  /* 3 per slot */
@@ -2012,7 +2010,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
     /* The substitution table depends on the TU list alone: for large lists it is built on the calling thread's side stream, NEXT TO the planner's
      * kernels (which are chains of dependent loads with the chip mostly idle), and joined in front of the first kernel that reads it. */
     bool jt_forked = false;
-    FfhipSide side = {nullptr, nullptr, nullptr, nullptr};
+    FfhipSide side = {nullptr, nullptr, nullptr, nullptr, nullptr};
     auto enqueue_jtable = [&](uint32_t *words, bool may_fork) -> int {
         ja.tus = d_tus; ja.n = (uint32_t)n_tus; ja.jt = (uint8_t *)words;
         a.jt = ja.jt;
@@ -2090,32 +2088,65 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
              * instead, from the TU records alone, with k_plan_emit settling the slot words afterwards -- the programs read no table any more --
              * they ran next to k_plan_owner and k_plan_count, which then took 341 and 383 us instead of 135 and 223: the eight-picture grid's
              * pre-pass 1.14 ms instead of 1.00.) */
-            bool programs_forked = false;
+            /* The side stream takes, behind the table: the depth sweep of the planner's cells (behind k_plan_owner, NEXT TO k_plan_count: three
+             * workgroups that walk diagonals for 50 - 130 us), then -- behind k_plan_count -- the ticket kernels and k_plan_emit.  The per-pixel
+             * programs, the one large kernel of that stretch, follow k_plan_count on `stream` itself, from what that kernel left (TU record,
+             * flag byte, wait count: the slots' other quarters are being written next door).  (Until late in round 4 the programs were the side
+             * stream's and the sweep ran next to them on `stream`: 360 us instead of 130, the long pole of the pre-pass.) */
+            bool programs_forked = false, tickets_aside = false;
+            auto ticket_stream = [&]() -> void * {
+                if (!jt_forked || FFHIP_ENV("FFHIP_HEVC_SWEEP_INLINE") || FFHIP_ENV("FFHIP_HEVC_PROGRAMS_INLINE")) return nullptr;
+                if (hipEventRecord((hipEvent_t)side.fork, st) != hipSuccess || hipStreamWaitEvent((hipStream_t)side.stream, (hipEvent_t)side.fork, 0) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return nullptr;
+                }
+                tickets_aside = true;
+                return side.stream;
+            };
             auto programs_early = [&](const uint8_t *flags, const uint32_t *wcount, const uint32_t *result) -> int {
                 if (!jt_forked) return FFHIP_OK; /* a small list: everything on `stream`, in order */
-                FFHIP_CHECK(hipEventRecord((hipEvent_t)side.mid, st), FFHIP_EIO);
-                FFHIP_CHECK(hipStreamWaitEvent((hipStream_t)side.stream, (hipEvent_t)side.mid, 0), FFHIP_EIO);
                 pa.tus = d_tus; pa.flags = flags; pa.wcount = wcount; pa.refused = nullptr;
                 a.sched = (const u32x4 *)g_work; /* where the planner puts the slots (ffhip_hevc_plan_gpu's layout starts with them) */
                 a.plan_result = result; a.wait_cap = (uint32_t)(8 * (size_t)n_tus);
-                enqueue_programs(jt_words + w_jt, win, (size_t)n_tus, (hipStream_t)side.stream);
-                FFHIP_CHECK(hipEventRecord((hipEvent_t)side.join, (hipStream_t)side.stream), FFHIP_EIO);
+                if (tickets_aside) { /* on `stream`, right behind k_plan_count -- and behind the point the ticket kernels wait for */
+                    FFHIP_CHECK(hipEventRecord((hipEvent_t)side.mid, st), FFHIP_EIO);
+                    enqueue_programs(jt_words + w_jt, win, (size_t)n_tus, st);
+                } else { /* the sweep and the ticket kernels stay on `stream`: the programs go next to them */
+                    FFHIP_CHECK(hipEventRecord((hipEvent_t)side.mid, st), FFHIP_EIO);
+                    FFHIP_CHECK(hipStreamWaitEvent((hipStream_t)side.stream, (hipEvent_t)side.mid, 0), FFHIP_EIO);
+                    enqueue_programs(jt_words + w_jt, win, (size_t)n_tus, (hipStream_t)side.stream);
+                    FFHIP_CHECK(hipEventRecord((hipEvent_t)side.join, (hipStream_t)side.stream), FFHIP_EIO);
+                }
                 programs_forked = true;
                 return FFHIP_OK;
             };
-            struct Hook { decltype(enqueue_jtable) *fn; decltype(programs_early) *pe; uint32_t *words; JTabArgs *ja; } hook = {&enqueue_jtable, &programs_early, jt_words, &ja};
-            auto after_check = [](void *ctx, const uint32_t *refused) -> int {
+            auto tickets_wait = [&]() -> int {
+                FFHIP_CHECK(hipStreamWaitEvent((hipStream_t)side.stream, (hipEvent_t)side.mid, 0), FFHIP_EIO); /* recorded behind k_plan_count, in front of the programs */
+                return FFHIP_OK;
+            };
+            auto tickets_enqueued = [&]() -> int {
+                FFHIP_CHECK(hipEventRecord((hipEvent_t)side.join, (hipStream_t)side.stream), FFHIP_EIO);
+                return FFHIP_OK;
+            };
+            struct Hook { decltype(enqueue_jtable) *fn; decltype(programs_early) *pe; uint32_t *words; JTabArgs *ja; decltype(ticket_stream) *ts; decltype(tickets_wait) *tw;
+                          decltype(tickets_enqueued) *te; } hook = {&enqueue_jtable, &programs_early, jt_words, &ja, &ticket_stream, &tickets_wait, &tickets_enqueued};
+            FfhipPlanHooks hooks = {};
+            hooks.ctx = &hook;
+            hooks.after_check = [](void *ctx, const unsigned *refused) -> int {
                 Hook *h = (Hook *)ctx;
                 h->ja->refused = refused;
                 return (*h->fn)(h->words, true);
             };
-            auto after_count = [](void *ctx, const uint8_t *flags, const uint32_t *wcount, const uint32_t *result) -> int {
-                Hook *h = (Hook *)ctx;
-                return (*h->pe)(flags, wcount, result);
-            };
+            hooks.ticket_stream = [](void *ctx) -> void * { return (*((Hook *)ctx)->ts)(); };
+            hooks.tickets_wait = [](void *ctx) -> int { return (*((Hook *)ctx)->tw)(); };
+            hooks.tickets_enqueued = [](void *ctx) -> int { return (*((Hook *)ctx)->te)(); };
+            if (!FFHIP_ENV("FFHIP_HEVC_PROGRAMS_INLINE"))
+                hooks.after_count = [](void *ctx, const unsigned char *flags, const unsigned *wcount, const unsigned *result) -> int {
+                    return (*((Hook *)ctx)->pe)(flags, wcount, result);
+                };
             const int check[2] = {(d_cb && d_cr && uv_stride >= width_c) ? 1 : 0, d_residual ? 1 : 0};
             const int prc = ffhip_hevc_plan_gpu_checked(d_tus, n_tus, pwc, ph, win, g_work, st, &a.sched, &a.groups, &a.wait_idx, &n_groups, &a.plan_result, &a.wait_cap,
-                                                        big_list ? check : nullptr, async_err, after_check, FFHIP_ENV("FFHIP_HEVC_PROGRAMS_INLINE") ? nullptr : after_count, &hook,
+                                                        big_list ? check : nullptr, async_err, &hooks,
                                                         g_work + ((w_plan + 3) & ~(size_t)3), w_ctrl /* the ticket counter and the done flags: cleared by the planner's first launch */);
             if (prc < 0) { (void)join_jtable(); return prc; } /* (`stream` must not run ahead of the side stream's read of the caller's list) */
             a.ctrl = g_work + ((w_plan + 3) & ~(size_t)3);

@@ -114,7 +114,14 @@ __global__ __launch_bounds__(256) void k_plan_scan(const uint32_t *v, uint32_t *
     __builtin_amdgcn_s_setprio(3);
     const uint32_t base = blockIdx.x * 4096u;
     uint32_t s = 0;
-    for (uint32_t i = threadIdx.x; i < base; i += 256) s += v[i];
+    { /* eight loads in flight per thread: one after the other they were up to 112 trips to memory in a row (0.2 ms next to a kernel that fills the chip) */
+        uint32_t s8[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        for (uint32_t i = threadIdx.x; i < base; i += 8 * 256) {
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) s8[u] += i + u * 256 < base ? v[i + u * 256] : 0u;
+        }
+        s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += (uint32_t)__shfl_xor((int)s, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -131,13 +138,26 @@ __global__ __launch_bounds__(256) void k_plan_scan(const uint32_t *v, uint32_t *
         if (i + k < n) out[i + k] = run;
         run += x[k];
     }
-    if (vmax) {
-        const uint32_t gend = ((base + 4096u < n ? base + 4096u : n) >> group_log2);
+    if (vmax) { /* group totals from what the threads hold (a loop of loads per group was up to 64 trips to memory in a row) */
+        __shared__ uint32_t tsum[256];
         uint32_t mx = 0;
-        for (uint32_t g = (base >> group_log2) + threadIdx.x; g < gend; g += 256) {
-            uint32_t t = 0;
-            for (uint32_t e = 0; e < (1u << group_log2); e++) t += v[(g << group_log2) + e];
-            mx = t > mx ? t : mx;
+        if (group_log2 >= 4) { /* a group is 1, 2 or 4 threads' sixteen entries */
+            const uint32_t gt = 1u << (group_log2 - 4);
+            tsum[threadIdx.x] = mine;
+            __syncthreads();
+            if ((threadIdx.x & (gt - 1)) == 0)
+                for (uint32_t q = 0; q < gt; q++) mx += tsum[threadIdx.x + q];
+        } else { /* several groups inside a thread's sixteen entries */
+            const uint32_t gs = 1u << group_log2;
+#pragma unroll
+            for (uint32_t g0 = 0; g0 < 16; g0++) {
+                uint32_t t = 0;
+                if ((g0 & (gs - 1)) == 0) {
+#pragma unroll
+                    for (uint32_t q = 0; q < 8; q++) t += (q < gs && g0 + q < 16) ? x[(g0 + q) & 15] : 0u;
+                    mx = t > mx ? t : mx;
+                }
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)mx, o, 64); mx = t > mx ? t : mx; }
@@ -202,6 +222,26 @@ __device__ __forceinline__ bool plan_owner_tu(const PlanArgs &a, const uint32_t 
     const uint32_t cellp = a.cell_off[tp.cidx] + (uint32_t)(tp.y >> a.cshift[tp.cidx]) * a.cgw[tp.cidx] + (uint32_t)(tp.x >> a.cshift[tp.cidx]);
     if (i == 0 || cell != cellp)
         if (atomicCAS(a.cell_claim + cell, ~0u, i) != ~0u) a.result[3] = 1; /* a cell entered twice: no wavefront keys */
+    /* Which neighbouring cells this cell's TUs read -- the edges the depth sweep runs over -- from where the TU's AVAILABLE neighbours lie:
+     * geometry and the masks alone.  (k_plan_count found them among the dependencies it counted, earlier TUs of other runs only; this is a
+     * superset -- a neighbour marked available that no earlier TU wrote adds an edge the wait list will not have, which only deepens a cell --
+     * and it lets the sweep start behind THIS kernel, next to k_plan_count, instead of behind that one.)  A neighbour in a cell no
+     * coding-tree wavefront has in front of this one (right of it in the same row, or below) keeps the tickets in decode order. */
+    {
+        const int cs = 1 << a.cshift[c], lx = t.x & (cs - 1), ly = t.y & (cs - 1), n2 = 2 << t.log2_size;
+        const unsigned long long span = n2 >= 64 ? ~0ull : (1ull << n2) - 1;
+        const unsigned long long top = t.avail_top & span, left = t.avail_left & span;
+        const int in_x = cs - lx, in_y = cs - ly; /* neighbour columns / rows that still belong to my cell's column / row of cells */
+        const unsigned long long top_in = in_x >= 64 ? top : top & ((1ull << in_x) - 1), left_in = in_y >= 64 ? left : left & ((1ull << in_y) - 1);
+        unsigned edges = 0;
+        bool odd = (left != left_in);                    /* left of me, but in the row of cells below */
+        if (ly == 0) edges |= (top_in ? 2u : 0u) | (top != top_in ? 8u : 0u);
+        else odd |= (top != top_in);                     /* the cell to the right, same row */
+        if (lx == 0 && left_in) edges |= 1u;
+        if (t.flags & 1) edges |= (lx == 0 && ly == 0) ? 4u : (lx == 0 ? 1u : (ly == 0 ? 2u : 0u));
+        if (odd) a.result[3] = 1;
+        if (edges) atomicOr(a.cell_edges + cell, edges);
+    }
     return starts;
 }
 
@@ -285,7 +325,7 @@ __global__ __launch_bounds__(1024) void k_plan_cell_depth(PlanArgs a)
         if (w >= nw) return; /* (a wave that has ended is not waited for at a barrier) */
         const bool row = yl < gh;
         const uint32_t rowbase = row ? yl * gw : 0u, gwv = row ? gw : 0u; /* a lane beyond the last row never has a cell */
-        const uint32_t iters = (gw - 1) + 2 * (gh - 1) + 1 + (nw - 1) * DEPTH_SKEW;
+        const uint32_t iters = ((gw - 1) + 2 * (gh - 1) + 1 + (nw - 1) * DEPTH_SKEW + 3) & ~3u; /* a multiple of four: results leave in fours */
         const __amdgpu_buffer_rsrc_t drs = ffhip_rsrc(dg, cnt * 4u);
         const unsigned short *up_edge = edge[w ? w - 1 : 0];
         unsigned short *my_edge = edge[w];
@@ -298,7 +338,7 @@ __global__ __launch_bounds__(1024) void k_plan_cell_depth(PlanArgs a)
         };
         uint32_t K = 0u - w * DEPTH_SKEW; /* wraps far beyond every diagonal while the wave has not started */
         uint32_t x = K - 2 * yl;          /* ... and where the row has not started */
-        uint32_t h1 = 0, n2 = 0, n3 = 0;
+        uint32_t h1 = 0, n2 = 0, n3 = 0, d4[4] = {0u, 0u, 0u, 0u};
         uint32_t e = load_e(x), ev = up_edge[(K - 1) & (DEPTH_RING - 1)];
         for (uint32_t T = 0; T < iters; T++) {
             const uint32_t en = load_e(x + 1), evn = up_edge[K & (DEPTH_RING - 1)];
@@ -306,7 +346,22 @@ __global__ __launch_bounds__(1024) void k_plan_cell_depth(PlanArgs a)
             n1 = l0 ? ev : n1;
             const uint32_t b0 = e & 1u, b1 = (e >> 1) & 1u, b2 = (e >> 2) & 1u, b3 = e >> 3;
             const uint32_t v = max(max(__umul24(h1, b0) + b0, __umul24(n2, b1) + b1), max(__umul24(n3, b2) + b2, __umul24(n1, b3) + b3));
-            __builtin_amdgcn_raw_buffer_store_b32(v, drs, x < gwv ? 4u * (rowbase + x) : 0x80000000u, 0, 0);
+            /* results leave four steps at a time (a lane's cells of consecutive steps are consecutive words): a store per step was a vector-memory
+             * instruction per step that had to find room in the CU's memory pipeline -- next to a kernel that keeps that pipeline full (the
+             * sweep runs beside k_plan_count) the sweep took four times as long as alone */
+            d4[T & 3] = v;
+            if ((T & 3) == 3) {
+                const uint32_t x0 = x - 3; /* the four cells x0 .. x0 + 3 (x0 may have wrapped: then none or some are cells) */
+                const bool all4 = x0 < gwv && x < gwv;
+                if (__builtin_amdgcn_ballot_w64(!all4 && (x0 < gwv || x < gwv || x0 + 1 < gwv || x0 + 2 < gwv)) == 0) {
+                    const u32x4 q = {d4[0], d4[1], d4[2], d4[3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(q, drs, all4 ? 4u * (rowbase + x0) : 0x80000000u, 0, 0);
+                } else {
+#pragma unroll
+                    for (uint32_t e = 0; e < 4; e++)
+                        __builtin_amdgcn_raw_buffer_store_b32(d4[e], drs, x0 + e < gwv ? 4u * (rowbase + x0 + e) : 0x80000000u, 0, 0);
+                }
+            }
             if (l63) my_edge[K & (DEPTH_RING - 1)] = (unsigned short)v;
             n3 = n2; n2 = n1; h1 = v; e = en; ev = evn;
             x++; K++;
@@ -352,6 +407,97 @@ __global__ __launch_bounds__(1024) void k_plan_cell_depth(PlanArgs a)
             __threadfence();
             __syncthreads();
         }
+    }
+}
+
+/* The same depths ROW BY ROW, for planes of up to 1024 columns of cells (a 65 536-sample line): a lane per column, one step per row of cells
+ * -- gh steps where the diagonal sweep above takes gw + 2 gh (an eight-picture grid of 480 x 144 cells: 144 against 766; the sweep is a chain
+ * of dependent instructions in three workgroups, and next to a kernel that fills the chip every instruction of it waits its turn: 130 us
+ * alone, 360 - 510 us there).  Inside a row the only dependency is on the cell to the left, d[x] = max(a[x], d[x - 1] + 1) where the cell has
+ * that edge, a[x] from the row above: a prefix scan over functions d -> max(A, d + B), which compose to functions of the same form.
+ * An element is (A, Be): Be = 0 "no edge to the left" (the function is the constant A), else the shift + 1. */
+__device__ __forceinline__ void depth_compose(uint32_t &A2, uint32_t &B2e, const uint32_t A1, const uint32_t B1e) /* (2) after (1), into (2) */
+{
+    const uint32_t sh2 = B2e - 1;
+    const uint32_t A = max(A2, A1 + sh2), Be = B1e ? B1e + sh2 : 0u;
+    A2 = B2e ? A : A2;
+    B2e = B2e ? Be : 0u;
+}
+__global__ __launch_bounds__(1024) void k_plan_cell_depth_rows(PlanArgs a)
+{
+    if (a.result[6]) return; /* the list was refused by k_hevc_check_tus */
+    __shared__ unsigned char el[CELLS_LDS / 2];
+    __shared__ unsigned short rowbuf[2][1024 + 2];
+    __shared__ uint32_t wtA[16], wtB[16];
+    const int c = blockIdx.x;
+    const uint32_t gw = a.cgw[c], gh = a.cgh[c];
+    if (gw == 0 || gh == 0) return;
+    const uint32_t x = threadIdx.x, w = x >> 6, lane = x & 63, nw = (gw + 63) >> 6, cnt = gw * gh;
+    uint32_t *dg = a.cell_depth + a.cell_off[c];
+    const uint32_t *eg = a.cell_edges + a.cell_off[c];
+    for (uint32_t i = x; i < 2 * (1024 + 2); i += blockDim.x) (&rowbuf[0][0])[i] = 0;
+    /* the plane's edge bits, two cells to a byte, fetched by the whole workgroup up front: a load from memory per row -- even one issued a
+     * row ahead -- was a trip to memory per step of the chain (3.5 us a row next to a kernel that fills the chip) */
+#pragma unroll 4
+    for (uint32_t k = x; 2 * k < cnt; k += blockDim.x)
+        el[k] = (unsigned char)((eg[2 * k] & 15u) | (2 * k + 1 < cnt ? (eg[2 * k + 1] & 15u) << 4 : 0u));
+    __syncthreads();
+    if (w >= nw) return; /* (a wave that has ended is not waited for at a barrier) */
+    const bool col = x < gw;
+    /* edge bits a cell cannot have, by column: left / above-left of column 0, above-right of the last column (the row above is all zeros
+     * for row 0: its bits do no harm) */
+    const uint32_t keep = col ? ((x > 0 ? 5u : 0u) | 2u | (x + 1 < gw ? 8u : 0u)) : 0u;
+    auto bits = [&](const uint32_t y) -> uint32_t {
+        const uint32_t k = (col && y < gh) ? y * gw + x : 0u;
+        return ((uint32_t)el[k >> 1] >> (4 * (k & 1))) & keep;
+    };
+    uint32_t e = bits(0) & ~14u; /* row 0: nothing above */
+    for (uint32_t y = 0; y < gh; y++) {
+        const unsigned short *prev = rowbuf[y & 1];
+        unsigned short *cur = rowbuf[(y & 1) ^ 1];
+        const uint32_t en = bits(y + 1); /* the next row's bits */
+        const uint32_t pl = prev[x], pu = prev[x + 1], pr = prev[x + 2]; /* rowbuf[.][1 + column] */
+        uint32_t A = max(max((e & 2u) ? pu + 1 : 0u, (e & 4u) ? pl + 1 : 0u), (e & 8u) ? pr + 1 : 0u);
+        uint32_t Be = (e & 1u) ? 2u : 0u;
+        /* inclusive scan inside the wave: offsets 1 .. 8 inside rows of sixteen lanes (DPP row_shr), then the rows one after the other */
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            uint32_t A1, B1;
+            if (o == 1) { A1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)A, 0x111, 0xf, 0xf, false); B1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Be, 0x111, 0xf, 0xf, false); }
+            else if (o == 2) { A1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)A, 0x112, 0xf, 0xf, false); B1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Be, 0x112, 0xf, 0xf, false); }
+            else if (o == 4) { A1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)A, 0x114, 0xf, 0xf, false); B1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Be, 0x114, 0xf, 0xf, false); }
+            else { A1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)A, 0x118, 0xf, 0xf, false); B1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Be, 0x118, 0xf, 0xf, false); }
+            uint32_t A2 = A, B2 = Be;
+            depth_compose(A2, B2, A1, B1);
+            const bool has = (int)(lane & 15) >= o;
+            A = has ? A2 : A; Be = has ? B2 : Be;
+        }
+#pragma unroll
+        for (int r = 1; r < 4; r++) { /* rows 1, 2, 3 of the wave take the (finished) last lane of the row before */
+            const uint32_t A1 = (uint32_t)__builtin_amdgcn_readlane((int)A, 16 * r - 1), B1 = (uint32_t)__builtin_amdgcn_readlane((int)Be, 16 * r - 1);
+            uint32_t A2 = A, B2 = Be;
+            depth_compose(A2, B2, A1, B1);
+            const bool mine = (int)(lane >> 4) == r;
+            A = mine ? A2 : A; Be = mine ? B2 : Be;
+        }
+        if (nw > 1) { /* the waves in front of mine: their totals through LDS, composed in order */
+            if (lane == 63) { wtA[w] = A; wtB[w] = Be; }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            uint32_t PA = 0, PB = 0; /* of nothing: the constant 0 */
+            for (uint32_t q = 0; q < w; q++) {
+                uint32_t A2 = wtA[q], B2 = wtB[q];
+                depth_compose(A2, B2, PA, PB);
+                PA = A2; PB = B2;
+            }
+            if (w) depth_compose(A, Be, PA, PB);
+        }
+        /* (the row's first cell has no edge to the left: every prefix is a constant by now, A is the depth) */
+        if (col) {
+            cur[x + 1] = (unsigned short)A;
+            dg[(size_t)y * gw + x] = A;
+        }
+        e = en;
+        if (nw > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
 
@@ -498,7 +644,6 @@ __global__ __launch_bounds__(256) void k_plan_count(PlanArgs a)
     const bool live = i < a.n;
     int nd = 0;
     bool ok = true;
-    unsigned edges = 0;
     ffhip_hevc_tu t = {};
     int c = 0, cx = 0, cy = 0;
     if (live) {
@@ -508,14 +653,6 @@ __global__ __launch_bounds__(256) void k_plan_count(PlanArgs a)
             if (nd < PLAN_STASH) stash[nd][threadIdx.x] = j;
             nd++;
             atomicOr((unsigned *)(a.flags + (j & ~3u)), 1u << (8 * (j & 3))); /* that TU must publish a done flag */
-            const ffhip_hevc_tu tj = a.tus[j];
-            const int dx = (tj.x >> a.cshift[c]) - cx, dy = (tj.y >> a.cshift[c]) - cy;
-            if (dx == 0 && dy == 0) return;
-            if (dx == -1 && dy == 0) edges |= 1u;
-            else if (dx == 0 && dy == -1) edges |= 2u;
-            else if (dx == -1 && dy == -1) edges |= 4u;
-            else if (dx == 1 && dy == -1) edges |= 8u;
-            else a.result[3] = 1; /* a dependency no coding-tree wavefront has: keep decode order */
         });
         if (nd > 64) a.result[0] = 1; /* more than the kernel's 64 pollers: leave it to the host planner */
     }
@@ -551,7 +688,6 @@ __global__ __launch_bounds__(256) void k_plan_count(PlanArgs a)
     }
     atomicOr((unsigned *)(a.flags + (i & ~3u)), (ok ? 2u : 0u) << (8 * (i & 3)));
     const uint32_t cell = a.cell_off[c] + (uint32_t)cy * a.cgw[c] + (uint32_t)cx;
-    if (edges) atomicOr(a.cell_edges + cell, edges);
     const bool starts = i == 0 || a.runid[i] != a.runid[i - 1];
     if (starts) {
         a.gstart[a.runid[i]] = i;
@@ -740,15 +876,13 @@ extern "C" size_t ffhip_hevc_plan_gpu_words(long long n_tus, const int pw[3], co
 extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long n_tus, const int pw[3], const int ph[3], const int wl[3],
                                            uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
                                            int *n_groups, const uint32_t **d_result, uint32_t *wait_cap_out, const int *check /* NULL, or {chroma_ok,
-                                           have_residual} */, int *async_err, int (*after_check)(void *, const uint32_t *),
-                                           int (*after_count)(void *, const uint8_t *, const uint32_t *, const uint32_t *), void *hook_ctx, uint32_t *also_zero,
-                                           size_t also_zero_words);
+                                           have_residual} */, int *async_err, const FfhipPlanHooks *hooks, uint32_t *also_zero, size_t also_zero_words);
 extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, const int pw[3], const int ph[3], const int wl[3],
                                    uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
                                    int *n_groups, const uint32_t **d_result, uint32_t *wait_cap_out)
 {
     return ffhip_hevc_plan_gpu_checked(d_tus, n_tus, pw, ph, wl, scratch, st, sched, groups, wait_idx, n_groups, d_result, wait_cap_out, nullptr, nullptr,
-                                       nullptr, nullptr, nullptr, nullptr, 0);
+                                       nullptr, nullptr, 0);
 }
 /* ... with the list's validation as the first kernel behind the scratch's reset (check != NULL), a hook that runs once that kernel is
  * enqueued: what the caller starts from there (the substitution table on a side stream) may rely on result[6], handed to the hook; and a
@@ -757,8 +891,7 @@ extern "C" int ffhip_hevc_plan_gpu(const ffhip_hevc_tu *d_tus, long long n_tus, 
 extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long n_tus, const int pw[3], const int ph[3], const int wl[3],
                                            uint32_t *scratch, hipStream_t st, const u32x4 **sched, const u32x4 **groups, const uint32_t **wait_idx,
                                            int *n_groups, const uint32_t **d_result, uint32_t *wait_cap_out, const int *check, int *async_err,
-                                           int (*after_check)(void *, const uint32_t *),
-                                           int (*after_count)(void *, const uint8_t *, const uint32_t *, const uint32_t *), void *hook_ctx, uint32_t *also_zero /* a region of the
+                                           const FfhipPlanHooks *hooks, uint32_t *also_zero /* a region of the
                                            caller's (the grouped kernel's ticket counter and done flags), cleared by the same launch */, size_t also_zero_words)
 {
     PlanArgs a;
@@ -786,39 +919,55 @@ extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long
         k.chroma_ok = check[0]; k.have_residual = check[1]; k.async_err = async_err;
         hipLaunchKernelGGL(k_hevc_check_tus, dim3(grid > 2048 ? 2048u : grid), dim3(256), 0, st, d_tus, (uint32_t)n, k, a.result);
     }
-    if (after_check) {
-        const int hrc = after_check(hook_ctx, a.result + 6);
+    if (hooks && hooks->after_check) {
+        const int hrc = hooks->after_check(hooks->ctx, a.result + 6);
         if (hrc) return hrc;
     }
     hipLaunchKernelGGL(k_plan_owner, dim3(grid), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_plan_scan, dim3((unsigned)((Lo.n_blocks + 4095) / 4096)), dim3(256), 0, st, (const uint32_t *)a.blk_tot, a.blk_pre, (uint32_t)Lo.n_blocks, (uint32_t *)nullptr, 0u,
-                       (const uint32_t *)(a.result + 6));
-    hipLaunchKernelGGL(k_plan_runid, dim3(grid), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_plan_count, dim3(grid), dim3(256), 0, st, a);
-    if (after_count) {
-        const int hrc = after_count(hook_ctx, a.flags, a.wcount, a.result);
-        if (hrc) return hrc;
-    }
-    /* tickets: runs by (wavefront index of their cell, decode order) */
-    {   /* one diagonal per step, at most one cell per row of cells, a lane per row: a picture of up to 64 rows of cells is swept by ONE
-         * wave per plane (a wave-local barrier per step), taller ones by as many waves as they have rows (up to 1024 threads) and a
-         * workgroup barrier per step.  (One wave with three rows per lane: 1.15 us a step on the 144-row plane of an eight-picture grid.) */
+    /* the depth sweep needs the cells' edges, which k_plan_owner has just left: three workgroups walking diagonals for 50 - 130 us -- next to
+     * k_plan_count on a stream of the caller's where there is one, in front of the ticket kernels otherwise */
+    auto enqueue_sweep = [&](hipStream_t ss) {
         uint32_t max_gh = 0;
         for (int c = 0; c < 3; c++) max_gh = a.cgh[c] > max_gh ? a.cgh[c] : max_gh;
         const unsigned threads = max_gh >= 1024 ? 1024u : (unsigned)((max_gh + 63) / 64 * 64);
         bool fast = max_gh <= DEPTH_ROWS;
         for (int c = 0; c < 3; c++) fast = fast && (size_t)a.cgw[c] * a.cgh[c] <= CELLS_LDS;
-        if (fast) hipLaunchKernelGGL(k_plan_cell_depth<true>, dim3(3), dim3(1024), 0, st, a);
-        else hipLaunchKernelGGL(k_plan_cell_depth<false>, dim3(3), dim3(threads ? threads : 64u), 0, st, a);
+        uint32_t max_gw = 0;
+        for (int c = 0; c < 3; c++) max_gw = a.cgw[c] > max_gw ? a.cgw[c] : max_gw;
+        if (max_gw <= 1024 && fast && !FFHIP_ENV("FFHIP_HEVC_DEPTH_DIAGONALS")) /* row by row: planes of up to 65 536 samples a line whose edge bits fit the LDS */
+            hipLaunchKernelGGL(k_plan_cell_depth_rows, dim3(3), dim3(1024), 0, ss, a); /* (1024 threads fetch the edge bits; the waves without columns leave then) */
+        else if (fast) hipLaunchKernelGGL(k_plan_cell_depth<true>, dim3(3), dim3(1024), 0, ss, a);
+        else hipLaunchKernelGGL(k_plan_cell_depth<false>, dim3(3), dim3(threads ? threads : 64u), 0, ss, a);
+    };
+    hipStream_t ts = st; /* the stream of the sweep, the ticket kernels and k_plan_emit */
+    if (hooks && hooks->ticket_stream) {
+        void *ss = hooks->ticket_stream(hooks->ctx);
+        if (ss) {
+            ts = (hipStream_t)ss;
+            enqueue_sweep(ts);
+        }
     }
+    hipLaunchKernelGGL(k_plan_scan, dim3((unsigned)((Lo.n_blocks + 4095) / 4096)), dim3(256), 0, st, (const uint32_t *)a.blk_tot, a.blk_pre, (uint32_t)Lo.n_blocks, (uint32_t *)nullptr, 0u,
+                       (const uint32_t *)(a.result + 6));
+    hipLaunchKernelGGL(k_plan_runid, dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_plan_count, dim3(grid), dim3(256), 0, st, a);
+    if (hooks && hooks->after_count) {
+        const int hrc = hooks->after_count(hooks->ctx, a.flags, a.wcount, a.result);
+        if (hrc) return hrc;
+    }
+    /* tickets: runs by (wavefront index of their cell, decode order).  The sweep: one diagonal per step, at most one cell per row of cells, a
+     * lane per row (k_plan_cell_depth) */
+    if (ts == st) enqueue_sweep(st);
+    else if (hooks->tickets_wait) { const int hrc = hooks->tickets_wait(hooks->ctx); if (hrc) return hrc; }
     const size_t m = n < wins ? n : wins; /* runs <= windows, or the plan is refused (k_plan_count: a window with two runs) */
     const unsigned cgrid = (unsigned)((cells + 255) / 256);
-    hipLaunchKernelGGL(k_plan_cell_hist, dim3(cgrid), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_plan_scan, dim3((unsigned)((((size_t)a.depths << a.shard_log2) + 4095) / 4096)), dim3(256), 0, st, (const uint32_t *)a.hist, a.hist_pre,
+    hipLaunchKernelGGL(k_plan_cell_hist, dim3(cgrid), dim3(256), 0, ts, a);
+    hipLaunchKernelGGL(k_plan_scan, dim3((unsigned)((((size_t)a.depths << a.shard_log2) + 4095) / 4096)), dim3(256), 0, ts, (const uint32_t *)a.hist, a.hist_pre,
                        (uint32_t)(a.depths << a.shard_log2), a.result + 4, a.shard_log2, (const uint32_t *)(a.result + 3));
-    hipLaunchKernelGGL(k_plan_cell_base, dim3(cgrid), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_plan_rank, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a, (uint32_t)m);
-    hipLaunchKernelGGL(k_plan_emit, dim3(grid), dim3(256), 0, st, a, (uint32_t)m);
+    hipLaunchKernelGGL(k_plan_cell_base, dim3(cgrid), dim3(256), 0, ts, a);
+    hipLaunchKernelGGL(k_plan_rank, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ts, a, (uint32_t)m);
+    hipLaunchKernelGGL(k_plan_emit, dim3(grid), dim3(256), 0, ts, a, (uint32_t)m);
+    if (ts != st && hooks->tickets_enqueued) { const int hrc = hooks->tickets_enqueued(hooks->ctx); if (hrc) return hrc; }
     FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
     if (d_result) {
         *sched = a.sched;

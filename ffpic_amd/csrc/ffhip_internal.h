@@ -86,7 +86,8 @@ struct FfhipVp8Fusion {
 extern thread_local FfhipVp8Fusion g_ffhip_vp8_fusion;
 
 /* the calling thread's side stream with its fork / join events (ffhip_vp8_lf.hip: one set per thread and device, released by ffhip_shutdown) */
-struct FfhipSide { void *stream, *fork, *join, *mid; }; /* mid: a second point of the main stream the side stream may wait for */
+struct FfhipSide { void *stream, *fork, *join, *mid, *aux; }; /* mid: a second point of the main stream the side stream may wait for; aux: a second
+                                                                point of the side stream the main stream may wait for */
 extern "C" int ffhip_side_stream_get(FfhipSide *out);
 
 /* bits of a schedule slot's program word (second quarter, .x) that two files know: k_hevc_intra_program writes the word, k_plan_emit adds
@@ -106,5 +107,21 @@ extern "C" int ffhip_side_stream_get(FfhipSide *out);
 #define FFHIP_VP8_CTRL_HDR 128
 #define FFHIP_VP8_LF_CTRL_ABORT 32
 #define FFHIP_VP8_LF_CTRL_HDR 64
+
+/* What ffhip_hevc_intra_recon hangs into the device planner's chain of launches (ffhip_hevc_plan_gpu_checked): everything is optional.
+ *   after_check       behind the list's validation kernel: start what depends on the TU list alone (the substitution table, side stream)
+ *   ticket_stream     behind k_plan_owner: a stream, already waiting for that kernel, that takes the depth sweep NOW -- next to k_plan_count
+ *                     -- and the ticket kernels and k_plan_emit later (NULL: everything in line on the planner's stream)
+ *   after_count       behind k_plan_count: flags and wait counts are final (the per-pixel programs)
+ *   tickets_wait      (ticket_stream given) make that stream wait for k_plan_count, in front of the ticket kernels
+ *   tickets_enqueued  (ticket_stream given) the schedule's last kernel is on that stream: whoever reads the schedule waits for it */
+struct FfhipPlanHooks {
+    void *ctx;
+    int (*after_check)(void *ctx, const unsigned *refused);
+    void *(*ticket_stream)(void *ctx);
+    int (*after_count)(void *ctx, const unsigned char *flags, const unsigned *wcount, const unsigned *result);
+    int (*tickets_wait)(void *ctx);
+    int (*tickets_enqueued)(void *ctx);
+};
 
 #endif

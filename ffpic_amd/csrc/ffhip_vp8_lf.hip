@@ -511,7 +511,7 @@ extern "C" int ffhip_vp8_filter_params(const ffhip_vp8_filter_header *h, uint8_t
  * use, recreated when the thread's current device has changed, released by ffhip_shutdown (ffhip_vp8_release_side_streams)
  * or when the thread ends. */
 namespace {
-struct SideStream { int device = -1; hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr, mid = nullptr; };
+struct SideStream { int device = -1; hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr, mid = nullptr, aux = nullptr; };
 std::mutex g_side_mu;
 std::vector<SideStream *> g_sides;
 void side_release(SideStream *s)
@@ -520,7 +520,8 @@ void side_release(SideStream *s)
     if (s->fork) (void)hipEventDestroy(s->fork);
     if (s->join) (void)hipEventDestroy(s->join);
     if (s->mid) (void)hipEventDestroy(s->mid);
-    s->side = nullptr; s->fork = s->join = s->mid = nullptr; s->device = -1;
+    if (s->aux) (void)hipEventDestroy(s->aux);
+    s->side = nullptr; s->fork = s->join = s->mid = s->aux = nullptr; s->device = -1;
 }
 struct SideHolder {
     SideStream s;
@@ -540,8 +541,15 @@ SideStream *side_stream_for_this_thread()
     std::lock_guard<std::mutex> l(g_side_mu);
     if (h.s.side && h.s.device != dev) side_release(&h.s);
     if (!h.s.side) {
-        if (hipStreamCreateWithFlags(&h.s.side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h.s.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h.s.join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h.s.mid, hipEventDisableTiming) != hipSuccess) {
+        /* the highest priority the device has: what runs here is the SHORT chain next to a large kernel of the caller's stream (the HEVC planner's
+         * ticket kernels next to the per-pixel programs: a few workgroups each, which otherwise queue behind thousands), or, in the VP8
+         * side-by-side call, a kernel whose share of the residency is its own (FFHIP_SIDE_PRIORITY=0: the default priority) */
+        int least = 0, greatest = 0;
+        const bool high = !FFHIP_ENV("FFHIP_SIDE_PRIORITY") || atoi(FFHIP_ENV("FFHIP_SIDE_PRIORITY")) != 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+        if (hipStreamCreateWithPriority(&h.s.side, hipStreamNonBlocking, high ? greatest : 0) != hipSuccess || hipEventCreateWithFlags(&h.s.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h.s.join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h.s.mid, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h.s.aux, hipEventDisableTiming) != hipSuccess) {
             side_release(&h.s);
             return nullptr;
         }
@@ -556,7 +564,7 @@ extern "C" int ffhip_side_stream_get(FfhipSide *out)
 {
     SideStream *ss = side_stream_for_this_thread();
     if (!ss) return FFHIP_EIO;
-    out->stream = ss->side; out->fork = ss->fork; out->join = ss->join; out->mid = ss->mid;
+    out->stream = ss->side; out->fork = ss->fork; out->join = ss->join; out->mid = ss->mid; out->aux = ss->aux;
     return FFHIP_OK;
 }
 extern "C" void ffhip_vp8_release_side_streams(void) /* ffhip_shutdown: nothing of the library's is in flight */

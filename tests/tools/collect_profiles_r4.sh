@@ -47,3 +47,13 @@ echo "done hevc grid"
 SIZES=16,64,256,1024 python3 tests/tools/bench_vp8_frames.py > $O/vp8_frames.jsonl 2> /dev/null
 echo "done vp8 frames"
 ls -la $O
+# the planner's kernels as a timeline, the grouped kernel's wave-time accounting and the single picture's critical path (diagnostics build)
+cd $R
+bash tests/tools/prof_hevc_timeline.sh > /dev/null 2>&1; cp gpurun_out/hevc_timeline/grid_8.txt $O/hevc_timeline_grid8.txt; cp gpurun_out/hevc_timeline/grid_1.txt $O/hevc_timeline_grid1.txt; cp gpurun_out/hevc_timeline/one_8k.txt $O/hevc_timeline_8k.txt
+echo "done timelines"
+if [ -f ffpic_amd/libffpic_hip_trace.so ]; then
+  python3 tests/tools/diag_intra_trace.py c5 > $O/intra_trace_c5.txt 2>&1; echo "done trace c5"
+  PICTURES=1 python3 tests/tools/diag_intra_trace_grid.py > $O/intra_trace_grid1.txt 2>&1; echo "done trace grid 1"
+  PICTURES=8 python3 tests/tools/diag_intra_trace_grid.py > $O/intra_trace_grid8.txt 2>&1; echo "done trace grid 8"
+fi
+ls -la $O | tail -12

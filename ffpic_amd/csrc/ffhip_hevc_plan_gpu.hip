@@ -4,10 +4,10 @@
  * The host planner (plan_groups in ffhip_hevc_intra.hip) costs ~30 ns per TU on one core: more than the kernel it
  * feeds once a picture has a few hundred thousand TUs (an 8K picture, a HEIF grid).  Everything it derives is a pure
  * function of the TU list, one TU at a time, given the map "which TU owns this 4x4 block":
- *   k_plan_owner   every TU stamps its index on its blocks, and says whether it starts a new RUN (a maximal stretch
- *                  of consecutive TUs whose top-left corners fall into the same window of the same plane); per block of
- *                  256 TUs the number of run starts
- *   k_plan_scan    exclusive scan of those block totals (one workgroup)
+ *   k_plan_owner   every TU stamps its index on its blocks, says whether it starts a new RUN (a maximal stretch of consecutive TUs whose
+ *                  top-left corners fall into the same window of the same plane) -- per block of 256 TUs the number of run starts -- and
+ *                  marks which neighbouring 64x64 cells its available neighbours lie in (the cells' dependency edges)
+ *   k_plan_scan    exclusive scan of those block totals (256 entries x 16 per workgroup, no chain between workgroups)
  *   k_plan_runid   run id per TU: the block's prefix + the starts in front of it inside the block (ballots)
  *   k_plan_count   per TU, ONCE: the TUs of OTHER runs among its available neighbours (only earlier ones count: a block
  *                  stamped by a later TU held older content when the sequential decoder looked) -- written straight into
@@ -16,7 +16,8 @@
  *                  allowed), who must publish a done flag; per run start: its position, the claim on its window -- a window
  *                  claimed by two runs means the list is not "groups contiguous in decode order" -- and the count of runs
  *                  per 64x64 cell
- *   k_plan_cell_depth   the wavefront index of every cell (longest chain of dependency edges ending there)
+ *   k_plan_cell_depth_rows / k_plan_cell_depth   the wavefront index of every cell (longest chain of dependency edges ending there):
+ *                  row by row, a prefix scan per row of cells; for planes wider than 1024 cells one anti-diagonal per step
  *   tickets        runs in (depth of their cell, decode order) order WITHOUT a sort: a cell is entered once, so its runs are
  *                  consecutive run ids and stay in decode order inside a contiguous range of tickets; the cells of one depth
  *                  never depend on each other, so their ranges may follow each other in any order -- a histogram of runs per

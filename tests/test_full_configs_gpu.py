@@ -152,7 +152,7 @@ def test_c5_135_tile_8k_grid(monkeypatch):
     """BASELINE configs[4] reads "single 8K tile grid": an 8K picture as a HEIF grid of 15 x 9 = 135 independent 512x512 tiles
     (7680x4608; the tile loop this replaces is heif.c:297-309), all tiles in ONE plane set and ONE ffhip_hevc_intra_recon call, against
     the oracle over the whole plane set; every tile is the same picture.  As shipped, with the throughput instance of the grouped kernel
-    forced (larger grids take it by themselves), and with the single ticket counter."""
+    forced (larger grids take it by themselves), with one and eight ticket counters, and with each piece of the two-stream pre-pass in line."""
     T, gx, gy = 512, 15, 9
     t0, res0 = synth.hevc_intra_tus(T, T, seed=6)
     K = gx * gy
@@ -162,7 +162,9 @@ def test_c5_135_tile_8k_grid(monkeypatch):
     tus["x"] = (tus["x"].astype(np.int64) + (k % gx) * sc).astype(np.uint16)
     tus["y"] = (tus["y"].astype(np.int64) + (k // gx) * sc).astype(np.uint16)
     tus["res_offset"] += (k * len(res0)).astype(np.uint32)
-    exp = _intra_full_picture(T * gx, T * gy, tus, np.tile(res0, K), envs=({}, {"FFHIP_HEVC_INTRA_TP_WIDTH": "1"}, {"FFHIP_HEVC_TICKET_SHARDS": "1"}, {"FFHIP_HEVC_TICKET_SHARDS": "8"}),
+    exp = _intra_full_picture(T * gx, T * gy, tus, np.tile(res0, K), envs=({}, {"FFHIP_HEVC_INTRA_TP_WIDTH": "1"}, {"FFHIP_HEVC_TICKET_SHARDS": "1"}, {"FFHIP_HEVC_TICKET_SHARDS": "8"},
+                                    {"FFHIP_HEVC_SWEEP_INLINE": "1"}, {"FFHIP_HEVC_DEPTH_DIAGONALS": "1"}, {"FFHIP_HEVC_PROGRAMS_INLINE": "1"},
+                                    {"FFHIP_HEVC_JT_INLINE": "1"}),
                               monkeypatch=monkeypatch)
     for i in range(1, K):
         ox, oy = (i % gx) * T, (i // gx) * T

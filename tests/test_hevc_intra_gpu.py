@@ -72,7 +72,8 @@ def test_every_mode_and_size_isolated():
 @pytest.mark.parametrize("env", [{"FFHIP_HEVC_INTRA_MODE": "levels"}, {"FFHIP_HEVC_PLAN": "host"}, {"FFHIP_HEVC_PLAN": "host", "FFHIP_HEVC_INTRA_WINDOW": "4"},
                                  {"FFHIP_HEVC_INTRA_WINDOW": "3"},
                                  {"FFHIP_HEVC_INTRA_WINDOW": "4"}, {"FFHIP_HEVC_INTRA_WINDOW": "5"},
-                                 {"FFHIP_HEVC_INTRA_WINDOW": "6"}, {"FFHIP_HEVC_INTRA_WAVES": "3"}])
+                                 {"FFHIP_HEVC_INTRA_WINDOW": "6"}, {"FFHIP_HEVC_INTRA_WAVES": "3"},
+                                 {"FFHIP_HEVC_DEPTH_DIAGONALS": "1"}, {"FFHIP_HEVC_TICKET_SHARDS": "1"}, {"FFHIP_HEVC_INTRA_WIDTH_PCT": "1"}])
 def test_schedulers_agree(env, monkeypatch):
     """the level-synchronous launches and the grouped single launch (any window) give the oracle's picture"""
     for k, v in env.items():

@@ -294,7 +294,8 @@ def test_webp_file_1080p_256_frames(golden):
                                  {"FFHIP_VP8_PRED_WAVES": "5", "FFHIP_VP8_LF_WAVES": "3"},
                                  {"FFHIP_VP8_PRED_SPLIT": "0"}, {"FFHIP_VP8_PRED_SPLIT": "1"},
                                  {"FFHIP_VP8_PRED_SPLIT": "1", "FFHIP_VP8_PRED_WAVES": "2", "FFHIP_VP8_LF_WAVES": "3"},
-                                 {"FFHIP_VP8_PRED_SPLIT": "1", "FFHIP_VP8_PRED_WAVES": "1", "FFHIP_VP8_FUSE": "0"}])
+                                 {"FFHIP_VP8_PRED_SPLIT": "1", "FFHIP_VP8_PRED_WAVES": "1", "FFHIP_VP8_FUSE": "0"},
+                                 {"FFHIP_VP8_PROGRESS_SHIFT": "0"}, {"FFHIP_VP8_PROGRESS_SHIFT": "3", "FFHIP_VP8_PRED_SPLIT": "1"}, {"FFHIP_SIDE_PRIORITY": "0"}])
 def test_side_by_side_call_under_every_scheduler(env, monkeypatch):
     """ffhip_vp8_predict_loopfilter when one of its stages cannot take the row form (then they run one after the other), when
     told not to overlap, with far fewer waves than rows (tickets, not residency, order the rows of both kernels), and in both

@@ -1805,10 +1805,10 @@ static void host_parallel_for(long long n, F &&fn)
 /* Are the groups of this window -- the TUs whose top-left corner falls into one window tile of one plane -- contiguous
  * runs of the list?  (Then a group is complete before a later one starts, the condition of the grouped kernel.)  One
  * byte map per plane, one pass; scratch kept per thread. */
-/* sampled: only the records of every 64th stretch of 4096 are looked at (large lists, whose full test runs on the device: a window that
+/* sampled: only the records of every 64th stretch of 4096 are looked at -- every 256th from a million records on -- (large lists, whose full test runs on the device: a window that
  * is not contiguous there is refused by the planner and the list decoded by the serial kernel -- exact, slow, and only for a list whose
  * coding-tree-block size changes between the sampled stretches) */
-#define SAMPLED_OUT(i) ((((i) >> 12) & 63) != 0)
+#define SAMPLED_OUT(i) ((((i) >> 12) & (n_tus >= (1LL << 20) ? 255 : 63)) != 0)
 static bool groups_contiguous(const ffhip_hevc_tu *tus, long long n_tus, const int pw[3], const int ph[3], const int win_log2[3], const bool sampled = false)
 {
     static thread_local std::vector<uint8_t> seen[3];

@@ -412,7 +412,7 @@ typedef struct ffhip_hevc_tu {
  * d_residual: int16 residual blocks (row-major n*n each) as ffhip_hevc_residual_batch writes
  * them.  Planes: int16, strides in samples; d_cb/d_cr may be NULL for 4:0:0.  ONLY ENQUEUES: h_tus is validated on
  * the host (and the scheduling window chosen from it) -- record by record up to 2^17 TUs; of a larger list the host
- * looks at a sample only (every 64th stretch of 4096 records) and EVERY record of d_tus is checked by a kernel in front
+ * looks at a sample only (every 64th stretch of 4096 records, every 256th from a million records on) and EVERY record of d_tus is checked by a kernel in front
  * of everything else: a bad record found there refuses the call through the stream (the call returns 0, nothing is
  * written, the next ffhip_stream_sync returns FFHIP_EINVAL; FFHIP_HEVC_HOST_CHECK=1 keeps the whole check on the host) --,
  * the schedule is built on the device (hand-written kernels: no library primitive) and ONE launch follows --

@@ -592,8 +592,11 @@ __global__ __launch_bounds__(256) void k_plan_rank(PlanArgs a, uint32_t m)
  * one window or cover whole windows -- an earlier TU is of my run exactly when its block lies in my window.  And the owners of all edge blocks
  * are loaded up front, into registers: with a conditional atomic and a record load between one block's owner and the next the loads went out one
  * at a time -- up to 33 trips to the L2 per TU, and a second one each for the run id: 0.39 ms for the 1.84 M TUs of an eight-picture grid. */
-template <class F>
-__device__ __forceinline__ bool for_each_dep(const PlanArgs &a, const uint32_t i, const ffhip_hevc_tu &t, F &&f)
+/* (Until late in round 4 every new dependency was handled where it was found -- an LDS stash store, an atomic, a counter, under a branch, at
+ * each of the 33 steps: ~80 instructions a step whether or not any lane of the wave had a dependency there, 2 600 a wave.  Now the 33 steps
+ * only mark which edge blocks bring a NEW dependency -- bit 0 of *mtop the corner, bits 1..16 the row above left to right, *mleft the column
+ * to the left top to bottom -- and the few that do are handled afterwards, in order, by k_plan_count.) */
+__device__ __forceinline__ bool plan_dep_masks(const PlanArgs &a, const uint32_t i, const ffhip_hevc_tu &t, uint32_t *mtop, uint32_t *mleft)
 {
     const int c = t.cidx, n = 1 << t.log2_size, wl = a.wl[c];
     const int wx0 = (t.x >> wl) << wl, wy0 = (t.y >> wl) << wl, wsz = 1 << wl;
@@ -601,7 +604,7 @@ __device__ __forceinline__ bool for_each_dep(const PlanArgs &a, const uint32_t i
     const int32_t *own = a.owner + a.owner_off[c];
     const int32_t *up = own + (ptrdiff_t)((t.y >> 2) - 1) * bwc + (t.x >> 2);   /* the block row above, from my first column */
     const int32_t *lf = own + (ptrdiff_t)(t.y >> 2) * bwc + (t.x >> 2) - 1;     /* the block column to the left, from my first row */
-    int32_t jc = -1, jt[16], jl[16];
+    int32_t jc = -2, jt[16], jl[16];
     if (t.flags & 1) jc = up[-1];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -609,55 +612,53 @@ __device__ __forceinline__ bool for_each_dep(const PlanArgs &a, const uint32_t i
         jt[k] = (in && ((t.avail_top >> (4 * k)) & 0xf)) ? up[k] : -2;
         jl[k] = (in && ((t.avail_left >> (4 * k)) & 0xf)) ? lf[(ptrdiff_t)k * bwc] : -2;
     }
+    /* inside my window?  The row above is (from the window's second row on), up to the window's right edge; the column to the left likewise */
+    const bool row_in = t.y > wy0, col_in = t.x > wx0;
+    const int room_x = wx0 + wsz - t.x, room_y = wy0 + wsz - t.y;
     bool ok = true;
-    int32_t corner = -1, last;
-    auto dep = [&](int32_t j, const int px, const int py) {
+    uint32_t mt = 0, ml = 0;
+    int32_t corner = -1, last = -1;
+    auto dep = [&](int32_t j, const bool inwin, uint32_t &m, const uint32_t bit) -> int32_t {
         if (j >= (int32_t)i) j = -1; /* stamped by a later TU: held older content when the sequential decoder looked */
-        const bool inwin = px >= wx0 && px < wx0 + wsz && py >= wy0 && py < wy0 + wsz;
         const bool other = j >= 0 && !inwin;
-        if (other && j != last && j != corner) f((uint32_t)j);
-        if (other) last = j;
-        if (inwin && j < 0) ok = false;
+        m |= (other && j != last && j != corner) ? bit : 0u;
+        last = other ? j : last;
+        ok = ok && !(inwin && j < 0);
         return other ? j : -1;
     };
-    last = -1;
-    if (t.flags & 1) corner = dep(jc, t.x - 1, t.y - 1);
-    last = -1;
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        if (jt[k] != -2) dep(jt[k], t.x + 4 * k, t.y - 1);
+    if (jc != -2) corner = dep(jc, row_in && col_in, mt, 1u);
     last = -1;
 #pragma unroll
     for (int k = 0; k < 16; k++)
-        if (jl[k] != -2) dep(jl[k], t.x - 1, t.y + 4 * k);
+        if (jt[k] != -2) dep(jt[k], row_in && 4 * k < room_x, mt, 2u << k);
+    last = -1;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (jl[k] != -2) dep(jl[k], col_in && 4 * k < room_y, ml, 1u << k);
+    *mtop = mt; *mleft = ml;
     return ok;
 }
 
 #define PLAN_WSUB 32
-#define PLAN_STASH 6 /* waited-for TUs a lane keeps in LDS between counting them and knowing where its wait entries go; a TU with more walks its edges again */
 __global__ __launch_bounds__(256) void k_plan_count(PlanArgs a)
 {
     if (a.result[6]) return; /* the list was refused by k_hevc_check_tus */
     __shared__ uint32_t wsum[17];
     __shared__ uint32_t blk_base;
-    __shared__ uint32_t stash[PLAN_STASH][256];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const bool live = i < a.n;
     int nd = 0;
     bool ok = true;
+    uint32_t mtop = 0, mleft = 0;
     ffhip_hevc_tu t = {};
     int c = 0, cx = 0, cy = 0;
     if (live) {
         t = a.tus[i];
         c = t.cidx; cx = t.x >> a.cshift[c]; cy = t.y >> a.cshift[c];
-        ok = for_each_dep(a, i, t, [&](uint32_t j) {
-            if (nd < PLAN_STASH) stash[nd][threadIdx.x] = j;
-            nd++;
-            atomicOr((unsigned *)(a.flags + (j & ~3u)), 1u << (8 * (j & 3))); /* that TU must publish a done flag */
-        });
-        if (nd > 64) a.result[0] = 1; /* more than the kernel's 64 pollers: leave it to the host planner */
+        ok = plan_dep_masks(a, i, t, &mtop, &mleft);
+        nd = __popc(mtop) + __popc(mleft); /* at most 33: never more than the grouped kernel's 64 pollers */
     }
-    /* room in the wait list: this block's entries together, reserved by ONE atomic add (result[2] ends up as the total) */
+    /* room in the wait list: this block's entries together, reserved by ONE atomic add */
     uint32_t total;
     const uint32_t off = block_excl_scan((uint32_t)nd, wsum, &total);
     if (threadIdx.x == 0) {
@@ -677,15 +678,27 @@ __global__ __launch_bounds__(256) void k_plan_count(PlanArgs a)
     const uint32_t wb = blk_base + off;
     a.wbegin[i] = wb;
     a.wcount[i] = (uint32_t)nd;
-    if (nd <= PLAN_STASH) {
-        for (int q = 0; q < nd; q++)
-            if (wb + q < a.wait_cap) a.wait_idx[wb + q] = stash[q][threadIdx.x]; /* beyond the reservation: the caller sees result[2] and falls back */
-    } else {
-        uint32_t q = 0;
-        for_each_dep(a, i, t, [&](uint32_t j) {
+    { /* the marked edge blocks, in order (corner, row above, column to the left): who owns it -- read again, the gather's registers cannot be
+         indexed by a lane's own bit -- must publish a done flag, and goes into my wait list */
+        const int32_t *own = a.owner + a.owner_off[c];
+        const int bwc = a.bw[c];
+        uint32_t q = 0, mt = mtop, ml = mleft;
+        while (mt | ml) {
+            int px = t.x - 1, py = t.y - 1;
+            if (mt) {
+                const int b = __builtin_ctz(mt);
+                mt &= mt - 1;
+                if (b) px = t.x + 4 * (b - 1);
+            } else {
+                const int b = __builtin_ctz(ml);
+                ml &= ml - 1;
+                py = t.y + 4 * b;
+            }
+            const uint32_t j = (uint32_t)own[(ptrdiff_t)(py >> 2) * bwc + (px >> 2)];
+            atomicOr((unsigned *)(a.flags + (j & ~3u)), 1u << (8 * (j & 3))); /* that TU must publish a done flag */
             if (wb + q < a.wait_cap) a.wait_idx[wb + q] = j;
             q++;
-        });
+        }
     }
     atomicOr((unsigned *)(a.flags + (i & ~3u)), (ok ? 2u : 0u) << (8 * (i & 3)));
     const uint32_t cell = a.cell_off[c] + (uint32_t)cy * a.cgw[c] + (uint32_t)cx;

@@ -1575,6 +1575,18 @@ __global__ __launch_bounds__(64, MINW) void k_hevc_intra_groups(HevcIntraArgs a)
 
 /* ------------------------------------------------------------------------ host */
 
+/* what the device planner said about this thread's last list (ffhip_debug_hevc_plan_result) */
+static thread_local const uint32_t *g_last_plan_result = nullptr;
+static thread_local hipStream_t g_last_plan_stream = nullptr;
+extern "C" int ffhip_debug_hevc_plan_result(uint32_t out[8])
+{
+    if (!out || !g_last_plan_result) return FFHIP_EINVAL;
+    FFHIP_CHECK(hipStreamSynchronize(g_last_plan_stream), FFHIP_EIO);
+    FFHIP_CHECK(hipMemcpy(out, g_last_plan_result, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost), FFHIP_EIO);
+    return FFHIP_OK;
+}
+
+
 #define SCRATCH_HEVC_INTRA 3
 
 extern "C" size_t ffhip_hevc_plan_gpu_words(long long n_tus, const int pw[3], const int ph[3], const int wl[3]);
@@ -2162,6 +2174,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             hipLaunchKernelGGL((k_hevc_intra_groups<2, 64>), dim3((unsigned)std::min<size_t>((size_t)n_tus, resident_waves)), dim3(64), 0, st, a);
             if (a.tp_width) hipLaunchKernelGGL((k_hevc_intra_groups<3, 16>), dim3((unsigned)std::min<size_t>((size_t)n_tus, resident_waves_tp)), dim3(64), 0, st, a);
             hipLaunchKernelGGL(k_hevc_intra_serial, dim3(1), dim3(64), 0, st, a); /* does something only for a list the planner refused */
+            g_last_plan_result = a.plan_result; g_last_plan_stream = st;
             if (host_times) {
                 const auto TH3 = std::chrono::steady_clock::now();
                 auto us = [](auto x, auto y) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(y - x).count(); };
@@ -2191,6 +2204,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             a.groups = (const u32x4 *)(g_work + o_groups);
             a.wait_idx = g_work + o_wait;
             a.ctrl = g_work + o_ctrl;
+            g_last_plan_result = nullptr;
             a.ctrl_ticket = (uint32_t)((32 - (((uintptr_t)a.ctrl >> 2) & 31)) & 31); a.ctrl_abort = a.ctrl_ticket + 32 * 9;
             a.async_err = async_err;
             a.n_groups = (int)plan.groups.size();

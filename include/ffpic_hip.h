@@ -428,6 +428,11 @@ typedef struct ffhip_hevc_tu {
 int ffhip_hevc_intra_plan(const ffhip_hevc_tu *h_tus, long long n_tus, int width_y, int height_y,
                           int width_c, int height_c, int window_log2, uint32_t *out_ticket,
                           uint32_t *out_wait, int32_t *stats);
+/* Diagnostics: what the DEVICE planner made of the list of this thread's last ffhip_hevc_intra_recon call (which it waits for):
+ * out[0] != 0 the plan was refused and the list decoded by the one-wave serial kernel (exact, slow); out[1] groups; out[3] != 0 the
+ * tickets are in decode order (no coding-tree wavefront found); out[4] the widest wavefront; out[6] != 0 a record failed the device's
+ * validation.  FFHIP_EINVAL when that call did not use the device planner. */
+int ffhip_debug_hevc_plan_result(uint32_t out[8]);
 int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu *d_tus, long long n_tus,
                            const int16_t *d_residual, int16_t *d_y, int16_t *d_cb, int16_t *d_cr,
                            int width_y, int height_y, int y_stride, int width_c, int height_c,

@@ -326,3 +326,27 @@ def test_one_bad_tu_in_a_large_list(host_check, monkeypatch):
     got = (dy.to_host((h, w), np.int16), du.to_host((h // 2, w // 2), np.int16), dv.to_host((h // 2, w // 2), np.int16))
     for a, b in zip(got, exp):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("w,h,seed,kw,keys", [(512, 512, 5, dict(tu_mix="c5"), True), (512, 384, 2, dict(), True), (1920, 1088, 2, dict(), True),
+                                              (128, 128, 43, dict(ccp=True, chroma_444=True, adversarial_masks=True), None),
+                                              (256, 192, 41, dict(adversarial_masks=True), None), (256, 128, 44, dict(ctb=32), False)])
+def test_device_planner_takes_what_it_should(w, h, seed, kw, keys):
+    """A list the device planner refuses is still decoded bit-exactly -- by ONE wave -- so parity alone would not notice a planner that
+    refuses what it should take: the planner's verdict of the call (ffhip_debug_hevc_plan_result) says "taken", and for lists in coding-tree
+    order of 64x64 blocks "tickets by wavefront" (a 32x32 coding tree block enters a 64x64 cell twice: decode order; lists with availability
+    masks that point at samples decoded later may go either way)."""
+    import ctypes as C
+    tus, res = synth.hevc_intra_tus(w, h, seed, **kw)
+    csub = 1 if kw.get("chroma_444") else 2
+    got = ops.hevc_intra_recon(tus, res, w, h, True, 8, 8, csub=csub)
+    out = (C.c_uint32 * 8)()
+    capi.check(capi.lib().ffhip_debug_hevc_plan_result(out), "ffhip_debug_hevc_plan_result")
+    assert out[6] == 0 and out[0] == 0, list(out)          # valid, and not left to the serial kernel
+    assert out[1] > 0
+    if keys is not None:
+        assert (out[3] == 0) == keys, list(out)
+    assert (out[4] > 0) == (out[3] == 0)                   # the widest wavefront is known exactly when there are wavefront tickets
+    exp = O.oracle_hevc_intra(tus, res, w, h, True, 8, 8, csub=csub)
+    for gp, e, name in zip(got, exp, "YUV"):
+        assert np.array_equal(gp, e), name

@@ -110,6 +110,9 @@ def _intra_full_picture(W, H, tus, res, envs=({},), monkeypatch=None):
             capi.check(L.ffhip_hevc_intra_recon(tus.ctypes.data, dt.data_ptr(), len(tus), dr.data_ptr(), py.data_ptr(), pu.data_ptr(),
                                                 pv.data_ptr(), W, H, W, W // 2, H // 2, W // 2, 8, 8, st), "ffhip_hevc_intra_recon")
             capi.check(L.ffhip_stream_sync(st), "sync")
+            verdict = (C.c_uint32 * 8)()   # the device planner took the list, with wavefront tickets: not the one-wave serial path
+            capi.check(L.ffhip_debug_hevc_plan_result(verdict), "ffhip_debug_hevc_plan_result")
+            assert verdict[0] == 0 and verdict[3] == 0 and verdict[6] == 0, (env, list(verdict))
             for got, e, name in zip((py, pu, pv), exp, "YUV"):
                 g = got.cpu().numpy()
                 if not np.array_equal(g, e):

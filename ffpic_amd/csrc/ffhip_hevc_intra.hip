@@ -1227,7 +1227,9 @@ __global__ __launch_bounds__(64, MINW) void k_hevc_intra_groups(HevcIntraArgs a)
 {
     __shared__ short tile[TILE_CELLS];
     __shared__ int nbA[NB_MAX], nbB[NB_MAX];
-    __shared__ __attribute__((aligned(16))) short resl[2][32 * 32];
+    constexpr int RESL = MINW >= 3 ? 1 : 2; /* residual blocks staged in LDS: two, alternating, where the registers are plentiful; ONE in the throughput instance --
+                                               a wave's LDS accesses are served in order, and 2 KB less is a twelfth wave per CU */
+    __shared__ __attribute__((aligned(16))) short resl[RESL][32 * 32];
     __shared__ __attribute__((aligned(16))) short resz[64]; /* zeros: the residual of a TU without one (every pass reads the same 64) */
     __shared__ u32x4 slots[(CHUNK + 2) * 3];
     const int lane = threadIdx.x;
@@ -1540,7 +1542,7 @@ __global__ __launch_bounds__(64, MINW) void k_hevc_intra_groups(HevcIntraArgs a)
                         STAMP(3);
                         fetch_next_extras(); /* a program is short: behind it */
                     } else {
-                        intra_tu_g_any(hot, gc, cur, lane, nbA, nbB, resl[k & 1], rp, jp, tile, resz, fetch_next_extras);
+                        intra_tu_g_any(hot, gc, cur, lane, nbA, nbB, resl[k & (RESL - 1)], rp, jp, tile, resz, fetch_next_extras);
                     }
                     if (cur.signal) { /* somebody outside the group reads this TU: publish it once its stores have completed */
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* compiler ordering; no L2-wide write-back */

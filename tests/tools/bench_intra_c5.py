@@ -13,7 +13,7 @@ st = torch.cuda.current_stream().cuda_stream
 e0, e1 = L.ffhip_event_create(), L.ffhip_event_create()
 W, H = 7680, 4352
 out = {}
-for tag, mix, seed in (("c5mix", "c5", 5), ("quadtree", None, 2)):
+for tag, mix, seed in [m for m in (("c5mix", "c5", 5), ("quadtree", None, 2)) if m[0] in os.environ.get("MIXES", "c5mix,quadtree").split(",")]:
     tus, res = synth.hevc_intra_tus(W, H, seed=seed, tu_mix=mix)
     dt = torch.from_numpy(tus.view(np.uint8).copy()).to(dev); dr = torch.from_numpy(res).to(dev)
     py = torch.zeros((H, W), dtype=torch.int16, device=dev); pu = torch.zeros((H // 2, W // 2), dtype=torch.int16, device=dev); pv = torch.zeros_like(pu)

@@ -15,4 +15,7 @@ done
 rm -rf /tmp/rp_tl
 rocprofv3 --kernel-trace -d /tmp/rp_tl -o tl --output-format csv -- python3 $R/tests/tools/bench_intra_c5.py 6 > /dev/null 2> $O/err_c5.txt
 python3 $R/tests/tools/kernel_timeline.py /tmp/rp_tl k_plan_init k_hevc_intra_serial > $O/one_8k.txt
+rm -rf /tmp/rp_tl
+MIXES=c5mix rocprofv3 --kernel-trace -d /tmp/rp_tl -o tl --output-format csv -- python3 $R/tests/tools/bench_intra_c5.py 6 > /dev/null 2>> $O/err_c5.txt
+python3 $R/tests/tools/kernel_timeline.py /tmp/rp_tl k_plan_init k_hevc_intra_serial > $O/one_8k_c5.txt
 echo "done 8k"

@@ -66,6 +66,7 @@ struct PlanArgs {
     uint32_t *hist_pre;    /* its exclusive scan: first ticket of the pair             */
     uint32_t *fill;        /* [depths][shards] tickets of the pair handed out so far   */
     uint32_t depths;       /* a bound on the depths: a chain ending at cell (x, y) has at most x + 2y edges */
+    float stripe_scale[3]; /* 2^shard_log2 / cells of the plane */
     uint32_t shard_log2;   /* the counters of one depth are spread over 2^shard_log2 words, picked by the cell's block: a grid of tiles has
                               two dozen distinct depths for its 200 000 cells, and that many atomic adds on two dozen words took 0.4 ms */
 };
@@ -517,8 +518,10 @@ __global__ __launch_bounds__(1024) void k_plan_cell_depth_rows(PlanArgs a)
 __device__ __forceinline__ uint32_t plan_cell_key(const PlanArgs &a, const uint32_t c)
 {
     const int pc = c >= a.cell_off[2] && a.cgw[2] ? 2 : (c >= a.cell_off[1] && a.cgw[1] ? 1 : 0);
-    const uint32_t local = c - a.cell_off[pc], count = a.cgw[pc] * a.cgh[pc];
-    const uint32_t stripe = (uint32_t)(((unsigned long long)local << a.shard_log2) / count);
+    const uint32_t local = c - a.cell_off[pc];
+    /* (a float product, rounded however it is rounded: the stripe only has to be the SAME wherever a cell's key is worked out, and roughly its
+     * place in the plane -- the 64-bit division this was cost each of the two kernels that call it a hundred instructions a cell) */
+    const uint32_t stripe = min((uint32_t)((float)local * a.stripe_scale[pc]), (1u << a.shard_log2) - 1u);
     return (a.cell_depth[c] << a.shard_log2) | stripe;
 }
 /* One atomic add per DISTINCT counter and wave, not per cell: the lanes that share a counter add their runs up first (a row of a tile grid has
@@ -530,7 +533,13 @@ __device__ __forceinline__ uint32_t plan_wave_add(uint32_t *counters, const uint
 {
     const int lane = threadIdx.x & 63;
     bool todo = nr != 0;
-    uint32_t before = 0, got = 0;
+    /* first, without touching memory: which lanes share a counter, who speaks for them (the first lane of the group), the group's total and
+     * what the lanes in front of me add -- a round per DISTINCT counter of the wave.  Then ONE atomic instruction for all the groups (their
+     * leaders), and the leaders' answers handed to their groups.  (With the atomic inside the loop every round was a trip to memory of its
+     * own -- eight in a row for a wave of a tile grid's row, a returning one each in k_plan_cell_base: 0.13 ms next to the programs kernel.) */
+    uint32_t before = 0, total = 0;
+    int leader = lane;
+    bool lead = false;
     for (;;) {
         const unsigned long long left = __builtin_amdgcn_ballot_w64(todo);
         if (!left) break;
@@ -539,21 +548,18 @@ __device__ __forceinline__ uint32_t plan_wave_add(uint32_t *counters, const uint
         const bool mine = todo && key == k0;
         if (__popcll(__builtin_amdgcn_ballot_w64(mine)) < 4) {
             /* the lanes' counters are (mostly) different ones -- a picture that is not a grid of tiles: neighbouring cells of a row have
-             * different depths -- and adding them up counter by counter would be up to 64 rounds, each with an atomic of its own (a returning
-             * one in k_plan_cell_base: 51 and 78 us for the 24 000 cells of ONE 8K picture): every lane its own atomic, in one instruction */
-            uint32_t old = 0;
-            if (todo) old = atomicAdd(counters + key, nr);
-            if (todo) { before = 0; got = old; todo = false; }
+             * different depths -- and going through them counter by counter would be up to 64 rounds (51 and 78 us for the 24 000 cells of
+             * ONE 8K picture): every lane that is left speaks for itself */
+            if (todo) { lead = true; leader = lane; total = nr; before = 0; todo = false; }
             break;
         }
         const uint32_t incl = wave_incl_scan(mine ? nr : 0u, lane);
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        uint32_t old = 0;
-        if (lane == first) old = atomicAdd(counters + k0, total);
-        if (BASE) old = (uint32_t)__builtin_amdgcn_readlane((int)old, first);
-        if (mine) { before = incl - nr; got = old; todo = false; }
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (mine) { before = incl - nr; leader = first; lead = lane == first; total = tot; todo = false; }
     }
-    if (BASE) *grant = got;
+    uint32_t old = 0;
+    if (lead) old = atomicAdd(counters + key, total);
+    if (BASE) *grant = (uint32_t)__shfl((int)old, leader, 64);
     return before;
 }
 __global__ __launch_bounds__(256) void k_plan_cell_hist(PlanArgs a)
@@ -873,6 +879,7 @@ static PlanLayout plan_layout(PlanArgs &a, uint32_t *base, const ffhip_hevc_tu *
     a.depths = depths;
     a.shard_log2 = 0; /* as many shards as keep the table at 32 K words or below, at most 64 */
     while (a.shard_log2 < 6 && ((size_t)depths << (a.shard_log2 + 1)) <= 32768) a.shard_log2++;
+    for (int c = 0; c < 3; c++) a.stripe_scale[c] = a.cgw[c] * a.cgh[c] ? (float)(1u << a.shard_log2) / (float)(a.cgw[c] * a.cgh[c]) : 0.0f;
     const size_t hwords = (size_t)depths << a.shard_log2;
     a.hist = p; p += hwords;
     a.fill = p; p += hwords;

@@ -880,7 +880,12 @@ __device__ __forceinline__ unsigned intra_program_slot(const ProgArgs &a, const 
     /* ... the substitution of 8.4.4.2.2 worked out here, from the availability bits: "the nearest available position at or before mine, else
      * the first available one" -- seven vector instructions where a byte of the substitution table was a trip to memory in front of every
      * program (the kernel waited 68 % of its wave cycles for those bytes once the scalar work was gone) */
-    auto src_cell = [&](const int pos, const bool use) -> unsigned {
+    /* What scan position p takes is worked out ONCE per slot, by lane p (33 positions at most): the LDS byte address of its source cell
+     * with two flags on top (bit 16: the source lies outside the window, bit 17: the tile layout has no cell for it).  A tap then is a
+     * cross-lane read of that word (ds_bpermute) instead of the whole evaluation again -- two to four of them per pixel before. */
+    unsigned tab;
+    {
+        const int pos = lane;
         const uint32_t upto = pos >= 31 ? ~0u : (2u << pos) - 1u;
         const uint32_t mm = M_LO & upto;
         const int jn = mm ? 31 - __builtin_clz(mm) : first;
@@ -894,10 +899,14 @@ __device__ __forceinline__ unsigned intra_program_slot(const ProgArgs &a, const 
         const int cell0 = TILE_ROW0 + tx, cell1 = TILE_BODY + (ty - 1) * TILE_STRIDE + tx, cell2 = TILE_LEFT_EXT + ty - 65;
         const bool has12 = m ? has1 : has2, has = z ? has0 : has12;
         const int cell12 = m ? cell1 : cell2, cellw = z ? cell0 : cell12;
-        outside = outside | (use & !none & out);
-        ok = ok & (!use | none | has);
         const unsigned cw = has ? 2u * (unsigned)cellw : 0u;
-        return none ? cconst : cw;
+        tab = none ? cconst : (cw | (out ? 1u << 16 : 0u) | (has ? 0u : 1u << 17));
+    }
+    auto src_cell = [&](const int pos, const bool use) -> unsigned {
+        const unsigned v = (unsigned)__shfl((int)tab, use ? pos : 0, 64);
+        outside = outside | (use & ((v >> 16) & 1u));
+        ok = ok & (!use | !((v >> 17) & 1u));
+        return v & 0xffffu;
     };
     auto cell = [&](const int pos, const bool use) -> unsigned { return filt ? 2u * (unsigned)(TILE_F + pos) : src_cell(pos, use); }; /* what a tap reads */
 #define POS_LEFT(yy) (2 * n - 1 - (yy))

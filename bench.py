@@ -582,6 +582,10 @@ def run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T=None):
         p.zero_()
     chain()
     capi.check(L.ffhip_stream_sync(stream))
+    if times is not None:      # what the device planner made of the list: taken, wavefront tickets, window, sorted by plane
+        v = (C.c_uint32 * 8)()
+        if L.ffhip_debug_hevc_plan_result(v) == 0:
+            times["plan"] = {"taken": v[0] == 0, "wavefront_tickets": v[3] == 0, "groups": int(v[1]), "width": int(v[4]), "window_log2": int(v[5]), "sorted_by_plane": bool(v[7])}
     return bgra, (py, pu, pv), d_res, times
 
 
@@ -613,6 +617,7 @@ def c5_grid_sweep(L, dev, stream, T, cpu=True, pictures=(1, 4, 8), tile=512, til
     ONE ffhip_hevc_residual_batch / ffhip_hevc_intra_recon / ffhip_yuv420_to_bgra_16 call each (the tile loop this replaces decodes them
     one after the other: heif.c:297-309).  Pictures side by side: 1, 4 (2 x 2), 8 (4 x 2)."""
     t0, _ = synth.hevc_intra_tus(tile, tile, seed=3, tu_mix="c5")
+    _, perm0 = synth.hevc_reference_order(t0, 64, 2, 3, return_perm=True)
     out = {"workload": f"8K pictures as grids of {tiles_xy[0]} x {tiles_xy[1]} independent {tile}x{tile} HEVC tiles ({len(t0)} TUs per tile, config-5 mix), "
                        "residual -> intra -> BGRA, one call per stage for all tiles", "rows": []}
     for npic in pictures:
@@ -625,9 +630,15 @@ def c5_grid_sweep(L, dev, stream, T, cpu=True, pictures=(1, 4, 8), tile=512, til
         tus["x"] = (tus["x"].astype(np.int64) + (k % gx) * sc).astype(np.uint16)
         tus["y"] = (tus["y"].astype(np.int64) + (k // gx) * sc).astype(np.uint16)
         tus, groups, total = hevc_chain_inputs(W, H, seed=40 + npic, tus=tus)
+        # the same tiles, every tile's list in the order the reference decodes it in (per coding unit: luma tree, Cb, Cr; coding/hevc.c:5013-5180)
+        tus_r = tus[(np.arange(gx * gy, dtype=np.int64)[:, None] * len(t0) + perm0[None, :]).reshape(-1)]
+        bgra_r, _, _, tr = run_hevc_chain_gpu(L, dev, stream, W, H, tus_r, groups, total, T)
         bgra, planes, d_res, t = run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T)
         row = {"pictures": npic, "tiles": gx * gy, "tus": int(len(tus)), "chain_ms": round(t["chain"], 4), "intra_recon_ms": round(t["intra_recon"], 4),
-               "intra_host_enqueue_ms": round(t["intra_host_enqueue"], 3), "value": round(W * H / t["chain"] / 1e3, 1), "unit": "Mpixels/s"}
+               "intra_host_enqueue_ms": round(t["intra_host_enqueue"], 3), "value": round(W * H / t["chain"] / 1e3, 1), "unit": "Mpixels/s", "plan": t.get("plan"),
+               "reference_order": {"chain_ms": round(tr["chain"], 4), "intra_recon_ms": round(tr["intra_recon"], 4), "intra_host_enqueue_ms": round(tr["intra_host_enqueue"], 3),
+                                   "value": round(W * H / tr["chain"] / 1e3, 1), "plan": tr.get("plan"), "same_pixels": bool(torch.equal(bgra, bgra_r))}}
+        del bgra_r
         if cpu and npic == max(pictures):
             # parity of the first and the last tile of the largest grid: each tile is a picture of its own for the reference's C chain
             ok = True
@@ -677,8 +688,17 @@ def extra_c5(L, dev, stream, T, cpu=True, grid=True):
                               "bound": "dependency chain (a wave per 64x64 window group), not HBM"},
               "yuv420_to_bgra_16": {"ms": round(t["yuv420_to_bgra_16"], 4), "GB/s": round(7 * px / t["yuv420_to_bgra_16"] / 1e6, 1),
                                     "algorithmic_bytes": int(7 * px), "frac_of_hbm_peak": round(7 * px / t["yuv420_to_bgra_16"] / 1e6 / HBM_PEAK_GBS, 4)}}
+    # the same picture from the list in the reference's order (per coding unit the luma tree, then Cb, then Cr: coding/hevc.c:5013-5180)
+    bg_p, _, _, _ = run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total)
+    bg_r, _, _, tr = run_hevc_chain_gpu(L, dev, stream, W, H, synth.hevc_reference_order(tus, 64, 2, 5), groups, total, T)
+    same = bool(torch.equal(bg_p, bg_r))
+    del bg_p, bg_r
     res = {"workload": "C5: one 7680x4352 HEVC intra picture, TU mix of SURVEY 8d (luma 32/16 at 60/40, chroma 16/8), qP 27", "chain_ms": round(t["chain"], 4),
-           "value": round(px / t["chain"] / 1e3, 1), "unit": "Mpixels/s", "stages": stages,
+           "value": round(px / t["chain"] / 1e3, 1), "unit": "Mpixels/s", "stages": stages, "plan": t.get("plan"),
+           "reference_order": {"chain_ms": round(tr["chain"], 4), "value": round(px / tr["chain"] / 1e3, 1), "intra_recon_ms": round(tr["intra_recon"], 4),
+                               "intra_host_enqueue_ms": round(tr["intra_host_enqueue"], 3), "plan": tr.get("plan"), "same_pixels": same,
+                               "note": "the same TUs, records interleaved per coding unit (luma tree, Cb, Cr) as decode_cu_coded_intra_prediction_mode walks them; "
+                                       "`value` above: each coding tree block's planes one after the other"},
            "roofline": dict(roof(9 * px, t["intra_recon"]), kernel="k_hevc_intra_groups",
                             note="algorithmic bytes 9 B/pixel (3 + 3 in, 3 out); the stage is bound by its dependency chain")}
     if cpu:
@@ -736,8 +756,15 @@ def compact_configs(extra):
         out["c5"] = c5
     else:
         rows = g(c5, "grid", "rows") or []
+        def planned(p):      # taken by the device planner with coding-tree wavefront tickets at the 64x64 window
+            return bool(p and p.get("taken") and p.get("wavefront_tickets") and p.get("window_log2") == 6)
         out["c5"] = {"one_8k_picture": {"value": g(c5, "value"), "ms": g(c5, "chain_ms"), "intra_ms": g(c5, "stages", "intra_recon", "ms"), "parity": g(c5, "parity_vs_reference_sample")},
+                     "one_8k_picture_reference_order": {"value": g(c5, "reference_order", "value"), "ms": g(c5, "reference_order", "chain_ms"), "intra_ms": g(c5, "reference_order", "intra_recon_ms"),
+                                                        "same_pixels": g(c5, "reference_order", "same_pixels"), "wavefront_64": planned(g(c5, "reference_order", "plan")),
+                                                        "sorted_by_plane": g(c5, "reference_order", "plan", "sorted_by_plane")},
                      "grid_135_tiles": {str(r["pictures"]): r["value"] for r in rows},
+                     "grid_135_tiles_reference_order": {str(r["pictures"]): g(r, "reference_order", "value") for r in rows},
+                     "grid_reference_order_ok": [bool(g(r, "reference_order", "same_pixels") and planned(g(r, "reference_order", "plan"))) for r in rows],
                      "grid_host_enqueue_ms": {str(r["pictures"]): r["intra_host_enqueue_ms"] for r in rows},
                      "grid_parity": [r.get("parity_first_and_last_tile_vs_reference") for r in rows if "parity_first_and_last_tile_vs_reference" in r],
                      "cpu_1_core": g(c5, "cpu_baseline", "value"), "cpu_all_cores": g(c5, "cpu_baseline_all_cores", "value"), "cpu_cores": g(c5, "cpu_baseline_all_cores", "cores")}
@@ -757,6 +784,7 @@ def main():
                     help="strong: the configuration's batch is shared out over the GPUs (BASELINE config 3: 256 images in total); weak: that many per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-extra", action="store_true", help="skip the C2 / C4 / C5 measurements of `extra`")
+    ap.add_argument("--extras", default="", help="comma-separated subset of c2,jpeg_layouts,c4,c5,f1,stage_kernels to measure (default: all)")
     ap.add_argument("--extra-file", default="", help="also write the result line WITH the verbose `extra` object (every stage, roofline and sample description) to this file")
     a = ap.parse_args()
 
@@ -926,6 +954,8 @@ def main():
             for key, fn in (("c2", lambda: extra_c2(L, dev, stream, T)), ("jpeg_layouts", lambda: extra_layouts(L, dev, stream, T)),
                             ("c4", lambda: extra_c4(L, dev, stream, T, not a.no_cpu)), ("c5", lambda: extra_c5(L, dev, stream, T, not a.no_cpu)),
                             ("stage_kernels", lambda: extra_stage_kernels(L, dev, stream, T))):
+                if a.extras and key not in a.extras.split(","):
+                    continue
                 try:
                     extra[key] = fn()
                 except Exception as e:   # an extra must never take the headline line with it

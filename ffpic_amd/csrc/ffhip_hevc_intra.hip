@@ -1826,40 +1826,106 @@ static void host_parallel_for(long long n, F &&fn)
 }
 
 /* Are the groups of this window -- the TUs whose top-left corner falls into one window tile of one plane -- contiguous
- * runs of the list?  (Then a group is complete before a later one starts, the condition of the grouped kernel.)  One
- * byte map per plane, one pass; scratch kept per thread. */
+ * runs of the list?  (Then a group is complete before a later one starts, the condition of the grouped kernel.)  Two rules in one
+ * pass, a byte map per plane and rule; scratch kept per thread:
+ *   bit 0  runs of the list AS IT IS: a TU opens a run where its window differs from that of the record in front of it
+ *   bit 1  runs of every plane's OWN subsequence: ... from that of the previous record of the same plane.  This is the rule the
+ *          reference's order needs: it decodes coding unit by coding unit, the unit's luma tree, then Cb, then Cr
+ *          (coding/hevc.c:5013-5180 calling decode_intra_block :4665-4805), so a coding tree block with several coding units
+ *          switches planes INSIDE every 64x64 area.  The planes do not read each other, so the device planner may work on the
+ *          list sorted by plane (ffhip_hevc_plan_gpu.hip, k_part_*), where bit 1 is what bit 0 is here.
+ * Bit 0 implies bit 1. */
 /* sampled: only the records of every 64th stretch of 4096 are looked at -- every 256th from a million records on -- (large lists, whose full test runs on the device: a window that
  * is not contiguous there is refused by the planner and the list decoded by the serial kernel -- exact, slow, and only for a list whose
  * coding-tree-block size changes between the sampled stretches) */
 #define SAMPLED_OUT(i) ((((i) >> 12) & (n_tus >= (1LL << 20) ? 255 : 63)) != 0)
-static bool groups_contiguous(const ffhip_hevc_tu *tus, long long n_tus, const int pw[3], const int ph[3], const int win_log2[3], const bool sampled = false)
+static int groups_contiguous(const ffhip_hevc_tu *tus, long long n_tus, const int pw[3], const int ph[3], const int win_log2[3], const bool sampled = false)
 {
     static thread_local std::vector<uint8_t> seen[3];
     int gw[3];
+    size_t cnt[3];
     for (int c = 0; c < 3; c++) {
         gw[c] = pw[c] > 0 ? ((pw[c] - 1) >> win_log2[c]) + 1 : 0;
-        seen[c].assign((size_t)gw[c] * (size_t)(ph[c] > 0 ? ((ph[c] - 1) >> win_log2[c]) + 1 : 0), 0);
+        cnt[c] = (size_t)gw[c] * (size_t)(ph[c] > 0 ? ((ph[c] - 1) >> win_log2[c]) + 1 : 0);
+        seen[c].assign(2 * cnt[c], 0); /* [0, cnt): the list as it is; [cnt, 2 cnt): the plane's own subsequence */
     }
     uint8_t *const map[3] = {seen[0].data(), seen[1].data(), seen[2].data()};
-    std::atomic<bool> twice{false};
-    /* a TU opens a run where its window differs from its predecessor's: stateless per TU, so the list is cut into pieces for as
-     * many threads as pay (a window entered by two pieces is entered twice all the same: the mark is an atomic exchange) */
+    std::atomic<bool> twice_raw{false}, twice_plane{false};
+    auto window_of = [&](const ffhip_hevc_tu &t) -> long long { /* -1: an unvalidated record of a sampled list (the device pass refuses it) */
+        const int c = t.cidx;
+        if (c > 2 || t.x >= pw[c] || t.y >= ph[c]) return -1;
+        return (long long)(t.y >> win_log2[c]) * gw[c] + (t.x >> win_log2[c]);
+    };
+    /* a TU opens a run where its window differs from its predecessor's: stateless per TU under the first rule, so the list is cut into
+     * pieces for as many threads as pay (a window entered by two pieces is entered twice all the same: the mark is an atomic exchange);
+     * under the second rule a piece -- and a sampled stretch -- first looks back for the last record of each plane in front of it */
     host_parallel_for(sampled ? 1 : n_tus, [&](long long b, long long e) { /* (a sample is one thread's work: starting sixteen costs more than the pass) */
         if (sampled) e = n_tus;
-        for (long long i = b; i < e && !twice.load(std::memory_order_relaxed); i++) {
-            if (sampled && SAMPLED_OUT(i)) { i |= 4095; continue; }
-            const ffhip_hevc_tu &t = tus[i];
-            const int c = t.cidx;
-            if (c > 2 || t.x >= pw[c] || t.y >= ph[c]) continue; /* (an unvalidated record of a sampled list: the device pass refuses it) */
-            const long long w = (long long)(t.y >> win_log2[c]) * gw[c] + (t.x >> win_log2[c]);
-            if (i > 0) {
-                const ffhip_hevc_tu &p = tus[i - 1];
-                if (p.cidx == c && p.x < pw[c] && p.y < ph[c] && (long long)(p.y >> win_log2[c]) * gw[c] + (p.x >> win_log2[c]) == w) continue;
+        long long last[3] = {-2, -2, -2}; /* the window of the plane's previous record; -2 = not looked up yet */
+        auto look_back = [&](long long i) {
+            int missing = 3;
+            last[0] = last[1] = last[2] = -1;
+            for (long long j = i - 1; j >= 0 && j >= i - 4096 && missing; j--) { /* (further back than any coding tree block reaches: a run that old is taken for a new one) */
+                const int c = tus[j].cidx;
+                if (c > 2 || last[c] != -1) continue;
+                const long long w = window_of(tus[j]);
+                if (w < 0) continue;
+                last[c] = w; missing--;
             }
-            if (__atomic_exchange_n(map[c] + w, (uint8_t)1, __ATOMIC_RELAXED)) twice.store(true, std::memory_order_relaxed);
+        };
+        look_back(b);
+        for (long long i = b; i < e && !twice_plane.load(std::memory_order_relaxed); i++) {
+            if (sampled && SAMPLED_OUT(i)) { i |= 4095; if (i + 1 < e) look_back(i + 1); continue; }
+            const ffhip_hevc_tu &t = tus[i];
+            const long long w = window_of(t);
+            if (w < 0) continue;
+            const int c = t.cidx;
+            if (last[c] != w) {
+                last[c] = w;
+                if (__atomic_exchange_n(map[c] + cnt[c] + w, (uint8_t)1, __ATOMIC_RELAXED)) twice_plane.store(true, std::memory_order_relaxed);
+            }
+            if (i > 0 && tus[i - 1].cidx == c && window_of(tus[i - 1]) == w) continue;
+            if (!twice_raw.load(std::memory_order_relaxed) && __atomic_exchange_n(map[c] + w, (uint8_t)1, __ATOMIC_RELAXED)) twice_raw.store(true, std::memory_order_relaxed);
         }
     });
-    return !twice.load();
+    const bool plane_ok = !twice_plane.load();
+    return (plane_ok && !twice_raw.load() ? 1 : 0) | (plane_ok ? 2 : 0);
+}
+
+/* The list sorted by plane (stable), on the host: for the host planner and ffhip_hevc_intra_plan, what k_part_* do for the device planner.
+ * perm[k] = the caller's index of sorted record k. */
+static void sort_by_plane(const ffhip_hevc_tu *tus, long long n_tus, std::vector<ffhip_hevc_tu> &sorted, std::vector<uint32_t> *perm)
+{
+    size_t cnt[3] = {0, 0, 0};
+    for (long long i = 0; i < n_tus; i++) cnt[tus[i].cidx > 2 ? 2 : tus[i].cidx]++;
+    size_t at[3] = {0, cnt[0], cnt[0] + cnt[1]};
+    sorted.resize((size_t)n_tus);
+    if (perm) perm->resize((size_t)n_tus);
+    for (long long i = 0; i < n_tus; i++) {
+        const size_t k = at[tus[i].cidx > 2 ? 2 : tus[i].cidx]++;
+        sorted[k] = tus[i];
+        if (perm) (*perm)[k] = (uint32_t)i;
+    }
+}
+/* the largest luma window (from `wl` down to 8x8) under which the list's groups are contiguous runs, by the plane's own subsequence; *by_plane:
+ * NOT by the list as it is, i.e. the list has to be sorted by plane for that window.  0 when there is none.  FFHIP_HEVC_BY_PLANE=0 keeps to the
+ * list as it is (the rule until round 5), =1 sorts whenever the sort alone does not make the window smaller (tests: both forms on every list). */
+static int pick_window(const ffhip_hevc_tu *tus, long long n_tus, const int pw[3], const int ph[3], int wl, const bool sampled, bool *by_plane)
+{
+    const char *bp = FFHIP_ENV("FFHIP_HEVC_BY_PLANE");
+    const int force = bp ? atoi(bp) : -1;
+    const int cs = (pw[1] > 0 && pw[1] * 2 <= pw[0] + 1) ? 1 : 0;
+    wl = wl < 3 ? 3 : (wl > 6 ? 6 : wl);
+    for (; wl >= 3; wl--) {
+        const int win[3] = {wl, wl - cs, wl - cs};
+        const int bits = groups_contiguous(tus, n_tus, pw, ph, win, sampled);
+        if (force == 0 ? (bits & 1) : (bits & 2)) {
+            *by_plane = force == 0 ? false : (force == 1 ? true : !(bits & 1));
+            return wl;
+        }
+    }
+    *by_plane = false;
+    return 0;
 }
 
 /* the window search both entry points share: the requested (or default) luma window, halved until a
@@ -1891,13 +1957,21 @@ extern "C" int ffhip_hevc_intra_plan(const ffhip_hevc_tu *h_tus, long long n_tus
     GroupPlan plan;
     int wl = 0;
     const uint32_t no_table[3] = {0, 0, 0};
-    if (!plan_with_window_search(h_tus, n_tus, pw, ph, window_log2 ? window_log2 : FFHIP_HEVC_INTRA_WINDOW_LOG2, plan, &wl, no_table)) return FFHIP_EINVAL;
+    /* as ffhip_hevc_intra_recon does: a list that interleaves the planes inside a window is planned sorted by plane */
+    std::vector<ffhip_hevc_tu> sorted;
+    std::vector<uint32_t> perm;
+    bool by_plane = false;
+    const int want = window_log2 ? window_log2 : FFHIP_HEVC_INTRA_WINDOW_LOG2;
+    (void)pick_window(h_tus, n_tus, pw, ph, want, false, &by_plane);
+    if (by_plane) sort_by_plane(h_tus, n_tus, sorted, &perm);
+    if (!plan_with_window_search(by_plane ? sorted.data() : h_tus, n_tus, pw, ph, want, plan, &wl, no_table)) return FFHIP_EINVAL;
     int tile_ok = 0;
     for (size_t g = 0; g < plan.groups.size(); g++)
         for (uint32_t k = 0; k < plan.groups[g].y; k++) {
             const u32x4 q = plan.sched[(size_t)(plan.groups[g].x + k) * 3 + 2];
-            if (out_ticket) out_ticket[q.z] = (uint32_t)g;
-            if (out_wait) out_wait[q.z] = q.y & 0xff;
+            const uint32_t i = by_plane ? perm[q.z] : q.z;
+            if (out_ticket) out_ticket[i] = (uint32_t)g;
+            if (out_wait) out_wait[i] = q.y & 0xff;
             tile_ok += (q.y >> 9) & 1;
         }
     if (stats) { stats[0] = (int32_t)plan.groups.size(); stats[1] = wl; stats[2] = (int32_t)plan.wait.size(); stats[3] = tile_ok; }
@@ -1984,6 +2058,9 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
     if (has_res && !d_residual) return FFHIP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     HevcIntraArgs a = {};
+    /* the records the schedule's TU indices refer to: the caller's, or -- for a list that interleaves the planes inside a scheduling window --
+     * a copy sorted by plane in the call's scratch (pick_window) */
+    const ffhip_hevc_tu *list = d_tus;
     a.tus = d_tus; a.residual = d_residual;
     a.plane[0] = d_y; a.plane[1] = d_cb; a.plane[2] = d_cr;
     a.stride[0] = y_stride; a.stride[1] = uv_stride; a.stride[2] = uv_stride;
@@ -2023,7 +2100,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
     const size_t w_desc = desc_px * 2 + 2;
     auto enqueue_programs = [&](uint32_t *words, const int win[3], size_t n_slots, hipStream_t ps) {
         pa.sched = (u32x4 *)a.sched; pa.n_slots = (uint32_t)n_slots; pa.jt = a.jt;
-        pa.records = d_tus;
+        pa.records = list;
         pa.desc = (uint2 *)(((uintptr_t)words + 7) & ~(uintptr_t)7);
         for (int c = 0; c < 3; c++) { pa.wl[c] = win[c]; pa.stride[c] = a.stride[c]; pa.jt_bw[c] = ja.bw[c]; pa.jt_boff[c] = ja.boff[c]; }
         pa.plan_result = a.plan_result; pa.wait_cap = a.wait_cap;
@@ -2076,15 +2153,11 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
          * planner and decoded by ONE wave (k_hevc_intra_serial: exact, seconds for an 8K list): such a list takes the host planner
          * with its window search -- or the levels form -- right away; the serial kernel stays for what only the device can find
          * (more than 64 TUs to wait for, an order its ticket rule cannot serve) */
-        int dev_wl = we ? atoi(we) : 6;
-        dev_wl = dev_wl < 3 ? 3 : (dev_wl > 6 ? 6 : dev_wl);
+        bool by_plane = false;
         const int dev_cs = (pw[1] > 0 && pw[1] * 2 <= pw[0] + 1) ? 1 : 0;
-        bool dev_ok = false;
-        for (; dev_wl >= 3 && !dev_ok; dev_wl--) {
-            const int win[3] = {dev_wl, dev_wl - dev_cs, dev_wl - dev_cs};
-            dev_ok = groups_contiguous(h_tus, n_tus, pw, ph, win, big_list);
-        }
-        dev_wl++;
+        int dev_wl = pick_window(h_tus, n_tus, pw, ph, we ? atoi(we) : 6, big_list, &by_plane);
+        bool dev_ok = dev_wl != 0;
+        if (!dev_ok) dev_wl = 3;
         const auto TH2 = std::chrono::steady_clock::now();
         if (pe && !strcmp(pe, "device")) dev_ok = true; /* tests: force the device planner (and with it the serial path of a list it refuses) */
         if (!(pe && !strcmp(pe, "host")) && dev_ok) {
@@ -2128,7 +2201,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             };
             auto programs_early = [&](const uint8_t *flags, const uint32_t *wcount, const uint32_t *result) -> int {
                 if (!jt_forked) return FFHIP_OK; /* a small list: everything on `stream`, in order */
-                pa.tus = d_tus; pa.flags = flags; pa.wcount = wcount; pa.refused = nullptr;
+                pa.tus = list; pa.flags = flags; pa.wcount = wcount; pa.refused = nullptr;
                 a.sched = (const u32x4 *)g_work; /* where the planner puts the slots (ffhip_hevc_plan_gpu's layout starts with them) */
                 a.plan_result = result; a.wait_cap = (uint32_t)(8 * (size_t)n_tus);
                 if (tickets_aside) { /* on `stream`, right behind k_plan_count -- and behind the point the ticket kernels wait for */
@@ -2155,6 +2228,8 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
                           decltype(tickets_enqueued) *te; } hook = {&enqueue_jtable, &programs_early, jt_words, &ja, &ticket_stream, &tickets_wait, &tickets_enqueued};
             FfhipPlanHooks hooks = {};
             hooks.ctx = &hook;
+            hooks.by_plane = by_plane ? 1 : 0;
+            hooks.tus_used = &list;
             hooks.after_check = [](void *ctx, const unsigned *refused) -> int {
                 Hook *h = (Hook *)ctx;
                 h->ja->refused = refused;
@@ -2177,6 +2252,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             a.async_err = async_err;
             a.n_groups = 0;
             a.n_tus = n_tus;
+            a.tus = list;
             { const int jrc = join_jtable(); if (jrc) return jrc; } /* (the side stream's last record: behind the programs when they went there) */
             if (!programs_forked) { pa.tus = nullptr; pa.flags = nullptr; pa.wcount = nullptr; pa.refused = nullptr; enqueue_programs(jt_words + w_jt, win, (size_t)n_tus, st); }
 #ifdef FFHIP_INTRA_TRACE
@@ -2199,15 +2275,28 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
         if (!validate_fully()) return FFHIP_EINVAL; /* the host planner walks every record */
         GroupPlan plan;
         int host_wl = 0;
-        if (plan_with_window_search(h_tus, n_tus, pw, ph, we ? atoi(we) : FFHIP_HEVC_INTRA_WINDOW_LOG2, plan, &host_wl, ja.boff)) {
+        /* the host planner works on the list sorted by plane where the device planner would (pick_window): its slots' TU indices then refer to
+         * the sorted records, which are uploaded next to the schedule */
+        std::vector<ffhip_hevc_tu> h_sorted;
+        if (big_list) (void)pick_window(h_tus, n_tus, pw, ph, we ? atoi(we) : FFHIP_HEVC_INTRA_WINDOW_LOG2, false, &by_plane); /* (the first answer came from a sample) */
+        if (by_plane) sort_by_plane(h_tus, n_tus, h_sorted, nullptr);
+        if (plan_with_window_search(by_plane ? h_sorted.data() : h_tus, n_tus, pw, ph, we ? atoi(we) : FFHIP_HEVC_INTRA_WINDOW_LOG2, plan, &host_wl, ja.boff)) {
             /* device image: sched | groups | wait | ctrl[CTRL_HDR] + one done flag per TU */
             const size_t w_sched = plan.sched.size() * 4, w_groups = plan.groups.size() * 4, w_wait = plan.wait.size();
             const size_t w_ctrl = CTRL_HDR + (size_t)n_tus;
             const size_t o_groups = w_sched, o_wait = o_groups + w_groups, o_ctrl = (o_wait + w_wait + 3) & ~(size_t)3;
+            const size_t w_sorted = by_plane ? 8 * (size_t)n_tus + 16 : 0;
             FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO); /* the work buffer may still be in use by an earlier call */
-            uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, o_ctrl + w_ctrl + 4 + w_jt + w_desc);
+            uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, o_ctrl + w_ctrl + 4 + w_jt + w_desc + w_sorted);
             if (!g_work) return FFHIP_ENOMEM;
             uint32_t *const jt_words = g_work + ((o_ctrl + w_ctrl + 3) & ~(size_t)3);
+            if (by_plane) {
+                uint32_t *ps = jt_words + w_jt + w_desc + 4;
+                ps += (8 - (((uintptr_t)ps >> 2) & 7)) & 7;
+                FFHIP_CHECK(hipMemcpy(ps, h_sorted.data(), (size_t)n_tus * sizeof(ffhip_hevc_tu), hipMemcpyHostToDevice), FFHIP_EIO);
+                list = (const ffhip_hevc_tu *)ps;
+                a.tus = list;
+            }
             { const int jrc = enqueue_jtable(jt_words, false); if (jrc) return jrc; }
             FFHIP_CHECK(hipMemcpy(g_work, plan.sched.data(), w_sched * 4, hipMemcpyHostToDevice), FFHIP_EIO);
             FFHIP_CHECK(hipMemcpy(g_work + o_groups, plan.groups.data(), w_groups * 4, hipMemcpyHostToDevice), FFHIP_EIO);

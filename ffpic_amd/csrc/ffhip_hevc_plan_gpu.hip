@@ -47,7 +47,8 @@ struct PlanArgs {
     uint32_t *wait_idx;
     u32x4 *sched, *groups;
     uint32_t *result;      /* [0] fail, [1] number of runs, [2] wait entries, [3] no wavefront keys, [4] the widest wavefront:
-                              the largest number of runs that share a dependency depth */
+                              the largest number of runs that share a dependency depth, [5] log2 of the luma window, [6] a record failed
+                              k_hevc_check_tus, [7] the list was sorted by plane (k_part_*) */
     uint32_t wait_cap;     /* words reserved for wait_idx                           */
     uint32_t wsub_n;       /* slices in use: a power of two, at most PLAN_WSUB, never more than blocks of 256 TUs */
     uint32_t *wsub;        /* PLAN_WSUB counters, one per 128-byte line: wait entries handed out of slice r of wait_idx */
@@ -69,6 +70,12 @@ struct PlanArgs {
     float stripe_scale[3]; /* 2^shard_log2 / cells of the plane */
     uint32_t shard_log2;   /* the counters of one depth are spread over 2^shard_log2 words, picked by the cell's block: a grid of tiles has
                               two dozen distinct depths for its 200 000 cells, and that many atomic adds on two dozen words took 0.4 ms */
+    /* the list sorted by plane (k_part_*): the caller's records, the copy the planner and everything behind it work on, and per
+     * (plane, block of 256 records) the records of that plane in the block / in front of it in the sorted list */
+    const ffhip_hevc_tu *raw;
+    ffhip_hevc_tu *sorted;
+    uint32_t *part_tot, *part_pre;
+    uint32_t part_nb;
 };
 
 /* ---- scans: a shuffle scan inside the wave, the waves' totals through LDS ---- */
@@ -187,6 +194,68 @@ __global__ __launch_bounds__(256) void k_plan_init(PlanInit in) /* blockIdx.y: t
     for (size_t i = tid; i < quads; i += nth) q[i] = v4;
     const size_t tail = head + quads * 4;
     if (tid < words - tail) p[tail + tid] = v;
+}
+
+/* ---- the list sorted by plane ----
+ * The reference decodes coding unit by coding unit -- the unit's luma tree, then its Cb tree, then its Cr tree
+ * (decode_cu_coded_intra_prediction_mode, coding/hevc.c:5013-5180, calling decode_intra_block :4665-4805 once per component) -- so a coding
+ * tree block with more than one coding unit visits its 64x64 area of every plane several times, with the other planes in between.  A run, a
+ * window visit and a cell visit as everything below defines them ("consecutive records of the list") would end at every such switch: seven
+ * of seven lists the reference's own decoder recorded had one group per 8x8 window and decode-order tickets that way.  The planes never read
+ * each other in this interface (cross-component prediction as the reference calls it reads the chroma block itself), so any order that
+ * keeps each plane's own subsequence decodes to the same samples: the planner, the programs and the grouped kernel work on a STABLE
+ * partition of the list by plane -- all luma records in list order, then Cb, then Cr.  A counting sort with three keys: records per (plane,
+ * block of 256), the exclusive scan of that table laid out plane by plane (k_plan_scan), and the scatter. */
+__device__ __forceinline__ uint32_t part_plane_of(const ffhip_hevc_tu *tus, const uint32_t i)
+{
+    const uint32_t w1 = ((const uint32_t *)(tus + i))[1]; /* log2_size | cidx << 8 | pred_mode << 16 | flags << 24 */
+    const uint32_t c = (w1 >> 8) & 0xffu;
+    return c > 2u ? 2u : c; /* (a record k_hevc_check_tus refuses: the copy is never read) */
+}
+/* ranks inside the block: what each of the three planes has in the waves in front of mine, and in the lanes in front of me */
+__device__ __forceinline__ uint32_t part_rank(const uint32_t c, const bool live, uint32_t (*wtot)[3], uint32_t tot[3])
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long b[3];
+#pragma unroll
+    for (uint32_t k = 0; k < 3; k++) b[k] = __builtin_amdgcn_ballot_w64(live && c == k);
+    if (lane == 0)
+        for (int k = 0; k < 3; k++) wtot[w][k] = (uint32_t)__popcll(b[k]);
+    __syncthreads();
+    const unsigned long long mine = c == 0 ? b[0] : (c == 1 ? b[1] : b[2]);
+    uint32_t r = (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+    for (int q = 0; q < 4; q++) {
+        if (q < w) r += wtot[q][c];
+#pragma unroll
+        for (int k = 0; k < 3; k++) tot[k] = (q ? tot[k] : 0u) + wtot[q][k];
+    }
+    return r;
+}
+__global__ __launch_bounds__(256) void k_part_count(PlanArgs a)
+{
+    __shared__ uint32_t wtot[4][3];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < a.n;
+    uint32_t tot[3];
+    part_rank(live ? part_plane_of(a.raw, i) : 0u, live, wtot, tot);
+    if (threadIdx.x < 3) a.part_tot[threadIdx.x * a.part_nb + blockIdx.x] = tot[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void k_part_scatter(PlanArgs a)
+{
+    if (a.result[6]) return; /* the list was refused by k_hevc_check_tus */
+    __shared__ uint32_t wtot[4][3];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < a.n;
+    const uint32_t c = live ? part_plane_of(a.raw, i) : 0u;
+    uint32_t tot[3];
+    const uint32_t r = part_rank(c, live, wtot, tot);
+    if (!live) return;
+    const uint32_t dst = a.part_pre[c * a.part_nb + blockIdx.x] + r;
+    const u32x4 *src = (const u32x4 *)(a.raw + i);
+    u32x4 *out = (u32x4 *)(a.sorted + dst);
+    const u32x4 q0 = src[0], q1 = src[1];
+    out[0] = q0; out[1] = q1;
+    if (i == 0) a.result[7] = 1u; /* (diagnostics: the planner worked on the sorted copy) */
 }
 
 __device__ __forceinline__ uint32_t win_of(const PlanArgs &a, const ffhip_hevc_tu &t)
@@ -726,6 +795,7 @@ __global__ __launch_bounds__(256) void k_plan_count(PlanArgs a)
     if (i == a.n - 1) {
         a.gstart[a.runid[i] + 1] = a.n;
         a.result[1] = a.runid[i] + 1;
+        a.result[5] = (uint32_t)a.wl[0]; /* (diagnostics: the luma window the schedule was built for) */
     }
 }
 
@@ -890,7 +960,13 @@ static PlanLayout plan_layout(PlanArgs &a, uint32_t *base, const ffhip_hevc_tu *
     a.blk_tot = p; p += L.n_blocks + 1;
     a.blk_pre = p; p += L.n_blocks + 1;
     a.hist_pre = p; p += hwords;
-    L.words = (size_t)(p - base) + 8;
+    a.part_nb = (uint32_t)L.n_blocks;
+    a.part_tot = p; p += 3 * L.n_blocks + 1;
+    a.part_pre = p; p += 3 * L.n_blocks + 1;
+    p += (8 - (((uintptr_t)p >> 2) & 7)) & 7; /* records are read and written as 16-byte quarters */
+    a.sorted = (ffhip_hevc_tu *)p; p += 8 * n;
+    a.raw = d_tus;
+    L.words = (size_t)(p - base) + 16;
     return L;
 }
 extern "C" size_t ffhip_hevc_plan_gpu_words(long long n_tus, const int pw[3], const int ph[3], const int wl[3])
@@ -953,6 +1029,14 @@ extern "C" int ffhip_hevc_plan_gpu_checked(const ffhip_hevc_tu *d_tus, long long
         const int hrc = hooks->after_check(hooks->ctx, a.result + 6);
         if (hrc) return hrc;
     }
+    if (hooks && hooks->by_plane) { /* the list sorted by plane (k_part_*): from here on `a.tus` is the sorted copy */
+        hipLaunchKernelGGL(k_part_count, dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_plan_scan, dim3((unsigned)((3 * Lo.n_blocks + 4095) / 4096)), dim3(256), 0, st, (const uint32_t *)a.part_tot, a.part_pre, (uint32_t)(3 * Lo.n_blocks),
+                           (uint32_t *)nullptr, 0u, (const uint32_t *)(a.result + 6));
+        hipLaunchKernelGGL(k_part_scatter, dim3(grid), dim3(256), 0, st, a);
+        a.tus = a.sorted;
+    }
+    if (hooks && hooks->tus_used) *hooks->tus_used = a.tus;
     hipLaunchKernelGGL(k_plan_owner, dim3(grid), dim3(256), 0, st, a);
     /* the depth sweep needs the cells' edges, which k_plan_owner has just left: three workgroups walking diagonals for 50 - 130 us -- next to
      * k_plan_count on a stream of the caller's where there is one, in front of the ticket kernels otherwise */

@@ -114,7 +114,9 @@ extern "C" int ffhip_side_stream_get(FfhipSide *out);
  *                     -- and the ticket kernels and k_plan_emit later (NULL: everything in line on the planner's stream)
  *   after_count       behind k_plan_count: flags and wait counts are final (the per-pixel programs)
  *   tickets_wait      (ticket_stream given) make that stream wait for k_plan_count, in front of the ticket kernels
- *   tickets_enqueued  (ticket_stream given) the schedule's last kernel is on that stream: whoever reads the schedule waits for it */
+ *   tickets_enqueued  (ticket_stream given) the schedule's last kernel is on that stream: whoever reads the schedule waits for it
+ *   by_plane          the list interleaves the planes inside a scheduling window (the reference's own order, coding/hevc.c:5013-5180): plan and
+ *                     decode a stable partition of it by plane; *tus_used then points at that copy (in the planner's scratch) */
 struct FfhipPlanHooks {
     void *ctx;
     int (*after_check)(void *ctx, const unsigned *refused);
@@ -122,6 +124,8 @@ struct FfhipPlanHooks {
     int (*after_count)(void *ctx, const unsigned char *flags, const unsigned *wcount, const unsigned *result);
     int (*tickets_wait)(void *ctx);
     int (*tickets_enqueued)(void *ctx);
+    int by_plane;                       /* sort the list by plane in front of k_plan_owner (ffhip_hevc_plan_gpu.hip, k_part_*) */
+    const ffhip_hevc_tu **tus_used;     /* out, set before after_count runs: the records the schedule's TU indices refer to (the caller's, or the sorted copy) */
 };
 
 #endif

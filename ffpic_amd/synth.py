@@ -193,11 +193,64 @@ def _c5_mix(rng, x0, y0, size, big, out):
         out.extend(((x0, y0, h), (x0 + h, y0, h), (x0, y0 + h, h), (x0 + h, y0 + h, h)))
 
 
+def _reference_cu_order(rng, per_plane, cx, cy, ctb, csub):
+    """The order decode_cu_coded_intra_prediction_mode (coding/hevc.c:5013-5180) walks one coding tree block in: coding unit by
+    coding unit in z-order, and per unit the whole luma transform tree, then the Cb tree, then the Cr tree (one
+    decode_intra_block call per component, hevc.c:4665-4805).  per_plane[c] = this block's TUs of plane c as (index, x, y, n) in
+    z-order; a coding unit is a quadtree node of 64 / 32 / 16 / 8 luma samples that no TU of any plane straddles (the node is
+    split further with probability 0.6 where the TUs allow it).  Returns the indices in that order."""
+    out = []
+
+    def inside(c, x0, y0, size):
+        sc = 1 if c == 0 else csub
+        x0, y0, size = x0 // sc, y0 // sc, size // sc
+        return [t for t in per_plane[c] if x0 <= t[1] < x0 + size and y0 <= t[2] < y0 + size]
+
+    def cu(x0, y0, size):
+        tus = [inside(c, x0, y0, size) for c in range(len(per_plane))]
+        if not any(tus):
+            return
+        h = size // 2
+        can_split = h >= 8 and all(t[3] <= h // (1 if c == 0 else csub) for c in range(len(per_plane)) for t in tus[c])
+        if can_split and rng.random() < 0.6:
+            for (dx, dy) in ((0, 0), (h, 0), (0, h), (h, h)):
+                cu(x0 + dx, y0 + dy, h)
+        else:
+            for c in range(len(per_plane)):
+                out.extend(t[0] for t in tus[c])
+    cu(cx, cy, ctb)
+    return out
+
+
+def hevc_reference_order(tus, ctb=64, csub=2, seed=0, return_perm=False):
+    """A list as hevc_intra_tus(order="plane") makes it -- per coding tree block the luma TUs, then Cb, then Cr -- in the order the
+    reference decodes it in (_reference_cu_order).  Every plane keeps its own order, so availability masks stay what they are."""
+    rng = np.random.default_rng(SEED_BASE + 15500 + seed)         # (its own stream: the TUs are the same in both orders)
+    sc = np.where(tus["cidx"] == 0, 1, csub).astype(np.int64)
+    bx, by = tus["x"].astype(np.int64) * sc // ctb, tus["y"].astype(np.int64) * sc // ctb
+    starts = np.concatenate([[0], np.nonzero((bx[1:] != bx[:-1]) | (by[1:] != by[:-1]))[0] + 1, [len(tus)]])
+    n_planes = int(tus["cidx"].max()) + 1 if len(tus) else 1
+    x, y, n, c = tus["x"].tolist(), tus["y"].tolist(), (1 << tus["log2_size"].astype(np.int64)).tolist(), tus["cidx"].tolist()
+    perm = []
+    for a, b in zip(starts[:-1].tolist(), starts[1:].tolist()):
+        per_plane = [[] for _ in range(n_planes)]
+        for i in range(a, b):
+            per_plane[c[i]].append((i, x[i], y[i], n[i]))
+        got = _reference_cu_order(rng, per_plane, int(bx[a]) * ctb, int(by[a]) * ctb, ctb, csub)
+        assert len(got) == b - a
+        perm.extend(got)
+    perm = np.asarray(perm, dtype=np.int64)
+    assert np.array_equal(np.sort(perm), np.arange(len(tus)))
+    return (tus[perm], perm) if return_perm else tus[perm]
+
+
 def hevc_intra_tus(width, height, seed=0, ctb=64, chroma=True, min_tu=4, adversarial_masks=False, ccp=False,
-                   chroma_444=False, tu_mix=None):
+                   chroma_444=False, tu_mix=None, order="plane"):
     """A whole intra picture as a list of TUs in decode order (CTBs in raster order, z-order
     inside a CTB; per CTB: luma TUs, then Cb, then Cr), with z-scan neighbour availability,
-    random modes 0..34 and flags.  ccp=True marks about half of the chroma TUs that carry a residual
+    random modes 0..34 and flags.  order="reference": the SAME TUs (records, residuals, availability) in the order the
+    reference decodes them in -- per coding unit the luma tree, then Cb, then Cr, with coding units of 64 / 32 / 16 / 8
+    inside a coding tree block (_reference_cu_order): every plane keeps its own order, the planes interleave.  ccp=True marks about half of the chroma TUs that carry a residual
     for cross-component prediction (ResScaleVal in {+-1, +-2, +-4, +-8}); chroma_444=True gives the chroma
     planes the luma size (ChromaArrayType 3, where the reference enables it).
     tu_mix="c5" replaces the random quadtree by the TU mix SURVEY 8d names for BASELINE config 5: luma 32/16 at
@@ -255,7 +308,10 @@ def hevc_intra_tus(width, height, seed=0, ctb=64, chroma=True, min_tu=4, adversa
                         rsv = int(rng.choice([1, 2, 4, 8])) * int(rng.choice([-1, 1]))
                     tus.append((x0, y0, int(np.log2(n)), c, mode, fl, ro, rsv, at, al))
                     d[y0:y0 + n, x0:x0 + n] = True
+    assert order in ("plane", "reference")
     arr = np.array(tus, dtype=HEVC_TU_DTYPE)
+    if order == "reference":
+        arr = hevc_reference_order(arr, ctb, csub, seed)
     res = np.concatenate(res_parts) if res_parts else np.zeros(1, np.int16)
     return arr, res
 

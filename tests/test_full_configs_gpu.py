@@ -88,7 +88,7 @@ def test_4k_batches_of_the_other_layouts(h, v):
     _jpeg_full_batch(cols, rows, 64, 3, seed=4100 + 10 * h + v, h=h, v=v)
 
 
-def _intra_full_picture(W, H, tus, res, envs=({},), monkeypatch=None):
+def _intra_full_picture(W, H, tus, res, envs=({},), monkeypatch=None, sorted_by_plane=None):
     """... once per entry of `envs` (library switches for the call: the oracle's picture is worked out once)"""
     torch = pytest.importorskip("torch")
     L = capi.require_device()
@@ -113,6 +113,7 @@ def _intra_full_picture(W, H, tus, res, envs=({},), monkeypatch=None):
             verdict = (C.c_uint32 * 8)()   # the device planner took the list, with wavefront tickets: not the one-wave serial path
             capi.check(L.ffhip_debug_hevc_plan_result(verdict), "ffhip_debug_hevc_plan_result")
             assert verdict[0] == 0 and verdict[3] == 0 and verdict[6] == 0, (env, list(verdict))
+            assert verdict[5] == 6 and (sorted_by_plane is None or bool(verdict[7]) == sorted_by_plane), (env, list(verdict))
             for got, e, name in zip((py, pu, pv), exp, "YUV"):
                 g = got.cpu().numpy()
                 if not np.array_equal(g, e):
@@ -132,7 +133,11 @@ def test_c5_8k_intra_picture(mix, seed):
     W, H = 7680, 4352
     tus, res = synth.hevc_intra_tus(W, H, seed=seed, tu_mix=mix)
     assert len(tus) > (600_000 if mix is None else 40_000)
-    _intra_full_picture(W, H, tus, res)
+    exp = _intra_full_picture(W, H, tus, res, sorted_by_plane=False)
+    # the same picture from the list in the reference's order: per coding unit the luma tree, then Cb, then Cr (coding/hevc.c:5013-5180)
+    exp_r = _intra_full_picture(W, H, synth.hevc_reference_order(tus, 64, 2, seed), res, sorted_by_plane=True)
+    for a, b in zip(exp, exp_r):
+        assert np.array_equal(a, b)
 
 
 def test_c5_48_tile_grid():
@@ -165,10 +170,24 @@ def test_c5_135_tile_8k_grid(monkeypatch):
     tus["x"] = (tus["x"].astype(np.int64) + (k % gx) * sc).astype(np.uint16)
     tus["y"] = (tus["y"].astype(np.int64) + (k // gx) * sc).astype(np.uint16)
     tus["res_offset"] += (k * len(res0)).astype(np.uint32)
+    def grid_of(t0):
+        tus = np.tile(t0, K)
+        k = np.repeat(np.arange(K), len(t0))
+        sc = np.where(tus["cidx"] == 0, T, T // 2)
+        tus["x"] = (tus["x"].astype(np.int64) + (k % gx) * sc).astype(np.uint16)
+        tus["y"] = (tus["y"].astype(np.int64) + (k // gx) * sc).astype(np.uint16)
+        tus["res_offset"] += (k * len(res0)).astype(np.uint32)
+        return tus
     exp = _intra_full_picture(T * gx, T * gy, tus, np.tile(res0, K), envs=({}, {"FFHIP_HEVC_INTRA_TP_WIDTH": "1"}, {"FFHIP_HEVC_TICKET_SHARDS": "1"}, {"FFHIP_HEVC_TICKET_SHARDS": "8"},
                                     {"FFHIP_HEVC_SWEEP_INLINE": "1"}, {"FFHIP_HEVC_DEPTH_DIAGONALS": "1"}, {"FFHIP_HEVC_PROGRAMS_INLINE": "1"},
                                     {"FFHIP_HEVC_JT_INLINE": "1"}),
-                              monkeypatch=monkeypatch)
+                              monkeypatch=monkeypatch, sorted_by_plane=False)
+    assert np.array_equal(grid_of(t0), tus)
+    # every tile's list in the reference's order (per coding unit: luma, Cb, Cr): sorted by plane on the device, same picture
+    exp_r = _intra_full_picture(T * gx, T * gy, grid_of(synth.hevc_reference_order(t0, 64, 2, 6)), np.tile(res0, K),
+                                envs=({}, {"FFHIP_HEVC_JT_INLINE": "1"}), monkeypatch=monkeypatch, sorted_by_plane=True)
+    for a, b in zip(exp, exp_r):
+        assert np.array_equal(a, b)
     for i in range(1, K):
         ox, oy = (i % gx) * T, (i // gx) * T
         assert np.array_equal(exp[0][oy:oy + T, ox:ox + T], exp[0][:T, :T]), i

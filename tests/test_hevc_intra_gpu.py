@@ -8,6 +8,20 @@ from ffpic_amd import capi, ops, synth
 pytestmark = pytest.mark.gpu
 
 
+def assert_wavefront_schedule(sorted_by_plane=None):
+    """what the device planner made of the list of the call just made: taken (not left to the one-wave serial kernel), tickets by coding-tree
+    wavefront (not decode order), 64x64 luma windows; sorted_by_plane: whether the list had to be sorted by plane for that"""
+    import ctypes as C
+    out = (C.c_uint32 * 8)()
+    capi.check(capi.lib().ffhip_debug_hevc_plan_result(out), "ffhip_debug_hevc_plan_result")
+    assert out[6] == 0 and out[0] == 0 and out[1] > 0, list(out)
+    assert out[3] == 0 and out[4] > 0, list(out)
+    assert out[5] == 6, list(out)
+    if sorted_by_plane is not None:
+        assert bool(out[7]) == sorted_by_plane, list(out)
+    return list(out)
+
+
 def test_golden_tu_lists(golden):
     g = golden("hevc_intra.npz")
     for tag in "abcde":     # d, e: 4:4:4 with cross-component prediction
@@ -73,18 +87,23 @@ def test_every_mode_and_size_isolated():
                                  {"FFHIP_HEVC_INTRA_WINDOW": "3"},
                                  {"FFHIP_HEVC_INTRA_WINDOW": "4"}, {"FFHIP_HEVC_INTRA_WINDOW": "5"},
                                  {"FFHIP_HEVC_INTRA_WINDOW": "6"}, {"FFHIP_HEVC_INTRA_WAVES": "3"},
-                                 {"FFHIP_HEVC_DEPTH_DIAGONALS": "1"}, {"FFHIP_HEVC_TICKET_SHARDS": "1"}, {"FFHIP_HEVC_INTRA_WIDTH_PCT": "1"}])
+                                 {"FFHIP_HEVC_DEPTH_DIAGONALS": "1"}, {"FFHIP_HEVC_TICKET_SHARDS": "1"}, {"FFHIP_HEVC_INTRA_WIDTH_PCT": "1"},
+                                 {"FFHIP_HEVC_BY_PLANE": "0"}, {"FFHIP_HEVC_BY_PLANE": "1"}, {"FFHIP_HEVC_BY_PLANE": "1", "FFHIP_HEVC_PLAN": "host"},
+                                 {"FFHIP_HEVC_INTRA_DECODE_ORDER": "1", "FFHIP_HEVC_PLAN": "host"}, {"FFHIP_HEVC_INTRA_POLL_REPS": "4"},
+                                 {"FFHIP_PLAN_THREADS": "3", "FFHIP_HEVC_PLAN": "host"}])
 def test_schedulers_agree(env, monkeypatch):
-    """the level-synchronous launches and the grouped single launch (any window) give the oracle's picture"""
+    """the level-synchronous launches and the grouped single launch (any window) give the oracle's picture -- on lists with each coding
+    tree block's planes one after the other and on the same lists in the reference's order (per coding unit: luma, Cb, Cr)"""
     for k, v in env.items():
         monkeypatch.setenv(k, v); capi.reload_env()
     for (w, h, seed, adv, c444) in ((256, 192, 41, False, False), (192, 128, 42, True, False), (128, 128, 43, True, True)):
         tus, res = synth.hevc_intra_tus(w, h, seed, adversarial_masks=adv, ccp=c444, chroma_444=c444)
         csub = 1 if c444 else 2
-        got = ops.hevc_intra_recon(tus, res, w, h, True, 8, 8, csub=csub)
         exp = O.oracle_hevc_intra(tus, res, w, h, True, 8, 8, csub=csub)
-        for gp, e, name in zip(got, exp, "YUV"):
-            assert np.array_equal(gp, e), (env, name)
+        for order, lst in (("plane", tus), ("reference", synth.hevc_reference_order(tus, 64, csub, seed))):
+            got = ops.hevc_intra_recon(lst, res, w, h, True, 8, 8, csub=csub)
+            for gp, e, name in zip(got, exp, "YUV"):
+                assert np.array_equal(gp, e), (env, order, name)
 
 
 def test_grouped_form_small_ctb_falls_back_to_smaller_window():
@@ -173,6 +192,7 @@ def test_hevc_file_config5(golden, tag):
             resid[o:o + n * n] = got[k]
     assert np.array_equal(resid[:len(lv)], g[f"{tag}_resid"])
     y, u, v = ops.hevc_intra_recon(tus, resid, w, h, True, 8, 8)
+    assert_wavefront_schedule()
     assert np.array_equal(y, g[f"{tag}_y"]) and np.array_equal(u, g[f"{tag}_u"]) and np.array_equal(v, g[f"{tag}_v"])
     bgra = ops.yuv420_to_bgra_16(y[None], u[None], v[None], h // 64, w // 64, 64)[0]
     assert np.array_equal(bgra, g[f"{tag}_bgra"])
@@ -203,6 +223,7 @@ def test_hevc_file_1080p(golden):
         resid[(offs[:, None] + np.arange(n * n)[None, :]).reshape(-1)] = got.reshape(-1)
     assert np.array_equal(sha(resid[:len(lv)]), g["g_sha_resid"])
     y, u, v = ops.hevc_intra_recon(tus, resid, w, h, True, 8, 8)
+    assert_wavefront_schedule(sorted_by_plane=True)    # 56 888 plane switches in 93 330 records
     assert np.array_equal(sha(y), g["g_sha_y"]) and np.array_equal(sha(u), g["g_sha_u"]) and np.array_equal(sha(v), g["g_sha_v"])
     size, rows = w * h, -(-h // 64) * 64
     planes = np.zeros(2 * size, np.int16)
@@ -349,4 +370,25 @@ def test_device_planner_takes_what_it_should(w, h, seed, kw, keys):
     assert (out[4] > 0) == (out[3] == 0)                   # the widest wavefront is known exactly when there are wavefront tickets
     exp = O.oracle_hevc_intra(tus, res, w, h, True, 8, 8, csub=csub)
     for gp, e, name in zip(got, exp, "YUV"):
+        assert np.array_equal(gp, e), name
+
+
+@pytest.mark.parametrize("w,h,seed,kw", [(512, 512, 5, dict(tu_mix="c5")), (512, 384, 2, dict()), (1920, 1088, 2, dict(tu_mix="c5")),
+                                         (256, 192, 9, dict(min_tu=8))])
+def test_reference_order_takes_the_wavefront_schedule(w, h, seed, kw):
+    """The reference decodes coding unit by coding unit -- luma tree, Cb, Cr (coding/hevc.c:5013-5180) -- so its TU lists switch planes inside
+    every 64x64 area.  The planner defines runs, window visits and cell visits on each plane's own subsequence (it works on the list sorted by
+    plane): such a list gets the 64x64 windows, as many groups and the coding-tree wavefront tickets of the same list with the planes of a
+    coding tree block one after the other -- and the same picture."""
+    tus, res = synth.hevc_intra_tus(w, h, seed, **kw)
+    ref = synth.hevc_reference_order(tus, 64, 2, seed)
+    assert (ref["cidx"][1:] != ref["cidx"][:-1]).sum() > (tus["cidx"][1:] != tus["cidx"][:-1]).sum()
+    exp = O.oracle_hevc_intra(ref, res, w, h, True, 8, 8)
+    got_p = ops.hevc_intra_recon(tus, res, w, h, True, 8, 8)
+    plan_p = assert_wavefront_schedule(sorted_by_plane=False)
+    got_r = ops.hevc_intra_recon(ref, res, w, h, True, 8, 8)
+    plan_r = assert_wavefront_schedule(sorted_by_plane=True)
+    assert plan_r[1] == plan_p[1] and plan_r[4] == plan_p[4], (plan_p, plan_r)     # groups, widest wavefront
+    for gp, gr, e, name in zip(got_p, got_r, exp, "YUV"):
+        assert np.array_equal(gr, e), name
         assert np.array_equal(gp, e), name

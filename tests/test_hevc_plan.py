@@ -71,3 +71,61 @@ def test_plan_rejects_a_list_no_window_fits():
     rc3, tk, _, _ = plan(t, 128, 64, 0, 0, 3)
     if rc3 == 0:
         assert tk[1] < tk[2]
+
+
+def check_order(tus, dims, tk, wt):
+    deps = neighbour_owners(tus, dims)
+    for i, d in enumerate(deps):
+        other = {j for j in d if tk[j] != tk[i]}
+        assert all(tk[j] < tk[i] for j in other), i
+        assert wt[i] == len(other), i
+
+
+@pytest.mark.parametrize("w,h,seed,kw", [(256, 192, 1, dict(tu_mix="c5")), (256, 128, 2, dict(adversarial_masks=True)),
+                                         (128, 128, 5, dict(chroma_444=True)), (192, 128, 7, dict(min_tu=8))])
+def test_reference_order_plans_like_plane_order(w, h, seed, kw):
+    """The reference decodes per coding unit: luma tree, Cb, Cr (coding/hevc.c:5013-5180).  A run, a window visit and a cell visit are
+    defined on each plane's OWN subsequence of the list, so the list in that order gets the same windows, groups and wait entries as the
+    list with each coding tree block's planes one after the other -- group for group (the same TUs share a ticket group)."""
+    a, _ = synth.hevc_intra_tus(w, h, seed, **kw)
+    b, _ = synth.hevc_intra_tus(w, h, seed, order="reference", **kw)
+    assert (b["cidx"][1:] != b["cidx"][:-1]).sum() > (a["cidx"][1:] != a["cidx"][:-1]).sum()
+    cw, ch = (w, h) if kw.get("chroma_444") else (w // 2, h // 2)
+    rca, tka, wta, sta = plan(a, w, h, cw, ch, 6)
+    rcb, tkb, wtb, stb = plan(b, w, h, cw, ch, 6)
+    assert rca == 0 and rcb == 0
+    assert list(sta) == list(stb) and int(stb[1]) == 6
+    check_order(b, [(w, h), (cw, ch), (cw, ch)], tkb, wtb)
+    key = lambda t: (int(t["cidx"]), int(t["y"]), int(t["x"]))
+    ga = {}
+    for i, t in enumerate(a):
+        ga.setdefault(int(tka[i]), set()).add(key(t))
+    gb = {}
+    for i, t in enumerate(b):
+        gb.setdefault(int(tkb[i]), set()).add(key(t))
+    assert sorted(map(sorted, ga.values())) == sorted(map(sorted, gb.values()))
+
+
+def test_by_plane_switch_off_still_plans(monkeypatch):
+    """FFHIP_HEVC_BY_PLANE=0 is the rule until round 5 (runs of the list as it is).  The HOST planner takes groups in order of first
+    appearance whether or not they are contiguous runs, so it still plans the reference's order at 64x64 -- with decode-order tickets; it is
+    the device planner that needs contiguous runs (tests/test_hevc_intra_gpu.py::test_reference_order_takes_the_wavefront_schedule)"""
+    b, _ = synth.hevc_intra_tus(256, 192, 1, tu_mix="c5", order="reference")
+    monkeypatch.setenv("FFHIP_HEVC_BY_PLANE", "0"); capi.reload_env()
+    rc, tk, wt, st = plan(b, 256, 192, 128, 96, 6)
+    monkeypatch.delenv("FFHIP_HEVC_BY_PLANE"); capi.reload_env()
+    assert rc == 0
+    check_order(b, [(256, 192), (128, 96), (128, 96)], tk, wt)
+
+
+@pytest.mark.parametrize("name,tags", [("hevc_file.npz", "abcdef"), ("hevc_file_1080p.npz", "g")])
+def test_lists_the_reference_recorded_take_the_64_window(golden, name, tags):
+    """the seven TU lists the reference's own decoder recorded (plane-major per coding unit): 64x64 windows, one group per window and plane"""
+    g = golden(name)
+    for tag in tags:
+        w, h = int(g[f"{tag}_dims"][0]), int(g[f"{tag}_dims"][1])
+        tus = np.ascontiguousarray(g[f"{tag}_tus"]).view(synth.HEVC_TU_DTYPE).reshape(-1).copy()
+        rc, tk, wt, st = plan(tus, w, h, w // 2, h // 2, 6)
+        assert rc == 0 and int(st[1]) == 6, (tag, list(st))
+        wins = {(int(t["cidx"]), int(t["y"]) >> (6 if t["cidx"] == 0 else 5), int(t["x"]) >> (6 if t["cidx"] == 0 else 5)) for t in tus}
+        assert int(st[0]) == len(wins), (tag, int(st[0]), len(wins))

@@ -385,7 +385,12 @@ int ffhip_vp8_decode_frames(int mbcols, int mbrows, int n_images, const uint8_t 
  * construct_pic_pior_to_filtering (hevc.c:4252-4274) into int16 sample planes laid out like
  * the reference's picture (hevc.c:7225-7230).  TUs are listed in decode order; what the
  * reference derives while parsing (neighbour availability by z-scan order / slice / tile,
- * hevc.c:4570-4608) arrives here as bit masks. */
+ * hevc.c:4570-4608) arrives here as bit masks.
+ * Order contract: inside each PLANE a TU follows every TU its availability bits point at; how the planes
+ * interleave is free (they never read each other here).  The reference's own order -- per coding unit the luma
+ * tree, then Cb, then Cr (decode_cu_coded_intra_prediction_mode, hevc.c:5013-5180) -- is taken as it comes:
+ * scheduling runs are defined on each plane's own subsequence, and a list that switches planes inside a
+ * scheduling window is sorted by plane (a stable device-side copy) in front of the planner. */
 typedef struct ffhip_hevc_tu {
     uint16_t x, y;       /* top-left of the TU in samples of its component plane           */
     uint8_t log2_size;   /* 2..5                                                            */
@@ -430,8 +435,9 @@ int ffhip_hevc_intra_plan(const ffhip_hevc_tu *h_tus, long long n_tus, int width
                           uint32_t *out_wait, int32_t *stats);
 /* Diagnostics: what the DEVICE planner made of the list of this thread's last ffhip_hevc_intra_recon call (which it waits for):
  * out[0] != 0 the plan was refused and the list decoded by the one-wave serial kernel (exact, slow); out[1] groups; out[3] != 0 the
- * tickets are in decode order (no coding-tree wavefront found); out[4] the widest wavefront; out[6] != 0 a record failed the device's
- * validation.  FFHIP_EINVAL when that call did not use the device planner. */
+ * tickets are in decode order (no coding-tree wavefront found); out[4] the widest wavefront; out[5] log2 of the luma scheduling window;
+ * out[6] != 0 a record failed the device's validation; out[7] != 0 the list was sorted by plane first (it interleaves the planes inside a
+ * window, as the reference's order does).  FFHIP_EINVAL when that call did not use the device planner. */
 int ffhip_debug_hevc_plan_result(uint32_t out[8]);
 int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu *d_tus, long long n_tus,
                            const int16_t *d_residual, int16_t *d_y, int16_t *d_cb, int16_t *d_cr,

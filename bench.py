@@ -443,7 +443,7 @@ class C4:
                 B.s_frames()
                 host_ms = (time.perf_counter() - t0) * 1e3          # what the enqueue call itself costs the host
                 row = {"frames": nf, "chain_ms": round(ms, 4), "value": round(nf * B.Hp * B.Wp / ms / 1e3, 1), "unit": "Mpixels/s",
-                       "decode_frames_ms": round(fr, 4), "form": "fused" if nf >= 128 else "rows",
+                       "decode_frames_ms": round(fr, 4), "form": "fused" if self.L.ffhip_vp8_decode_frames_form(nf) == 1 else "rows",
                        "row_kernels_predict+loopfilter_ms": round(pl, 4), "host_enqueue_ms": round(host_ms, 3)}
                 if parity_at_largest and nf == max(sizes):
                     B.one_clean_pass()
@@ -511,7 +511,7 @@ def extra_c4(L, dev, stream, T, cpu=True, sweep_sizes=(1, 16, 64, 256, 1024)):
         del E
         torch.cuda.empty_cache()
     if sweep_sizes:
-        res["batch_sweep"] = {"workload": "the chain (ffhip_vp8_residual_batch -> ffhip_vp8_decode_frames: the fused frame kernel from 128 frames on, the row kernels + colour "
+        res["batch_sweep"] = {"workload": "the chain (ffhip_vp8_residual_batch -> ffhip_vp8_decode_frames: the fused frame kernel from half the device's compute units in frames on (128 on an MI355X; ffhip_vp8_decode_frames_form), the row kernels + colour "
                                           "kernel below) against the number of 1920x1088 frames in ONE call each; `encoder`: copies of the libwebp frame, `random`: 16 distinct "
                                           "frames of uniformly random modes, tiled",
                               **X.sweep(sweep_sizes)}

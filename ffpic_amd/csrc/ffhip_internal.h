@@ -82,8 +82,14 @@ struct FfhipVp8Fusion {
     void *fork;  /* hipEvent_t  */
     int pred_split; /* the prediction runs luma and chroma rows apart: its chroma counters (behind the luma ones) count too */
     int pshift; /* a row's progress counter is word (image * mbrows + row) << pshift */
+    int *err_word; /* where the two kernels of THIS call report a bounded wait that ran out: the call's own pinned word (its retry record's), so that
+                      nobody else's abort can set off the retry; NULL = the process-wide word */
 };
 extern thread_local FfhipVp8Fusion g_ffhip_vp8_fusion;
+/* ffhip_vp8_decode_frames (row form) -> ffhip_vp8_predict_loopfilter: the colour conversion the caller enqueues behind the call belongs to it -- a
+ * retry has to run it again, behind the filter (consumed, i.e. switched off, by the callee) */
+struct FfhipVp8Then { int on; uint8_t *bgra; int pitch; int64_t image_stride; };
+extern thread_local FfhipVp8Then g_ffhip_vp8_then;
 
 /* the calling thread's side stream with its fork / join events (ffhip_vp8_lf.hip: one set per thread and device, released by ffhip_shutdown) */
 struct FfhipSide { void *stream, *fork, *join, *mid, *aux; }; /* mid: a second point of the main stream the side stream may wait for; aux: a second

@@ -216,6 +216,7 @@ extern "C" const char *ffhip_strerror(int code)
 {
     switch (code) {
     case FFHIP_OK: return "ok";
+    case FFHIP_RETRIED: return "a side-by-side VP8 call was repeated by the sync: its outputs are good, what was enqueued behind it is stale";
     case FFHIP_EINVAL: return "invalid argument or unsupported geometry";
     case FFHIP_ENOMEM: return "out of memory";
     case FFHIP_ENODEV: return g_last_error[0] ? g_last_error : "no usable gfx950 device";
@@ -256,36 +257,30 @@ extern "C" void *ffhip_stream_create(void)
     return (void *)s;
 }
 extern "C" void ffhip_stream_destroy(void *s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
-extern "C" int ffhip_vp8_side_by_side_retry(void *stream, int code); /* ffhip_vp8_lf.hip: > 0 nothing to retry on this stream, 0 healed, < 0 failed */
+extern "C" int ffhip_vp8_side_by_side_retry(void *stream); /* ffhip_vp8_lf.hip: 0 nothing reported by a side-by-side call of this stream, FFHIP_RETRIED repeated, FFHIP_EIO */
 extern "C" void ffhip_vp8_retry_forget(void *stream);
 extern "C" int ffhip_stream_sync(void *s)
 {
     FFHIP_CHECK(hipStreamSynchronize((hipStream_t)s), FFHIP_EIO);
+    /* A bounded wait of a side-by-side VP8 call of THIS stream ran out (reported in a pinned word of that call's own: possible on a device
+     * shared with other work, where one of its two kernels may not become resident next to the other).  Its inputs are intact and the one thing
+     * of the planes' former contents it reads is kept (the last luma column), so the library repeats the stages ONE AFTER THE OTHER here and
+     * says so: FFHIP_RETRIED, not FFHIP_OK -- what the caller had enqueued behind the call has consumed the aborted run's planes. */
+    const int retried = ffhip_vp8_side_by_side_retry(s);
+    if (retried < 0) {
+        snprintf(g_last_error, sizeof g_last_error, "a side-by-side VP8 call aborted and could not be repeated");
+        if (g_async_err) *(volatile int *)g_async_err = 0;
+        return FFHIP_EIO;
+    }
     if (g_async_err && *(volatile int *)g_async_err) {
-        int code = *(volatile int *)g_async_err;
-        /* A bounded wait of the side-by-side VP8 call ran out (codes 2 / 3: possible on a device shared with other work, where one of its two
-         * kernels may not become resident next to the other).  Its inputs are intact and the one thing of the planes' former contents it reads is
-         * kept (the last luma column), so the library repeats the two stages ONE AFTER THE OTHER here and reports what that run did. */
-        if (code == 2 || code == 3) {
-            *(volatile int *)g_async_err = 0;
-            const int rc = ffhip_vp8_side_by_side_retry(s, code);
-            if (rc == 0) {
-                if (hipStreamSynchronize((hipStream_t)s) != hipSuccess) return FFHIP_EIO;
-                code = *(volatile int *)g_async_err;
-                if (!code) return FFHIP_OK;
-            } else if (rc > 0 || !*(volatile int *)g_async_err) {
-                *(volatile int *)g_async_err = code; /* not this stream's call, or the retry could not be enqueued: as before */
-            } else {
-                code = *(volatile int *)g_async_err;
-            }
-        }
+        const int code = *(volatile int *)g_async_err;
         snprintf(g_last_error, sizeof g_last_error, code == FFHIP_ASYNC_BAD_INPUT ? "a dependency-scheduled kernel refused its input (code %d)"
                                                                                    : "a dependency-scheduled kernel aborted (code %d)", code);
         *(volatile int *)g_async_err = 0;
         return code == FFHIP_ASYNC_BAD_INPUT ? FFHIP_EINVAL : FFHIP_EIO;
     }
     ffhip_vp8_retry_forget(s);
-    return FFHIP_OK;
+    return retried;
 }
 extern "C" void *ffhip_event_create(void)
 {

@@ -401,6 +401,7 @@ extern "C" int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int fi
     /* row form (default): one launch, no host-side scheduling */
     const char *mode_env = FFHIP_ENV("FFHIP_VP8_LF_MODE");
     int *async_err = (mode_env && !strcmp(mode_env, "levels")) ? nullptr : ffhip_async_err_word();
+    if (async_err && g_ffhip_vp8_fusion.active && g_ffhip_vp8_fusion.err_word) async_err = g_ffhip_vp8_fusion.err_word; /* the side-by-side call's own word */
     if (async_err && !((uintptr_t)d_modes & 3) && !(((uintptr_t)d_y | (uintptr_t)d_u | (uintptr_t)d_v | (uintptr_t)plane_stride_y | (uintptr_t)plane_stride_uv) & 3) &&
         n_mb < (1LL << 23)) {
         const int pshift = []{ const char *e = FFHIP_ENV("FFHIP_VP8_PROGRESS_SHIFT"); return e ? std::min(5, std::max(0, atoi(e))) : 5; }();
@@ -567,18 +568,23 @@ extern "C" int ffhip_side_stream_get(FfhipSide *out)
     out->stream = ss->side; out->fork = ss->fork; out->join = ss->join; out->mid = ss->mid; out->aux = ss->aux;
     return FFHIP_OK;
 }
+extern "C" void ffhip_vp8_retry_release(void);
 extern "C" void ffhip_vp8_release_side_streams(void) /* ffhip_shutdown: nothing of the library's is in flight */
 {
+    ffhip_vp8_retry_release();
     std::lock_guard<std::mutex> l(g_side_mu);
     for (SideStream *s : g_sides) side_release(s);
 }
 
-/* ---- the side-by-side call heals itself ----
+/* ---- the side-by-side call is repeated by ffhip_stream_sync when it could not finish ----
  * What the prediction reads of the planes' FORMER contents is one column: the reference's wrapped 16x16 H_PRED at x = 0 reads the sample left
  * of a row's first pixel, i.e. the plane's last column a line further up (predict.c:346-353).  The one-call form keeps a copy of that column
- * (one byte per picture line) and a record of its arguments per stream; when a bounded wait of either kernel has run out, ffhip_stream_sync
- * puts the column back and runs prediction, then filter, one after the other -- everything else the two stages read is their inputs, which are
- * intact -- so the caller sees FFHIP_OK and the bytes of an undisturbed call. */
+ * (one byte per picture line) and a record of its arguments per stream; its two kernels report a bounded wait that ran out in a pinned word
+ * of the RECORD's own -- so no other stream's or kernel's abort can set the retry off, and a record whose call ran clean never fires --; when
+ * that word is set, ffhip_stream_sync puts the column back and runs prediction, then filter (then the colour conversion, for
+ * ffhip_vp8_decode_frames' row form), one after the other -- everything else the stages read is their inputs, which are intact.  The sync
+ * then says FFHIP_RETRIED, not FFHIP_OK: the planes hold the bytes of an undisturbed call, but what the CALLER enqueued behind the call has
+ * consumed the aborted run's (round 4 said FFHIP_OK, and converted the aborted planes to BGRA in ffhip_vp8_decode_frames' row form). */
 #define SCRATCH_VP8_RETRY 8
 __global__ __launch_bounds__(256) void k_vp8_last_column(uint8_t *y, long long plane_y, int ys, int rows, int n_images, uint8_t *keep, int restore)
 {
@@ -589,16 +595,20 @@ __global__ __launch_bounds__(256) void k_vp8_last_column(uint8_t *y, long long p
     if (restore) *p = keep[i];
     else keep[i] = *p;
 }
+thread_local FfhipVp8Then g_ffhip_vp8_then = {0, nullptr, 0, 0};
 namespace {
-struct Vp8Retry {
-    int mbcols, mbrows, n_images, filter_type;
+struct Vp8Retry { /* one per stream, kept (the mode copy's storage and the pinned word are reused call after call); `armed` says whether it describes a call */
+    bool armed = false;
+    int mbcols = 0, mbrows = 0, n_images = 0, filter_type = 0;
     std::vector<uint8_t> h_modes;
-    const uint8_t *d_modes, *d_filters;
-    const int16_t *d_residual;
-    int64_t residual_stride, plane_y, plane_uv;
-    const int32_t *d_resmap;
-    uint8_t *y, *u, *v, *keep;
-    unsigned long long seq;
+    const uint8_t *d_modes = nullptr, *d_filters = nullptr;
+    const int16_t *d_residual = nullptr;
+    int64_t residual_stride = 0, plane_y = 0, plane_uv = 0;
+    const int32_t *d_resmap = nullptr;
+    uint8_t *y = nullptr, *u = nullptr, *v = nullptr, *keep = nullptr;
+    FfhipVp8Then then = {0, nullptr, 0, 0};
+    int *err = nullptr; /* pinned, device-visible: the call's own abort word */
+    unsigned long long seq = 0;
 };
 std::mutex g_retry_mu;
 std::map<void *, Vp8Retry> g_retry; /* by stream: the last side-by-side call enqueued there */
@@ -612,19 +622,33 @@ extern "C" void ffhip_vp8_note_enqueue(void *stream)
 extern "C" void ffhip_vp8_retry_forget(void *stream) /* a clean ffhip_stream_sync: whatever was enqueued there has run */
 {
     std::lock_guard<std::mutex> l(g_retry_mu);
-    g_retry.erase(stream);
+    auto it = g_retry.find(stream);
+    if (it != g_retry.end()) it->second.armed = false;
 }
-extern "C" int ffhip_vp8_side_by_side_retry(void *stream, int code)
+extern "C" void ffhip_vp8_retry_release(void) /* ffhip_shutdown */
 {
-    (void)code;
+    std::lock_guard<std::mutex> l(g_retry_mu);
+    for (auto &e : g_retry)
+        if (e.second.err) (void)hipHostFree(e.second.err);
+    g_retry.clear();
+    g_vp8_seq.clear();
+}
+/* ffhip_stream_sync(stream), the stream having drained: 0 = no side-by-side call of this stream reported anything; FFHIP_RETRIED = one had
+ * run into a bounded wait, was repeated stage by stage and is done; FFHIP_EIO = it had, and could not be repeated (no longer the stream's
+ * last VP8 call) or the repeat failed */
+extern "C" int ffhip_vp8_side_by_side_retry(void *stream)
+{
     Vp8Retry r;
     {
         std::lock_guard<std::mutex> l(g_retry_mu);
         auto it = g_retry.find(stream);
-        if (it == g_retry.end()) return 1;
+        if (it == g_retry.end() || !it->second.armed || !it->second.err) return 0;
+        const int code = *(volatile int *)it->second.err;
+        if (!code) return 0;
+        *(volatile int *)it->second.err = 0;
+        it->second.armed = false;
+        if (it->second.seq != g_vp8_seq[stream]) return FFHIP_EIO; /* other VP8 calls went onto the stream behind it: their order cannot be restored */
         r = it->second;
-        g_retry.erase(it);
-        if (r.seq != g_vp8_seq[stream]) return 1; /* other VP8 calls went onto the stream behind it: their order cannot be restored */
     }
     hipStream_t st = (hipStream_t)stream;
     const long long lines = (long long)16 * r.mbrows * r.n_images;
@@ -633,7 +657,12 @@ extern "C" int ffhip_vp8_side_by_side_retry(void *stream, int code)
     int rc = ffhip_vp8_predict_recon(r.mbcols, r.mbrows, r.n_images, r.h_modes.data(), r.d_modes, r.d_residual, r.residual_stride, r.d_resmap, r.y, r.u, r.v,
                                      r.plane_y, r.plane_uv, stream);
     if (rc == FFHIP_OK) rc = ffhip_vp8_loopfilter(r.mbcols, r.mbrows, r.n_images, r.filter_type, r.d_modes, r.d_filters, r.y, r.u, r.v, r.plane_y, r.plane_uv, stream);
-    return rc;
+    if (rc == FFHIP_OK && r.then.on)
+        rc = ffhip_yuv420_to_bgra(r.then.bgra, r.then.pitch, r.y, r.u, r.v, 16 * r.mbcols, 8 * r.mbcols, r.mbrows, r.mbcols, r.n_images, r.plane_y, r.plane_uv,
+                                  r.then.image_stride, stream);
+    if (rc != FFHIP_OK) return FFHIP_EIO;
+    if (hipStreamSynchronize(st) != hipSuccess) return FFHIP_EIO;
+    return FFHIP_RETRIED; /* (a wait of the repeat that ran out is in the process-wide word: the caller looks there next) */
 }
 
 /* Prediction + reconstruction and the loop filter of a batch of key frames as ONE call: both row kernels are enqueued
@@ -659,28 +688,42 @@ extern "C" int ffhip_vp8_predict_loopfilter(int mbcols, int mbrows, int n_images
         if (!ss) return FFHIP_EIO;
         side = ss->side; fork_ev = ss->fork; join_ev = ss->join;
     }
-    /* for the self-healing path: the last luma column as it is now, and who to call again (small batches only: the record holds a copy of the
+    /* for the repeat: the last luma column as it is now, and who to call again (small batches only: the record holds a copy of the
      * host's mode bytes, which the row form checks on the host; a chip-filling batch leaves no room for the second kernel to be kept out) */
     uint8_t *keep = nullptr;
+    const FfhipVp8Then then = g_ffhip_vp8_then;
+    g_ffhip_vp8_then.on = 0;
     const bool heal = fuse && h_modes && d_y && (long long)mbcols * mbrows * n_images <= (1LL << 17) && !FFHIP_ENV("FFHIP_VP8_NO_RETRY");
-    if (heal) {
-        const long long lines = (long long)16 * mbrows * n_images;
-        keep = (uint8_t *)ffhip_scratch(SCRATCH_VP8_RETRY, stream, (size_t)(lines + 3) / 4);
-        if (keep) {
-            hipLaunchKernelGGL(k_vp8_last_column, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_y, (long long)plane_stride_y, 16 * mbcols,
-                               16 * mbrows, n_images, keep, 0);
-            Vp8Retry r;
-            r.mbcols = mbcols; r.mbrows = mbrows; r.n_images = n_images; r.filter_type = filter_type;
-            r.h_modes.assign(h_modes, h_modes + (size_t)mbcols * mbrows * n_images * 20);
-            r.d_modes = d_modes; r.d_filters = d_filters; r.d_residual = d_residual; r.residual_stride = residual_stride; r.d_resmap = d_resmap;
-            r.plane_y = plane_stride_y; r.plane_uv = plane_stride_uv; r.y = d_y; r.u = d_u; r.v = d_v; r.keep = keep;
-            std::lock_guard<std::mutex> l(g_retry_mu);
-            g_retry[stream] = std::move(r);
-        }
-    } else {
+    int *err_word = nullptr;
+    {
         std::lock_guard<std::mutex> l(g_retry_mu);
-        g_retry.erase(stream);
+        Vp8Retry &r = g_retry[stream];
+        if (r.err && *(volatile int *)r.err) { /* an earlier call's abort nobody collected (the caller never came back with ffhip_stream_sync): not lost */
+            int *g = ffhip_async_err_word();
+            if (g) *(volatile int *)g = *(volatile int *)r.err;
+            *(volatile int *)r.err = 0;
+        }
+        r.armed = false;
+        if (heal) {
+            const long long lines = (long long)16 * mbrows * n_images;
+            keep = (uint8_t *)ffhip_scratch(SCRATCH_VP8_RETRY, stream, (size_t)(lines + 3) / 4);
+            if (!r.err && hipHostMalloc((void **)&r.err, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); r.err = nullptr; }
+            if (keep && r.err) {
+                *(volatile int *)r.err = 0;
+                hipLaunchKernelGGL(k_vp8_last_column, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_y, (long long)plane_stride_y, 16 * mbcols,
+                                   16 * mbrows, n_images, keep, 0);
+                if (hipGetLastError() == hipSuccess) {
+                    r.mbcols = mbcols; r.mbrows = mbrows; r.n_images = n_images; r.filter_type = filter_type;
+                    r.h_modes.assign(h_modes, h_modes + (size_t)mbcols * mbrows * n_images * 20); /* (the vector keeps its storage between calls) */
+                    r.d_modes = d_modes; r.d_filters = d_filters; r.d_residual = d_residual; r.residual_stride = residual_stride; r.d_resmap = d_resmap;
+                    r.plane_y = plane_stride_y; r.plane_uv = plane_stride_uv; r.y = d_y; r.u = d_u; r.v = d_v; r.keep = keep; r.then = then;
+                    r.armed = true;
+                    err_word = r.err;
+                }
+            }
+        }
     }
+    g_ffhip_vp8_fusion.err_word = err_word;
     g_ffhip_vp8_fusion.active = fuse ? 1 : 0;
     g_ffhip_vp8_fusion.pred_progress = nullptr;
     g_ffhip_vp8_fusion.side = side;
@@ -692,12 +735,13 @@ extern "C" int ffhip_vp8_predict_loopfilter(int mbcols, int mbrows, int n_images
         rc = ffhip_vp8_loopfilter(mbcols, mbrows, n_images, filter_type, d_modes, d_filters, d_y, d_u, d_v, plane_stride_y, plane_stride_uv, stream);
     g_ffhip_vp8_fusion.active = 0;
     g_ffhip_vp8_fusion.pred_progress = nullptr;
+    g_ffhip_vp8_fusion.err_word = nullptr;
     {
         std::lock_guard<std::mutex> l(g_retry_mu);
         auto it = g_retry.find(stream);
-        if (it != g_retry.end()) {
+        if (it != g_retry.end() && it->second.armed) {
             if (rc == FFHIP_OK && forked) it->second.seq = g_vp8_seq[stream];
-            else g_retry.erase(it); /* nothing ran side by side: nothing to heal */
+            else it->second.armed = false; /* nothing ran side by side: nothing to repeat */
         }
     }
     if (forked) { /* whatever happened to the filter's launch: `stream` continues behind the side stream */

@@ -198,6 +198,9 @@ def vp8_predict_recon(mbcols, mbrows, modes, residual, resmap=None):
             dv.to_host((n, 8 * mbrows, 8 * mbcols), np.uint8))
 
 
+last_sync_status = 0     # what the stream sync of the last vp8_predict_loopfilter / vp8_decode_frames call returned (0 or capi.FFHIP_RETRIED)
+
+
 def vp8_predict_loopfilter(mbcols, mbrows, modes, residual, filter_type, filters, resmap=None):
     """ffhip_vp8_predict_loopfilter: prediction + reconstruction and the loop filter of whole key frames as one call
     (format/webp.c:1833-1866), the two row kernels side by side.  Arguments as vp8_predict_recon / vp8_loopfilter;
@@ -215,7 +218,8 @@ def vp8_predict_loopfilter(mbcols, mbrows, modes, residual, filter_type, filters
     capi.check(L.ffhip_vp8_predict_loopfilter(mbcols, mbrows, n, modes.ctypes.data, dm.ptr, dr.ptr, residual.shape[1] * 384,
                                               dmap.ptr if dmap else None, filter_type, df.ptr, dy.ptr, du.ptr, dv.ptr, ysz, csz, None),
                "ffhip_vp8_predict_loopfilter")
-    capi.check(L.ffhip_stream_sync(None))
+    global last_sync_status
+    last_sync_status = capi.sync(None)
     return (dy.to_host((n, 16 * mbrows, 16 * mbcols), np.uint8), du.to_host((n, 8 * mbrows, 8 * mbcols), np.uint8),
             dv.to_host((n, 8 * mbrows, 8 * mbcols), np.uint8))
 
@@ -244,7 +248,8 @@ def vp8_decode_frames(mbcols, mbrows, modes, residual, filter_type, filters, res
                                          dmap.ptr if dmap else None, filter_type, df.ptr if df else None, do.ptr, pitch, H * pitch,
                                          dy.ptr if planes else None, du.ptr if planes else None, dv.ptr if planes else None, ysz, csz, None),
                "ffhip_vp8_decode_frames")
-    capi.check(L.ffhip_stream_sync(None), "ffhip_stream_sync")
+    global last_sync_status
+    last_sync_status = capi.sync(None)
     bgra = do.to_host((n, H, pitch), np.uint8)
     if not planes:
         return bgra

@@ -35,6 +35,9 @@ extern "C" {
 #define FFHIP_ENOMEM (-12)  /* device or host allocation failed             */
 #define FFHIP_ENODEV (-19)  /* no usable gfx950 device / HIP runtime error  */
 #define FFHIP_EIO    (-5)   /* kernel launch or copy failed                 */
+#define FFHIP_RETRIED 1     /* ffhip_stream_sync only, not an error: a side-by-side VP8 call on the stream ran into a bounded wait and was
+                               repeated by the sync; its outputs are now those of an undisturbed call, but whatever the CALLER had enqueued
+                               behind it on the stream has consumed the aborted run's output and must be enqueued again */
 
 /* ------------------------------------------------------------------ runtime */
 
@@ -65,7 +68,8 @@ int ffhip_memset(void *dst, int value, size_t bytes, void *stream);
 void *ffhip_stream_create(void);
 void ffhip_stream_destroy(void *stream);
 int ffhip_stream_sync(void *stream); /* NULL = the default stream; FFHIP_EIO also if a dependency-scheduled
-                                         kernel (VP8 predict / loop filter, HEVC intra) reported an abort */
+                                         kernel (VP8 predict / loop filter, HEVC intra) reported an abort;
+                                         FFHIP_RETRIED (> 0) when a side-by-side VP8 call was repeated, see there */
 void *ffhip_event_create(void);
 void ffhip_event_destroy(void *event);
 int ffhip_event_record(void *event, void *stream);
@@ -292,13 +296,18 @@ int ffhip_vp8_loopfilter(int mbcols, int mbrows, int n_images, int filter_type, 
  * prediction's through its per-row progress counters (a macroblock is filtered once the prediction has finished its right
  * neighbour in the row below: the prediction reads reconstructed, not filtered, samples), so the two dependency chains
  * overlap instead of adding up.  filter_type 0 = prediction only.  FFHIP_VP8_FUSE=0: one after the other.
- * The call HEALS ITSELF (batches of up to 2^17 macroblocks): on a device shared with other work one of the two kernels can be
- * kept from becoming resident next to the other, and a bounded wait then runs out.  The library keeps a copy of the one thing of
- * the planes' former contents the prediction reads (their last luma column, for the wrapped H_PRED read of predict.c:346-353) and
- * of the call's arguments; ffhip_stream_sync on `stream` then restores that column, runs prediction and filter one after the
- * other and returns what THAT run did -- FFHIP_OK and the bytes of an undisturbed call, as a rule -- provided the call is still
- * the last VP8 prediction / filter call enqueued on `stream` and d_modes, d_residual, d_resmap and d_filters are still what
- * they were (FFHIP_VP8_NO_RETRY=1: FFHIP_EIO, planes unspecified, as before round 4). */
+ * The call is REPEATED by ffhip_stream_sync when it could not finish (batches of up to 2^17 macroblocks): on a device shared with other
+ * work one of the two kernels can be kept from becoming resident next to the other, and a bounded wait then runs out.  The two kernels report
+ * that in a pinned word of the CALL's own (nobody else's abort sets the retry off); the library keeps a copy of the one thing of the planes'
+ * former contents the prediction reads (their last luma column, for the wrapped H_PRED read of predict.c:346-353) and of the call's arguments;
+ * ffhip_stream_sync on `stream` then restores that column, runs prediction and filter one after the other, waits, and returns FFHIP_RETRIED
+ * (> 0) with the bytes of an undisturbed call in the planes -- or FFHIP_EIO when the repeat failed too, or when the call is no longer the last
+ * VP8 prediction / filter call enqueued on `stream`.  FFHIP_RETRIED is not FFHIP_OK on purpose: whatever the CALLER enqueued on `stream` behind
+ * the call (a copy, a kernel of its own, ffhip_yuv420_to_bgra) has already consumed the planes of the aborted run and must be enqueued again;
+ * the library knows this only of its own stages (ffhip_vp8_decode_frames repeats its colour conversion as part of the retry, and still says
+ * FFHIP_RETRIED for the sake of what the caller put behind IT).  Contract: the call's inputs (d_modes, d_residual, d_resmap, d_filters) and
+ * planes stay valid and unchanged until ffhip_stream_sync(stream) has returned.  FFHIP_VP8_NO_RETRY=1: FFHIP_EIO, planes unspecified, as
+ * before round 4. */
 int ffhip_vp8_predict_loopfilter(int mbcols, int mbrows, int n_images, const uint8_t *h_modes, const uint8_t *d_modes,
                                  const int16_t *d_residual, int64_t residual_stride, const int32_t *d_resmap,
                                  int filter_type, const uint8_t *d_filters, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
@@ -372,6 +381,9 @@ int ffhip_vp8_predict_recon(int mbcols, int mbrows, int n_images, const uint8_t 
  * waves the frame's macroblock rows, and a wave predicts, filters and converts its macroblock before anything is stored
  * (every pixel is written once, as BGRA); smaller batches run the three stages (row kernels, then the colour
  * kernel: a single frame's critical path is shorter there).  FFHIP_VP8_FRAMES=fused|rows forces either. */
+/* which form ffhip_vp8_decode_frames takes for a batch of n_images on the current device: 1 the frame kernel, 0 the row kernels + colour kernel
+ * (half the device's compute units and more take the frame kernel; FFHIP_VP8_FRAMES / FFHIP_VP8_FRAMES_MIN move that) */
+int ffhip_vp8_decode_frames_form(int n_images);
 int ffhip_vp8_decode_frames(int mbcols, int mbrows, int n_images, const uint8_t *h_modes, const uint8_t *d_modes,
                             const int16_t *d_residual, int64_t residual_stride, const int32_t *d_resmap, int filter_type,
                             const uint8_t *d_filters, uint8_t *d_bgra, int pitch, int64_t image_stride, uint8_t *d_y,

@@ -104,11 +104,13 @@ def test_give_up_path_reports_eio_and_the_library_recovers(monkeypatch):
         assert np.array_equal(g, e)
 
 
-def test_side_by_side_vp8_call_heals_itself(monkeypatch):
+def test_side_by_side_vp8_call_is_repeated_by_the_sync(monkeypatch):
     """ffhip_vp8_predict_loopfilter on a device where the filter's wait for the prediction runs out (test hook FFHIP_DEBUG_VP8_LF_GIVEUP: the fused
     filter launch gives up half-way down every frame): ffhip_stream_sync puts the one column of the planes' former contents the prediction
-    reads back, runs prediction and filter one after the other and returns FFHIP_OK with the bytes of an undisturbed call -- H_PRED in the
-    first column included, whose wrapped read sees that column.  With FFHIP_VP8_NO_RETRY the sync says FFHIP_EIO, as before round 4."""
+    reads back, runs prediction and filter one after the other and returns FFHIP_RETRIED (> 0: outputs good, consumers behind the call stale)
+    with the bytes of an undisturbed call -- H_PRED in the first column included, whose wrapped read sees that column.  The abort is reported in
+    a word of the call's own: the process-wide word stays clear, and a later abort of ANOTHER kernel does not set the retry off again.  With
+    FFHIP_VP8_NO_RETRY the sync says FFHIP_EIO, as before round 4."""
     import oracle_lib as O
     from ffpic_amd import capi, ops, synth
     from test_vp8_lf_gpu import oracle_lf
@@ -123,11 +125,22 @@ def test_side_by_side_vp8_call_heals_itself(monkeypatch):
         y0, u0, v0 = O.oracle_vp8_frame(c, r, modes[i], resid[i])
         exp.append(oracle_lf(c, r, 2, modes[i], flt, (y0, u0, v0)))
     want = ops.vp8_predict_loopfilter(c, r, modes, resid, 2, flt)          # undisturbed
+    assert ops.last_sync_status == 0
     monkeypatch.setenv("FFHIP_DEBUG_VP8_LF_GIVEUP", "1"); capi.reload_env()
-    got = ops.vp8_predict_loopfilter(c, r, modes, resid, 2, flt)           # gives up, heals inside the wrapper's ffhip_stream_sync
+    got = ops.vp8_predict_loopfilter(c, r, modes, resid, 2, flt)           # gives up, is repeated inside the wrapper's ffhip_stream_sync
+    assert ops.last_sync_status == capi.FFHIP_RETRIED
     for i in range(n):
         for gp, wp, e, name in zip(got, want, exp[i], "YUV"):
             assert np.array_equal(gp[i], e) and np.array_equal(wp[i], e), (i, name)
+    assert L.ffhip_stream_sync(None) == 0
+    # an abort of some OTHER dependency-scheduled kernel on the stream afterwards is that kernel's FFHIP_EIO, not a second repeat of this call
+    tus, res = synth.hevc_intra_tus(256, 192, seed=91)
+    first = [i for i, t in enumerate(tus) if t["cidx"] == 0 and t["x"] < 64 and t["y"] < 64]
+    monkeypatch.setenv("FFHIP_DEBUG_WITHHOLD_TU", str(first[-1])); capi.reload_env()
+    with pytest.raises(capi.FfhipError) as ei:
+        ops.hevc_intra_recon(tus, res, 256, 192, True, 8, 8)
+    assert "-5" in str(ei.value)
+    monkeypatch.delenv("FFHIP_DEBUG_WITHHOLD_TU"); capi.reload_env()
     assert L.ffhip_stream_sync(None) == 0
     monkeypatch.setenv("FFHIP_VP8_NO_RETRY", "1"); capi.reload_env()
     with pytest.raises(capi.FfhipError) as ei:
@@ -136,6 +149,37 @@ def test_side_by_side_vp8_call_heals_itself(monkeypatch):
     assert L.ffhip_stream_sync(None) == 0
     monkeypatch.delenv("FFHIP_VP8_NO_RETRY"); monkeypatch.delenv("FFHIP_DEBUG_VP8_LF_GIVEUP"); capi.reload_env()
     again = ops.vp8_predict_loopfilter(c, r, modes, resid, 2, flt)
+    assert ops.last_sync_status == 0
     for i in range(n):
         for gp, e in zip(again, exp[i]):
             assert np.array_equal(gp[i], e)
+
+
+@pytest.mark.parametrize("planes", [False, True])
+def test_decode_frames_row_form_repeats_its_colour_conversion(monkeypatch, planes):
+    """ffhip_vp8_decode_frames in its row form (prediction || filter, then the planar colour kernel on the same stream) with the filter giving up
+    (FFHIP_DEBUG_VP8_LF_GIVEUP): the colour conversion has converted the ABORTED planes by the time ffhip_stream_sync repeats prediction and
+    filter -- it belongs to the call, so the retry runs it again behind the filter, and the BGRA is the oracle's (round 4 returned FFHIP_OK with
+    the broken run's pixels).  The status is FFHIP_RETRIED all the same: the caller may have enqueued consumers of the BGRA behind the call."""
+    from ffpic_amd import capi, ops, synth
+    from test_vp8_frames_gpu import oracle_chain
+    capi.require_device()
+    c, r, n = 21, 13, 3
+    modes = np.stack([synth.vp8_modes(c, r, seed=1300 + i) for i in range(n)])
+    modes.reshape(n, r, c, 20)[:, 1::2, 0, 0] = 3
+    resid = np.stack([synth.vp8_residual(c * r, seed=1310 + i) for i in range(n)])
+    flt = synth.vp8_filters(seed=32)
+    exp = [oracle_chain(c, r, 2, modes[i], resid[i], flt)[0] for i in range(n)]
+    monkeypatch.setenv("FFHIP_VP8_FRAMES", "rows"); capi.reload_env()
+    out = ops.vp8_decode_frames(c, r, modes, resid, 2, flt, planes=planes)
+    assert ops.last_sync_status == 0
+    bgra = out[0] if planes else out
+    for i in range(n):
+        assert np.array_equal(bgra[i], exp[i]), i
+    monkeypatch.setenv("FFHIP_DEBUG_VP8_LF_GIVEUP", "1"); capi.reload_env()
+    out = ops.vp8_decode_frames(c, r, modes, resid, 2, flt, planes=planes)
+    assert ops.last_sync_status == capi.FFHIP_RETRIED
+    bgra = out[0] if planes else out
+    for i in range(n):
+        assert np.array_equal(bgra[i], exp[i]), i
+    monkeypatch.delenv("FFHIP_DEBUG_VP8_LF_GIVEUP"); monkeypatch.delenv("FFHIP_VP8_FRAMES"); capi.reload_env()

@@ -132,14 +132,12 @@ struct WaveCtx {
     u32 tr_odd;     /*   reads (even rows 0,4,2,6 / odd rows 1,3,5,7)         */
     u32 blk, idx;   /* after a transposing read: block and column/row index   */
     int rnd1, rnd2; /* the two passes' rounding constants, held in VGPRs               */
-    int kflip, kwait; /* store-pattern experiments (JpegBatch::store_exp), 0 in the shipped configuration */
 };
 
 __device__ __forceinline__ void wave_ctx_init(WaveCtx &c, char *lds, u32 lane)
 {
     c.lds = lds;
     c.lane = lane;
-    c.kflip = 0; c.kwait = 0;
     c.wr_off = tile_off(lane >> 3, lane & 7);
     const u32 g = lane >> 4, t = lane & 15, q = t >> 2, p = t & 3;
     const u32 b = 2 * g + (p >> 1);
@@ -212,8 +210,6 @@ struct JpegBatch {
     int wgs_per_image;     /* workgroups that cover one image                            */
     u32 wpi_magic;         /* same trick for image = workgroup / wgs_per_image          */
     int xcd_remap;         /* 1: give each XCD a contiguous chunk of the workgroup sequence */
-    int store_exp;         /* experiments on the store pattern (FFHIP_JPEG_STORE_EXP): bit 0 odd waves write rows 8-15 of a quad first,
-                              bit 1 a wave waits for each half's stores before it issues the next (8 rows of a quad in flight, not 16) */
 };
 
 /* exact floor((x)/d) for the small non-negative ranges of the chroma terms:
@@ -391,8 +387,7 @@ __device__ __forceinline__ void quad_recon(const JpegBatch &p, const WaveCtx &c,
             *(u32x4 *)(c.lds + LDS_W + r.yc_wr) = pk;
         }
 #pragma unroll
-        for (int k0 = 0; k0 < 2; k0++) {
-            const int k = k0 ^ c.kflip; /* (0 unless the store-order experiment is on: a wave-uniform value) */
+        for (int k = 0; k < 2; k++) {
             /* output role: 8 lanes cover one 32-px row segment (128 B); all LDS addresses are a
              * per-lane base (LaneRoles) plus a compile-time constant */
             const u32x2 yy = *(const u32x2 *)(c.lds + LDS_W + k * 512 + r.yc_rd);
@@ -431,7 +426,6 @@ __device__ __forceinline__ void quad_recon(const JpegBatch &p, const WaveCtx &c,
                 if (NT & 2) __builtin_nontemporal_store(px, dst);
                 else *dst = px;
             }
-            if (c.kwait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
 }
@@ -468,8 +462,6 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg420_fused(JpegBatch p)
 
     WaveCtx c;
     wave_ctx_init(c, lds_all + wave * LDS_WAVE_BYTES, lane);
-    c.kflip = (p.store_exp & 1) ? (int)((wave + blockIdx.x) & 1u) : 0;
-    c.kwait = (p.store_exp >> 1) & 1;
     LaneRoles r;
     lane_roles_init(r, c, lane, (u32)p.pitch);
 
@@ -819,7 +811,6 @@ static void launch_fused(const JpegBatch &q_in, int n_images, hipStream_t st)
     const int qpw = g_variant / 10;
     JpegBatch q = q_in;
     q.xcd_remap = jpeg_remap_mode();
-    { const char *se = FFHIP_ENV("FFHIP_JPEG_STORE_EXP"); q.store_exp = se ? atoi(se) : 0; }
     const int slots = (q.quads_per_image + qpw - 1) / qpw;
     q.wgs_per_image = (slots + WAVES_PER_WG - 1) / WAVES_PER_WG;
     q.wpi_magic = q.wgs_per_image == 1 ? 0xffffffffu : (u32)(0x100000000ULL / (unsigned)q.wgs_per_image) + 1u;
@@ -1020,8 +1011,13 @@ extern "C" int ffhip_jpeg_recon_batch_host(const ffhip_jpeg_geom *g, int n_image
     const size_t mcus = (size_t)g->mcu_cols * g->mcu_rows;
     const size_t ybytes = mcus * g->h * g->v * 128 * n_images, cbytes = mcus * 128 * n_images;
     const size_t qbytes = (quant_stride ? (size_t)quant_stride * (n_images - 1) + 256 : 256) * 2;
-    const int64_t height = (int64_t)g->mcu_rows * 8 * g->v;
-    const size_t obytes = (size_t)image_stride * (n_images - 1) + (size_t)pitch * height;
+    const int64_t height = (int64_t)g->mcu_rows * 8 * g->v, row_bytes = 32LL * g->h * g->mcu_cols;
+    if (pitch < row_bytes || (n_images > 1 && image_stride < pitch * height)) return FFHIP_EINVAL;
+    /* the device buffer is the library's: it has the pitch ffhip_bgra_layout recommends (a slow output placement costs the fused kernel up to
+     * 8 % at the reference's pitch), and the pixels reach the caller's layout by a 2-D copy */
+    int64_t dpitch = 0, dstride = 0;
+    if (ffhip_bgra_layout(g, &dpitch, &dstride) != FFHIP_OK) return FFHIP_EINVAL;
+    const size_t obytes = (size_t)dstride * (size_t)n_images;
     const size_t wbytes = ffhip_jpeg_workspace_bytes(g, n_images);
     /* the device buffers are library scratch kept between calls (one allocation, grown on demand, released by
      * ffhip_shutdown): this is the per-picture entry a patched format/jpg.c calls, and allocating and freeing ~60 MB of
@@ -1041,8 +1037,13 @@ extern "C" int ffhip_jpeg_recon_batch_host(const ffhip_jpeg_geom *g, int n_image
     }
     FFHIP_CHECK(hipMemcpy(dq, quant, qbytes, hipMemcpyHostToDevice), FFHIP_EIO);
     const int rc = ffhip_jpeg_recon_batch(g, n_images, (const int16_t *)dy, (const int16_t *)du, (const int16_t *)dv,
-                                          (const uint16_t *)dq, quant_stride, (uint8_t *)dout, pitch, image_stride, dws, wbytes, nullptr);
+                                          (const uint16_t *)dq, quant_stride, (uint8_t *)dout, dpitch, dstride, dws, wbytes, nullptr);
     if (rc) return rc;
-    FFHIP_CHECK(hipMemcpy(bgra, dout, obytes, hipMemcpyDeviceToHost), FFHIP_EIO);
+    if (n_images == 1 || image_stride == pitch * height) /* the caller's pictures follow each other row after row: one copy */
+        FFHIP_CHECK(hipMemcpy2D(bgra, (size_t)pitch, dout, (size_t)dpitch, (size_t)row_bytes, (size_t)(height * n_images), hipMemcpyDeviceToHost), FFHIP_EIO);
+    else
+        for (int i = 0; i < n_images; i++)
+            FFHIP_CHECK(hipMemcpy2D(bgra + (int64_t)i * image_stride, (size_t)pitch, (const uint8_t *)dout + (int64_t)i * dstride, (size_t)dpitch, (size_t)row_bytes,
+                                    (size_t)height, hipMemcpyDeviceToHost), FFHIP_EIO);
     return FFHIP_OK;
 }

@@ -142,7 +142,11 @@ extern "C" int ffhip_jpeg_decode_files(const uint8_t *const *files, const size_t
     if (chunk > n) chunk = n;
     const size_t mcus = (size_t)g.mcu_cols * g.mcu_rows;
     const size_t yb = mcus * g.h * g.v * 64, cb = g.ncomp == 3 ? mcus * 64 : 0; /* int16 elements per picture */
-    const size_t dev_pitch = (size_t)width * 4, out_b = dev_pitch * (size_t)height; /* tight on the device */
+    /* on the device the pictures have the pitch ffhip_bgra_layout recommends (the buffer is the library's); the pinned staging
+     * for a pageable destination is tight, and every copy off the device is a 2-D copy */
+    int64_t lp = 0, ls = 0;
+    if (ffhip_bgra_layout(&g, &lp, &ls) != FFHIP_OK) return FFHIP_EINVAL;
+    const size_t dev_pitch = (size_t)lp, out_b = (size_t)ls, row_b = (size_t)width * 4;
     /* a pinned (hipHostMalloc'ed / registered) destination takes the D2H copy directly */
     hipPointerAttribute_t attr;
     const bool pinned_dst = hipPointerGetAttributes(&attr, bgra) == hipSuccess && attr.type == hipMemoryTypeHost;
@@ -157,7 +161,7 @@ extern "C" int ffhip_jpeg_decode_files(const uint8_t *const *files, const size_t
     auto drain = [&](Slot &sl) -> int {
         if (sl.count == 0) return FFHIP_OK;
         if (hipStreamSynchronize(sl.st) != hipSuccess) return FFHIP_EIO;
-        if (!pinned_dst) copy_out(bgra, pitch, image_stride, sl.h_out, dev_pitch, height, sl.first, sl.count, n_threads);
+        if (!pinned_dst) copy_out(bgra, pitch, image_stride, sl.h_out, row_b, height, sl.first, sl.count, n_threads);
         sl.count = 0;
         return FFHIP_OK;
     };
@@ -193,14 +197,14 @@ extern "C" int ffhip_jpeg_decode_files(const uint8_t *const *files, const size_t
                                     (int64_t)out_b, nullptr, 0, sl.st);
         if (rc) break;
         if (pinned_dst) {
-            if ((size_t)pitch == dev_pitch && (cnt == 1 || (size_t)image_stride == out_b))
-                e = hipMemcpyAsync(bgra + (int64_t)first * image_stride, sl.d_out, cnt * out_b, hipMemcpyDeviceToHost, sl.st);
+            if (cnt == 1 || image_stride == pitch * height) /* the caller's pictures follow each other row after row: one copy for the chunk */
+                e = hipMemcpy2DAsync(bgra + (int64_t)first * image_stride, (size_t)pitch, sl.d_out, dev_pitch, row_b, (size_t)height * cnt, hipMemcpyDeviceToHost, sl.st);
             else
                 for (int i = 0; i < cnt && e == hipSuccess; i++)
-                    e = hipMemcpy2DAsync(bgra + (int64_t)(first + i) * image_stride, (size_t)pitch, sl.d_out + (size_t)i * out_b, dev_pitch, dev_pitch,
+                    e = hipMemcpy2DAsync(bgra + (int64_t)(first + i) * image_stride, (size_t)pitch, sl.d_out + (size_t)i * out_b, dev_pitch, row_b,
                                          (size_t)height, hipMemcpyDeviceToHost, sl.st);
         } else {
-            e = hipMemcpyAsync(sl.h_out, sl.d_out, cnt * out_b, hipMemcpyDeviceToHost, sl.st);
+            e = hipMemcpy2DAsync(sl.h_out, row_b, sl.d_out, dev_pitch, row_b, (size_t)height * cnt, hipMemcpyDeviceToHost, sl.st);
         }
         if (e != hipSuccess) { rc = FFHIP_EIO; break; }
         sl.first = first;

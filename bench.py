@@ -723,6 +723,152 @@ def extra_c5(L, dev, stream, T, cpu=True, grid=True):
         res["grid"] = c5_grid_sweep(L, dev, stream, T, cpu=cpu)
     return res
 
+_REF_LOAD_CHILD = r"""
+import ctypes as C, hashlib, sys, time
+path, so, out = sys.argv[1], sys.argv[2], sys.argv[3]
+R = C.CDLL(so, mode=C.RTLD_GLOBAL)
+class Pic(C.Structure):      # struct pic, format/file.h:29-40 (leading fields)
+    _fields_ = [("pixels", C.c_void_p), ("left", C.c_int), ("top", C.c_int), ("width", C.c_int), ("height", C.c_int), ("depth", C.c_int), ("pitch", C.c_int)]
+R.file_ops_init.restype = None
+R.file_probe.restype = C.c_void_p
+R.file_probe.argtypes = [C.c_char_p]
+R.file_load.restype = C.POINTER(Pic)
+R.file_load.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+R.file_ops_init()
+ops = R.file_probe(path.encode())
+t0 = time.perf_counter()
+p = R.file_load(ops, path.encode(), 0).contents
+dt = time.perf_counter() - t0
+h, hm = hashlib.sha256(), hashlib.sha256()      # all rows; and all but the last 16x16 MCU (the reference's bit reader can run dry in a scan's very last data unit)
+buf = (C.c_uint8 * (p.height * p.pitch)).from_address(p.pixels)
+mv = memoryview(buf)
+for y in range(p.height):
+    row = mv[y * p.pitch:y * p.pitch + p.width * 4]
+    h.update(row)
+    hm.update(row[:(p.width - 16) * 4] if y >= p.height - 16 else row)
+open(out, "w").write("%d %d %.6f %s %s" % (p.width, p.height, dt, h.hexdigest(), hm.hexdigest()))
+sys.stdout.flush()
+import os
+os._exit(0)     # the reference's loader leaves the heap in a state interpreter teardown does not survive
+"""
+
+
+def f1_reference_load(path, so, copies=1):
+    """The reference's own whole-file decode (file_load -> JPG_load: format/jpg.c, coding/huffman.c, utils/idct.c, utils/colorspace.c) of one file,
+    in `copies` child processes at once (one load each: its loader is single-threaded and not safe to call twice in a process).  Returns
+    (width, height, [seconds per load], (sha256 of the BGRA rows, the same without the last 16x16 MCU))."""
+    import subprocess, tempfile
+    outs = [tempfile.mktemp(suffix=".txt") for _ in range(copies)]
+    procs = [subprocess.Popen([sys.executable, "-c", _REF_LOAD_CHILD, path, so, o], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for o in outs]
+    for pr in procs:
+        pr.wait(timeout=300)
+    res = []
+    for o in outs:
+        if not os.path.exists(o):
+            raise RuntimeError("the reference's loader did not finish on " + path)
+        w, h, dt, sha, sha_m = open(o).read().split()
+        os.unlink(o)
+        res.append((int(w), int(h), float(dt), (sha, sha_m)))
+    return res[0][0], res[0][1], [r[2] for r in res], res[0][3]
+
+
+def extra_f1(L, dev, stream, T, cpu=True, n=256):
+    """SURVEY 8f row f1, the step in front of the hot path: baseline JPEG FILES in, BGRA in device memory out (ffhip_jpeg_decode_files_device: the
+    marker loop, read_dqt, read_compressed_scan / decode_data_unit of format/jpg.c:78-105, 255-415, 588-637 and coding/huffman.c:92-222, then the
+    fused reconstruction) on `n` 4K files -- with restart markers (one interval per MCU row: the Huffman decode runs on the device, a lane per
+    interval) and without (host threads) --, the device Huffman stage alone (ffhip_jpeg_entropy_batch_gpu) with its phases, and the reference's own
+    JPG_load on the same file as the CPU baseline.  Wall-clock figures: host code and PCIe are part of this row."""
+    import hashlib, io, tempfile
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    W, H = 3840, 2160
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.stack([128 + 100 * np.sin(xx / 37.0) * np.cos(yy / 23.0), 128 + 90 * np.cos(xx / 11.0 + yy / 53.0), (xx * 255 / (W - 1) + yy * 255 / (H - 1)) / 2], axis=2)
+    img = np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+    del yy, xx
+    vp = C.c_void_p
+    threads = max(1, min(os.cpu_count() or 1, 16))
+    res = {"workload": f"{n} x {W}x{H} baseline 4:2:0 JPEG files (PIL, quality 85; the same file {n} times) -> BGRA in device memory; wall clock of the calls, "
+                       f"{threads} host threads for header parsing / staging / host entropy", "files": {}}
+    geom = capi.JpegGeom()
+    for tag, kw in (("dri_per_mcu_row", dict(restart_marker_rows=1)), ("no_dri", dict())):
+        bio = io.BytesIO()
+        Image.fromarray(img).save(bio, "JPEG", quality=85, subsampling=2, **kw)
+        data = bio.getvalue()
+        buf = np.frombuffer(data, dtype=np.uint8)
+        ptrs = (vp * n)(*([buf.ctypes.data] * n))
+        lens = (C.c_size_t * n)(*([buf.size] * n))
+        status = (C.c_int * n)()
+        d_out = torch.empty((n, H, W * 4), dtype=torch.uint8, device=dev)
+
+        def files_to_pixels():
+            capi.check(L.ffhip_jpeg_decode_files_device(ptrs, lens, n, threads, C.byref(geom), d_out.data_ptr(), W * 4, W * 4 * H, status, stream), "ffhip_jpeg_decode_files_device")
+            capi.check(L.ffhip_stream_sync(stream))
+        files_to_pixels()
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter(); files_to_pixels(); best = min(best, time.perf_counter() - t0)
+        row = {"file_bytes": len(data), "files_to_device_pixels_ms": round(best * 1e3, 2), "value": round(n * W * H / best / 1e6, 1), "unit": "Mpixels/s",
+               "files_per_s": round(n / best), "compressed_GB/s": round(n * len(data) / best / 1e9, 2)}
+        px0 = d_out[0].cpu().numpy()
+        sha_gpu = hashlib.sha256(px0.tobytes()).hexdigest()
+        sha_gpu_m = hashlib.sha256(px0[:H - 16].tobytes() + px0[H - 16:, :(W - 16) * 4].tobytes()).hexdigest()
+        del px0
+        if tag == "dri_per_mcu_row":
+            # the device Huffman stage alone, with its phases (ffhip_debug_huff_times), and the reconstruction of its planes alone
+            g = geom
+            yb, cb = g.mcu_cols * g.mcu_rows * 4 * 64, g.mcu_cols * g.mcu_rows * 64
+            d_y = torch.empty(n * yb, dtype=torch.int16, device=dev)
+            d_u = torch.empty(n * cb, dtype=torch.int16, device=dev)
+            d_v = torch.empty(n * cb, dtype=torch.int16, device=dev)
+            d_q = torch.empty(n * 256, dtype=torch.int16, device=dev)
+
+            def entropy():
+                capi.check(L.ffhip_jpeg_entropy_batch_gpu(ptrs, lens, n, threads, C.byref(g), d_y.data_ptr(), d_u.data_ptr(), d_v.data_ptr(), d_q.data_ptr(), status, stream),
+                           "ffhip_jpeg_entropy_batch_gpu")
+            entropy()
+            eb, ph = 1e9, None
+            for _ in range(3):
+                t0 = time.perf_counter(); entropy(); dt = time.perf_counter() - t0
+                if dt < eb:
+                    eb = dt
+                    tt = (C.c_double * 8)()
+                    L.ffhip_debug_huff_times(tt)
+                    ph = [float(x) for x in tt]
+            rms = T.ms(lambda: capi.check(L.ffhip_jpeg_recon_batch(C.byref(g), n, d_y.data_ptr(), d_u.data_ptr(), d_v.data_ptr(), d_q.data_ptr(), 256, d_out.data_ptr(), W * 4, W * 4 * H,
+                                                                   None, 0, stream)), reps=5, warm=1)
+            row["entropy_batch_gpu"] = {"ms": round(eb * 1e3, 2), "value": round(n * W * H / eb / 1e6, 1), "unit": "Mpixels/s",
+                                        "phases_ms": {"header_parse": round(ph[0] / 1e3, 2), "layout": round(ph[1] / 1e3, 2), "unstuff_and_markers_with_uploads_enqueued": round(ph[2] / 1e3, 2),
+                                                      "tables": round(ph[3] / 1e3, 2), "enqueue": round(ph[4] / 1e3, 2), "wait_uploads_clears_kernel": round(ph[5] / 1e3, 2)},
+                                        "k_jpeg_huff_ms": round(ph[6] / 1e3, 3), "k_jpeg_huff_compressed_GB/s": round(n * len(data) / (ph[6] / 1e6) / 1e9, 1) if ph[6] else None}
+            row["reconstruction_ms"] = round(rms, 3)
+            row["share_of_the_call"] = {"host_staging": round((ph[0] + ph[1] + ph[2] + ph[3]) / 1e3 / (best * 1e3), 3), "device_huffman_kernel": round(ph[6] / 1e3 / (best * 1e3), 3),
+                                        "reconstruction": round(rms / (best * 1e3), 3)}
+            del d_y, d_u, d_v, d_q
+        if cpu:
+            O = oracle_lib()
+            if os.path.exists(O.REF_SO):
+                try:
+                    with tempfile.NamedTemporaryFile(suffix=".jpg", delete=False) as fh:
+                        fh.write(data)
+                    w1, h1, dts, sha_ref = f1_reference_load(fh.name, O.REF_SO, 1)
+                    row["parity_vs_reference_whole_file_decode"] = bool(sha_ref[1] == sha_gpu_m and (w1, h1) == (W, H))
+                    if sha_ref[0] != sha_gpu:     # a reference defect kept out of the comparison (DESIGN.md 2): its bit reader runs dry in the scan's last data unit
+                        row["parity_note"] = "every pixel but the picture's last 16x16 MCU, which the reference's own loader gets wrong on this file (utils/bitstream.c:117)"
+                    row["cpu_baseline"] = {"value": round(W * H / min(dts) / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "reference",
+                                           "sample": "the reference's own whole-file decode (file_load -> JPG_load) of the same file, one load in a process of its own"}
+                    cores = threads
+                    _, _, dta, _ = f1_reference_load(fh.name, O.REF_SO, cores)
+                    row["cpu_baseline_all_cores"] = {"value": round(cores * W * H / max(dta) / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "reference",
+                                                     "sample": f"{cores} processes at once, one load each; pixels / the slowest load"}
+                    os.unlink(fh.name)
+                except Exception as e:
+                    row["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+        res["files"][tag] = row
+        del d_out
+        torch.cuda.empty_cache()
+    return res
+
 
 def compact_configs(extra):
     """Every BASELINE config and layout in a few hundred bytes each: what the result line carries (the verbose `extra` goes to stderr /
@@ -768,6 +914,12 @@ def compact_configs(extra):
                      "grid_host_enqueue_ms": {str(r["pictures"]): r["intra_host_enqueue_ms"] for r in rows},
                      "grid_parity": [r.get("parity_first_and_last_tile_vs_reference") for r in rows if "parity_first_and_last_tile_vs_reference" in r],
                      "cpu_1_core": g(c5, "cpu_baseline", "value"), "cpu_all_cores": g(c5, "cpu_baseline_all_cores", "value"), "cpu_cores": g(c5, "cpu_baseline_all_cores", "cores")}
+    f1 = extra.get("f1", {})
+    if f1:
+        out["f1"] = f1 if "error" in f1 else {k: {"value": g(v, "value"), "ms": g(v, "files_to_device_pixels_ms"), "entropy_gpu": g(v, "entropy_batch_gpu", "value"),
+                                                   "k_jpeg_huff_ms": g(v, "entropy_batch_gpu", "k_jpeg_huff_ms"), "recon_ms": g(v, "reconstruction_ms"), "share": g(v, "share_of_the_call"),
+                                                   "parity": g(v, "parity_vs_reference_whole_file_decode"), "cpu_1_core": g(v, "cpu_baseline", "value"),
+                                                   "cpu_all_cores": g(v, "cpu_baseline_all_cores", "value")} for k, v in (f1.get("files") or {}).items()}
     sk = extra.get("stage_kernels", {})
     out["stage_kernels"] = {k: g(v, "frac") for k, v in sk.items() if isinstance(v, dict)} if "error" not in sk else sk
     return out
@@ -953,6 +1105,7 @@ def main():
             extra = {}
             for key, fn in (("c2", lambda: extra_c2(L, dev, stream, T)), ("jpeg_layouts", lambda: extra_layouts(L, dev, stream, T)),
                             ("c4", lambda: extra_c4(L, dev, stream, T, not a.no_cpu)), ("c5", lambda: extra_c5(L, dev, stream, T, not a.no_cpu)),
+                            ("f1", lambda: extra_f1(L, dev, stream, T, not a.no_cpu)),
                             ("stage_kernels", lambda: extra_stage_kernels(L, dev, stream, T))):
                 if a.extras and key not in a.extras.split(","):
                     continue

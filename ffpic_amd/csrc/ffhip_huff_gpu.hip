@@ -327,6 +327,17 @@ extern "C" int ffhip_jpeg_stage_scan_test(uint8_t *dst, const uint8_t *src, size
     return (int)stage_scan(dst, src, src + len, seg, n_seg, clean_len);
 }
 
+/* what the calling thread's last ffhip_jpeg_entropy_batch_gpu call spent where (bench.py's configs.f1): microseconds of host time per phase,
+ * and the Huffman kernel's own time by HIP events on the call's stream */
+static thread_local double g_huff_times[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static thread_local hipEvent_t g_huff_ev[2] = {nullptr, nullptr};
+extern "C" int ffhip_debug_huff_times(double out[8])
+{
+    if (!out) return FFHIP_EINVAL;
+    for (int k = 0; k < 8; k++) out[k] = g_huff_times[k];
+    return FFHIP_OK;
+}
+
 extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const size_t *lens, int n, int n_threads,
                                             const ffhip_jpeg_geom *geom, int16_t *d_coef_y, int16_t *d_coef_u, int16_t *d_coef_v,
                                             uint16_t *d_quant, int *status, void *stream)
@@ -460,9 +471,9 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     });
     memcpy(stage + o_img, images.data(), images.size() * sizeof(HuffImage));
     memset(stage + o_status, 0, (size_t)n * 4);
+    const auto T4 = std::chrono::steady_clock::now();
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
     if (times) {
-        const auto T4 = std::chrono::steady_clock::now();
-        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
         fprintf(stderr, "huff staging: header parse %ld us, layout %ld us, unstuff + markers (uploads enqueued by quarters) %ld us, tables %ld us (%d files, %zu bytes, %d threads)\n", us(T0, T1), us(T1, T2), us(T2, T3), us(T3, T4), n, total, n_threads);
     }
     /* the rest of the image: scan padding, tables, picture records, interval lists, status, quantiser tables */
@@ -478,16 +489,24 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     a.plane[0] = d_coef_y; a.plane[1] = d_coef_u; a.plane[2] = d_coef_v;
     a.status = (int *)(dev + o_status);
     a.n_work = (uint32_t)seg_total;
+    if (!g_huff_ev[0] && (hipEventCreate(&g_huff_ev[0]) != hipSuccess || hipEventCreate(&g_huff_ev[1]) != hipSuccess)) { (void)hipGetLastError(); g_huff_ev[0] = nullptr; }
+    if (g_huff_ev[0]) (void)hipEventRecord(g_huff_ev[0], st);
     hipLaunchKernelGGL(k_jpeg_huff, dim3((a.n_work + 63) / 64), dim3(64), 0, st, a);
     FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
+    if (g_huff_ev[0]) (void)hipEventRecord(g_huff_ev[1], st);
     /* per-picture verdicts come back with the stream (tiny); the staging buffer is free again after this sync */
     FFHIP_CHECK(hipMemcpyAsync(stage + o_status, dev + o_status, (size_t)n * 4, hipMemcpyDeviceToHost, st), FFHIP_EIO);
     const auto T5 = std::chrono::steady_clock::now();
     FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO);
+    const auto T6 = std::chrono::steady_clock::now();
     if (times)
-        fprintf(stderr, "huff device: enqueue %ld us, wait for uploads + clears + kernel %ld us\n",
-                (long)std::chrono::duration_cast<std::chrono::microseconds>(T5 - T3).count(),
-                (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - T5).count());
+        fprintf(stderr, "huff device: enqueue %ld us, wait for uploads + clears + kernel %ld us\n", us(T3, T5), us(T5, T6));
+    {
+        float kms = 0.0f;
+        if (!g_huff_ev[0] || hipEventElapsedTime(&kms, g_huff_ev[0], g_huff_ev[1]) != hipSuccess) { (void)hipGetLastError(); kms = 0.0f; }
+        g_huff_times[0] = (double)us(T0, T1); g_huff_times[1] = (double)us(T1, T2); g_huff_times[2] = (double)us(T2, T3); g_huff_times[3] = (double)us(T3, T4);
+        g_huff_times[4] = (double)us(T4, T5); g_huff_times[5] = (double)us(T5, T6); g_huff_times[6] = (double)kms * 1e3; g_huff_times[7] = (double)us(T0, T6);
+    }
     memcpy(status, stage + o_status, (size_t)n * 4);
     for (int i = 0; i < n; i++)
         if (status[i]) return status[i];

@@ -235,32 +235,49 @@ extern "C" int ffhip_jpeg_decode_files_device(const uint8_t *const *files, const
     if (!ffhip_have_device()) return FFHIP_ENODEV;
     const size_t mcus = (size_t)g.mcu_cols * g.mcu_rows;
     const size_t yb = mcus * g.h * g.v * 64, cb = g.ncomp == 3 ? mcus * 64 : 0; /* int16 elements per picture */
-    const size_t words = ((size_t)n * (yb + 2 * cb) * 2 + (size_t)n * 512 + 64) / 4 + 16;
-    uint8_t *base = (uint8_t *)ffhip_scratch(SCRATCH_FILES_DEV, stream, words);
-    if (!base) return FFHIP_ENOMEM;
-    int16_t *dy = (int16_t *)base, *du = cb ? dy + (size_t)n * yb : nullptr, *dv = cb ? du + (size_t)n * cb : nullptr;
-    uint16_t *dq = (uint16_t *)(base + (((size_t)n * (yb + 2 * cb) * 2 + 15) & ~(size_t)15));
     hipStream_t st = (hipStream_t)stream;
     const char *ge = FFHIP_ENV("FFHIP_JPEG_GPU_ENTROPY");
-    bool on_device = false;
     if (!(ge && ge[0] == '0') && ((ge && ge[0] == '1') || ffhip_jpeg_probe_restart(files[0], lens[0]) > 0 || n >= 1024)) {
+        /* entropy decode on the device, a lane per restart interval, straight into planes in library scratch; one reconstruction launch behind it */
+        const size_t words = ((size_t)n * (yb + 2 * cb) * 2 + (size_t)n * 512 + 64) / 4 + 16;
+        uint8_t *base = (uint8_t *)ffhip_scratch(SCRATCH_FILES_DEV, stream, words);
+        if (!base) return FFHIP_ENOMEM;
+        int16_t *dy = (int16_t *)base, *du = cb ? dy + (size_t)n * yb : nullptr, *dv = cb ? du + (size_t)n * cb : nullptr;
+        uint16_t *dq = (uint16_t *)(base + (((size_t)n * (yb + 2 * cb) * 2 + 15) & ~(size_t)15));
         rc = ffhip_jpeg_entropy_batch_gpu(files, lens, n, n_threads, &g, dy, du, dv, dq, status, stream);
-        on_device = rc == FFHIP_OK;
-        if (!on_device && rc != FFHIP_EINVAL) return rc;
+        if (rc == FFHIP_OK) return ffhip_jpeg_recon_batch(&g, n, dy, du, dv, dq, 256, d_bgra, pitch, image_stride, nullptr, 0, stream);
+        if (rc != FFHIP_EINVAL) return rc;
     }
-    int result = FFHIP_OK;
-    if (!on_device) { /* host threads, then one upload (pageable staging: this path is the fallback) */
-        std::vector<int16_t> hy((size_t)n * yb), hu((size_t)n * cb), hv((size_t)n * cb);
-        std::vector<uint16_t> hq((size_t)n * 256);
-        result = ffhip_jpeg_entropy_batch(files, lens, n, n_threads, &g, hy.data(), cb ? hu.data() : nullptr, cb ? hv.data() : nullptr, hq.data(), status);
-        FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO); /* the scratch may still be read by this stream's previous batch */
-        FFHIP_CHECK(hipMemcpy(dy, hy.data(), hy.size() * 2, hipMemcpyHostToDevice), FFHIP_EIO);
-        if (cb) {
-            FFHIP_CHECK(hipMemcpy(du, hu.data(), hu.size() * 2, hipMemcpyHostToDevice), FFHIP_EIO);
-            FFHIP_CHECK(hipMemcpy(dv, hv.data(), hv.size() * 2, hipMemcpyHostToDevice), FFHIP_EIO);
-        }
-        FFHIP_CHECK(hipMemcpy(dq, hq.data(), hq.size() * 2, hipMemcpyHostToDevice), FFHIP_EIO);
+    /* Host threads (files without restart markers are one interval each: a lane per FILE only pays from a thousand files on).  A pipeline of
+     * chunks over the two slots ffhip_jpeg_decode_files uses: while the host threads decode chunk k + 1 into pinned memory, chunk k is copied
+     * to the device and reconstructed on the slot's own stream, straight into the caller's d_bgra.  (Until round 5 this path decoded the whole
+     * batch into pageable vectors, then uploaded it: 1.84 s for 256 4K files, most of it page faults and a pageable copy of 9.5 GB.)  Everything
+     * has run when the call returns. */
+    int chunk = n_threads < 8 ? 8 : (n_threads > 32 ? 32 : n_threads);
+    if (chunk > n) chunk = n;
+    FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO); /* d_bgra may still be read by what `stream` holds */
+    std::lock_guard<std::mutex> lock(g_pipe_mu);
+    Slot *slot = g_slot;
+    for (int s = 0; s < 2; s++)
+        if (!prepare(slot[s], chunk * yb * 2, chunk * cb * 2, (size_t)chunk * 512, 0, false)) return FFHIP_ENOMEM;
+    int result = FFHIP_OK, k = 0;
+    rc = FFHIP_OK;
+    for (int first = 0; first < n && rc == FFHIP_OK; first += chunk, k++) {
+        Slot &sl = slot[k & 1];
+        const int cnt = n - first < chunk ? n - first : chunk;
+        if (hipStreamSynchronize(sl.st) != hipSuccess) { rc = FFHIP_EIO; break; } /* the slot's previous chunk (k - 2) has left its pinned planes */
+        const int erc = ffhip_jpeg_entropy_batch(files + first, lens + first, cnt, n_threads, &g, sl.h_y, cb ? sl.h_u : nullptr, cb ? sl.h_v : nullptr, sl.h_q,
+                                                 status + first);
+        if (erc && !result) result = erc; /* per-picture codes are in status[]; bad pictures still occupy their place */
+        hipError_t e = hipMemcpyAsync(sl.d_y, sl.h_y, cnt * yb * 2, hipMemcpyHostToDevice, sl.st);
+        if (e == hipSuccess && cb) e = hipMemcpyAsync(sl.d_u, sl.h_u, cnt * cb * 2, hipMemcpyHostToDevice, sl.st);
+        if (e == hipSuccess && cb) e = hipMemcpyAsync(sl.d_v, sl.h_v, cnt * cb * 2, hipMemcpyHostToDevice, sl.st);
+        if (e == hipSuccess) e = hipMemcpyAsync(sl.d_q, sl.h_q, (size_t)cnt * 512, hipMemcpyHostToDevice, sl.st);
+        if (e != hipSuccess) { rc = FFHIP_EIO; break; }
+        rc = ffhip_jpeg_recon_batch(&g, cnt, sl.d_y, cb ? sl.d_u : nullptr, cb ? sl.d_v : nullptr, sl.d_q, 256, d_bgra + (int64_t)first * image_stride, pitch, image_stride,
+                                    nullptr, 0, sl.st);
     }
-    rc = ffhip_jpeg_recon_batch(&g, n, dy, du, dv, dq, 256, d_bgra, pitch, image_stride, nullptr, 0, stream);
+    for (int s = 0; s < 2; s++)
+        if (hipStreamSynchronize(slot[s].st) != hipSuccess && rc == FFHIP_OK) rc = FFHIP_EIO;
     return rc ? rc : result;
 }

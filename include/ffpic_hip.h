@@ -494,6 +494,11 @@ int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const size_t *lens
                                  parsing, marker search, staging */, const ffhip_jpeg_geom *geom, int16_t *d_coef_y, int16_t *d_coef_u, int16_t *d_coef_v, uint16_t *d_quant,
                                  int *status, void *stream);
 
+/* Diagnostics: where the calling thread's last ffhip_jpeg_entropy_batch_gpu call spent its time, in microseconds: out[0] header parse,
+ * [1] layout, [2] unstuffing + marker search into pinned memory (the uploads are enqueued by quarters behind it), [3] tables, [4] enqueue,
+ * [5] the wait for uploads + clears + kernel, [6] the Huffman kernel alone (HIP events on the call's stream), [7] the whole call. */
+int ffhip_debug_huff_times(double out[8]);
+
 /* Files in, pixels out (f1 + the hot path + f2's producer side): n baseline JPEG files of ONE geometry are
  * entropy-decoded `chunk` pictures at a time (0 = default) -- on the device when they carry restart markers
  * (ffhip_jpeg_entropy_batch_gpu), else by n_threads host threads into pinned memory -- while the
@@ -506,8 +511,10 @@ int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const size_t *lens
  * directly; a pageable one goes through pinned staging and a threaded copy.  Buffers are kept between calls;
  * one call at a time. */
 /* The same with the pixels left ON THE DEVICE (d_bgra, pitch and image_stride as for ffhip_jpeg_recon_batch): for a
- * consumer that lives on the GPU only the compressed bytes cross PCIe.  One batch, no chunking; the reconstruction
- * is enqueued on `stream` (the entropy stage in front of it synchronises the stream when it runs on the device). */
+ * consumer that lives on the GPU only the compressed bytes cross PCIe.  Files with restart markers: one batch, entropy decode
+ * on the device, the reconstruction enqueued on `stream` behind it (the entropy stage synchronises the stream).  Files without:
+ * host threads decode chunks of a few pictures into pinned memory while the previous chunk is uploaded and reconstructed on a
+ * stream of the library's own; `stream` is synchronised first and every picture is in d_bgra when the call returns. */
 int ffhip_jpeg_decode_files_device(const uint8_t *const *files, const size_t *lens, int n, int n_threads,
                                    ffhip_jpeg_geom *geom_out, uint8_t *d_bgra, int64_t pitch, int64_t image_stride,
                                    int *status, void *stream);

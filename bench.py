@@ -548,7 +548,7 @@ def hevc_chain_inputs(W, H, seed, tus=None):
     return tus, groups, off
 
 
-def run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T=None):
+def run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T=None, tile_first=None):
     d_tus = torch.from_numpy(tus.view(np.uint8).copy()).to(dev)
     d_res = torch.zeros(total + 64, dtype=torch.int16, device=dev)
     dg = {n: (torch.from_numpy(lv).to(dev), torch.from_numpy(info).to(dev), off, len(idx)) for n, (idx, lv, info, off) in groups.items()}
@@ -561,7 +561,13 @@ def run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T=None):
         for n, (lv, info, off, cnt) in dg.items():
             capi.check(L.ffhip_hevc_residual_batch(n, cnt, lv.data_ptr(), info.data_ptr(), None, 8, 0, d_res.data_ptr() + 2 * off, stream))
 
+    tf = None if tile_first is None else np.ascontiguousarray(tile_first, dtype=np.int64)
+
     def s_intra():
+        if tf is not None:   # the tile loop as one pipelined call: the list is the concatenation of independent tiles
+            capi.check(L.ffhip_hevc_intra_recon_tiles(tus.ctypes.data, d_tus.data_ptr(), len(tus), tf.ctypes.data, len(tf), d_res.data_ptr(), py.data_ptr(), pu.data_ptr(),
+                                                      pv.data_ptr(), W, H, W, W // 2, H // 2, W // 2, 8, 8, stream))
+            return
         capi.check(L.ffhip_hevc_intra_recon(tus.ctypes.data, d_tus.data_ptr(), len(tus), d_res.data_ptr(), py.data_ptr(), pu.data_ptr(), pv.data_ptr(),
                                             W, H, W, W // 2, H // 2, W // 2, 8, 8, stream))
 
@@ -619,7 +625,8 @@ def c5_grid_sweep(L, dev, stream, T, cpu=True, pictures=(1, 4, 8), tile=512, til
     t0, _ = synth.hevc_intra_tus(tile, tile, seed=3, tu_mix="c5")
     _, perm0 = synth.hevc_reference_order(t0, 64, 2, 3, return_perm=True)
     out = {"workload": f"8K pictures as grids of {tiles_xy[0]} x {tiles_xy[1]} independent {tile}x{tile} HEVC tiles ({len(t0)} TUs per tile, config-5 mix), "
-                       "residual -> intra -> BGRA, one call per stage for all tiles", "rows": []}
+                       "residual -> intra -> BGRA, one call per stage for all tiles (the intra stage: ffhip_hevc_intra_recon_tiles, the tile loop as a pipeline of "
+                       "chunks; `one_call_unpipelined`: ffhip_hevc_intra_recon over the whole list)", "rows": []}
     for npic in pictures:
         px_, py_ = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}[npic]
         gx, gy = tiles_xy[0] * px_, tiles_xy[1] * py_
@@ -632,13 +639,17 @@ def c5_grid_sweep(L, dev, stream, T, cpu=True, pictures=(1, 4, 8), tile=512, til
         tus, groups, total = hevc_chain_inputs(W, H, seed=40 + npic, tus=tus)
         # the same tiles, every tile's list in the order the reference decodes it in (per coding unit: luma tree, Cb, Cr; coding/hevc.c:5013-5180)
         tus_r = tus[(np.arange(gx * gy, dtype=np.int64)[:, None] * len(t0) + perm0[None, :]).reshape(-1)]
-        bgra_r, _, _, tr = run_hevc_chain_gpu(L, dev, stream, W, H, tus_r, groups, total, T)
-        bgra, planes, d_res, t = run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T)
+        tile_first = np.arange(gx * gy, dtype=np.int64) * len(t0)
+        bgra_1, _, _, t1 = run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T)                 # one ffhip_hevc_intra_recon call over the whole list
+        bgra_r, _, _, tr = run_hevc_chain_gpu(L, dev, stream, W, H, tus_r, groups, total, T, tile_first)
+        bgra, planes, d_res, t = run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T, tile_first)   # ffhip_hevc_intra_recon_tiles: the pipelined tile loop
         row = {"pictures": npic, "tiles": gx * gy, "tus": int(len(tus)), "chain_ms": round(t["chain"], 4), "intra_recon_ms": round(t["intra_recon"], 4),
                "intra_host_enqueue_ms": round(t["intra_host_enqueue"], 3), "value": round(W * H / t["chain"] / 1e3, 1), "unit": "Mpixels/s", "plan": t.get("plan"),
                "reference_order": {"chain_ms": round(tr["chain"], 4), "intra_recon_ms": round(tr["intra_recon"], 4), "intra_host_enqueue_ms": round(tr["intra_host_enqueue"], 3),
-                                   "value": round(W * H / tr["chain"] / 1e3, 1), "plan": tr.get("plan"), "same_pixels": bool(torch.equal(bgra, bgra_r))}}
-        del bgra_r
+                                   "value": round(W * H / tr["chain"] / 1e3, 1), "plan": tr.get("plan"), "same_pixels": bool(torch.equal(bgra, bgra_r))},
+               "one_call_unpipelined": {"chain_ms": round(t1["chain"], 4), "intra_recon_ms": round(t1["intra_recon"], 4), "value": round(W * H / t1["chain"] / 1e3, 1),
+                                        "same_pixels": bool(torch.equal(bgra, bgra_1))}}
+        del bgra_r, bgra_1
         if cpu and npic == max(pictures):
             # parity of the first and the last tile of the largest grid: each tile is a picture of its own for the reference's C chain
             ok = True
@@ -910,6 +921,7 @@ def compact_configs(extra):
                                                         "sorted_by_plane": g(c5, "reference_order", "plan", "sorted_by_plane")},
                      "grid_135_tiles": {str(r["pictures"]): r["value"] for r in rows},
                      "grid_135_tiles_reference_order": {str(r["pictures"]): g(r, "reference_order", "value") for r in rows},
+                     "grid_135_tiles_unpipelined": {str(r["pictures"]): g(r, "one_call_unpipelined", "value") for r in rows},
                      "grid_reference_order_ok": [bool(g(r, "reference_order", "same_pixels") and planned(g(r, "reference_order", "plan"))) for r in rows],
                      "grid_host_enqueue_ms": {str(r["pictures"]): r["intra_host_enqueue_ms"] for r in rows},
                      "grid_parity": [r.get("parity_first_and_last_tile_vs_reference") for r in rows if "parity_first_and_last_tile_vs_reference" in r],

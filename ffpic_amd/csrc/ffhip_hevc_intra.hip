@@ -1978,10 +1978,21 @@ extern "C" int ffhip_hevc_intra_plan(const ffhip_hevc_tu *h_tus, long long n_tus
     return FFHIP_OK;
 }
 
-extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu *d_tus, long long n_tus,
-                                      const int16_t *d_residual, int16_t *d_y, int16_t *d_cb, int16_t *d_cr,
-                                      int width_y, int height_y, int y_stride, int width_c, int height_c,
-                                      int uv_stride, int bitdepth_y, int bitdepth_c, void *stream)
+/* ffhip_hevc_intra_recon_tiles runs a call's chunks as a pipeline: a chunk's pre-pass (validation, planner, substitution table, programs) on
+ * `plan` -- a stream of the library's own, one pre-pass behind the other -- and its grouped kernel on `groups` (the caller's stream and a second
+ * library stream in turn), behind `plan_done`.  Scratch of its own per chunk (`scratch_kind`); the substitution table and the per-pixel words,
+ * which are indexed by position in the planes, are shared (`jt_desc`: the chunks cover different areas). */
+struct IntraRoles {
+    hipStream_t plan, groups;
+    hipEvent_t plan_done;
+    int scratch_kind;
+    uint32_t *jt_desc;
+    bool big_call; /* the call this chunk is cut from is a large list (2^17 records and more): the host samples, the device validates, as for the whole list */
+};
+static int intra_recon_impl(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu *d_tus, long long n_tus,
+                            const int16_t *d_residual, int16_t *d_y, int16_t *d_cb, int16_t *d_cr,
+                            int width_y, int height_y, int y_stride, int width_c, int height_c,
+                            int uv_stride, int bitdepth_y, int bitdepth_c, void *stream, const IntraRoles *roles)
 {
     if (n_tus < 0 || n_tus > 0x7fffffffLL) return FFHIP_EINVAL;
     if (n_tus == 0) return FFHIP_OK;
@@ -1993,7 +2004,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
     /* lists of 2^17 TUs and more: the host looks at a sample (a bad record there is refused here, at once), every record is checked by a
      * kernel in front of the planner (k_hevc_check_tus), which refuses the call through the stream -- or by a full host pass below, should the
      * call not take the device planner */
-    const bool big_list = n_tus >= (1LL << 17) && !FFHIP_ENV("FFHIP_HEVC_HOST_CHECK");
+    const bool big_list = (n_tus >= (1LL << 17) || (roles && roles->big_call)) && !FFHIP_ENV("FFHIP_HEVC_HOST_CHECK");
     std::atomic<bool> bad{false}, any_res{false};
     auto validate = [&](const bool sampled) {
     host_parallel_for(sampled ? 1 : n_tus, [&](long long b, long long e) {
@@ -2056,7 +2067,8 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
         }
     };
     if (has_res && !d_residual) return FFHIP_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t st = roles ? roles->plan : (hipStream_t)stream; /* everything in front of the grouped kernel */
+    const int scratch_kind = roles ? roles->scratch_kind : SCRATCH_HEVC_INTRA;
     HevcIntraArgs a = {};
     /* the records the schedule's TU indices refer to: the caller's, or -- for a list that interleaves the planes inside a scheduling window --
      * a copy sorted by plane in the call's scratch (pick_window) */
@@ -2174,9 +2186,10 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             const int wl = dev_wl, cs = dev_cs;
             const int win[3] = {wl, wl - cs, wl - cs};
             const size_t w_plan = ffhip_hevc_plan_gpu_words(n_tus, pwc, ph, win), w_ctrl = CTRL_HDR + (size_t)n_tus;
-            uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, w_plan + w_ctrl + 16 + w_jt + w_desc);
+            const bool shared_jt = roles && roles->jt_desc;
+            uint32_t *g_work = ffhip_scratch(scratch_kind, stream, w_plan + w_ctrl + 16 + (shared_jt ? 0 : w_jt + w_desc));
             if (!g_work) return FFHIP_ENOMEM;
-            uint32_t *const jt_words = g_work + ((w_plan + 3) & ~(size_t)3) + ((w_ctrl + 3) & ~(size_t)3);
+            uint32_t *const jt_words = shared_jt ? roles->jt_desc : g_work + ((w_plan + 3) & ~(size_t)3) + ((w_ctrl + 3) & ~(size_t)3);
             int n_groups = 0;
             /* the substitution table starts (on the side stream) behind the list's validation: a bad record's position would send its stores anywhere */
             /* ... and the per-pixel programs follow it there, behind k_plan_count (whose flags and wait counts are all they need of the schedule),
@@ -2258,12 +2271,24 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
 #ifdef FFHIP_INTRA_TRACE
             a.trace = g_intra_trace;
 #endif
-            hipLaunchKernelGGL((k_hevc_intra_groups<2, 64>), dim3((unsigned)std::min<size_t>((size_t)n_tus, resident_waves)), dim3(64), 0, st, a);
+            hipStream_t gst = st;
+            if (roles) { /* a chunk of a pipelined call: the grouped kernel runs elsewhere, behind this pre-pass */
+                FFHIP_CHECK(hipEventRecord(roles->plan_done, st), FFHIP_EIO);
+                FFHIP_CHECK(hipStreamWaitEvent(roles->groups, roles->plan_done, 0), FFHIP_EIO);
+                gst = roles->groups;
+            }
+            /* a chunk of a pipelined call leaves a share of the wave slots free: its waves hold ALL of their SIMD's registers (3 x 168), so with the
+             * chip full of them the next chunk's pre-pass did not start before they left (its first kernel: 8 us alone, 550 us there), and no two
+             * chunks' grouped kernels ever overlapped.  Tickets, not residency, are what a launch of any size is safe by. */
+            size_t share = 100;
+            if (roles && roles->jt_desc) { const char *sp = FFHIP_ENV("FFHIP_HEVC_TILE_WAVES_PCT"); share = sp ? (size_t)std::max(10, std::min(100, atoi(sp))) : 67; }
+            const size_t rw = std::max<size_t>(64, resident_waves * share / 100), rw_tp = std::max<size_t>(64, resident_waves_tp * share / 100);
+            hipLaunchKernelGGL((k_hevc_intra_groups<2, 64>), dim3((unsigned)std::min<size_t>((size_t)n_tus, rw)), dim3(64), 0, gst, a);
             /* (an instance with four waves per SIMD's worth of registers -- 128, 27 of them spilled -- would be thirteen waves per CU by LDS: measured,
              * 3.46 against 3.18 ms at eight pictures) */
-            if (a.tp_width) hipLaunchKernelGGL((k_hevc_intra_groups<3, 16>), dim3((unsigned)std::min<size_t>((size_t)n_tus, resident_waves_tp)), dim3(64), 0, st, a);
-            hipLaunchKernelGGL(k_hevc_intra_serial, dim3(1), dim3(64), 0, st, a); /* does something only for a list the planner refused */
-            g_last_plan_result = a.plan_result; g_last_plan_stream = st;
+            if (a.tp_width) hipLaunchKernelGGL((k_hevc_intra_groups<3, 16>), dim3((unsigned)std::min<size_t>((size_t)n_tus, rw_tp)), dim3(64), 0, gst, a);
+            hipLaunchKernelGGL(k_hevc_intra_serial, dim3(1), dim3(64), 0, gst, a); /* does something only for a list the planner refused */
+            g_last_plan_result = a.plan_result; g_last_plan_stream = gst;
             if (host_times) {
                 const auto TH3 = std::chrono::steady_clock::now();
                 auto us = [](auto x, auto y) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(y - x).count(); };
@@ -2273,6 +2298,10 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             return FFHIP_OK;
         }
         if (!validate_fully()) return FFHIP_EINVAL; /* the host planner walks every record */
+        if (roles) { /* (a chunk of a pipelined call that does not take the device planner: in line on its groups stream, which has the inputs) */
+            FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO);
+            st = roles->groups;
+        }
         GroupPlan plan;
         int host_wl = 0;
         /* the host planner works on the list sorted by plane where the device planner would (pick_window): its slots' TU indices then refer to
@@ -2287,7 +2316,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
             const size_t o_groups = w_sched, o_wait = o_groups + w_groups, o_ctrl = (o_wait + w_wait + 3) & ~(size_t)3;
             const size_t w_sorted = by_plane ? 8 * (size_t)n_tus + 16 : 0;
             FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO); /* the work buffer may still be in use by an earlier call */
-            uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, o_ctrl + w_ctrl + 4 + w_jt + w_desc + w_sorted);
+            uint32_t *g_work = ffhip_scratch(scratch_kind, stream, o_ctrl + w_ctrl + 4 + w_jt + w_desc + w_sorted);
             if (!g_work) return FFHIP_ENOMEM;
             uint32_t *const jt_words = g_work + ((o_ctrl + w_ctrl + 3) & ~(size_t)3);
             if (by_plane) {
@@ -2324,12 +2353,16 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
     }
 
     if (!validate_fully()) return FFHIP_EINVAL;
+    if (roles && st == roles->plan) {
+        FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO);
+        st = roles->groups;
+    }
     build_levels();
     std::vector<uint32_t> flat;
     flat.reserve((size_t)n_tus);
     for (auto &l : lists) flat.insert(flat.end(), l.begin(), l.end());
     FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO);
-    uint32_t *g_work = ffhip_scratch(SCRATCH_HEVC_INTRA, stream, (size_t)n_tus);
+    uint32_t *g_work = ffhip_scratch(scratch_kind, stream, (size_t)n_tus);
     if (!g_work) return FFHIP_ENOMEM;
     FFHIP_CHECK(hipMemcpy(g_work, flat.data(), flat.size() * sizeof(uint32_t), hipMemcpyHostToDevice), FFHIP_EIO);
     size_t off = 0;
@@ -2341,4 +2374,114 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
     }
     FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
     return FFHIP_OK;
+}
+
+extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu *d_tus, long long n_tus,
+                                      const int16_t *d_residual, int16_t *d_y, int16_t *d_cb, int16_t *d_cr,
+                                      int width_y, int height_y, int y_stride, int width_c, int height_c,
+                                      int uv_stride, int bitdepth_y, int bitdepth_c, void *stream)
+{
+    return intra_recon_impl(h_tus, d_tus, n_tus, d_residual, d_y, d_cb, d_cr, width_y, height_y, y_stride, width_c, height_c, uv_stride, bitdepth_y, bitdepth_c, stream, nullptr);
+}
+
+/* The tile loop of a HEIF grid (format/heif.c:297-309: decode one tile after the other, no dependency between tiles) as ONE call over the
+ * concatenated lists of independent pictures that share one plane set -- and as a PIPELINE: the list is cut at tile boundaries into up to four
+ * chunks of about equal size; the pre-pass of chunk k + 1 (validation, planner, substitution table, per-pixel programs: a third of an
+ * eight-picture call's span when it ran in front of the one grouped kernel) runs on streams of the library's own while chunk k reconstructs, and
+ * the chunks' grouped kernels run on two streams in turn so that one chunk's start fills the other's tail.  What makes that legal is the
+ * caller's word that tiles never reference each other; the results are those of ffhip_hevc_intra_recon on the whole list. */
+#define SCRATCH_HEVC_TILES_JT 20
+#define SCRATCH_HEVC_TILES_CHUNK 21 /* .. + 3 */
+extern "C" int ffhip_hevc_intra_recon_tiles(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu *d_tus, long long n_tus, const long long *tile_first, int n_tiles,
+                                            const int16_t *d_residual, int16_t *d_y, int16_t *d_cb, int16_t *d_cr, int width_y, int height_y, int y_stride,
+                                            int width_c, int height_c, int uv_stride, int bitdepth_y, int bitdepth_c, void *stream)
+{
+    if (n_tus < 0 || n_tus > 0x7fffffffLL || n_tiles < 0 || (n_tiles > 0 && !tile_first)) return FFHIP_EINVAL;
+    if (n_tus == 0) return FFHIP_OK;
+    for (int k = 0; k < n_tiles; k++)
+        if (tile_first[k] < (k ? tile_first[k - 1] : 0) || tile_first[k] > n_tus) return FFHIP_EINVAL;
+    if (n_tiles > 0 && tile_first[0] != 0) return FFHIP_EINVAL;
+    /* chunks (FFHIP_HEVC_TILE_CHUNKS=2..4; default 1: see below), cut at the tile boundaries nearest to equal shares */
+    const char *ce = FFHIP_ENV("FFHIP_HEVC_TILE_CHUNKS");
+    int want = ce ? std::max(1, std::min(4, atoi(ce))) : 1;
+    long long cut[5] = {0, n_tus, n_tus, n_tus, n_tus};
+    int chunks = 1;
+    if (n_tiles > 1 && want > 1) {
+        int ti = 1;
+        for (int c = 1; c < want; c++) {
+            const long long target = n_tus * c / want;
+            while (ti < n_tiles && tile_first[ti] < target) ti++;
+            if (ti >= n_tiles) break;
+            /* the boundary at or behind the target, or the one in front of it when that is nearer */
+            long long at = tile_first[ti];
+            if (ti > 1 && target - tile_first[ti - 1] < at - target && tile_first[ti - 1] > cut[chunks - 1]) at = tile_first[ti - 1];
+            if (at <= cut[chunks - 1] || at >= n_tus) continue;
+            cut[chunks++] = at;
+        }
+        cut[chunks] = n_tus;
+    }
+    FfhipPipe pipe;
+    const char *early_e = FFHIP_ENV("FFHIP_HEVC_TILE_EARLY");
+    const bool early = !(early_e && early_e[0] == '0');
+    if ((chunks == 1 && !early) || !ffhip_have_device() || ffhip_pipe_streams_get(&pipe) != FFHIP_OK)
+        return intra_recon_impl(h_tus, d_tus, n_tus, d_residual, d_y, d_cb, d_cr, width_y, height_y, y_stride, width_c, height_c, uv_stride, bitdepth_y, bitdepth_c, stream, nullptr);
+    /* the library's pre-pass stream may not touch this thread's pipeline scratch (schedule, tables) before the grouped kernel of the call before has
+     * finished with it: an event recorded behind every call, waited for in front of the next */
+    static thread_local bool prev_recorded = false;
+    hipEvent_t ev_prev = (hipEvent_t)pipe.ev[FFHIP_PIPE_EVENTS - 1];
+    if (chunks == 1) {
+        /* ONE chunk -- the default: cutting the list does not pay (below) --, but the pre-pass does not wait for `stream`: it reads the TU list alone,
+         * so it runs while the stream is still busy with what the caller enqueued in front of this call -- the residual batches of this picture, the
+         * colour conversion of the picture before.  (d_tus must be COMPLETE when the call is made: see the header.) */
+        IntraRoles roles;
+        roles.plan = (hipStream_t)pipe.plan; roles.groups = (hipStream_t)stream; roles.plan_done = (hipEvent_t)pipe.ev[2];
+        roles.scratch_kind = SCRATCH_HEVC_TILES_CHUNK; roles.jt_desc = nullptr; roles.big_call = n_tus >= (1LL << 17);
+        if (prev_recorded) FFHIP_CHECK(hipStreamWaitEvent(roles.plan, ev_prev, 0), FFHIP_EIO);
+        const int rc1 = intra_recon_impl(h_tus, d_tus, n_tus, d_residual, d_y, d_cb, d_cr, width_y, height_y, y_stride, width_c, height_c, uv_stride, bitdepth_y, bitdepth_c, stream,
+                                         &roles);
+        if (hipEventRecord(ev_prev, (hipStream_t)stream) == hipSuccess) prev_recorded = true;
+        else { (void)hipGetLastError(); (void)hipStreamSynchronize((hipStream_t)stream); prev_recorded = false; }
+        return rc1;
+    }
+    if (!h_tus || !d_tus || !d_y || width_y <= 0 || height_y <= 0) return FFHIP_EINVAL;
+    /* the tables indexed by position in the planes, shared by the chunks: the substitution table (JT_STRIDE bytes per 4x4 block) and the per-pixel
+     * program words (8 bytes per sample) -- laid out as intra_recon_impl lays them out behind its own scratch */
+    const bool chroma = d_cb && d_cr;
+    size_t jt_blocks = 0, desc_px = 0;
+    for (int c = 0; c < 3; c++) {
+        const int w = c == 0 ? width_y : (chroma ? width_c : 0), h = c == 0 ? height_y : height_c;
+        if (w > 0) { jt_blocks += (size_t)((w + 3) / 4) * (size_t)((h + 3) / 4); desc_px += (size_t)w * (size_t)h; }
+    }
+    const size_t w_jt = (jt_blocks * JT_STRIDE + 256 + 3) / 4, w_desc = desc_px * 2 + 2;
+    uint32_t *jt_desc = ffhip_scratch(SCRATCH_HEVC_TILES_JT, stream, w_jt + w_desc + 16);
+    if (!jt_desc) return FFHIP_ENOMEM;
+    hipStream_t st = (hipStream_t)stream, s_plan = (hipStream_t)pipe.plan, s_g2 = (hipStream_t)pipe.groups2;
+    hipEvent_t ev_in = (hipEvent_t)pipe.ev[0], ev_g2 = (hipEvent_t)pipe.ev[1];
+    /* (measured on the eight-picture grid, profiles/r5_hevc_tiles_timeline_8x4.txt: a quarter of the tiles is a grouped kernel of 0.6 ms -- the length
+     * of a tile's dependency chain -- where the whole list's is 1.73, and the grouped kernel's waves hold all of their SIMDs' registers, so the next
+     * chunk's pre-pass does not start before they leave: 3.5 ms against 2.6 for the one launch; with two chunks, or with a third or half of the wave
+     * slots left free, 2.65 - 3.8.  The cut stays as a tested switch; the default is one chunk.) */
+    /* the library's streams start behind what the caller's holds (the residuals) */
+    if (prev_recorded) FFHIP_CHECK(hipStreamWaitEvent(s_plan, ev_prev, 0), FFHIP_EIO);
+    FFHIP_CHECK(hipEventRecord(ev_in, st), FFHIP_EIO);
+    FFHIP_CHECK(hipStreamWaitEvent(s_plan, ev_in, 0), FFHIP_EIO);
+    FFHIP_CHECK(hipStreamWaitEvent(s_g2, ev_in, 0), FFHIP_EIO);
+    int rc = FFHIP_OK;
+    for (int k = 0; k < chunks && rc == FFHIP_OK; k++) {
+        IntraRoles roles;
+        roles.plan = s_plan;
+        roles.groups = (k & 1) ? s_g2 : st;
+        roles.plan_done = (hipEvent_t)pipe.ev[2 + k];
+        roles.scratch_kind = SCRATCH_HEVC_TILES_CHUNK + k;
+        roles.jt_desc = jt_desc;
+        roles.big_call = n_tus >= (1LL << 17);
+        rc = intra_recon_impl(h_tus + cut[k], d_tus + cut[k], cut[k + 1] - cut[k], d_residual, d_y, d_cb, d_cr, width_y, height_y, y_stride, width_c, height_c, uv_stride,
+                              bitdepth_y, bitdepth_c, stream, &roles);
+    }
+    /* the caller's stream continues behind everything, whatever happened */
+    if (hipEventRecord(ev_g2, s_g2) != hipSuccess || hipStreamWaitEvent(st, ev_g2, 0) != hipSuccess) return FFHIP_EIO;
+    if (hipEventRecord(ev_in, s_plan) != hipSuccess || hipStreamWaitEvent(st, ev_in, 0) != hipSuccess) return FFHIP_EIO;
+    if (hipEventRecord(ev_prev, st) == hipSuccess) prev_recorded = true;
+    else { (void)hipGetLastError(); (void)hipStreamSynchronize(st); prev_recorded = false; }
+    return rc;
 }

@@ -95,6 +95,11 @@ extern thread_local FfhipVp8Then g_ffhip_vp8_then;
 struct FfhipSide { void *stream, *fork, *join, *mid, *aux; }; /* mid: a second point of the main stream the side stream may wait for; aux: a second
                                                                 point of the side stream the main stream may wait for */
 extern "C" int ffhip_side_stream_get(FfhipSide *out);
+/* the calling thread's streams and events for a pipelined call (ffhip_hevc_intra_recon_tiles): a stream the chunks' pre-passes follow each other
+ * on, a second stream for grouped kernels (the caller's is the first), events; same owner and lifetime as the side stream */
+#define FFHIP_PIPE_EVENTS 12
+struct FfhipPipe { void *plan, *groups2, *ev[FFHIP_PIPE_EVENTS]; };
+extern "C" int ffhip_pipe_streams_get(FfhipPipe *out);
 
 /* bits of a schedule slot's program word (second quarter, .x) that two files know: k_hevc_intra_program writes the word, k_plan_emit adds
  * what only the planner knows when the programs were built NEXT TO it (ffhip_hevc_intra.hip has the rest of the layout) */

@@ -512,7 +512,14 @@ extern "C" int ffhip_vp8_filter_params(const ffhip_vp8_filter_header *h, uint8_t
  * use, recreated when the thread's current device has changed, released by ffhip_shutdown (ffhip_vp8_release_side_streams)
  * or when the thread ends. */
 namespace {
-struct SideStream { int device = -1; hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr, mid = nullptr, aux = nullptr; };
+struct SideStream {
+    int device = -1;
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, mid = nullptr, aux = nullptr;
+    /* ffhip_hevc_intra_recon_tiles' pipeline (made on first use): a stream for the chunks' pre-passes, a second stream for grouped kernels, events */
+    hipStream_t plan = nullptr, groups2 = nullptr;
+    hipEvent_t pev[FFHIP_PIPE_EVENTS] = {};
+};
 std::mutex g_side_mu;
 std::vector<SideStream *> g_sides;
 void side_release(SideStream *s)
@@ -522,6 +529,10 @@ void side_release(SideStream *s)
     if (s->join) (void)hipEventDestroy(s->join);
     if (s->mid) (void)hipEventDestroy(s->mid);
     if (s->aux) (void)hipEventDestroy(s->aux);
+    if (s->plan) (void)hipStreamDestroy(s->plan);
+    if (s->groups2) (void)hipStreamDestroy(s->groups2);
+    for (auto &e : s->pev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    s->plan = s->groups2 = nullptr;
     s->side = nullptr; s->fork = s->join = s->mid = s->aux = nullptr; s->device = -1;
 }
 struct SideHolder {
@@ -566,6 +577,28 @@ extern "C" int ffhip_side_stream_get(FfhipSide *out)
     SideStream *ss = side_stream_for_this_thread();
     if (!ss) return FFHIP_EIO;
     out->stream = ss->side; out->fork = ss->fork; out->join = ss->join; out->mid = ss->mid; out->aux = ss->aux;
+    return FFHIP_OK;
+}
+/* ... and the streams and events of a pipelined call (ffhip_hevc_intra_recon_tiles), next to the thread's side stream and released with it */
+extern "C" int ffhip_pipe_streams_get(FfhipPipe *out)
+{
+    SideStream *ss = side_stream_for_this_thread();
+    if (!ss) return FFHIP_EIO;
+    std::lock_guard<std::mutex> l(g_side_mu);
+    if (!ss->plan) {
+        bool ok = hipStreamCreateWithFlags(&ss->plan, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&ss->groups2, hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; ok && k < FFHIP_PIPE_EVENTS; k++) ok = hipEventCreateWithFlags(&ss->pev[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            if (ss->plan) (void)hipStreamDestroy(ss->plan);
+            if (ss->groups2) (void)hipStreamDestroy(ss->groups2);
+            for (auto &e : ss->pev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+            ss->plan = ss->groups2 = nullptr;
+            return FFHIP_EIO;
+        }
+    }
+    out->plan = ss->plan; out->groups2 = ss->groups2;
+    for (int k = 0; k < FFHIP_PIPE_EVENTS; k++) out->ev[k] = ss->pev[k];
     return FFHIP_OK;
 }
 extern "C" void ffhip_vp8_retry_release(void);

@@ -456,6 +456,23 @@ int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu *d_tu
                            int width_y, int height_y, int y_stride, int width_c, int height_c,
                            int uv_stride, int bitdepth_y, int bitdepth_c, void *stream);
 
+/* The same for a list that is the CONCATENATION of independent pictures sharing one plane set -- the tiles of a HEIF grid, decoded one after
+ * the other by the tile loop of format/heif.c:297-309 -- tile k being records [tile_first[k], tile_first[k + 1]) (tile_first[0] = 0; the last tile
+ * ends at n_tus).  Same samples as ffhip_hevc_intra_recon on the whole list.  What the call adds is a PIPELINE across the stages of a decoder:
+ * the pre-pass (validation, planner, substitution table, per-pixel programs: a third of an eight-picture call) depends on the TU list alone, so it
+ * runs on a stream of the library's own WITHOUT waiting for `stream` -- next to whatever the caller enqueued there in front of this call: the
+ * residual batches of these tiles, the colour conversion of the picture before -- and only the grouped kernel takes its place in `stream`.
+ * Contract: d_tus holds the records WHEN THE CALL IS MADE (uploaded by a blocking copy, or by a copy whose event the host has waited for), not merely
+ * by work enqueued on `stream`; h_tus / d_tus stay untouched until `stream` has passed the call.  d_residual and the planes are read and written in
+ * `stream` order as always.  FFHIP_HEVC_TILE_EARLY=0: everything in `stream` order (= ffhip_hevc_intra_recon).
+ * FFHIP_HEVC_TILE_CHUNKS=2..4 cuts the list at tile boundaries into chunks whose pre-passes and grouped kernels overlap on streams of the library's
+ * own (the caller's word that no tile references another makes that legal): built, bit-exact, and measured SLOWER than the one launch (DESIGN.md
+ * 4.7 "Round 5") -- a tested switch, not the default. */
+int ffhip_hevc_intra_recon_tiles(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu *d_tus, long long n_tus,
+                                 const long long *tile_first, int n_tiles, const int16_t *d_residual, int16_t *d_y,
+                                 int16_t *d_cb, int16_t *d_cr, int width_y, int height_y, int y_stride, int width_c,
+                                 int height_c, int uv_stride, int bitdepth_y, int bitdepth_c, void *stream);
+
 /* ---- host-side JPEG front end and BMP sink (plain C, no GPU) ----
  * ffhip_jpeg_probe / ffhip_jpeg_entropy_decode stand where the marker loop, read_dqt,
  * read_compressed_scan and decode_data_unit stand (format/jpg.c:78-105, 255-415, 588-655,

@@ -88,12 +88,15 @@ def test_4k_batches_of_the_other_layouts(h, v):
     _jpeg_full_batch(cols, rows, 64, 3, seed=4100 + 10 * h + v, h=h, v=v)
 
 
-def _intra_full_picture(W, H, tus, res, envs=({},), monkeypatch=None, sorted_by_plane=None):
-    """... once per entry of `envs` (library switches for the call: the oracle's picture is worked out once)"""
+def _intra_full_picture(W, H, tus, res, envs=({},), monkeypatch=None, sorted_by_plane=None, tile_first=None, exp=None):
+    """... once per entry of `envs` (library switches for the call: the oracle's picture is worked out once).  tile_first: through
+    ffhip_hevc_intra_recon_tiles (the list is the concatenation of independent tiles starting at these records)"""
     torch = pytest.importorskip("torch")
     L = capi.require_device()
     dev = torch.device("cuda:0")
-    exp = O.oracle_hevc_intra(tus, res, W, H, True, 8, 8)
+    if exp is None:
+        exp = O.oracle_hevc_intra(tus, res, W, H, True, 8, 8)
+    tf = None if tile_first is None else np.ascontiguousarray(tile_first, dtype=np.int64)
     dt = torch.from_numpy(tus.view(np.uint8).copy()).to(dev)
     dr = torch.from_numpy(res).to(dev)
     py = torch.zeros((H, W), dtype=torch.int16, device=dev)
@@ -107,8 +110,12 @@ def _intra_full_picture(W, H, tus, res, envs=({},), monkeypatch=None, sorted_by_
         for rep in range(2):                               # the second call reuses the per-stream scratch and schedule buffers
             for p in (py, pu, pv):
                 p.zero_()
-            capi.check(L.ffhip_hevc_intra_recon(tus.ctypes.data, dt.data_ptr(), len(tus), dr.data_ptr(), py.data_ptr(), pu.data_ptr(),
-                                                pv.data_ptr(), W, H, W, W // 2, H // 2, W // 2, 8, 8, st), "ffhip_hevc_intra_recon")
+            if tf is None:
+                capi.check(L.ffhip_hevc_intra_recon(tus.ctypes.data, dt.data_ptr(), len(tus), dr.data_ptr(), py.data_ptr(), pu.data_ptr(),
+                                                    pv.data_ptr(), W, H, W, W // 2, H // 2, W // 2, 8, 8, st), "ffhip_hevc_intra_recon")
+            else:
+                capi.check(L.ffhip_hevc_intra_recon_tiles(tus.ctypes.data, dt.data_ptr(), len(tus), tf.ctypes.data, len(tf), dr.data_ptr(), py.data_ptr(), pu.data_ptr(),
+                                                          pv.data_ptr(), W, H, W, W // 2, H // 2, W // 2, 8, 8, st), "ffhip_hevc_intra_recon_tiles")
             capi.check(L.ffhip_stream_sync(st), "sync")
             verdict = (C.c_uint32 * 8)()   # the device planner took the list, with wavefront tickets: not the one-wave serial path
             capi.check(L.ffhip_debug_hevc_plan_result(verdict), "ffhip_debug_hevc_plan_result")
@@ -188,6 +195,14 @@ def test_c5_135_tile_8k_grid(monkeypatch):
                                 envs=({}, {"FFHIP_HEVC_JT_INLINE": "1"}), monkeypatch=monkeypatch, sorted_by_plane=True)
     for a, b in zip(exp, exp_r):
         assert np.array_equal(a, b)
+    # the tile loop as a pipeline (ffhip_hevc_intra_recon_tiles): the list cut at tile boundaries into 1 .. 4 chunks, each chunk's pre-pass next to
+    # the chunk before's grouped kernel -- in both orders of the records
+    tile_first = np.arange(K, dtype=np.int64) * len(t0)
+    _intra_full_picture(T * gx, T * gy, tus, np.tile(res0, K), envs=({}, {"FFHIP_HEVC_TILE_EARLY": "0"}, {"FFHIP_HEVC_TILE_CHUNKS": "2", "FFHIP_HEVC_TILE_WAVES_PCT": "50"}, {"FFHIP_HEVC_TILE_CHUNKS": "3"}, {"FFHIP_HEVC_TILE_CHUNKS": "4"},
+                                                                       {"FFHIP_HEVC_TILE_CHUNKS": "4", "FFHIP_HEVC_JT_INLINE": "1"}),
+                        monkeypatch=monkeypatch, tile_first=tile_first, exp=exp)
+    _intra_full_picture(T * gx, T * gy, grid_of(synth.hevc_reference_order(t0, 64, 2, 6)), np.tile(res0, K), envs=({"FFHIP_HEVC_TILE_CHUNKS": "4"},),
+                        monkeypatch=monkeypatch, tile_first=tile_first, exp=exp, sorted_by_plane=True)
     for i in range(1, K):
         ox, oy = (i % gx) * T, (i // gx) * T
         assert np.array_equal(exp[0][oy:oy + T, ox:ox + T], exp[0][:T, :T]), i

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The LAST occurrence of a chain of kernels in a rocprofv3 --kernel-trace CSV as a timeline: start offset, duration, queue.
-usage: kernel_timeline.py <dir with *_kernel_trace.csv> <first kernel of the chain (substring)> <last kernel (substring)>"""
+usage: kernel_timeline.py <dir with *_kernel_trace.csv> <first kernel of the chain (substring)> <last kernel (substring)> [n]
+n (default 1): the chain starts at the n-th last kernel matching <first> in front of the end (a pipelined call has one per chunk)"""
 import csv, glob, os, sys
 d, first, last = sys.argv[1], sys.argv[2], sys.argv[3]
 rows = []
@@ -11,7 +12,8 @@ rows.sort()
 ends = [i for i, r in enumerate(rows) if last in r[2]]
 if not ends: sys.exit("no kernel matching " + last)
 e = ends[-1]
-s = max(i for i in range(e + 1) if first in rows[i][2])
+back = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+s = sorted(i for i in range(e + 1) if first in rows[i][2])[-back]
 t0 = rows[s][0]
 tot = 0
 for st, en, name, q in rows[s:e + 1]:

@@ -2392,6 +2392,7 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
  * caller's word that tiles never reference each other; the results are those of ffhip_hevc_intra_recon on the whole list. */
 #define SCRATCH_HEVC_TILES_JT 20
 #define SCRATCH_HEVC_TILES_CHUNK 21 /* .. + 3 */
+#define SCRATCH_HEVC_TILES_ONE 25   /* .. + 1 */
 extern "C" int ffhip_hevc_intra_recon_tiles(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu *d_tus, long long n_tus, const long long *tile_first, int n_tiles,
                                             const int16_t *d_residual, int16_t *d_y, int16_t *d_cb, int16_t *d_cr, int width_y, int height_y, int y_stride,
                                             int width_c, int height_c, int uv_stride, int bitdepth_y, int bitdepth_c, void *stream)
@@ -2425,24 +2426,31 @@ extern "C" int ffhip_hevc_intra_recon_tiles(const ffhip_hevc_tu *h_tus, const ff
     const bool early = !(early_e && early_e[0] == '0');
     if ((chunks == 1 && !early) || !ffhip_have_device() || ffhip_pipe_streams_get(&pipe) != FFHIP_OK)
         return intra_recon_impl(h_tus, d_tus, n_tus, d_residual, d_y, d_cb, d_cr, width_y, height_y, y_stride, width_c, height_c, uv_stride, bitdepth_y, bitdepth_c, stream, nullptr);
-    /* the library's pre-pass stream may not touch this thread's pipeline scratch (schedule, tables) before the grouped kernel of the call before has
-     * finished with it: an event recorded behind every call, waited for in front of the next */
-    static thread_local bool prev_recorded = false;
-    hipEvent_t ev_prev = (hipEvent_t)pipe.ev[FFHIP_PIPE_EVENTS - 1];
+    /* The library's pre-pass stream may not touch a pipeline scratch (schedule, tables) before the grouped kernel of the call that used it last has
+     * finished with it: an event recorded behind every call, waited for in front of the next call that takes the same scratch.  The one-chunk form
+     * alternates between TWO scratches, so the pre-pass of call n + 1 only waits for call n - 1 and runs next to the tail of call n's grouped kernel
+     * (whose waves leave as the wavefront narrows), the colour conversion behind it and the next residual batches. */
+    static thread_local bool prev_recorded[2] = {false, false};
+    static thread_local unsigned call_parity = 0;
+    hipEvent_t ev_prev2[2] = {(hipEvent_t)pipe.ev[FFHIP_PIPE_EVENTS - 1], (hipEvent_t)pipe.ev[FFHIP_PIPE_EVENTS - 2]};
     if (chunks == 1) {
         /* ONE chunk -- the default: cutting the list does not pay (below) --, but the pre-pass does not wait for `stream`: it reads the TU list alone,
          * so it runs while the stream is still busy with what the caller enqueued in front of this call -- the residual batches of this picture, the
          * colour conversion of the picture before.  (d_tus must be COMPLETE when the call is made: see the header.) */
+        const char *db = FFHIP_ENV("FFHIP_HEVC_TILE_SCRATCHES");
+        const unsigned par = (db && db[0] == '1') ? 0u : (call_parity++ & 1u);
         IntraRoles roles;
         roles.plan = (hipStream_t)pipe.plan; roles.groups = (hipStream_t)stream; roles.plan_done = (hipEvent_t)pipe.ev[2];
-        roles.scratch_kind = SCRATCH_HEVC_TILES_CHUNK; roles.jt_desc = nullptr; roles.big_call = n_tus >= (1LL << 17);
-        if (prev_recorded) FFHIP_CHECK(hipStreamWaitEvent(roles.plan, ev_prev, 0), FFHIP_EIO);
+        roles.scratch_kind = SCRATCH_HEVC_TILES_ONE + (int)par; roles.jt_desc = nullptr; roles.big_call = n_tus >= (1LL << 17);
+        for (unsigned q = 0; q < 2; q++) /* (with one scratch: the call before; with two: the call before that -- and, for the side stream's events, nothing more) */
+            if (prev_recorded[q] && (q == par)) FFHIP_CHECK(hipStreamWaitEvent(roles.plan, ev_prev2[q], 0), FFHIP_EIO);
         const int rc1 = intra_recon_impl(h_tus, d_tus, n_tus, d_residual, d_y, d_cb, d_cr, width_y, height_y, y_stride, width_c, height_c, uv_stride, bitdepth_y, bitdepth_c, stream,
                                          &roles);
-        if (hipEventRecord(ev_prev, (hipStream_t)stream) == hipSuccess) prev_recorded = true;
-        else { (void)hipGetLastError(); (void)hipStreamSynchronize((hipStream_t)stream); prev_recorded = false; }
+        if (hipEventRecord(ev_prev2[par], (hipStream_t)stream) == hipSuccess) prev_recorded[par] = true;
+        else { (void)hipGetLastError(); (void)hipStreamSynchronize((hipStream_t)stream); prev_recorded[par] = false; }
         return rc1;
     }
+    hipEvent_t ev_prev = ev_prev2[0];
     if (!h_tus || !d_tus || !d_y || width_y <= 0 || height_y <= 0) return FFHIP_EINVAL;
     /* the tables indexed by position in the planes, shared by the chunks: the substitution table (JT_STRIDE bytes per 4x4 block) and the per-pixel
      * program words (8 bytes per sample) -- laid out as intra_recon_impl lays them out behind its own scratch */
@@ -2462,7 +2470,6 @@ extern "C" int ffhip_hevc_intra_recon_tiles(const ffhip_hevc_tu *h_tus, const ff
      * chunk's pre-pass does not start before they leave: 3.5 ms against 2.6 for the one launch; with two chunks, or with a third or half of the wave
      * slots left free, 2.65 - 3.8.  The cut stays as a tested switch; the default is one chunk.) */
     /* the library's streams start behind what the caller's holds (the residuals) */
-    if (prev_recorded) FFHIP_CHECK(hipStreamWaitEvent(s_plan, ev_prev, 0), FFHIP_EIO);
     FFHIP_CHECK(hipEventRecord(ev_in, st), FFHIP_EIO);
     FFHIP_CHECK(hipStreamWaitEvent(s_plan, ev_in, 0), FFHIP_EIO);
     FFHIP_CHECK(hipStreamWaitEvent(s_g2, ev_in, 0), FFHIP_EIO);
@@ -2481,7 +2488,6 @@ extern "C" int ffhip_hevc_intra_recon_tiles(const ffhip_hevc_tu *h_tus, const ff
     /* the caller's stream continues behind everything, whatever happened */
     if (hipEventRecord(ev_g2, s_g2) != hipSuccess || hipStreamWaitEvent(st, ev_g2, 0) != hipSuccess) return FFHIP_EIO;
     if (hipEventRecord(ev_in, s_plan) != hipSuccess || hipStreamWaitEvent(st, ev_in, 0) != hipSuccess) return FFHIP_EIO;
-    if (hipEventRecord(ev_prev, st) == hipSuccess) prev_recorded = true;
-    else { (void)hipGetLastError(); (void)hipStreamSynchronize(st); prev_recorded = false; }
+    (void)ev_prev; /* (the chunked form's streams start behind `stream`, which the call before has joined everything into) */
     return rc;
 }

@@ -464,7 +464,9 @@ int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu *d_tu
  * residual batches of these tiles, the colour conversion of the picture before -- and only the grouped kernel takes its place in `stream`.
  * Contract: d_tus holds the records WHEN THE CALL IS MADE (uploaded by a blocking copy, or by a copy whose event the host has waited for), not merely
  * by work enqueued on `stream`; h_tus / d_tus stay untouched until `stream` has passed the call.  d_residual and the planes are read and written in
- * `stream` order as always.  FFHIP_HEVC_TILE_EARLY=0: everything in `stream` order (= ffhip_hevc_intra_recon).
+ * `stream` order as always.  Consecutive calls alternate between two sets of library scratch, so the pre-pass of call n + 1 also runs next to the
+ * tail of call n's grouped kernel (FFHIP_HEVC_TILE_SCRATCHES=1: one set).  FFHIP_HEVC_TILE_EARLY=0: everything in `stream` order
+ * (= ffhip_hevc_intra_recon).  Eight / four / one 8K picture(s) as grids of 135 tiles, whole chain: 103 / 95 / 57 Gpixel/s against 90 / 85 / 48.
  * FFHIP_HEVC_TILE_CHUNKS=2..4 cuts the list at tile boundaries into chunks whose pre-passes and grouped kernels overlap on streams of the library's
  * own (the caller's word that no tile references another makes that legal): built, bit-exact, and measured SLOWER than the one launch (DESIGN.md
  * 4.7 "Round 5") -- a tested switch, not the default. */

@@ -198,7 +198,7 @@ def test_c5_135_tile_8k_grid(monkeypatch):
     # the tile loop as a pipeline (ffhip_hevc_intra_recon_tiles): the list cut at tile boundaries into 1 .. 4 chunks, each chunk's pre-pass next to
     # the chunk before's grouped kernel -- in both orders of the records
     tile_first = np.arange(K, dtype=np.int64) * len(t0)
-    _intra_full_picture(T * gx, T * gy, tus, np.tile(res0, K), envs=({}, {"FFHIP_HEVC_TILE_EARLY": "0"}, {"FFHIP_HEVC_TILE_CHUNKS": "2", "FFHIP_HEVC_TILE_WAVES_PCT": "50"}, {"FFHIP_HEVC_TILE_CHUNKS": "3"}, {"FFHIP_HEVC_TILE_CHUNKS": "4"},
+    _intra_full_picture(T * gx, T * gy, tus, np.tile(res0, K), envs=({}, {"FFHIP_HEVC_TILE_EARLY": "0"}, {"FFHIP_HEVC_TILE_SCRATCHES": "1"}, {"FFHIP_HEVC_TILE_CHUNKS": "2", "FFHIP_HEVC_TILE_WAVES_PCT": "50"}, {"FFHIP_HEVC_TILE_CHUNKS": "3"}, {"FFHIP_HEVC_TILE_CHUNKS": "4"},
                                                                        {"FFHIP_HEVC_TILE_CHUNKS": "4", "FFHIP_HEVC_JT_INLINE": "1"}),
                         monkeypatch=monkeypatch, tile_first=tile_first, exp=exp)
     _intra_full_picture(T * gx, T * gy, grid_of(synth.hevc_reference_order(t0, 64, 2, 6)), np.tile(res0, K), envs=({"FFHIP_HEVC_TILE_CHUNKS": "4"},),

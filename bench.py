@@ -703,13 +703,19 @@ def extra_c5(L, dev, stream, T, cpu=True, grid=True):
     bg_p, _, _, _ = run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total)
     bg_r, _, _, tr = run_hevc_chain_gpu(L, dev, stream, W, H, synth.hevc_reference_order(tus, 64, 2, 5), groups, total, T)
     same = bool(torch.equal(bg_p, bg_r))
-    del bg_p, bg_r
+    # ... and as a one-tile call of ffhip_hevc_intra_recon_tiles: the pre-pass does not wait for the stream (the TU list is complete when the call is
+    # made), so in a decoder's loop over pictures it runs next to the colour conversion of the picture before and this picture's residual batches
+    bg_t, _, _, tt = run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T, tile_first=np.zeros(1, np.int64))
+    same_t = bool(torch.equal(bg_p, bg_t))
+    del bg_p, bg_r, bg_t
     res = {"workload": "C5: one 7680x4352 HEVC intra picture, TU mix of SURVEY 8d (luma 32/16 at 60/40, chroma 16/8), qP 27", "chain_ms": round(t["chain"], 4),
            "value": round(px / t["chain"] / 1e3, 1), "unit": "Mpixels/s", "stages": stages, "plan": t.get("plan"),
            "reference_order": {"chain_ms": round(tr["chain"], 4), "value": round(px / tr["chain"] / 1e3, 1), "intra_recon_ms": round(tr["intra_recon"], 4),
                                "intra_host_enqueue_ms": round(tr["intra_host_enqueue"], 3), "plan": tr.get("plan"), "same_pixels": same,
                                "note": "the same TUs, records interleaved per coding unit (luma tree, Cb, Cr) as decode_cu_coded_intra_prediction_mode walks them; "
                                        "`value` above: each coding tree block's planes one after the other"},
+           "pipelined": {"chain_ms": round(tt["chain"], 4), "value": round(px / tt["chain"] / 1e3, 1), "intra_recon_ms": round(tt["intra_recon"], 4), "same_pixels": same_t,
+                         "note": "ffhip_hevc_intra_recon_tiles with one tile: the pre-pass on the library's stream, not waiting for `stream`; pictures back to back"},
            "roofline": dict(roof(9 * px, t["intra_recon"]), kernel="k_hevc_intra_groups",
                             note="algorithmic bytes 9 B/pixel (3 + 3 in, 3 out); the stage is bound by its dependency chain")}
     if cpu:
@@ -919,6 +925,7 @@ def compact_configs(extra):
                      "one_8k_picture_reference_order": {"value": g(c5, "reference_order", "value"), "ms": g(c5, "reference_order", "chain_ms"), "intra_ms": g(c5, "reference_order", "intra_recon_ms"),
                                                         "same_pixels": g(c5, "reference_order", "same_pixels"), "wavefront_64": planned(g(c5, "reference_order", "plan")),
                                                         "sorted_by_plane": g(c5, "reference_order", "plan", "sorted_by_plane")},
+                     "one_8k_picture_pipelined": {"value": g(c5, "pipelined", "value"), "ms": g(c5, "pipelined", "chain_ms"), "same_pixels": g(c5, "pipelined", "same_pixels")},
                      "grid_135_tiles": {str(r["pictures"]): r["value"] for r in rows},
                      "grid_135_tiles_reference_order": {str(r["pictures"]): g(r, "reference_order", "value") for r in rows},
                      "grid_135_tiles_unpipelined": {str(r["pictures"]): g(r, "one_call_unpipelined", "value") for r in rows},

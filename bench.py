@@ -548,7 +548,7 @@ def hevc_chain_inputs(W, H, seed, tus=None):
     return tus, groups, off
 
 
-def run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T=None, tile_first=None):
+def run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T=None, tile_first=None, fused_colour=False):
     d_tus = torch.from_numpy(tus.view(np.uint8).copy()).to(dev)
     d_res = torch.zeros(total + 64, dtype=torch.int16, device=dev)
     dg = {n: (torch.from_numpy(lv).to(dev), torch.from_numpy(info).to(dev), off, len(idx)) for n, (idx, lv, info, off) in groups.items()}
@@ -575,8 +575,15 @@ def run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T=None, tile_fi
         capi.check(L.ffhip_yuv420_to_bgra_16(bgra.data_ptr(), W * 4, py.data_ptr(), pu.data_ptr(), pv.data_ptr(), W, W // 2, H // 64, W // 64, 64, 1,
                                              H * W, H * W // 4, H * W * 4, stream))
 
+    def s_decode():      # intra reconstruction + colour conversion as ONE call (ffhip_hevc_decode_tiles)
+        capi.check(L.ffhip_hevc_decode_tiles(tus.ctypes.data, d_tus.data_ptr(), len(tus), tf.ctypes.data, len(tf), d_res.data_ptr(), py.data_ptr(), pu.data_ptr(), pv.data_ptr(),
+                                             W, H, W, W // 2, H // 2, W // 2, 8, 8, bgra.data_ptr(), W * 4, stream))
+
     def chain():
-        s_res(); s_intra(); s_col()
+        if fused_colour:
+            s_res(); s_decode()
+        else:
+            s_res(); s_intra(); s_col()
     times = None
     if T is not None:
         times = {"chain": T.ms(chain, reps=5, warm=2), "residual": T.ms(s_res, reps=5, warm=1), "intra_recon": T.ms(s_intra, reps=5, warm=1),
@@ -625,8 +632,8 @@ def c5_grid_sweep(L, dev, stream, T, cpu=True, pictures=(1, 4, 8), tile=512, til
     t0, _ = synth.hevc_intra_tus(tile, tile, seed=3, tu_mix="c5")
     _, perm0 = synth.hevc_reference_order(t0, 64, 2, 3, return_perm=True)
     out = {"workload": f"8K pictures as grids of {tiles_xy[0]} x {tiles_xy[1]} independent {tile}x{tile} HEVC tiles ({len(t0)} TUs per tile, config-5 mix), "
-                       "residual -> intra -> BGRA, one call per stage for all tiles (the intra stage: ffhip_hevc_intra_recon_tiles, the tile loop as a pipeline of "
-                       "chunks; `one_call_unpipelined`: ffhip_hevc_intra_recon over the whole list)", "rows": []}
+                       "residual batches -> ffhip_hevc_decode_tiles (the tile loop with its colour conversion as one call: the pre-pass off the stream, on two scratch sets in turn); "
+                       "`pipelined_three_calls`: ffhip_hevc_intra_recon_tiles + ffhip_yuv420_to_bgra_16; `one_call_unpipelined`: ffhip_hevc_intra_recon over the whole list + the colour kernel", "rows": []}
     for npic in pictures:
         px_, py_ = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}[npic]
         gx, gy = tiles_xy[0] * px_, tiles_xy[1] * py_
@@ -641,15 +648,17 @@ def c5_grid_sweep(L, dev, stream, T, cpu=True, pictures=(1, 4, 8), tile=512, til
         tus_r = tus[(np.arange(gx * gy, dtype=np.int64)[:, None] * len(t0) + perm0[None, :]).reshape(-1)]
         tile_first = np.arange(gx * gy, dtype=np.int64) * len(t0)
         bgra_1, _, _, t1 = run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T)                 # one ffhip_hevc_intra_recon call over the whole list
-        bgra_r, _, _, tr = run_hevc_chain_gpu(L, dev, stream, W, H, tus_r, groups, total, T, tile_first)
-        bgra, planes, d_res, t = run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T, tile_first)   # ffhip_hevc_intra_recon_tiles: the pipelined tile loop
+        bgra_r, _, _, tr = run_hevc_chain_gpu(L, dev, stream, W, H, tus_r, groups, total, T, tile_first, fused_colour=True)
+        bgra_3, _, _, t3 = run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T, tile_first)    # ffhip_hevc_intra_recon_tiles + ffhip_yuv420_to_bgra_16
+        bgra, planes, d_res, t = run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T, tile_first, fused_colour=True)   # ffhip_hevc_decode_tiles: the pipelined tile loop with its colour conversion
         row = {"pictures": npic, "tiles": gx * gy, "tus": int(len(tus)), "chain_ms": round(t["chain"], 4), "intra_recon_ms": round(t["intra_recon"], 4),
                "intra_host_enqueue_ms": round(t["intra_host_enqueue"], 3), "value": round(W * H / t["chain"] / 1e3, 1), "unit": "Mpixels/s", "plan": t.get("plan"),
                "reference_order": {"chain_ms": round(tr["chain"], 4), "intra_recon_ms": round(tr["intra_recon"], 4), "intra_host_enqueue_ms": round(tr["intra_host_enqueue"], 3),
                                    "value": round(W * H / tr["chain"] / 1e3, 1), "plan": tr.get("plan"), "same_pixels": bool(torch.equal(bgra, bgra_r))},
                "one_call_unpipelined": {"chain_ms": round(t1["chain"], 4), "intra_recon_ms": round(t1["intra_recon"], 4), "value": round(W * H / t1["chain"] / 1e3, 1),
-                                        "same_pixels": bool(torch.equal(bgra, bgra_1))}}
-        del bgra_r, bgra_1
+                                        "same_pixels": bool(torch.equal(bgra, bgra_1))},
+               "pipelined_three_calls": {"chain_ms": round(t3["chain"], 4), "value": round(W * H / t3["chain"] / 1e3, 1), "same_pixels": bool(torch.equal(bgra, bgra_3))}}
+        del bgra_r, bgra_1, bgra_3
         if cpu and npic == max(pictures):
             # parity of the first and the last tile of the largest grid: each tile is a picture of its own for the reference's C chain
             ok = True
@@ -705,7 +714,7 @@ def extra_c5(L, dev, stream, T, cpu=True, grid=True):
     same = bool(torch.equal(bg_p, bg_r))
     # ... and as a one-tile call of ffhip_hevc_intra_recon_tiles: the pre-pass does not wait for the stream (the TU list is complete when the call is
     # made), so in a decoder's loop over pictures it runs next to the colour conversion of the picture before and this picture's residual batches
-    bg_t, _, _, tt = run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T, tile_first=np.zeros(1, np.int64))
+    bg_t, _, _, tt = run_hevc_chain_gpu(L, dev, stream, W, H, tus, groups, total, T, tile_first=np.zeros(1, np.int64), fused_colour=True)
     same_t = bool(torch.equal(bg_p, bg_t))
     del bg_p, bg_r, bg_t
     res = {"workload": "C5: one 7680x4352 HEVC intra picture, TU mix of SURVEY 8d (luma 32/16 at 60/40, chroma 16/8), qP 27", "chain_ms": round(t["chain"], 4),
@@ -715,7 +724,7 @@ def extra_c5(L, dev, stream, T, cpu=True, grid=True):
                                "note": "the same TUs, records interleaved per coding unit (luma tree, Cb, Cr) as decode_cu_coded_intra_prediction_mode walks them; "
                                        "`value` above: each coding tree block's planes one after the other"},
            "pipelined": {"chain_ms": round(tt["chain"], 4), "value": round(px / tt["chain"] / 1e3, 1), "intra_recon_ms": round(tt["intra_recon"], 4), "same_pixels": same_t,
-                         "note": "ffhip_hevc_intra_recon_tiles with one tile: the pre-pass on the library's stream, not waiting for `stream`; pictures back to back"},
+                         "note": "ffhip_hevc_decode_tiles with one tile: the pre-pass on the library's stream, not waiting for `stream`; pictures back to back"},
            "roofline": dict(roof(9 * px, t["intra_recon"]), kernel="k_hevc_intra_groups",
                             note="algorithmic bytes 9 B/pixel (3 + 3 in, 3 out); the stage is bound by its dependency chain")}
     if cpu:
@@ -929,6 +938,7 @@ def compact_configs(extra):
                      "grid_135_tiles": {str(r["pictures"]): r["value"] for r in rows},
                      "grid_135_tiles_reference_order": {str(r["pictures"]): g(r, "reference_order", "value") for r in rows},
                      "grid_135_tiles_unpipelined": {str(r["pictures"]): g(r, "one_call_unpipelined", "value") for r in rows},
+                     "grid_135_tiles_three_calls": {str(r["pictures"]): g(r, "pipelined_three_calls", "value") for r in rows},
                      "grid_reference_order_ok": [bool(g(r, "reference_order", "same_pixels") and planned(g(r, "reference_order", "plan"))) for r in rows],
                      "grid_host_enqueue_ms": {str(r["pictures"]): r["intra_host_enqueue_ms"] for r in rows},
                      "grid_parity": [r.get("parity_first_and_last_tile_vs_reference") for r in rows if "parity_first_and_last_tile_vs_reference" in r],

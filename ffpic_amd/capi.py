@@ -20,7 +20,7 @@ EXPORTS = [
     "ffhip_jpeg_kernel_name", "ffhip_copy_calibrate",
     "ffhip_yuv420_to_bgra", "ffhip_yuv420_to_bgra_16", "ffhip_yuv400_to_bgra_16",
     "ffhip_vp8_residual_batch", "ffhip_hevc_residual_batch", "ffhip_vp8_predict_recon",
-    "ffhip_hevc_intra_recon", "ffhip_hevc_intra_plan", "ffhip_debug_hevc_plan_result", "ffhip_vp8_decode_frames_form", "ffhip_debug_huff_times", "ffhip_hevc_intra_recon_tiles", "ffhip_vp8_loopfilter",
+    "ffhip_hevc_intra_recon", "ffhip_hevc_intra_plan", "ffhip_debug_hevc_plan_result", "ffhip_vp8_decode_frames_form", "ffhip_debug_huff_times", "ffhip_hevc_intra_recon_tiles", "ffhip_hevc_decode_tiles", "ffhip_vp8_loopfilter",
     "ffhip_jpeg_probe", "ffhip_jpeg_entropy_decode", "ffhip_jpeg_entropy_decode_mt", "ffhip_jpeg_entropy_batch", "ffhip_bmp_write",
     "ffhip_heif_grid_parse", "ffhip_heif_grid_compose", "ffhip_hevc_picture_layout", "ffhip_jpeg_decode_files", "ffhip_jpeg_decode_files_device", "ffhip_jpeg_entropy_batch_gpu", "ffhip_jpeg_stage_scan_test", "ffhip_host_malloc", "ffhip_host_free",
     "ffhip_shard_range", "ffhip_comm_unique_id", "ffhip_comm_init_rank", "ffhip_comm_destroy", "ffhip_batch_close", "ffhip_batch_complete",
@@ -190,6 +190,7 @@ def lib():
     L.ffhip_debug_hevc_plan_result.argtypes = [vp]
     L.ffhip_hevc_intra_recon.argtypes = [vp, vp, C.c_longlong, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.ffhip_hevc_intra_recon_tiles.argtypes = [vp, vp, C.c_longlong, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    L.ffhip_hevc_decode_tiles.argtypes = [vp, vp, C.c_longlong, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, i64, vp]
     L.ffhip_vp8_loopfilter.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, i64, i64, vp]
     L.ffhip_vp8_predict_recon.argtypes = [ci, ci, ci, vp, vp, vp, i64, vp, vp, vp, vp, i64, i64, vp]
     L.ffhip_vp8_predict_loopfilter.argtypes = [ci, ci, ci, vp, vp, vp, i64, vp, ci, vp, vp, vp, vp, i64, i64, vp]

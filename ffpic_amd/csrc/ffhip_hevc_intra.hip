@@ -2491,3 +2491,24 @@ extern "C" int ffhip_hevc_intra_recon_tiles(const ffhip_hevc_tu *h_tus, const ff
     (void)ev_prev; /* (the chunked form's streams start behind `stream`, which the call before has joined everything into) */
     return rc;
 }
+
+/* ffhip_hevc_intra_recon_tiles + YUV420_to_BGRA32_16bit (utils/colorspace.c:628-669; hevc.c:7260-7270) of the plane set as ONE call: the tile loop
+ * of format/heif.c:297-309 with its colour conversion.  The colour kernel follows the grouped kernel on `stream` -- next to the pre-pass of the NEXT
+ * call, which runs on the library's stream.  (The BGRA written by the grouped kernel itself -- the last group to finish inside a 64x64 cell, counted
+ * over the three planes against the planner's runs per cell, converts the cell -- was built, bit-exact on every test of this entry point, and is
+ * SLOWER: tests/tools/experiments/r5_hevc_fused_colour.patch.  A cell's conversion is a dozen dependent trips to memory on ONE wave of a kernel
+ * whose throughput is its waves' latency: eight 8K pictures 3.37 ms against 2.89 with the colour kernel, four 1.69 against 1.51, one 0.64 against
+ * 0.62.  The colour kernel moves the same bytes at the HBM's rate in 0.31 ms.) */
+extern "C" int ffhip_yuv420_to_bgra_16(uint8_t *d_bgra, int pitch, const int16_t *d_y, const int16_t *d_u, const int16_t *d_v, int y_stride, int uv_stride, int ctbrows,
+                                       int ctbcols, int ctbsize, int n_images, int64_t plane_stride_y, int64_t plane_stride_uv, int64_t image_stride, void *stream);
+extern "C" int ffhip_hevc_decode_tiles(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu *d_tus, long long n_tus, const long long *tile_first, int n_tiles,
+                                       const int16_t *d_residual, int16_t *d_y, int16_t *d_cb, int16_t *d_cr, int width_y, int height_y, int y_stride,
+                                       int width_c, int height_c, int uv_stride, int bitdepth_y, int bitdepth_c, uint8_t *d_bgra, int64_t pitch, void *stream)
+{
+    if (!d_bgra || !d_cb || !d_cr || width_y <= 0 || height_y <= 0 || (width_y & 3) || (height_y & 1) || width_c != width_y / 2 || height_c != height_y / 2) return FFHIP_EINVAL;
+    if (pitch < 4LL * width_y || (pitch & 15) || ((uintptr_t)d_bgra & 15) || pitch > 0x7fffffffLL) return FFHIP_EINVAL;
+    const int rc = ffhip_hevc_intra_recon_tiles(h_tus, d_tus, n_tus, tile_first, n_tiles, d_residual, d_y, d_cb, d_cr, width_y, height_y, y_stride, width_c, height_c, uv_stride,
+                                                bitdepth_y, bitdepth_c, stream);
+    if (rc) return rc;
+    return ffhip_yuv420_to_bgra_16(d_bgra, (int)pitch, d_y, d_cb, d_cr, y_stride, uv_stride, height_y / 2, width_y / 2, 2, 1, 0, 0, 0, stream);
+}

@@ -256,6 +256,25 @@ def vp8_decode_frames(mbcols, mbrows, modes, residual, filter_type, filters, res
     return bgra, (dy.to_host((n, H, W), np.uint8), du.to_host((n, H // 2, W // 2), np.uint8), dv.to_host((n, H // 2, W // 2), np.uint8))
 
 
+def hevc_decode_tiles(tus, residual, width, height, tile_first=None, bd=8, pitch=None):
+    """ffhip_hevc_decode_tiles on a 4:2:0 plane set: intra reconstruction of the (concatenated) TU lists and the colour conversion as one call.
+    Returns (bgra uint8 [height][pitch], (Y, U, V) int16 planes)."""
+    L = capi.require_device()
+    tus = np.ascontiguousarray(tus)
+    dt, dr = DeviceBuffer(tus.view(np.uint8)), DeviceBuffer(np.ascontiguousarray(residual))
+    cw, ch = width // 2, height // 2
+    dy, du, dv = DeviceBuffer(nbytes=width * height * 2), DeviceBuffer(nbytes=cw * ch * 2), DeviceBuffer(nbytes=cw * ch * 2)
+    pitch = pitch or width * 4
+    do = DeviceBuffer(nbytes=height * pitch)
+    for d in (dy, du, dv, do):
+        capi.check(L.ffhip_memset(d.ptr, 0, d.nbytes, None))
+    tf = np.ascontiguousarray(tile_first if tile_first is not None else [0], dtype=np.int64)
+    capi.check(L.ffhip_hevc_decode_tiles(tus.ctypes.data, dt.ptr, len(tus), tf.ctypes.data, len(tf), dr.ptr, dy.ptr, du.ptr, dv.ptr, width, height, width, cw, ch, cw, bd, bd,
+                                         do.ptr, pitch, None), "ffhip_hevc_decode_tiles")
+    capi.check(L.ffhip_stream_sync(None), "ffhip_stream_sync")
+    return do.to_host((height, pitch), np.uint8), (dy.to_host((height, width), np.int16), du.to_host((ch, cw), np.int16), dv.to_host((ch, cw), np.int16))
+
+
 def hevc_intra_recon(tus, residual, width, height, chroma=True, bd_y=8, bd_c=8, csub=2):
     """decode_intra_block steps 5-10 (coding/hevc.c:4730-4790) for a TU list in decode order
     (structured array of dtype synth.HEVC_TU_DTYPE == struct ffhip_hevc_tu); planes start at 0;

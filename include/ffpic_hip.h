@@ -475,6 +475,16 @@ int ffhip_hevc_intra_recon_tiles(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu
                                  int16_t *d_cb, int16_t *d_cr, int width_y, int height_y, int y_stride, int width_c,
                                  int height_c, int uv_stride, int bitdepth_y, int bitdepth_c, void *stream);
 
+/* ffhip_hevc_intra_recon_tiles and the colour conversion of the plane set (YUV420_to_BGRA32_16bit, utils/colorspace.c:628-669, as hevc.c:7260-7270
+ * calls it) as ONE call: the tile loop of format/heif.c:297-309 with the conversion behind it.  d_bgra: pixel (x, y) of the plane set at
+ * d_bgra + y * pitch + 4 * x (width_y x height_y pixels; 4:2:0: width_c = width_y / 2, height_c = height_y / 2; width_y a multiple of 4, height_y
+ * even).  The colour kernel follows the grouped kernel on `stream`, next to the NEXT call's pre-pass on the library's stream.  One tile
+ * (n_tiles = 1, tile_first = {0}) is an ordinary picture. */
+int ffhip_hevc_decode_tiles(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu *d_tus, long long n_tus, const long long *tile_first,
+                            int n_tiles, const int16_t *d_residual, int16_t *d_y, int16_t *d_cb, int16_t *d_cr, int width_y,
+                            int height_y, int y_stride, int width_c, int height_c, int uv_stride, int bitdepth_y, int bitdepth_c,
+                            uint8_t *d_bgra, int64_t pitch, void *stream);
+
 /* ---- host-side JPEG front end and BMP sink (plain C, no GPU) ----
  * ffhip_jpeg_probe / ffhip_jpeg_entropy_decode stand where the marker loop, read_dqt,
  * read_compressed_scan and decode_data_unit stand (format/jpg.c:78-105, 255-415, 588-655,

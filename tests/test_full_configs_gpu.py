@@ -88,7 +88,7 @@ def test_4k_batches_of_the_other_layouts(h, v):
     _jpeg_full_batch(cols, rows, 64, 3, seed=4100 + 10 * h + v, h=h, v=v)
 
 
-def _intra_full_picture(W, H, tus, res, envs=({},), monkeypatch=None, sorted_by_plane=None, tile_first=None, exp=None):
+def _intra_full_picture(W, H, tus, res, envs=({},), monkeypatch=None, sorted_by_plane=None, tile_first=None, exp=None, bgra_exp=None):
     """... once per entry of `envs` (library switches for the call: the oracle's picture is worked out once).  tile_first: through
     ffhip_hevc_intra_recon_tiles (the list is the concatenation of independent tiles starting at these records)"""
     torch = pytest.importorskip("torch")
@@ -110,7 +110,11 @@ def _intra_full_picture(W, H, tus, res, envs=({},), monkeypatch=None, sorted_by_
         for rep in range(2):                               # the second call reuses the per-stream scratch and schedule buffers
             for p in (py, pu, pv):
                 p.zero_()
-            if tf is None:
+            if bgra_exp is not None:
+                out = torch.zeros((H, W * 4), dtype=torch.uint8, device=dev)
+                capi.check(L.ffhip_hevc_decode_tiles(tus.ctypes.data, dt.data_ptr(), len(tus), tf.ctypes.data, len(tf), dr.data_ptr(), py.data_ptr(), pu.data_ptr(),
+                                                     pv.data_ptr(), W, H, W, W // 2, H // 2, W // 2, 8, 8, out.data_ptr(), W * 4, st), "ffhip_hevc_decode_tiles")
+            elif tf is None:
                 capi.check(L.ffhip_hevc_intra_recon(tus.ctypes.data, dt.data_ptr(), len(tus), dr.data_ptr(), py.data_ptr(), pu.data_ptr(),
                                                     pv.data_ptr(), W, H, W, W // 2, H // 2, W // 2, 8, 8, st), "ffhip_hevc_intra_recon")
             else:
@@ -126,6 +130,11 @@ def _intra_full_picture(W, H, tus, res, envs=({},), monkeypatch=None, sorted_by_
                 if not np.array_equal(g, e):
                     ys, xs = np.nonzero(g != e)
                     raise AssertionError(f"{name} plane differs in {len(ys)} samples (pass {rep}, {env}), first at x={xs[0]} y={ys[0]}")
+            if bgra_exp is not None:
+                g = out.cpu().numpy()
+                if not np.array_equal(g, bgra_exp):
+                    ys, xs = np.nonzero(g != bgra_exp)
+                    raise AssertionError(f"BGRA differs in {len(ys)} bytes (pass {rep}, {env}), first at x={xs[0] // 4} y={ys[0]}")
         for k in env:
             monkeypatch.delenv(k)
         capi.reload_env()
@@ -203,6 +212,11 @@ def test_c5_135_tile_8k_grid(monkeypatch):
                         monkeypatch=monkeypatch, tile_first=tile_first, exp=exp)
     _intra_full_picture(T * gx, T * gy, grid_of(synth.hevc_reference_order(t0, 64, 2, 6)), np.tile(res0, K), envs=({"FFHIP_HEVC_TILE_CHUNKS": "4"},),
                         monkeypatch=monkeypatch, tile_first=tile_first, exp=exp, sorted_by_plane=True)
+    # ... and with the colour conversion in the same call (ffhip_hevc_decode_tiles)
+    from test_color_gpu import oracle_420_16
+    bgra_exp = oracle_420_16(exp[0], exp[1], exp[2], T * gy // 2, T * gx // 2, 2)
+    _intra_full_picture(T * gx, T * gy, tus, np.tile(res0, K), envs=({}, {"FFHIP_HEVC_TILE_CHUNKS": "3"}, {"FFHIP_HEVC_TILE_EARLY": "0"}),
+                        monkeypatch=monkeypatch, tile_first=tile_first, exp=exp, bgra_exp=bgra_exp)
     for i in range(1, K):
         ox, oy = (i % gx) * T, (i // gx) * T
         assert np.array_equal(exp[0][oy:oy + T, ox:ox + T], exp[0][:T, :T]), i

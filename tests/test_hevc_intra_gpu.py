@@ -392,3 +392,60 @@ def test_reference_order_takes_the_wavefront_schedule(w, h, seed, kw):
     for gp, gr, e, name in zip(got_p, got_r, exp, "YUV"):
         assert np.array_equal(gr, e), name
         assert np.array_equal(gp, e), name
+
+
+def _raster_420_list(w, h, seed):
+    """4x4 TUs of all three planes in RASTER order (no window has contiguous groups: the device planner refuses the list)"""
+    rng = np.random.default_rng(seed)
+    recs, parts, off = [], [], 0
+    for c, (pw, ph) in enumerate(((w, h), (w // 2, h // 2), (w // 2, h // 2))):
+        done = np.zeros((ph, pw), bool)
+        for y0 in range(0, ph, 4):
+            for x0 in range(0, pw, 4):
+                at = al = 0
+                for k in range(8):
+                    if y0 > 0 and x0 + k < pw and done[y0 - 1, x0 + k]:
+                        at |= 1 << k
+                    if x0 > 0 and y0 + k < ph and done[y0 + k, x0 - 1]:
+                        al |= 1 << k
+                fl = synth.TU_RESIDUAL | (synth.TU_CORNER if x0 > 0 and y0 > 0 else 0)
+                recs.append((x0, y0, 2, c, int(rng.integers(0, 35)), fl, off, 0, at, al))
+                parts.append(np.rint(rng.laplace(0, 12, size=16)).astype(np.int16))
+                off += 16
+                done[y0:y0 + 4, x0:x0 + 4] = True
+    return np.array(recs, dtype=synth.HEVC_TU_DTYPE), np.concatenate(parts)
+
+
+@pytest.mark.parametrize("w,h,seed,kw,env", [(64, 64, 1, dict(), {}), (192, 128, 2, dict(adversarial_masks=True), {}), (512, 512, 5, dict(tu_mix="c5"), {}),
+                                             (1920, 1080, 3, dict(), {}), (200, 104, 4, dict(ctb=8), {}),                                              (320, 192, 6, dict(), {"FFHIP_HEVC_PLAN": "host"}), (320, 192, 6, dict(), {"FFHIP_HEVC_INTRA_MODE": "levels"}),
+                                             (320, 192, 6, dict(), {"FFHIP_HEVC_INTRA_WINDOW": "4"}), (320, 192, 6, dict(), {"FFHIP_HEVC_TILE_EARLY": "0"}),
+                                             (256, 192, 7, dict(ctb=32), {}), (96, 48, 8, "raster", {"FFHIP_HEVC_PLAN": "device"})])
+def test_decode_tiles_emits_the_colour_cell_by_cell(w, h, seed, kw, env, monkeypatch):
+    """ffhip_hevc_decode_tiles: the planes of ffhip_hevc_intra_recon and the BGRA of YUV420_to_BGRA32_16bit over them (the oracle's restatement), for
+    pictures of any 4:2:0 size, whichever schedule the list takes (the device planner's, the host's, levels, the serial kernel of a refused list)"""
+    from test_color_gpu import oracle_420_16
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    capi.reload_env()
+    if kw == "raster":
+        tus, res = _raster_420_list(w, h, seed)
+    else:
+        tus, res = synth.hevc_intra_tus(w, h, seed, **kw)
+    exp = O.oracle_hevc_intra(tus, res, w, h, True, 8, 8)
+    want = oracle_420_16(exp[0], exp[1], exp[2], h // 2, w // 2, 2)
+    for rep in range(2):
+        bgra, planes = ops.hevc_decode_tiles(tus, res, w, h)
+        for gp, e, name in zip(planes, exp, "YUV"):
+            assert np.array_equal(gp, e), (name, rep)
+        assert np.array_equal(bgra, want), (rep, np.argwhere(bgra != want)[:4])
+    for k in env:
+        monkeypatch.delenv(k)
+    capi.reload_env()
+
+
+def test_decode_tiles_padded_pitch_and_reference_order():
+    tus, res = synth.hevc_intra_tus(384, 256, 12, tu_mix="c5")
+    ref = synth.hevc_reference_order(tus, 64, 2, 12)
+    a, _ = ops.hevc_decode_tiles(tus, res, 384, 256)
+    b, _ = ops.hevc_decode_tiles(ref, res, 384, 256, pitch=384 * 4 + 1024)
+    assert np.array_equal(b[:, :384 * 4], a) and not b[:, 384 * 4:].any()

@@ -56,3 +56,8 @@ echo "done vp8 frames"
 bash tests/tools/prof_hevc_timeline.sh > /dev/null 2>&1; cp gpurun_out/hevc_timeline/grid_8.txt $O/hevc_timeline_grid8.txt; cp gpurun_out/hevc_timeline/grid_1.txt $O/hevc_timeline_grid1.txt; cp gpurun_out/hevc_timeline/one_8k_c5.txt $O/hevc_timeline_8k_c5.txt
 echo "done timelines"
 ls -la $O | tail -40
+# the headline ALONE (bench.py --no-extra: the same K launches, no other workload of the same kernel name in the statistics)
+cd /tmp
+prof bench_headline $R/bench.py --no-extra
+grep '^{' $O/bench_headline.stdout | tail -1 > $O/bench_headline.json
+cd $R

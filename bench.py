@@ -893,6 +893,29 @@ def extra_f1(L, dev, stream, T, cpu=True, n=256):
         res["files"][tag] = row
         del d_out
         torch.cuda.empty_cache()
+        if tag == "dri_per_mcu_row":
+            # the same files four to a lane slot more: the device Huffman kernel's time is that of its LONGEST restart interval, whatever the number of
+            # intervals in flight (540 waves of 256 files leave half the SIMDs idle), so the call's throughput grows with the batch
+            n4 = 4 * n
+            ptrs4 = (vp * n4)(*([buf.ctypes.data] * n4))
+            lens4 = (C.c_size_t * n4)(*([buf.size] * n4))
+            status4 = (C.c_int * n4)()
+            d_out4 = torch.empty((n4, H, W * 4), dtype=torch.uint8, device=dev)
+
+            def files4():
+                capi.check(L.ffhip_jpeg_decode_files_device(ptrs4, lens4, n4, threads, C.byref(geom), d_out4.data_ptr(), W * 4, W * 4 * H, status4, stream), "ffhip_jpeg_decode_files_device")
+                capi.check(L.ffhip_stream_sync(stream))
+            files4()
+            b4 = 1e9
+            for _ in range(2):
+                t0 = time.perf_counter(); files4(); b4 = min(b4, time.perf_counter() - t0)
+            tt = (C.c_double * 8)()
+            L.ffhip_debug_huff_times(tt)
+            res["files"][f"{tag}_x{n4}"] = {"files": n4, "files_to_device_pixels_ms": round(b4 * 1e3, 2), "value": round(n4 * W * H / b4 / 1e6, 1), "unit": "Mpixels/s",
+                                            "files_per_s": round(n4 / b4), "k_jpeg_huff_ms": round(float(tt[6]) / 1e3, 3),
+                                            "same_pixels_as_first_file": bool(torch.equal(d_out4[0], d_out4[n4 - 1]))}
+            del d_out4
+            torch.cuda.empty_cache()
     return res
 
 

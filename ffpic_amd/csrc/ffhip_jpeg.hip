@@ -505,11 +505,18 @@ template <int H, int V, int NC, int NT>
 __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
 {
     constexpr int BPM = H * V;                            /* luma blocks per MCU          */
-    constexpr int MPS = (NC == 1 || BPM == 1) ? 8 : (BPM == 4 ? 2 : 4); /* MCUs per strip */
-    constexpr int SW = MPS * 8 * H, SH = 8 * V;          /* strip size in pixels (512)   */
+    constexpr int MPS = (NC == 1 || BPM == 1) ? 8 : (BPM == 4 ? (H == 4 ? 4 : 2) : 4); /* MCUs per strip */
+    constexpr int LR = H == 4 ? 2 : 1;                   /* luma rounds: 4:1:1 takes TWO strips' worth of luma per wave, so that its one chroma round
+                                                            (4 U + 4 V blocks) has no idle block -- 1.5 rounds per 512 pixels where the single strip took 2 */
+    constexpr int PASSES = 2 * LR;                       /* colour passes of 256 pixels */
+    constexpr int SW = MPS * 8 * H, SH = 8 * V;          /* strip size in pixels (512; 4:1:1: 1024) */
     constexpr int CW = MPS * 8;                          /* chroma samples per strip row */
     constexpr int GPR = SW / 4;                          /* 4-pixel groups per pixel row */
-    static_assert(SW * SH == 512 && BPM <= 4 && BPM != 3 && (H == 1 || V == 1), "strip geometry");
+    static_assert(SW * SH == 512 * LR && BPM <= 4 && BPM != 3 && (H == 1 || V == 1), "strip geometry");
+    /* the sample planes in the wave's LDS behind the 1 KB work tile: luma SW x SH, then U and V (8 rows of CW) */
+    constexpr int YP = SM_YP, UP = YP + SW * SH * 2, VP = UP + (H == 4 ? 512 : 1024);
+    static_assert(UP == SM_UP || H == 4, "plane offsets");
+    static_assert(VP + CW * 8 * 2 <= SM_WAVE_BYTES, "planes fit the wave's LDS");
     __shared__ __attribute__((aligned(16))) char lds_all[WAVES_PER_WG * SM_WAVE_BYTES];
     const u32 lane = threadIdx.x & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -535,11 +542,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
     const uint16_t *qt = p.quant + (long long)img * p.quant_stride;
 
     /* ---- all loads up front: ragged strips re-read their last MCU, its pixels are never stored ---- */
-    u32x4 ly, lc0, lc1;
-    {
-        int m = (int)lblk / BPM;
+    u32x4 ly[LR], lc0, lc1;
+#pragma unroll
+    for (int lr = 0; lr < LR; lr++) {
+        int m = ((int)lblk + 8 * lr) / BPM;
         m = m > rem ? rem : m;
-        ly = load16<NT & 1>((const char *)(p.coef_y + (mcu_base + m) * (64 * BPM) + ((int)lblk % BPM) * 64 + row * 8));
+        ly[lr] = load16<NT & 1>((const char *)(p.coef_y + (mcu_base + m) * (64 * BPM) + (((int)lblk + 8 * lr) % BPM) * 64 + row * 8));
     }
     const u32x4 q_y = *(const u32x4 *)(qt + p.qt_y * 64 + row * 8);
     u32x4 q_c0 = q_y, q_c1 = q_y;
@@ -567,25 +575,26 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
      * four rows a pass reads at once in four different bank quarters */
     auto yrow_pos = [](u32 r) -> u32 { return (r >> 1) + 8 * (r & 1u); };
     auto sw_off = [](u32 row, u32 col, u32 row_samples) -> u32 { /* byte offset of sample (row, col) in a swizzled plane */
-        const u32 key = row_samples == 64 ? (row & 7u) : ((row >> 2) & 3u);
+        const u32 key = row_samples >= 64 ? (row & 7u) : ((row >> 2) & 3u);
         return row * row_samples * 2 + ((((col >> 3) ^ key) & (row_samples / 8 - 1)) << 4) + (col & 7u) * 2;
     };
-    {
-        const u32x4 pk = idct8x8_round(c, ly, q_y);
-        const u32 m = c.blk / BPM, sub = c.blk % BPM;
+#pragma unroll
+    for (int lr = 0; lr < LR; lr++) {
+        const u32x4 pk = idct8x8_round(c, ly[lr], q_y);
+        const u32 gb = c.blk + 8 * lr, m = gb / BPM, sub = gb % BPM;
         const u32 pcol = (m * H + (H > 1 ? sub : 0)) * 8, prow = (V > 1 ? sub : 0) * 8 + c.idx;
-        *(u32x4 *)(c.lds + SM_YP + sw_off(V == 2 ? yrow_pos(prow) : prow, pcol, SW)) = pk;
+        *(u32x4 *)(c.lds + YP + sw_off(V == 2 ? yrow_pos(prow) : prow, pcol, SW)) = pk;
     }
     if (NC == 3) {
         if (BPM == 1) {
             const u32x4 pu = idct8x8_round(c, lc0, q_c0);
-            *(u32x4 *)(c.lds + SM_UP + sw_off(c.idx, c.blk * 8, CW)) = pu;
+            *(u32x4 *)(c.lds + UP + sw_off(c.idx, c.blk * 8, CW)) = pu;
             const u32x4 pv = idct8x8_round(c, lc1, q_c1);
-            *(u32x4 *)(c.lds + SM_VP + sw_off(c.idx, c.blk * 8, CW)) = pv;
+            *(u32x4 *)(c.lds + VP + sw_off(c.idx, c.blk * 8, CW)) = pv;
         } else {
             const u32x4 pc = idct8x8_round(c, lc0, q_c0);
             if (MPS == 4 || (c.blk & 3) < MPS) /* h*v = 4: blocks 2, 3, 6, 7 of the round are repeats of the strip's last MCU */
-                *(u32x4 *)(c.lds + (c.blk < 4 ? SM_UP : SM_VP) + sw_off(c.idx, (c.blk & 3) * 8, CW)) = pc;
+                *(u32x4 *)(c.lds + (c.blk < 4 ? UP : VP) + sw_off(c.idx, (c.blk & 3) * 8, CW)) = pc;
         }
     }
 
@@ -601,14 +610,23 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
     const u32 y_off0 = sw_off(V == 2 ? yrow_pos(row0) : row0, pc0, SW);
     /* v = 4: rows 2j and 2j + 1 share (row >> 2), i.e. the swizzle key: the next plane row, 32 bytes on */
     const u32 y_off1 = SW == 64 ? (y_off0 ^ 0x40u) + 4 * 128 : (SW == 32 ? (y_off0 ^ 0x20u) + 8 * 64 : y_off0 + 32);
-    static_assert((SW == 64 && 64 / GPR == 4 && V == 1) || (SW == 32 && V == 2) || (SW == 16 && V == 4), "pass-1 offset identities");
+    static_assert((SW == 64 && 64 / GPR == 4 && V == 1) || (SW == 32 && V == 2) || (SW == 16 && V == 4) || H == 4, "pass-1 offset identities");
+    /* 4:1:1 (128 x 8 pixels, four passes of two rows): the passes' offsets worked out one by one */
+    u32 y_offs[PASSES], c_offs[PASSES];
+#pragma unroll
+    for (int it = 0; it < PASSES; it++) {
+        y_offs[it] = H == 4 ? sw_off(row0 + 2 * it, pc0, SW) : (it ? y_off1 : y_off0);
+        c_offs[it] = 0;
+    }
     const u32 c_off0 = NC == 3 ? sw_off(row0 / V, pc0 / H, CW) : 0;
     /* v = 1: pass 1 is four rows down -- one bit of the key flips and four chroma rows (CW samples each) are skipped */
     const u32 c_off1 = V >= 2 ? c_off0 : (CW == 64 ? (c_off0 ^ 0x40u) + 4 * 128 : (c_off0 ^ 0x10u) + 4 * CW * 2);
 #pragma unroll
-    for (int it = 0; it < 2; it++) {
+    for (int it = 0; it < PASSES; it++) c_offs[it] = (H == 4 && NC == 3) ? sw_off(row0 + 2 * it, pc0 / H, CW) : (it ? c_off1 : c_off0);
+#pragma unroll
+    for (int it = 0; it < PASSES; it++) {
         const u32 prow = row0 + (V >= 2 ? it : it * (64 / GPR));
-        const u32x2 yy = *(const u32x2 *)(c.lds + SM_YP + (it ? y_off1 : y_off0));
+        const u32x2 yy = *(const u32x2 *)(c.lds + YP + y_offs[it]);
         if (V >= 2 && it == 1) {
             /* the terms of pass 0 serve this row too */
         } else if (NC == 1) {
@@ -616,17 +634,17 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
             tg2[0] = tg2[1] = __builtin_amdgcn_perm(grey_t.g, grey_t.g, 0x01000100u);
             tb2[0] = tb2[1] = __builtin_amdgcn_perm(grey_t.b, grey_t.b, 0x01000100u);
         } else {
-            const u32 c_off = it ? c_off1 : c_off0;
+            const u32 c_off = c_offs[it];
             if (H == 1) {
-                const u32x2 a = *(const u32x2 *)(c.lds + SM_UP + c_off), b = *(const u32x2 *)(c.lds + SM_VP + c_off);
+                const u32x2 a = *(const u32x2 *)(c.lds + UP + c_off), b = *(const u32x2 *)(c.lds + VP + c_off);
                 us[0] = a[0]; us[1] = a[1]; vs[0] = b[0]; vs[1] = b[1];
             } else if (H == 2) {
-                us[0] = *(const u32 *)(c.lds + SM_UP + c_off);
-                vs[0] = *(const u32 *)(c.lds + SM_VP + c_off);
+                us[0] = *(const u32 *)(c.lds + UP + c_off);
+                vs[0] = *(const u32 *)(c.lds + VP + c_off);
                 us[1] = vs[1] = 0;
             } else { /* h = 4: the lane's four pixels share one chroma sample */
-                us[0] = *(const uint16_t *)(c.lds + SM_UP + c_off);
-                vs[0] = *(const uint16_t *)(c.lds + SM_VP + c_off);
+                us[0] = *(const uint16_t *)(c.lds + UP + c_off);
+                vs[0] = *(const uint16_t *)(c.lds + VP + c_off);
                 us[1] = vs[1] = 0;
             }
             sens = 0;
@@ -936,7 +954,7 @@ extern "C" int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *g, int n_images, co
     }
 
     if (is_fused_strip(g)) {
-        const int mps = (g->ncomp == 1 || g->h * g->v == 1) ? 8 : (g->h * g->v == 4 ? 2 : 4), bpm = g->ncomp == 1 ? 1 : g->h * g->v;
+        const int mps = (g->ncomp == 1 || g->h * g->v == 1) ? 8 : (g->h * g->v == 4 ? (g->h == 4 ? 4 : 2) : 4), bpm = g->ncomp == 1 ? 1 : g->h * g->v;
         JpegBatch p = {};
         p.coef_y = d_coef_y; p.coef_u = d_coef_u; p.coef_v = d_coef_v;
         p.quant = d_quant; p.quant_stride = quant_stride;

@@ -505,17 +505,18 @@ template <int H, int V, int NC, int NT>
 __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
 {
     constexpr int BPM = H * V;                            /* luma blocks per MCU          */
-    constexpr int MPS = (NC == 1 || BPM == 1) ? 8 : (BPM == 4 ? (H == 4 ? 4 : 2) : 4); /* MCUs per strip */
-    constexpr int LR = H == 4 ? 2 : 1;                   /* luma rounds: 4:1:1 takes TWO strips' worth of luma per wave, so that its one chroma round
-                                                            (4 U + 4 V blocks) has no idle block -- 1.5 rounds per 512 pixels where the single strip took 2 */
+    constexpr int MPS = (NC == 1 || BPM == 1) ? 8 : 4;   /* MCUs per strip */
+    constexpr int LR = BPM == 4 ? 2 : 1;                 /* luma rounds: 4:1:1 and its transpose take TWO strips' worth of luma per wave (1 024 pixels), so that
+                                                            their one chroma round (4 U + 4 V blocks) has no idle block -- 1.5 rounds per 512 pixels where the
+                                                            single strip took 2 -- and the transpose's rows are runs of 128 bytes, not 64 */
     constexpr int PASSES = 2 * LR;                       /* colour passes of 256 pixels */
-    constexpr int SW = MPS * 8 * H, SH = 8 * V;          /* strip size in pixels (512; 4:1:1: 1024) */
+    constexpr int SW = MPS * 8 * H, SH = 8 * V;          /* strip size in pixels (512; h * v = 4: 1024) */
     constexpr int CW = MPS * 8;                          /* chroma samples per strip row */
     constexpr int GPR = SW / 4;                          /* 4-pixel groups per pixel row */
     static_assert(SW * SH == 512 * LR && BPM <= 4 && BPM != 3 && (H == 1 || V == 1), "strip geometry");
     /* the sample planes in the wave's LDS behind the 1 KB work tile: luma SW x SH, then U and V (8 rows of CW) */
-    constexpr int YP = SM_YP, UP = YP + SW * SH * 2, VP = UP + (H == 4 ? 512 : 1024);
-    static_assert(UP == SM_UP || H == 4, "plane offsets");
+    constexpr int YP = SM_YP, UP = YP + SW * SH * 2, VP = UP + (LR == 2 ? 512 : 1024);
+    static_assert(UP == SM_UP || LR == 2, "plane offsets");
     static_assert(VP + CW * 8 * 2 <= SM_WAVE_BYTES, "planes fit the wave's LDS");
     __shared__ __attribute__((aligned(16))) char lds_all[WAVES_PER_WG * SM_WAVE_BYTES];
     const u32 lane = threadIdx.x & 63;
@@ -610,24 +611,28 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
     const u32 y_off0 = sw_off(V == 2 ? yrow_pos(row0) : row0, pc0, SW);
     /* v = 4: rows 2j and 2j + 1 share (row >> 2), i.e. the swizzle key: the next plane row, 32 bytes on */
     const u32 y_off1 = SW == 64 ? (y_off0 ^ 0x40u) + 4 * 128 : (SW == 32 ? (y_off0 ^ 0x20u) + 8 * 64 : y_off0 + 32);
-    static_assert((SW == 64 && 64 / GPR == 4 && V == 1) || (SW == 32 && V == 2) || (SW == 16 && V == 4) || H == 4, "pass-1 offset identities");
-    /* 4:1:1 (128 x 8 pixels, four passes of two rows): the passes' offsets worked out one by one */
+    static_assert((SW == 64 && 64 / GPR == 4 && V == 1) || (SW == 32 && V == 2) || LR == 2, "pass-1 offset identities");
+    /* the pixel row of pass `it`.  h * v = 4 (four passes): 4:1:1 is 128 x 8 pixels, two rows a pass; its transpose 32 x 32, rows 2j and 2j + 1 of the upper
+     * half, then of the lower half (a lane's two rows of a half share their chroma row) */
+    auto pass_row = [&](int it) -> u32 {
+        return LR == 2 ? (H == 4 ? row0 + 2 * it : row0 + (it & 1) + 16 * (it >> 1)) : row0 + (V >= 2 ? it : it * (64 / GPR));
+    };
     u32 y_offs[PASSES], c_offs[PASSES];
 #pragma unroll
     for (int it = 0; it < PASSES; it++) {
-        y_offs[it] = H == 4 ? sw_off(row0 + 2 * it, pc0, SW) : (it ? y_off1 : y_off0);
+        y_offs[it] = LR == 2 ? sw_off(pass_row(it), pc0, SW) : (it ? y_off1 : y_off0); /* (h * v = 4: worked out pass by pass) */
         c_offs[it] = 0;
     }
     const u32 c_off0 = NC == 3 ? sw_off(row0 / V, pc0 / H, CW) : 0;
     /* v = 1: pass 1 is four rows down -- one bit of the key flips and four chroma rows (CW samples each) are skipped */
     const u32 c_off1 = V >= 2 ? c_off0 : (CW == 64 ? (c_off0 ^ 0x40u) + 4 * 128 : (c_off0 ^ 0x10u) + 4 * CW * 2);
 #pragma unroll
-    for (int it = 0; it < PASSES; it++) c_offs[it] = (H == 4 && NC == 3) ? sw_off(row0 + 2 * it, pc0 / H, CW) : (it ? c_off1 : c_off0);
+    for (int it = 0; it < PASSES; it++) c_offs[it] = (LR == 2 && NC == 3) ? sw_off(pass_row(it) / V, pc0 / H, CW) : (it ? c_off1 : c_off0);
 #pragma unroll
     for (int it = 0; it < PASSES; it++) {
-        const u32 prow = row0 + (V >= 2 ? it : it * (64 / GPR));
+        const u32 prow = pass_row(it);
         const u32x2 yy = *(const u32x2 *)(c.lds + YP + y_offs[it]);
-        if (V >= 2 && it == 1) {
+        if (V >= 2 && (it & 1)) {
             /* the terms of pass 0 serve this row too */
         } else if (NC == 1) {
             tr2[0] = tr2[1] = __builtin_amdgcn_perm(grey_t.r, grey_t.r, 0x01000100u);
@@ -954,7 +959,7 @@ extern "C" int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *g, int n_images, co
     }
 
     if (is_fused_strip(g)) {
-        const int mps = (g->ncomp == 1 || g->h * g->v == 1) ? 8 : (g->h * g->v == 4 ? (g->h == 4 ? 4 : 2) : 4), bpm = g->ncomp == 1 ? 1 : g->h * g->v;
+        const int mps = (g->ncomp == 1 || g->h * g->v == 1) ? 8 : 4, bpm = g->ncomp == 1 ? 1 : g->h * g->v;
         JpegBatch p = {};
         p.coef_y = d_coef_y; p.coef_u = d_coef_u; p.coef_v = d_coef_v;
         p.quant = d_quant; p.quant_stride = quant_stride;

@@ -489,9 +489,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg420_fused(JpegBatch p)
 /* ------------------------------------------------------------------------
  * Fused kernel for the other baseline layouts: 4:4:4 (h = v = 1), 4:2:2 (h = 2), 4:4:0 (v = 2),
  * 4:1:1 (h = 4) and its transpose (v = 4), grey.  One wave reconstructs a strip of 512 pixels -- 8 MCUs
- * of 4:4:4 / grey (64x8), 4 MCUs of 4:2:2 (64x8) or 4:4:0 (32x16), 2 MCUs of 4:1:1 (64x8) or of its
- * transpose (16x32) -- in 1-3 IDCT rounds of 8 blocks (at h*v = 4 the chroma round carries 2 U + 2 V blocks
- * and four idle ones), parks the samples as small
+ * of 4:4:4 / grey (64x8), 4 MCUs of 4:2:2 (64x8) or 4:4:0 (32x16) -- or, at h * v = 4, of 1024: 4 MCUs of 4:1:1
+ * (128x8) or of its transpose (32x32) -- in 1-3 IDCT rounds of 8 blocks (h * v = 4: two luma rounds and ONE chroma
+ * round of 4 U + 4 V blocks; with a strip of 2 MCUs, until round 5, that round carried four idle blocks and the
+ * transpose's rows were 64-byte runs: 0.69 and 0.60 of the HBM peak where the paired strips reach 0.76 and 0.72), parks
+ * the samples as small
  * int16 planes in LDS and converts 4 pixels per lane and pass with the same exact integer forms
  * as the 4:2:0 kernel (fp64 only where the G sum is an exact multiple of 1000).  Same launch shape:
  * short-lived waves, all loads up front, 16-byte non-temporal stores, XCD-contiguous workgroups.

@@ -58,17 +58,17 @@ __device__ static const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 1
  * reader feeds itself at a marker.  Why the shape below: lanes of a wave advance independently, so any
  * memory wait inside a data-dependent branch is paid by the whole wave on almost every iteration (with 64 lanes
  * SOME lane always needs bytes, SOME lane always ends a block).  Hence
- *  - bytes come from a 256-byte ring per lane in LDS ([dword][lane]: conflict-free), topped up for all lanes at
+ *  - bytes come from a 128-byte ring per lane in LDS ([dword][lane]: conflict-free; 256 bytes until round 5), topped up for all lanes at
  *    once every 16 symbols by aligned 16-byte global loads -- one memory wait per 16 iterations per wave;
  *  - the next dword of the ring is read at the top of every iteration, needed or not, and spliced into the
  *    64-bit bit buffer at the bottom: the LDS latency hides behind the symbol decode;
  *  - what changes per block only (block base, component tables, predictor) is state, not recomputed per symbol. */
 #define LUT_GROUPS 8
 #define LUT_WORDS (512 + 128 * LUT_GROUPS) /* 1536 uint16 = 3 KB per table */
-#define RING_DW 64
+#define RING_DW 32
 #define REFILL_EVERY 16
 
-__global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
+__global__ __launch_bounds__(256) void k_jpeg_huff(HuffArgs a)
 {
     __shared__ uint8_t zz[64];
     /* two-level look-up tables of the wave's FIRST picture in LDS (a wave's 64 intervals belong to one picture, rarely
@@ -77,28 +77,32 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
      * of symbols with long codes (JPEG's 16-bit codes mostly) mean the whole wave walks on nearly every symbol.
      * (A 12-bit single level does not help -- the misses ARE the 15/16-bit codes -- and costs 48 KB of LDS; the host
      * decoder's one-look-up run/value path for small AC coefficients lost for the same serialisation reason.) */
+    /* FOUR waves to a workgroup (round 5), sharing the tables: with a wave per workgroup the kernel's 38 KB of LDS per wave -- these 18 KB of tables, a
+     * 16 KB ring, 4 KB of block-change state -- allowed ONE wave per SIMD, and a batch of more than 1 024 waves (486 4K files of 135 intervals) ran in
+     * rounds: 1 024 files 32.2 ms where 256 take 12.6.  Shared tables and half the ring are 17 KB a wave: two waves per SIMD. */
     __shared__ uint16_t lt[6][LUT_WORDS];
-    __shared__ uint32_t ring[RING_DW][64];
-    const uint32_t lane = threadIdx.x;
-    zz[lane] = kZigzag[lane];
-    const uint32_t gid0 = blockIdx.x * 64;
+    __shared__ uint32_t ring[4][RING_DW][64];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x < 64) zz[threadIdx.x] = kZigzag[threadIdx.x];
+    const uint32_t gid0 = blockIdx.x * 256;
     const uint32_t img0 = a.work[gid0].x; /* gid0 < n_work: the grid is not larger than the work list */
-    {
-        const HuffImage im0 = a.images[img0];
-        for (int t = 0; t < 3; t++) {
-            const u32x4 *sd = (const u32x4 *)(a.lut + (size_t)im0.tab_dc[t] * LUT_WORDS), *sa = (const u32x4 *)(a.lut + (size_t)im0.tab_ac[t] * LUT_WORDS);
-            for (int i = lane; i < LUT_WORDS / 8; i += 64) {
-                ((u32x4 *)lt[t])[i] = sd[i];
-                ((u32x4 *)lt[3 + t])[i] = sa[i];
-            }
+    const HuffImage im0 = a.images[img0];
+    for (int t = 0; t < 3; t++) {
+        const u32x4 *sd = (const u32x4 *)(a.lut + (size_t)im0.tab_dc[t] * LUT_WORDS), *sa = (const u32x4 *)(a.lut + (size_t)im0.tab_ac[t] * LUT_WORDS);
+        for (int i = (int)threadIdx.x; i < LUT_WORDS / 8; i += 256) {
+            ((u32x4 *)lt[t])[i] = sd[i];
+            ((u32x4 *)lt[3 + t])[i] = sa[i];
         }
     }
-    __syncthreads();
-    const uint32_t gid = gid0 + lane;
+    __syncthreads(); /* (the kernel's only barrier: every wave of the workgroup reaches it, whether or not it has intervals) */
+    const uint32_t gid = gid0 + wv * 64 + lane;
     const bool exists = gid < a.n_work;
     const u32x2 w = a.work[exists ? gid : gid0];
     const HuffImage im = a.images[w.x];
-    const bool in_lds = w.x == img0;
+    /* the tables in LDS are the first interval's picture's: good for every picture that uses the SAME tables (distinct tables are uploaded once per
+     * batch and pictures refer to them by index: an encoder's defaults are one set for the whole batch) */
+    bool in_lds = true;
+    for (int t = 0; t < 3; t++) in_lds = in_lds && im.tab_dc[t] == im0.tab_dc[t] && im.tab_ac[t] == im0.tab_ac[t];
     /* this lane's byte stream: 16-byte aligned chunks from `src`, and never a byte that is not the interval's own:
      * dwords at or behind `dw_end` (the end of the interval with its zero padding = the start of the next one) read as
      * zero, as the host reader feeds itself zeros at `end`, and a lane that has taken more than the look-ahead of a
@@ -112,23 +116,23 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
     /* ---- what a block change needs, as per-lane tables in LDS, so that it is a few look-ups and not chains of
      * three-way selects: per block slot of the MCU its component, tables and block count; per component the
      * predictor and the byte address of the picture's plane ---- */
-    __shared__ uint32_t slotrec[8][64];            /* c | kb << 2 | nb_c << 5 | tix_dc << 8 | tix_ac << 20 */
-    __shared__ int predv[3][64];
-    __shared__ unsigned long long planeb[3][64];
+    __shared__ uint32_t slotrec[4][8][64];         /* c | kb << 2 | nb_c << 5 | tix_dc << 8 | tix_ac << 20 */
+    __shared__ int predv[4][3][64];
+    __shared__ unsigned long long planeb[4][3][64];
     uint32_t nbt = 0;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const unsigned long long pb = a.plane[c] ? (unsigned long long)(uintptr_t)(a.plane[c] + (size_t)w.x * im.mcus * im.nb[c] * 64) : 0ull;
-        planeb[c][lane] = pb;
-        predv[c][lane] = 0;
+        planeb[wv][c][lane] = pb;
+        predv[wv][c][lane] = 0;
         for (uint32_t kb0 = 0; kb0 < im.nb[c] && nbt < 8; kb0++)
-            slotrec[nbt++][lane] = (uint32_t)c | (kb0 << 2) | (im.nb[c] << 5) | ((im.tab_dc[c] & 0xfffu) << 8) | ((im.tab_ac[c] & 0xfffu) << 20);
+            slotrec[wv][nbt++][lane] = (uint32_t)c | (kb0 << 2) | (im.nb[c] << 5) | ((im.tab_dc[c] & 0xfffu) << 8) | ((im.tab_ac[c] & 0xfffu) << 20);
     }
     unsigned long long acc = 0; /* LEFT-aligned: next unread bit is bit 63 */
     int n = 0;
     bool active = exists && mcu < mcu_end, bad = false;
-    uint32_t slot = 0, k = 0, rec = slotrec[0][lane];
-    int16_t *blk = (int16_t *)(uintptr_t)planeb[0][lane] + (size_t)mcu * im.nb[0] * 64;
+    uint32_t slot = 0, k = 0, rec = slotrec[wv][0][lane];
+    int16_t *blk = (int16_t *)(uintptr_t)planeb[wv][0][lane] + (size_t)mcu * im.nb[0] * 64;
     int pred_cur = 0;
     auto refill = [&]() { /* all lanes: fetch 16-byte chunks while the ring has room for one */
         while (__builtin_amdgcn_ballot_w64(wr + 4 <= rd + RING_DW)) {
@@ -136,21 +140,21 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
                 u32x4 v = {0u, 0u, 0u, 0u};
                 if (wr < dw_end) v = src[wr >> 2]; /* a chunk that starts inside the interval ends inside the staged buffer */
 #pragma unroll
-                for (int j = 0; j < 4; j++) ring[(wr + j) & (RING_DW - 1)][lane] = wr + j < dw_end ? v[j] : 0u;
+                for (int j = 0; j < 4; j++) ring[wv][(wr + j) & (RING_DW - 1)][lane] = wr + j < dw_end ? v[j] : 0u;
                 wr += 4;
             }
         }
     };
     refill();
     for (int i = 0; i < 2; i++) { /* 64 bits to start with */
-        const uint32_t d = ring[rd & (RING_DW - 1)][lane];
+        const uint32_t d = ring[wv][rd & (RING_DW - 1)][lane];
         acc = (acc << 32) | __builtin_bswap32(d);
         rd++;
     }
     n = 64;
     for (uint32_t iter = 1; __builtin_amdgcn_ballot_w64(active); iter++) {
         if ((iter & (REFILL_EVERY - 1)) == 0) refill(); /* at most 16 x 31 bits = 16 dwords used since the last one */
-        const uint32_t nextdw = ring[rd & (RING_DW - 1)][lane]; /* wanted at the bottom, if at all */
+        const uint32_t nextdw = ring[wv][rd & (RING_DW - 1)][lane]; /* wanted at the bottom, if at all */
         if (active) {
             const bool dc = k == 0;
             const uint32_t c = rec & 3u;
@@ -201,11 +205,11 @@ __global__ __launch_bounds__(64) void k_jpeg_huff(HuffArgs a)
                 const bool wrap = slot == nbt;
                 slot = wrap ? 0u : slot;
                 mcu += wrap ? 1u : 0u;
-                rec = slotrec[slot][lane];
+                rec = slotrec[wv][slot][lane];
                 const uint32_t c2 = rec & 3u, nbc = (rec >> 5) & 7u, kb = (rec >> 2) & 7u;
-                predv[c][lane] = pred_cur;      /* LDS keeps program order: when c2 == c the read returns this value */
-                pred_cur = predv[c2][lane];
-                blk = (int16_t *)(uintptr_t)planeb[c2][lane] + (size_t)(mcu * nbc + kb) * 64;
+                predv[wv][c][lane] = pred_cur;      /* LDS keeps program order: when c2 == c the read returns this value */
+                pred_cur = predv[wv][c2][lane];
+                blk = (int16_t *)(uintptr_t)planeb[wv][c2][lane] + (size_t)(mcu * nbc + kb) * 64;
                 if (mcu >= mcu_end) active = false;
             }
             /* a well-formed interval ends before its padding: rd is at most two dwords ahead of the bits consumed */
@@ -491,7 +495,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     a.n_work = (uint32_t)seg_total;
     if (!g_huff_ev[0] && (hipEventCreate(&g_huff_ev[0]) != hipSuccess || hipEventCreate(&g_huff_ev[1]) != hipSuccess)) { (void)hipGetLastError(); g_huff_ev[0] = nullptr; }
     if (g_huff_ev[0]) (void)hipEventRecord(g_huff_ev[0], st);
-    hipLaunchKernelGGL(k_jpeg_huff, dim3((a.n_work + 63) / 64), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_jpeg_huff, dim3((a.n_work + 255) / 256), dim3(256), 0, st, a);
     FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
     if (g_huff_ev[0]) (void)hipEventRecord(g_huff_ev[1], st);
     /* per-picture verdicts come back with the stream (tiny); the staging buffer is free again after this sync */

@@ -106,3 +106,17 @@ def test_diagnostics_prints_change_nothing(switch, capfd):
     for a, b, c in zip(got_y, want_y, got_yh):
         assert np.array_equal(a, b) and np.array_equal(c, b)
     assert "intra_recon host:" in err and "plan:" in err
+
+
+@pytest.mark.parametrize("ring", [16, 32])
+def test_huffman_ring_sizes(ring, switch):
+    """FFHIP_HUFF_RING: the device Huffman kernel's byte ring per lane (64 bytes and a refill every 8 symbols for batches beyond what two workgroups per CU
+    hold, 128 bytes and every 16 otherwise): the same pixels from files with restart markers, with several tables, and from plain files forced onto the device"""
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    for tag in ("q85_420_dri", "q85_411", "q92_444"):
+        data = open(os.path.join(here, FILES[tag]), "rb").read()
+        switch(FFHIP_JPEG_GPU_ENTROPY=0)
+        want = ops.jpeg_decode_files_device([data] * 5, n_threads=2)[1]
+        switch(FFHIP_JPEG_GPU_ENTROPY=1, FFHIP_HUFF_RING=ring)
+        got = ops.jpeg_decode_files_device([data] * 5, n_threads=2)[1]
+        assert np.array_equal(got, want), (tag, ring)

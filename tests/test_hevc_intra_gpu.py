@@ -449,3 +449,38 @@ def test_decode_tiles_padded_pitch_and_reference_order():
     a, _ = ops.hevc_decode_tiles(tus, res, 384, 256)
     b, _ = ops.hevc_decode_tiles(ref, res, 384, 256, pitch=384 * 4 + 1024)
     assert np.array_equal(b[:, :384 * 4], a) and not b[:, 384 * 4:].any()
+
+
+def test_tile_call_refuses_a_bad_record_and_recovers():
+    """ffhip_hevc_intra_recon_tiles with one bad record in a large list: the validation kernel runs on the library's plan stream, the refusal travels through the
+    planner's result words to the grouped kernel on the caller's stream, ffhip_stream_sync says FFHIP_EINVAL once and nothing is written; the calls behind it (the
+    other scratch set, then the first again) decode the untouched list bit for bit"""
+    L = capi.require_device()
+    w, h = 3840, 2176
+    tus, res = synth.hevc_intra_tus(w, h, seed=91)
+    n = len(tus)
+    assert n >= (1 << 17) + 1000
+    exp = O.oracle_hevc_intra(tus, res, w, h, True, 8, 8)
+    dr = ops.DeviceBuffer(res)
+    dy, du, dv = ops.DeviceBuffer(nbytes=w * h * 2), ops.DeviceBuffer(nbytes=w * h // 2), ops.DeviceBuffer(nbytes=w * h // 2)
+    tf = np.zeros(1, np.int64)
+
+    def call(t):
+        dt = ops.DeviceBuffer(np.ascontiguousarray(t).view(np.uint8))
+        for d in (dy, du, dv):
+            capi.check(L.ffhip_memset(d.ptr, 0x11, d.nbytes, None))
+        capi.check(L.ffhip_stream_sync(None))
+        rc = L.ffhip_hevc_intra_recon_tiles(t.ctypes.data, dt.ptr, len(t), tf.ctypes.data, 1, dr.ptr, dy.ptr, du.ptr, dv.ptr, w, h, w, w // 2, h // 2, w // 2, 8, 8, None)
+        return rc, L.ffhip_stream_sync(None), dt
+    bad = tus.copy()
+    bad["x"][5 * 4096 + 77] = w                       # a stretch the host's sample skips: the device finds it
+    rc, rs, _ = call(bad)
+    assert (rc, rs) in ((capi.FFHIP_EINVAL, 0), (0, capi.FFHIP_EINVAL)), (rc, rs)
+    assert L.ffhip_stream_sync(None) == 0
+    assert (dy.to_host((w * h * 2,), np.uint8) == 0x11).all() and (du.to_host((w * h // 2,), np.uint8) == 0x11).all()
+    for rep in range(3):
+        rc, rs, _ = call(tus)
+        assert (rc, rs) == (0, 0), rep
+        got = (dy.to_host((h, w), np.int16), du.to_host((h // 2, w // 2), np.int16), dv.to_host((h // 2, w // 2), np.int16))
+        for a, b in zip(got, exp):
+            assert np.array_equal(a, b), rep

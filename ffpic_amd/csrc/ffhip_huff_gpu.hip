@@ -26,6 +26,7 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include <type_traits>
 
 struct HuffImage {
     uint32_t scan_off, scan_len; /* this picture's entropy-coded bytes inside `scan` */
@@ -64,6 +65,7 @@ __device__ static const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 1
  *    64-bit bit buffer at the bottom: the LDS latency hides behind the symbol decode;
  *  - what changes per block only (block base, component tables, predictor) is state, not recomputed per symbol. */
 #define LUT_GROUPS 8
+#define LUT_NO_CODE 0x5000u /* (16 << 8) | bit 14: no code starts with these bits */
 #define LUT_WORDS (512 + 128 * LUT_GROUPS) /* 1536 uint16 = 3 KB per table */
 
 template <int RING_DW, int REFILL_EVERY> /* dwords of a lane's byte ring, symbols between two refills (at most 31 bits a symbol: RING_DW >= REFILL_EVERY + 8) */
@@ -171,8 +173,9 @@ __global__ __launch_bounds__(256) void k_jpeg_huff(HuffArgs a)
                 e = l[peek];
                 if (e & 0x8000u) e = l[512 + ((e & 0xffu) << 7) + ((top >> (32 - 16)) & 127u)];
             }
-            int sym = (int)(e & 0xff), len = (int)(e >> 8);
-            if (!e) { /* a table with more long-code groups than the LUT holds, or a code that does not exist */
+            int sym = (int)(e & 0xff), len = (int)((e >> 8) & 31u);
+            bad |= (e & 0x4000u) != 0; /* no such code (LUT_NO_CODE) */
+            if (!e) { /* a table with more long-code groups than the LUT holds, or a malformed one */
                 const struct huff *T = a.tabs + tix;
                 int code = (int)peek;
                 len = LOOK;
@@ -228,6 +231,7 @@ __global__ __launch_bounds__(256) void k_jpeg_huff(HuffArgs a)
 }
 
 #define SCRATCH_HUFF 4
+#define SCRATCH_HUFF_SYNC 30
 
 namespace {
 /* One pass over a picture's entropy-coded segment: the bytes without their stuffing (FF 00 -> FF) into dst, every
@@ -237,7 +241,7 @@ namespace {
  * bytes is, in entropy-coded data): the first form, memchr + memcpy per run and a separate marker scan before it,
  * spent its time in call overhead -- 7 ms of staging per 256 4K files on 16 threads, against 12 ms of kernel.
  * May store up to 15 bytes past the clean length: the caller reserves the slack. */
-uint32_t stage_scan(uint8_t *dst, const uint8_t *src, const uint8_t *end, uint32_t *seg, uint32_t n_seg, size_t *clean_len)
+uint32_t stage_scan(uint8_t *dst, const uint8_t *src, const uint8_t *end, uint32_t *seg, uint32_t n_seg, size_t *clean_len, size_t *last_len = nullptr)
 {
     uint8_t *d = dst;
     uint32_t k = 0;
@@ -276,6 +280,7 @@ uint32_t stage_scan(uint8_t *dst, const uint8_t *src, const uint8_t *end, uint32
         const size_t len = (size_t)(d - dst) - seg[k], padded = ((len + 3) & ~(size_t)3) + 4;
         memset(d, 0, padded - len);
         d = dst + seg[k] + padded;
+        if (last_len) *last_len = len; /* the last interval's own bytes, without the padding */
     }
     *clean_len = (size_t)(d - dst);
     return k + 1;
@@ -292,6 +297,7 @@ void build_lut(const struct huff &h, uint16_t *out)
     memset(out, 0, LUT_WORDS * sizeof(uint16_t));
     memcpy(out, h.look, 512 * sizeof(uint16_t));
     int groups = 0;
+    bool complete = true;
     for (int len = LOOK + 1; len <= 16; len++) {
         if (h.maxcode[len] < 0) continue;
         for (int code = h.mincode[len]; code <= h.maxcode[len]; code++) {
@@ -300,7 +306,7 @@ void build_lut(const struct huff &h, uint16_t *out)
             const int prefix = code >> (len - LOOK);
             if (out[prefix] && !(out[prefix] & 0x8000)) return;       /* not prefix-free: leave it to the walk */
             if (!out[prefix]) {
-                if (groups == LUT_GROUPS) continue;
+                if (groups == LUT_GROUPS) { complete = false; continue; }
                 out[prefix] = (uint16_t)(0x8000 | groups++);
             }
             const int g = out[prefix] & 0xff;
@@ -308,6 +314,11 @@ void build_lut(const struct huff &h, uint16_t *out)
             for (int k = 0; k < cnt; k++) out[512 + 128 * g + rest + k] = (uint16_t)((len << 8) | h.vals[idx]);
         }
     }
+    /* every code of the table is in: what is still 0 is no code at all.  Say so in the entry (length 16, bit 14), so that a lane on damaged data -- or one
+     * of the subsequence decoder's, started at a wrong bit -- takes one look-up to find out instead of the canonical-code walk through global memory */
+    if (complete)
+        for (int i = 0; i < 512 + 128 * groups; i++)
+            if (!out[i]) out[i] = LUT_NO_CODE;
 }
 
 template <typename F>
@@ -334,12 +345,31 @@ extern "C" int ffhip_jpeg_stage_scan_test(uint8_t *dst, const uint8_t *src, size
  * and the Huffman kernel's own time by HIP events on the call's stream */
 static thread_local double g_huff_times[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 static thread_local hipEvent_t g_huff_ev[2] = {nullptr, nullptr};
+#define SYNC_PARTS 8
+static thread_local hipStream_t g_huff_up = nullptr;       /* the subsequence decoder's uploads */
+static thread_local hipEvent_t g_huff_part_ev[SYNC_PARTS];
 extern "C" int ffhip_debug_huff_times(double out[8])
 {
     if (!out) return FFHIP_EINVAL;
     for (int k = 0; k < 8; k++) out[k] = g_huff_times[k];
     return FFHIP_OK;
 }
+
+/* files without restart markers: the self-synchronising subsequence decoder at the end of this file */
+struct SyncJob {
+    uint8_t *dev;                 /* the call's device image: scan bytes, tables, look-up tables, status */
+    size_t o_tabs, o_l12, o_status;
+    int n, part;
+    const HuffImage *images;      /* scan offsets, tables and block counts as for the kernel above */
+    const uint32_t *clean_len, *raw_len; /* staged bytes with and without the zero padding */
+    int16_t *plane[3];
+    uint32_t rounds_used;         /* out: synchronisation rounds that changed something (diagnostics) */
+    uint32_t n_tasks;             /* out */
+    uint32_t rounds;              /* out: list rounds per batch of launches */
+    uint32_t sub_bits;            /* out: bits of a subsequence */
+};
+static int huff_sync_enqueue(SyncJob &job, void *stream, uint32_t **h_changed);
+static int huff_sync_finish(SyncJob &job, void *stream, uint32_t *h_changed, int *status);
 
 extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const size_t *lens, int n, int n_threads,
                                             const ffhip_jpeg_geom *geom, int16_t *d_coef_y, int16_t *d_coef_u, int16_t *d_coef_v,
@@ -358,6 +388,8 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     /* ---- host, pictures over threads: headers, tables, restart-interval starts ---- */
     std::vector<struct jpeg_hdr> hdr((size_t)n);
     std::vector<std::vector<uint32_t>> segs((size_t)n);
+    std::vector<uint32_t> clean_len((size_t)n), raw_len((size_t)n);
+    std::vector<char> has_dri((size_t)n);
     parallel_for(n, n_threads, [&](int i) {
         struct jpeg_hdr &j = hdr[(size_t)i];
         status[i] = ffhip_jpeg_parse(files[i], lens[i], &j);
@@ -368,12 +400,19 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
             status[i] = FFHIP_EINVAL; /* another geometry */
             return;
         }
-        if (!j.restart) j.restart = (int)mcus; /* no DRI: the whole scan is one interval = one lane (worth it for large batches only) */
+        has_dri[(size_t)i] = j.restart != 0;
+        if (!j.restart) j.restart = (int)mcus; /* no DRI: the whole scan is one interval (cut into subsequences by bit position further down; one lane if FFHIP_JPEG_SYNC=0) */
         /* the interval starts are found while the bytes are staged (stage_scan) */
         segs[(size_t)i].assign((size_t)((mcus + j.restart - 1) / j.restart), 0u);
     });
-    for (int i = 0; i < n; i++)
+    bool plain = true;
+    for (int i = 0; i < n; i++) {
         if (status[i]) return status[i];
+        plain = plain && !has_dri[(size_t)i];
+    }
+    /* a batch of files WITHOUT restart markers: subsequences of the scan per lane, brought into step with each other (FFHIP_JPEG_SYNC=0: one lane per file) */
+    const char *sy = FFHIP_ENV("FFHIP_JPEG_SYNC");
+    const bool use_sync = plain && !(sy && sy[0] == '0');
     const auto T1 = std::chrono::steady_clock::now();
     /* ---- layout of the one upload: scan bytes | tables | picture records | interval starts | work list | status ---- */
     std::vector<HuffImage> images((size_t)n);
@@ -433,7 +472,46 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
             FFHIP_CHECK(hipMemsetAsync(d_coef_v, 0, (size_t)n * mcus * 128, st), FFHIP_EIO);
         }
     }
-    const int n_parts = n >= 32 ? 4 : 1;
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+    /* tables, picture records, status, quantiser tables: behind the scan bytes in the image.  The files with markers send them last (the interval lists are
+     * found while staging); the subsequence decoder first, because it starts on a part of the batch as soon as that part's bytes are up */
+    long tables_us = 0;
+    auto tail_up = [&]() -> int {
+        const auto Ta = std::chrono::steady_clock::now();
+        memset(stage + scan_total, 0, 16);
+        parallel_for((int)n_tabs, n_threads, [&](int u) {
+            ((struct huff *)(stage + o_tabs))[u] = *uniq[(size_t)u];
+            build_lut(*uniq[(size_t)u], (uint16_t *)(stage + o_l12) + (size_t)u * LUT_WORDS);
+        });
+        memcpy(stage + o_img, images.data(), images.size() * sizeof(HuffImage));
+        memset(stage + o_status, 0, (size_t)n * 4);
+        tables_us = us(Ta, std::chrono::steady_clock::now());
+        FFHIP_CHECK(hipMemcpyAsync(dev + scan_total, stage + scan_total, total - scan_total, hipMemcpyHostToDevice, st), FFHIP_EIO);
+        FFHIP_CHECK(hipMemcpyAsync(d_quant, dev + o_quant, (size_t)n * 512, hipMemcpyDeviceToDevice, st), FFHIP_EIO);
+        return FFHIP_OK;
+    };
+    if (!g_huff_ev[0] && (hipEventCreate(&g_huff_ev[0]) != hipSuccess || hipEventCreate(&g_huff_ev[1]) != hipSuccess)) { (void)hipGetLastError(); g_huff_ev[0] = nullptr; }
+    int n_parts = use_sync ? (n >= 128 ? SYNC_PARTS : n >= 32 ? 4 : 1) : (n >= 32 ? 4 : 1);
+    if (use_sync) {
+        const char *e = FFHIP_ENV("FFHIP_JPEG_SYNC_PARTS"); /* parts of the batch that are staged, sent and decoded one behind the other (1..8) */
+        if (e && atoi(e) >= 1) n_parts = atoi(e) > SYNC_PARTS ? SYNC_PARTS : atoi(e);
+        if (n_parts > n) n_parts = n;
+    }
+    SyncJob jobs[SYNC_PARTS];
+    uint32_t *h_cnt[SYNC_PARTS];
+    if (use_sync) {
+        /* the parts' bytes go up on a stream of their own, the copy engine's, while the rounds of the parts before run on the caller's: 256 4K files are
+         * 8 ms of PCIe and 11 ms of kernels */
+        if (!g_huff_up) {
+            if (hipStreamCreateWithFlags(&g_huff_up, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); g_huff_up = nullptr; return FFHIP_EIO; }
+            for (int k = 0; k < SYNC_PARTS; k++)
+                if (hipEventCreateWithFlags(&g_huff_part_ev[k], hipEventDisableTiming) != hipSuccess) return FFHIP_EIO;
+        }
+        for (int i = 0; i < n; i++) memcpy(stage + o_quant + (size_t)i * 512, hdr[(size_t)i].quant, 512);
+        const int rc = tail_up();
+        if (rc) return rc;
+        if (g_huff_ev[0]) (void)hipEventRecord(g_huff_ev[0], st);
+    }
     for (int part = 0; part < n_parts; part++) {
     const int p_lo = (int)((long long)n * part / n_parts), p_hi = (int)((long long)n * (part + 1) / n_parts);
     parallel_for(p_hi - p_lo, n_threads, [&](int i_rel) {
@@ -443,9 +521,12 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         /* the picture's bytes, unstuffed, every restart interval 4-byte aligned and followed by >= 4 zero bytes */
         uint8_t *dst = stage + im.scan_off;
         std::vector<uint32_t> &sgv = segs[(size_t)i];
-        size_t off = 0;
-        if (stage_scan(dst, j.scan, j.scan + j.scan_len, sgv.data(), im.n_seg, &off) != im.n_seg) status[i] = FFHIP_EINVAL;
+        size_t off = 0, last = 0;
+        if (stage_scan(dst, j.scan, j.scan + j.scan_len, sgv.data(), im.n_seg, &off, &last) != im.n_seg) status[i] = FFHIP_EINVAL;
         memset(dst + off, 0, 16);
+        clean_len[(size_t)i] = (uint32_t)off;
+        raw_len[(size_t)i] = (uint32_t)last;
+        if (use_sync) return; /* (no interval lists; the tail of the image is on its way already) */
         uint32_t *sg = (uint32_t *)(stage + o_seg) + im.seg_base;
         u32x2 *wk = (u32x2 *)(stage + o_work) + (im.seg_base - (uint32_t)i);
         for (uint32_t k = 0; k < im.n_seg; k++) {
@@ -458,7 +539,28 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     });
     {
         const size_t b0 = images[(size_t)p_lo].scan_off, b1 = p_hi < n ? images[(size_t)p_hi].scan_off : scan_total;
-        FFHIP_CHECK(hipMemcpyAsync(dev + b0, stage + b0, b1 - b0, hipMemcpyHostToDevice, st), FFHIP_EIO);
+        if (!use_sync) {
+            FFHIP_CHECK(hipMemcpyAsync(dev + b0, stage + b0, b1 - b0, hipMemcpyHostToDevice, st), FFHIP_EIO);
+        } else {
+            SyncJob &job = jobs[part];
+            int rc = FFHIP_OK;
+            if (hipMemcpyAsync(dev + b0, stage + b0, b1 - b0, hipMemcpyHostToDevice, g_huff_up) != hipSuccess || hipEventRecord(g_huff_part_ev[part], g_huff_up) != hipSuccess ||
+                hipStreamWaitEvent(st, g_huff_part_ev[part], 0) != hipSuccess) rc = FFHIP_EIO;
+            if (!rc) {
+                job.dev = dev; job.o_tabs = o_tabs; job.o_l12 = o_l12; job.o_status = o_status + (size_t)p_lo * 4; job.n = p_hi - p_lo; job.part = part;
+                job.images = images.data() + p_lo; job.clean_len = clean_len.data() + p_lo; job.raw_len = raw_len.data() + p_lo;
+                job.plane[0] = d_coef_y + (size_t)p_lo * mcus * images[0].nb[0] * 64;
+                job.plane[1] = d_coef_u ? d_coef_u + (size_t)p_lo * mcus * images[0].nb[1] * 64 : nullptr;
+                job.plane[2] = d_coef_v ? d_coef_v + (size_t)p_lo * mcus * images[0].nb[2] * 64 : nullptr;
+                rc = huff_sync_enqueue(job, stream, &h_cnt[part]);
+            }
+            if (rc) { /* nothing of this call may be in flight when its buffers are handed back */
+                (void)hipStreamSynchronize(g_huff_up);
+                (void)hipStreamSynchronize(st);
+                (void)hipGetLastError();
+                return rc;
+            }
+        }
     }
     } /* parts */
     for (int i = 0; i < n; i++)
@@ -466,22 +568,15 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
             (void)hipStreamSynchronize(st);
             return status[i];
         }
-    memset(stage + scan_total, 0, 16);
     const auto T3 = std::chrono::steady_clock::now();
-    parallel_for((int)n_tabs, n_threads, [&](int u) {
-        ((struct huff *)(stage + o_tabs))[u] = *uniq[(size_t)u];
-        build_lut(*uniq[(size_t)u], (uint16_t *)(stage + o_l12) + (size_t)u * LUT_WORDS);
-    });
-    memcpy(stage + o_img, images.data(), images.size() * sizeof(HuffImage));
-    memset(stage + o_status, 0, (size_t)n * 4);
-    const auto T4 = std::chrono::steady_clock::now();
-    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
-    if (times) {
-        fprintf(stderr, "huff staging: header parse %ld us, layout %ld us, unstuff + markers (uploads enqueued by quarters) %ld us, tables %ld us (%d files, %zu bytes, %d threads)\n", us(T0, T1), us(T1, T2), us(T2, T3), us(T3, T4), n, total, n_threads);
+    if (!use_sync) {
+        const int rc = tail_up();
+        if (rc) return rc;
     }
-    /* the rest of the image: scan padding, tables, picture records, interval lists, status, quantiser tables */
-    FFHIP_CHECK(hipMemcpyAsync(dev + scan_total, stage + scan_total, total - scan_total, hipMemcpyHostToDevice, st), FFHIP_EIO);
-    FFHIP_CHECK(hipMemcpyAsync(d_quant, dev + o_quant, (size_t)n * 512, hipMemcpyDeviceToDevice, st), FFHIP_EIO);
+    const auto T4 = std::chrono::steady_clock::now();
+    if (times) {
+        fprintf(stderr, "huff staging: header parse %ld us, layout %ld us, unstuff + markers (uploads enqueued by parts) %ld us, tables %ld us (%d files, %zu bytes, %d threads)\n", us(T0, T1), us(T1, T2), us(T2, T3) - (use_sync ? tables_us : 0), tables_us, n, total, n_threads);
+    }
     HuffArgs a;
     a.scan = dev;
     a.tabs = (const struct huff *)(dev + o_tabs);
@@ -492,8 +587,8 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     a.plane[0] = d_coef_y; a.plane[1] = d_coef_u; a.plane[2] = d_coef_v;
     a.status = (int *)(dev + o_status);
     a.n_work = (uint32_t)seg_total;
-    if (!g_huff_ev[0] && (hipEventCreate(&g_huff_ev[0]) != hipSuccess || hipEventCreate(&g_huff_ev[1]) != hipSuccess)) { (void)hipGetLastError(); g_huff_ev[0] = nullptr; }
-    if (g_huff_ev[0]) (void)hipEventRecord(g_huff_ev[0], st);
+    if (!use_sync && g_huff_ev[0]) (void)hipEventRecord(g_huff_ev[0], st);
+    if (!use_sync)
     {   /* 128-byte rings (two workgroups of four waves per CU) while that holds the whole batch at once; 64-byte rings (three per CU, a refill every 8 symbols instead
          * of 16) beyond: 256 4K files of 135 intervals 9.9 ms against 10.4, 1 024 files 25.2 against 20.2 */
         int cus = 256, dev = 0;
@@ -515,11 +610,573 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     {
         float kms = 0.0f;
         if (!g_huff_ev[0] || hipEventElapsedTime(&kms, g_huff_ev[0], g_huff_ev[1]) != hipSuccess) { (void)hipGetLastError(); kms = 0.0f; }
-        g_huff_times[0] = (double)us(T0, T1); g_huff_times[1] = (double)us(T1, T2); g_huff_times[2] = (double)us(T2, T3); g_huff_times[3] = (double)us(T3, T4);
+        g_huff_times[0] = (double)us(T0, T1); g_huff_times[1] = (double)us(T1, T2); g_huff_times[2] = (double)(us(T2, T3) - (use_sync ? tables_us : 0)); g_huff_times[3] = (double)tables_us;
         g_huff_times[4] = (double)us(T4, T5); g_huff_times[5] = (double)us(T5, T6); g_huff_times[6] = (double)kms * 1e3; g_huff_times[7] = (double)us(T0, T6);
     }
     memcpy(status, stage + o_status, (size_t)n * 4);
+    if (use_sync)
+        for (int part = 0; part < n_parts; part++) {
+            SyncJob &job = jobs[part];
+            const int rc = huff_sync_finish(job, stream, h_cnt[part], status + (job.o_status - o_status) / 4);
+            if (rc) return rc;
+            if (times) fprintf(stderr, "huff sync, part %d: %u subsequences of %u bits, %u rounds\n", part, job.n_tasks, job.sub_bits, job.rounds_used);
+        }
     for (int i = 0; i < n; i++)
         if (status[i]) return status[i];
+    return FFHIP_OK;
+}
+
+/* =====================================================================================================================
+ * Files WITHOUT restart markers on the device (round 5): the scan cut into subsequences of `sub_bits` bits, a lane each.
+ *
+ * A baseline scan is one bit-serial stream per picture, and most files carry no DRI segment: to the kernel above such a
+ * file is one interval = one lane (1.3 s of it for a 4K picture), so until now these files went to the host threads (6-8
+ * Gpixel/s for 256 4K files on sixteen threads, the GPU idle).  Huffman-coded data SELF-SYNCHRONISES: a decoder started
+ * at a wrong bit position falls into step with the true decode after a few symbols, and one in a wrong block state --
+ * coefficient index, block slot of the MCU -- after a few blocks, MCUs at worst, because luma and chroma tables differ
+ * (the observation parallel JPEG decoders are built on: Klein & Wiseman 2003; Weissenberger & Schmidt, "Accelerating JPEG
+ * decompression on GPUs", 2021).  So:
+ *   round 0     lane t decodes subsequence t from ITS first bit with a guessed state (first block of an MCU, k = 0) and
+ *               records where and in which state it crossed into t + 1, how many blocks it completed and the sum of
+ *               the DC differences it decoded, per component;
+ *   round 1     every lane again, now from what lane t - 1 recorded;
+ *   round r     a list of the lanes whose entry is no longer what they used (the lane in front changed its exit), and
+ *               those lanes again, packed into waves: a picture's first lane always starts from the truth, so by
+ *               induction the fixed point IS the sequential decode; it is reached when a list comes out empty (a
+ *               handful of rounds; never more than the longest picture has subsequences);
+ *   scan        per picture the exclusive prefix sums of blocks and DC sums over its lanes: every lane's first block
+ *               and its DC predictors (jpg.c:255-415's running sums) there;
+ *   write       every lane decodes its subsequence once more, now storing coefficients.
+ * The host does what it does for the files with markers: headers, tables, unstuffing into pinned memory.
+ * ===================================================================================================================== */
+#define SYNC_ROUNDS_MAX 32 /* list rounds per batch of launches; FFHIP_JPEG_SYNC_ROUNDS (1..32), 12 unless set */
+
+struct SyncImage {
+    uint32_t scan_off;   /* byte offset of the picture's unstuffed scan inside `scan` (16-byte aligned) */
+    uint32_t clean_len;  /* bytes staged: the data and its zero padding                                 */
+    uint32_t data_bits;  /* bits of entropy-coded data (without the padding)                            */
+    uint32_t mcus, ncomp, nbt; /* nbt: blocks per MCU over all components                               */
+    uint32_t nb[3], tab_dc[3], tab_ac[3];
+};
+struct SyncArgs {
+    const uint8_t *scan;
+    const struct huff *tabs;
+    const uint16_t *lut;
+    const SyncImage *images;
+    const uint32_t *sub_base;    /* [n_images + 1]: first task of a picture */
+    unsigned long long *exit_;   /* per task: bit position | (slot | k << 8) << 32 where the NEXT task starts */
+    unsigned long long *used;    /* per task: the entry its exit was worked out from                           */
+    u32x4 *sums;                 /* per task: blocks completed, DC differences summed per component; after the scan their exclusive prefix sums */
+    uint32_t *list;              /* the tasks of a list round */
+    uint32_t *cnt;               /* [last + 1]: tasks in round r's list; cnt[last] == 0: the fixed point is reached */
+    uint32_t *end_pos;           /* per picture: bit position behind its last block (write pass)               */
+    int16_t *plane[3];
+    int *status;
+    uint32_t n_tasks, n_images, round, last, sub_bits;
+};
+
+__device__ __forceinline__ uint32_t sync_picture_of(const SyncArgs &a, uint32_t t)
+{ /* the last picture whose first task is <= t */
+    uint32_t lo = 0, hi = a.n_images;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.sub_base[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+/* the tasks whose entry is not what they used: round `a.round`'s list (wave-aggregated append; the order does not matter) */
+__global__ __launch_bounds__(256) void k_huff_sync_list(SyncArgs a)
+{
+    if (a.round >= 3 && a.cnt[a.round - 1] == 0) return; /* the list before was empty: so is this one */
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    bool stale = false;
+    if (t > 0 && t < a.n_tasks) {
+        const uint32_t p = sync_picture_of(a, t);
+        stale = a.sub_base[p] != t && a.exit_[t - 1] != a.used[t];
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(stale);
+    if (!m) return;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&a.cnt[a.round], (uint32_t)__builtin_popcountll(m));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (stale) a.list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = t;
+}
+
+enum { SPAN_ALL = 0, SPAN_LIST = 1, SPAN_WRITE = 2 };
+#define SPAN_THREADS 512
+#define WRITE_THREADS 256
+/* What bounds this kernel is the SIMD's vector ALU -- a wave64 instruction takes four cycles, and a symbol took some 80 of them in the first form (64-bit
+ * shifts, predictors and block addresses looked up and selected at every block change, the compiler's copies around a tangled refill loop) -- and, below
+ * that, LDS for the waves per SIMD.  So:
+ *   - the bit reader is two dwords and a shift count: the next 32 bits are ONE v_alignbit, the magnitude bits one v_bfe; a symbol takes at most 31 bits;
+ *   - EIGHT waves to a workgroup share the six look-up tables (18 KB), and nothing else is in LDS but each lane's 64-byte ring: three workgroups per CU,
+ *     six waves per SIMD; the MCU's block slots are packed words (one geometry per call), the predictors three registers that ROTATE when the component
+ *     changes (the components of an interleaved scan follow each other in a cycle);
+ *   - the ring is topped up one refill point AHEAD -- a chunk is loaded at one point and put into the ring at the next, so the wave does not wait for
+ *     the load; a point every four symbols and a chunk of four dwords each keep a full ring ahead of any stream (31 bits a symbol at most);
+ *   - a look-up table that holds every code of its Huffman table answers "no such code" itself (build_lut), so lanes decoding from a wrong entry do
+ *     not walk the canonical code through global memory. */
+template <int MODE, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_huff_span(SyncArgs a)
+{
+    constexpr bool WRITE = MODE == SPAN_WRITE;
+    constexpr int RING = 16, REFILL = 4, WAVES = THREADS / 64;
+    constexpr uint32_t LUT_BYTES = LUT_WORDS * 2;
+    __shared__ uint8_t zz[64];
+    __shared__ uint16_t lt[6][LUT_WORDS];
+    __shared__ uint32_t ring[WAVES][RING][64];
+    /* the write pass: a lane's block is put together in LDS -- its first four rows, the 64 bytes nearly all coefficients of a photograph land in -- and
+     * goes out row by row, 16 bytes a store, when the block is complete: a store of TWO bytes costs the L2 what one of sixteen does, and with nine
+     * coefficients a block that was 6 of the pass's 7.4 ms */
+    __shared__ uint32_t stage[WRITE ? 16 : 1][WRITE ? THREADS : 1]; /* [row * 4 + dword of the row][thread] */
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t i0 = blockIdx.x * THREADS;
+    uint32_t n_here = a.n_tasks;
+    if (MODE == SPAN_LIST) {
+        n_here = a.cnt[a.round];
+        if (i0 >= n_here) return;            /* (the whole workgroup) */
+    }
+    if (WRITE && a.cnt[a.last]) return;      /* the rounds launched did not reach the fixed point: the host adds rounds and launches this again */
+    if (threadIdx.x < 64) zz[threadIdx.x] = kZigzag[threadIdx.x];
+    const uint32_t t_first = MODE == SPAN_LIST ? a.list[i0] : i0;
+    const uint32_t p0 = sync_picture_of(a, t_first);
+    const SyncImage im0 = a.images[p0];
+    for (int k2 = 0; k2 < 3; k2++) {
+        const u32x4 *sd = (const u32x4 *)(a.lut + (size_t)im0.tab_dc[k2] * LUT_WORDS), *sa = (const u32x4 *)(a.lut + (size_t)im0.tab_ac[k2] * LUT_WORDS);
+        for (int i = (int)threadIdx.x; i < LUT_WORDS / 8; i += THREADS) {
+            ((u32x4 *)lt[k2])[i] = sd[i];
+            ((u32x4 *)lt[3 + k2])[i] = sa[i];
+        }
+    }
+    if (WRITE)
+        for (int i = 0; i < 16; i++) stage[i][threadIdx.x] = 0u;
+    /* the MCU's block slots, packed: component (2 bits a slot), block of the component (3 bits a slot), blocks of a component (3 bits a component) */
+    uint32_t cpack = 0, kbpack = 0, nbpack = 0;
+    {
+        uint32_t s = 0;
+        for (uint32_t c = 0; c < 3; c++) {
+            nbpack |= im0.nb[c] << (3 * c);
+            for (uint32_t kb0 = 0; kb0 < im0.nb[c] && s < 8; kb0++, s++) {
+                cpack |= c << (2 * s);
+                kbpack |= kb0 << (3 * s);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t idx = i0 + threadIdx.x;
+    const bool exists = idx < n_here;
+    const uint32_t t = exists ? (MODE == SPAN_LIST ? a.list[idx] : idx) : t_first;
+    const uint32_t p = exists ? sync_picture_of(a, t) : p0;
+    const SyncImage im = a.images[p];
+    bool in_lds = true;
+    for (int k2 = 0; k2 < 3; k2++) in_lds = in_lds && im.tab_dc[k2] == im0.tab_dc[k2] && im.tab_ac[k2] == im0.tab_ac[k2];
+    const uint32_t ti = t - a.sub_base[p];
+    const uint32_t total_bits = im.clean_len * 8u;
+    uint32_t limit = (ti + 1) * a.sub_bits;
+    limit = limit < total_bits ? limit : total_bits;
+    /* the entry: the truth for a picture's first lane, a guess in round 0, else what the lane in front recorded */
+    unsigned long long entry = 0;
+    if (ti > 0) {
+        if (WRITE) entry = a.used[t];
+        else if (a.round == 0) entry = (unsigned long long)(ti * a.sub_bits);
+        else entry = __hip_atomic_load(&a.exit_[t - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const bool fresh = !WRITE && exists && (a.round == 0 || entry != a.used[t]); /* this lane's record is to be (re)written */
+    bool active = WRITE ? exists : fresh;
+    uint32_t pos = (uint32_t)entry, slot = (uint32_t)(entry >> 32) & 0xffu, k = (uint32_t)(entry >> 40) & 0xffu;
+    if (pos >= limit) active = false; /* (an entry behind the lane's own end is handed on as it is) */
+    const uint32_t nbt = im.nbt, ncomp = im.ncomp;
+    u32x4 sm = {0u, 0u, 0u, 0u};
+    if (WRITE && exists) sm = a.sums[t]; /* first block, DC predictors */
+    slot = slot < nbt ? slot : 0;
+    k = k < 64 ? k : 0;
+    const uint32_t total_blocks = im.mcus * nbt;
+    uint32_t bidx = 0, mcu = 0, blocks = 0;
+    bool bad = false;
+    if (WRITE) {
+        bidx = sm[0];
+        mcu = bidx / nbt;
+        if (active && bidx < total_blocks && bidx - mcu * nbt != slot) { bad = true; active = false; } /* the scan and the entry disagree: not a fixed point */
+        if (bidx >= total_blocks) active = false;
+        mcu += p * im.mcus; /* from here on: the MCU's index in the whole plane */
+    }
+    /* the predictors: the current component's, the next one's in the scan's cycle, the one's after that */
+    uint32_t c = (cpack >> (2 * slot)) & 3u;
+    int pcur, pn1, pn2;
+    {
+        const int q0 = (int)sm[1], q1 = (int)sm[2], q2 = (int)sm[3];
+        pcur = c == 0 ? q0 : c == 1 ? q1 : q2;
+        pn1 = c == 0 ? q1 : c == 1 ? q2 : q0;
+        pn2 = c == 0 ? q2 : c == 1 ? q0 : q1;
+    }
+    /* the bit reader: a ring of dwords per lane in LDS, (w0, w1) the two dwords in use, sh = 32 - bits of w0 taken (0..31): the next 32 bits of the
+     * stream are ({w0, w1} >> sh) */
+    const uint32_t start = im.scan_off + ((pos >> 5) << 2);
+    const u32x4 *src = (const u32x4 *)(a.scan + (start & ~15u));
+    uint32_t rd = (start & 15u) >> 2, wr = 0;
+    const uint32_t dw_end = (im.scan_off + im.clean_len - (start & ~15u) + 3) >> 2;
+    uint32_t *const myring = &ring[wv][0][lane];
+    u32x4 pend = {0u, 0u, 0u, 0u};
+    bool has_pend = false;
+    auto issue = [&]() { /* (a lane with room for a chunk; behind the picture's bytes: zeros) */
+        pend = u32x4{0u, 0u, 0u, 0u};
+        if (wr < dw_end) pend = src[wr >> 2];
+        has_pend = true;
+    };
+    auto commit = [&]() { /* (a lane with a chunk on its way; wr is a multiple of 4) */
+        uint32_t *d = myring + (wr & (RING - 1)) * 64;
+        d[0] = pend[0]; d[64] = pend[1]; d[128] = pend[2]; d[192] = pend[3];
+        wr += 4;
+        has_pend = false;
+    };
+    while (__builtin_amdgcn_ballot_w64(wr + 4 <= rd + RING)) /* to start with: the ring full */
+        if (wr + 4 <= rd + RING) { issue(); commit(); }
+    uint32_t w0 = 0, w1;
+    int sh;
+    {
+        const uint32_t b = pos & 31u;
+        if (b) { w0 = __builtin_bswap32(myring[(rd & (RING - 1)) * 64]); rd++; }
+        w1 = __builtin_bswap32(myring[(rd & (RING - 1)) * 64]);
+        rd++;
+        sh = b ? 32 - (int)b : 0;
+    }
+    int16_t *blk = nullptr;
+    auto block_of = [&]() -> int16_t * {
+        const uint32_t nbc = (nbpack >> (3 * c)) & 7u, kb = (kbpack >> (3 * slot)) & 7u;
+        int16_t *base = c == 0 ? a.plane[0] : c == 1 ? a.plane[1] : a.plane[2];
+        return base + (size_t)(mcu * nbc + kb) * 64;
+    };
+    if (WRITE) blk = block_of();
+    uint32_t tb_dc = c * LUT_BYTES; /* byte offset of the component's DC table in lt; its AC table 3 tables on */
+    /* write pass: coefficients of the block in LDS (bit per coefficient), and whether the block is one to put together there: a block that began in the
+     * lane in front, or ends in the lane behind, shares its rows with that lane and goes out coefficient by coefficient */
+    uint32_t cmask = 0;
+    bool staged = k == 0;
+    auto flush_rows = [&]() { /* the complete block's non-zero rows, 16 bytes each */
+#pragma unroll
+        for (int row = 0; row < 4; row++)
+            if (cmask & (0xffu << (8 * row))) {
+                u32x4 q;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { q[j] = stage[row * 4 + j][threadIdx.x]; stage[row * 4 + j][threadIdx.x] = 0u; }
+                *(u32x4 *)(blk + 8 * row) = q;
+            }
+        cmask = 0;
+    };
+    /* The loop is a plain divergent one -- a lane leaves when its subsequence is done -- and it comes in two copies: one for waves whose lanes all find
+     * their tables in LDS (all but those that straddle two pictures with different tables), one with the look-ups in global memory beside it.  The only
+     * global load in flight across iterations of the first is the ring's chunk: the counter waits the compiler has to place where a value MAY come from
+     * memory would otherwise wait for that chunk at every symbol.  (Hence also the explicit waits at the end of the rare branches that do load.) */
+    __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0): everything loaded so far is there, as far as the waits inside the loop are concerned */
+    auto run = [&](auto lds_only) {
+        constexpr bool LDS_ONLY = decltype(lds_only)::value;
+        uint32_t iter = 1;
+        while (active) {
+            if ((iter & (REFILL - 1)) == 0) {
+                if (has_pend) commit();
+                if (wr + 4 <= rd + RING) issue();
+            }
+            iter++;
+            const uint32_t nextdw = myring[(rd & (RING - 1)) * 64];
+            const uint32_t W = __builtin_amdgcn_alignbit(w0, w1, (uint32_t)sh);
+            const bool dc = k == 0;
+            unsigned e;
+            if (LDS_ONLY || in_lds) {
+                const uint16_t *l = (const uint16_t *)((const uint8_t *)lt + tb_dc + (dc ? 0u : 3u * LUT_BYTES));
+                e = l[W >> (32 - LOOK)];
+                if (e & 0x8000u) e = l[512 + ((e & 0xffu) << 7) + ((W >> 16) & 127u)];
+            } else {
+                const uint32_t tix = dc ? (c == 0 ? im.tab_dc[0] : c == 1 ? im.tab_dc[1] : im.tab_dc[2]) : (c == 0 ? im.tab_ac[0] : c == 1 ? im.tab_ac[1] : im.tab_ac[2]);
+                const uint16_t *l = a.lut + (size_t)tix * LUT_WORDS;
+                e = l[W >> (32 - LOOK)];
+                if (e & 0x8000u) e = l[512 + ((e & 0xffu) << 7) + ((W >> 16) & 127u)];
+            }
+            uint32_t sym = e & 0xffu, len = (e >> 8) & 31u;
+            if (WRITE) bad |= (e & 0x4000u) != 0; /* "no such code", from a table that holds all there are */
+            if (!e) { /* a code the two-level table does not hold: the canonical code, length by length */
+                const uint32_t tix = dc ? (c == 0 ? im.tab_dc[0] : c == 1 ? im.tab_dc[1] : im.tab_dc[2]) : (c == 0 ? im.tab_ac[0] : c == 1 ? im.tab_ac[1] : im.tab_ac[2]);
+                const struct huff *T = a.tabs + tix;
+                int code = (int)(W >> (32 - LOOK)), ln = LOOK;
+                while (ln < 17 && code > T->maxcode[ln]) {
+                    ln++;
+                    code = (int)(W >> (32 - ln));
+                }
+                if (ln > 16) { bad = bad || WRITE; ln = 16; code = T->mincode[16]; }
+                sym = T->vals[(T->valptr[ln] + code - T->mincode[ln]) & 255];
+                len = (uint32_t)ln;
+                __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0) here, not behind the branch */
+            }
+            const uint32_t s = sym & 15u, r = dc ? 0u : sym >> 4;
+            const bool skip = !dc && s == 0;
+            const uint32_t used = len + s;                                        /* at most 31 */
+            const uint32_t vb = __builtin_amdgcn_ubfe(W, 32u - used, s);          /* the s bits behind the code; none: 0 */
+            const uint32_t m1 = (1u << s) - 1u;
+            const int v = (vb << 1) > m1 ? (int)vb : (int)vb - (int)m1;          /* EXTEND, T.81 F.2.2.1 */
+            pcur += dc ? v : 0; /* the predictor is a running sum: relative to the lane's start until the scan, absolute in the write pass */
+            k += skip ? (r == 15 ? 16u : 64u) : r;
+            if (WRITE) {
+                bad |= (dc && sym > 11) || (!skip && k > 63);
+                if (!skip && k <= 63) {
+                    const uint32_t nat = zz[k];
+                    const int16_t val = (int16_t)(dc ? pcur : v);
+                    if (staged && nat < 32) { /* (a block this lane has from its first coefficient on) */
+                        ((int16_t *)&stage[nat >> 1][threadIdx.x])[nat & 1u] = val;
+                        cmask |= 1u << nat;
+                    } else blk[nat] = val;
+                }
+            }
+            k += skip ? 0u : 1u;
+            pos += used;
+            sh -= (int)used;
+            if (sh < 0) { /* w0 is used up */
+                w0 = w1;
+                w1 = __builtin_bswap32(nextdw);
+                sh += 32;
+                rd++;
+            }
+            if (k >= 64) { /* next block: the MCU's next slot, or the next MCU */
+                k = 0;
+                blocks++;
+                slot++;
+                const bool wrap = slot == nbt;
+                slot = wrap ? 0u : slot;
+                const uint32_t c2 = (cpack >> (2 * slot)) & 3u;
+                if (c2 != c) { const int q = pcur; pcur = pn1; pn1 = ncomp == 3 ? pn2 : q; pn2 = q; } /* (two components: they alternate) */
+                c = c2;
+                tb_dc = c * LUT_BYTES;
+                if (WRITE) {
+                    flush_rows();
+                    staged = true;
+                    bidx++;
+                    mcu += wrap ? 1u : 0u;
+                    blk = block_of();
+                    if (bidx >= total_blocks) { active = false; a.end_pos[p] = pos; } /* the picture's last block */
+                }
+            }
+            if (pos >= limit || bad) active = false;
+        }
+    };
+    if (__builtin_amdgcn_ballot_w64(!in_lds) == 0) run(std::true_type{});
+    else run(std::false_type{});
+    if (WRITE) {
+        while (cmask) { /* the block goes on in the lane behind: its coefficients one by one, as that lane stores them */
+            const uint32_t nat = (uint32_t)__builtin_ctz(cmask);
+            cmask &= cmask - 1u;
+            blk[nat] = ((const int16_t *)&stage[nat >> 1][threadIdx.x])[nat & 1u];
+        }
+        if (bad) a.status[p] = FFHIP_EINVAL;
+        return;
+    }
+    if (fresh) {
+        const int q0 = c == 0 ? pcur : c == 1 ? pn2 : pn1, q1 = c == 0 ? pn1 : c == 1 ? pcur : pn2, q2 = c == 0 ? pn2 : c == 1 ? pn1 : pcur;
+        const unsigned long long ex = (unsigned long long)pos | ((unsigned long long)(slot | (k << 8)) << 32);
+        __hip_atomic_store(&a.exit_[t], ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.used[t] = entry;
+        u32x4 o;
+        o[0] = blocks; o[1] = (uint32_t)q0; o[2] = (uint32_t)q1; o[3] = (uint32_t)q2;
+        a.sums[t] = o;
+    }
+}
+
+/* per picture: exclusive prefix sums over its tasks of the blocks completed and of the DC differences per component -- every task's first block and DC
+ * predictors; one workgroup per picture.  A picture whose tasks hold fewer blocks than it has is truncated or damaged. */
+__global__ __launch_bounds__(256) void k_huff_sync_scan(SyncArgs a)
+{
+    __shared__ u32x4 wsum[4];
+    const uint32_t p = blockIdx.x;
+    if (a.cnt[a.last]) return;
+    const SyncImage im = a.images[p];
+    const uint32_t t0 = a.sub_base[p], t1 = a.sub_base[p + 1];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    u32x4 carry = {0u, 0u, 0u, 0u};
+    for (uint32_t base = t0; base < t1; base += 256) {
+        const uint32_t t = base + threadIdx.x;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (t < t1) v = a.sums[t];
+        u32x4 inc = v; /* shuffle scan inside the wave (wrapping uint32 adds: the DC sums are two's complement), the waves' totals through LDS */
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t u = (uint32_t)__shfl_up((int)inc[q], o, 64);
+                if (lane >= o) inc[q] += u;
+            }
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        u32x4 before = carry, total = {0u, 0u, 0u, 0u};
+        for (int q = 0; q < 4; q++) {
+            if (q < w) before += wsum[q];
+            total += wsum[q];
+        }
+        if (t < t1) a.sums[t] = before + inc - v;
+        carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && carry[0] < im.mcus * im.nbt) a.status[p] = FFHIP_EINVAL;
+}
+
+/* behind the write pass: a picture whose last block ends behind its data has taken bits from the padding -- truncated (the host decoder's rule,
+ * ffhip_entropy.c: bytes fed behind the end are look-ahead only); one that never reached its last block left end_pos at ~0 */
+__global__ __launch_bounds__(256) void k_huff_sync_verdict(SyncArgs a)
+{
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (a.cnt[a.last] || p >= a.n_images) return;
+    if (a.end_pos[p] > a.images[p].data_bits) a.status[p] = FFHIP_EINVAL;
+}
+
+namespace {
+struct SyncLayout { size_t o_img, o_sub, o_cnt, o_end, o_list, o_sums, o_exit, o_used, words; };
+SyncLayout sync_layout(size_t n, size_t tasks)
+{
+    SyncLayout L;
+    size_t w = 0;
+    auto take = [&](size_t words) { const size_t at = w; w += (words + 3) & ~(size_t)3; return at; };
+    L.o_img = take(n * sizeof(SyncImage) / 4);
+    L.o_sub = take(n + 1);
+    L.o_cnt = take(SYNC_ROUNDS_MAX + 3);
+    L.o_end = take(n);
+    L.o_list = take(tasks);
+    L.o_sums = take(4 * tasks);
+    L.o_exit = take(2 * tasks);
+    L.o_used = take(2 * tasks);
+    L.words = w;
+    return L;
+}
+void sync_args(SyncArgs &a, const SyncJob &job, uint32_t *d, const SyncLayout &L)
+{
+    a.scan = job.dev;
+    a.tabs = (const struct huff *)(job.dev + job.o_tabs);
+    a.lut = (const uint16_t *)(job.dev + job.o_l12);
+    a.images = (const SyncImage *)(d + L.o_img);
+    a.sub_base = d + L.o_sub;
+    a.exit_ = (unsigned long long *)(d + L.o_exit);
+    a.used = (unsigned long long *)(d + L.o_used);
+    a.sums = (u32x4 *)(d + L.o_sums);
+    a.list = d + L.o_list;
+    a.cnt = d + L.o_cnt;
+    a.end_pos = d + L.o_end;
+    for (int c = 0; c < 3; c++) a.plane[c] = job.plane[c];
+    a.status = (int *)(job.dev + job.o_status);
+    a.n_tasks = job.n_tasks;
+    a.n_images = (uint32_t)job.n;
+    a.round = 0;
+    a.last = job.rounds + 2;
+    a.sub_bits = job.sub_bits;
+}
+uint32_t sync_tasks_of(uint32_t raw_len, uint32_t sub_bits)
+{
+    const uint64_t bits = (uint64_t)raw_len * 8;
+    return bits ? (uint32_t)((bits + sub_bits - 1) / sub_bits) : 1u;
+}
+/* list rounds 2 .. rounds + 1, the list of round rounds + 2 (empty: the fixed point), then the passes that need it */
+int sync_launch_rounds_and_passes(SyncArgs &a, const SyncJob &job, hipStream_t st)
+{
+    const unsigned wgs = (job.n_tasks + SPAN_THREADS - 1) / SPAN_THREADS, wgl = (job.n_tasks + 255) / 256;
+    for (uint32_t r = 2; r <= job.rounds + 2; r++) {
+        a.round = r;
+        hipLaunchKernelGGL(k_huff_sync_list, dim3(wgl), dim3(256), 0, st, a);
+        if (r < job.rounds + 2) hipLaunchKernelGGL((k_huff_span<SPAN_LIST, SPAN_THREADS>), dim3(wgs), dim3(SPAN_THREADS), 0, st, a);
+    }
+    hipLaunchKernelGGL(k_huff_sync_scan, dim3((unsigned)job.n), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_huff_span<SPAN_WRITE, WRITE_THREADS>), dim3((job.n_tasks + WRITE_THREADS - 1) / WRITE_THREADS), dim3(WRITE_THREADS), 0, st, a);
+    hipLaunchKernelGGL(k_huff_sync_verdict, dim3(((unsigned)job.n + 255) / 256), dim3(256), 0, st, a);
+    FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
+    return FFHIP_OK;
+}
+} // namespace
+
+/* everything of the subsequence decoder on the call's stream: picture records up, rounds, scan, write pass, the rounds' verdict back */
+static int huff_sync_enqueue(SyncJob &job, void *stream, uint32_t **h_cnt)
+{
+    static_assert(sizeof(SyncImage) % 4 == 0, "SyncImage is copied by words");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)job.n;
+    {
+        const char *e = FFHIP_ENV("FFHIP_JPEG_SYNC_ROUNDS");
+        const int r = e ? atoi(e) : 12;
+        job.rounds = (uint32_t)(r < 1 ? 1 : r > SYNC_ROUNDS_MAX ? SYNC_ROUNDS_MAX : r);
+        const char *b = FFHIP_ENV("FFHIP_JPEG_SYNC_BITS"); /* bits of a subsequence */
+        const int sb = b ? atoi(b) : 1024;
+        job.sub_bits = (uint32_t)(sb < 128 ? 128 : sb > 65536 ? 65536 : sb);
+    }
+    uint64_t tasks = 0;
+    for (size_t i = 0; i < n; i++) tasks += sync_tasks_of(job.raw_len[i], job.sub_bits);
+    if (tasks > 0x7fffff00u) return FFHIP_EINVAL;
+    const SyncLayout L = sync_layout(n, (size_t)tasks);
+    const size_t head = L.o_list; /* words the host fills: picture records, first tasks, list counts, end positions */
+    uint8_t *pin = ffhip_pinned_scratch(SCRATCH_HUFF_SYNC + job.part, stream, (head + SYNC_ROUNDS_MAX + 3) * 4);
+    uint32_t *d = ffhip_scratch(SCRATCH_HUFF_SYNC + job.part, stream, L.words);
+    if (!pin || !d) return FFHIP_ENOMEM;
+    uint32_t *h = (uint32_t *)pin;
+    SyncImage *si = (SyncImage *)(h + L.o_img);
+    uint32_t t = 0;
+    for (size_t i = 0; i < n; i++) {
+        const HuffImage &im = job.images[i];
+        SyncImage &s = si[i];
+        s.scan_off = im.scan_off;
+        s.clean_len = job.clean_len[i];
+        s.data_bits = job.raw_len[i] * 8u;
+        s.mcus = im.mcus;
+        s.ncomp = im.ncomp;
+        s.nbt = 0;
+        for (int c = 0; c < 3; c++) { s.nb[c] = im.nb[c]; s.tab_dc[c] = im.tab_dc[c]; s.tab_ac[c] = im.tab_ac[c]; s.nbt += im.nb[c]; }
+        if (s.nb[0] != si[0].nb[0] || s.nb[1] != si[0].nb[1] || s.nb[2] != si[0].nb[2]) return FFHIP_EINVAL; /* (one geometry per call: the kernels keep one record of the MCU's blocks) */
+        h[L.o_sub + i] = t;
+        t += sync_tasks_of(job.raw_len[i], job.sub_bits);
+    }
+    h[L.o_sub + n] = t;
+    job.n_tasks = t;
+    memset(h + L.o_cnt, 0, (L.o_end - L.o_cnt) * 4);
+    memset(h + L.o_end, 0xff, (L.o_list - L.o_end) * 4);
+    FFHIP_CHECK(hipMemcpyAsync(d, h, head * 4, hipMemcpyHostToDevice, st), FFHIP_EIO);
+    SyncArgs a;
+    sync_args(a, job, d, L);
+    const unsigned wgs = (t + SPAN_THREADS - 1) / SPAN_THREADS;
+    for (uint32_t r = 0; r < 2; r++) {
+        a.round = r;
+        hipLaunchKernelGGL((k_huff_span<SPAN_ALL, SPAN_THREADS>), dim3(wgs), dim3(SPAN_THREADS), 0, st, a);
+    }
+    const int rc = sync_launch_rounds_and_passes(a, job, st);
+    if (rc) return rc;
+    *h_cnt = h + head;
+    FFHIP_CHECK(hipMemcpyAsync(*h_cnt, d + L.o_cnt, (SYNC_ROUNDS_MAX + 3) * 4, hipMemcpyDeviceToHost, st), FFHIP_EIO);
+    return FFHIP_OK;
+}
+
+/* behind the stream's sync.  The rounds reached their fixed point: nothing to do.  They did not (a scan built so that a wrong start stays wrong over many
+ * subsequences -- no encoder's output): further rounds until they do, at most as many as the longest picture has subsequences, then the passes again. */
+static int huff_sync_finish(SyncJob &job, void *stream, uint32_t *h_cnt, int *status)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t last = job.rounds + 2;
+    job.rounds_used = 2;
+    for (uint32_t r = 2; r < last; r++) job.rounds_used += h_cnt[r] ? 1u : 0u;
+    if (!h_cnt[last]) return FFHIP_OK;
+    const size_t n = (size_t)job.n;
+    const SyncLayout L = sync_layout(n, job.n_tasks);
+    uint32_t *d = ffhip_scratch(SCRATCH_HUFF_SYNC + job.part, stream, L.words);
+    if (!d) return FFHIP_ENOMEM;
+    SyncArgs a;
+    sync_args(a, job, d, L);
+    uint32_t longest = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t ti = sync_tasks_of(job.raw_len[i], job.sub_bits);
+        longest = ti > longest ? ti : longest;
+    }
+    for (uint32_t done = last;; done += job.rounds) {
+        if (done > longest + last) return FFHIP_EIO; /* (cannot happen: lane t is final after round t) */
+        memset(h_cnt, 0, (SYNC_ROUNDS_MAX + 3) * 4);
+        FFHIP_CHECK(hipMemcpyAsync(d + L.o_cnt, h_cnt, (SYNC_ROUNDS_MAX + 3) * 4, hipMemcpyHostToDevice, st), FFHIP_EIO);
+        const int rc = sync_launch_rounds_and_passes(a, job, st); /* (the passes look at the last list themselves) */
+        if (rc) return rc;
+        FFHIP_CHECK(hipMemcpyAsync(h_cnt, d + L.o_cnt, (SYNC_ROUNDS_MAX + 3) * 4, hipMemcpyDeviceToHost, st), FFHIP_EIO);
+        FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO);
+        for (uint32_t r = 2; r < last; r++) job.rounds_used += h_cnt[r] ? 1u : 0u;
+        if (!h_cnt[last]) break;
+    }
+    FFHIP_CHECK(hipMemcpy(status, job.dev + job.o_status, n * 4, hipMemcpyDeviceToHost), FFHIP_EIO);
     return FFHIP_OK;
 }

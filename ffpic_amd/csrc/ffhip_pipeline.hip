@@ -136,8 +136,10 @@ extern "C" int ffhip_jpeg_decode_files(const uint8_t *const *files, const size_t
      * Its latency per batch is that of ONE restart interval, so it wants large chunks */
     const char *ge = FFHIP_ENV("FFHIP_JPEG_GPU_ENTROPY");
     bool gpu_entropy = !(ge && ge[0] == '0');
-    if (gpu_entropy && !(ge && ge[0] == '1')) /* "1" forces it; default: restart markers, or enough files to give every lane one */
-        gpu_entropy = ffhip_jpeg_probe_restart(files[0], lens[0]) > 0 || n >= 1024;
+    if (gpu_entropy && !(ge && ge[0] == '1')) { /* "1" forces it; default: always, unless files without restart markers are to be one lane each (FFHIP_JPEG_SYNC=0) */
+        const char *sy = FFHIP_ENV("FFHIP_JPEG_SYNC");
+        gpu_entropy = !(sy && sy[0] == '0') || ffhip_jpeg_probe_restart(files[0], lens[0]) > 0 || n >= 1024;
+    }
     if (chunk <= 0) chunk = gpu_entropy ? 32 : 8;
     if (chunk > n) chunk = n;
     const size_t mcus = (size_t)g.mcu_cols * g.mcu_rows;
@@ -237,7 +239,8 @@ extern "C" int ffhip_jpeg_decode_files_device(const uint8_t *const *files, const
     const size_t yb = mcus * g.h * g.v * 64, cb = g.ncomp == 3 ? mcus * 64 : 0; /* int16 elements per picture */
     hipStream_t st = (hipStream_t)stream;
     const char *ge = FFHIP_ENV("FFHIP_JPEG_GPU_ENTROPY");
-    if (!(ge && ge[0] == '0') && ((ge && ge[0] == '1') || ffhip_jpeg_probe_restart(files[0], lens[0]) > 0 || n >= 1024)) {
+    const char *sy = FFHIP_ENV("FFHIP_JPEG_SYNC"); /* =0: files without restart markers are one lane each on the device, worth it from a thousand files only */
+    if (!(ge && ge[0] == '0') && ((ge && ge[0] == '1') || !(sy && sy[0] == '0') || ffhip_jpeg_probe_restart(files[0], lens[0]) > 0 || n >= 1024)) {
         /* entropy decode on the device, a lane per restart interval, straight into planes in library scratch; one reconstruction launch behind it */
         const size_t words = ((size_t)n * (yb + 2 * cb) * 2 + (size_t)n * 512 + 64) / 4 + 16;
         uint8_t *base = (uint8_t *)ffhip_scratch(SCRATCH_FILES_DEV, stream, words);

@@ -29,10 +29,49 @@ def test_dri_fixture():
     same_planes([data] * 5)
 
 
-def test_files_without_restart_markers_take_one_lane_each():
-    for name in ("file_q85_420.jpg", "file_q92_444.jpg", "file_q80_grey.jpg"):
+def test_files_without_restart_markers():
+    """no DRI: the scan is cut into 1024-bit subsequences, a lane each, that synchronise with each other (round 5)"""
+    for name in ("file_q85_420.jpg", "file_q92_444.jpg", "file_q80_grey.jpg", "file_q85_411.jpg", "file_q85_114.jpg", "file_q88_422.jpg"):
         data = open(os.path.join(GOLDEN, name), "rb").read()
+        same_planes([data])
         same_planes([data] * 3)
+
+
+def _plain_file(size, q, sub=2, mode="RGB", seed=0, noise=25.0, optimize=False):
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:size[0], 0:size[1]]
+    img = np.stack([128 + 100 * np.sin(xx / (9.0 + seed)), 128 + 90 * np.cos(yy / 7.0), (xx * 3 + yy * 5) % 256], axis=2)
+    img = np.clip(img + rng.normal(0, noise, img.shape), 0, 255).astype(np.uint8)
+    bio = io.BytesIO()
+    kw = dict(quality=q, optimize=optimize)
+    if mode == "RGB":
+        kw["subsampling"] = sub
+    PIL.fromarray(img).convert(mode).save(bio, "JPEG", **kw)
+    data = bio.getvalue()
+    assert b"\xff\xdd" not in data
+    return data
+
+
+@pytest.mark.parametrize("size,q,sub,mode,noise,optimize", [
+    ((200, 296), 90, 2, "RGB", 25.0, False),      # a few dozen subsequences
+    ((1080, 1920), 85, 2, "RGB", 25.0, False),    # thousands, several workgroups per picture
+    ((1080, 1920), 100, 0, "RGB", 40.0, False),   # long codes and magnitudes: few symbols per subsequence
+    ((1080, 1920), 20, 2, "RGB", 0.0, False),     # smooth at low quality: whole rows of blocks inside one subsequence
+    ((600, 808), 75, 1, "RGB", 25.0, True),       # 4:2:2, the file's own optimised tables (a set per file)
+    ((600, 808), 85, 0, "L", 25.0, True),         # one component
+    ((8, 8), 90, 2, "RGB", 25.0, False),          # one MCU: less than one subsequence
+])
+def test_generated_files_without_restart_markers(size, q, sub, mode, noise, optimize):
+    files = [_plain_file(size, q, sub, mode, seed=i, noise=noise, optimize=optimize) for i in range(3)]
+    same_planes(files)
+    same_planes(files[1:2])
+
+
+def test_many_small_plain_files_share_workgroups():
+    """pictures of a few subsequences each: a workgroup's 256 lanes span many pictures, with the tables of the first in LDS"""
+    files = [_plain_file((48, 64), 60 + (i % 5) * 8, seed=i, optimize=bool(i & 1)) for i in range(40)]
+    same_planes(files)
 
 
 def test_other_geometry_is_refused():

@@ -120,3 +120,21 @@ def test_huffman_ring_sizes(ring, switch):
         switch(FFHIP_JPEG_GPU_ENTROPY=1, FFHIP_HUFF_RING=ring)
         got = ops.jpeg_decode_files_device([data] * 5, n_threads=2)[1]
         assert np.array_equal(got, want), (tag, ring)
+
+
+def test_plain_files_one_lane_each_and_few_rounds(switch):
+    """FFHIP_JPEG_SYNC=0: a file without restart markers is one lane's (round 4's form, for batches of thousands); FFHIP_JPEG_SYNC_ROUNDS: the
+    list rounds are launched one (two) at a time, the host looks whether they reached their fixed point and launches more -- the path a scan takes that does
+    not settle within the twelve rounds launched at once; FFHIP_JPEG_SYNC_BITS: the length of a subsequence, 128 bits (a few symbols, hardly ever in step
+    after one) to the whole scan in one"""
+    from test_huff_gpu import _plain_file, same_planes
+    files = [_plain_file((360, 640), 85, seed=i) for i in range(3)]
+    want = ops.jpeg_entropy_batch_gpu(files)
+    for env in ({"FFHIP_JPEG_SYNC": 0}, {"FFHIP_JPEG_SYNC_ROUNDS": 1}, {"FFHIP_JPEG_SYNC_ROUNDS": 2}, {"FFHIP_JPEG_SYNC_ROUNDS": 32}, {"FFHIP_JPEG_SYNC_BITS": 128},
+                {"FFHIP_JPEG_SYNC_BITS": 128, "FFHIP_JPEG_SYNC_ROUNDS": 1}, {"FFHIP_JPEG_SYNC_BITS": 4096}, {"FFHIP_JPEG_SYNC_BITS": 65536}):
+        switch(**env)
+        got = ops.jpeg_entropy_batch_gpu(files)
+        for a, b in zip(got[1:], want[1:]):
+            assert np.array_equal(a, b), env
+        same_planes(files)
+        switch(FFHIP_JPEG_SYNC=1, FFHIP_JPEG_SYNC_ROUNDS=12, FFHIP_JPEG_SYNC_BITS=1024)

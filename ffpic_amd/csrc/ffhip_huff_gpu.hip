@@ -346,6 +346,7 @@ extern "C" int ffhip_jpeg_stage_scan_test(uint8_t *dst, const uint8_t *src, size
 static thread_local double g_huff_times[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 static thread_local hipEvent_t g_huff_ev[2] = {nullptr, nullptr};
 #define SYNC_PARTS 8
+thread_local FfhipHuffThen g_ffhip_huff_then = {0, nullptr, 0, 0};
 static thread_local hipStream_t g_huff_up = nullptr;       /* the subsequence decoder's uploads */
 static thread_local hipEvent_t g_huff_part_ev[SYNC_PARTS];
 extern "C" int ffhip_debug_huff_times(double out[8])
@@ -365,6 +366,7 @@ struct SyncJob {
     int16_t *plane[3];
     uint32_t rounds_used;         /* out: synchronisation rounds that changed something (diagnostics) */
     uint32_t n_tasks;             /* out */
+    int reran;                    /* out: the rounds launched at first did not do; the passes ran from huff_sync_finish */
     uint32_t rounds;              /* out: list rounds per batch of launches */
     uint32_t sub_bits;            /* out: bits of a subsequence */
 };
@@ -375,6 +377,8 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
                                             const ffhip_jpeg_geom *geom, int16_t *d_coef_y, int16_t *d_coef_u, int16_t *d_coef_v,
                                             uint16_t *d_quant, int *status, void *stream)
 {
+    const FfhipHuffThen then = g_ffhip_huff_then;
+    g_ffhip_huff_then.on = 0;
     if (n < 0 || !geom || (n > 0 && (!files || !lens || !d_coef_y || !d_quant || !status))) return FFHIP_EINVAL;
     if (n == 0) return FFHIP_OK;
     if (geom->ncomp == 3 && (!d_coef_u || !d_coef_v)) return FFHIP_EINVAL;
@@ -491,7 +495,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         return FFHIP_OK;
     };
     if (!g_huff_ev[0] && (hipEventCreate(&g_huff_ev[0]) != hipSuccess || hipEventCreate(&g_huff_ev[1]) != hipSuccess)) { (void)hipGetLastError(); g_huff_ev[0] = nullptr; }
-    int n_parts = use_sync ? (n >= 128 ? SYNC_PARTS : n >= 32 ? 4 : 1) : (n >= 32 ? 4 : 1);
+    int n_parts = n >= 32 ? 4 : 1;
     if (use_sync) {
         const char *e = FFHIP_ENV("FFHIP_JPEG_SYNC_PARTS"); /* parts of the batch that are staged, sent and decoded one behind the other (1..8) */
         if (e && atoi(e) >= 1) n_parts = atoi(e) > SYNC_PARTS ? SYNC_PARTS : atoi(e);
@@ -512,8 +516,15 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         if (rc) return rc;
         if (g_huff_ev[0]) (void)hipEventRecord(g_huff_ev[0], st);
     }
+    /* the subsequence decoder's parts of a large batch: a small one first, so that the uploads start early, and a small one last, whose kernels are what is
+     * left to wait for when the last byte is up; the uploads in between run back to back */
+    const bool graded = use_sync && n_parts == 4 && n >= 128 && !FFHIP_ENV("FFHIP_JPEG_SYNC_PARTS");
+    auto part_lo = [&](int part) -> int {
+        static const int eighths[5] = {0, 1, 4, 7, 8};
+        return graded ? (int)((long long)n * eighths[part] / 8) : (int)((long long)n * part / n_parts);
+    };
     for (int part = 0; part < n_parts; part++) {
-    const int p_lo = (int)((long long)n * part / n_parts), p_hi = (int)((long long)n * (part + 1) / n_parts);
+    const int p_lo = part_lo(part), p_hi = part_lo(part + 1);
     parallel_for(p_hi - p_lo, n_threads, [&](int i_rel) {
         const int i = p_lo + i_rel;
         const struct jpeg_hdr &j = hdr[(size_t)i];
@@ -553,6 +564,9 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
                 job.plane[1] = d_coef_u ? d_coef_u + (size_t)p_lo * mcus * images[0].nb[1] * 64 : nullptr;
                 job.plane[2] = d_coef_v ? d_coef_v + (size_t)p_lo * mcus * images[0].nb[2] * 64 : nullptr;
                 rc = huff_sync_enqueue(job, stream, &h_cnt[part]);
+                if (!rc && then.on) /* the part's pictures: coefficients -> BGRA while the next part's bytes come up */
+                    rc = ffhip_jpeg_recon_batch(geom, p_hi - p_lo, job.plane[0], job.plane[1], job.plane[2], d_quant + (size_t)p_lo * 256, 256,
+                                                then.bgra + (int64_t)p_lo * then.image_stride, then.pitch, then.image_stride, nullptr, 0, stream);
             }
             if (rc) { /* nothing of this call may be in flight when its buffers are handed back */
                 (void)hipStreamSynchronize(g_huff_up);
@@ -600,6 +614,10 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     }
     FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
     if (g_huff_ev[0]) (void)hipEventRecord(g_huff_ev[1], st);
+    if (!use_sync && then.on) {
+        const int rc = ffhip_jpeg_recon_batch(geom, n, d_coef_y, d_coef_u, d_coef_v, d_quant, 256, then.bgra, then.pitch, then.image_stride, nullptr, 0, stream);
+        if (rc) return rc;
+    }
     /* per-picture verdicts come back with the stream (tiny); the staging buffer is free again after this sync */
     FFHIP_CHECK(hipMemcpyAsync(stage + o_status, dev + o_status, (size_t)n * 4, hipMemcpyDeviceToHost, st), FFHIP_EIO);
     const auto T5 = std::chrono::steady_clock::now();
@@ -617,7 +635,11 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     if (use_sync)
         for (int part = 0; part < n_parts; part++) {
             SyncJob &job = jobs[part];
-            const int rc = huff_sync_finish(job, stream, h_cnt[part], status + (job.o_status - o_status) / 4);
+            const int p_lo = (int)((job.o_status - o_status) / 4);
+            int rc = huff_sync_finish(job, stream, h_cnt[part], status + p_lo);
+            if (!rc && job.reran && then.on) /* the part's passes ran only now: so must its reconstruction */
+                rc = ffhip_jpeg_recon_batch(geom, job.n, job.plane[0], job.plane[1], job.plane[2], d_quant + (size_t)p_lo * 256, 256,
+                                            then.bgra + (int64_t)p_lo * then.image_stride, then.pitch, then.image_stride, nullptr, 0, stream);
             if (rc) return rc;
             if (times) fprintf(stderr, "huff sync, part %d: %u subsequences of %u bits, %u rounds\n", part, job.n_tasks, job.sub_bits, job.rounds_used);
         }
@@ -649,7 +671,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
  *   write       every lane decodes its subsequence once more, now storing coefficients.
  * The host does what it does for the files with markers: headers, tables, unstuffing into pinned memory.
  * ===================================================================================================================== */
-#define SYNC_ROUNDS_MAX 32 /* list rounds per batch of launches; FFHIP_JPEG_SYNC_ROUNDS (1..32), 12 unless set */
+#define SYNC_ROUNDS_MAX 32 /* list rounds per batch of launches; FFHIP_JPEG_SYNC_ROUNDS (1..32), 6 unless set */
 
 struct SyncImage {
     uint32_t scan_off;   /* byte offset of the picture's unstuffed scan inside `scan` (16-byte aligned) */
@@ -1096,10 +1118,10 @@ static int huff_sync_enqueue(SyncJob &job, void *stream, uint32_t **h_cnt)
     const size_t n = (size_t)job.n;
     {
         const char *e = FFHIP_ENV("FFHIP_JPEG_SYNC_ROUNDS");
-        const int r = e ? atoi(e) : 12;
+        const int r = e ? atoi(e) : 6;
         job.rounds = (uint32_t)(r < 1 ? 1 : r > SYNC_ROUNDS_MAX ? SYNC_ROUNDS_MAX : r);
         const char *b = FFHIP_ENV("FFHIP_JPEG_SYNC_BITS"); /* bits of a subsequence */
-        const int sb = b ? atoi(b) : 1024;
+        const int sb = b ? atoi(b) : 2048;
         job.sub_bits = (uint32_t)(sb < 128 ? 128 : sb > 65536 ? 65536 : sb);
     }
     uint64_t tasks = 0;
@@ -1153,6 +1175,7 @@ static int huff_sync_finish(SyncJob &job, void *stream, uint32_t *h_cnt, int *st
     hipStream_t st = (hipStream_t)stream;
     const uint32_t last = job.rounds + 2;
     job.rounds_used = 2;
+    job.reran = 0;
     for (uint32_t r = 2; r < last; r++) job.rounds_used += h_cnt[r] ? 1u : 0u;
     if (!h_cnt[last]) return FFHIP_OK;
     const size_t n = (size_t)job.n;
@@ -1178,5 +1201,6 @@ static int huff_sync_finish(SyncJob &job, void *stream, uint32_t *h_cnt, int *st
         if (!h_cnt[last]) break;
     }
     FFHIP_CHECK(hipMemcpy(status, job.dev + job.o_status, n * 4, hipMemcpyDeviceToHost), FFHIP_EIO);
+    job.reran = 1;
     return FFHIP_OK;
 }

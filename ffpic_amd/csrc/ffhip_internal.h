@@ -91,6 +91,11 @@ extern thread_local FfhipVp8Fusion g_ffhip_vp8_fusion;
 struct FfhipVp8Then { int on; uint8_t *bgra; int pitch; int64_t image_stride; };
 extern thread_local FfhipVp8Then g_ffhip_vp8_then;
 
+/* ffhip_jpeg_decode_files_device -> ffhip_jpeg_entropy_batch_gpu: the reconstruction of the pictures, enqueued by the entropy call itself behind each
+ * part of the batch it has decoded (consumed, i.e. switched off, by the callee) */
+struct FfhipHuffThen { int on; uint8_t *bgra; int64_t pitch, image_stride; };
+extern thread_local FfhipHuffThen g_ffhip_huff_then;
+
 /* the calling thread's side stream with its fork / join events (ffhip_vp8_lf.hip: one set per thread and device, released by ffhip_shutdown) */
 struct FfhipSide { void *stream, *fork, *join, *mid, *aux; }; /* mid: a second point of the main stream the side stream may wait for; aux: a second
                                                                 point of the side stream the main stream may wait for */

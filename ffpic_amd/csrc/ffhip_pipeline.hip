@@ -247,8 +247,11 @@ extern "C" int ffhip_jpeg_decode_files_device(const uint8_t *const *files, const
         if (!base) return FFHIP_ENOMEM;
         int16_t *dy = (int16_t *)base, *du = cb ? dy + (size_t)n * yb : nullptr, *dv = cb ? du + (size_t)n * cb : nullptr;
         uint16_t *dq = (uint16_t *)(base + (((size_t)n * (yb + 2 * cb) * 2 + 15) & ~(size_t)15));
+        /* (the reconstruction is enqueued by the entropy call itself, behind each part of the batch as it is decoded) */
+        g_ffhip_huff_then.on = 1; g_ffhip_huff_then.bgra = d_bgra; g_ffhip_huff_then.pitch = pitch; g_ffhip_huff_then.image_stride = image_stride;
         rc = ffhip_jpeg_entropy_batch_gpu(files, lens, n, n_threads, &g, dy, du, dv, dq, status, stream);
-        if (rc == FFHIP_OK) return ffhip_jpeg_recon_batch(&g, n, dy, du, dv, dq, 256, d_bgra, pitch, image_stride, nullptr, 0, stream);
+        g_ffhip_huff_then.on = 0;
+        if (rc == FFHIP_OK) return FFHIP_OK;
         if (rc != FFHIP_EINVAL) return rc;
     }
     /* Host threads (files without restart markers are one interval each: a lane per FILE only pays from a thousand files on).  A pipeline of

@@ -752,7 +752,7 @@ __global__ __launch_bounds__(THREADS) void k_huff_span(SyncArgs a)
     /* the write pass: a lane's block is put together in LDS -- its first four rows, the 64 bytes nearly all coefficients of a photograph land in -- and
      * goes out row by row, 16 bytes a store, when the block is complete: a store of TWO bytes costs the L2 what one of sixteen does, and with nine
      * coefficients a block that was 6 of the pass's 7.4 ms */
-    __shared__ uint32_t stage[WRITE ? 16 : 1][WRITE ? THREADS : 1]; /* [row * 4 + dword of the row][thread] */
+    __shared__ u32x4 stage[WRITE ? 4 : 1][WRITE ? THREADS : 1]; /* [row][thread]: the row's eight coefficients, one 16-byte LDS access to take out and clear */
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t i0 = blockIdx.x * THREADS;
     uint32_t n_here = a.n_tasks;
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(THREADS) void k_huff_span(SyncArgs a)
         }
     }
     if (WRITE)
-        for (int i = 0; i < 16; i++) stage[i][threadIdx.x] = 0u;
+        for (int i = 0; i < 4; i++) stage[i][threadIdx.x] = u32x4{0u, 0u, 0u, 0u};
     /* the MCU's block slots, packed: component (2 bits a slot), block of the component (3 bits a slot), blocks of a component (3 bits a component) */
     uint32_t cpack = 0, kbpack = 0, nbpack = 0;
     {
@@ -880,9 +880,8 @@ __global__ __launch_bounds__(THREADS) void k_huff_span(SyncArgs a)
 #pragma unroll
         for (int row = 0; row < 4; row++)
             if (cmask & (0xffu << (8 * row))) {
-                u32x4 q;
-#pragma unroll
-                for (int j = 0; j < 4; j++) { q[j] = stage[row * 4 + j][threadIdx.x]; stage[row * 4 + j][threadIdx.x] = 0u; }
+                const u32x4 q = stage[row][threadIdx.x];
+                stage[row][threadIdx.x] = u32x4{0u, 0u, 0u, 0u};
                 *(u32x4 *)(blk + 8 * row) = q;
             }
         cmask = 0;
@@ -944,7 +943,7 @@ __global__ __launch_bounds__(THREADS) void k_huff_span(SyncArgs a)
                     const uint32_t nat = zz[k];
                     const int16_t val = (int16_t)(dc ? pcur : v);
                     if (staged && nat < 32) { /* (a block this lane has from its first coefficient on) */
-                        ((int16_t *)&stage[nat >> 1][threadIdx.x])[nat & 1u] = val;
+                        ((int16_t *)&stage[nat >> 3][threadIdx.x])[nat & 7u] = val;
                         cmask |= 1u << nat;
                     } else blk[nat] = val;
                 }
@@ -986,7 +985,7 @@ __global__ __launch_bounds__(THREADS) void k_huff_span(SyncArgs a)
         while (cmask) { /* the block goes on in the lane behind: its coefficients one by one, as that lane stores them */
             const uint32_t nat = (uint32_t)__builtin_ctz(cmask);
             cmask &= cmask - 1u;
-            blk[nat] = ((const int16_t *)&stage[nat >> 1][threadIdx.x])[nat & 1u];
+            blk[nat] = ((const int16_t *)&stage[nat >> 3][threadIdx.x])[nat & 7u];
         }
         if (bad) a.status[p] = FFHIP_EINVAL;
         return;

@@ -1,4 +1,7 @@
 set -u
-for b in 1024 2048 4096; do for parts in 8 4 2; do
-  echo "bits $b parts $parts: $(FFHIP_JPEG_SYNC_PARTS=$parts FFHIP_JPEG_SYNC_BITS=$b python3 tests/tools/bench_huff_plain.py 2>&1 | tail -1)"
-done; done
+R=$PWD
+python3 -m pytest tests/test_huff_gpu.py -x -q -m gpu 2>&1 | tail -2
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/rp_hp
+FFHIP_JPEG_SYNC_PARTS=1 rocprofv3 --kernel-trace -d /tmp/rp_hp -o hp --output-format csv -- python3 $R/tests/tools/bench_huff_plain.py > /dev/null 2>&1
+python3 $R/tests/tools/kernel_timeline.py /tmp/rp_hp "k_huff_span<0" k_huff_sync_verdict 2 | grep "span<2"

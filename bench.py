@@ -802,7 +802,8 @@ def extra_f1(L, dev, stream, T, cpu=True, n=256):
     """SURVEY 8f row f1, the step in front of the hot path: baseline JPEG FILES in, BGRA in device memory out (ffhip_jpeg_decode_files_device: the
     marker loop, read_dqt, read_compressed_scan / decode_data_unit of format/jpg.c:78-105, 255-415, 588-637 and coding/huffman.c:92-222, then the
     fused reconstruction) on `n` 4K files -- with restart markers (one interval per MCU row: the Huffman decode runs on the device, a lane per
-    interval) and without (host threads) --, the device Huffman stage alone (ffhip_jpeg_entropy_batch_gpu) with its phases, and the reference's own
+    interval) and without (on the device as well: a lane per 2048-bit subsequence of the scan, synchronised over rounds) --, the device Huffman stage
+    alone (ffhip_jpeg_entropy_batch_gpu) with its phases, and the reference's own
     JPG_load on the same file as the CPU baseline.  Wall-clock figures: host code and PCIe are part of this row."""
     import hashlib, io, tempfile
     from PIL import Image
@@ -815,7 +816,7 @@ def extra_f1(L, dev, stream, T, cpu=True, n=256):
     vp = C.c_void_p
     threads = max(1, min(os.cpu_count() or 1, 16))
     res = {"workload": f"{n} x {W}x{H} baseline 4:2:0 JPEG files (PIL, quality 85; the same file {n} times) -> BGRA in device memory; wall clock of the calls, "
-                       f"{threads} host threads for header parsing / staging / host entropy", "files": {}}
+                       f"{threads} host threads for header parsing / staging", "files": {}}
     geom = capi.JpegGeom()
     for tag, kw in (("dri_per_mcu_row", dict(restart_marker_rows=1)), ("no_dri", dict())):
         bio = io.BytesIO()
@@ -840,7 +841,7 @@ def extra_f1(L, dev, stream, T, cpu=True, n=256):
         sha_gpu = hashlib.sha256(px0.tobytes()).hexdigest()
         sha_gpu_m = hashlib.sha256(px0[:H - 16].tobytes() + px0[H - 16:, :(W - 16) * 4].tobytes()).hexdigest()
         del px0
-        if tag == "dri_per_mcu_row":
+        if True:
             # the device Huffman stage alone, with its phases (ffhip_debug_huff_times), and the reconstruction of its planes alone
             g = geom
             yb, cb = g.mcu_cols * g.mcu_rows * 4 * 64, g.mcu_cols * g.mcu_rows * 64
@@ -867,9 +868,17 @@ def extra_f1(L, dev, stream, T, cpu=True, n=256):
                                         "phases_ms": {"header_parse": round(ph[0] / 1e3, 2), "layout": round(ph[1] / 1e3, 2), "unstuff_and_markers_with_uploads_enqueued": round(ph[2] / 1e3, 2),
                                                       "tables": round(ph[3] / 1e3, 2), "enqueue": round(ph[4] / 1e3, 2), "wait_uploads_clears_kernel": round(ph[5] / 1e3, 2)},
                                         "k_jpeg_huff_ms": round(ph[6] / 1e3, 3), "k_jpeg_huff_compressed_GB/s": round(n * len(data) / (ph[6] / 1e6) / 1e9, 1) if ph[6] else None}
+            if tag == "no_dri":
+                # no single kernel here: the batch goes in parts -- bytes up on a copy stream, two rounds over all subsequences, list rounds, scan, write pass --
+                # and the events bracket all of it, the uploads it waits for included
+                e = row["entropy_batch_gpu"]
+                e["device_pipeline_ms"] = e.pop("k_jpeg_huff_ms")
+                e.pop("k_jpeg_huff_compressed_GB/s")
+                e["form"] = "subsequences of 2048 bits a lane, synchronised over rounds (ffhip_huff_gpu.hip, k_huff_span); profiles/r5_huff_plain_timeline.txt has the kernels of one call"
             row["reconstruction_ms"] = round(rms, 3)
-            row["share_of_the_call"] = {"host_staging": round((ph[0] + ph[1] + ph[2] + ph[3]) / 1e3 / (best * 1e3), 3), "device_huffman_kernel": round(ph[6] / 1e3 / (best * 1e3), 3),
-                                        "reconstruction": round(rms / (best * 1e3), 3)}
+            if tag == "dri_per_mcu_row":
+                row["share_of_the_call"] = {"host_staging": round((ph[0] + ph[1] + ph[2] + ph[3]) / 1e3 / (best * 1e3), 3), "device_huffman_kernel": round(ph[6] / 1e3 / (best * 1e3), 3),
+                                            "reconstruction": round(rms / (best * 1e3), 3)}
             del d_y, d_u, d_v, d_q
         if cpu:
             O = oracle_lib()
@@ -893,9 +902,10 @@ def extra_f1(L, dev, stream, T, cpu=True, n=256):
         res["files"][tag] = row
         del d_out
         torch.cuda.empty_cache()
-        if tag == "dri_per_mcu_row":
-            # the same files four to a lane slot more: the device Huffman kernel's time is that of its LONGEST restart interval, whatever the number of
-            # intervals in flight (540 waves of 256 files leave half the SIMDs idle), so the call's throughput grows with the batch
+        if True:
+            # four times the files.  With restart markers: the device Huffman kernel's time is that of its LONGEST restart interval, whatever the number of
+            # intervals in flight (540 waves of 256 files leave half the SIMDs idle), so the call's throughput grows with the batch.  Without: the parts are
+            # larger, the uploads (PCIe) and the kernels overlap over a longer stretch
             n4 = 4 * n
             ptrs4 = (vp * n4)(*([buf.ctypes.data] * n4))
             lens4 = (C.c_size_t * n4)(*([buf.size] * n4))
@@ -912,7 +922,7 @@ def extra_f1(L, dev, stream, T, cpu=True, n=256):
             tt = (C.c_double * 8)()
             L.ffhip_debug_huff_times(tt)
             res["files"][f"{tag}_x{n4}"] = {"files": n4, "files_to_device_pixels_ms": round(b4 * 1e3, 2), "value": round(n4 * W * H / b4 / 1e6, 1), "unit": "Mpixels/s",
-                                            "files_per_s": round(n4 / b4), "k_jpeg_huff_ms": round(float(tt[6]) / 1e3, 3),
+                                            "files_per_s": round(n4 / b4), ("k_jpeg_huff_ms" if tag == "dri_per_mcu_row" else "device_pipeline_ms"): round(float(tt[6]) / 1e3, 3),
                                             "same_pixels_as_first_file": bool(torch.equal(d_out4[0], d_out4[n4 - 1]))}
             del d_out4
             torch.cuda.empty_cache()

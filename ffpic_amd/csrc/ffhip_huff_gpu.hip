@@ -241,7 +241,7 @@ namespace {
  * bytes is, in entropy-coded data): the first form, memchr + memcpy per run and a separate marker scan before it,
  * spent its time in call overhead -- 7 ms of staging per 256 4K files on 16 threads, against 12 ms of kernel.
  * May store up to 15 bytes past the clean length: the caller reserves the slack. */
-uint32_t stage_scan(uint8_t *dst, const uint8_t *src, const uint8_t *end, uint32_t *seg, uint32_t n_seg, size_t *clean_len, size_t *last_len = nullptr)
+uint32_t stage_scan(uint8_t *dst, const uint8_t *src, const uint8_t *end, uint32_t *seg, uint32_t n_seg, size_t *clean_len, uint32_t *raw = nullptr)
 {
     uint8_t *d = dst;
     uint32_t k = 0;
@@ -272,6 +272,7 @@ uint32_t stage_scan(uint8_t *dst, const uint8_t *src, const uint8_t *end, uint32
             const size_t len = (size_t)(d - dst) - seg[k], padded = ((len + 3) & ~(size_t)3) + 4;
             memset(d, 0, padded - len);
             d = dst + seg[k] + padded;
+            if (raw) raw[k] = (uint32_t)len; /* the interval's own bytes, without the padding */
             seg[++k] = (uint32_t)(d - dst);
             src += 2;
         }
@@ -280,7 +281,7 @@ uint32_t stage_scan(uint8_t *dst, const uint8_t *src, const uint8_t *end, uint32
         const size_t len = (size_t)(d - dst) - seg[k], padded = ((len + 3) & ~(size_t)3) + 4;
         memset(d, 0, padded - len);
         d = dst + seg[k] + padded;
-        if (last_len) *last_len = len; /* the last interval's own bytes, without the padding */
+        if (raw) raw[k] = (uint32_t)len;
     }
     *clean_len = (size_t)(d - dst);
     return k + 1;
@@ -357,12 +358,19 @@ extern "C" int ffhip_debug_huff_times(double out[8])
 }
 
 /* files without restart markers: the self-synchronising subsequence decoder at the end of this file */
+struct SyncSeg { /* a restart interval of a picture of the part (a file without restart markers: its whole scan) */
+    uint32_t pic;                 /* picture of the part */
+    uint32_t scan_off, clean_len; /* in the call's device image; staged bytes with the zero padding */
+    uint32_t raw_len;             /* the interval's own bytes */
+    uint32_t mcu0, mcus;          /* first MCU (counted over the part's pictures) and MCUs of the interval */
+};
 struct SyncJob {
     uint8_t *dev;                 /* the call's device image: scan bytes, tables, look-up tables, status */
     size_t o_tabs, o_l12, o_status;
-    int n, part;
-    const HuffImage *images;      /* scan offsets, tables and block counts as for the kernel above */
-    const uint32_t *clean_len, *raw_len; /* staged bytes with and without the zero padding */
+    int n, part;                  /* pictures of the part */
+    const HuffImage *images;      /* tables and block counts as for the kernel above */
+    const SyncSeg *segs;
+    size_t n_segs;
     int16_t *plane[3];
     uint32_t rounds_used;         /* out: synchronisation rounds that changed something (diagnostics) */
     uint32_t n_tasks;             /* out */
@@ -370,8 +378,8 @@ struct SyncJob {
     uint32_t rounds;              /* out: list rounds per batch of launches */
     uint32_t sub_bits;            /* out: bits of a subsequence */
 };
-static int huff_sync_enqueue(SyncJob &job, void *stream, uint32_t **h_changed);
-static int huff_sync_finish(SyncJob &job, void *stream, uint32_t *h_changed, int *status);
+static int huff_sync_enqueue(SyncJob &job, void *stream, uint32_t **h_cnt);
+static int huff_sync_finish(SyncJob &job, void *stream, uint32_t *h_cnt, int *status);
 
 extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const size_t *lens, int n, int n_threads,
                                             const ffhip_jpeg_geom *geom, int16_t *d_coef_y, int16_t *d_coef_u, int16_t *d_coef_v,
@@ -392,8 +400,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     /* ---- host, pictures over threads: headers, tables, restart-interval starts ---- */
     std::vector<struct jpeg_hdr> hdr((size_t)n);
     std::vector<std::vector<uint32_t>> segs((size_t)n);
-    std::vector<uint32_t> clean_len((size_t)n), raw_len((size_t)n);
-    std::vector<char> has_dri((size_t)n);
+    std::vector<std::vector<uint32_t>> raws((size_t)n); /* per picture: its intervals' own lengths */
     parallel_for(n, n_threads, [&](int i) {
         struct jpeg_hdr &j = hdr[(size_t)i];
         status[i] = ffhip_jpeg_parse(files[i], lens[i], &j);
@@ -404,19 +411,17 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
             status[i] = FFHIP_EINVAL; /* another geometry */
             return;
         }
-        has_dri[(size_t)i] = j.restart != 0;
-        if (!j.restart) j.restart = (int)mcus; /* no DRI: the whole scan is one interval (cut into subsequences by bit position further down; one lane if FFHIP_JPEG_SYNC=0) */
+        if (!j.restart) j.restart = (int)mcus; /* no DRI: the whole scan is one interval */
         /* the interval starts are found while the bytes are staged (stage_scan) */
-        segs[(size_t)i].assign((size_t)((mcus + j.restart - 1) / j.restart), 0u);
+        segs[(size_t)i].assign((size_t)((mcus + j.restart - 1) / j.restart) + 1, 0u); /* (one more: the end of the last) */
+        raws[(size_t)i].assign(segs[(size_t)i].size(), 0u);
     });
-    bool plain = true;
-    for (int i = 0; i < n; i++) {
+    for (int i = 0; i < n; i++)
         if (status[i]) return status[i];
-        plain = plain && !has_dri[(size_t)i];
-    }
-    /* a batch of files WITHOUT restart markers: subsequences of the scan per lane, brought into step with each other (FFHIP_JPEG_SYNC=0: one lane per file) */
+    /* the subsequence decoder: a lane per 2048 bits of a restart interval (of the whole scan, in a file without restart markers), brought into step with
+     * each other over rounds.  FFHIP_JPEG_SYNC=0: the kernel above, a lane per restart interval -- a file without markers is ONE lane's then */
     const char *sy = FFHIP_ENV("FFHIP_JPEG_SYNC");
-    const bool use_sync = plain && !(sy && sy[0] == '0');
+    const bool use_sync = !(sy && sy[0] == '0');
     const auto T1 = std::chrono::steady_clock::now();
     /* ---- layout of the one upload: scan bytes | tables | picture records | interval starts | work list | status ---- */
     std::vector<HuffImage> images((size_t)n);
@@ -438,7 +443,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         im.mcus = (uint32_t)mcus;
         im.ncomp = (uint32_t)j.ncomp;
         im.seg_base = (uint32_t)seg_total;
-        im.n_seg = (uint32_t)segs[(size_t)i].size();
+        im.n_seg = (uint32_t)segs[(size_t)i].size() - 1;
         for (int c = 0; c < 3; c++) {
             im.nb[c] = c < j.ncomp ? (uint32_t)(j.h[c] * j.v[c]) : 0;
             im.tab_dc[c] = table_id(&j.dc[c < j.ncomp ? j.td[c] : j.td[0]]);
@@ -502,6 +507,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         if (n_parts > n) n_parts = n;
     }
     SyncJob jobs[SYNC_PARTS];
+    std::vector<SyncSeg> part_segs[SYNC_PARTS];
     uint32_t *h_cnt[SYNC_PARTS];
     if (use_sync) {
         /* the parts' bytes go up on a stream of their own, the copy engine's, while the rounds of the parts before run on the caller's: 256 4K files are
@@ -532,12 +538,11 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         /* the picture's bytes, unstuffed, every restart interval 4-byte aligned and followed by >= 4 zero bytes */
         uint8_t *dst = stage + im.scan_off;
         std::vector<uint32_t> &sgv = segs[(size_t)i];
-        size_t off = 0, last = 0;
-        if (stage_scan(dst, j.scan, j.scan + j.scan_len, sgv.data(), im.n_seg, &off, &last) != im.n_seg) status[i] = FFHIP_EINVAL;
+        size_t off = 0;
+        if (stage_scan(dst, j.scan, j.scan + j.scan_len, sgv.data(), im.n_seg, &off, raws[(size_t)i].data()) != im.n_seg) status[i] = FFHIP_EINVAL;
         memset(dst + off, 0, 16);
-        clean_len[(size_t)i] = (uint32_t)off;
-        raw_len[(size_t)i] = (uint32_t)last;
-        if (use_sync) return; /* (no interval lists; the tail of the image is on its way already) */
+        sgv[im.n_seg] = (uint32_t)off;
+        if (use_sync) return; /* (the interval lists stay on the host; the tail of the image is on its way already) */
         uint32_t *sg = (uint32_t *)(stage + o_seg) + im.seg_base;
         u32x2 *wk = (u32x2 *)(stage + o_work) + (im.seg_base - (uint32_t)i);
         for (uint32_t k = 0; k < im.n_seg; k++) {
@@ -559,7 +564,27 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
                 hipStreamWaitEvent(st, g_huff_part_ev[part], 0) != hipSuccess) rc = FFHIP_EIO;
             if (!rc) {
                 job.dev = dev; job.o_tabs = o_tabs; job.o_l12 = o_l12; job.o_status = o_status + (size_t)p_lo * 4; job.n = p_hi - p_lo; job.part = part;
-                job.images = images.data() + p_lo; job.clean_len = clean_len.data() + p_lo; job.raw_len = raw_len.data() + p_lo;
+                job.images = images.data() + p_lo;
+                part_segs[part].clear();
+                for (int i = p_lo; i < p_hi && !rc; i++) {
+                    const HuffImage &im = images[(size_t)i];
+                    const std::vector<uint32_t> &sgv = segs[(size_t)i];
+                    if (status[i]) { rc = status[i]; break; } /* a file whose restart markers do not add up */
+                    for (uint32_t k = 0; k < im.n_seg; k++) {
+                        SyncSeg sg;
+                        sg.pic = (uint32_t)(i - p_lo);
+                        sg.scan_off = im.scan_off + sgv[k];
+                        sg.clean_len = sgv[k + 1] - sgv[k];
+                        sg.raw_len = raws[(size_t)i][k];
+                        sg.mcu0 = (uint32_t)((size_t)(i - p_lo) * mcus + (size_t)k * im.restart);
+                        const size_t left = mcus - (size_t)k * im.restart;
+                        sg.mcus = (uint32_t)(left < im.restart ? left : im.restart);
+                        part_segs[part].push_back(sg);
+                    }
+                }
+                job.segs = part_segs[part].data();
+                job.n_segs = part_segs[part].size();
+                if (rc) { (void)hipStreamSynchronize(g_huff_up); (void)hipStreamSynchronize(st); return rc; }
                 job.plane[0] = d_coef_y + (size_t)p_lo * mcus * images[0].nb[0] * 64;
                 job.plane[1] = d_coef_u ? d_coef_u + (size_t)p_lo * mcus * images[0].nb[1] * 64 : nullptr;
                 job.plane[2] = d_coef_v ? d_coef_v + (size_t)p_lo * mcus * images[0].nb[2] * 64 : nullptr;
@@ -677,8 +702,9 @@ struct SyncImage {
     uint32_t scan_off;   /* byte offset of the picture's unstuffed scan inside `scan` (16-byte aligned) */
     uint32_t clean_len;  /* bytes staged: the data and its zero padding                                 */
     uint32_t data_bits;  /* bits of entropy-coded data (without the padding)                            */
-    uint32_t mcus, ncomp, nbt; /* nbt: blocks per MCU over all components                               */
+    uint32_t mcus, ncomp, nbt; /* MCUs of the interval; nbt: blocks per MCU over all components         */
     uint32_t nb[3], tab_dc[3], tab_ac[3];
+    uint32_t pic, mcu0;  /* picture of the part (status), first MCU counted over the part's pictures    */
 };
 struct SyncArgs {
     const uint8_t *scan;
@@ -822,7 +848,7 @@ __global__ __launch_bounds__(THREADS) void k_huff_span(SyncArgs a)
         mcu = bidx / nbt;
         if (active && bidx < total_blocks && bidx - mcu * nbt != slot) { bad = true; active = false; } /* the scan and the entry disagree: not a fixed point */
         if (bidx >= total_blocks) active = false;
-        mcu += p * im.mcus; /* from here on: the MCU's index in the whole plane */
+        mcu += im.mcu0;     /* from here on: the MCU's index in the whole plane */
     }
     /* the predictors: the current component's, the next one's in the scan's cycle, the one's after that */
     uint32_t c = (cpack >> (2 * slot)) & 3u;
@@ -987,7 +1013,7 @@ __global__ __launch_bounds__(THREADS) void k_huff_span(SyncArgs a)
             cmask &= cmask - 1u;
             blk[nat] = ((const int16_t *)&stage[nat >> 3][threadIdx.x])[nat & 7u];
         }
-        if (bad) a.status[p] = FFHIP_EINVAL;
+        if (bad) a.status[im.pic] = FFHIP_EINVAL;
         return;
     }
     if (fresh) {
@@ -1036,7 +1062,7 @@ __global__ __launch_bounds__(256) void k_huff_sync_scan(SyncArgs a)
         carry += total;
         __syncthreads();
     }
-    if (threadIdx.x == 0 && carry[0] < im.mcus * im.nbt) a.status[p] = FFHIP_EINVAL;
+    if (threadIdx.x == 0 && carry[0] < im.mcus * im.nbt) a.status[im.pic] = FFHIP_EINVAL;
 }
 
 /* behind the write pass: a picture whose last block ends behind its data has taken bits from the padding -- truncated (the host decoder's rule,
@@ -1045,7 +1071,7 @@ __global__ __launch_bounds__(256) void k_huff_sync_verdict(SyncArgs a)
 {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     if (a.cnt[a.last] || p >= a.n_images) return;
-    if (a.end_pos[p] > a.images[p].data_bits) a.status[p] = FFHIP_EINVAL;
+    if (a.end_pos[p] > a.images[p].data_bits) a.status[a.images[p].pic] = FFHIP_EINVAL;
 }
 
 namespace {
@@ -1082,7 +1108,7 @@ void sync_args(SyncArgs &a, const SyncJob &job, uint32_t *d, const SyncLayout &L
     for (int c = 0; c < 3; c++) a.plane[c] = job.plane[c];
     a.status = (int *)(job.dev + job.o_status);
     a.n_tasks = job.n_tasks;
-    a.n_images = (uint32_t)job.n;
+    a.n_images = (uint32_t)job.n_segs;
     a.round = 0;
     a.last = job.rounds + 2;
     a.sub_bits = job.sub_bits;
@@ -1101,9 +1127,9 @@ int sync_launch_rounds_and_passes(SyncArgs &a, const SyncJob &job, hipStream_t s
         hipLaunchKernelGGL(k_huff_sync_list, dim3(wgl), dim3(256), 0, st, a);
         if (r < job.rounds + 2) hipLaunchKernelGGL((k_huff_span<SPAN_LIST, SPAN_THREADS>), dim3(wgs), dim3(SPAN_THREADS), 0, st, a);
     }
-    hipLaunchKernelGGL(k_huff_sync_scan, dim3((unsigned)job.n), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_huff_sync_scan, dim3((unsigned)job.n_segs), dim3(256), 0, st, a);
     hipLaunchKernelGGL((k_huff_span<SPAN_WRITE, WRITE_THREADS>), dim3((job.n_tasks + WRITE_THREADS - 1) / WRITE_THREADS), dim3(WRITE_THREADS), 0, st, a);
-    hipLaunchKernelGGL(k_huff_sync_verdict, dim3(((unsigned)job.n + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_huff_sync_verdict, dim3(((unsigned)job.n_segs + 255) / 256), dim3(256), 0, st, a);
     FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
     return FFHIP_OK;
 }
@@ -1114,7 +1140,7 @@ static int huff_sync_enqueue(SyncJob &job, void *stream, uint32_t **h_cnt)
 {
     static_assert(sizeof(SyncImage) % 4 == 0, "SyncImage is copied by words");
     hipStream_t st = (hipStream_t)stream;
-    const size_t n = (size_t)job.n;
+    const size_t n = job.n_segs; /* "pictures" of the kernels: the intervals */
     {
         const char *e = FFHIP_ENV("FFHIP_JPEG_SYNC_ROUNDS");
         const int r = e ? atoi(e) : 6;
@@ -1124,10 +1150,10 @@ static int huff_sync_enqueue(SyncJob &job, void *stream, uint32_t **h_cnt)
         job.sub_bits = (uint32_t)(sb < 128 ? 128 : sb > 65536 ? 65536 : sb);
     }
     uint64_t tasks = 0;
-    for (size_t i = 0; i < n; i++) tasks += sync_tasks_of(job.raw_len[i], job.sub_bits);
-    if (tasks > 0x7fffff00u) return FFHIP_EINVAL;
+    for (size_t i = 0; i < n; i++) tasks += sync_tasks_of(job.segs[i].raw_len, job.sub_bits);
+    if (tasks > 0x7fffff00u || n > 0x7fffff00u) return FFHIP_EINVAL;
     const SyncLayout L = sync_layout(n, (size_t)tasks);
-    const size_t head = L.o_list; /* words the host fills: picture records, first tasks, list counts, end positions */
+    const size_t head = L.o_list; /* words the host fills: interval records, first tasks, list counts, end positions */
     uint8_t *pin = ffhip_pinned_scratch(SCRATCH_HUFF_SYNC + job.part, stream, (head + SYNC_ROUNDS_MAX + 3) * 4);
     uint32_t *d = ffhip_scratch(SCRATCH_HUFF_SYNC + job.part, stream, L.words);
     if (!pin || !d) return FFHIP_ENOMEM;
@@ -1135,18 +1161,21 @@ static int huff_sync_enqueue(SyncJob &job, void *stream, uint32_t **h_cnt)
     SyncImage *si = (SyncImage *)(h + L.o_img);
     uint32_t t = 0;
     for (size_t i = 0; i < n; i++) {
-        const HuffImage &im = job.images[i];
+        const SyncSeg &sg = job.segs[i];
+        const HuffImage &im = job.images[sg.pic];
         SyncImage &s = si[i];
-        s.scan_off = im.scan_off;
-        s.clean_len = job.clean_len[i];
-        s.data_bits = job.raw_len[i] * 8u;
-        s.mcus = im.mcus;
+        s.scan_off = sg.scan_off;
+        s.clean_len = sg.clean_len;
+        s.data_bits = sg.raw_len * 8u;
+        s.mcus = sg.mcus;
+        s.pic = sg.pic;
+        s.mcu0 = sg.mcu0;
         s.ncomp = im.ncomp;
         s.nbt = 0;
         for (int c = 0; c < 3; c++) { s.nb[c] = im.nb[c]; s.tab_dc[c] = im.tab_dc[c]; s.tab_ac[c] = im.tab_ac[c]; s.nbt += im.nb[c]; }
         if (s.nb[0] != si[0].nb[0] || s.nb[1] != si[0].nb[1] || s.nb[2] != si[0].nb[2]) return FFHIP_EINVAL; /* (one geometry per call: the kernels keep one record of the MCU's blocks) */
         h[L.o_sub + i] = t;
-        t += sync_tasks_of(job.raw_len[i], job.sub_bits);
+        t += sync_tasks_of(sg.raw_len, job.sub_bits);
     }
     h[L.o_sub + n] = t;
     job.n_tasks = t;
@@ -1177,7 +1206,7 @@ static int huff_sync_finish(SyncJob &job, void *stream, uint32_t *h_cnt, int *st
     job.reran = 0;
     for (uint32_t r = 2; r < last; r++) job.rounds_used += h_cnt[r] ? 1u : 0u;
     if (!h_cnt[last]) return FFHIP_OK;
-    const size_t n = (size_t)job.n;
+    const size_t n = job.n_segs;
     const SyncLayout L = sync_layout(n, job.n_tasks);
     uint32_t *d = ffhip_scratch(SCRATCH_HUFF_SYNC + job.part, stream, L.words);
     if (!d) return FFHIP_ENOMEM;
@@ -1185,7 +1214,7 @@ static int huff_sync_finish(SyncJob &job, void *stream, uint32_t *h_cnt, int *st
     sync_args(a, job, d, L);
     uint32_t longest = 0;
     for (size_t i = 0; i < n; i++) {
-        const uint32_t ti = sync_tasks_of(job.raw_len[i], job.sub_bits);
+        const uint32_t ti = sync_tasks_of(job.segs[i].raw_len, job.sub_bits);
         longest = ti > longest ? ti : longest;
     }
     for (uint32_t done = last;; done += job.rounds) {
@@ -1199,7 +1228,7 @@ static int huff_sync_finish(SyncJob &job, void *stream, uint32_t *h_cnt, int *st
         for (uint32_t r = 2; r < last; r++) job.rounds_used += h_cnt[r] ? 1u : 0u;
         if (!h_cnt[last]) break;
     }
-    FFHIP_CHECK(hipMemcpy(status, job.dev + job.o_status, n * 4, hipMemcpyDeviceToHost), FFHIP_EIO);
+    FFHIP_CHECK(hipMemcpy(status, job.dev + job.o_status, (size_t)job.n * 4, hipMemcpyDeviceToHost), FFHIP_EIO);
     job.reran = 1;
     return FFHIP_OK;
 }

@@ -1,4 +1,4 @@
-"""GPU: the JPEG entropy front end on the device (one lane per restart interval) against the host decoder,
+"""GPU: the JPEG entropy front end on the device (both forms, see `form` below) against the host decoder,
 whose planes the CPU tests pin to the reference's whole-file decode -- and (round 4, bottom of the file) against the
 reference's whole-file decode directly."""
 import io
@@ -11,6 +11,20 @@ from ffpic_amd import capi, ops
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(params=["subsequences", "lane_per_interval"], autouse=True)
+def form(request, monkeypatch):
+    """every test of this file with both device decoders: the subsequence decoder (round 5, the default: a lane per 2048 bits of a restart interval,
+    synchronised over rounds) and the kernel of rounds 3-4 (FFHIP_JPEG_SYNC=0: a lane per restart interval, a file without markers one lane's)"""
+    if request.param == "lane_per_interval":
+        monkeypatch.setenv("FFHIP_JPEG_SYNC", "0")
+    else:
+        monkeypatch.delenv("FFHIP_JPEG_SYNC", raising=False)
+    capi.reload_env()
+    yield request.param
+    monkeypatch.undo()
+    capi.reload_env()
 
 
 def same_planes(files):
@@ -66,6 +80,63 @@ def test_generated_files_without_restart_markers(size, q, sub, mode, noise, opti
     files = [_plain_file(size, q, sub, mode, seed=i, noise=noise, optimize=optimize) for i in range(3)]
     same_planes(files)
     same_planes(files[1:2])
+
+
+def _pixels(files, **env):
+    """files -> BGRA through ffhip_jpeg_decode_files_device with library switches set for the call"""
+    import os as _os
+    old = {k: _os.environ.get(k) for k in env}
+    try:
+        for k, v in env.items():
+            _os.environ[k] = str(v)
+        capi.reload_env()
+        return ops.jpeg_decode_files_device(files, n_threads=4)[1]
+    finally:
+        for k, v in old.items():
+            if v is None:
+                _os.environ.pop(k, None)
+            else:
+                _os.environ[k] = v
+        capi.reload_env()
+
+
+@pytest.mark.parametrize("n", [1, 5, 40, 130])
+def test_plain_files_to_pixels_in_parts(n):
+    """files without restart markers -> BGRA on the device: the batch goes in parts (four from 32 files, graded 1/8 - 3/8 - 3/8 - 1/8 from 128), every
+    part's reconstruction enqueued by the entropy call behind the part's write pass.  Same pixels as with the entropy decode on the host."""
+    files = [_plain_file((64, 96), 70 + (i % 4) * 7, seed=i % 9, optimize=bool(i % 3 == 0)) for i in range(n)]
+    want = _pixels(files, FFHIP_JPEG_GPU_ENTROPY=0)
+    got = _pixels(files)
+    assert np.array_equal(got, want)
+
+
+def test_batch_of_files_with_and_without_restart_markers():
+    """one file without DRI among files with: the batch takes the lane-per-interval kernel, the plain file one lane"""
+    files = [_good_dri_file(blocks=3), _good_dri_file(blocks=0), _good_dri_file(blocks=5)]
+    assert b"\xff\xdd" not in files[1]
+    same_planes(files)
+    assert np.array_equal(_pixels(files), _pixels(files, FFHIP_JPEG_GPU_ENTROPY=0))
+
+
+def test_damaged_plain_file_in_a_batch_goes_to_the_host_decoder():
+    """a plain file with bytes of its scan replaced: the device decoder refuses the batch, ffhip_jpeg_decode_files_device falls back to the host decoder
+    for it -- the same pixels and the same per-picture verdicts as with FFHIP_JPEG_GPU_ENTROPY=0, whatever those are"""
+    good = _plain_file((128, 160), 85, seed=3)
+    bad = bytearray(good)
+    sos = good.find(b"\xff\xda")
+    rng = np.random.default_rng(9)
+    for k in rng.integers(sos + 40, len(bad) - 8, size=12):
+        if bad[k] != 0xFF and bad[k - 1] != 0xFF:
+            bad[k] ^= 0x55
+    files = [good, bytes(bad), good]
+    try:
+        want = _pixels(files, FFHIP_JPEG_GPU_ENTROPY=0)
+    except capi.FfhipError:
+        with pytest.raises(capi.FfhipError):
+            _pixels(files)
+    else:
+        assert np.array_equal(_pixels(files), want)
+    assert np.array_equal(_pixels([good] * 2), _pixels([good] * 2, FFHIP_JPEG_GPU_ENTROPY=0))
 
 
 def test_many_small_plain_files_share_workgroups():

@@ -110,14 +110,14 @@ def test_diagnostics_prints_change_nothing(switch, capfd):
 
 @pytest.mark.parametrize("ring", [16, 32])
 def test_huffman_ring_sizes(ring, switch):
-    """FFHIP_HUFF_RING: the device Huffman kernel's byte ring per lane (64 bytes and a refill every 8 symbols for batches beyond what two workgroups per CU
+    """FFHIP_HUFF_RING (with FFHIP_JPEG_SYNC=0, the lane-per-interval kernel): the device Huffman kernel's byte ring per lane (64 bytes and a refill every 8 symbols for batches beyond what two workgroups per CU
     hold, 128 bytes and every 16 otherwise): the same pixels from files with restart markers, with several tables, and from plain files forced onto the device"""
     here = os.path.join(os.path.dirname(__file__), "golden")
     for tag in ("q85_420_dri", "q85_411", "q92_444"):
         data = open(os.path.join(here, FILES[tag]), "rb").read()
         switch(FFHIP_JPEG_GPU_ENTROPY=0)
         want = ops.jpeg_decode_files_device([data] * 5, n_threads=2)[1]
-        switch(FFHIP_JPEG_GPU_ENTROPY=1, FFHIP_HUFF_RING=ring)
+        switch(FFHIP_JPEG_GPU_ENTROPY=1, FFHIP_HUFF_RING=ring, FFHIP_JPEG_SYNC=0)
         got = ops.jpeg_decode_files_device([data] * 5, n_threads=2)[1]
         assert np.array_equal(got, want), (tag, ring)
 
@@ -125,16 +125,17 @@ def test_huffman_ring_sizes(ring, switch):
 def test_plain_files_one_lane_each_and_few_rounds(switch):
     """FFHIP_JPEG_SYNC=0: a file without restart markers is one lane's (round 4's form, for batches of thousands); FFHIP_JPEG_SYNC_ROUNDS: the
     list rounds are launched one (two) at a time, the host looks whether they reached their fixed point and launches more -- the path a scan takes that does
-    not settle within the twelve rounds launched at once; FFHIP_JPEG_SYNC_BITS: the length of a subsequence, 128 bits (a few symbols, hardly ever in step
-    after one) to the whole scan in one"""
+    not settle within the six rounds launched at once; FFHIP_JPEG_SYNC_BITS: the length of a subsequence, 128 bits (a few symbols, hardly ever in step
+    after one) to the whole scan in one; FFHIP_JPEG_SYNC_PARTS: the parts a batch is staged, sent and decoded in"""
     from test_huff_gpu import _plain_file, same_planes
-    files = [_plain_file((360, 640), 85, seed=i) for i in range(3)]
+    files = [_plain_file((360, 640), 85, seed=i) for i in range(3)] + [_plain_file((360, 640), 60, seed=i) for i in range(6)]
     want = ops.jpeg_entropy_batch_gpu(files)
     for env in ({"FFHIP_JPEG_SYNC": 0}, {"FFHIP_JPEG_SYNC_ROUNDS": 1}, {"FFHIP_JPEG_SYNC_ROUNDS": 2}, {"FFHIP_JPEG_SYNC_ROUNDS": 32}, {"FFHIP_JPEG_SYNC_BITS": 128},
-                {"FFHIP_JPEG_SYNC_BITS": 128, "FFHIP_JPEG_SYNC_ROUNDS": 1}, {"FFHIP_JPEG_SYNC_BITS": 4096}, {"FFHIP_JPEG_SYNC_BITS": 65536}):
+                {"FFHIP_JPEG_SYNC_BITS": 128, "FFHIP_JPEG_SYNC_ROUNDS": 1}, {"FFHIP_JPEG_SYNC_BITS": 4096}, {"FFHIP_JPEG_SYNC_BITS": 65536}, {"FFHIP_JPEG_SYNC_PARTS": 1},
+                {"FFHIP_JPEG_SYNC_PARTS": 3}, {"FFHIP_JPEG_SYNC_PARTS": 8}):
         switch(**env)
         got = ops.jpeg_entropy_batch_gpu(files)
         for a, b in zip(got[1:], want[1:]):
             assert np.array_equal(a, b), env
         same_planes(files)
-        switch(FFHIP_JPEG_SYNC=1, FFHIP_JPEG_SYNC_ROUNDS=12, FFHIP_JPEG_SYNC_BITS=1024)
+        switch(FFHIP_JPEG_SYNC=1, FFHIP_JPEG_SYNC_ROUNDS=6, FFHIP_JPEG_SYNC_BITS=2048, FFHIP_JPEG_SYNC_PARTS=0)

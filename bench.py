@@ -819,6 +819,8 @@ def extra_f1(L, dev, stream, T, cpu=True, n=256):
                        f"{threads} host threads for header parsing / staging", "files": {}}
     geom = capi.JpegGeom()
     for tag, kw in (("dri_per_mcu_row", dict(restart_marker_rows=1)), ("no_dri", dict())):
+        if os.environ.get("F1_TAGS") and tag not in os.environ["F1_TAGS"].split(","):      # (a row alone, for profiling)
+            continue
         bio = io.BytesIO()
         Image.fromarray(img).save(bio, "JPEG", quality=85, subsampling=2, **kw)
         data = bio.getvalue()
@@ -868,17 +870,15 @@ def extra_f1(L, dev, stream, T, cpu=True, n=256):
                                         "phases_ms": {"header_parse": round(ph[0] / 1e3, 2), "layout": round(ph[1] / 1e3, 2), "unstuff_and_markers_with_uploads_enqueued": round(ph[2] / 1e3, 2),
                                                       "tables": round(ph[3] / 1e3, 2), "enqueue": round(ph[4] / 1e3, 2), "wait_uploads_clears_kernel": round(ph[5] / 1e3, 2)},
                                         "k_jpeg_huff_ms": round(ph[6] / 1e3, 3), "k_jpeg_huff_compressed_GB/s": round(n * len(data) / (ph[6] / 1e6) / 1e9, 1) if ph[6] else None}
-            if tag == "no_dri":
-                # no single kernel here: the batch goes in parts -- bytes up on a copy stream, two rounds over all subsequences, list rounds, scan, write pass --
-                # and the events bracket all of it, the uploads it waits for included
-                e = row["entropy_batch_gpu"]
-                e["device_pipeline_ms"] = e.pop("k_jpeg_huff_ms")
-                e.pop("k_jpeg_huff_compressed_GB/s")
-                e["form"] = "subsequences of 2048 bits a lane, synchronised over rounds (ffhip_huff_gpu.hip, k_huff_span); profiles/r5_huff_plain_timeline.txt has the kernels of one call"
+            # no single kernel behind this figure: the batch goes in parts -- bytes up on a copy stream, two rounds over all subsequences, list rounds, scan,
+            # write pass -- and the events bracket all of it, the uploads it waits for included (FFHIP_JPEG_SYNC=0: the lane-per-interval kernel alone)
+            e = row["entropy_batch_gpu"]
+            e["device_pipeline_ms"] = e.pop("k_jpeg_huff_ms")
+            e.pop("k_jpeg_huff_compressed_GB/s")
+            e["form"] = ("one lane per restart interval (k_jpeg_huff)" if os.environ.get("FFHIP_JPEG_SYNC", "1")[:1] == "0" else
+                         "subsequences of 2048 bits of a restart interval (of the scan) a lane, synchronised over rounds (ffhip_huff_gpu.hip, k_huff_span); "
+                         "profiles/r5_huff_plain_timeline.txt has the kernels of one call")
             row["reconstruction_ms"] = round(rms, 3)
-            if tag == "dri_per_mcu_row":
-                row["share_of_the_call"] = {"host_staging": round((ph[0] + ph[1] + ph[2] + ph[3]) / 1e3 / (best * 1e3), 3), "device_huffman_kernel": round(ph[6] / 1e3 / (best * 1e3), 3),
-                                            "reconstruction": round(rms / (best * 1e3), 3)}
             del d_y, d_u, d_v, d_q
         if cpu:
             O = oracle_lib()
@@ -922,7 +922,7 @@ def extra_f1(L, dev, stream, T, cpu=True, n=256):
             tt = (C.c_double * 8)()
             L.ffhip_debug_huff_times(tt)
             res["files"][f"{tag}_x{n4}"] = {"files": n4, "files_to_device_pixels_ms": round(b4 * 1e3, 2), "value": round(n4 * W * H / b4 / 1e6, 1), "unit": "Mpixels/s",
-                                            "files_per_s": round(n4 / b4), ("k_jpeg_huff_ms" if tag == "dri_per_mcu_row" else "device_pipeline_ms"): round(float(tt[6]) / 1e3, 3),
+                                            "files_per_s": round(n4 / b4), "device_pipeline_ms": round(float(tt[6]) / 1e3, 3),
                                             "same_pixels_as_first_file": bool(torch.equal(d_out4[0], d_out4[n4 - 1]))}
             del d_out4
             torch.cuda.empty_cache()
@@ -979,7 +979,7 @@ def compact_configs(extra):
     f1 = extra.get("f1", {})
     if f1:
         out["f1"] = f1 if "error" in f1 else {k: {"value": g(v, "value"), "ms": g(v, "files_to_device_pixels_ms"), "entropy_gpu": g(v, "entropy_batch_gpu", "value"),
-                                                   "k_jpeg_huff_ms": g(v, "entropy_batch_gpu", "k_jpeg_huff_ms"), "recon_ms": g(v, "reconstruction_ms"), "share": g(v, "share_of_the_call"),
+                                                   "device_pipeline_ms": g(v, "entropy_batch_gpu", "device_pipeline_ms") or g(v, "device_pipeline_ms"), "recon_ms": g(v, "reconstruction_ms"),
                                                    "parity": g(v, "parity_vs_reference_whole_file_decode"), "cpu_1_core": g(v, "cpu_baseline", "value"),
                                                    "cpu_all_cores": g(v, "cpu_baseline_all_cores", "value")} for k, v in (f1.get("files") or {}).items()}
     sk = extra.get("stage_kernels", {})

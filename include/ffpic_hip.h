@@ -514,23 +514,29 @@ int ffhip_jpeg_entropy_batch(const uint8_t *const *files, const size_t *lens, in
  * (format/jpg.c:588-637). */
 int ffhip_jpeg_stage_scan_test(uint8_t *dst, const uint8_t *src, size_t len, uint32_t *seg, uint32_t n_seg, size_t *clean_len);
 
-/* The same front end ON the device for files that carry restart markers (DRI): one lane per restart interval
- * decodes straight into DEVICE planes (d_coef_*, d_quant [n][4][64]) laid out for ffhip_jpeg_recon_batch with
- * quant_stride 256; the host only parses headers and finds the RSTn markers.  files/lens/status are HOST
- * arrays.  A file without DRI is one interval = one lane (worth it for batches of a thousand files or more only);
- * FFHIP_EINVAL for a file of another geometry.  Synchronises `stream` (the per-picture verdicts come back with it). */
+/* The same front end ON the device: decodes straight into DEVICE planes (d_coef_*, d_quant [n][4][64]) laid out for
+ * ffhip_jpeg_recon_batch with quant_stride 256; the host only parses headers, finds the RSTn markers and unstuffs the
+ * bytes into pinned memory.  files/lens/status are HOST arrays.  Round 5: a lane decodes 2048 bits of a restart interval
+ * -- of the whole scan, in a file without DRI -- and the lanes are brought into step with each other over a few rounds
+ * (Huffman-coded data self-synchronises; DESIGN.md 5 "The subsequence decoder"), so files need no restart markers to decode
+ * in parallel, and a batch may mix files with and without.  FFHIP_JPEG_SYNC=0: the kernel of rounds 3-4, one lane per restart
+ * interval (a file without DRI is ONE lane's then: for batches of a thousand files or more only).
+ * FFHIP_EINVAL for a file of another geometry, and for a damaged or truncated scan (status[] says which picture; nothing of
+ * the batch is to be used then -- ffhip_jpeg_decode_files* fall back to the host decoder).  Synchronises `stream` (the
+ * per-picture verdicts come back with it). */
 int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const size_t *lens, int n, int n_threads /* host: header
                                  parsing, marker search, staging */, const ffhip_jpeg_geom *geom, int16_t *d_coef_y, int16_t *d_coef_u, int16_t *d_coef_v, uint16_t *d_quant,
                                  int *status, void *stream);
 
 /* Diagnostics: where the calling thread's last ffhip_jpeg_entropy_batch_gpu call spent its time, in microseconds: out[0] header parse,
- * [1] layout, [2] unstuffing + marker search into pinned memory (the uploads are enqueued by quarters behind it), [3] tables, [4] enqueue,
- * [5] the wait for uploads + clears + kernel, [6] the Huffman kernel alone (HIP events on the call's stream), [7] the whole call. */
+ * [1] layout, [2] unstuffing + marker search into pinned memory (each part's upload and kernels are enqueued behind it), [3] tables, [4] enqueue,
+ * [5] the wait for uploads + clears + kernels, [6] HIP events on the call's stream around everything the call has the device do (the subsequence
+ * decoder: uploads waited for, rounds, scan, write pass of all parts; FFHIP_JPEG_SYNC=0: the Huffman kernel alone), [7] the whole call. */
 int ffhip_debug_huff_times(double out[8]);
 
 /* Files in, pixels out (f1 + the hot path + f2's producer side): n baseline JPEG files of ONE geometry are
- * entropy-decoded `chunk` pictures at a time (0 = default) -- on the device when they carry restart markers
- * (ffhip_jpeg_entropy_batch_gpu), else by n_threads host threads into pinned memory -- while the
+ * entropy-decoded `chunk` pictures at a time (0 = default) -- on the device (ffhip_jpeg_entropy_batch_gpu), or, when that
+ * refuses a chunk or FFHIP_JPEG_GPU_ENTROPY=0 says so, by n_threads host threads into pinned memory -- while the
  * previous chunk is copied to the device, reconstructed by one launch and copied back -- a double-buffered
  * pipeline whose steady state is the slower of host entropy decode and PCIe.  bgra is HOST memory,
  * pixel (x, y) of picture i at bgra + i*image_stride + y*pitch + 4*x (coded size, geom_out tells it);

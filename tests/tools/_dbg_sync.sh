@@ -1,7 +1,8 @@
 set -u
-R=$PWD
-python3 -m pytest tests/test_huff_gpu.py -x -q -m gpu 2>&1 | tail -2
-cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/rp_hp
-FFHIP_JPEG_SYNC_PARTS=1 rocprofv3 --kernel-trace -d /tmp/rp_hp -o hp --output-format csv -- python3 $R/tests/tools/bench_huff_plain.py > /dev/null 2>&1
-python3 $R/tests/tools/kernel_timeline.py /tmp/rp_hp "k_huff_span<0" k_huff_sync_verdict 2 | grep "span<2"
+for t in no_dri dri_per_mcu_row no_dri,dri_per_mcu_row; do
+F1_TAGS=$t python bench.py --extras f1 --no-cpu 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+f=d['configs']['f1']
+print({k:(v['ms'],v['entropy_gpu']) for k,v in f.items()})"
+done

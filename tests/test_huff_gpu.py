@@ -389,3 +389,44 @@ def test_device_entropy_planes_reconstruct_to_the_reference_decode(golden, tag):
     out = dout.to_host((n, H, W, 4), np.uint8)
     for i in range(n):
         _equals_reference_decode(g, tag, geom, out[i])
+
+
+def test_three_threads_each_on_its_own_stream():
+    """callers on different streams overlap completely: staging, device scratch, the upload stream and its events are per stream or per thread.
+    Three threads decode different batches (files with and without restart markers) several times over; every result is the single-threaded one."""
+    import ctypes as C
+    import threading
+    torch = pytest.importorskip("torch")
+    L = capi.require_device()
+    batches = [[_plain_file((96, 128), 80, seed=i) for i in range(9)], [_good_dri_file(blocks=3)] * 7 + [_good_dri_file(blocks=0)] * 2,
+               [_plain_file((96, 128), 92, seed=i, optimize=True) for i in range(33)]]
+    want = [_pixels(b) for b in batches]
+    errors = []
+
+    def worker(k):
+        try:
+            files = batches[k]
+            n = len(files)
+            g, _, _ = ops.jpeg_probe(files[0])
+            bufs = [np.frombuffer(f, dtype=np.uint8) for f in files]
+            ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+            lens = (C.c_size_t * n)(*[b.size for b in bufs])
+            status = (C.c_int * n)()
+            g2 = capi.JpegGeom()
+            st = torch.cuda.Stream()
+            out = torch.empty((n, g.height, g.width, 4), dtype=torch.uint8, device="cuda:0")
+            for _ in range(6):
+                out.zero_()
+                torch.cuda.synchronize()
+                capi.check(L.ffhip_jpeg_decode_files_device(ptrs, lens, n, 2, C.byref(g2), out.data_ptr(), g.width * 4, g.width * 4 * g.height, status, st.cuda_stream))
+                capi.check(L.ffhip_stream_sync(st.cuda_stream))
+                if not np.array_equal(out.cpu().numpy(), want[k]):
+                    errors.append((k, "pixels differ"))
+        except Exception as e:      # noqa: BLE001 -- reported below, from the main thread
+            errors.append((k, repr(e)))
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

@@ -716,6 +716,7 @@ struct SyncArgs {
     unsigned long long *used;    /* per task: the entry its exit was worked out from                           */
     u32x4 *sums;                 /* per task: blocks completed, DC differences summed per component; after the scan their exclusive prefix sums */
     uint32_t *list;              /* the tasks of a list round */
+    uint32_t *seg_of;            /* per task: its interval (filled by k_huff_sync_segs; looked up, not searched for, by every pass) */
     uint32_t *cnt;               /* [last + 1]: tasks in round r's list; cnt[last] == 0: the fixed point is reached */
     uint32_t *end_pos;           /* per picture: bit position behind its last block (write pass)               */
     int16_t *plane[3];
@@ -724,32 +725,38 @@ struct SyncArgs {
 };
 
 __device__ __forceinline__ uint32_t sync_picture_of(const SyncArgs &a, uint32_t t)
-{ /* the last picture whose first task is <= t */
-    uint32_t lo = 0, hi = a.n_images;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (a.sub_base[mid] <= t) lo = mid; else hi = mid;
-    }
-    return lo;
+{ /* the interval ("picture" of these kernels) task t belongs to */
+    return a.seg_of[t];
+}
+/* one workgroup per interval writes the interval's index over its tasks: every pass starts with one load per lane instead of a binary search of 17
+ * loads that depend on each other (8 us a wave; the list kernels were nothing but that search) */
+__global__ __launch_bounds__(256) void k_huff_sync_segs(SyncArgs a)
+{
+    const uint32_t p = blockIdx.x, t1 = a.sub_base[p + 1];
+    for (uint32_t t = a.sub_base[p] + threadIdx.x; t < t1; t += 256) a.seg_of[t] = p;
 }
 
-/* the tasks whose entry is not what they used: round `a.round`'s list (wave-aggregated append; the order does not matter) */
-__global__ __launch_bounds__(256) void k_huff_sync_list(SyncArgs a)
+/* the tasks whose entry is not what they used: round `a.round`'s list.  The append is aggregated per workgroup of sixteen waves -- one atomic on the
+ * list's counter per 1 024 tasks: with one per wave the kernel was 0.29 ms of atomics on one address for 1.6 M tasks.  The order does not matter. */
+#define LIST_THREADS 1024
+__global__ __launch_bounds__(LIST_THREADS) void k_huff_sync_list(SyncArgs a)
 {
+    __shared__ uint32_t wcount[LIST_THREADS / 64], wbase[LIST_THREADS / 64];
     if (a.round >= 3 && a.cnt[a.round - 1] == 0) return; /* the list before was empty: so is this one */
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t t = blockIdx.x * LIST_THREADS + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     bool stale = false;
-    if (t > 0 && t < a.n_tasks) {
-        const uint32_t p = sync_picture_of(a, t);
-        stale = a.sub_base[p] != t && a.exit_[t - 1] != a.used[t];
-    }
+    if (t > 0 && t < a.n_tasks) stale = a.seg_of[t - 1] == a.seg_of[t] && a.exit_[t - 1] != a.used[t]; /* (an interval's first task starts from the truth) */
     const unsigned long long m = __builtin_amdgcn_ballot_w64(stale);
-    if (!m) return;
-    const uint32_t lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&a.cnt[a.round], (uint32_t)__builtin_popcountll(m));
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    if (stale) a.list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = t;
+    if (lane == 0) wcount[wv] = (uint32_t)__builtin_popcountll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < LIST_THREADS / 64; w++) { wbase[w] = total; total += wcount[w]; }
+        const uint32_t base = total ? atomicAdd(&a.cnt[a.round], total) : 0u;
+        for (int w = 0; w < LIST_THREADS / 64; w++) wbase[w] += base;
+    }
+    __syncthreads();
+    if (stale) a.list[wbase[wv] + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = t;
 }
 
 enum { SPAN_ALL = 0, SPAN_LIST = 1, SPAN_WRITE = 2 };
@@ -1075,7 +1082,7 @@ __global__ __launch_bounds__(256) void k_huff_sync_verdict(SyncArgs a)
 }
 
 namespace {
-struct SyncLayout { size_t o_img, o_sub, o_cnt, o_end, o_list, o_sums, o_exit, o_used, words; };
+struct SyncLayout { size_t o_img, o_sub, o_cnt, o_end, o_list, o_seg, o_sums, o_exit, o_used, words; };
 SyncLayout sync_layout(size_t n, size_t tasks)
 {
     SyncLayout L;
@@ -1086,6 +1093,7 @@ SyncLayout sync_layout(size_t n, size_t tasks)
     L.o_cnt = take(SYNC_ROUNDS_MAX + 3);
     L.o_end = take(n);
     L.o_list = take(tasks);
+    L.o_seg = take(tasks);
     L.o_sums = take(4 * tasks);
     L.o_exit = take(2 * tasks);
     L.o_used = take(2 * tasks);
@@ -1103,6 +1111,7 @@ void sync_args(SyncArgs &a, const SyncJob &job, uint32_t *d, const SyncLayout &L
     a.used = (unsigned long long *)(d + L.o_used);
     a.sums = (u32x4 *)(d + L.o_sums);
     a.list = d + L.o_list;
+    a.seg_of = d + L.o_seg;
     a.cnt = d + L.o_cnt;
     a.end_pos = d + L.o_end;
     for (int c = 0; c < 3; c++) a.plane[c] = job.plane[c];
@@ -1121,10 +1130,10 @@ uint32_t sync_tasks_of(uint32_t raw_len, uint32_t sub_bits)
 /* list rounds 2 .. rounds + 1, the list of round rounds + 2 (empty: the fixed point), then the passes that need it */
 int sync_launch_rounds_and_passes(SyncArgs &a, const SyncJob &job, hipStream_t st)
 {
-    const unsigned wgs = (job.n_tasks + SPAN_THREADS - 1) / SPAN_THREADS, wgl = (job.n_tasks + 255) / 256;
+    const unsigned wgs = (job.n_tasks + SPAN_THREADS - 1) / SPAN_THREADS, wgl = (job.n_tasks + LIST_THREADS - 1) / LIST_THREADS;
     for (uint32_t r = 2; r <= job.rounds + 2; r++) {
         a.round = r;
-        hipLaunchKernelGGL(k_huff_sync_list, dim3(wgl), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_huff_sync_list, dim3(wgl), dim3(LIST_THREADS), 0, st, a);
         if (r < job.rounds + 2) hipLaunchKernelGGL((k_huff_span<SPAN_LIST, SPAN_THREADS>), dim3(wgs), dim3(SPAN_THREADS), 0, st, a);
     }
     hipLaunchKernelGGL(k_huff_sync_scan, dim3((unsigned)job.n_segs), dim3(256), 0, st, a);
@@ -1185,6 +1194,7 @@ static int huff_sync_enqueue(SyncJob &job, void *stream, uint32_t **h_cnt)
     SyncArgs a;
     sync_args(a, job, d, L);
     const unsigned wgs = (t + SPAN_THREADS - 1) / SPAN_THREADS;
+    hipLaunchKernelGGL(k_huff_sync_segs, dim3((unsigned)n), dim3(256), 0, st, a);
     for (uint32_t r = 0; r < 2; r++) {
         a.round = r;
         hipLaunchKernelGGL((k_huff_span<SPAN_ALL, SPAN_THREADS>), dim3(wgs), dim3(SPAN_THREADS), 0, st, a);

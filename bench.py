@@ -818,6 +818,7 @@ def extra_f1(L, dev, stream, T, cpu=True, n=256):
     res = {"workload": f"{n} x {W}x{H} baseline 4:2:0 JPEG files (PIL, quality 85; the same file {n} times) -> BGRA in device memory; wall clock of the calls, "
                        f"{threads} host threads for header parsing / staging", "files": {}}
     geom = capi.JpegGeom()
+    bufs = {}
     for tag, kw in (("dri_per_mcu_row", dict(restart_marker_rows=1)), ("no_dri", dict())):
         if os.environ.get("F1_TAGS") and tag not in os.environ["F1_TAGS"].split(","):      # (a row alone, for profiling)
             continue
@@ -902,10 +903,12 @@ def extra_f1(L, dev, stream, T, cpu=True, n=256):
         res["files"][tag] = row
         del d_out
         torch.cuda.empty_cache()
+        bufs[tag] = buf
+    # four times the files, behind BOTH rows of 256 (the library's pinned staging grows for these calls and stays grown: a 256-file row measured behind
+    # them uploads from a buffer five times its size, and on the boxes of this pool that was 4 ms slower).  With restart markers and without alike: the
+    # parts are larger, the uploads (PCIe) and the kernels overlap over a longer stretch
+    for tag, buf in bufs.items():
         if True:
-            # four times the files.  With restart markers: the device Huffman kernel's time is that of its LONGEST restart interval, whatever the number of
-            # intervals in flight (540 waves of 256 files leave half the SIMDs idle), so the call's throughput grows with the batch.  Without: the parts are
-            # larger, the uploads (PCIe) and the kernels overlap over a longer stretch
             n4 = 4 * n
             ptrs4 = (vp * n4)(*([buf.ctypes.data] * n4))
             lens4 = (C.c_size_t * n4)(*([buf.size] * n4))

@@ -904,9 +904,9 @@ def extra_f1(L, dev, stream, T, cpu=True, n=256):
         del d_out
         torch.cuda.empty_cache()
         bufs[tag] = buf
-    # four times the files, behind BOTH rows of 256 (the library's pinned staging grows for these calls and stays grown: a 256-file row measured behind
-    # them uploads from a buffer five times its size, and on the boxes of this pool that was 4 ms slower).  With restart markers and without alike: the
-    # parts are larger, the uploads (PCIe) and the kernels overlap over a longer stretch
+    # four times the files, behind BOTH rows of 256 (so that those two are measured in the same state of the process: the library's staging buffers grow for
+    # these calls and stay grown).  With restart markers and without alike: the parts are larger, the uploads (PCIe) and the kernels overlap over a longer
+    # stretch.  Rows late in the process come out slower than the same row run alone (16 -> 20 ms, 50 -> 70 ms; F1_TAGS=<row> runs one alone): DESIGN.md 5
     for tag, buf in bufs.items():
         if True:
             n4 = 4 * n

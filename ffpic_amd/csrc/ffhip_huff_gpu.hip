@@ -1159,7 +1159,10 @@ static int huff_sync_enqueue(SyncJob &job, void *stream, uint32_t **h_cnt)
         job.sub_bits = (uint32_t)(sb < 128 ? 128 : sb > 65536 ? 65536 : sb);
     }
     uint64_t tasks = 0;
-    for (size_t i = 0; i < n; i++) tasks += sync_tasks_of(job.segs[i].raw_len, job.sub_bits);
+    for (size_t i = 0; i < n; i++) {
+        if (job.segs[i].clean_len >= (1u << 28)) return FFHIP_EINVAL; /* (bit positions are 32-bit words: an interval of a quarter of a gigabyte goes to the host decoder) */
+        tasks += sync_tasks_of(job.segs[i].raw_len, job.sub_bits);
+    }
     if (tasks > 0x7fffff00u || n > 0x7fffff00u) return FFHIP_EINVAL;
     const SyncLayout L = sync_layout(n, (size_t)tasks);
     const size_t head = L.o_list; /* words the host fills: interval records, first tasks, list counts, end positions */

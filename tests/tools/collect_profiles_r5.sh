@@ -33,9 +33,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "done pmc $c"
 done
 # f1: the device Huffman stage (256 x 4K files with one restart interval per MCU row) -- kernel statistics and one PMC pass
-prof huff_gpu $R/bench.py --steps 2 --warmup 1 --no-cpu --extras f1
-pmc huff_gpu_pmc k_jpeg_huff SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES -- $R/bench.py --steps 2 --warmup 1 --no-cpu --extras f1
-pmc huff_gpu_pmc k_jpeg_huff SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_INSTS_SMEM -- $R/bench.py --steps 2 --warmup 1 --no-cpu --extras f1
+# the JPEG entropy front end: its own collection (the subsequence decoder; FFHIP_JPEG_SYNC=0 below for round 4's lane-per-interval kernel)
+FFHIP_JPEG_SYNC=0 F1_TAGS=dri_per_mcu_row prof huff_gpu $R/bench.py --steps 2 --warmup 1 --no-cpu --extras f1
+FFHIP_JPEG_SYNC=0 F1_TAGS=dri_per_mcu_row pmc huff_gpu_pmc k_jpeg_huff SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES -- $R/bench.py --steps 2 --warmup 1 --no-cpu --extras f1
+FFHIP_JPEG_SYNC=0 F1_TAGS=dri_per_mcu_row pmc huff_gpu_pmc k_jpeg_huff SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_INSTS_SMEM -- $R/bench.py --steps 2 --warmup 1 --no-cpu --extras f1
 # the single 8K picture and the grids
 prof intra_c5 $R/tests/tools/bench_intra_c5.py 6
 pmc intra_c5_pmc k_hevc_intra_groups SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES -- $R/tests/tools/bench_intra_c5.py 6
@@ -61,3 +62,5 @@ cd /tmp
 prof bench_headline $R/bench.py --no-extra
 grep '^{' $O/bench_headline.stdout | tail -1 > $O/bench_headline.json
 cd $R
+cd $R
+bash tests/tools/collect_profiles_r5_huff.sh > $O/huff_sync.log 2>&1; echo "done subsequence decoder"

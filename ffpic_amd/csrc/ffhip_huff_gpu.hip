@@ -502,6 +502,10 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     if (!g_huff_ev[0] && (hipEventCreate(&g_huff_ev[0]) != hipSuccess || hipEventCreate(&g_huff_ev[1]) != hipSuccess)) { (void)hipGetLastError(); g_huff_ev[0] = nullptr; }
     int n_parts = n >= 32 ? 4 : 1;
     if (use_sync) {
+        /* parts of about a hundred files -- a round over fewer subsequences fills the chip badly, and what is left to wait for behind the last upload are the
+         * last part's kernels: 256 4K files 13.7-14.0 ms in three parts, 14.0-14.5 in four, 14.2 in two, 14.4-14.5 in six (and 14.7-14.9 in four of
+         * 1/8, 3/8, 3/8, 1/8 of the files, which looked good on paper) */
+        n_parts = n < 32 ? 1 : (n + 64) / 96 < 2 ? 2 : (n + 64) / 96 > SYNC_PARTS ? SYNC_PARTS : (n + 64) / 96;
         const char *e = FFHIP_ENV("FFHIP_JPEG_SYNC_PARTS"); /* parts of the batch that are staged, sent and decoded one behind the other (1..8) */
         if (e && atoi(e) >= 1) n_parts = atoi(e) > SYNC_PARTS ? SYNC_PARTS : atoi(e);
         if (n_parts > n) n_parts = n;
@@ -522,13 +526,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         if (rc) return rc;
         if (g_huff_ev[0]) (void)hipEventRecord(g_huff_ev[0], st);
     }
-    /* the subsequence decoder's parts of a large batch: a small one first, so that the uploads start early, and a small one last, whose kernels are what is
-     * left to wait for when the last byte is up; the uploads in between run back to back */
-    const bool graded = use_sync && n_parts == 4 && n >= 128 && !FFHIP_ENV("FFHIP_JPEG_SYNC_PARTS");
-    auto part_lo = [&](int part) -> int {
-        static const int eighths[5] = {0, 1, 4, 7, 8};
-        return graded ? (int)((long long)n * eighths[part] / 8) : (int)((long long)n * part / n_parts);
-    };
+    auto part_lo = [&](int part) -> int { return (int)((long long)n * part / n_parts); };
     for (int part = 0; part < n_parts; part++) {
     const int p_lo = part_lo(part), p_hi = part_lo(part + 1);
     parallel_for(p_hi - p_lo, n_threads, [&](int i_rel) {

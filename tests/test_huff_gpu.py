@@ -100,9 +100,9 @@ def _pixels(files, **env):
         capi.reload_env()
 
 
-@pytest.mark.parametrize("n", [1, 5, 40, 130])
+@pytest.mark.parametrize("n", [1, 5, 40, 130, 300])
 def test_plain_files_to_pixels_in_parts(n):
-    """files without restart markers -> BGRA on the device: the batch goes in parts (four from 32 files, graded 1/8 - 3/8 - 3/8 - 1/8 from 128), every
+    """files without restart markers -> BGRA on the device: the batch goes in parts of about a hundred files (two from 32 files on), every
     part's reconstruction enqueued by the entropy call behind the part's write pass.  Same pixels as with the entropy decode on the host."""
     files = [_plain_file((64, 96), 70 + (i % 4) * 7, seed=i % 9, optimize=bool(i % 3 == 0)) for i in range(n)]
     want = _pixels(files, FFHIP_JPEG_GPU_ENTROPY=0)

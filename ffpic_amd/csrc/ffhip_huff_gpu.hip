@@ -20,12 +20,15 @@
 #endif
 #include "ffhip_entropy_internal.h"
 
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
 #include <thread>
 #include <vector>
+#include <memory>
+#include <new>
 #include <type_traits>
 
 struct HuffImage {
@@ -398,7 +401,16 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     const bool times = FFHIP_ENV("FFHIP_HUFF_TIMES") != nullptr; /* host phases on stderr */
     const auto T0 = std::chrono::steady_clock::now();
     /* ---- host, pictures over threads: headers, tables, restart-interval starts ---- */
-    std::vector<struct jpeg_hdr> hdr((size_t)n);
+    /* (not a std::vector: that would zero 20 KB a file on this thread before the parsing threads start -- 84 MB and 10 ms for 4 096 thumbnails -- and
+     * ffhip_jpeg_parse clears its record itself) */
+    static thread_local std::unique_ptr<struct jpeg_hdr[]> hdr_keep; /* kept between calls: 84 MB of fresh pages, and their return, are milliseconds */
+    static thread_local size_t hdr_cap = 0;
+    if ((size_t)n > hdr_cap) {
+        hdr_keep.reset(new (std::nothrow) struct jpeg_hdr[(size_t)n + (size_t)n / 4]);
+        hdr_cap = hdr_keep ? (size_t)n + (size_t)n / 4 : 0;
+        if (!hdr_keep) return FFHIP_ENOMEM;
+    }
+    struct jpeg_hdr *const hdr = hdr_keep.get();
     std::vector<std::vector<uint32_t>> segs((size_t)n);
     std::vector<std::vector<uint32_t>> raws((size_t)n); /* per picture: its intervals' own lengths */
     parallel_for(n, n_threads, [&](int i) {
@@ -429,7 +441,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     std::vector<const struct huff *> uniq;
     auto table_id = [&](const struct huff *t) -> uint32_t {
         for (size_t u = uniq.size(); u-- > 0;) /* newest first: the previous picture's are the likely match */
-            if (uniq[u] == t || !memcmp(uniq[u], t, sizeof(struct huff))) return (uint32_t)u;
+            if (uniq[u] == t || !memcmp(&uniq[u]->maxcode, &t->maxcode, offsetof(struct huff, fast) - offsetof(struct huff, maxcode))) return (uint32_t)u; /* (look[] and fast[] follow from the rest) */
         uniq.push_back(t);
         return (uint32_t)(uniq.size() - 1);
     };

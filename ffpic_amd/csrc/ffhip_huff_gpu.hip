@@ -514,10 +514,11 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     if (!g_huff_ev[0] && (hipEventCreate(&g_huff_ev[0]) != hipSuccess || hipEventCreate(&g_huff_ev[1]) != hipSuccess)) { (void)hipGetLastError(); g_huff_ev[0] = nullptr; }
     int n_parts = n >= 32 ? 4 : 1;
     if (use_sync) {
-        /* parts of about a hundred files -- a round over fewer subsequences fills the chip badly, and what is left to wait for behind the last upload are the
-         * last part's kernels: 256 4K files 13.7-14.0 ms in three parts, 14.0-14.5 in four, 14.2 in two, 14.4-14.5 in six (and 14.7-14.9 in four of
+        /* parts of about 140 MB of scan bytes, a hundred 4K files -- a round over fewer subsequences fills the chip badly, and what is left to wait for
+         * behind the last upload are the last part's kernels: 256 4K files 13.7-14.0 ms in three parts, 14.0-14.5 in four, 14.2 in two, 14.4-14.5 in six (and 14.7-14.9 in four of
          * 1/8, 3/8, 3/8, 1/8 of the files, which looked good on paper) */
-        n_parts = n < 32 ? 1 : (n + 64) / 96 < 2 ? 2 : (n + 64) / 96 > SYNC_PARTS ? SYNC_PARTS : (n + 64) / 96;
+        const int by_bytes = (int)((scan_total + (70u << 20)) / (140u << 20)); /* (by bytes, not by files: 4 096 thumbnails are a hundred megabytes) */
+        n_parts = n < 32 || scan_total < (16u << 20) ? 1 : by_bytes < 2 ? 2 : by_bytes > SYNC_PARTS ? SYNC_PARTS : by_bytes;
         const char *e = FFHIP_ENV("FFHIP_JPEG_SYNC_PARTS"); /* parts of the batch that are staged, sent and decoded one behind the other (1..8) */
         if (e && atoi(e) >= 1) n_parts = atoi(e) > SYNC_PARTS ? SYNC_PARTS : atoi(e);
         if (n_parts > n) n_parts = n;

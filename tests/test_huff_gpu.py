@@ -102,12 +102,13 @@ def _pixels(files, **env):
 
 @pytest.mark.parametrize("n", [1, 5, 40, 130, 300])
 def test_plain_files_to_pixels_in_parts(n):
-    """files without restart markers -> BGRA on the device: the batch goes in parts of about a hundred files (two from 32 files on), every
+    """files without restart markers -> BGRA on the device: the batch goes in parts (of about 140 MB of scan bytes by default; forced here), every
     part's reconstruction enqueued by the entropy call behind the part's write pass.  Same pixels as with the entropy decode on the host."""
     files = [_plain_file((64, 96), 70 + (i % 4) * 7, seed=i % 9, optimize=bool(i % 3 == 0)) for i in range(n)]
     want = _pixels(files, FFHIP_JPEG_GPU_ENTROPY=0)
-    got = _pixels(files)
-    assert np.array_equal(got, want)
+    assert np.array_equal(_pixels(files), want)                                   # (a few megabytes: one part by default)
+    for parts in (2, 3, 5):
+        assert np.array_equal(_pixels(files, FFHIP_JPEG_SYNC_PARTS=parts), want), parts
 
 
 def test_batch_of_files_with_and_without_restart_markers():

@@ -140,7 +140,13 @@ extern "C" int ffhip_jpeg_decode_files(const uint8_t *const *files, const size_t
         const char *sy = FFHIP_ENV("FFHIP_JPEG_SYNC");
         gpu_entropy = !(sy && sy[0] == '0') || ffhip_jpeg_probe_restart(files[0], lens[0]) > 0 || n >= 1024;
     }
-    if (chunk <= 0) chunk = gpu_entropy ? 32 : 8;
+    if (chunk <= 0) {
+        /* a chunk is a device call and a stream sync: 32 pictures of 4K (a gigabyte of BGRA per slot), and as many small pictures as make 256 MB of BGRA
+         * -- 1 024 thumbnails of 256x256, not 32 */
+        chunk = gpu_entropy ? 32 : 8;
+        const int64_t px = width * height * 4;
+        if (gpu_entropy && px > 0 && (256ll << 20) / px > chunk) chunk = (int)((256ll << 20) / px > 4096 ? 4096 : (256ll << 20) / px);
+    }
     if (chunk > n) chunk = n;
     const size_t mcus = (size_t)g.mcu_cols * g.mcu_rows;
     const size_t yb = mcus * g.h * g.v * 64, cb = g.ncomp == 3 ? mcus * 64 : 0; /* int16 elements per picture */

@@ -535,7 +535,8 @@ int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const size_t *lens
 int ffhip_debug_huff_times(double out[8]);
 
 /* Files in, pixels out (f1 + the hot path + f2's producer side): n baseline JPEG files of ONE geometry are
- * entropy-decoded `chunk` pictures at a time (0 = default) -- on the device (ffhip_jpeg_entropy_batch_gpu), or, when that
+ * entropy-decoded `chunk` pictures at a time (0 = default: 32 pictures, or as many small ones as make 256 MB of BGRA; 8 with the
+ * host decoder) -- on the device (ffhip_jpeg_entropy_batch_gpu), or, when that
  * refuses a chunk or FFHIP_JPEG_GPU_ENTROPY=0 says so, by n_threads host threads into pinned memory -- while the
  * previous chunk is copied to the device, reconstructed by one launch and copied back -- a double-buffered
  * pipeline whose steady state is the slower of host entropy decode and PCIe.  bgra is HOST memory,

@@ -384,6 +384,16 @@ struct SyncJob {
 static int huff_sync_enqueue(SyncJob &job, void *stream, uint32_t **h_cnt);
 static int huff_sync_finish(SyncJob &job, void *stream, uint32_t *h_cnt, int *status);
 
+/* the header records of a batch, kept by the thread between calls (84 MB of fresh pages for 4 096 files, and their return, are milliseconds);
+ * ffhip_release_caches lets the calling thread's go */
+static thread_local std::unique_ptr<struct jpeg_hdr[]> hdr_keep;
+static thread_local size_t hdr_cap = 0;
+extern "C" void ffhip_huff_release_thread(void)
+{
+    hdr_keep.reset();
+    hdr_cap = 0;
+}
+
 extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const size_t *lens, int n, int n_threads,
                                             const ffhip_jpeg_geom *geom, int16_t *d_coef_y, int16_t *d_coef_u, int16_t *d_coef_v,
                                             uint16_t *d_quant, int *status, void *stream)
@@ -403,8 +413,6 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     /* ---- host, pictures over threads: headers, tables, restart-interval starts ---- */
     /* (not a std::vector: that would zero 20 KB a file on this thread before the parsing threads start -- 84 MB and 10 ms for 4 096 thumbnails -- and
      * ffhip_jpeg_parse clears its record itself) */
-    static thread_local std::unique_ptr<struct jpeg_hdr[]> hdr_keep; /* kept between calls: 84 MB of fresh pages, and their return, are milliseconds */
-    static thread_local size_t hdr_cap = 0;
     if ((size_t)n > hdr_cap) {
         hdr_keep.reset(new (std::nothrow) struct jpeg_hdr[(size_t)n + (size_t)n / 4]);
         hdr_cap = hdr_keep ? (size_t)n + (size_t)n / 4 : 0;

@@ -22,7 +22,7 @@ EXPORTS = [
     "ffhip_vp8_residual_batch", "ffhip_hevc_residual_batch", "ffhip_vp8_predict_recon",
     "ffhip_hevc_intra_recon", "ffhip_hevc_intra_plan", "ffhip_debug_hevc_plan_result", "ffhip_vp8_decode_frames_form", "ffhip_debug_huff_times", "ffhip_hevc_intra_recon_tiles", "ffhip_hevc_decode_tiles", "ffhip_vp8_loopfilter",
     "ffhip_jpeg_probe", "ffhip_jpeg_entropy_decode", "ffhip_jpeg_entropy_decode_mt", "ffhip_jpeg_entropy_batch", "ffhip_bmp_write",
-    "ffhip_heif_grid_parse", "ffhip_heif_grid_compose", "ffhip_hevc_picture_layout", "ffhip_jpeg_decode_files", "ffhip_jpeg_decode_files_device", "ffhip_jpeg_entropy_batch_gpu", "ffhip_jpeg_stage_scan_test", "ffhip_host_malloc", "ffhip_host_free",
+    "ffhip_heif_grid_parse", "ffhip_heif_grid_compose", "ffhip_hevc_picture_layout", "ffhip_jpeg_decode_files", "ffhip_jpeg_decode_files_device", "ffhip_jpeg_entropy_batch_gpu", "ffhip_jpeg_stage_scan_test", "ffhip_jpeg_stage_scan_raw_test", "ffhip_jpeg_lut_test", "ffhip_host_malloc", "ffhip_host_free",
     "ffhip_shard_range", "ffhip_comm_unique_id", "ffhip_comm_init_rank", "ffhip_comm_destroy", "ffhip_batch_close", "ffhip_batch_complete",
     "ffhip_bgra_checksum", "ffhip_vp8_filter_params", "ffhip_vp8_predict_loopfilter", "ffhip_reload_env", "ffhip_env_value_test", "ffhip_vp8_decode_frames", "ffhip_bgra_layout",
 ]

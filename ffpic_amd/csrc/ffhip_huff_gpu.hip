@@ -345,6 +345,26 @@ extern "C" int ffhip_jpeg_stage_scan_test(uint8_t *dst, const uint8_t *src, size
     return (int)stage_scan(dst, src, src + len, seg, n_seg, clean_len);
 }
 
+/* The same with the intervals' own lengths (without padding) in raw[0 .. n_seg): what the subsequence decoder cuts into lanes. */
+extern "C" int ffhip_jpeg_stage_scan_raw_test(uint8_t *dst, const uint8_t *src, size_t len, uint32_t *seg, uint32_t n_seg, size_t *clean_len, uint32_t *raw)
+{
+    if (!dst || !src || !seg || !clean_len || !raw || n_seg == 0) return FFHIP_EINVAL;
+    return (int)stage_scan(dst, src, src + len, seg, n_seg, clean_len, raw);
+}
+/* Test hook (host only): the two-level look-up table the device kernels use for Huffman table `which` (0..3 DC, 4..7 AC) of a file, LUT_WORDS = 1536
+ * uint16 (build_lut above).  FFHIP_EINVAL if the file does not parse or has no such table. */
+extern "C" int ffhip_jpeg_lut_test(const uint8_t *file, size_t len, int which, uint16_t *out)
+{
+    if (!file || !out || which < 0 || which > 7) return FFHIP_EINVAL;
+    std::unique_ptr<struct jpeg_hdr> j(new (std::nothrow) struct jpeg_hdr);
+    if (!j) return FFHIP_ENOMEM;
+    if (ffhip_jpeg_parse(file, len, j.get())) return FFHIP_EINVAL;
+    const struct huff &h = which < 4 ? j->dc[which] : j->ac[which - 4];
+    if (!h.present) return FFHIP_EINVAL;
+    build_lut(h, out);
+    return FFHIP_OK;
+}
+
 /* what the calling thread's last ffhip_jpeg_entropy_batch_gpu call spent where (bench.py's configs.f1): microseconds of host time per phase,
  * and the Huffman kernel's own time by HIP events on the call's stream */
 static thread_local double g_huff_times[8] = {0, 0, 0, 0, 0, 0, 0, 0};

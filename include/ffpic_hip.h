@@ -513,6 +513,13 @@ int ffhip_jpeg_entropy_batch(const uint8_t *const *files, const size_t *lens, in
  * dst must hold len + 8 * n_seg + 64 bytes.  The reference's counterpart is the byte loop of read_compressed_scan
  * (format/jpg.c:588-637). */
 int ffhip_jpeg_stage_scan_test(uint8_t *dst, const uint8_t *src, size_t len, uint32_t *seg, uint32_t n_seg, size_t *clean_len);
+/* the same, and raw[k] = the bytes of interval k without its padding (what the subsequence decoder cuts into lanes of 2048 bits) */
+int ffhip_jpeg_stage_scan_raw_test(uint8_t *dst, const uint8_t *src, size_t len, uint32_t *seg, uint32_t n_seg, size_t *clean_len, uint32_t *raw);
+/* Test hook (needs no device): the two-level look-up table the device Huffman kernels use for table `which` (0..3 DC, 4..7 AC) of a file, 1536 uint16:
+ * [0..511] by the next 9 bits: (length << 8) | symbol, or 0x8000 | g for a prefix of longer codes; [512 + 128 g + b] group g by the 7 bits behind
+ * the prefix; 0x5000 = no code starts with these bits (a table that holds all its codes says so itself); 0 = take the canonical-code walk.  The
+ * reference's counterpart is huffman_decode_symbol (coding/huffman.c:92-222). */
+int ffhip_jpeg_lut_test(const uint8_t *file, size_t len, int which, uint16_t *out);
 
 /* The same front end ON the device: decodes straight into DEVICE planes (d_coef_*, d_quant [n][4][64]) laid out for
  * ffhip_jpeg_recon_batch with quant_stride 256; the host only parses headers, finds the RSTn markers and unstuffs the

@@ -44,7 +44,7 @@ def test_dri_fixture():
 
 
 def test_files_without_restart_markers():
-    """no DRI: the scan is cut into 1024-bit subsequences, a lane each, that synchronise with each other (round 5)"""
+    """no DRI: the scan is cut into subsequences of 2048 bits, a lane each, that synchronise with each other (round 5)"""
     for name in ("file_q85_420.jpg", "file_q92_444.jpg", "file_q80_grey.jpg", "file_q85_411.jpg", "file_q85_114.jpg", "file_q88_422.jpg"):
         data = open(os.path.join(GOLDEN, name), "rb").read()
         same_planes([data])

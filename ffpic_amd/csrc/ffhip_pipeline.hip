@@ -132,8 +132,8 @@ extern "C" int ffhip_jpeg_decode_files(const uint8_t *const *files, const size_t
     if (g.mcu_cols <= 0 || g.mcu_rows <= 0) return FFHIP_EINVAL; /* workspace_bytes is 0 for a geometry it rejects, too */
     if (ffhip_jpeg_workspace_bytes(&g, 1) != 0) return FFHIP_EINVAL; /* one component with several blocks per MCU: not here */
     if (!ffhip_have_device()) return FFHIP_ENODEV;
-    /* restart markers in the first file: try the device-side entropy decoder (FFHIP_JPEG_GPU_ENTROPY=0 keeps it off).
-     * Its latency per batch is that of ONE restart interval, so it wants large chunks */
+    /* the entropy decode runs on the device (FFHIP_JPEG_GPU_ENTROPY=0 keeps it off): the subsequence decoder, whatever the files' restart markers; with
+     * FFHIP_JPEG_SYNC=0, round 4's kernel -- a lane per restart interval, its latency per batch that of ONE interval --, for files that have markers */
     const char *ge = FFHIP_ENV("FFHIP_JPEG_GPU_ENTROPY");
     bool gpu_entropy = !(ge && ge[0] == '0');
     if (gpu_entropy && !(ge && ge[0] == '1')) { /* "1" forces it; default: always, unless files without restart markers are to be one lane each (FFHIP_JPEG_SYNC=0) */

@@ -461,7 +461,20 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     /* the subsequence decoder: a lane per 2048 bits of a restart interval (of the whole scan, in a file without restart markers), brought into step with
      * each other over rounds.  FFHIP_JPEG_SYNC=0: the kernel above, a lane per restart interval -- a file without markers is ONE lane's then */
     const char *sy = FFHIP_ENV("FFHIP_JPEG_SYNC");
-    const bool use_sync = !(sy && sy[0] == '0');
+    bool use_sync = !(sy && sy[0] == '0');
+    if (use_sync && !(sy && sy[0] == '1')) {
+        /* restart intervals of a subsequence or two (a DRI of one or a few MCUs: 32 400 intervals in a 4K picture) are lanes enough as they are, every
+         * one starting from the truth: three passes, a 60-byte record per interval and rounds that have nothing to settle are the wrong tool; the kernel
+         * above takes such batches (FFHIP_JPEG_SYNC=1 keeps the subsequence decoder on them) */
+        const char *b = FFHIP_ENV("FFHIP_JPEG_SYNC_BITS");
+        const long sb = b ? atol(b) : 2048;
+        unsigned long long bits = 0, n_int = 0;
+        for (int i = 0; i < n; i++) {
+            bits += 8ull * hdr[(size_t)i].scan_len;
+            n_int += segs[(size_t)i].size() - 1;
+        }
+        if (bits <= 2ull * (unsigned long long)(sb < 128 ? 128 : sb) * n_int) use_sync = false;
+    }
     const auto T1 = std::chrono::steady_clock::now();
     /* ---- layout of the one upload: scan bytes | tables | picture records | interval starts | work list | status ---- */
     std::vector<HuffImage> images((size_t)n);

@@ -20,7 +20,7 @@ def form(request, monkeypatch):
     if request.param == "lane_per_interval":
         monkeypatch.setenv("FFHIP_JPEG_SYNC", "0")
     else:
-        monkeypatch.delenv("FFHIP_JPEG_SYNC", raising=False)
+        monkeypatch.setenv("FFHIP_JPEG_SYNC", "1")      # (unset, batches whose restart intervals are a subsequence or two long take the other kernel)
     capi.reload_env()
     yield request.param
     monkeypatch.undo()
@@ -431,3 +431,20 @@ def test_three_threads_each_on_its_own_stream():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_short_restart_intervals_take_the_lane_per_interval_kernel_by_default(monkeypatch):
+    """a DRI of one MCU: thousands of intervals of a few dozen bytes.  As shipped (FFHIP_JPEG_SYNC unset) such a batch goes to the lane-per-interval kernel
+    -- every interval is a lane that starts from the truth --; forced either way it decodes to the same planes"""
+    files = [_good_dri_file(blocks=1, size=(128, 160))] * 3
+    assert files[0].count(b"\xff\xd0") > 5
+    monkeypatch.delenv("FFHIP_JPEG_SYNC", raising=False)
+    capi.reload_env()
+    want = ops.jpeg_entropy_batch_gpu(files)
+    same_planes(files)
+    for v in ("0", "1"):
+        monkeypatch.setenv("FFHIP_JPEG_SYNC", v)
+        capi.reload_env()
+        got = ops.jpeg_entropy_batch_gpu(files)
+        for a, b in zip(got[1:], want[1:]):
+            assert np.array_equal(a, b), v

@@ -527,7 +527,8 @@ int ffhip_jpeg_lut_test(const uint8_t *file, size_t len, int which, uint16_t *ou
  * -- of the whole scan, in a file without DRI -- and the lanes are brought into step with each other over a few rounds
  * (Huffman-coded data self-synchronises; DESIGN.md 5 "The subsequence decoder"), so files need no restart markers to decode
  * in parallel, and a batch may mix files with and without.  FFHIP_JPEG_SYNC=0: the kernel of rounds 3-4, one lane per restart
- * interval (a file without DRI is ONE lane's then: for batches of a thousand files or more only).
+ * interval (a file without DRI is ONE lane's then: for batches of a thousand files or more only); unset, that kernel also takes
+ * the batches whose restart intervals are a subsequence or two long (a DRI of a few MCUs); =1 keeps the subsequence decoder on those.
  * FFHIP_EINVAL for a file of another geometry, and for a damaged or truncated scan (status[] says which picture; nothing of
  * the batch is to be used then -- ffhip_jpeg_decode_files* fall back to the host decoder).  Synchronises `stream` (the
  * per-picture verdicts come back with it). */

@@ -448,3 +448,33 @@ def test_short_restart_intervals_take_the_lane_per_interval_kernel_by_default(mo
         got = ops.jpeg_entropy_batch_gpu(files)
         for a, b in zip(got[1:], want[1:]):
             assert np.array_equal(a, b), v
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_geometries_qualities_and_restart_intervals(seed):
+    """a soak over what an encoder can be asked for: random sizes (down to less than an MCU), qualities 3..100, 4:4:4 / 4:2:2 / 4:2:0 / grey, the encoder's
+    or optimised tables, no restart markers / every block / every few blocks / every MCU row -- batches of four files of one geometry with different content,
+    the device decoder's planes against the host decoder's"""
+    PIL = pytest.importorskip("PIL.Image")
+    from PIL import ImageFile
+    ImageFile.MAXBLOCK = max(ImageFile.MAXBLOCK, 1 << 22)      # (the encoder's output buffer: optimised tables on a noisy picture overrun the default)
+    rng = np.random.default_rng(1000 + seed)
+    h, w = int(rng.integers(1, 420)), int(rng.integers(1, 640))
+    mode = "L" if rng.random() < 0.2 else "RGB"
+    kw = dict(quality=int(rng.choice([3, 15, 40, 75, 90, 97, 100])), optimize=bool(rng.random() < 0.4))
+    if mode == "RGB":
+        kw["subsampling"] = int(rng.integers(0, 3))
+    r = rng.random()
+    if r < 0.25:
+        kw["restart_marker_blocks"] = int(rng.integers(1, 12))
+    elif r < 0.4:
+        kw["restart_marker_rows"] = int(rng.integers(1, 4))
+    files = []
+    for i in range(4):
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.stack([128 + 100 * np.sin(xx / (3.0 + 5 * i) + seed), 128 + 90 * np.cos(yy / (2.0 + 3 * i)), (xx * (3 + i) + yy * 5) % 256], axis=2)
+        img = np.clip(img + rng.normal(0, float(rng.choice([0, 5, 30, 80])), img.shape), 0, 255).astype(np.uint8)
+        bio = io.BytesIO()
+        PIL.fromarray(img).convert(mode).save(bio, "JPEG", **kw)
+        files.append(bio.getvalue())
+    same_planes(files)

@@ -748,7 +748,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
  *   write       every lane decodes its subsequence once more, now storing coefficients.
  * The host does what it does for the files with markers: headers, tables, unstuffing into pinned memory.
  * ===================================================================================================================== */
-#define SYNC_ROUNDS_MAX 32 /* list rounds per batch of launches; FFHIP_JPEG_SYNC_ROUNDS (1..32), 6 unless set */
+#define SYNC_ROUNDS_MAX 32 /* list rounds per batch of launches; FFHIP_JPEG_SYNC_ROUNDS (1..32), 10 unless set */
 
 struct SyncImage {
     uint32_t scan_off;   /* byte offset of the picture's unstuffed scan inside `scan` (16-byte aligned) */
@@ -1204,10 +1204,16 @@ static int huff_sync_enqueue(SyncJob &job, void *stream, uint32_t **h_cnt)
     const size_t n = job.n_segs; /* "pictures" of the kernels: the intervals */
     {
         const char *e = FFHIP_ENV("FFHIP_JPEG_SYNC_ROUNDS");
-        const int r = e ? atoi(e) : 6;
+        const int r = e ? atoi(e) : 10;
         job.rounds = (uint32_t)(r < 1 ? 1 : r > SYNC_ROUNDS_MAX ? SYNC_ROUNDS_MAX : r);
         const char *b = FFHIP_ENV("FFHIP_JPEG_SYNC_BITS"); /* bits of a subsequence */
-        const int sb = b ? atoi(b) : 2048;
+        /* unless set: by the bits an MCU takes in this part.  A wrong block state is put right over a few MCUs, and every subsequence it survives is
+         * a round -- of a sparse kernel that takes as long as one lane takes for its subsequence: 128 4K files of quality 95 (1 500 bits an MCU) 11 rounds
+         * and 29 ms at 2 048 bits, 6 rounds and 24 ms at 4 096; quality 100 on noise (2 800 bits an MCU, hardly an end-of-block anywhere) 59 rounds and
+         * 91 ms at 2 048, 16 and 71 at 8 192.  Longer subsequences than that lose more in the sparse rounds than they save in their number. */
+        uint64_t bits = 0, mcus = 0;
+        for (size_t i = 0; i < job.n_segs; i++) { bits += 8ull * job.segs[i].raw_len; mcus += job.segs[i].mcus; }
+        const int sb = b ? atoi(b) : bits <= 1024 * mcus ? 2048 : bits <= 2048 * mcus ? 4096 : 8192;
         job.sub_bits = (uint32_t)(sb < 128 ? 128 : sb > 65536 ? 65536 : sb);
     }
     uint64_t tasks = 0;

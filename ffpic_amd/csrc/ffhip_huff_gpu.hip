@@ -373,6 +373,8 @@ static thread_local hipEvent_t g_huff_ev[2] = {nullptr, nullptr};
 thread_local FfhipHuffThen g_ffhip_huff_then = {0, nullptr, 0, 0};
 static thread_local hipStream_t g_huff_up = nullptr;       /* the subsequence decoder's uploads */
 static thread_local hipEvent_t g_huff_part_ev[SYNC_PARTS];
+static thread_local hipStream_t g_huff_c2 = nullptr;       /* every other part's kernels: a part's sparse rounds under the next part's full ones */
+static thread_local hipEvent_t g_huff_fork = nullptr, g_huff_join = nullptr;
 extern "C" int ffhip_debug_huff_times(double out[8])
 {
     if (!out) return FFHIP_EINVAL;
@@ -391,6 +393,7 @@ struct SyncJob {
     uint8_t *dev;                 /* the call's device image: scan bytes, tables, look-up tables, status */
     size_t o_tabs, o_l12, o_status;
     int n, part;                  /* pictures of the part */
+    void *stream;                 /* the stream the part's kernels are on */
     const HuffImage *images;      /* tables and block counts as for the kernel above */
     const SyncSeg *segs;
     size_t n_segs;
@@ -565,6 +568,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         if (n_parts > n) n_parts = n;
     }
     SyncJob jobs[SYNC_PARTS];
+    bool two_streams = false;
     std::vector<SyncSeg> part_segs[SYNC_PARTS];
     uint32_t *h_cnt[SYNC_PARTS];
     if (use_sync) {
@@ -574,11 +578,20 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
             if (hipStreamCreateWithFlags(&g_huff_up, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); g_huff_up = nullptr; return FFHIP_EIO; }
             for (int k = 0; k < SYNC_PARTS; k++)
                 if (hipEventCreateWithFlags(&g_huff_part_ev[k], hipEventDisableTiming) != hipSuccess) return FFHIP_EIO;
+            if (hipStreamCreateWithFlags(&g_huff_c2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&g_huff_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&g_huff_join, hipEventDisableTiming) != hipSuccess) return FFHIP_EIO;
         }
         for (int i = 0; i < n; i++) memcpy(stage + o_quant + (size_t)i * 512, hdr[(size_t)i].quant, 512);
         const int rc = tail_up();
         if (rc) return rc;
         if (g_huff_ev[0]) (void)hipEventRecord(g_huff_ev[0], st);
+        /* the parts' kernels alternate between the caller's stream and one of the library's: the list rounds of a part are a handful of sparse kernels
+         * that each take as long as one lane takes for its subsequence, and run under the next part's full rounds instead of in front of them
+         * (FFHIP_JPEG_SYNC_STREAMS=1: all on the caller's) */
+        const char *ss = FFHIP_ENV("FFHIP_JPEG_SYNC_STREAMS");
+        two_streams = n_parts > 1 && !(ss && ss[0] == '1');
+        if (two_streams) FFHIP_CHECK(hipEventRecord(g_huff_fork, st), FFHIP_EIO); /* behind the plane clears, the tables and the quantiser copy */
+        if (two_streams) FFHIP_CHECK(hipStreamWaitEvent(g_huff_c2, g_huff_fork, 0), FFHIP_EIO);
     }
     auto part_lo = [&](int part) -> int { return (int)((long long)n * part / n_parts); };
     for (int part = 0; part < n_parts; part++) {
@@ -612,8 +625,10 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         } else {
             SyncJob &job = jobs[part];
             int rc = FFHIP_OK;
+            void *const pstream = two_streams && (part & 1) ? (void *)g_huff_c2 : stream; /* this part's kernels */
+            job.stream = pstream;
             if (hipMemcpyAsync(dev + b0, stage + b0, b1 - b0, hipMemcpyHostToDevice, g_huff_up) != hipSuccess || hipEventRecord(g_huff_part_ev[part], g_huff_up) != hipSuccess ||
-                hipStreamWaitEvent(st, g_huff_part_ev[part], 0) != hipSuccess) rc = FFHIP_EIO;
+                hipStreamWaitEvent((hipStream_t)pstream, g_huff_part_ev[part], 0) != hipSuccess) rc = FFHIP_EIO;
             if (!rc) {
                 job.dev = dev; job.o_tabs = o_tabs; job.o_l12 = o_l12; job.o_status = o_status + (size_t)p_lo * 4; job.n = p_hi - p_lo; job.part = part;
                 job.images = images.data() + p_lo;
@@ -636,17 +651,18 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
                 }
                 job.segs = part_segs[part].data();
                 job.n_segs = part_segs[part].size();
-                if (rc) { (void)hipStreamSynchronize(g_huff_up); (void)hipStreamSynchronize(st); return rc; }
+                if (rc) { (void)hipStreamSynchronize(g_huff_up); (void)hipStreamSynchronize(g_huff_c2); (void)hipStreamSynchronize(st); return rc; }
                 job.plane[0] = d_coef_y + (size_t)p_lo * mcus * images[0].nb[0] * 64;
                 job.plane[1] = d_coef_u ? d_coef_u + (size_t)p_lo * mcus * images[0].nb[1] * 64 : nullptr;
                 job.plane[2] = d_coef_v ? d_coef_v + (size_t)p_lo * mcus * images[0].nb[2] * 64 : nullptr;
-                rc = huff_sync_enqueue(job, stream, &h_cnt[part]);
+                rc = huff_sync_enqueue(job, pstream, &h_cnt[part]);
                 if (!rc && then.on) /* the part's pictures: coefficients -> BGRA while the next part's bytes come up */
                     rc = ffhip_jpeg_recon_batch(geom, p_hi - p_lo, job.plane[0], job.plane[1], job.plane[2], d_quant + (size_t)p_lo * 256, 256,
-                                                then.bgra + (int64_t)p_lo * then.image_stride, then.pitch, then.image_stride, nullptr, 0, stream);
+                                                then.bgra + (int64_t)p_lo * then.image_stride, then.pitch, then.image_stride, nullptr, 0, pstream);
             }
             if (rc) { /* nothing of this call may be in flight when its buffers are handed back */
                 (void)hipStreamSynchronize(g_huff_up);
+                (void)hipStreamSynchronize(g_huff_c2);
                 (void)hipStreamSynchronize(st);
                 (void)hipGetLastError();
                 return rc;
@@ -654,6 +670,10 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         }
     }
     } /* parts */
+    if (two_streams) { /* the caller's stream is behind everything again */
+        FFHIP_CHECK(hipEventRecord(g_huff_join, g_huff_c2), FFHIP_EIO);
+        FFHIP_CHECK(hipStreamWaitEvent(st, g_huff_join, 0), FFHIP_EIO);
+    }
     for (int i = 0; i < n; i++)
         if (status[i]) { /* a file whose restart markers do not add up: nothing is decoded */
             (void)hipStreamSynchronize(st);
@@ -713,10 +733,12 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         for (int part = 0; part < n_parts; part++) {
             SyncJob &job = jobs[part];
             const int p_lo = (int)((job.o_status - o_status) / 4);
-            int rc = huff_sync_finish(job, stream, h_cnt[part], status + p_lo);
-            if (!rc && job.reran && then.on) /* the part's passes ran only now: so must its reconstruction */
+            int rc = huff_sync_finish(job, job.stream, h_cnt[part], status + p_lo);
+            if (!rc && job.reran && then.on) { /* the part's passes ran only now: so must its reconstruction (and the caller's stream be behind it) */
                 rc = ffhip_jpeg_recon_batch(geom, job.n, job.plane[0], job.plane[1], job.plane[2], d_quant + (size_t)p_lo * 256, 256,
-                                            then.bgra + (int64_t)p_lo * then.image_stride, then.pitch, then.image_stride, nullptr, 0, stream);
+                                            then.bgra + (int64_t)p_lo * then.image_stride, then.pitch, then.image_stride, nullptr, 0, job.stream);
+                if (!rc && job.stream != stream && hipStreamSynchronize((hipStream_t)job.stream) != hipSuccess) rc = FFHIP_EIO;
+            }
             if (rc) return rc;
             if (times) fprintf(stderr, "huff sync, part %d: %u subsequences of %u bits, %u rounds\n", part, job.n_tasks, job.sub_bits, job.rounds_used);
         }

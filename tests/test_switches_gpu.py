@@ -126,16 +126,17 @@ def test_plain_files_one_lane_each_and_few_rounds(switch):
     """FFHIP_JPEG_SYNC=0: a file without restart markers is one lane's (round 4's form, for batches of thousands); FFHIP_JPEG_SYNC_ROUNDS: the
     list rounds are launched one (two) at a time, the host looks whether they reached their fixed point and launches more -- the path a scan takes that does
     not settle within the ten rounds launched at once; FFHIP_JPEG_SYNC_BITS: the length of a subsequence, 128 bits (a few symbols, hardly ever in step
-    after one) to the whole scan in one; FFHIP_JPEG_SYNC_PARTS: the parts a batch is staged, sent and decoded in"""
+    after one) to the whole scan in one; FFHIP_JPEG_SYNC_PARTS: the parts a batch is staged, sent and decoded in (their kernels alternate between the caller's stream and one of
+    the library's; FFHIP_JPEG_SYNC_STREAMS=1: all on the caller's)"""
     from test_huff_gpu import _plain_file, same_planes
     files = [_plain_file((360, 640), 85, seed=i) for i in range(3)] + [_plain_file((360, 640), 60, seed=i) for i in range(6)]
     want = ops.jpeg_entropy_batch_gpu(files)
     for env in ({"FFHIP_JPEG_SYNC": 0}, {"FFHIP_JPEG_SYNC_ROUNDS": 1}, {"FFHIP_JPEG_SYNC_ROUNDS": 2}, {"FFHIP_JPEG_SYNC_ROUNDS": 32}, {"FFHIP_JPEG_SYNC_BITS": 128},
                 {"FFHIP_JPEG_SYNC_BITS": 128, "FFHIP_JPEG_SYNC_ROUNDS": 1}, {"FFHIP_JPEG_SYNC_BITS": 4096}, {"FFHIP_JPEG_SYNC_BITS": 65536}, {"FFHIP_JPEG_SYNC_PARTS": 1},
-                {"FFHIP_JPEG_SYNC_PARTS": 3}, {"FFHIP_JPEG_SYNC_PARTS": 8}):
+                {"FFHIP_JPEG_SYNC_PARTS": 3}, {"FFHIP_JPEG_SYNC_PARTS": 8}, {"FFHIP_JPEG_SYNC_PARTS": 4, "FFHIP_JPEG_SYNC_STREAMS": 1}):
         switch(**env)
         got = ops.jpeg_entropy_batch_gpu(files)
         for a, b in zip(got[1:], want[1:]):
             assert np.array_equal(a, b), env
         same_planes(files)
-        switch(FFHIP_JPEG_SYNC=1, FFHIP_JPEG_SYNC_ROUNDS=10, FFHIP_JPEG_SYNC_BITS=2048, FFHIP_JPEG_SYNC_PARTS=0)
+        switch(FFHIP_JPEG_SYNC=1, FFHIP_JPEG_SYNC_ROUNDS=10, FFHIP_JPEG_SYNC_BITS=2048, FFHIP_JPEG_SYNC_PARTS=0, FFHIP_JPEG_SYNC_STREAMS=0)

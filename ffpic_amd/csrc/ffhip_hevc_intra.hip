@@ -30,6 +30,10 @@
 #include <cstring>
 #include <thread>
 #include <vector>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <new>
 
 #ifndef FFHIP_HEVC_INTRA_WAVES
 #define FFHIP_HEVC_INTRA_WAVES 256 /* waves of the grouped form's one launch: enough for the widest wavefront of an 8K picture (~200 groups)
@@ -2393,6 +2397,43 @@ extern "C" int ffhip_hevc_intra_recon(const ffhip_hevc_tu *h_tus, const ffhip_he
 #define SCRATCH_HEVC_TILES_JT 20
 #define SCRATCH_HEVC_TILES_CHUNK 21 /* .. + 3 */
 #define SCRATCH_HEVC_TILES_ONE 25   /* .. + 1 */
+/* Who used a one-chunk scratch last: the scratch belongs to (kind, CALLER's stream), so its guard does too -- the parity of the call, and per scratch an
+ * event recorded on the caller's stream behind the call's grouped kernel.  (Kept per calling thread until round 6: a thread that alternated between two
+ * streams, or two threads on one stream, could let a pre-pass rewrite a schedule the grouped kernel of another call was still reading.)  Calls that
+ * share a stream take turns for the length of their enqueue: they share the scratch. */
+namespace {
+struct TileGuard {
+    std::mutex mu;
+    unsigned parity = 0;
+    bool recorded[2] = {false, false};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+std::mutex g_tile_guard_mu;
+std::map<void *, std::unique_ptr<TileGuard>> g_tile_guards;
+TileGuard *tile_guard_for(void *stream)
+{
+    std::lock_guard<std::mutex> l(g_tile_guard_mu);
+    std::unique_ptr<TileGuard> &g = g_tile_guards[stream];
+    if (!g) {
+        std::unique_ptr<TileGuard> n(new (std::nothrow) TileGuard);
+        if (!n) return nullptr;
+        if (hipEventCreateWithFlags(&n->ev[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&n->ev[1], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (n->ev[0]) (void)hipEventDestroy(n->ev[0]);
+            return nullptr; /* (the map keeps an empty slot: the next call tries again) */
+        }
+        g = std::move(n);
+    }
+    return g.get();
+}
+} // namespace
+extern "C" void ffhip_hevc_tiles_release(void) /* ffhip_release_caches: nothing of the library's is in flight, the scratches go as well */
+{
+    std::lock_guard<std::mutex> l(g_tile_guard_mu);
+    for (auto &e : g_tile_guards)
+        if (e.second) { (void)hipEventDestroy(e.second->ev[0]); (void)hipEventDestroy(e.second->ev[1]); }
+    g_tile_guards.clear();
+}
 extern "C" int ffhip_hevc_intra_recon_tiles(const ffhip_hevc_tu *h_tus, const ffhip_hevc_tu *d_tus, long long n_tus, const long long *tile_first, int n_tiles,
                                             const int16_t *d_residual, int16_t *d_y, int16_t *d_cb, int16_t *d_cr, int width_y, int height_y, int y_stride,
                                             int width_c, int height_c, int uv_stride, int bitdepth_y, int bitdepth_c, void *stream)
@@ -2430,27 +2471,26 @@ extern "C" int ffhip_hevc_intra_recon_tiles(const ffhip_hevc_tu *h_tus, const ff
      * finished with it: an event recorded behind every call, waited for in front of the next call that takes the same scratch.  The one-chunk form
      * alternates between TWO scratches, so the pre-pass of call n + 1 only waits for call n - 1 and runs next to the tail of call n's grouped kernel
      * (whose waves leave as the wavefront narrows), the colour conversion behind it and the next residual batches. */
-    static thread_local bool prev_recorded[2] = {false, false};
-    static thread_local unsigned call_parity = 0;
-    hipEvent_t ev_prev2[2] = {(hipEvent_t)pipe.ev[FFHIP_PIPE_EVENTS - 1], (hipEvent_t)pipe.ev[FFHIP_PIPE_EVENTS - 2]};
     if (chunks == 1) {
+        TileGuard *const guard = tile_guard_for(stream);
+        if (!guard) return FFHIP_EIO;
+        std::lock_guard<std::mutex> turn(guard->mu);
         /* ONE chunk -- the default: cutting the list does not pay (below) --, but the pre-pass does not wait for `stream`: it reads the TU list alone,
          * so it runs while the stream is still busy with what the caller enqueued in front of this call -- the residual batches of this picture, the
          * colour conversion of the picture before.  (d_tus must be COMPLETE when the call is made: see the header.) */
         const char *db = FFHIP_ENV("FFHIP_HEVC_TILE_SCRATCHES");
-        const unsigned par = (db && db[0] == '1') ? 0u : (call_parity++ & 1u);
+        const unsigned par = (db && db[0] == '1') ? 0u : (guard->parity++ & 1u);
         IntraRoles roles;
         roles.plan = (hipStream_t)pipe.plan; roles.groups = (hipStream_t)stream; roles.plan_done = (hipEvent_t)pipe.ev[2];
         roles.scratch_kind = SCRATCH_HEVC_TILES_ONE + (int)par; roles.jt_desc = nullptr; roles.big_call = n_tus >= (1LL << 17);
-        for (unsigned q = 0; q < 2; q++) /* (with one scratch: the call before; with two: the call before that -- and, for the side stream's events, nothing more) */
-            if (prev_recorded[q] && (q == par)) FFHIP_CHECK(hipStreamWaitEvent(roles.plan, ev_prev2[q], 0), FFHIP_EIO);
+        /* (with one scratch: the stream's call before; with two: the one before that) */
+        if (guard->recorded[par]) FFHIP_CHECK(hipStreamWaitEvent(roles.plan, guard->ev[par], 0), FFHIP_EIO);
         const int rc1 = intra_recon_impl(h_tus, d_tus, n_tus, d_residual, d_y, d_cb, d_cr, width_y, height_y, y_stride, width_c, height_c, uv_stride, bitdepth_y, bitdepth_c, stream,
                                          &roles);
-        if (hipEventRecord(ev_prev2[par], (hipStream_t)stream) == hipSuccess) prev_recorded[par] = true;
-        else { (void)hipGetLastError(); (void)hipStreamSynchronize((hipStream_t)stream); prev_recorded[par] = false; }
+        if (hipEventRecord(guard->ev[par], (hipStream_t)stream) == hipSuccess) guard->recorded[par] = true;
+        else { (void)hipGetLastError(); (void)hipStreamSynchronize((hipStream_t)stream); guard->recorded[par] = false; }
         return rc1;
     }
-    hipEvent_t ev_prev = ev_prev2[0];
     if (!h_tus || !d_tus || !d_y || width_y <= 0 || height_y <= 0) return FFHIP_EINVAL;
     /* the tables indexed by position in the planes, shared by the chunks: the substitution table (JT_STRIDE bytes per 4x4 block) and the per-pixel
      * program words (8 bytes per sample) -- laid out as intra_recon_impl lays them out behind its own scratch */
@@ -2488,7 +2528,7 @@ extern "C" int ffhip_hevc_intra_recon_tiles(const ffhip_hevc_tu *h_tus, const ff
     /* the caller's stream continues behind everything, whatever happened */
     if (hipEventRecord(ev_g2, s_g2) != hipSuccess || hipStreamWaitEvent(st, ev_g2, 0) != hipSuccess) return FFHIP_EIO;
     if (hipEventRecord(ev_in, s_plan) != hipSuccess || hipStreamWaitEvent(st, ev_in, 0) != hipSuccess) return FFHIP_EIO;
-    (void)ev_prev; /* (the chunked form's streams start behind `stream`, which the call before has joined everything into) */
+    /* (the chunked form's streams start behind `stream`, which the call before has joined everything into) */
     return rc;
 }
 

@@ -368,13 +368,16 @@ extern "C" int ffhip_jpeg_lut_test(const uint8_t *file, size_t len, int which, u
 /* what the calling thread's last ffhip_jpeg_entropy_batch_gpu call spent where (bench.py's configs.f1): microseconds of host time per phase,
  * and the Huffman kernel's own time by HIP events on the call's stream */
 static thread_local double g_huff_times[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-static thread_local hipEvent_t g_huff_ev[2] = {nullptr, nullptr};
-#define SYNC_PARTS 8
+#define SYNC_PARTS FFHIP_HUFF_PARTS
 thread_local FfhipHuffThen g_ffhip_huff_then = {0, nullptr, 0, 0};
-static thread_local hipStream_t g_huff_up = nullptr;       /* the subsequence decoder's uploads */
-static thread_local hipEvent_t g_huff_part_ev[SYNC_PARTS];
-static thread_local hipStream_t g_huff_c2 = nullptr;       /* every other part's kernels: a part's sparse rounds under the next part's full ones */
-static thread_local hipEvent_t g_huff_fork = nullptr, g_huff_join = nullptr;
+/* (the upload stream, the second kernel stream and the events of a call are the thread's and the device's: ffhip_huff_streams_get) */
+/* bits of a subsequence, unless FFHIP_JPEG_SYNC_BITS sets them: by the bits an MCU takes (huff_sync_enqueue has the measurements) */
+static uint32_t sync_sub_bits(unsigned long long bits, unsigned long long mcus)
+{
+    const char *b = FFHIP_ENV("FFHIP_JPEG_SYNC_BITS");
+    const long sb = b ? atol(b) : bits <= 1024 * mcus ? 2048 : bits <= 2048 * mcus ? 4096 : 8192;
+    return (uint32_t)(sb < 128 ? 128 : sb > 65536 ? 65536 : sb);
+}
 extern "C" int ffhip_debug_huff_times(double out[8])
 {
     if (!out) return FFHIP_EINVAL;
@@ -465,18 +468,17 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
      * each other over rounds.  FFHIP_JPEG_SYNC=0: the kernel above, a lane per restart interval -- a file without markers is ONE lane's then */
     const char *sy = FFHIP_ENV("FFHIP_JPEG_SYNC");
     bool use_sync = !(sy && sy[0] == '0');
+    /* the subsequences' length is worked out ONCE, from the batch's scan bytes: the choice of kernel below and every part's passes go by the same figure */
+    unsigned long long batch_bits = 0;
+    for (int i = 0; i < n; i++) batch_bits += 8ull * hdr[(size_t)i].scan_len;
+    const uint32_t sub_bits = sync_sub_bits(batch_bits, (unsigned long long)n * mcus);
     if (use_sync && !(sy && sy[0] == '1')) {
         /* restart intervals of a subsequence or two (a DRI of one or a few MCUs: 32 400 intervals in a 4K picture) are lanes enough as they are, every
          * one starting from the truth: three passes, a 60-byte record per interval and rounds that have nothing to settle are the wrong tool; the kernel
          * above takes such batches (FFHIP_JPEG_SYNC=1 keeps the subsequence decoder on them) */
-        const char *b = FFHIP_ENV("FFHIP_JPEG_SYNC_BITS");
-        const long sb = b ? atol(b) : 2048;
-        unsigned long long bits = 0, n_int = 0;
-        for (int i = 0; i < n; i++) {
-            bits += 8ull * hdr[(size_t)i].scan_len;
-            n_int += segs[(size_t)i].size() - 1;
-        }
-        if (bits <= 2ull * (unsigned long long)(sb < 128 ? 128 : sb) * n_int) use_sync = false;
+        unsigned long long n_int = 0;
+        for (int i = 0; i < n; i++) n_int += segs[(size_t)i].size() - 1;
+        if (batch_bits <= 2ull * sub_bits * n_int) use_sync = false;
     }
     const auto T1 = std::chrono::steady_clock::now();
     /* ---- layout of the one upload: scan bytes | tables | picture records | interval starts | work list | status ---- */
@@ -555,7 +557,22 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         FFHIP_CHECK(hipMemcpyAsync(d_quant, dev + o_quant, (size_t)n * 512, hipMemcpyDeviceToDevice, st), FFHIP_EIO);
         return FFHIP_OK;
     };
-    if (!g_huff_ev[0] && (hipEventCreate(&g_huff_ev[0]) != hipSuccess || hipEventCreate(&g_huff_ev[1]) != hipSuccess)) { (void)hipGetLastError(); g_huff_ev[0] = nullptr; }
+    FfhipHuffStreams hs;
+    if (ffhip_huff_streams_get(&hs) != FFHIP_OK) return FFHIP_EIO; /* (nothing of this call is enqueued yet but the plane clears, which touch no buffer of the library's) */
+    const hipStream_t g_huff_up = (hipStream_t)hs.up, g_huff_c2 = (hipStream_t)hs.c2;
+    hipEvent_t *const g_huff_part_ev = (hipEvent_t *)hs.part_ev;
+    const hipEvent_t g_huff_fork = (hipEvent_t)hs.fork, g_huff_join = (hipEvent_t)hs.join;
+    const hipEvent_t g_huff_ev[2] = {(hipEvent_t)hs.time_ev[0], (hipEvent_t)hs.time_ev[1]};
+    /* every failure behind this point leaves through `fail`: uploads, part kernels or a `then` reconstruction into the caller's pixels may be in flight,
+     * and the pinned stage, the device image and the parts' scratch are refilled by the thread's next call */
+    auto fail = [&](int code) -> int {
+        (void)hipStreamSynchronize(g_huff_up);
+        (void)hipStreamSynchronize(g_huff_c2);
+        (void)hipStreamSynchronize(st);
+        (void)hipGetLastError();
+        return code;
+    };
+#define HUFF_CHECK(call) do { if ((call) != hipSuccess) return fail(FFHIP_EIO); } while (0)
     int n_parts = n >= 32 ? 4 : 1;
     if (use_sync) {
         /* parts of about 140 MB of scan bytes, a hundred 4K files -- a round over fewer subsequences fills the chip badly, and what is left to wait for
@@ -574,24 +591,17 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     if (use_sync) {
         /* the parts' bytes go up on a stream of their own, the copy engine's, while the rounds of the parts before run on the caller's: 256 4K files are
          * 8 ms of PCIe and 11 ms of kernels */
-        if (!g_huff_up) {
-            if (hipStreamCreateWithFlags(&g_huff_up, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); g_huff_up = nullptr; return FFHIP_EIO; }
-            for (int k = 0; k < SYNC_PARTS; k++)
-                if (hipEventCreateWithFlags(&g_huff_part_ev[k], hipEventDisableTiming) != hipSuccess) return FFHIP_EIO;
-            if (hipStreamCreateWithFlags(&g_huff_c2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&g_huff_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&g_huff_join, hipEventDisableTiming) != hipSuccess) return FFHIP_EIO;
-        }
         for (int i = 0; i < n; i++) memcpy(stage + o_quant + (size_t)i * 512, hdr[(size_t)i].quant, 512);
         const int rc = tail_up();
-        if (rc) return rc;
-        if (g_huff_ev[0]) (void)hipEventRecord(g_huff_ev[0], st);
+        if (rc) return fail(rc);
+        (void)hipEventRecord(g_huff_ev[0], st);
         /* the parts' kernels alternate between the caller's stream and one of the library's: the list rounds of a part are a handful of sparse kernels
          * that each take as long as one lane takes for its subsequence, and run under the next part's full rounds instead of in front of them
          * (FFHIP_JPEG_SYNC_STREAMS=1: all on the caller's) */
         const char *ss = FFHIP_ENV("FFHIP_JPEG_SYNC_STREAMS");
         two_streams = n_parts > 1 && !(ss && ss[0] == '1');
-        if (two_streams) FFHIP_CHECK(hipEventRecord(g_huff_fork, st), FFHIP_EIO); /* behind the plane clears, the tables and the quantiser copy */
-        if (two_streams) FFHIP_CHECK(hipStreamWaitEvent(g_huff_c2, g_huff_fork, 0), FFHIP_EIO);
+        if (two_streams) HUFF_CHECK(hipEventRecord(g_huff_fork, st)); /* behind the plane clears, the tables and the quantiser copy */
+        if (two_streams) HUFF_CHECK(hipStreamWaitEvent(g_huff_c2, g_huff_fork, 0));
     }
     auto part_lo = [&](int part) -> int { return (int)((long long)n * part / n_parts); };
     for (int part = 0; part < n_parts; part++) {
@@ -621,7 +631,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     {
         const size_t b0 = images[(size_t)p_lo].scan_off, b1 = p_hi < n ? images[(size_t)p_hi].scan_off : scan_total;
         if (!use_sync) {
-            FFHIP_CHECK(hipMemcpyAsync(dev + b0, stage + b0, b1 - b0, hipMemcpyHostToDevice, st), FFHIP_EIO);
+            HUFF_CHECK(hipMemcpyAsync(dev + b0, stage + b0, b1 - b0, hipMemcpyHostToDevice, st));
         } else {
             SyncJob &job = jobs[part];
             int rc = FFHIP_OK;
@@ -630,6 +640,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
             if (hipMemcpyAsync(dev + b0, stage + b0, b1 - b0, hipMemcpyHostToDevice, g_huff_up) != hipSuccess || hipEventRecord(g_huff_part_ev[part], g_huff_up) != hipSuccess ||
                 hipStreamWaitEvent((hipStream_t)pstream, g_huff_part_ev[part], 0) != hipSuccess) rc = FFHIP_EIO;
             if (!rc) {
+                job.sub_bits = sub_bits;
                 job.dev = dev; job.o_tabs = o_tabs; job.o_l12 = o_l12; job.o_status = o_status + (size_t)p_lo * 4; job.n = p_hi - p_lo; job.part = part;
                 job.images = images.data() + p_lo;
                 part_segs[part].clear();
@@ -651,7 +662,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
                 }
                 job.segs = part_segs[part].data();
                 job.n_segs = part_segs[part].size();
-                if (rc) { (void)hipStreamSynchronize(g_huff_up); (void)hipStreamSynchronize(g_huff_c2); (void)hipStreamSynchronize(st); return rc; }
+                if (rc) return fail(rc);
                 job.plane[0] = d_coef_y + (size_t)p_lo * mcus * images[0].nb[0] * 64;
                 job.plane[1] = d_coef_u ? d_coef_u + (size_t)p_lo * mcus * images[0].nb[1] * 64 : nullptr;
                 job.plane[2] = d_coef_v ? d_coef_v + (size_t)p_lo * mcus * images[0].nb[2] * 64 : nullptr;
@@ -660,29 +671,20 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
                     rc = ffhip_jpeg_recon_batch(geom, p_hi - p_lo, job.plane[0], job.plane[1], job.plane[2], d_quant + (size_t)p_lo * 256, 256,
                                                 then.bgra + (int64_t)p_lo * then.image_stride, then.pitch, then.image_stride, nullptr, 0, pstream);
             }
-            if (rc) { /* nothing of this call may be in flight when its buffers are handed back */
-                (void)hipStreamSynchronize(g_huff_up);
-                (void)hipStreamSynchronize(g_huff_c2);
-                (void)hipStreamSynchronize(st);
-                (void)hipGetLastError();
-                return rc;
-            }
+            if (rc) return fail(rc); /* nothing of this call may be in flight when its buffers are handed back */
         }
     }
     } /* parts */
     if (two_streams) { /* the caller's stream is behind everything again */
-        FFHIP_CHECK(hipEventRecord(g_huff_join, g_huff_c2), FFHIP_EIO);
-        FFHIP_CHECK(hipStreamWaitEvent(st, g_huff_join, 0), FFHIP_EIO);
+        HUFF_CHECK(hipEventRecord(g_huff_join, g_huff_c2));
+        HUFF_CHECK(hipStreamWaitEvent(st, g_huff_join, 0));
     }
     for (int i = 0; i < n; i++)
-        if (status[i]) { /* a file whose restart markers do not add up: nothing is decoded */
-            (void)hipStreamSynchronize(st);
-            return status[i];
-        }
+        if (status[i]) return fail(status[i]); /* a file whose restart markers do not add up: nothing is decoded */
     const auto T3 = std::chrono::steady_clock::now();
     if (!use_sync) {
         const int rc = tail_up();
-        if (rc) return rc;
+        if (rc) return fail(rc);
     }
     const auto T4 = std::chrono::steady_clock::now();
     if (times) {
@@ -698,7 +700,7 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
     a.plane[0] = d_coef_y; a.plane[1] = d_coef_u; a.plane[2] = d_coef_v;
     a.status = (int *)(dev + o_status);
     a.n_work = (uint32_t)seg_total;
-    if (!use_sync && g_huff_ev[0]) (void)hipEventRecord(g_huff_ev[0], st);
+    if (!use_sync) (void)hipEventRecord(g_huff_ev[0], st);
     if (!use_sync)
     {   /* 128-byte rings (two workgroups of four waves per CU) while that holds the whole batch at once; 64-byte rings (three per CU, a refill every 8 symbols instead
          * of 16) beyond: 256 4K files of 135 intervals 9.9 ms against 10.4, 1 024 files 25.2 against 20.2 */
@@ -709,22 +711,22 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
         if (fr ? atoi(fr) == 16 : wgs > 2u * (unsigned)cus) hipLaunchKernelGGL((k_jpeg_huff<16, 8>), dim3(wgs), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_jpeg_huff<32, 16>), dim3(wgs), dim3(256), 0, st, a);
     }
-    FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
-    if (g_huff_ev[0]) (void)hipEventRecord(g_huff_ev[1], st);
+    HUFF_CHECK(hipGetLastError());
+    (void)hipEventRecord(g_huff_ev[1], st);
     if (!use_sync && then.on) {
         const int rc = ffhip_jpeg_recon_batch(geom, n, d_coef_y, d_coef_u, d_coef_v, d_quant, 256, then.bgra, then.pitch, then.image_stride, nullptr, 0, stream);
-        if (rc) return rc;
+        if (rc) return fail(rc);
     }
     /* per-picture verdicts come back with the stream (tiny); the staging buffer is free again after this sync */
-    FFHIP_CHECK(hipMemcpyAsync(stage + o_status, dev + o_status, (size_t)n * 4, hipMemcpyDeviceToHost, st), FFHIP_EIO);
+    HUFF_CHECK(hipMemcpyAsync(stage + o_status, dev + o_status, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     const auto T5 = std::chrono::steady_clock::now();
-    FFHIP_CHECK(hipStreamSynchronize(st), FFHIP_EIO);
+    HUFF_CHECK(hipStreamSynchronize(st));
     const auto T6 = std::chrono::steady_clock::now();
     if (times)
         fprintf(stderr, "huff device: enqueue %ld us, wait for uploads + clears + kernel %ld us\n", us(T3, T5), us(T5, T6));
     {
         float kms = 0.0f;
-        if (!g_huff_ev[0] || hipEventElapsedTime(&kms, g_huff_ev[0], g_huff_ev[1]) != hipSuccess) { (void)hipGetLastError(); kms = 0.0f; }
+        if (hipEventElapsedTime(&kms, g_huff_ev[0], g_huff_ev[1]) != hipSuccess) { (void)hipGetLastError(); kms = 0.0f; }
         g_huff_times[0] = (double)us(T0, T1); g_huff_times[1] = (double)us(T1, T2); g_huff_times[2] = (double)(us(T2, T3) - (use_sync ? tables_us : 0)); g_huff_times[3] = (double)tables_us;
         g_huff_times[4] = (double)us(T4, T5); g_huff_times[5] = (double)us(T5, T6); g_huff_times[6] = (double)kms * 1e3; g_huff_times[7] = (double)us(T0, T6);
     }
@@ -739,12 +741,13 @@ extern "C" int ffhip_jpeg_entropy_batch_gpu(const uint8_t *const *files, const s
                                             then.bgra + (int64_t)p_lo * then.image_stride, then.pitch, then.image_stride, nullptr, 0, job.stream);
                 if (!rc && job.stream != stream && hipStreamSynchronize((hipStream_t)job.stream) != hipSuccess) rc = FFHIP_EIO;
             }
-            if (rc) return rc;
+            if (rc) return fail(rc);
             if (times) fprintf(stderr, "huff sync, part %d: %u subsequences of %u bits, %u rounds\n", part, job.n_tasks, job.sub_bits, job.rounds_used);
         }
     for (int i = 0; i < n; i++)
         if (status[i]) return status[i];
     return FFHIP_OK;
+#undef HUFF_CHECK
 }
 
 /* =====================================================================================================================
@@ -1228,15 +1231,11 @@ static int huff_sync_enqueue(SyncJob &job, void *stream, uint32_t **h_cnt)
         const char *e = FFHIP_ENV("FFHIP_JPEG_SYNC_ROUNDS");
         const int r = e ? atoi(e) : 10;
         job.rounds = (uint32_t)(r < 1 ? 1 : r > SYNC_ROUNDS_MAX ? SYNC_ROUNDS_MAX : r);
-        const char *b = FFHIP_ENV("FFHIP_JPEG_SYNC_BITS"); /* bits of a subsequence */
-        /* unless set: by the bits an MCU takes in this part.  A wrong block state is put right over a few MCUs, and every subsequence it survives is
+        /* bits of a subsequence (job.sub_bits, from sync_sub_bits): by the bits an MCU takes in the batch, unless FFHIP_JPEG_SYNC_BITS sets them.  A wrong block state is put right over a few MCUs, and every subsequence it survives is
          * a round -- of a sparse kernel that takes as long as one lane takes for its subsequence: 128 4K files of quality 95 (1 500 bits an MCU) 11 rounds
          * and 29 ms at 2 048 bits, 6 rounds and 24 ms at 4 096; quality 100 on noise (2 800 bits an MCU, hardly an end-of-block anywhere) 59 rounds and
          * 91 ms at 2 048, 16 and 71 at 8 192.  Longer subsequences than that lose more in the sparse rounds than they save in their number. */
-        uint64_t bits = 0, mcus = 0;
-        for (size_t i = 0; i < job.n_segs; i++) { bits += 8ull * job.segs[i].raw_len; mcus += job.segs[i].mcus; }
-        const int sb = b ? atoi(b) : bits <= 1024 * mcus ? 2048 : bits <= 2048 * mcus ? 4096 : 8192;
-        job.sub_bits = (uint32_t)(sb < 128 ? 128 : sb > 65536 ? 65536 : sb);
+        if (job.sub_bits < 128 || job.sub_bits > 65536) return FFHIP_EINVAL;
     }
     uint64_t tasks = 0;
     for (size_t i = 0; i < n; i++) {

@@ -106,6 +106,13 @@ extern "C" int ffhip_side_stream_get(FfhipSide *out);
 struct FfhipPipe { void *plan, *groups2, *ev[FFHIP_PIPE_EVENTS]; };
 extern "C" int ffhip_pipe_streams_get(FfhipPipe *out);
 
+/* ... and the device Huffman decoder's (ffhip_jpeg_entropy_batch_gpu): the copy stream its parts' bytes go up on, the second kernel stream, the
+ * parts' events, fork / join, two timing events; all made together (none is published unless all exist), keyed by the thread's device like
+ * the side stream and released with it */
+#define FFHIP_HUFF_PARTS 8
+struct FfhipHuffStreams { void *up, *c2, *part_ev[FFHIP_HUFF_PARTS], *fork, *join, *time_ev[2]; };
+extern "C" int ffhip_huff_streams_get(FfhipHuffStreams *out);
+
 /* bits of a schedule slot's program word (second quarter, .x) that two files know: k_hevc_intra_program writes the word, k_plan_emit adds
  * what only the planner knows when the programs were built NEXT TO it (ffhip_hevc_intra.hip has the rest of the layout) */
 #define FFHIP_PK_KIND_MASK 7u

@@ -183,9 +183,11 @@ extern "C" uint8_t *ffhip_pinned_scratch(int kind, void *stream, size_t bytes)
 }
 
 extern "C" void ffhip_huff_release_thread(void); /* ffhip_huff_gpu.hip: the calling thread's header records */
+extern "C" void ffhip_hevc_tiles_release(void); /* ffhip_hevc_intra.hip: the per-stream guards of the tile call's two scratch sets */
 extern "C" void ffhip_release_caches(void)
 {
     ffhip_huff_release_thread();
+    ffhip_hevc_tiles_release();
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     for (auto &e : g_scratch)
         if (e.second.dev) (void)hipFree(e.second.dev);

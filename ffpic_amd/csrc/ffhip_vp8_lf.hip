@@ -519,6 +519,9 @@ struct SideStream {
     /* ffhip_hevc_intra_recon_tiles' pipeline (made on first use): a stream for the chunks' pre-passes, a second stream for grouped kernels, events */
     hipStream_t plan = nullptr, groups2 = nullptr;
     hipEvent_t pev[FFHIP_PIPE_EVENTS] = {};
+    /* ffhip_jpeg_entropy_batch_gpu's (made on first use, all or none) */
+    hipStream_t huff_up = nullptr, huff_c2 = nullptr;
+    hipEvent_t huff_ev[FFHIP_HUFF_PARTS + 4] = {};
 };
 std::mutex g_side_mu;
 std::vector<SideStream *> g_sides;
@@ -532,6 +535,10 @@ void side_release(SideStream *s)
     if (s->plan) (void)hipStreamDestroy(s->plan);
     if (s->groups2) (void)hipStreamDestroy(s->groups2);
     for (auto &e : s->pev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    if (s->huff_up) (void)hipStreamDestroy(s->huff_up);
+    if (s->huff_c2) (void)hipStreamDestroy(s->huff_c2);
+    for (auto &e : s->huff_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    s->huff_up = s->huff_c2 = nullptr;
     s->plan = s->groups2 = nullptr;
     s->side = nullptr; s->fork = s->join = s->mid = s->aux = nullptr; s->device = -1;
 }
@@ -599,6 +606,34 @@ extern "C" int ffhip_pipe_streams_get(FfhipPipe *out)
     }
     out->plan = ss->plan; out->groups2 = ss->groups2;
     for (int k = 0; k < FFHIP_PIPE_EVENTS; k++) out->ev[k] = ss->pev[k];
+    return FFHIP_OK;
+}
+extern "C" int ffhip_huff_streams_get(FfhipHuffStreams *out)
+{
+    SideStream *ss = side_stream_for_this_thread(); /* (recreated, and these with it, when the thread's current device has changed) */
+    if (!ss) return FFHIP_EIO;
+    std::lock_guard<std::mutex> l(g_side_mu);
+    if (!ss->huff_up) {
+        hipStream_t up = nullptr, c2 = nullptr;
+        hipEvent_t ev[FFHIP_HUFF_PARTS + 4] = {};
+        bool ok = hipStreamCreateWithFlags(&up, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&c2, hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; ok && k < FFHIP_HUFF_PARTS + 2; k++) ok = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) == hipSuccess;
+        for (int k = FFHIP_HUFF_PARTS + 2; ok && k < FFHIP_HUFF_PARTS + 4; k++) ok = hipEventCreate(&ev[k]) == hipSuccess;
+        if (!ok) { /* nothing half-made is kept: the next call tries again from nothing */
+            (void)hipGetLastError();
+            if (up) (void)hipStreamDestroy(up);
+            if (c2) (void)hipStreamDestroy(c2);
+            for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+            return FFHIP_EIO;
+        }
+        for (int k = 0; k < FFHIP_HUFF_PARTS + 4; k++) ss->huff_ev[k] = ev[k];
+        ss->huff_c2 = c2;
+        ss->huff_up = up; /* last */
+    }
+    out->up = ss->huff_up; out->c2 = ss->huff_c2;
+    for (int k = 0; k < FFHIP_HUFF_PARTS; k++) out->part_ev[k] = ss->huff_ev[k];
+    out->fork = ss->huff_ev[FFHIP_HUFF_PARTS]; out->join = ss->huff_ev[FFHIP_HUFF_PARTS + 1];
+    out->time_ev[0] = ss->huff_ev[FFHIP_HUFF_PARTS + 2]; out->time_ev[1] = ss->huff_ev[FFHIP_HUFF_PARTS + 3];
     return FFHIP_OK;
 }
 extern "C" void ffhip_vp8_retry_release(void);
@@ -710,6 +745,9 @@ extern "C" int ffhip_vp8_predict_loopfilter(int mbcols, int mbrows, int n_images
                                             int filter_type, const uint8_t *d_filters, uint8_t *d_y, uint8_t *d_u, uint8_t *d_v,
                                             int64_t plane_stride_y, int64_t plane_stride_uv, void *stream)
 {
+    /* taken and cleared before anything can return: an early return must not leave the record armed for the thread's next direct call */
+    const FfhipVp8Then then = g_ffhip_vp8_then;
+    g_ffhip_vp8_then.on = 0;
     if (filter_type < 0 || filter_type > 2) return FFHIP_EINVAL;
     if (filter_type != 0 && !d_filters) return FFHIP_EINVAL;
     const char *off = FFHIP_ENV("FFHIP_VP8_FUSE"); /* =0: one after the other on `stream` (A/B knob) */
@@ -724,8 +762,6 @@ extern "C" int ffhip_vp8_predict_loopfilter(int mbcols, int mbrows, int n_images
     /* for the repeat: the last luma column as it is now, and who to call again (small batches only: the record holds a copy of the
      * host's mode bytes, which the row form checks on the host; a chip-filling batch leaves no room for the second kernel to be kept out) */
     uint8_t *keep = nullptr;
-    const FfhipVp8Then then = g_ffhip_vp8_then;
-    g_ffhip_vp8_then.on = 0;
     const bool heal = fuse && h_modes && d_y && (long long)mbcols * mbrows * n_images <= (1LL << 17) && !FFHIP_ENV("FFHIP_VP8_NO_RETRY");
     int *err_word = nullptr;
     {

@@ -513,7 +513,7 @@ int ffhip_jpeg_entropy_batch(const uint8_t *const *files, const size_t *lens, in
  * dst must hold len + 8 * n_seg + 64 bytes.  The reference's counterpart is the byte loop of read_compressed_scan
  * (format/jpg.c:588-637). */
 int ffhip_jpeg_stage_scan_test(uint8_t *dst, const uint8_t *src, size_t len, uint32_t *seg, uint32_t n_seg, size_t *clean_len);
-/* the same, and raw[k] = the bytes of interval k without its padding (what the subsequence decoder cuts into lanes of 2048 bits) */
+/* the same, and raw[k] = the bytes of interval k without its padding (what the subsequence decoder cuts into lanes of 2048 / 4096 / 8192 bits) */
 int ffhip_jpeg_stage_scan_raw_test(uint8_t *dst, const uint8_t *src, size_t len, uint32_t *seg, uint32_t n_seg, size_t *clean_len, uint32_t *raw);
 /* Test hook (needs no device): the two-level look-up table the device Huffman kernels use for table `which` (0..3 DC, 4..7 AC) of a file, 1536 uint16:
  * [0..511] by the next 9 bits: (length << 8) | symbol, or 0x8000 | g for a prefix of longer codes; [512 + 128 g + b] group g by the 7 bits behind
@@ -523,12 +523,13 @@ int ffhip_jpeg_lut_test(const uint8_t *file, size_t len, int which, uint16_t *ou
 
 /* The same front end ON the device: decodes straight into DEVICE planes (d_coef_*, d_quant [n][4][64]) laid out for
  * ffhip_jpeg_recon_batch with quant_stride 256; the host only parses headers, finds the RSTn markers and unstuffs the
- * bytes into pinned memory.  files/lens/status are HOST arrays.  Round 5: a lane decodes 2048 bits of a restart interval
- * -- of the whole scan, in a file without DRI -- and the lanes are brought into step with each other over a few rounds
+ * bytes into pinned memory.  files/lens/status are HOST arrays.  Round 5: a lane decodes one SUBSEQUENCE of a restart interval
+ * -- of the whole scan, in a file without DRI; 2048, 4096 or 8192 bits, by the bits an MCU takes in the batch (up to 1024, up to 2048, more;
+ * FFHIP_JPEG_SYNC_BITS sets it), worked out once per call -- and the lanes are brought into step with each other over a few rounds
  * (Huffman-coded data self-synchronises; DESIGN.md 5 "The subsequence decoder"), so files need no restart markers to decode
  * in parallel, and a batch may mix files with and without.  FFHIP_JPEG_SYNC=0: the kernel of rounds 3-4, one lane per restart
  * interval (a file without DRI is ONE lane's then: for batches of a thousand files or more only); unset, that kernel also takes
- * the batches whose restart intervals are a subsequence or two long (a DRI of a few MCUs); =1 keeps the subsequence decoder on those.
+ * the batches whose restart intervals are a subsequence or two long by that same figure (a DRI of a few MCUs); =1 keeps the subsequence decoder on those.
  * FFHIP_EINVAL for a file of another geometry, and for a damaged or truncated scan (status[] says which picture; nothing of
  * the batch is to be used then -- ffhip_jpeg_decode_files* fall back to the host decoder).  Synchronises `stream` (the
  * per-picture verdicts come back with it). */
@@ -555,10 +556,12 @@ int ffhip_debug_huff_times(double out[8]);
  * directly; a pageable one goes through pinned staging and a threaded copy.  Buffers are kept between calls;
  * one call at a time. */
 /* The same with the pixels left ON THE DEVICE (d_bgra, pitch and image_stride as for ffhip_jpeg_recon_batch): for a
- * consumer that lives on the GPU only the compressed bytes cross PCIe.  Files with restart markers: one batch, entropy decode
- * on the device, the reconstruction enqueued on `stream` behind it (the entropy stage synchronises the stream).  Files without:
- * host threads decode chunks of a few pictures into pinned memory while the previous chunk is uploaded and reconstructed on a
- * stream of the library's own; `stream` is synchronised first and every picture is in d_bgra when the call returns. */
+ * consumer that lives on the GPU only the compressed bytes cross PCIe.  Files with or without restart markers: one batch, entropy
+ * decode on the device (ffhip_jpeg_entropy_batch_gpu: the subsequence decoder by default), each part's reconstruction enqueued behind its
+ * write pass (the entropy stage synchronises the stream).  Only when the device decoder refuses the batch with FFHIP_EINVAL (or
+ * FFHIP_JPEG_GPU_ENTROPY=0 says so) do host threads decode chunks of a few pictures into pinned memory while the previous chunk is
+ * uploaded and reconstructed on a stream of the library's own; `stream` is synchronised first and every picture is in d_bgra when the
+ * call returns. */
 int ffhip_jpeg_decode_files_device(const uint8_t *const *files, const size_t *lens, int n, int n_threads,
                                    ffhip_jpeg_geom *geom_out, uint8_t *d_bgra, int64_t pitch, int64_t image_stride,
                                    int *status, void *stream);

@@ -484,3 +484,42 @@ def test_tile_call_refuses_a_bad_record_and_recovers():
         got = (dy.to_host((h, w), np.int16), du.to_host((h // 2, w // 2), np.int16), dv.to_host((h // 2, w // 2), np.int16))
         for a, b in zip(got, exp):
             assert np.array_equal(a, b), rep
+
+
+def test_tile_calls_alternating_between_two_streams():
+    """The one-chunk tile call keeps two scratch sets per CALLER'S stream and guards each with an event of that stream (round 6; the guard was the calling
+    thread's before).  One thread, streams A, B, B, A, A, five different lists into five plane sets, no sync in between: the fifth call's pre-pass runs on
+    the library's plan stream and must wait for the first call's grouped kernel on A -- it takes that call's scratch.  Every plane set equals the oracle."""
+    L = capi.require_device()
+    w, h = 1024, 512
+    sa, sb = L.ffhip_stream_create(), L.ffhip_stream_create()
+    assert sa and sb
+    order = [sa, sb, sb, sa, sa]
+    tf = np.zeros(1, np.int64)
+    keep, jobs = [], []
+    for k, st in enumerate(order):
+        tus, res = synth.hevc_intra_tus(w, h, seed=300 + k, tu_mix="c5")
+        t = np.ascontiguousarray(tus)
+        dt, dr = ops.DeviceBuffer(t.view(np.uint8)), ops.DeviceBuffer(res)
+        pl = (ops.DeviceBuffer(nbytes=w * h * 2), ops.DeviceBuffer(nbytes=w * h // 2), ops.DeviceBuffer(nbytes=w * h // 2))
+        for d in pl:
+            capi.check(L.ffhip_memset(d.ptr, 0, d.nbytes, None))
+        keep.append((t, dt, dr))
+        jobs.append((tus, res, pl))
+    capi.check(L.ffhip_stream_sync(None))
+    for (t, dt, dr), (_, _, pl), st in zip(keep, jobs, order):
+        capi.check(L.ffhip_hevc_intra_recon_tiles(t.ctypes.data, dt.ptr, len(t), tf.ctypes.data, 1, dr.ptr, pl[0].ptr, pl[1].ptr, pl[2].ptr, w, h, w, w // 2, h // 2, w // 2,
+                                                  8, 8, st))
+    assert L.ffhip_stream_sync(sa) == 0 and L.ffhip_stream_sync(sb) == 0
+    for k, (tus, res, pl) in enumerate(jobs):
+        exp = O.oracle_hevc_intra(tus, res, w, h, True, 8, 8)
+        got = (pl[0].to_host((h, w), np.int16), pl[1].to_host((h // 2, w // 2), np.int16), pl[2].to_host((h // 2, w // 2), np.int16))
+        for a, b in zip(got, exp):
+            assert np.array_equal(a, b), k
+    L.ffhip_release_caches()                       # the guards go with the scratches; the next call makes new ones
+    t, dt, dr = keep[0]
+    pl = jobs[0][2]
+    capi.check(L.ffhip_hevc_intra_recon_tiles(t.ctypes.data, dt.ptr, len(t), tf.ctypes.data, 1, dr.ptr, pl[0].ptr, pl[1].ptr, pl[2].ptr, w, h, w, w // 2, h // 2, w // 2, 8, 8, sa))
+    assert L.ffhip_stream_sync(sa) == 0
+    L.ffhip_stream_destroy(sa)
+    L.ffhip_stream_destroy(sb)

@@ -5,7 +5,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libffpic_hip.so")
+LIB_PATH = os.path.join(HERE, os.environ.get("FFHIP_LIB") or "libffpic_hip.so")   # FFHIP_LIB: A/B runs of two builds in one gpurun call (tests/tools/ab_*.sh)
 CSRC = os.path.join(HERE, "csrc")
 
 # every symbol include/ffpic_hip.h declares (tests check the library exports them all)

@@ -1213,6 +1213,24 @@ def main():
         except Exception as e:
             rec_pitch = {"error": f"{type(e).__name__}: {e}"}
 
+    # the fused kernel's own access pattern with the arithmetic taken out (ffhip_jpeg_pattern_calibrate: same grid, loads, store addresses) on the
+    # HEADLINE's buffers -- the ceiling this placement of them allows; `out` holds meaningless bytes afterwards (nothing below reads it)
+    pattern_gbs = None
+    if rank == 0 and world == 1:
+        try:
+            cal = lambda: capi.check(L.ffhip_jpeg_pattern_calibrate(C.byref(geom), n, t_y.data_ptr(), t_u.data_ptr(), t_v.data_ptr(), t_q.data_ptr(), 0,
+                                                                      out.data_ptr(), pitch, stride, stream), "ffhip_jpeg_pattern_calibrate")
+            for _ in range(2):
+                cal()
+            capi.check(L.ffhip_event_record(ev0, stream))
+            for _ in range(10):
+                cal()
+            capi.check(L.ffhip_event_record(ev1, stream))
+            capi.check(L.ffhip_stream_sync(stream))
+            pattern_gbs = BYTES_PER_PIXEL * n * H * W / (L.ffhip_event_elapsed_ms(ev0, ev1) / 10 * 1e-3) / 1e9
+        except Exception as e:
+            pattern_gbs = None
+
     if rank == 0:
         px_per_launch = n * H * W
         achieved = BYTES_PER_PIXEL * px_per_launch / (kernel_ms * 1e-3) / 1e9
@@ -1238,6 +1256,8 @@ def main():
                          "kernel": "k_jpeg420_fused", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": int(BYTES_PER_PIXEL * px_per_launch),
                          "copy_kernel_GBps": None if copy_gbs is None else round(copy_gbs, 1),
+                         "pattern_GBps": None if pattern_gbs is None else round(pattern_gbs, 1),
+                         "frac_of_pattern": None if pattern_gbs is None else round(achieved / pattern_gbs, 4),
                          "at_recommended_pitch": rec_pitch},
         }
         if rehearse:

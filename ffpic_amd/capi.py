@@ -17,7 +17,7 @@ EXPORTS = [
     "hip_accl_init", "hip_accl_uninit", "ffhip_accl_ops_get",
     "ffhip_get_dct_ops", "ffhip_get_cs_ops", "ffhip_idct_4x4_hevc",
     "ffhip_jpeg_recon_batch", "ffhip_jpeg_workspace_bytes", "ffhip_jpeg_recon_batch_host",
-    "ffhip_jpeg_kernel_name", "ffhip_copy_calibrate",
+    "ffhip_jpeg_kernel_name", "ffhip_copy_calibrate", "ffhip_jpeg_pattern_calibrate",
     "ffhip_yuv420_to_bgra", "ffhip_yuv420_to_bgra_16", "ffhip_yuv400_to_bgra_16",
     "ffhip_vp8_residual_batch", "ffhip_hevc_residual_batch", "ffhip_vp8_predict_recon",
     "ffhip_hevc_intra_recon", "ffhip_hevc_intra_plan", "ffhip_debug_hevc_plan_result", "ffhip_vp8_decode_frames_form", "ffhip_debug_huff_times", "ffhip_hevc_intra_recon_tiles", "ffhip_hevc_decode_tiles", "ffhip_vp8_loopfilter",
@@ -165,6 +165,7 @@ def lib():
     L.ffhip_jpeg_kernel_name.argtypes = [C.POINTER(JpegGeom)]
     L.ffhip_jpeg_kernel_name.restype = C.c_char_p
     L.ffhip_copy_calibrate.argtypes = [vp, vp, sz, vp]
+    L.ffhip_jpeg_pattern_calibrate.argtypes = [C.POINTER(JpegGeom), C.c_int, vp, vp, vp, vp, i64, vp, i64, i64, vp]
     ci = C.c_int
     L.ffhip_yuv420_to_bgra.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, i64, i64, i64, vp]
     L.ffhip_yuv420_to_bgra_16.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, i64, i64, i64, vp]

@@ -210,6 +210,7 @@ struct JpegBatch {
     int wgs_per_image;     /* workgroups that cover one image                            */
     u32 wpi_magic;         /* same trick for image = workgroup / wgs_per_image          */
     int xcd_remap;         /* 1: give each XCD a contiguous chunk of the workgroup sequence */
+    int pattern_only;      /* host side: launch the arithmetic-free twin (ffhip_jpeg_pattern_calibrate) */
 };
 
 /* exact floor((x)/d) for the small non-negative ranges of the chroma terms:
@@ -430,13 +431,37 @@ __device__ __forceinline__ void quad_recon(const JpegBatch &p, const WaveCtx &c,
     }
 }
 
+/* The same quad with the arithmetic taken out (ffhip_jpeg_pattern_calibrate): the three loads as they are, the four store instructions at the
+ * addresses, in the order and with the masks of quad_recon, the stored words an XOR of the loaded ones.  What this runs at is the ceiling of the
+ * kernel's ACCESS PATTERN on the buffers it is given -- the figure the kernel's own rate is to be read against (DESIGN.md 5 "Round 6"). */
+template <int NT>
+__device__ __forceinline__ void quad_pattern(const JpegBatch &p, const LaneRoles &r, const QuadLoads &ld, int img, int mrow, int mcu0)
+{
+    const int last = p.mcu_cols - 1;
+    const bool full = mcu0 + 3 <= last;
+    uint8_t *const orow = p.bgra + (long long)img * p.image_stride + (long long)mrow * 16 * p.pitch + (long long)mcu0 * 64;
+    const u32x4 s = ld.c ^ ld.y0 ^ ld.y1;
+#pragma unroll
+    for (int rnd = 0; rnd < 2; rnd++)
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const u32 m = 2 * rnd + r.lane_m;
+            if (full || mcu0 + (int)m <= last) {
+                u32x4 *dst = (u32x4 *)(orow + (long long)k * 8 * p.pitch + rnd * 128 + r.st_lane);
+                const u32x4 px = s + (u32)(2 * rnd + k);
+                if (NT & 2) __builtin_nontemporal_store(px, dst);
+                else *dst = px;
+            }
+        }
+}
+
 /* QPW quads per wave (adjacent in the MCU row), WAVES_PER_WG waves per workgroup;
  * blockIdx = (quad group, MCU row, image).  A short-lived wave issues all its loads up
  * front and never waits on its own earlier stores (vmcnt is in-order), which streams
  * measurably faster on MI355X than a persistent grid-stride loop (tests/tools/membench.hip:
  * 6.2-6.5 TB/s vs 4.7-5.3 TB/s for a 16 B/lane copy).  NT bit 0: non-temporal loads,
  * bit 1: non-temporal stores. */
-template <int QPW, int NT>
+template <int QPW, int NT, bool PATTERN = false>
 __global__ __launch_bounds__(WG_THREADS) void k_jpeg420_fused(JpegBatch p)
 {
     __shared__ __attribute__((aligned(16))) char lds_all[WAVES_PER_WG * LDS_WAVE_BYTES];
@@ -483,7 +508,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg420_fused(JpegBatch p)
     const u32x4 q_c = *(const u32x4 *)(qt + (lane < 32 ? p.qt_u : p.qt_v) * 64 + r.row * 8);
 #pragma unroll
     for (int i = 0; i < QPW; i++)
-        if (qidx0 + i < p.quads_per_image) quad_recon<NT>(p, c, r, lane, ld[i], q_y, q_c, img, mrow[i], qcol[i] * 4);
+        if (qidx0 + i < p.quads_per_image) {
+            if (PATTERN) quad_pattern<NT>(p, r, ld[i], img, mrow[i], qcol[i] * 4);
+            else quad_recon<NT>(p, c, r, lane, ld[i], q_y, q_c, img, mrow[i], qcol[i] * 4);
+        }
 }
 
 /* ------------------------------------------------------------------------
@@ -840,6 +868,10 @@ static void launch_fused(const JpegBatch &q_in, int n_images, hipStream_t st)
     q.wgs_per_image = (slots + WAVES_PER_WG - 1) / WAVES_PER_WG;
     q.wpi_magic = q.wgs_per_image == 1 ? 0xffffffffu : (u32)(0x100000000ULL / (unsigned)q.wgs_per_image) + 1u;
     const dim3 grid((unsigned)((long long)q.wgs_per_image * n_images), 1, 1);
+    if (q.pattern_only) { /* the shipped variant's twin: same grid, same loads, same stores */
+        hipLaunchKernelGGL((k_jpeg420_fused<FFHIP_JPEG_DEFAULT_VARIANT / 10, FFHIP_JPEG_DEFAULT_VARIANT % 10, true>), grid, dim3(WG_THREADS), 0, st, q);
+        return;
+    }
 #define FFHIP_LAUNCH(Q, N) hipLaunchKernelGGL((k_jpeg420_fused<Q, N>), grid, dim3(WG_THREADS), 0, st, q)
     switch (g_variant) {
     case 10: FFHIP_LAUNCH(1, 0); break;
@@ -910,11 +942,11 @@ extern "C" const char *ffhip_jpeg_kernel_name(const ffhip_jpeg_geom *g)
     return is_fused420(g) ? "k_jpeg420_fused" : (is_fused_strip(g) ? "k_jpeg_fused_strip" : "k_jpeg_idct_planes");
 }
 
-extern "C" int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *g, int n_images, const int16_t *d_coef_y,
-                                      const int16_t *d_coef_u, const int16_t *d_coef_v,
-                                      const uint16_t *d_quant, int64_t quant_stride, uint8_t *d_bgra,
-                                      int64_t pitch, int64_t image_stride, void *d_workspace,
-                                      size_t workspace_bytes, void *stream)
+static int jpeg_recon_batch_impl(const ffhip_jpeg_geom *g, int n_images, const int16_t *d_coef_y,
+                                 const int16_t *d_coef_u, const int16_t *d_coef_v,
+                                 const uint16_t *d_quant, int64_t quant_stride, uint8_t *d_bgra,
+                                 int64_t pitch, int64_t image_stride, void *d_workspace,
+                                 size_t workspace_bytes, void *stream, const bool pattern_only)
 {
     if (!geom_ok(g) || n_images < 0) return FFHIP_EINVAL;
     if (n_images == 0) return FFHIP_OK;
@@ -930,8 +962,10 @@ extern "C" int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *g, int n_images, co
     if (!ffhip_have_device()) return FFHIP_ENODEV;
     hipStream_t st = (hipStream_t)stream;
 
+    if (pattern_only && !is_fused420(g)) return FFHIP_EINVAL;
     if (is_fused420(g)) {
         JpegBatch p;
+        p.pattern_only = pattern_only ? 1 : 0;
         p.coef_y = d_coef_y; p.coef_u = d_coef_u; p.coef_v = d_coef_v;
         p.quant = d_quant; p.quant_stride = quant_stride;
         p.bgra = d_bgra; p.pitch = pitch; p.image_stride = image_stride;
@@ -1019,6 +1053,22 @@ extern "C" int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *g, int n_images, co
     hipLaunchKernelGGL(k_jpeg_color_generic, dim3(grid), dim3(256), 0, st, cg);
     FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
     return FFHIP_OK;
+}
+
+extern "C" int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *g, int n_images, const int16_t *d_coef_y,
+                                      const int16_t *d_coef_u, const int16_t *d_coef_v,
+                                      const uint16_t *d_quant, int64_t quant_stride, uint8_t *d_bgra,
+                                      int64_t pitch, int64_t image_stride, void *d_workspace,
+                                      size_t workspace_bytes, void *stream)
+{
+    return jpeg_recon_batch_impl(g, n_images, d_coef_y, d_coef_u, d_coef_v, d_quant, quant_stride, d_bgra, pitch, image_stride, d_workspace, workspace_bytes, stream, false);
+}
+/* Calibration (bench.py's roofline.pattern_GBps): the 4:2:0 fused kernel's loads and stores on the caller's buffers with NO arithmetic in between -- same
+ * grid, same workgroup-to-XCD mapping, same addresses and masks; d_bgra receives meaningless bytes.  4:2:0 only (FFHIP_EINVAL otherwise). */
+extern "C" int ffhip_jpeg_pattern_calibrate(const ffhip_jpeg_geom *g, int n_images, const int16_t *d_coef_y, const int16_t *d_coef_u, const int16_t *d_coef_v,
+                                            const uint16_t *d_quant, int64_t quant_stride, uint8_t *d_bgra, int64_t pitch, int64_t image_stride, void *stream)
+{
+    return jpeg_recon_batch_impl(g, n_images, d_coef_y, d_coef_u, d_coef_v, d_quant, quant_stride, d_bgra, pitch, image_stride, nullptr, 0, stream, true);
 }
 
 #define SCRATCH_JPEG_HOST 6

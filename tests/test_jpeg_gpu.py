@@ -379,3 +379,40 @@ def test_shutdown_releases_and_rebinds():
     _, b = ops.jpeg_decode_files([data] * 3, n_threads=2)
     yb = ops.hevc_intra_recon(tus, res, 128, 128)[0]
     assert np.array_equal(a, b) and np.array_equal(ya, yb)
+
+
+@pytest.mark.parametrize("cols,rows,pad", [(13, 7, 0), (40, 30, 1024), (5, 1, 0)])
+def test_pattern_calibration_touches_what_the_kernel_touches(cols, rows, pad):
+    """ffhip_jpeg_pattern_calibrate (bench.py's roofline.pattern_GBps): the fused 4:2:0 kernel's loads and stores without the arithmetic.  It must write
+    exactly the bytes the real kernel writes -- every pixel of the coded picture, nothing in the pitch padding, nothing of a ragged quad's missing MCUs --
+    and leave the next real launch bit-exact; other layouts are refused."""
+    import ctypes as C
+    L = capi.require_device()
+    geom = O.make_geom(cols, rows)
+    cg = to_capi(geom)
+    n = 2
+    q = synth.quant_tables(80)
+    cy, cu, cv = synth.coef_batch(n, cols, rows, quant=q)
+    W, H = cols * 16, rows * 16
+    pitch = W * 4 + pad
+    stride = pitch * H
+    dy, du, dv = ops.DeviceBuffer(cy), ops.DeviceBuffer(cu), ops.DeviceBuffer(cv)
+    dq = ops.DeviceBuffer(np.ascontiguousarray(q.astype(np.uint16)))
+    out = ops.DeviceBuffer(nbytes=n * stride + 4096)
+    capi.check(L.ffhip_memset(out.ptr, 0xA5, n * stride + 4096, None))
+    capi.check(L.ffhip_jpeg_pattern_calibrate(C.byref(cg), n, dy.ptr, du.ptr, dv.ptr, dq.ptr, 0, out.ptr, pitch, stride, None))
+    capi.check(L.ffhip_stream_sync(None))
+    raw = out.to_host((n * stride + 4096,), np.uint8)
+    assert (raw[n * stride:] == 0xA5).all()                               # nothing behind the last picture
+    img = raw[:n * stride].reshape(n, H, pitch)
+    if pad:
+        assert (img[:, :, W * 4:] == 0xA5).all()                           # nothing in the padding of a row
+    # the words it stores are XORs of coefficient words + a small counter: with random coefficients practically none equals the fill pattern
+    touched = (img[:, :, :W * 4].reshape(n, H, W, 4).view(np.uint32)[..., 0] != 0xA5A5A5A5)
+    assert touched.mean() > 0.99
+    capi.check(L.ffhip_jpeg_recon_batch(C.byref(cg), n, dy.ptr, du.ptr, dv.ptr, dq.ptr, 0, out.ptr, pitch, stride, None, 0, None))
+    capi.check(L.ffhip_stream_sync(None))
+    got = out.to_host((n * stride + 4096,), np.uint8)[:n * stride].reshape(n, H, pitch)[:, :, :W * 4].reshape(n, H, W, 4)
+    assert np.array_equal(got, O.oracle_jpeg_recon(geom, cy, cu, cv, q, n_images=n))
+    g444 = to_capi(O.make_geom(cols, rows, 3, 1, 1))
+    assert L.ffhip_jpeg_pattern_calibrate(C.byref(g444), 1, dy.ptr, du.ptr, dv.ptr, dq.ptr, 0, out.ptr, cols * 8 * 4, cols * 8 * 4 * rows * 8, None) == capi.FFHIP_EINVAL

@@ -441,6 +441,10 @@ __device__ __forceinline__ void quad_pattern(const JpegBatch &p, const LaneRoles
     const bool full = mcu0 + 3 <= last;
     uint8_t *const orow = p.bgra + (long long)img * p.image_stride + (long long)mrow * 16 * p.pitch + (long long)mcu0 * 64;
     const u32x4 s = ld.c ^ ld.y0 ^ ld.y1;
+    /* FFHIP_JPEG_PATTERN_SLEEP=<n>: the wave idles n x ~0.4 us between its loads and its stores, as long as the real kernel computes (diagnostics: the
+     * pattern with the kernel's residency and none of its instruction issue) */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int i = 1; i < p.pattern_only; i++) __builtin_amdgcn_s_sleep(15);
 #pragma unroll
     for (int rnd = 0; rnd < 2; rnd++)
 #pragma unroll
@@ -868,11 +872,15 @@ static void launch_fused(const JpegBatch &q_in, int n_images, hipStream_t st)
     q.wgs_per_image = (slots + WAVES_PER_WG - 1) / WAVES_PER_WG;
     q.wpi_magic = q.wgs_per_image == 1 ? 0xffffffffu : (u32)(0x100000000ULL / (unsigned)q.wgs_per_image) + 1u;
     const dim3 grid((unsigned)((long long)q.wgs_per_image * n_images), 1, 1);
+    /* FFHIP_JPEG_LDS_PAD=<bytes>: that much dynamic LDS per workgroup on top of the kernel's own 21 KB, which nobody touches -- fewer workgroups per CU
+     * (7 as shipped; 8192 -> 5, 16384 -> 4, 32768 -> 3, 61440 -> 1): the occupancy experiment of DESIGN.md 5 as a run-time switch */
+    const char *pe = FFHIP_ENV("FFHIP_JPEG_LDS_PAD");
+    const unsigned pad = pe && atoi(pe) > 0 && atoi(pe) <= 120 * 1024 ? (unsigned)atoi(pe) & ~15u : 0u;
     if (q.pattern_only) { /* the shipped variant's twin: same grid, same loads, same stores */
-        hipLaunchKernelGGL((k_jpeg420_fused<FFHIP_JPEG_DEFAULT_VARIANT / 10, FFHIP_JPEG_DEFAULT_VARIANT % 10, true>), grid, dim3(WG_THREADS), 0, st, q);
+        hipLaunchKernelGGL((k_jpeg420_fused<FFHIP_JPEG_DEFAULT_VARIANT / 10, FFHIP_JPEG_DEFAULT_VARIANT % 10, true>), grid, dim3(WG_THREADS), pad, st, q);
         return;
     }
-#define FFHIP_LAUNCH(Q, N) hipLaunchKernelGGL((k_jpeg420_fused<Q, N>), grid, dim3(WG_THREADS), 0, st, q)
+#define FFHIP_LAUNCH(Q, N) hipLaunchKernelGGL((k_jpeg420_fused<Q, N>), grid, dim3(WG_THREADS), pad, st, q)
     switch (g_variant) {
     case 10: FFHIP_LAUNCH(1, 0); break;
     case 11: FFHIP_LAUNCH(1, 1); break;
@@ -965,7 +973,11 @@ static int jpeg_recon_batch_impl(const ffhip_jpeg_geom *g, int n_images, const i
     if (pattern_only && !is_fused420(g)) return FFHIP_EINVAL;
     if (is_fused420(g)) {
         JpegBatch p;
-        p.pattern_only = pattern_only ? 1 : 0;
+        p.pattern_only = 0;
+        if (pattern_only) {
+            const char *sl = FFHIP_ENV("FFHIP_JPEG_PATTERN_SLEEP");
+            p.pattern_only = 1 + (sl && atoi(sl) > 0 && atoi(sl) < 4096 ? atoi(sl) : 0);
+        }
         p.coef_y = d_coef_y; p.coef_u = d_coef_u; p.coef_v = d_coef_v;
         p.quant = d_quant; p.quant_stride = quant_stride;
         p.bgra = d_bgra; p.pitch = pitch; p.image_stride = image_stride;

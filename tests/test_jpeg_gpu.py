@@ -400,8 +400,12 @@ def test_pattern_calibration_touches_what_the_kernel_touches(cols, rows, pad):
     dq = ops.DeviceBuffer(np.ascontiguousarray(q.astype(np.uint16)))
     out = ops.DeviceBuffer(nbytes=n * stride + 4096)
     capi.check(L.ffhip_memset(out.ptr, 0xA5, n * stride + 4096, None))
-    capi.check(L.ffhip_jpeg_pattern_calibrate(C.byref(cg), n, dy.ptr, du.ptr, dv.ptr, dq.ptr, 0, out.ptr, pitch, stride, None))
-    capi.check(L.ffhip_stream_sync(None))
+    capi.setenv("FFHIP_JPEG_PATTERN_SLEEP", "3" if pad else None)      # (diagnostics: the wave idles between its loads and its stores)
+    try:
+        capi.check(L.ffhip_jpeg_pattern_calibrate(C.byref(cg), n, dy.ptr, du.ptr, dv.ptr, dq.ptr, 0, out.ptr, pitch, stride, None))
+        capi.check(L.ffhip_stream_sync(None))
+    finally:
+        capi.setenv("FFHIP_JPEG_PATTERN_SLEEP", None)
     raw = out.to_host((n * stride + 4096,), np.uint8)
     assert (raw[n * stride:] == 0xA5).all()                               # nothing behind the last picture
     img = raw[:n * stride].reshape(n, H, pitch)

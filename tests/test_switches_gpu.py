@@ -30,7 +30,7 @@ def switch(monkeypatch):
 
 @pytest.mark.parametrize("env", [{"FFHIP_JPEG_VARIANT": v} for v in ("10", "11", "12", "13", "20", "21", "22", "23")] +
                          [{"FFHIP_JPEG_NO_XCD_REMAP": "1"}, {"FFHIP_JPEG_XCD_CHUNK_LOG2": "2"}, {"FFHIP_JPEG_XCD_CHUNK_LOG2": "5"},
-                          {"FFHIP_JPEG_XCD_CHUNK_LOG2": "5", "FFHIP_JPEG_VARIANT": "21"}])
+                          {"FFHIP_JPEG_XCD_CHUNK_LOG2": "5", "FFHIP_JPEG_VARIANT": "21"}, {"FFHIP_JPEG_LDS_PAD": "16384"}, {"FFHIP_JPEG_LDS_PAD": "61440"}])
 def test_jpeg_launch_shapes(env, switch):
     """quads per wave, store policy and the workgroup -> XCD mapping of k_jpeg420_fused: ragged and whole MCU counts, several images"""
     switch(**env)

@@ -20,9 +20,13 @@ ty = torch.randint(-30, 31, (n * mcus * 256,), device=dev, dtype=torch.int16)
 tu = torch.randint(-30, 31, (n * mcus * 64,), device=dev, dtype=torch.int16)
 tv = torch.randint(-30, 31, (n * mcus * 64,), device=dev, dtype=torch.int16)
 PAD = 8192
+import ctypes as C
+PATTERN = False   # time ffhip_jpeg_pattern_calibrate (the kernel's loads and stores without the arithmetic) instead of the kernel
 def timed(out, pitch, reps=6):
     stride = pitch * H
-    def step(): ops.jpeg_recon_batch(geom, n, ty.data_ptr(), tu.data_ptr(), tv.data_ptr(), q.data_ptr(), 0, out.data_ptr(), pitch, stride, None, 0, st)
+    def step():
+        if PATTERN: capi.check(L.ffhip_jpeg_pattern_calibrate(C.byref(geom), n, ty.data_ptr(), tu.data_ptr(), tv.data_ptr(), q.data_ptr(), 0, out.data_ptr(), pitch, stride, st))
+        else: ops.jpeg_recon_batch(geom, n, ty.data_ptr(), tu.data_ptr(), tv.data_ptr(), q.data_ptr(), 0, out.data_ptr(), pitch, stride, None, 0, st)
     for _ in range(2): step()
     L.ffhip_event_record(e0, st)
     for _ in range(reps): step()
@@ -51,6 +55,9 @@ for name, buf in (("slow", slow), ("fast", fast)):
     for sw in sets:
         for k, v in sw.items(): capi.setenv(k, v)
         row = {"placement": name, "switches": sw, "TB/s": timed(buf, W * 4), "TB/s_pitch+1K": timed(buf, W * 4 + 1024), "TB/s_pitch+8K": timed(buf, W * 4 + 8192)}
+        PATTERN = True
+        row["pattern_TB/s"] = timed(buf, W * 4)
+        PATTERN = False
         for k in sw: capi.setenv(k, None)
         print(json.dumps(row), flush=True)
 # ---- where in the buffer is the slow mode?  Sub-batches of 32 images (an eighth of the output each), all XCDs on each

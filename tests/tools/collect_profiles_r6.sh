@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-6 evidence run on the MI355X box: rocprofv3 kernel statistics and PMC passes for bench.py, the f1 row and the stage benches.
-# usage (from the repo root on the box): bash tests/tools/collect_profiles_r6.sh   -> gpurun_out/profiles_r6/   (copy what is kept into profiles/r6_*)
+# usage (from the repo root on the box): bash tests/tools/collect_profiles_r6.sh [main]   -> gpurun_out/profiles_r6/ (main: without the subsequence decoder's own collection, tests/tools/collect_profiles_r5_huff.sh)   (copy what is kept into profiles/r6_*)
 # (every step prints a line when it is done: the box's watchdog kills a command that is silent for seven minutes)
 set -u
 R=$PWD
@@ -63,7 +63,7 @@ prof bench_headline $R/bench.py --no-extra
 grep '^{' $O/bench_headline.stdout | tail -1 > $O/bench_headline.json
 cd $R
 cd $R
-bash tests/tools/collect_profiles_r5_huff.sh > $O/huff_sync.log 2>&1; echo "done subsequence decoder"
+if [ "${1:-all}" != "main" ]; then bash tests/tools/collect_profiles_r5_huff.sh > $O/huff_sync.log 2>&1; echo "done subsequence decoder"; fi
 # the store-shape / placement microbenchmark: several allocations of the output buffer held at once
 cd $R
 if [ -x tests/tools/membench_jpeg_rows.bin ]; then timeout -k 10 200 tests/tools/membench_jpeg_rows.bin 7 0 > $O/membench_rows.txt 2>&1; echo "done membench rows"; fi

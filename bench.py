@@ -10,8 +10,9 @@ A "step" is one pass of the hot path over one batch: 256 synthetic 3840x2160 4:2
 k_jpeg420_fused per GPU.  Images are independent, so ranks own disjoint contiguous image ranges
 (ffhip_shard_range) and the only collective is the batch close: one RCCL all-gather of a 32-byte
 {rank, status, first, count, checksum} record per rank, issued from C (ffhip_batch_close).
-Default scaling is STRONG -- the batch is config 3's 256 images in total, 32 per GPU at N = 8;
-`--scaling weak` keeps 256 images per GPU instead.  Rank 0 prints one JSON line.
+Default scaling is WEAK -- the path partitions into independent images with no data-path collective, so every GPU takes the
+configuration's 256 images (at N = 1 that IS BASELINE config 3; at N = 8 it is 2 048 images, 256 per GPU);
+`--scaling strong` is config 3 read literally: 256 images in total, 32 per GPU at N = 8.  Rank 0 prints one JSON line.
 
 At N = 1 the line also carries `extra`: BASELINE configs 2, 4 and 5 measured the same way (HIP events on the
 launch stream, inputs resident in HBM), each with its own roofline figures, parity flag and CPU baseline.
@@ -1078,8 +1079,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--images", type=int, default=0, help="override the number of images (per batch if strong, per GPU if weak)")
-    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
-                    help="strong: the configuration's batch is shared out over the GPUs (BASELINE config 3: 256 images in total); weak: that many per GPU")
+    ap.add_argument("--scaling", default="weak", choices=["strong", "weak"],
+                    help="weak (default): the configuration's batch per GPU (independent images, no data-path collective); strong: that batch shared out over the GPUs (BASELINE config 3 read literally: 256 images in total)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-extra", action="store_true", help="skip the C2 / C4 / C5 measurements of `extra`")
     ap.add_argument("--extras", default="", help="comma-separated subset of c2,jpeg_layouts,c4,c5,f1,stage_kernels to measure (default: all)")

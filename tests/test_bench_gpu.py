@@ -24,7 +24,7 @@ def test_one_gpu_line_small():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--images", "5", "--no-cpu", "--no-extra"],
                          capture_output=True, text=True, cwd=ROOT, timeout=600)
     rec = _line(out)
-    assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["scaling"] == "strong"
+    assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["scaling"] == "weak"
     assert rec["config"]["batch_complete"] is True and rec["config"]["parity_vs_oracle_first_and_last_image"] is True
     assert rec["config"]["images_total"] == 5 and rec["roofline"]["bound"] == "hbm" and rec["roofline"]["frac"] > 0
 

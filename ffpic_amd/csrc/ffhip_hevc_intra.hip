@@ -1531,7 +1531,7 @@ __global__ __launch_bounds__(64, MINW) void k_hevc_intra_groups(HevcIntraArgs a)
                     uint32_t widxn = 0;
                     /* zeroed on purpose (twenty v_mov per generic TU): left undefined, the compiler lets the fetch below load straight
                      * into the registers the NEXT TU reads, and the copies at the tail then wait for the loads on the spot (measured:
-                     * config-5 mix 5.56 -> 6.10 ms) */
+                     * config-5 mix 5.56 -> 6.10 ms; round 6, "defined" by empty asm statements instead of moves -- no instruction at all --: the same, 4.88 -> 5.50) */
                     jpn.j[0] = jpn.j[1] = jpn.j[2] = 0; rpn.wide = false; rpn.v[0] = rpn.v[1] = nq0;
                     auto fetch_next_extras = [&]() {
                         if (nx_have) {

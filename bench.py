@@ -244,8 +244,18 @@ def extra_layouts(L, dev, stream, T):
                                   tv[:bc].cpu().numpy() if nc == 3 else None, q)[0]
         parity = bool(np.array_equal(out[:W * H * 4].cpu().numpy().reshape(H, W, 4), exp))
         bpp = 4 + 2 * (1 + (2.0 / (h * v) if nc == 3 else 0))
+        # the layout's bare access pattern on the same buffers (ffhip_jpeg_pattern_calibrate; `out` holds meaningless bytes afterwards)
+        def cal():
+            capi.check(L.ffhip_jpeg_pattern_calibrate(C.byref(g), n, ty.data_ptr(), tu.data_ptr() if nc == 3 else None, tv.data_ptr() if nc == 3 else None,
+                                                      t_q.data_ptr(), 0, out.data_ptr(), W * 4, W * 4 * H, stream), "ffhip_jpeg_pattern_calibrate")
+        try:
+            ms_pat = T.ms(cal, reps=10, warm=2)
+        except Exception:
+            ms_pat = None
         res[name] = {"ms_per_step": round(ms, 4), "value": round(n * W * H / ms / 1e3, 1), "unit": "Mpixels/s", "parity_vs_oracle_first_image": parity,
-                     "roofline": dict(roof(bpp * n * W * H, ms), kernel="k_jpeg_fused_strip")}
+                     "roofline": dict(roof(bpp * n * W * H, ms), kernel="k_jpeg_fused_strip",
+                                      pattern_GBps=None if ms_pat is None else round(bpp * n * W * H / ms_pat / 1e6, 1),
+                                      frac_of_pattern=None if ms_pat is None else round(ms_pat / ms, 4))}
         del ty, tu, tv, out
         torch.cuda.empty_cache()
     return {"workload": "256 x 3840x2160 grids of the other baseline layouts (4:4:4, 4:2:2, 4:4:0, grey, 4:1:1 = h4v1 and its transpose h1v4), one launch each", **res}
@@ -1027,7 +1037,8 @@ def compact_configs(extra):
     c2 = extra.get("c2", {})
     out["c2"] = {"value": g(c2, "value"), "frac": g(c2, "roofline", "frac"), "parity": g(c2, "parity_vs_oracle_first_and_last_image")} if "error" not in c2 else c2
     lay = extra.get("jpeg_layouts", {})
-    out["layouts"] = {k: {"frac": g(v, "roofline", "frac"), "parity": g(v, "parity_vs_oracle_first_image")} for k, v in lay.items() if isinstance(v, dict)} if "error" not in lay else lay
+    out["layouts"] = {k: {"frac": g(v, "roofline", "frac"), "of_pattern": g(v, "roofline", "frac_of_pattern"), "parity": g(v, "parity_vs_oracle_first_image")}
+                      for k, v in lay.items() if isinstance(v, dict)} if "error" not in lay else lay
     c4 = extra.get("c4", {})
     if "error" in c4:
         out["c4"] = c4

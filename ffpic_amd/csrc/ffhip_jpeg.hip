@@ -535,7 +535,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg420_fused(JpegBatch p)
 #define SM_VP 3072
 #define SM_WAVE_BYTES 4096
 
-template <int H, int V, int NC, int NT>
+template <int H, int V, int NC, int NT, bool PATTERN = false> /* PATTERN: the loads and the stores only (ffhip_jpeg_pattern_calibrate) */
 __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
 {
     constexpr int BPM = H * V;                            /* luma blocks per MCU          */
@@ -613,14 +613,21 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
         const u32 key = row_samples >= 64 ? (row & 7u) : ((row >> 2) & 3u);
         return row * row_samples * 2 + ((((col >> 3) ^ key) & (row_samples / 8 - 1)) << 4) + (col & 7u) * 2;
     };
+    u32x4 pat = {0u, 0u, 0u, 0u}; /* PATTERN: what gets stored -- an XOR of everything the wave loaded */
+    if (PATTERN) {
 #pragma unroll
-    for (int lr = 0; lr < LR; lr++) {
+        for (int lr = 0; lr < LR; lr++) pat = pat ^ ly[lr];
+        if (NC == 3) pat = pat ^ lc0;
+        if (NC == 3 && BPM == 1) pat = pat ^ lc1;
+    }
+#pragma unroll
+    for (int lr = 0; lr < LR && !PATTERN; lr++) {
         const u32x4 pk = idct8x8_round(c, ly[lr], q_y);
         const u32 gb = c.blk + 8 * lr, m = gb / BPM, sub = gb % BPM;
         const u32 pcol = (m * H + (H > 1 ? sub : 0)) * 8, prow = (V > 1 ? sub : 0) * 8 + c.idx;
         *(u32x4 *)(c.lds + YP + sw_off(V == 2 ? yrow_pos(prow) : prow, pcol, SW)) = pk;
     }
-    if (NC == 3) {
+    if (NC == 3 && !PATTERN) {
         if (BPM == 1) {
             const u32x4 pu = idct8x8_round(c, lc0, q_c0);
             *(u32x4 *)(c.lds + UP + sw_off(c.idx, c.blk * 8, CW)) = pu;
@@ -665,6 +672,14 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
 #pragma unroll
     for (int it = 0; it < PASSES; it++) {
         const u32 prow = pass_row(it);
+        if (PATTERN) { /* the pass's store, at its address and under its mask */
+            if (mcu0 + (int)(pc0 / (8 * H)) <= last) {
+                u32x4 *dst = (u32x4 *)(obase + (long long)prow * p.pitch + pc0 * 4);
+                if (NT & 2) __builtin_nontemporal_store(pat + (u32)it, dst);
+                else *dst = pat + (u32)it;
+            }
+            continue;
+        }
         const u32x2 yy = *(const u32x2 *)(c.lds + YP + y_offs[it]);
         if (V >= 2 && (it & 1)) {
             /* the terms of pass 0 serve this row too */
@@ -876,8 +891,9 @@ static void launch_fused(const JpegBatch &q_in, int n_images, hipStream_t st)
      * (7 as shipped; 8192 -> 5, 16384 -> 4, 32768 -> 3, 61440 -> 1): the occupancy experiment of DESIGN.md 5 as a run-time switch */
     const char *pe = FFHIP_ENV("FFHIP_JPEG_LDS_PAD");
     const unsigned pad = pe && atoi(pe) > 0 && atoi(pe) <= 120 * 1024 ? (unsigned)atoi(pe) & ~15u : 0u;
-    if (q.pattern_only) { /* the shipped variant's twin: same grid, same loads, same stores */
-        hipLaunchKernelGGL((k_jpeg420_fused<FFHIP_JPEG_DEFAULT_VARIANT / 10, FFHIP_JPEG_DEFAULT_VARIANT % 10, true>), grid, dim3(WG_THREADS), pad, st, q);
+    if (q.pattern_only) { /* the variant's twin (non-temporal loads and stores): same grid, same loads, same stores */
+        if (qpw == 2) hipLaunchKernelGGL((k_jpeg420_fused<2, 3, true>), grid, dim3(WG_THREADS), pad, st, q);
+        else hipLaunchKernelGGL((k_jpeg420_fused<1, 3, true>), grid, dim3(WG_THREADS), pad, st, q);
         return;
     }
 #define FFHIP_LAUNCH(Q, N) hipLaunchKernelGGL((k_jpeg420_fused<Q, N>), grid, dim3(WG_THREADS), pad, st, q)
@@ -910,6 +926,15 @@ static void launch_strip(const ffhip_jpeg_geom *g, const JpegBatch &q_in, int n_
     q.wgs_per_image = (q.quads_per_image + WAVES_PER_WG - 1) / WAVES_PER_WG;
     q.wpi_magic = q.wgs_per_image == 1 ? 0xffffffffu : (u32)(0x100000000ULL / (unsigned)q.wgs_per_image) + 1u;
     const dim3 grid((unsigned)((long long)q.wgs_per_image * n_images), 1, 1);
+    if (q.pattern_only) { /* the arithmetic-free twins: same grids, loads and stores */
+        if (g->ncomp == 1) hipLaunchKernelGGL((k_jpeg_fused_strip<1, 1, 1, 3, true>), grid, dim3(WG_THREADS), 0, st, q);
+        else if (g->h == 1 && g->v == 1) hipLaunchKernelGGL((k_jpeg_fused_strip<1, 1, 3, 3, true>), grid, dim3(WG_THREADS), 0, st, q);
+        else if (g->h == 2) hipLaunchKernelGGL((k_jpeg_fused_strip<2, 1, 3, 3, true>), grid, dim3(WG_THREADS), 0, st, q);
+        else if (g->v == 2) hipLaunchKernelGGL((k_jpeg_fused_strip<1, 2, 3, 3, true>), grid, dim3(WG_THREADS), 0, st, q);
+        else if (g->h == 4) hipLaunchKernelGGL((k_jpeg_fused_strip<4, 1, 3, 3, true>), grid, dim3(WG_THREADS), 0, st, q);
+        else hipLaunchKernelGGL((k_jpeg_fused_strip<1, 4, 3, 3, true>), grid, dim3(WG_THREADS), 0, st, q);
+        return;
+    }
     if (g->ncomp == 1) hipLaunchKernelGGL((k_jpeg_fused_strip<1, 1, 1, 3>), grid, dim3(WG_THREADS), 0, st, q);
     else if (g->h == 1 && g->v == 1) hipLaunchKernelGGL((k_jpeg_fused_strip<1, 1, 3, 3>), grid, dim3(WG_THREADS), 0, st, q);
     else if (g->h == 2) hipLaunchKernelGGL((k_jpeg_fused_strip<2, 1, 3, 3>), grid, dim3(WG_THREADS), 0, st, q);
@@ -970,7 +995,7 @@ static int jpeg_recon_batch_impl(const ffhip_jpeg_geom *g, int n_images, const i
     if (!ffhip_have_device()) return FFHIP_ENODEV;
     hipStream_t st = (hipStream_t)stream;
 
-    if (pattern_only && !is_fused420(g)) return FFHIP_EINVAL;
+    if (pattern_only && !is_fused420(g) && !is_fused_strip(g)) return FFHIP_EINVAL;
     if (is_fused420(g)) {
         JpegBatch p;
         p.pattern_only = 0;
@@ -1009,6 +1034,7 @@ static int jpeg_recon_batch_impl(const ffhip_jpeg_geom *g, int n_images, const i
     if (is_fused_strip(g)) {
         const int mps = (g->ncomp == 1 || g->h * g->v == 1) ? 8 : 4, bpm = g->ncomp == 1 ? 1 : g->h * g->v;
         JpegBatch p = {};
+        p.pattern_only = pattern_only ? 1 : 0;
         p.coef_y = d_coef_y; p.coef_u = d_coef_u; p.coef_v = d_coef_v;
         p.quant = d_quant; p.quant_stride = quant_stride;
         p.bgra = d_bgra; p.pitch = pitch; p.image_stride = image_stride;
@@ -1075,8 +1101,9 @@ extern "C" int ffhip_jpeg_recon_batch(const ffhip_jpeg_geom *g, int n_images, co
 {
     return jpeg_recon_batch_impl(g, n_images, d_coef_y, d_coef_u, d_coef_v, d_quant, quant_stride, d_bgra, pitch, image_stride, d_workspace, workspace_bytes, stream, false);
 }
-/* Calibration (bench.py's roofline.pattern_GBps): the 4:2:0 fused kernel's loads and stores on the caller's buffers with NO arithmetic in between -- same
- * grid, same workgroup-to-XCD mapping, same addresses and masks; d_bgra receives meaningless bytes.  4:2:0 only (FFHIP_EINVAL otherwise). */
+/* Calibration (bench.py's roofline.pattern_GBps): the fused kernel's loads and stores on the caller's buffers with NO arithmetic in between -- same
+ * grid, same workgroup-to-XCD mapping, same addresses and masks; d_bgra receives meaningless bytes.  Every layout a fused kernel takes (4:2:0 and the
+ * strip layouts); FFHIP_EINVAL for the two-pass geometries. */
 extern "C" int ffhip_jpeg_pattern_calibrate(const ffhip_jpeg_geom *g, int n_images, const int16_t *d_coef_y, const int16_t *d_coef_u, const int16_t *d_coef_v,
                                             const uint16_t *d_quant, int64_t quant_stride, uint8_t *d_bgra, int64_t pitch, int64_t image_stride, void *stream)
 {

@@ -579,7 +579,8 @@ int ffhip_bmp_write(const char *path, const uint8_t *bgra, int width, int height
 int ffhip_copy_calibrate(void *d_dst, const void *d_src, size_t bytes, void *stream);
 /* A second calibration for the same purpose: the 4:2:0 fused kernel's own ACCESS PATTERN -- its loads and its stores, same grid, same addresses --
  * with the arithmetic taken out, on the caller's buffers (d_bgra receives meaningless bytes).  The rate of this launch is the ceiling the fused
- * kernel can be read against on exactly this placement of its buffers (DESIGN.md 5 "Round 6").  Arguments as ffhip_jpeg_recon_batch; 4:2:0 only. */
+ * kernel can be read against on exactly this placement of its buffers (DESIGN.md 5 "Round 6").  Arguments as ffhip_jpeg_recon_batch; every layout a fused kernel takes
+ * (4:2:0, 4:4:4, 4:2:2, 4:4:0, 4:1:1, its transpose, grey), FFHIP_EINVAL for the others. */
 int ffhip_jpeg_pattern_calibrate(const ffhip_jpeg_geom *geom, int n_images, const int16_t *d_coef_y, const int16_t *d_coef_u, const int16_t *d_coef_v,
                                  const uint16_t *d_quant, int64_t quant_stride, uint8_t *d_bgra, int64_t pitch, int64_t image_stride, void *stream);
 

@@ -412,11 +412,45 @@ def test_pattern_calibration_touches_what_the_kernel_touches(cols, rows, pad):
     if pad:
         assert (img[:, :, W * 4:] == 0xA5).all()                           # nothing in the padding of a row
     # the words it stores are XORs of coefficient words + a small counter: with random coefficients practically none equals the fill pattern
-    touched = (img[:, :, :W * 4].reshape(n, H, W, 4).view(np.uint32)[..., 0] != 0xA5A5A5A5)
+    touched = (np.ascontiguousarray(img[:, :, :W * 4]).reshape(n, H, W, 4).view(np.uint32)[..., 0] != 0xA5A5A5A5)
     assert touched.mean() > 0.99
     capi.check(L.ffhip_jpeg_recon_batch(C.byref(cg), n, dy.ptr, du.ptr, dv.ptr, dq.ptr, 0, out.ptr, pitch, stride, None, 0, None))
     capi.check(L.ffhip_stream_sync(None))
     got = out.to_host((n * stride + 4096,), np.uint8)[:n * stride].reshape(n, H, pitch)[:, :, :W * 4].reshape(n, H, W, 4)
     assert np.array_equal(got, O.oracle_jpeg_recon(geom, cy, cu, cv, q, n_images=n))
-    g444 = to_capi(O.make_geom(cols, rows, 3, 1, 1))
-    assert L.ffhip_jpeg_pattern_calibrate(C.byref(g444), 1, dy.ptr, du.ptr, dv.ptr, dq.ptr, 0, out.ptr, cols * 8 * 4, cols * 8 * 4 * rows * 8, None) == capi.FFHIP_EINVAL
+    g31 = to_capi(O.make_geom(cols, rows, 3, 3, 1))     # a two-pass geometry has no fused kernel, hence no twin
+    assert L.ffhip_jpeg_pattern_calibrate(C.byref(g31), 1, dy.ptr, du.ptr, dv.ptr, dq.ptr, 0, out.ptr, cols * 24 * 4, cols * 24 * 4 * rows * 8, None) == capi.FFHIP_EINVAL
+
+
+@pytest.mark.parametrize("nc,h,v", [(3, 1, 1), (3, 2, 1), (3, 1, 2), (1, 1, 1), (3, 4, 1), (3, 1, 4)])
+def test_pattern_calibration_of_the_strip_layouts(nc, h, v):
+    """the arithmetic-free twins of k_jpeg_fused_strip: every pixel of the coded picture written (ragged strip ends included), nothing beyond it, and the
+    next real launch bit-exact"""
+    import ctypes as C
+    L = capi.require_device()
+    cols, rows, n = 11, 6, 2
+    geom = O.make_geom(cols, rows, nc, h, v)
+    cg = to_capi(geom)
+    q = synth.quant_tables(70)
+    cy, cu, cv = synth.coef_batch(n, cols, rows, nc, h, v, quant=q)
+    W, H = cols * 8 * h, rows * 8 * v
+    pitch = (W * 4 + 15) // 16 * 16 + 64
+    stride = pitch * H
+    dy = ops.DeviceBuffer(cy)
+    du, dv = (ops.DeviceBuffer(cu), ops.DeviceBuffer(cv)) if nc == 3 else (None, None)
+    dq = ops.DeviceBuffer(np.ascontiguousarray(q.astype(np.uint16)))
+    out = ops.DeviceBuffer(nbytes=n * stride + 4096)
+    capi.check(L.ffhip_memset(out.ptr, 0xA5, n * stride + 4096, None))
+    up, vp = (du.ptr, dv.ptr) if nc == 3 else (None, None)
+    capi.check(L.ffhip_jpeg_pattern_calibrate(C.byref(cg), n, dy.ptr, up, vp, dq.ptr, 0, out.ptr, pitch, stride, None))
+    capi.check(L.ffhip_stream_sync(None))
+    raw = out.to_host((n * stride + 4096,), np.uint8)
+    assert (raw[n * stride:] == 0xA5).all()
+    img = raw[:n * stride].reshape(n, H, pitch)
+    assert (img[:, :, W * 4:] == 0xA5).all()
+    touched = np.ascontiguousarray(img[:, :, :W * 4]).reshape(n, H, W, 4).view(np.uint32)[..., 0] != 0xA5A5A5A5
+    assert touched.mean() > 0.99
+    capi.check(L.ffhip_jpeg_recon_batch(C.byref(cg), n, dy.ptr, up, vp, dq.ptr, 0, out.ptr, pitch, stride, None, 0, None))
+    capi.check(L.ffhip_stream_sync(None))
+    got = np.ascontiguousarray(out.to_host((n * stride + 4096,), np.uint8)[:n * stride].reshape(n, H, pitch)[:, :, :W * 4]).reshape(n, H, W, 4)
+    assert np.array_equal(got, O.oracle_jpeg_recon(geom, cy, cu, cv, q, n_images=n))

@@ -47,6 +47,9 @@
 #define FFHIP_LDS_PAD 0 /* experiment knob: extra LDS per wave to lower occupancy */
 #endif
 #define FFHIP_JPEG_DEFAULT_VARIANT 13 /* <quads per wave><nt bits> */
+#ifndef FFHIP_JPEG_STRIPS_DEFAULT
+#define FFHIP_JPEG_STRIPS_DEFAULT 2 /* strips' worth per wave of the 4:4:4, 4:2:2 and 4:4:0 kernels (FFHIP_JPEG_STRIPS=1 / 2 at run time, grey too) */
+#endif
 #define WG_THREADS (64 * WAVES_PER_WG)
 
 /* per-wave LDS layout (bytes) */
@@ -535,24 +538,31 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg420_fused(JpegBatch p)
 #define SM_VP 3072
 #define SM_WAVE_BYTES 4096
 
-template <int H, int V, int NC, int NT, bool PATTERN = false> /* PATTERN: the loads and the stores only (ffhip_jpeg_pattern_calibrate) */
+/* TWO (round 6): two strips' worth per wave for the layouts with h * v <= 2 and grey as well -- 16 MCUs of 4:4:4 / grey (128x8), 8 MCUs of 4:2:2 (128x8) or 4:4:0
+ * (64x16): 1 024 pixels, four colour passes, the chroma in two rounds (U, V) or four (4:4:4).  4:4:4 and 4:2:2 are the two layouts that stop short of their access
+ * pattern on a fast placement (5.9-6.0 of 6.7-6.8 TB/s, profiles/r6_layout_patterns.jsonl) with the most instructions per byte; what a wave spends before its first
+ * IDCT round -- index arithmetic, lane roles, quantiser rows -- is paid once per 1 024 pixels instead of per 512. */
+template <int H, int V, int NC, int NT, bool PATTERN = false, int TWO = 0> /* PATTERN: the loads and the stores only (ffhip_jpeg_pattern_calibrate) */
 __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
 {
     constexpr int BPM = H * V;                            /* luma blocks per MCU          */
-    constexpr int MPS = (NC == 1 || BPM == 1) ? 8 : 4;   /* MCUs per strip */
-    constexpr int LR = BPM == 4 ? 2 : 1;                 /* luma rounds: 4:1:1 and its transpose take TWO strips' worth of luma per wave (1 024 pixels), so that
+    constexpr int MPS = ((NC == 1 || BPM == 1) ? 8 : 4) * ((TWO && BPM < 4) ? 2 : 1); /* MCUs per strip (of a wave) */
+    constexpr int LR = MPS * BPM / 8;                    /* luma rounds: 4:1:1 and its transpose take TWO strips' worth of luma per wave (1 024 pixels), so that
                                                             their one chroma round (4 U + 4 V blocks) has no idle block -- 1.5 rounds per 512 pixels where the
                                                             single strip took 2 -- and the transpose's rows are runs of 128 bytes, not 64 */
     constexpr int PASSES = 2 * LR;                       /* colour passes of 256 pixels */
-    constexpr int SW = MPS * 8 * H, SH = 8 * V;          /* strip size in pixels (512; h * v = 4: 1024) */
+    constexpr int SW = MPS * 8 * H, SH = 8 * V;          /* strip size in pixels (512; h * v = 4 or TWO: 1024) */
     constexpr int CW = MPS * 8;                          /* chroma samples per strip row */
     constexpr int GPR = SW / 4;                          /* 4-pixel groups per pixel row */
-    static_assert(SW * SH == 512 * LR && BPM <= 4 && BPM != 3 && (H == 1 || V == 1), "strip geometry");
+    constexpr int RPP = 64 / GPR;                        /* lane rows per pass */
+    static_assert((LR == 1 || LR == 2) && SW * SH == 512 * LR && BPM <= 4 && BPM != 3 && (H == 1 || V == 1), "strip geometry");
     /* the sample planes in the wave's LDS behind the 1 KB work tile: luma SW x SH, then U and V (8 rows of CW) */
-    constexpr int YP = SM_YP, UP = YP + SW * SH * 2, VP = UP + (LR == 2 ? 512 : 1024);
+    constexpr int CPB = CW * 8 * 2;                      /* bytes of a chroma plane */
+    constexpr int YP = SM_YP, UP = YP + SW * SH * 2, VP = UP + ((LR == 1 && CPB < 1024) ? 1024 : CPB);
+    constexpr int WAVE_LDS = NC == 3 ? VP + CPB : UP;
+    constexpr int WAVE_BYTES = WAVE_LDS <= SM_WAVE_BYTES ? SM_WAVE_BYTES : (WAVE_LDS + 1023) / 1024 * 1024; /* 4 KB as ever; TWO: 4:4:4 7 KB, 4:2:2 / 4:4:0 5 KB */
     static_assert(UP == SM_UP || LR == 2, "plane offsets");
-    static_assert(VP + CW * 8 * 2 <= SM_WAVE_BYTES, "planes fit the wave's LDS");
-    __shared__ __attribute__((aligned(16))) char lds_all[WAVES_PER_WG * SM_WAVE_BYTES];
+    __shared__ __attribute__((aligned(16))) char lds_all[WAVES_PER_WG * WAVE_BYTES];
     const u32 lane = threadIdx.x & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     u32 wg;
@@ -571,13 +581,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
     const int rem = last - mcu0 < MPS - 1 ? last - mcu0 : MPS - 1; /* MCUs of this strip that exist, minus one */
 
     WaveCtx c;
-    wave_ctx_init(c, lds_all + wave * SM_WAVE_BYTES, lane);
+    wave_ctx_init(c, lds_all + wave * WAVE_BYTES, lane);
     const u32 row = lane & 7, lblk = lane >> 3;
     const long long mcu_base = ((long long)img * p.mcu_rows + mrow) * p.mcu_cols + mcu0; /* scalar */
     const uint16_t *qt = p.quant + (long long)img * p.quant_stride;
 
     /* ---- all loads up front: ragged strips re-read their last MCU, its pixels are never stored ---- */
-    u32x4 ly[LR], lc0, lc1;
+    u32x4 ly[LR], lc0, lc1, lc2, lc3; /* (lc2, lc3: the second halves of U and V where a wave has sixteen MCUs of 4:4:4) */
 #pragma unroll
     for (int lr = 0; lr < LR; lr++) {
         int m = ((int)lblk + 8 * lr) / BPM;
@@ -587,10 +597,15 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
     const u32x4 q_y = *(const u32x4 *)(qt + p.qt_y * 64 + row * 8);
     u32x4 q_c0 = q_y, q_c1 = q_y;
     if (NC == 3) {
-        if (BPM == 1) { /* two rounds of 8 blocks: U, then V */
+        if (MPS >= 8) { /* rounds of 8 blocks: U, then V (sixteen MCUs: two of each) */
             const int m = (int)lblk > rem ? rem : (int)lblk;
             lc0 = load16<NT & 1>((const char *)(p.coef_u + (mcu_base + m) * 64 + row * 8));
             lc1 = load16<NT & 1>((const char *)(p.coef_v + (mcu_base + m) * 64 + row * 8));
+            if (MPS == 16) {
+                const int m2 = (int)lblk + 8 > rem ? rem : (int)lblk + 8;
+                lc2 = load16<NT & 1>((const char *)(p.coef_u + (mcu_base + m2) * 64 + row * 8));
+                lc3 = load16<NT & 1>((const char *)(p.coef_v + (mcu_base + m2) * 64 + row * 8));
+            }
             q_c0 = *(const u32x4 *)(qt + p.qt_u * 64 + row * 8);
             q_c1 = *(const u32x4 *)(qt + p.qt_v * 64 + row * 8);
         } else {        /* one round: blocks 0-3 = U of MCU 0-3, blocks 4-7 = V */
@@ -618,7 +633,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
 #pragma unroll
         for (int lr = 0; lr < LR; lr++) pat = pat ^ ly[lr];
         if (NC == 3) pat = pat ^ lc0;
-        if (NC == 3 && BPM == 1) pat = pat ^ lc1;
+        if (NC == 3 && MPS >= 8) pat = pat ^ lc1;
+        if (NC == 3 && MPS == 16) pat = pat ^ lc2 ^ lc3;
     }
 #pragma unroll
     for (int lr = 0; lr < LR && !PATTERN; lr++) {
@@ -628,11 +644,17 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
         *(u32x4 *)(c.lds + YP + sw_off(V == 2 ? yrow_pos(prow) : prow, pcol, SW)) = pk;
     }
     if (NC == 3 && !PATTERN) {
-        if (BPM == 1) {
+        if (MPS >= 8) {
             const u32x4 pu = idct8x8_round(c, lc0, q_c0);
             *(u32x4 *)(c.lds + UP + sw_off(c.idx, c.blk * 8, CW)) = pu;
             const u32x4 pv = idct8x8_round(c, lc1, q_c1);
             *(u32x4 *)(c.lds + VP + sw_off(c.idx, c.blk * 8, CW)) = pv;
+            if (MPS == 16) {
+                const u32x4 pu2 = idct8x8_round(c, lc2, q_c0);
+                *(u32x4 *)(c.lds + UP + sw_off(c.idx, (c.blk + 8) * 8, CW)) = pu2;
+                const u32x4 pv2 = idct8x8_round(c, lc3, q_c1);
+                *(u32x4 *)(c.lds + VP + sw_off(c.idx, (c.blk + 8) * 8, CW)) = pv2;
+            }
         } else {
             const u32x4 pc = idct8x8_round(c, lc0, q_c0);
             if (MPS == 4 || (c.blk & 3) < MPS) /* h*v = 4: blocks 2, 3, 6, 7 of the round are repeats of the strip's last MCU */
@@ -653,15 +675,16 @@ __global__ __launch_bounds__(WG_THREADS) void k_jpeg_fused_strip(JpegBatch p)
     /* v = 4: rows 2j and 2j + 1 share (row >> 2), i.e. the swizzle key: the next plane row, 32 bytes on */
     const u32 y_off1 = SW == 64 ? (y_off0 ^ 0x40u) + 4 * 128 : (SW == 32 ? (y_off0 ^ 0x20u) + 8 * 64 : y_off0 + 32);
     static_assert((SW == 64 && 64 / GPR == 4 && V == 1) || (SW == 32 && V == 2) || LR == 2, "pass-1 offset identities");
-    /* the pixel row of pass `it`.  h * v = 4 (four passes): 4:1:1 is 128 x 8 pixels, two rows a pass; its transpose 32 x 32, rows 2j and 2j + 1 of the upper
-     * half, then of the lower half (a lane's two rows of a half share their chroma row) */
+    /* the pixel row of pass `it`.  v = 1: RPP lane rows a pass, one below the other (128 x 8 pixels: two rows a pass, four passes).  v >= 2: a lane takes rows
+     * 2j and 2j + 1 in two passes running (they share their chroma row), RPP such pairs a pass pair -- the transpose of 4:1:1 (32 x 32): the upper half, then the
+     * lower half; two strips of 4:4:0 (64 x 16): rows 0-7, then 8-15 */
     auto pass_row = [&](int it) -> u32 {
-        return LR == 2 ? (H == 4 ? row0 + 2 * it : row0 + (it & 1) + 16 * (it >> 1)) : row0 + (V >= 2 ? it : it * (64 / GPR));
+        return V >= 2 ? row0 + (u32)(it & 1) + (u32)(2 * RPP * (it >> 1)) : row0 + (u32)(it * RPP);
     };
     u32 y_offs[PASSES], c_offs[PASSES];
 #pragma unroll
     for (int it = 0; it < PASSES; it++) {
-        y_offs[it] = LR == 2 ? sw_off(pass_row(it), pc0, SW) : (it ? y_off1 : y_off0); /* (h * v = 4: worked out pass by pass) */
+        y_offs[it] = LR == 2 ? sw_off(V == 2 ? yrow_pos(pass_row(it)) : pass_row(it), pc0, SW) : (it ? y_off1 : y_off0); /* (four passes: worked out pass by pass) */
         c_offs[it] = 0;
     }
     const u32 c_off0 = NC == 3 ? sw_off(row0 / V, pc0 / H, CW) : 0;
@@ -919,6 +942,16 @@ static int is_fused_strip(const ffhip_jpeg_geom *g)
     return (g->ncomp == 3 && (g->h * g->v <= 2 || g->h == 4 || g->v == 4)) || (g->ncomp == 1 && g->h == 1 && g->v == 1);
 }
 
+/* two strips' worth per wave for the layouts with h * v <= 2 and grey (k_jpeg_fused_strip<..., TWO = 1>); h * v = 4 always has.  FFHIP_JPEG_STRIPS=1 / 2 forces either */
+static bool strip_two(const ffhip_jpeg_geom *g)
+{
+    if (g->ncomp == 3 && g->h * g->v == 4) return false;
+    const char *e = FFHIP_ENV("FFHIP_JPEG_STRIPS");
+    if (e && (e[0] == '1' || e[0] == '2')) return e[0] == '2';
+    /* 4:4:4, 4:2:2, 4:4:0: + 2-3 %, + 4-5 %, + 3-6 % on the same output buffer, slow and fast placements alike; grey, which runs at its access pattern with one
+     * strip, loses 1-4 % with two (the pattern of 128 x 8-pixel strips is that much slower than that of 64 x 8: profiles/r6_strips_ab*.jsonl) */
+    return FFHIP_JPEG_STRIPS_DEFAULT == 2 && g->ncomp == 3;
+}
 static void launch_strip(const ffhip_jpeg_geom *g, const JpegBatch &q_in, int n_images, hipStream_t st)
 {
     JpegBatch q = q_in;
@@ -926,21 +959,21 @@ static void launch_strip(const ffhip_jpeg_geom *g, const JpegBatch &q_in, int n_
     q.wgs_per_image = (q.quads_per_image + WAVES_PER_WG - 1) / WAVES_PER_WG;
     q.wpi_magic = q.wgs_per_image == 1 ? 0xffffffffu : (u32)(0x100000000ULL / (unsigned)q.wgs_per_image) + 1u;
     const dim3 grid((unsigned)((long long)q.wgs_per_image * n_images), 1, 1);
-    if (q.pattern_only) { /* the arithmetic-free twins: same grids, loads and stores */
-        if (g->ncomp == 1) hipLaunchKernelGGL((k_jpeg_fused_strip<1, 1, 1, 3, true>), grid, dim3(WG_THREADS), 0, st, q);
-        else if (g->h == 1 && g->v == 1) hipLaunchKernelGGL((k_jpeg_fused_strip<1, 1, 3, 3, true>), grid, dim3(WG_THREADS), 0, st, q);
-        else if (g->h == 2) hipLaunchKernelGGL((k_jpeg_fused_strip<2, 1, 3, 3, true>), grid, dim3(WG_THREADS), 0, st, q);
-        else if (g->v == 2) hipLaunchKernelGGL((k_jpeg_fused_strip<1, 2, 3, 3, true>), grid, dim3(WG_THREADS), 0, st, q);
-        else if (g->h == 4) hipLaunchKernelGGL((k_jpeg_fused_strip<4, 1, 3, 3, true>), grid, dim3(WG_THREADS), 0, st, q);
-        else hipLaunchKernelGGL((k_jpeg_fused_strip<1, 4, 3, 3, true>), grid, dim3(WG_THREADS), 0, st, q);
-        return;
-    }
-    if (g->ncomp == 1) hipLaunchKernelGGL((k_jpeg_fused_strip<1, 1, 1, 3>), grid, dim3(WG_THREADS), 0, st, q);
-    else if (g->h == 1 && g->v == 1) hipLaunchKernelGGL((k_jpeg_fused_strip<1, 1, 3, 3>), grid, dim3(WG_THREADS), 0, st, q);
-    else if (g->h == 2) hipLaunchKernelGGL((k_jpeg_fused_strip<2, 1, 3, 3>), grid, dim3(WG_THREADS), 0, st, q);
-    else if (g->v == 2) hipLaunchKernelGGL((k_jpeg_fused_strip<1, 2, 3, 3>), grid, dim3(WG_THREADS), 0, st, q);
-    else if (g->h == 4) hipLaunchKernelGGL((k_jpeg_fused_strip<4, 1, 3, 3>), grid, dim3(WG_THREADS), 0, st, q);
-    else hipLaunchKernelGGL((k_jpeg_fused_strip<1, 4, 3, 3>), grid, dim3(WG_THREADS), 0, st, q);
+    const bool two = strip_two(g);
+#define STRIP_LAUNCH(H_, V_, NC_) do { \
+        if (q.pattern_only) { /* the arithmetic-free twins: same grids, loads and stores */ \
+            if (two) hipLaunchKernelGGL((k_jpeg_fused_strip<H_, V_, NC_, 3, true, 1>), grid, dim3(WG_THREADS), 0, st, q); \
+            else hipLaunchKernelGGL((k_jpeg_fused_strip<H_, V_, NC_, 3, true, 0>), grid, dim3(WG_THREADS), 0, st, q); \
+        } else if (two) hipLaunchKernelGGL((k_jpeg_fused_strip<H_, V_, NC_, 3, false, 1>), grid, dim3(WG_THREADS), 0, st, q); \
+        else hipLaunchKernelGGL((k_jpeg_fused_strip<H_, V_, NC_, 3, false, 0>), grid, dim3(WG_THREADS), 0, st, q); \
+    } while (0)
+    if (g->ncomp == 1) STRIP_LAUNCH(1, 1, 1);
+    else if (g->h == 1 && g->v == 1) STRIP_LAUNCH(1, 1, 3);
+    else if (g->h == 2) STRIP_LAUNCH(2, 1, 3);
+    else if (g->v == 2) STRIP_LAUNCH(1, 2, 3);
+    else if (g->h == 4) STRIP_LAUNCH(4, 1, 3);
+    else STRIP_LAUNCH(1, 4, 3);
+#undef STRIP_LAUNCH
 }
 
 static int grid_for(long long work_items_per_wg_unit)
@@ -1032,7 +1065,7 @@ static int jpeg_recon_batch_impl(const ffhip_jpeg_geom *g, int n_images, const i
     }
 
     if (is_fused_strip(g)) {
-        const int mps = (g->ncomp == 1 || g->h * g->v == 1) ? 8 : 4, bpm = g->ncomp == 1 ? 1 : g->h * g->v;
+        const int mps = ((g->ncomp == 1 || g->h * g->v == 1) ? 8 : 4) * (strip_two(g) ? 2 : 1), bpm = g->ncomp == 1 ? 1 : g->h * g->v;
         JpegBatch p = {};
         p.pattern_only = pattern_only ? 1 : 0;
         p.coef_y = d_coef_y; p.coef_u = d_coef_u; p.coef_v = d_coef_v;

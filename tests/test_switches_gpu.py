@@ -42,6 +42,29 @@ def test_jpeg_launch_shapes(env, switch):
         assert np.array_equal(gpu_recon(geom, n, cy, cu, cv, q), exp), (env, cols, rows, n)
 
 
+@pytest.mark.parametrize("strips", ["1", "2"])
+@pytest.mark.parametrize("nc,h,v", [(3, 1, 1), (3, 2, 1), (3, 1, 2), (1, 1, 1), (3, 4, 1), (3, 1, 4)])
+def test_jpeg_strips_per_wave(nc, h, v, strips, switch):
+    """FFHIP_JPEG_STRIPS=1 / 2: one or two strips' worth per wave of k_jpeg_fused_strip (h * v = 4 always has two) -- whole and ragged MCU counts (a strip of 16, 8
+    or 4 MCUs cut anywhere), several images, per-image quantiser tables, and the exact-integer green branch via adversarial coefficients"""
+    switch(FFHIP_JPEG_STRIPS=strips)
+    for cols, rows, n in ((1, 1, 1), (7, 3, 2), (9, 2, 3), (16, 5, 1), (17, 4, 2), (33, 3, 1), (64, 9, 1)):
+        geom = O.make_geom(cols, rows, nc, h, v)
+        q = np.stack([synth.quant_tables(40 + 9 * i) for i in range(n)])
+        cy, cu, cv = synth.coef_batch(n, cols, rows, nc, h, v, quant=q[0])
+        exp = O.oracle_jpeg_recon(geom, cy, cu, cv, q, n_images=n, n_threads=4)
+        assert np.array_equal(gpu_recon(geom, n, cy, cu, cv, q), exp), (nc, h, v, strips, cols, rows, n)
+    rng = np.random.default_rng(77)                                  # full-range coefficients: int16 wrap, clamps, exact-integer G
+    cols, rows, n = 18, 3, 1
+    geom = O.make_geom(cols, rows, nc, h, v)
+    by = cols * rows * (h * v if nc == 3 else 1)
+    cy = rng.integers(-32768, 32768, size=by * 64, dtype=np.int16)
+    cu = rng.integers(-2048, 2048, size=cols * rows * 64, dtype=np.int16) if nc == 3 else None
+    cv = rng.integers(-2048, 2048, size=cols * rows * 64, dtype=np.int16) if nc == 3 else None
+    q = synth.quant_tables(95)
+    assert np.array_equal(gpu_recon(geom, n, cy, cu, cv, q), O.oracle_jpeg_recon(geom, cy, cu, cv, q, n_images=n)), (nc, h, v, strips, "adversarial")
+
+
 def test_color8_scalar_form(switch):
     """FFHIP_COLOR8_SCALAR=1: the one-pixel-per-lane form of the 8-bit planar converter instead of the packed one -- all 65 536 chroma pairs"""
     rng = np.random.default_rng(3)

@@ -40,4 +40,9 @@ for a in range(int(os.environ.get("ALLOCS", "4"))):
     row = {"allocation": a}
     for name in layouts:
         row[name] = {"kernel_TB/s": timed(name, out, False), "pattern_TB/s": timed(name, out, True)}
+        if os.environ.get("STRIPS_AB") and name not in ("420", "411", "114"):      # one and two strips' worth per wave on the same buffer (FFHIP_JPEG_STRIPS)
+            for sv in ("1", "2"):
+                capi.setenv("FFHIP_JPEG_STRIPS", sv)
+                row[name][f"strips{sv}"] = (timed(name, out, False), timed(name, out, True))
+            capi.setenv("FFHIP_JPEG_STRIPS", None)
     print(json.dumps(row), flush=True)

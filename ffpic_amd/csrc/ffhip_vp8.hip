@@ -99,6 +99,7 @@ __device__ __forceinline__ u32x4 pair_pick(u32x4 s0, u32x4 s1, unsigned long lon
  * broadcasts: even lane 2b computes luma block b from chunks 2b (its own) and 2b + 1 (its neighbour's); odd lane
  * 2j + 1 computes block 16 + j (U/V blocks 16-23, the Y2 block 24 on lane 17) from chunks 32 + 2j (its neighbour's
  * second load) and 32 + 2j + 1 (its own).  The results go back the same way (pair_pick). */
+template <bool PATTERN> /* PATTERN: the loads and the stores without the arithmetic (diagnostics, FFHIP_VP8_RESIDUAL_PATTERN=1: the kernel's access pattern as its ceiling) */
 __global__ __launch_bounds__(256) void k_vp8_residual(Vp8ResArgs a)
 {
     __shared__ __attribute__((aligned(16))) short y2in[8][16];
@@ -122,6 +123,13 @@ __global__ __launch_bounds__(256) void k_vp8_residual(Vp8ResArgs a)
     const u32x4 c1 = __builtin_nontemporal_load(src + t);
     u32x4 c2 = {0u, 0u, 0u, 0u};
     if (t < 18) c2 = __builtin_nontemporal_load(src + 32 + t);
+    if (PATTERN) { /* (info and quantiser words are loaded as ever: iw, ic, qpair feed the stored words so that nothing is dropped) */
+        u32x4 *dstp = (u32x4 *)(a.out + mb * 384);
+        const u32 k = iw ^ ic ^ qpair;
+        __builtin_nontemporal_store(c1 + k, dstp + t);
+        if (t < 16) __builtin_nontemporal_store(c2 + k, dstp + 32 + t);
+        return;
+    }
     /* block assembly inside the lane pair */
     const unsigned long long even_lanes = 0x5555555555555555ull;
     const u32x4 l0 = pair_pick<false>(c2, c1, even_lanes);  /* even: my first chunk; odd: my even neighbour's second load */
@@ -192,7 +200,8 @@ extern "C" int ffhip_vp8_residual_batch(long long n_mb, const int16_t *d_levels,
         return FFHIP_EINVAL;
     if (!ffhip_have_device()) return FFHIP_ENODEV;
     Vp8ResArgs a = {d_levels, d_mbinfo, d_quant, d_residual, n_mb};
-    hipLaunchKernelGGL(k_vp8_residual, dim3((unsigned)((n_mb + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a);
+    if (FFHIP_ENV("FFHIP_VP8_RESIDUAL_PATTERN")) hipLaunchKernelGGL(k_vp8_residual<true>, dim3((unsigned)((n_mb + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_vp8_residual<false>, dim3((unsigned)((n_mb + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a);
     FFHIP_CHECK(hipGetLastError(), FFHIP_EIO);
     return FFHIP_OK;
 }

@@ -65,6 +65,33 @@ def test_jpeg_strips_per_wave(nc, h, v, strips, switch):
     assert np.array_equal(gpu_recon(geom, n, cy, cu, cv, q), O.oracle_jpeg_recon(geom, cy, cu, cv, q, n_images=n)), (nc, h, v, strips, "adversarial")
 
 
+def test_vp8_residual_pattern_twin(switch):
+    """FFHIP_VP8_RESIDUAL_PATTERN=1 (bench.py's stage_kernels.vp8_residual_of_pattern): k_vp8_residual's loads and stores without the arithmetic -- it writes the residual
+    buffer (every macroblock's 768 bytes, nothing beyond) with meaningless words, and the next real call is exact again"""
+    L = capi.require_device()
+    n_mb = 999
+    lv, info = synth.vp8_macroblocks(n_mb, seed=4)
+    q = synth.vp8_quant()
+    from test_vp8_gpu import oracle_residual
+    exp = oracle_residual(lv, info, q)
+    dl, di = ops.DeviceBuffer(np.ascontiguousarray(lv)), ops.DeviceBuffer(np.ascontiguousarray(info))
+    dq = ops.DeviceBuffer(np.ascontiguousarray(q.astype(np.uint16)))
+    out = ops.DeviceBuffer(nbytes=n_mb * 768 + 256)
+    capi.check(L.ffhip_memset(out.ptr, 0xA5, n_mb * 768 + 256, None))
+    switch(FFHIP_VP8_RESIDUAL_PATTERN=1)
+    capi.check(L.ffhip_vp8_residual_batch(n_mb, dl.ptr, di.ptr, dq.ptr, out.ptr, None))
+    capi.check(L.ffhip_stream_sync(None))
+    raw = out.to_host((n_mb * 768 + 256,), np.uint8)
+    assert (raw[n_mb * 768:] == 0xA5).all()
+    assert (raw[:n_mb * 768].view(np.uint32) != 0xA5A5A5A5).mean() > 0.99
+    switch(FFHIP_VP8_RESIDUAL_PATTERN="")
+    os.environ.pop("FFHIP_VP8_RESIDUAL_PATTERN", None)
+    capi.reload_env()
+    capi.check(L.ffhip_vp8_residual_batch(n_mb, dl.ptr, di.ptr, dq.ptr, out.ptr, None))
+    capi.check(L.ffhip_stream_sync(None))
+    assert np.array_equal(out.to_host((n_mb, 384), np.int16), exp.reshape(n_mb, 384))
+
+
 def test_color8_scalar_form(switch):
     """FFHIP_COLOR8_SCALAR=1: the one-pixel-per-lane form of the 8-bit planar converter instead of the packed one -- all 65 536 chroma pairs"""
     rng = np.random.default_rng(3)
